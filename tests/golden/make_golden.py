@@ -1,0 +1,218 @@
+"""Generate the committed golden fixtures by running the REFERENCE's own code.
+
+Run in the build container only (needs /root/reference):
+    python tests/golden/make_golden.py
+Writes tests/golden/*.npz.  Inputs and weights are regenerated from
+oracle/filler.py (counter hash) by name, so only outputs / digests are stored.
+
+What is reference-authored arithmetic and what is not:
+  * G1 blocks, G2 decoder, G4 loss            -> reference classes, directly.
+  * G3 whole net, G5 train steps, G6 predict  -> reference FootprintNetwork /
+    LossManager / Adam, but the ENCODER inside is oracle/standin_resnet.py
+    (torchvision is absent) => encoder part "parity unpinned" by the reference.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+from oracle import filler, ref_import, restatement as R  # noqa: E402
+from tests.golden.digest import digest, GOLDEN_DIR, fill, fill_value      # noqa: E402
+
+
+def fill_module(mod, tag):
+    """Deterministic weights for a reference sub-module (keys = its own state_dict names)."""
+    sd = mod.state_dict()
+    mod.load_state_dict({k: fill_value(tag, k, tuple(v.shape), v.dtype == torch.int64) for k, v in sd.items()})
+
+
+def g1_blocks(net):
+    out = {}
+    torch.manual_seed(0)
+    # ConvBlock 16->8 @ 6x10
+    m = net.ConvBlock(in_ch=16, out_ch=8, use_elu=True, use_bn=False)
+    fill_module(m, "g1.convblock")
+    x = fill("g1.convblock.x", (2, 16, 6, 10)).requires_grad_(True)
+    y = m(x)
+    g = fill("g1.convblock.g", tuple(y.shape))
+    (y * g).sum().backward()
+    out.update({"convblock.y": y, "convblock.dx": x.grad,
+                "convblock.dw1": m.conv1.weight.grad, "convblock.db1": m.conv1.bias.grad,
+                "convblock.dw2": m.conv2.weight.grad, "convblock.db2": m.conv2.bias.grad})
+    # ConvUpsampleAndConcatBlock 16->8, x @4x6, skip @8x12
+    m = net.ConvUpsampleAndConcatBlock(in_ch=16, out_ch=8, use_elu=True, use_bn=False)
+    fill_module(m, "g1.upcat")
+    x = fill("g1.upcat.x", (2, 16, 4, 6)).requires_grad_(True)
+    s = fill("g1.upcat.skip", (2, 8, 8, 12)).requires_grad_(True)
+    y = m(x, s)
+    g = fill("g1.upcat.g", tuple(y.shape))
+    (y * g).sum().backward()
+    out.update({"upcat.y": y, "upcat.dx": x.grad, "upcat.dskip": s.grad,
+                "upcat.pre.dw1": m.pre_concat_conv.conv1.weight.grad,
+                "upcat.pre.dw2": m.pre_concat_conv.conv2.weight.grad,
+                "upcat.post.dw1": m.post_concat_conv.conv1.weight.grad,
+                "upcat.post.db1": m.post_concat_conv.conv1.bias.grad,
+                "upcat.post.dw2": m.post_concat_conv.conv2.weight.grad})
+    # OutConvBlock 16->2, scales 1/2/4/8, sigmoid on/off
+    for scale in (1, 2, 4, 8):
+        for sig in (False, True):
+            m = net.OutConvBlock(in_ch=16, out_ch=2, scale=scale, apply_sigmoid=sig)
+            fill_module(m, "g1.outconv")
+            x = fill("g1.outconv.x", (2, 16, 6, 10)).requires_grad_(True)
+            y = m(x)
+            g = fill("g1.outconv.g%d" % scale, tuple(y.shape))
+            (y * g).sum().backward()
+            tag = "outconv.s%d.%s" % (scale, "sig" if sig else "lin")
+            out.update({tag + ".y": y, tag + ".dx": x.grad,
+                        tag + ".dw": m.conv1.weight.grad, tag + ".db": m.conv1.bias.grad})
+    return {k: v.detach().numpy() for k, v in out.items()}
+
+
+def g2_decoder(net):
+    out = {}
+    shapes = [(2, 64, 32, 48), (2, 64, 16, 24), (2, 128, 8, 12), (2, 256, 4, 6), (2, 512, 2, 3)]
+    for sig in (False, True):
+        tag = "dec.%s" % ("sig" if sig else "lin")
+        m = net.SkipDecoder(apply_sigmoid=sig)
+        fill_module(m, "g2.decoder")
+        feats = [fill("g2.feat%d" % i, s).requires_grad_(True) for i, s in enumerate(shapes)]
+        o = m(feats)
+        loss = 0
+        for k in o:
+            loss = loss + (o[k] * fill("g2.g" + k, tuple(o[k].shape))).sum()
+        loss.backward()
+        for k in o:
+            out.update(digest(tag + ".out" + k, o[k]))
+        for i, f in enumerate(feats):
+            out.update(digest(tag + ".dfeat%d" % i, f.grad))
+        for name in ("block1.pre_concat_conv.conv1.weight", "block4.post_concat_conv.conv2.weight",
+                     "outconv1.conv1.weight", "outconv4.0.conv1.weight", "outconv4.1.conv1.bias",
+                     "block2.post_concat_conv.conv1.bias"):
+            p = dict(m.named_parameters())[name]
+            out.update(digest(tag + ".d." + name, p.grad))
+    return out
+
+
+def g3_network(net):
+    out = {}
+    P, B = R.make_state()
+    batch = R.make_batch(2, 64, 96)
+    for mode in ("train", "eval"):
+        m = net.FootprintNetwork(pretrained=False)
+        m.load_state_dict({**P, **B})
+        m.train(mode == "train")
+        with torch.no_grad():
+            o = m(batch["image"])
+        for k in o:
+            out.update(digest("net.%s.out%s" % (mode, k), o[k], full_limit=1 << 17))
+        if mode == "train":
+            sd = m.state_dict()
+            rm = torch.cat([sd[k].flatten() for k in sd if k.endswith("running_mean") and "encoder" in k])
+            rv = torch.cat([sd[k].flatten() for k in sd if k.endswith("running_var") and "encoder" in k])
+            out["net.train.running_mean"] = rm.numpy()
+            out["net.train.running_var"] = rv.numpy()
+    return out
+
+
+def g4_loss(loss_mod):
+    out = {}
+    B, H, W = 2, 8, 16
+    batch = R.make_batch(B, H, W, tag="g4")
+    preds = {}
+    for k in R.SCALES:
+        p = fill("g4.pred" + k, (B, 4, H, W), -3.0, 3.0)
+        p[:, 2:] = torch.sigmoid(p[:, 2:])            # depth channels are sigmoid outputs
+        preds[k] = p.requires_grad_(True)
+    lm = loss_mod.LossManager((0.1, 100), 0.25)
+    d = dict(preds)
+    losses = lm(d, batch)
+    losses["loss"].backward()
+    out["loss.values"] = np.array([float(losses[k]) for k in R.LOSS_KEYS], dtype=np.float64)
+    for k in R.SCALES:
+        out["loss.dpred" + k] = preds[k].grad.numpy()
+        out["loss.viz.ground_depth_masked" + k] = d[("ground_depth_masked", k)].detach().numpy()
+    return out
+
+
+def g5_train(net, loss_mod):
+    """Two optimiser steps exactly as training/train.py:150-156 + model_manager.py:27."""
+    out = {}
+    P, B = R.make_state()
+    m = net.FootprintNetwork(pretrained=False)
+    m.load_state_dict({**P, **B})
+    m.train()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+    lm = loss_mod.LossManager((0.1, 100), 0.25)
+    names = [k for k, _ in m.named_parameters()]
+    for step in range(2):
+        batch = R.make_batch(2, 64, 96, tag="g5.step%d" % step)
+        outputs = m(batch["image"])
+        losses = lm(outputs, batch)
+        m.zero_grad()
+        losses["loss"].backward()
+        if step == 0:
+            dead = [k for k, p in m.named_parameters() if p.grad is None]
+            out["train.dead_params"] = np.array(dead)
+            g = dict(m.named_parameters())
+            out["train.grad_sums"] = np.array([float(g[k].grad.double().sum()) if g[k].grad is not None else 0.0 for k in names])
+            out["train.grad_abs"] = np.array([float(g[k].grad.double().abs().sum()) if g[k].grad is not None else 0.0 for k in names])
+            for k in ("encoder.layer0.0.weight", "encoder.layer4.2.conv2.weight", "encoder.layer2.0.downsample.0.weight",
+                      "encoder.layer1.1.0.bn1.weight", "encoder.layer3.5.bn2.bias",
+                      "mask_decoder.block1.pre_concat_conv.conv1.weight", "depth_decoder.outconv4.1.conv1.weight",
+                      "depth_decoder.block4.post_concat_conv.conv1.weight"):
+                out.update(digest("train.grad." + k, g[k].grad))
+        opt.step()
+        out["train.losses%d" % step] = np.array([float(losses[k]) for k in R.LOSS_KEYS], dtype=np.float64)
+        sd = m.state_dict()
+        out["train.param_sums%d" % step] = np.array([float(sd[k].double().sum()) for k in names])
+        out["train.param_abs%d" % step] = np.array([float(sd[k].double().abs().sum()) for k in names])
+    out["train.param_names"] = np.array(names)
+    st = opt.state_dict()["state"]
+    out["train.adam_steps"] = np.array([float(st[i]["step"]) if i in st else -1.0 for i in range(len(names))])
+    out["train.exp_avg_abs"] = np.array([float(st[i]["exp_avg"].double().abs().sum()) if i in st else 0.0 for i in range(len(names))])
+    out["train.exp_avg_sq_sum"] = np.array([float(st[i]["exp_avg_sq"].double().sum()) if i in st else 0.0 for i in range(len(names))])
+    sd = m.state_dict()
+    out["train.nbt"] = np.array([int(sd[k]) for k in sd if k.endswith("num_batches_tracked")])
+    return out
+
+
+def g6_predict(net):
+    """predict_simple.py:51-68 plumbing: LANCZOS resize -> ToTensor -> eval forward -> [4,H,W] npy."""
+    from PIL import Image
+    out = {}
+    img = (filler.uniform("g6.image", (269, 477, 3)) * 255).astype(np.uint8)   # same size as test_data/cyclist.jpg
+    pil = Image.fromarray(img, "RGB")
+    pil = pil.resize((640, 192), Image.LANCZOS)     # transforms.Resize((192,640), ANTIALIAS) predict_simple.py:41-42
+    x = torch.from_numpy(np.asarray(pil).astype(np.float32) / 255.0).permute(2, 0, 1)[None].contiguous()  # ToTensor
+    out.update(digest("predict.input", x))
+    P, B = R.make_state()
+    m = net.FootprintNetwork(pretrained=False)
+    m.load_state_dict({**P, **B})
+    m.eval()
+    pred = m(x)["1/1"].data.cpu().numpy().squeeze(0)          # predict_simple.py:67-68 (no no_grad: quirk)
+    out.update(digest("predict.npy", torch.from_numpy(pred), full_limit=0))
+    out["predict.mask_logit_gt_half"] = np.packbits(pred[1] > 0.5)   # predict_simple.py:77 threshold on the LOGIT
+    return out
+
+
+def main():
+    mods = ref_import.load_reference()
+    assert mods is not None, "needs /root/reference"
+    net, loss_mod = mods
+    torch.set_num_threads(8)
+    os.makedirs(GOLDEN_DIR, exist_ok=True)
+    for name, fn in (("g1_blocks", lambda: g1_blocks(net)), ("g2_decoder", lambda: g2_decoder(net)),
+                     ("g3_network", lambda: g3_network(net)), ("g4_loss", lambda: g4_loss(loss_mod)),
+                     ("g5_train", lambda: g5_train(net, loss_mod)), ("g6_predict", lambda: g6_predict(net))):
+        d = fn()
+        path = os.path.join(GOLDEN_DIR, name + ".npz")
+        np.savez_compressed(path, **d)
+        print("%-12s %4d arrays %8.1f KB" % (name, len(d), os.path.getsize(path) / 1024))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,181 @@
+"""CPU: the oracle restatement against the committed golden fixtures (reference outputs).
+
+Runs without /root/reference (the fixtures were generated from it by
+tests/golden/make_golden.py).  Tolerances: 1e-4 relative to the tensor's max
+(north_star: "within 1e-4 rel fp32"); in practice the restatement is bit-exact.
+"""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from oracle import restatement as R
+from tests.golden.digest import compare, fill, fill_value, load
+
+
+def _convblock_state(tag, prefix, cin, cout):
+    P = {}
+    for key, shape in ((".conv1.weight", (cout, cin, 3, 3)), (".conv1.bias", (cout,)),
+                       (".conv2.weight", (cout, cout, 3, 3)), (".conv2.bias", (cout,))):
+        P[prefix + key] = fill_value(tag, (prefix + key).lstrip("."), shape).requires_grad_(True)
+    return P
+
+
+def test_g1_convblock():
+    gold = load("g1_blocks")
+    P = _convblock_state("g1.convblock", "", 16, 8)
+    x = fill("g1.convblock.x", (2, 16, 6, 10)).requires_grad_(True)
+    y = R.conv_block(x, P, "")
+    (y * fill("g1.convblock.g", tuple(y.shape))).sum().backward()
+    compare(gold, "convblock.y", y)
+    compare(gold, "convblock.dx", x.grad)
+    compare(gold, "convblock.dw1", P[".conv1.weight"].grad)
+    compare(gold, "convblock.db2", P[".conv2.bias"].grad)
+
+
+def test_g1_upcat():
+    gold = load("g1_blocks")
+    P = {}
+    P.update(_convblock_state("g1.upcat", ".pre_concat_conv", 16, 8))
+    P.update(_convblock_state("g1.upcat", ".post_concat_conv", 16, 8))
+    x = fill("g1.upcat.x", (2, 16, 4, 6)).requires_grad_(True)
+    s = fill("g1.upcat.skip", (2, 8, 8, 12)).requires_grad_(True)
+    y = R.up_concat_block(x, s, P, "")
+    (y * fill("g1.upcat.g", tuple(y.shape))).sum().backward()
+    compare(gold, "upcat.y", y)
+    compare(gold, "upcat.dx", x.grad)
+    compare(gold, "upcat.dskip", s.grad)
+    compare(gold, "upcat.post.dw1", P[".post_concat_conv.conv1.weight"].grad)
+    compare(gold, "upcat.pre.dw2", P[".pre_concat_conv.conv2.weight"].grad)
+
+
+def test_g1_outconv_all_scales():
+    gold = load("g1_blocks")
+    for scale in (1, 2, 4, 8):
+        for sig in (False, True):
+            P = {".conv1.weight": fill_value("g1.outconv", "conv1.weight", (2, 16, 3, 3)).requires_grad_(True),
+                 ".conv1.bias": fill_value("g1.outconv", "conv1.bias", (2,)).requires_grad_(True)}
+            x = fill("g1.outconv.x", (2, 16, 6, 10)).requires_grad_(True)
+            y = R.out_conv_block(x, P, "", scale, sig)
+            (y * fill("g1.outconv.g%d" % scale, tuple(y.shape))).sum().backward()
+            tag = "outconv.s%d.%s" % (scale, "sig" if sig else "lin")
+            compare(gold, tag + ".y", y)
+            compare(gold, tag + ".dx", x.grad)
+            compare(gold, tag + ".dw", P[".conv1.weight"].grad)
+            compare(gold, tag + ".db", P[".conv1.bias"].grad)
+
+
+def decoder_state(tag="g2.decoder", prefix="dec"):
+    """SkipDecoder weights as make_golden.fill_module produced them (module-local key names)."""
+    P = OrderedDict()
+    for key, shape, kind in R.state_spec():
+        if key.startswith("mask_decoder.") and kind in ("conv_w", "conv_b"):
+            local = key[len("mask_decoder."):]
+            P[prefix + "." + local] = fill_value(tag, local, shape).requires_grad_(True)
+    return P
+
+
+G2_SHAPES = [(2, 64, 32, 48), (2, 64, 16, 24), (2, 128, 8, 12), (2, 256, 4, 6), (2, 512, 2, 3)]
+
+
+def test_g2_decoder():
+    gold = load("g2_decoder")
+    for sig in (False, True):
+        tag = "dec.%s" % ("sig" if sig else "lin")
+        P = decoder_state()
+        feats = [fill("g2.feat%d" % i, s).requires_grad_(True) for i, s in enumerate(G2_SHAPES)]
+        o = R.skip_decoder(feats, P, "dec", sig)
+        loss = 0
+        for k in o:
+            loss = loss + (o[k] * fill("g2.g" + k, tuple(o[k].shape))).sum()
+        loss.backward()
+        for k in o:
+            compare(gold, tag + ".out" + k, o[k])
+        for i, f in enumerate(feats):
+            compare(gold, tag + ".dfeat%d" % i, f.grad)
+        for name in ("block1.pre_concat_conv.conv1.weight", "block4.post_concat_conv.conv2.weight",
+                     "outconv1.conv1.weight", "outconv4.0.conv1.weight", "outconv4.1.conv1.bias",
+                     "block2.post_concat_conv.conv1.bias"):
+            compare(gold, tag + ".d." + name, P["dec." + name].grad)
+
+
+def test_g3_network_train_eval():
+    gold = load("g3_network")
+    P, B = R.make_state()
+    batch = R.make_batch(2, 64, 96)
+    for mode in ("train", "eval"):
+        B2 = OrderedDict((k, v.clone()) for k, v in B.items())
+        with torch.no_grad():
+            o = R.footprint_network(batch["image"], P, B2, mode == "train")
+        assert list(o.keys()) == ["1/8", "1/4", "1/2", "1/1"]          # network.py:26-30 insertion order
+        for k in o:
+            assert tuple(o[k].shape) == (2, 4, 64, 96)
+            compare(gold, "net.%s.out%s" % (mode, k), o[k])
+        if mode == "train":
+            rm = torch.cat([B2[k].flatten() for k in B2 if k.endswith("running_mean") and "encoder" in k])
+            rv = torch.cat([B2[k].flatten() for k in B2 if k.endswith("running_var") and "encoder" in k])
+            compare(gold, "net.train.running_mean", rm)
+            compare(gold, "net.train.running_var", rv)
+
+
+def g4_inputs():
+    B, H, W = 2, 8, 16
+    batch = R.make_batch(B, H, W, tag="g4")
+    preds = OrderedDict()
+    for k in R.SCALES:
+        p = fill("g4.pred" + k, (B, 4, H, W), -3.0, 3.0)
+        p[:, 2:] = torch.sigmoid(p[:, 2:])
+        preds[k] = p.requires_grad_(True)
+    return preds, batch
+
+
+def test_g4_loss():
+    gold = load("g4_loss")
+    preds, batch = g4_inputs()
+    losses, viz = R.loss_manager(preds, batch)
+    assert list(losses.keys()) == R.LOSS_KEYS and len(losses) == 21 and len(viz) == 20
+    losses["loss"].backward()
+    vals = np.array([float(losses[k]) for k in R.LOSS_KEYS])
+    np.testing.assert_allclose(vals, gold["loss.values"], rtol=2e-6)
+    for k in R.SCALES:
+        compare(gold, "loss.dpred" + k, preds[k].grad, rtol=1e-5)
+        compare(gold, "loss.viz.ground_depth_masked" + k, viz[("ground_depth_masked", k)], rtol=1e-6)
+
+
+def test_g5_two_train_steps():
+    gold = load("g5_train")
+    P, B = R.make_state()
+    tr = R.OracleTrainer(P, B, lr=1e-4)
+    names = [k for k in tr.P]
+    assert names == list(gold["train.param_names"])
+    for step in range(2):
+        batch = R.make_batch(2, 64, 96, tag="g5.step%d" % step)
+        if step == 0:
+            _, losses = tr.forward_backward(batch)
+            dead = [k for k in names if tr.P[k].grad is None]
+            assert dead == list(gold["train.dead_params"]) and len(dead) == 72
+            assert all(R.is_dead_param(k) for k in dead)
+            gs = np.array([float(tr.P[k].grad.double().sum()) if tr.P[k].grad is not None else 0.0 for k in names])
+            ga = gold["train.grad_abs"]
+            assert np.all(np.abs(gs - gold["train.grad_sums"]) <= 1e-4 * np.maximum(ga, 1e-12))
+            tr.opt.step()
+        else:
+            _, losses = tr.step(batch)
+        vals = np.array([float(losses[k]) for k in R.LOSS_KEYS])
+        np.testing.assert_allclose(vals, gold["train.losses%d" % step], rtol=1e-5)
+        ps = np.array([float(tr.P[k].detach().double().sum()) for k in names])
+        pa = gold["train.param_abs%d" % step]
+        assert np.all(np.abs(ps - gold["train.param_sums%d" % step]) <= 1e-5 * np.maximum(pa, 1e-12))
+    nbt = np.array([int(tr.B[k]) for k in tr.B if k.endswith("num_batches_tracked")])
+    assert np.array_equal(nbt, gold["train.nbt"])
+
+
+def test_state_spec_counts():
+    spec = R.state_spec()
+    assert len(spec) == 484
+    params = [s for s in spec if s[2] in ("conv_w", "conv_b", "bn_w", "bn_b")]
+    assert len(params) == 268
+    n_all = sum(int(np.prod(s[1])) for s in params)
+    n_live = sum(int(np.prod(s[1])) for s in params if not R.is_dead_param(s[0]))
+    assert n_all == 31021392 and n_live == 31012944
+    assert sum(1 for s in params if not R.is_dead_param(s[0])) == 196
