@@ -1,0 +1,178 @@
+"""bench.py -- headline benchmark of BASELINE.json: training images/sec at 192x640 bs=12 on 1..8 MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W                                   (N > 1, one rank per GPU, RCCL)
+
+A "step" = one full training step of the hot path on one per-GPU batch of 12 synthetic 192x640 images:
+forward + fused loss + backward + (bucketed gradient all-reduce when N > 1) + fused Adam, all inputs resident
+in HBM before the timed region (configs[2] of BASELINE.json; configs[1], the inference-only forward, is reported
+beside it as fwd_ms_per_img).  Weak scaling: every rank keeps batch 12.  Rank 0 prints ONE JSON line.
+
+Extra objects in the line:
+  roofline      dominant kernel = the fp32-MFMA implicit-GEMM conv (forward + data-gradient launches).
+                achieved = sum of algorithmic FLOPs of its launches / sum of their durations, measured with HIP
+                events recorded around every launch on the launch stream during the timed steps.
+  cpu_baseline  the CPU oracle (a restatement of the reference's PyTorch CPU path, kind "port") timed on this
+                box's host cores on a bounded sample of the same workload (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_F32_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix peak
+B, H, W = 12, 192, 640
+
+
+class KernelTimer:
+    """HIP-event bracket around every launch of one kernel family (events go on torch's current stream, which
+    is the stream the C ABI launches on)."""
+
+    def __init__(self):
+        self.records = []
+
+    def wrap(self, fn, flops_of):
+        def wrapped(desc, *a, **k):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = fn(desc, *a, **k)
+            e.record()
+            self.records.append((s, e, flops_of(desc)))
+            return r
+        return wrapped
+
+    def summary(self):
+        ms = sum(s.elapsed_time(e) for s, e, _ in self.records)
+        fl = sum(f for _, _, f in self.records)
+        return len(self.records), ms, fl
+
+
+def conv_flops(d):
+    taps = 1 if d.gather == 5 else d.KH * d.KW
+    k = 147 if d.gather == 5 else d.C0 + d.C1
+    return 2.0 * d.N * d.OH * d.OW * d.Nout * taps * k
+
+
+def cpu_baseline(sample_b=4, steps=2):
+    from oracle import restatement as R
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    P, Bf = R.make_state(tag="bench")
+    tr = R.OracleTrainer(P, Bf)
+    tr.step(R.make_batch(1, H, W, tag="bench.warm"))
+    batch = R.make_batch(sample_b, H, W, tag="bench.cpu")
+    t0 = time.time()
+    for _ in range(steps):
+        tr.step(batch)
+    dt = (time.time() - t0) / steps
+    return {"value": round(sample_b / dt, 4), "unit": "img/s", "cores": cores, "kind": "port",
+            "sample": "%d timed full train steps (fwd+loss+bwd+Adam) of the CPU oracle at %dx%d, batch %d of the 12-image "
+                      "workload, torch.set_num_threads(%d), after 1 warm-up step" % (steps, H, W, sample_b, cores),
+            "s_per_step": round(dt, 3)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from footprints_amd import ops
+    from footprints_amd.model_manager import ModelManager
+    from footprints_amd.parallel import broadcast_state
+    from footprints_amd.training.train import SEED, TrainStep, synthetic_batch
+
+    torch.manual_seed(SEED)
+    mm = ModelManager(use_cuda=True, learning_rate=1e-4)          # random-init weights (no checkpoints offline)
+    if distributed:
+        broadcast_state(mm.model)
+    step = TrainStep(mm.model, mm.optimiser, distributed=distributed)
+    batch = synthetic_batch(B, H, W, "cuda", seed=SEED + rank)     # per-rank shard, resident in HBM
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(batch)
+    timer = None
+    orig = ops.conv_igemm
+    if rank == 0 and not args.no_kernel_events:
+        timer = KernelTimer()
+        import footprints_amd.engine as engine_mod
+        engine_mod.ops.conv_igemm = timer.wrap(orig, conv_flops)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(batch)
+    barrier()
+    dt = time.perf_counter() - t0
+    ops.conv_igemm = orig
+    t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+    if distributed:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    final_loss = float(step.losses[20])
+
+    # forward-only latency (configs[1]): eval-mode, no_grad, batch 12
+    mm.model.eval()
+    with torch.no_grad():
+        for _ in range(2):
+            mm.model(batch["image"])
+        torch.cuda.synchronize()
+        f0 = time.perf_counter()
+        for _ in range(5):
+            mm.model(batch["image"])
+        torch.cuda.synchronize()
+        fwd_ms_img = (time.perf_counter() - f0) / 5 / B * 1e3
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        out = {"metric": "training images/sec at 192x640 bs=12", "value": round(world * B * args.steps / dt, 2), "unit": "img/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "KITTI 192x640 bs=12 full train step (fwd+loss+bwd+Adam), random-init weights, synthetic RGB + masks",
+                          "per_gpu_batch": B, "global_batch": B * world, "height": H, "width": W,
+                          "parallelism": "dp%d" % world if world > 1 else "single"},
+               "fwd_ms_per_img": round(fwd_ms_img, 4), "final_loss": round(final_loss, 5)}
+        if timer is not None:
+            n, ms, fl = timer.summary()
+            ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                               "kernel": "igemm_kernel (implicit-GEMM conv fwd + dgrad, v_mfma_f32_32x32x2_f32)",
+                               "launches_per_step": n // max(args.steps, 1), "avg_launch_us": round(ms / max(n, 1) * 1e3, 2),
+                               "algorithmic_gflop_per_launch": round(fl / max(n, 1) / 1e9, 3),
+                               "kernel_ms_per_step": round(ms / max(args.steps, 1), 3)}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,86 @@
+"""ctypes binding of libfootprints_hip.so (the C ABI declared in include/footprints_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a kernel
+reports an error, a RuntimeError is raised -- nothing silently routes to PyTorch
+ops or to the CPU oracle.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfootprints_hip.so")
+
+# enum fp_gather
+GATHER_FWD_ZERO, GATHER_FWD_REFLECT, GATHER_FWD_REFLECT_UP2, GATHER_DGRAD_ZERO, GATHER_DGRAD_REFLECT, GATHER_STEM = range(6)
+ACT_NONE, ACT_ELU, ACT_RELU = range(3)
+EPI_BIAS, EPI_ADDEND, EPI_ADDEND_MASK, EPI_ACTGRAD_ELU, EPI_ACTGRAD_RELU, EPI_ACCUM = 1, 2, 4, 8, 16, 32
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("N", "OH", "OW", "IH", "IW", "C0", "C1", "Nout", "KH", "KW", "stride", "pad",
+                                         "gather", "act")] + [("epi", C.c_uint32)]
+
+
+_P, _I32, _I64, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+_DESC = C.POINTER(ConvDesc)
+
+# name -> (restype, argtypes); mirrors include/footprints_hip.h one to one
+SIGNATURES = {
+    "fp_conv_igemm": (C.c_int, [_DESC, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "fp_conv_wgrad_workspace": (_I64, [_DESC]),
+    "fp_conv_wgrad": (C.c_int, [_DESC, _P, _P, _P, _P, C.c_int, _P, _I64, _P]),
+    "fp_packed_weight_elems": (_I64, [_I32, _I32, _I32, _I32, _I32, _I32]),
+    "fp_pack_conv_weight": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _P]),
+    "fp_pack_conv_weight_dgrad": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P]),
+    "fp_colsum_workspace": (_I64, [_I64, _I32]),
+    "fp_colsum": (C.c_int, [_P, _I64, _I32, _P, C.c_int, _P, _I64, _P]),
+    "fp_up2cat_bwd": (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, C.c_int, _P]),
+    "fp_head_fwd": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P]),
+    "fp_head_upsample": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
+    "fp_head_upsample_bwd": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
+    "fp_head_dgrad": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
+    "fp_head_wgrad_workspace": (_I64, [_I32, _I32, _I32, _I32]),
+    "fp_head_wgrad": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, C.c_int, _P, _I64, _P]),
+    "fp_bn_workspace": (_I64, [_I64, _I32]),
+    "fp_bn_train_stats": (C.c_int, [_P, _I64, _I32, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
+    "fp_bn_eval_coeffs": (C.c_int, [_P, _P, _P, _P, _F, _I32, _P, _P, _P]),
+    "fp_bn_apply": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _I32, _P]),
+    "fp_bn_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, _I64, _I32, _P, _I64, _P]),
+    "fp_maxpool_fwd": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _P]),
+    "fp_maxpool_bwd": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, C.c_int, _P]),
+    "fp_loss_workspace": (_I64, [_I32, _I32, _I32]),
+    "fp_loss_fwd_bwd": (C.c_int, [C.POINTER(_P), _P, _P, _P, _P, _P, _P, _F, _F, _F, C.POINTER(_P), _P, _I32, _I32, _I32,
+                                  _P, _I64, _P]),
+    "fp_adam_step": (C.c_int, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _I32, _F, _P]),
+    "fp_nchw_to_nhwc": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P]),
+    "fp_nhwc_to_nchw": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P]),
+    "fp_fill": (C.c_int, [_P, _I64, _F, _P]),
+    "fp_version": (C.c_int, []),
+    "fp_last_error_string": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+def load():
+    """Load the HIP library (once).  Raises RuntimeError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "footprints_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C footprints_amd/csrc`). There is no CPU / PyTorch fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().fp_last_error_string()
+        raise RuntimeError("footprints_hip %s failed (code %d): %s" % (what, rc, msg.decode() if msg else "?"))

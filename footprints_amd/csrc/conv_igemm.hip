@@ -1,0 +1,257 @@
+// Implicit-GEMM convolution (forward and data-gradient) on fp32 MFMA, NHWC, gfx950.
+//
+//   Y[m][n] = epilogue( sum_{tap} sum_{k<C0+C1} A[m][tap,k] * Wp[tap][k][n] )
+//
+// m = flattened output pixel (n, oy, ox); A is never materialised: each K-step (one tap x 16 channels) is
+// gathered straight from the NHWC source(s) -- zero / reflection padding, the nearest-x2 upsample, the skip
+// concat and (for dgrad) the fold-back of the reflection halo are all index arithmetic in the tile loader
+// (fp_gather_tap).  Replaces aten::convolution + reflection_pad2d + upsample_nearest2d + cat + elu_ and the
+// dgrad half of convolution_backward (reference: footprints/network.py:109-136,151-158,167-170 and the
+// torchvision BasicBlock convs behind network.py:38-44).
+//
+// Tiling: workgroup = 4 waves (256 threads), tile BM pixels x BN channels, K-step 16.  Both operands are staged
+// in LDS as [row][16 k + 4 pad] (LD = 20 floats): a lane's MFMA operand is "row idx = lane&31, k-slot = lane>>5",
+// and one ds_read_b128 at [row][4*(lane>>5) (+8)] feeds four v_mfma_f32_32x32x2_f32 (k = j for the low half-wave,
+// 4 + j for the high one; A and B use the same k permutation so the dot product is unchanged).  LD = 20 makes
+// that b128 read conflict-free (5*idx mod 16 is a bijection over each 16-lane service group).
+// v_mfma_f32_32x32x2_f32 is an exact k-ordered fmaf chain (64 cycles/SIMD, 157 TF peak), so the kernel is
+// MFMA-issue bound by design; global->LDS staging is software-pipelined through registers with two LDS
+// buffers and a single barrier per K-step.
+#include "fp_common.h"
+
+namespace {
+
+struct IgemmArgs {
+  const float* src0;
+  const float* src1;
+  const float* w;
+  const float* bias;
+  const float* addend;
+  const float* addend_mask;
+  const float* actsrc;
+  float* y;
+  FpGeom g;
+  int Nout, act;
+  unsigned epi;
+  int M, KC16, T, tilesN, nwg;
+};
+
+constexpr int LD = 20;
+
+template <int BM, int BN, int WM, int WN, bool STEM>
+__global__ void __launch_bounds__(256) igemm_kernel(const IgemmArgs a) {
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int AV = BM / 64;         // float4 A slots per thread per K-step
+  constexpr int BV = (BN + 63) / 64;  // float4 B slots per thread per K-step
+  static_assert(WM * WN == 4, "4 waves");
+  __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * LD];
+  float* const As = lds;                // [2][BM*LD]
+  float* const Bs = lds + 2 * BM * LD;  // [2][BN*LD]
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int idx = lane & 31, h = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+  const int tile = fp_xcd_remap(blockIdx.x, a.nwg);
+  const int tile_n = tile % a.tilesN, tile_m = tile / a.tilesN;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const FpGeom& g = a.g;
+
+  // ---- per-thread staging coordinates -----------------------------------------------------------------
+  const int q = t & 3;  // which float4 of the 16-channel K-step
+  int pn[AV], py[AV], px[AV];
+  bool pvalid[AV];
+#pragma unroll
+  for (int i = 0; i < AV; ++i) {
+    const int m = m0 + (t >> 2) + 64 * i;
+    pvalid[i] = m < a.M;
+    const int mm = pvalid[i] ? m : 0;
+    const int ox = mm % g.OW, r = mm / g.OW;
+    px[i] = ox;
+    py[i] = r % g.OH;
+    pn[i] = r / g.OH;
+  }
+  int pix[AV][4], pix1[AV];
+  float4 areg[AV], breg[BV];
+
+  auto set_tap = [&](int tap) {
+    if (STEM) return;
+    const int ky = tap / g.KW, kx = tap - ky * g.KW;
+#pragma unroll
+    for (int i = 0; i < AV; ++i) {
+      fp_gather_tap(g, pn[i], py[i], px[i], ky, kx, pix[i], pix1[i]);
+      if (!pvalid[i]) { pix[i][0] = pix[i][1] = pix[i][2] = pix[i][3] = -1; pix1[i] = -1; }
+    }
+  };
+  auto load_step = [&](int tap, int cc) {
+#pragma unroll
+    for (int i = 0; i < AV; ++i) {
+      if (STEM) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (pvalid[i]) {
+          const int kk = cc * 16 + q * 4;
+          v.x = fp_stem_load(g, a.src0, pn[i], py[i], px[i], kk + 0);
+          v.y = fp_stem_load(g, a.src0, pn[i], py[i], px[i], kk + 1);
+          v.z = fp_stem_load(g, a.src0, pn[i], py[i], px[i], kk + 2);
+          v.w = fp_stem_load(g, a.src0, pn[i], py[i], px[i], kk + 3);
+        }
+        areg[i] = v;
+      } else {
+        areg[i] = fp_gather_load4(g, a.src0, a.src1, pix[i], pix1[i], cc * 16 + q * 4);
+      }
+    }
+    const float* wstep = a.w + (size_t)(tap * a.KC16 + cc) * a.Nout * 16;
+#pragma unroll
+    for (int j = 0; j < BV; ++j) {
+      const int nb = (t >> 2) + 64 * j;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (nb < BN && n0 + nb < a.Nout) v = *reinterpret_cast<const float4*>(wstep + (size_t)(n0 + nb) * 16 + q * 4);
+      breg[j] = v;
+    }
+  };
+  auto store_step = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < AV; ++i)
+      *reinterpret_cast<float4*>(As + buf * BM * LD + ((t >> 2) + 64 * i) * LD + q * 4) = areg[i];
+#pragma unroll
+    for (int j = 0; j < BV; ++j) {
+      const int nb = (t >> 2) + 64 * j;
+      if (nb < BN) *reinterpret_cast<float4*>(Bs + buf * BN * LD + nb * LD + q * 4) = breg[j];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int steps = a.T * a.KC16;
+  int ltap = 0, lcc = 0;
+  set_tap(0);
+  load_step(0, 0);
+  store_step(0);
+  __syncthreads();
+
+  for (int s = 0; s < steps; ++s) {
+    const bool more = s + 1 < steps;
+    if (more) {
+      if (++lcc == a.KC16) { lcc = 0; ++ltap; set_tap(ltap); }
+      load_step(ltap, lcc);  // global loads for step s+1 stay in flight under this step's MFMAs
+    }
+    const float* Ab = As + (s & 1) * BM * LD + (wm * TM * 32 + idx) * LD + h * 4;
+    const float* Bb = Bs + (s & 1) * BN * LD + (wn * TN * 32 + idx) * LD + h * 4;
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+      float4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LD + kh * 8);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LD + kh * 8);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+    if (more) store_step((s + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + (wn * TN + j) * 32 + idx;
+      if (n >= a.Nout) continue;
+      const float bias = (a.epi & FP_EPI_BIAS) ? a.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m >= a.M) continue;
+        const size_t o = (size_t)m * a.Nout + n;
+        float v = acc[i][j][r] + bias;
+        if (a.epi & FP_EPI_ADDEND) {
+          float ad = a.addend[o];
+          if (a.epi & FP_EPI_ADDEND_MASK) ad = a.addend_mask[o] > 0.f ? ad : 0.f;
+          v += ad;
+        }
+        if (a.epi & FP_EPI_ACTGRAD_ELU) {
+          const float sv = a.actsrc[o];
+          v *= (sv > 0.f ? 1.f : sv + 1.f);
+        }
+        if (a.epi & FP_EPI_ACTGRAD_RELU) v = a.actsrc[o] > 0.f ? v : 0.f;
+        if (a.act == FP_ACT_ELU) v = v > 0.f ? v : expm1f(v);
+        if (a.act == FP_ACT_RELU) v = fmaxf(v, 0.f);
+        if (a.epi & FP_EPI_ACCUM) v += a.y[o];
+        a.y[o] = v;
+      }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, bool STEM>
+int launch(IgemmArgs& a, hipStream_t stream) {
+  const int tilesM = (int)fp_ceil_div(a.M, BM);
+  a.tilesN = (int)fp_ceil_div(a.Nout, BN);
+  a.nwg = tilesM * a.tilesN;
+  hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, STEM>), dim3(a.nwg), dim3(256), 0, stream, a);
+  return fp_check_launch("fp_conv_igemm");
+}
+
+}  // namespace
+
+extern "C" int fp_conv_igemm(const fp_conv_desc* d, const float* src0, const float* src1, const float* wpacked,
+                             const float* bias, const float* addend, const float* addend_mask, const float* actsrc,
+                             float* y, fp_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  FP_REQUIRE(d && src0 && wpacked && y, "fp_conv_igemm: null pointer");
+  FP_REQUIRE(d->N > 0 && d->OH > 0 && d->OW > 0 && d->Nout > 0, "fp_conv_igemm: empty problem");
+  const bool stem = d->gather == FP_GATHER_STEM;
+  if (stem) {
+    FP_REQUIRE(d->KH == 7 && d->KW == 7 && d->stride == 2 && d->pad == 3 && d->C0 == 3 && d->C1 == 0,
+               "fp_conv_igemm: STEM expects 7x7/2 pad 3 on 3 channels");
+  } else {
+    FP_REQUIRE(d->C0 > 0 && d->C0 % 4 == 0 && d->C1 >= 0 && d->C1 % 4 == 0, "fp_conv_igemm: C0=%d C1=%d must be multiples of 4",
+               d->C0, d->C1);
+    if (d->gather == FP_GATHER_FWD_REFLECT || d->gather == FP_GATHER_FWD_REFLECT_UP2 || d->gather == FP_GATHER_DGRAD_REFLECT)
+      FP_REQUIRE(d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->IH == d->OH && d->IW == d->OW && d->IH >= 2 &&
+                     d->IW >= 2,
+                 "fp_conv_igemm: reflect modes need 3x3 stride 1 pad 1, dims >= 2");
+    if (d->gather == FP_GATHER_FWD_REFLECT_UP2) FP_REQUIRE(d->IH % 2 == 0 && d->IW % 2 == 0, "fp_conv_igemm: UP2 needs even dims");
+    FP_REQUIRE(d->C1 == 0 || (d->gather == FP_GATHER_FWD_REFLECT_UP2 && src1), "fp_conv_igemm: C1 only with UP2 concat");
+  }
+  FP_REQUIRE(!(d->epi & FP_EPI_BIAS) || bias, "fp_conv_igemm: bias flag without pointer");
+  FP_REQUIRE(!(d->epi & FP_EPI_ADDEND) || addend, "fp_conv_igemm: addend flag without pointer");
+  FP_REQUIRE(!(d->epi & FP_EPI_ADDEND_MASK) || addend_mask, "fp_conv_igemm: addend_mask flag without pointer");
+  FP_REQUIRE(!(d->epi & (FP_EPI_ACTGRAD_ELU | FP_EPI_ACTGRAD_RELU)) || actsrc, "fp_conv_igemm: actgrad flag without pointer");
+  const int64_t M64 = (int64_t)d->N * d->OH * d->OW;
+  FP_REQUIRE(M64 * (int64_t)(d->Nout > d->C0 + d->C1 ? d->Nout : d->C0 + d->C1) < (int64_t)1 << 40 && M64 < (int64_t)1 << 31,
+             "fp_conv_igemm: problem too large");
+
+  IgemmArgs a;
+  a.src0 = src0; a.src1 = src1; a.w = wpacked; a.bias = bias; a.addend = addend; a.addend_mask = addend_mask;
+  a.actsrc = actsrc; a.y = y;
+  a.g = FpGeom{d->N, d->OH, d->OW, d->IH, d->IW, d->C0, d->C1, d->KH, d->KW, d->stride, d->pad, d->gather};
+  a.Nout = d->Nout; a.act = d->act; a.epi = d->epi;
+  a.M = (int)M64;
+  a.T = stem ? 1 : d->KH * d->KW;
+  a.KC16 = stem ? 10 : (d->C0 + d->C1 + 15) / 16;
+
+  if (stem) return launch<128, 64, 2, 2, true>(a, stream);
+  const int64_t M = a.M;
+  if (d->Nout <= 32) {
+    if (fp_ceil_div(M, 256) >= 512) return launch<256, 32, 4, 1, false>(a, stream);
+    return launch<128, 32, 4, 1, false>(a, stream);
+  }
+  const int64_t t128 = fp_ceil_div(M, 128);
+  if (d->Nout % 128 == 0 && t128 * (d->Nout / 128) >= 512) return launch<128, 128, 2, 2, false>(a, stream);
+  if (t128 * fp_ceil_div(d->Nout, 64) >= 384) return launch<128, 64, 2, 2, false>(a, stream);
+  return launch<64, 64, 2, 2, false>(a, stream);
+}

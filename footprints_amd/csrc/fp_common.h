@@ -1,0 +1,122 @@
+// Shared device/host helpers for libfootprints_hip (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "footprints_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+int fp_set_error(int code, const char* fmt, ...);
+int fp_check_launch(const char* what);
+
+#define FP_REQUIRE(cond, ...)                          \
+  do {                                                 \
+    if (!(cond)) return fp_set_error(FP_EINVAL, __VA_ARGS__); \
+  } while (0)
+
+static inline int64_t fp_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- XCD-aware workgroup id remap (8 XCDs, private L2 each): consecutive logical tiles share halo rows
+// and weight slices, so give each XCD a contiguous range of logical ids. Bijective for any grid size.
+__device__ __forceinline__ int fp_xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = bid & 7, local = bid >> 3;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + local;
+}
+
+// ---- gather geometry shared by the implicit-GEMM forward/dgrad kernel and the wgrad kernel ------------
+struct FpGeom {
+  int N, OH, OW, IH, IW, C0, C1, KH, KW, stride, pad, gather;
+};
+
+__device__ __forceinline__ int fp_reflect(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+
+// Source pixel indices for output pixel (n, oy, ox) and tap (ky, kx).
+// pix[0..3]: pixels of src0 whose values are SUMMED (only DGRAD_REFLECT uses more than one: the reflection
+//            halo folds gradient rows -1/H and cols -1/W back onto rows 1/H-2, cols 1/W-2); -1 = absent.
+// pix1:      pixel of src1 (the full-resolution skip tensor of the UP2 concat); -1 = absent.
+__device__ __forceinline__ void fp_gather_tap(const FpGeom& g, int n, int oy, int ox, int ky, int kx, int pix[4],
+                                              int& pix1) {
+  pix[0] = pix[1] = pix[2] = pix[3] = -1;
+  pix1 = -1;
+  switch (g.gather) {
+    case FP_GATHER_FWD_ZERO: {
+      const int iy = oy * g.stride + ky - g.pad, ix = ox * g.stride + kx - g.pad;
+      if (iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW) pix[0] = (n * g.IH + iy) * g.IW + ix;
+      break;
+    }
+    case FP_GATHER_FWD_REFLECT: {
+      const int iy = fp_reflect(oy + ky - 1, g.IH), ix = fp_reflect(ox + kx - 1, g.IW);
+      pix[0] = (n * g.IH + iy) * g.IW + ix;
+      break;
+    }
+    case FP_GATHER_FWD_REFLECT_UP2: {
+      const int iy = fp_reflect(oy + ky - 1, g.IH), ix = fp_reflect(ox + kx - 1, g.IW);
+      pix[0] = (n * (g.IH >> 1) + (iy >> 1)) * (g.IW >> 1) + (ix >> 1);  // nearest x2: src = dst // 2
+      pix1 = (n * g.IH + iy) * g.IW + ix;
+      break;
+    }
+    case FP_GATHER_DGRAD_ZERO: {
+      const int ry = oy + g.pad - ky, rx = ox + g.pad - kx;
+      if (ry >= 0 && rx >= 0) {
+        const int sy = ry / g.stride, sx = rx / g.stride;
+        if (sy * g.stride == ry && sx * g.stride == rx && sy < g.IH && sx < g.IW) pix[0] = (n * g.IH + sy) * g.IW + sx;
+      }
+      break;
+    }
+    case FP_GATHER_DGRAD_REFLECT: {
+      const int r0 = oy + 1 - ky, c0 = ox + 1 - kx;
+      const bool r0v = r0 >= 0 && r0 < g.IH, c0v = c0 >= 0 && c0 < g.IW;
+      // virtual padded row -1 mirrors onto row 1 (tap ky=0 reads dZ row 0); row H mirrors onto H-2 (ky=2 reads row H-1)
+      const int er = (ky == 0 && oy == 1) ? 0 : ((ky == 2 && oy == g.OH - 2) ? g.IH - 1 : -1);
+      const int ec = (kx == 0 && ox == 1) ? 0 : ((kx == 2 && ox == g.OW - 2) ? g.IW - 1 : -1);
+      const int nb = n * g.IH;
+      if (r0v && c0v) pix[0] = (nb + r0) * g.IW + c0;
+      if (er >= 0 && c0v) pix[1] = (nb + er) * g.IW + c0;
+      if (r0v && ec >= 0) pix[2] = (nb + r0) * g.IW + ec;
+      if (er >= 0 && ec >= 0) pix[3] = (nb + er) * g.IW + ec;
+      break;
+    }
+    default: break;
+  }
+}
+
+// 4 consecutive K-channels [c4, c4+4) of one tap for one pixel (C0, C1 multiples of 4 => never straddles).
+__device__ __forceinline__ float4 fp_gather_load4(const FpGeom& g, const float* __restrict__ src0,
+                                                  const float* __restrict__ src1, const int pix[4], int pix1, int c4) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c4 < g.C0) {
+    if (pix[0] >= 0) v = *reinterpret_cast<const float4*>(src0 + (size_t)pix[0] * g.C0 + c4);
+    if ((pix[1] & pix[2] & pix[3]) >= 0) {  // any extra present (entries are -1 or >= 0)
+#pragma unroll
+      for (int j = 1; j < 4; ++j)
+        if (pix[j] >= 0) {
+          const float4 u = *reinterpret_cast<const float4*>(src0 + (size_t)pix[j] * g.C0 + c4);
+          v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        }
+    }
+  } else if (c4 < g.C0 + g.C1) {
+    if (pix1 >= 0) v = *reinterpret_cast<const float4*>(src1 + (size_t)pix1 * g.C1 + (c4 - g.C0));
+  }
+  return v;
+}
+
+// Stem: K index kk = (ky*7 + kx)*3 + ci over the NCHW image, (x - 0.45)/0.225 applied before zero padding.
+__device__ __forceinline__ float fp_stem_load(const FpGeom& g, const float* __restrict__ img, int n, int oy, int ox,
+                                              int kk) {
+  if (kk >= 147) return 0.f;
+  const int ky = kk / 21, rem = kk - ky * 21, kx = rem / 3, ci = rem - kx * 3;
+  const int iy = oy * 2 + ky - 3, ix = ox * 2 + kx - 3;
+  if (iy < 0 || iy >= g.IH || ix < 0 || ix >= g.IW) return 0.f;
+  const float x = img[((size_t)(n * 3 + ci) * g.IH + iy) * g.IW + ix];
+  return (x - 0.45f) / 0.225f;
+}
+
+// ---- wave / block reductions (wave = 64) ---------------------------------------------------------------
+__device__ __forceinline__ float fp_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}

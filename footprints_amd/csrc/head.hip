@@ -1,0 +1,364 @@
+// 2-channel output heads (OutConvBlock, reference footprints/network.py:161-183): reflection-pad 3x3 conv
+// Cin->2 (+sigmoid), bilinear upsample (align_corners=False) into the NCHW network output, and their
+// backward passes.  ~8.7 flop/byte => HBM-bound and MFMA-hostile: direct VALU kernels, one pixel per Cin/4
+// adjacent lanes (float4 NHWC loads, 128-B contiguous per pixel), wave-shuffle reductions, no atomics
+// (every reduction has a fixed order => bit-reproducible).
+#include "fp_common.h"
+
+namespace {
+
+constexpr int MAXC = 128;
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+// Ws0/Ws1[tap][Cin] <- w_oihw[2][Cin][3][3]
+__device__ __forceinline__ void load_head_weights(const float* __restrict__ w, int Cin, float* Ws0, float* Ws1) {
+  for (int e = threadIdx.x; e < 9 * Cin; e += blockDim.x) {
+    const int tap = e / Cin, c = e - tap * Cin;
+    Ws0[e] = w[(size_t)c * 9 + tap];
+    Ws1[e] = w[(size_t)(Cin + c) * 9 + tap];
+  }
+}
+
+__global__ void __launch_bounds__(256) head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, float* __restrict__ low, int N, int H,
+                                                       int W, int Cin, int sig) {
+  __shared__ __attribute__((aligned(16))) float Ws0[9 * MAXC];
+  __shared__ __attribute__((aligned(16))) float Ws1[9 * MAXC];
+  load_head_weights(w, Cin, Ws0, Ws1);
+  __syncthreads();
+  const int Q = Cin >> 2, PPB = 256 / Q;
+  const int q = threadIdx.x % Q, slot = threadIdx.x / Q;
+  const int M = N * H * W;
+  const float b0 = bias[0], b1 = bias[1];
+  for (int mb = blockIdx.x * PPB; mb < M; mb += gridDim.x * PPB) {   // uniform trip count per block
+    const int m = mb + slot;
+    float a0 = 0.f, a1 = 0.f;
+    if (m < M) {
+      const int ox = m % W, r = m / W, oy = r % H, n = r / H;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int iy = fp_reflect(oy + ky - 1, H);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int ix = fp_reflect(ox + kx - 1, W);
+          const float4 v = *reinterpret_cast<const float4*>(x + ((size_t)(n * H + iy) * W + ix) * Cin + q * 4);
+          const float4 w0 = *reinterpret_cast<const float4*>(Ws0 + (ky * 3 + kx) * Cin + q * 4);
+          const float4 w1 = *reinterpret_cast<const float4*>(Ws1 + (ky * 3 + kx) * Cin + q * 4);
+          a0 += v.x * w0.x + v.y * w0.y + v.z * w0.z + v.w * w0.w;
+          a1 += v.x * w1.x + v.y * w1.y + v.z * w1.z + v.w * w1.w;
+        }
+      }
+    }
+    for (int o = Q >> 1; o > 0; o >>= 1) {   // Q is a power of two <= 32: the pixel's lanes are adjacent
+      a0 += __shfl_xor(a0, o, 64);
+      a1 += __shfl_xor(a1, o, 64);
+    }
+    if (q == 0 && m < M) {
+      float y0 = a0 + b0, y1 = a1 + b1;
+      if (sig) { y0 = sigmoidf_(y0); y1 = sigmoidf_(y1); }
+      *reinterpret_cast<float2*>(low + (size_t)m * 2) = make_float2(y0, y1);
+    }
+  }
+}
+
+// bilinear source coordinate, PyTorch align_corners=False: src = (dst+0.5)/scale - 0.5, clamped at 0
+__device__ __forceinline__ void bilin(int dst, float rscale, int n, int& i0, int& i1, float& l0, float& l1) {
+  float src = ((float)dst + 0.5f) * rscale - 0.5f;
+  src = src < 0.f ? 0.f : src;
+  i0 = (int)src;
+  i1 = i0 + (i0 < n - 1 ? 1 : 0);
+  l1 = src - (float)i0;
+  l0 = 1.f - l1;
+}
+
+__global__ void __launch_bounds__(256) head_upsample_kernel(const float* __restrict__ low, float* __restrict__ out, int N, int h,
+                                                            int w, int scale, int OC, int c0) {
+  const int H = h * scale, W = w * scale;
+  const size_t total = (size_t)N * H * W;
+  const float rs = 1.f / (float)scale;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int X = (int)(e % W);
+    const size_t r = e / W;
+    const int Y = (int)(r % H), n = (int)(r / H);
+    float2 v;
+    if (scale == 1) {
+      v = *reinterpret_cast<const float2*>(low + e * 2);
+    } else {
+      int y0, y1, x0, x1;
+      float ly0, ly1, lx0, lx1;
+      bilin(Y, rs, h, y0, y1, ly0, ly1);
+      bilin(X, rs, w, x0, x1, lx0, lx1);
+      const float2 v00 = *reinterpret_cast<const float2*>(low + ((size_t)(n * h + y0) * w + x0) * 2);
+      const float2 v01 = *reinterpret_cast<const float2*>(low + ((size_t)(n * h + y0) * w + x1) * 2);
+      const float2 v10 = *reinterpret_cast<const float2*>(low + ((size_t)(n * h + y1) * w + x0) * 2);
+      const float2 v11 = *reinterpret_cast<const float2*>(low + ((size_t)(n * h + y1) * w + x1) * 2);
+      v.x = ly0 * (lx0 * v00.x + lx1 * v01.x) + ly1 * (lx0 * v10.x + lx1 * v11.x);
+      v.y = ly0 * (lx0 * v00.y + lx1 * v01.y) + ly1 * (lx0 * v10.y + lx1 * v11.y);
+    }
+    const size_t plane = (size_t)H * W;
+    float* o = out + ((size_t)n * OC + c0) * plane + (size_t)Y * W + X;
+    o[0] = v.x;
+    o[plane] = v.y;
+  }
+}
+
+// gather-form transpose of the bilinear upsample: every low-res pixel sums the hi-res pixels that read it.
+__global__ void __launch_bounds__(256) head_upsample_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ low,
+                                                                float* __restrict__ dz, int N, int h, int w, int scale, int OC,
+                                                                int c0, int sig) {
+  const int H = h * scale, W = w * scale;
+  const size_t total = (size_t)N * h * w;
+  const size_t plane = (size_t)H * W;
+  const float rs = 1.f / (float)scale;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int x = (int)(e % w);
+    const size_t r = e / w;
+    const int y = (int)(r % h), n = (int)(r / h);
+    const float* d0 = dout + ((size_t)n * OC + c0) * plane;
+    float g0 = 0.f, g1 = 0.f;
+    if (scale == 1) {
+      g0 = d0[(size_t)y * W + x];
+      g1 = d0[plane + (size_t)y * W + x];
+    } else {
+      const int Y0 = max(0, scale * (y - 1)), Y1 = min(H - 1, scale * (y + 2));
+      const int X0 = max(0, scale * (x - 1)), X1 = min(W - 1, scale * (x + 2));
+      for (int Y = Y0; Y <= Y1; ++Y) {
+        int i0, i1; float l0, l1;
+        bilin(Y, rs, h, i0, i1, l0, l1);
+        const float wy = (i0 == y ? l0 : 0.f) + (i1 == y ? l1 : 0.f);
+        if (wy == 0.f) continue;
+        float r0 = 0.f, r1 = 0.f;
+        for (int X = X0; X <= X1; ++X) {
+          int j0, j1; float m0, m1;
+          bilin(X, rs, w, j0, j1, m0, m1);
+          const float wx = (j0 == x ? m0 : 0.f) + (j1 == x ? m1 : 0.f);
+          if (wx == 0.f) continue;
+          r0 += wx * d0[(size_t)Y * W + X];
+          r1 += wx * d0[plane + (size_t)Y * W + X];
+        }
+        g0 += wy * r0;
+        g1 += wy * r1;
+      }
+    }
+    if (sig) {
+      const float2 s = *reinterpret_cast<const float2*>(low + e * 2);
+      g0 *= s.x * (1.f - s.x);
+      g1 *= s.y * (1.f - s.y);
+    }
+    *reinterpret_cast<float2*>(dz + e * 2) = make_float2(g0, g1);
+  }
+}
+
+__global__ void __launch_bounds__(256) head_dgrad_kernel(const float* __restrict__ dz, const float* __restrict__ w,
+                                                         const float* __restrict__ elu_src, float* __restrict__ dx, int N, int H,
+                                                         int W, int Cin) {
+  __shared__ __attribute__((aligned(16))) float Ws0[9 * MAXC];
+  __shared__ __attribute__((aligned(16))) float Ws1[9 * MAXC];
+  load_head_weights(w, Cin, Ws0, Ws1);
+  __syncthreads();
+  const int Q = Cin >> 2;
+  const size_t total = (size_t)N * H * W * Q;
+  FpGeom g{N, H, W, H, W, 2, 0, 3, 3, 1, 1, FP_GATHER_DGRAD_REFLECT};
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int q = (int)(e % Q);
+    const int m = (int)(e / Q);
+    const int ox = m % W, r = m / W, oy = r % H, n = r / H;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      int pix[4], pix1;
+      fp_gather_tap(g, n, oy, ox, tap / 3, tap % 3, pix, pix1);
+      float z0 = 0.f, z1 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (pix[j] >= 0) {
+          const float2 z = *reinterpret_cast<const float2*>(dz + (size_t)pix[j] * 2);
+          z0 += z.x;
+          z1 += z.y;
+        }
+      const float4 w0 = *reinterpret_cast<const float4*>(Ws0 + tap * Cin + q * 4);
+      const float4 w1 = *reinterpret_cast<const float4*>(Ws1 + tap * Cin + q * 4);
+      acc.x += z0 * w0.x + z1 * w1.x;
+      acc.y += z0 * w0.y + z1 * w1.y;
+      acc.z += z0 * w0.z + z1 * w1.z;
+      acc.w += z0 * w0.w + z1 * w1.w;
+    }
+    if (elu_src) {
+      const float4 s = *reinterpret_cast<const float4*>(elu_src + (size_t)m * Cin + q * 4);
+      acc.x *= (s.x > 0.f ? 1.f : s.x + 1.f); acc.y *= (s.y > 0.f ? 1.f : s.y + 1.f);
+      acc.z *= (s.z > 0.f ? 1.f : s.z + 1.f); acc.w *= (s.w > 0.f ? 1.f : s.w + 1.f);
+    }
+    *reinterpret_cast<float4*>(dx + (size_t)m * Cin + q * 4) = acc;
+  }
+}
+
+// partial[block][(tap*Cin + c)*2 + o] and partial_b[block][2]
+__global__ void __launch_bounds__(256) head_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dz,
+                                                         float* __restrict__ part, int N, int H, int W, int Cin) {
+  __shared__ float red[4 * 32 * 74];
+  const int Q = Cin >> 2, PPB = 256 / Q;
+  const int q = threadIdx.x % Q, slot = threadIdx.x / Q;
+  const int M = N * H * W;
+  float acc[9][4][2];
+  float bsum0 = 0.f, bsum1 = 0.f;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[t][c][0] = acc[t][c][1] = 0.f;
+  for (int m = blockIdx.x * PPB + slot; m < M; m += gridDim.x * PPB) {
+    const int ox = m % W, r = m / W, oy = r % H, n = r / H;
+    const float2 z = *reinterpret_cast<const float2*>(dz + (size_t)m * 2);
+    bsum0 += z.x;
+    bsum1 += z.y;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = fp_reflect(oy + ky - 1, H);
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = fp_reflect(ox + kx - 1, W);
+        const float4 v = *reinterpret_cast<const float4*>(x + ((size_t)(n * H + iy) * W + ix) * Cin + q * 4);
+        const int t = ky * 3 + kx;
+        acc[t][0][0] += v.x * z.x; acc[t][0][1] += v.x * z.y;
+        acc[t][1][0] += v.y * z.x; acc[t][1][1] += v.y * z.y;
+        acc[t][2][0] += v.z * z.x; acc[t][2][1] += v.z * z.y;
+        acc[t][3][0] += v.w * z.x; acc[t][3][1] += v.w * z.y;
+      }
+    }
+  }
+  // reduce over the pixel slots of this wave (lanes q, q+Q, q+2Q, ...), fixed xor tree
+  for (int o = Q; o < 64; o <<= 1) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        acc[t][c][0] += __shfl_xor(acc[t][c][0], o, 64);
+        acc[t][c][1] += __shfl_xor(acc[t][c][1], o, 64);
+      }
+    bsum0 += __shfl_xor(bsum0, o, 64);
+    bsum1 += __shfl_xor(bsum1, o, 64);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane < Q) {
+    float* dst = red + (wave * 32 + lane) * 74;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        dst[(t * 4 + c) * 2 + 0] = acc[t][c][0];
+        dst[(t * 4 + c) * 2 + 1] = acc[t][c][1];
+      }
+    dst[72] = bsum0;
+    dst[73] = bsum1;
+  }
+  __syncthreads();
+  float* out = part + (size_t)blockIdx.x * (9 * Cin * 2 + 2);
+  for (int e = threadIdx.x; e < Q * 72; e += 256) {
+    const int qq = e / 72, j = e - qq * 72;
+    const float s = red[(0 * 32 + qq) * 74 + j] + red[(1 * 32 + qq) * 74 + j] + red[(2 * 32 + qq) * 74 + j] +
+                    red[(3 * 32 + qq) * 74 + j];
+    const int t = j / 8, c = (j >> 1) & 3, o = j & 1;
+    out[(t * Cin + qq * 4 + c) * 2 + o] = s;
+  }
+  if (threadIdx.x < 2) {
+    // each wave's Q lanes hold the same wave-total bias sum (all slots reduced): take lane 0 of each wave
+    const int o = threadIdx.x;
+    out[9 * Cin * 2 + o] = red[(0 * 32) * 74 + 72 + o] + red[(1 * 32) * 74 + 72 + o] + red[(2 * 32) * 74 + 72 + o] +
+                           red[(3 * 32) * 74 + 72 + o];
+  }
+}
+
+__global__ void __launch_bounds__(256) head_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                                float* __restrict__ db, int nblk, int Cin, int accumulate) {
+  const int per = 9 * Cin * 2 + 2;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < per; e += gridDim.x * 256) {
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += part[(size_t)b * per + e];
+    if (e < 9 * Cin * 2) {
+      const int o = e & 1, tc = e >> 1, c = tc % Cin, t = tc / Cin;
+      float* p = dw + ((size_t)o * Cin + c) * 9 + t;
+      *p = accumulate ? *p + s : s;
+    } else {
+      float* p = db + (e - 9 * Cin * 2);
+      *p = accumulate ? *p + s : s;
+    }
+  }
+}
+
+int head_wgrad_blocks(int64_t M, int Cin) {
+  const int64_t ppb = 256 / (Cin / 4);
+  int64_t b = fp_ceil_div(M, ppb * 8);
+  if (b > 1024) b = 1024;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+bool head_cin_ok(int Cin) { return Cin >= 4 && Cin <= MAXC && (Cin & (Cin - 1)) == 0; }
+
+}  // namespace
+
+extern "C" int fp_head_fwd(const float* x, const float* w_oihw, const float* bias, float* low, int32_t N, int32_t h, int32_t w,
+                           int32_t Cin, int32_t apply_sigmoid, fp_stream_t stream) {
+  FP_REQUIRE(x && w_oihw && bias && low, "fp_head_fwd: null pointer");
+  FP_REQUIRE(head_cin_ok(Cin) && h >= 2 && w >= 2, "fp_head_fwd: Cin=%d must be a power of two in [4,128], dims >= 2", Cin);
+  const int64_t M = (int64_t)N * h * w;
+  const int ppb = 256 / (Cin / 4);
+  int grid = (int)fp_ceil_div(M, ppb);
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(head_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, w_oihw, bias, low, N, h, w, Cin,
+                     apply_sigmoid);
+  return fp_check_launch("fp_head_fwd");
+}
+
+extern "C" int fp_head_upsample(const float* low, float* out_nchw, int32_t N, int32_t h, int32_t w, int32_t scale,
+                                int32_t out_channels, int32_t c0, fp_stream_t stream) {
+  FP_REQUIRE(low && out_nchw && scale >= 1 && c0 + 2 <= out_channels, "fp_head_upsample: bad arguments");
+  const int64_t total = (int64_t)N * h * scale * w * scale;
+  int grid = (int)fp_ceil_div(total, 256);
+  if (grid > 16384) grid = 16384;
+  hipLaunchKernelGGL(head_upsample_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, low, out_nchw, N, h, w, scale,
+                     out_channels, c0);
+  return fp_check_launch("fp_head_upsample");
+}
+
+extern "C" int fp_head_upsample_bwd(const float* dout_nchw, const float* low, float* dzlow, int32_t N, int32_t h, int32_t w,
+                                    int32_t scale, int32_t out_channels, int32_t c0, int32_t apply_sigmoid, fp_stream_t stream) {
+  FP_REQUIRE(dout_nchw && dzlow && scale >= 1 && c0 + 2 <= out_channels, "fp_head_upsample_bwd: bad arguments");
+  FP_REQUIRE(!apply_sigmoid || low, "fp_head_upsample_bwd: sigmoid needs the saved head output");
+  const int64_t total = (int64_t)N * h * w;
+  int grid = (int)fp_ceil_div(total, 256);
+  if (grid > 16384) grid = 16384;
+  hipLaunchKernelGGL(head_upsample_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dout_nchw, low, dzlow, N, h, w, scale,
+                     out_channels, c0, apply_sigmoid);
+  return fp_check_launch("fp_head_upsample_bwd");
+}
+
+extern "C" int fp_head_dgrad(const float* dzlow, const float* w_oihw, const float* elu_src, float* dx, int32_t N, int32_t h,
+                             int32_t w, int32_t Cin, fp_stream_t stream) {
+  FP_REQUIRE(dzlow && w_oihw && dx, "fp_head_dgrad: null pointer");
+  FP_REQUIRE(head_cin_ok(Cin) && h >= 2 && w >= 2, "fp_head_dgrad: unsupported Cin=%d", Cin);
+  const int64_t total = (int64_t)N * h * w * (Cin / 4);
+  int grid = (int)fp_ceil_div(total, 256);
+  if (grid > 16384) grid = 16384;
+  hipLaunchKernelGGL(head_dgrad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dzlow, w_oihw, elu_src, dx, N, h, w, Cin);
+  return fp_check_launch("fp_head_dgrad");
+}
+
+extern "C" int64_t fp_head_wgrad_workspace(int32_t N, int32_t h, int32_t w, int32_t Cin) {
+  return (int64_t)head_wgrad_blocks((int64_t)N * h * w, Cin) * (9 * Cin * 2 + 2) * (int64_t)sizeof(float);
+}
+
+extern "C" int fp_head_wgrad(const float* x, const float* dzlow, float* dw_oihw, float* db, int32_t N, int32_t h, int32_t w,
+                             int32_t Cin, int accumulate, void* workspace, int64_t workspace_bytes, fp_stream_t stream) {
+  FP_REQUIRE(x && dzlow && dw_oihw && db && workspace, "fp_head_wgrad: null pointer");
+  FP_REQUIRE(head_cin_ok(Cin) && h >= 2 && w >= 2, "fp_head_wgrad: unsupported Cin=%d", Cin);
+  FP_REQUIRE(workspace_bytes >= fp_head_wgrad_workspace(N, h, w, Cin), "fp_head_wgrad: workspace too small");
+  const int nblk = head_wgrad_blocks((int64_t)N * h * w, Cin);
+  hipLaunchKernelGGL(head_wgrad_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, dzlow, (float*)workspace, N, h, w, Cin);
+  int rc = fp_check_launch("fp_head_wgrad");
+  if (rc) return rc;
+  const int per = 9 * Cin * 2 + 2;
+  hipLaunchKernelGGL(head_wgrad_reduce_kernel, dim3((int)fp_ceil_div(per, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)workspace, dw_oihw, db, nblk, Cin, accumulate);
+  return fp_check_launch("fp_head_wgrad(reduce)");
+}

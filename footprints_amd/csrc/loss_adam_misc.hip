@@ -1,0 +1,410 @@
+// Fused multi-head loss (forward + backward in one pass), fused Adam, weight packing, column sums, the backward
+// of the virtual nearest-x2 + concat, and layout transforms.  All HBM-bound streaming kernels: one pass over the
+// data, float4 where the layout allows, fixed-order reductions (no atomics) so reruns are bit-stable.
+#include "fp_common.h"
+
+namespace {
+
+int ew_grid(size_t total, int cap = 8192) {
+  size_t g = (total + 255) / 256;
+  return (int)(g > (size_t)cap ? cap : (g < 1 ? 1 : g));
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Loss: reference footprints/training/losses.py:31-152 (+ utils.py:36-42), closed form per pixel.
+// ------------------------------------------------------------------------------------------------------------
+struct LossArgs {
+  const float* pred[4];
+  float* dpred[4];
+  const float *vg, *ag, *depth, *gdepth, *mov, *dm;
+  float min_disp, disp_range, prior, gscale;
+  int B, HW;
+  float* part;
+};
+
+__device__ __forceinline__ float bce_logits(float x, float t) {  // BCEWithLogitsLoss(reduction='none')
+  return fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
+}
+__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
+
+__global__ void __launch_bounds__(256) loss_kernel(const LossArgs a) {
+  __shared__ float sm[4][16];
+  const size_t npix = (size_t)a.B * a.HW;
+  float sums[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) sums[i] = 0.f;
+  for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += (size_t)gridDim.x * 256) {
+    const int b = (int)(p / a.HW);
+    const size_t yx = p - (size_t)b * a.HW;
+    const float vg = a.vg[p], ag = a.ag[p], depth = a.depth[p], gdepth = a.gdepth[p];
+    const float keep = 1.f - a.mov[p];                         // losses.py:44 (mask is 1 if moving)
+    const float m = (ag + a.dm[p]) > 0.f ? 1.f : 0.f;           // losses.py:138
+    const float vd = depth > 0.f ? 1.f : 0.f, vgd = gdepth > 0.f ? 1.f : 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const size_t base = (size_t)b * 4 * a.HW + yx;
+      const float o0 = a.pred[s][base], o1 = a.pred[s][base + a.HW], o2 = a.pred[s][base + 2 * (size_t)a.HW],
+                  o3 = a.pred[s][base + 3 * (size_t)a.HW];
+      // ch0 visible ground
+      sums[s * 4 + 0] += bce_logits(o0, vg);
+      // ch1 three-class loss
+      const float w1 = m * keep, w0 = a.prior * (1.f - m);
+      sums[s * 4 + 1] += bce_logits(o1, ag) * w1 + bce_logits(o1, 0.f) * w0;
+      // ch2/ch3 log-L1 on depth = 1/(min_disp + range*sigmoid_disp)
+      const float sc2 = __fadd_rn(a.min_disp, __fmul_rn(a.disp_range, o2));
+      const float d2 = 1.f / sc2;
+      const float e2 = d2 - depth;
+      sums[s * 4 + 2] += logf(fabsf(e2) + 1.f) * vd;
+      const float sc3 = __fadd_rn(a.min_disp, __fmul_rn(a.disp_range, o3));
+      const float d3 = 1.f / sc3;
+      const float e3 = d3 - gdepth;
+      sums[s * 4 + 3] += logf(fabsf(e3) + 1.f) * vgd;
+      if (a.dpred[0]) {
+        const float s0 = sigm(o0), s1 = sigm(o1);
+        const float sg2 = e2 > 0.f ? 1.f : (e2 < 0.f ? -1.f : 0.f), sg3 = e3 > 0.f ? 1.f : (e3 < 0.f ? -1.f : 0.f);
+        a.dpred[s][base] = (s0 - vg) * a.gscale;
+        a.dpred[s][base + a.HW] = ((s1 - ag) * w1 + s1 * w0) * a.gscale;
+        a.dpred[s][base + 2 * (size_t)a.HW] = vd * sg2 / (fabsf(e2) + 1.f) * (-a.disp_range * d2 * d2) * a.gscale;
+        a.dpred[s][base + 3 * (size_t)a.HW] = vgd * sg3 / (fabsf(e3) + 1.f) * (-a.disp_range * d3 * d3) * a.gscale;
+      }
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const float v = fp_wave_sum(sums[i]);
+    if (lane == 0) sm[wave][i] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 16) a.part[(size_t)blockIdx.x * 16 + threadIdx.x] = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
+}
+
+__global__ void loss_final_kernel(const float* __restrict__ part, int nblk, double inv_n, float* __restrict__ out) {
+  __shared__ float mean[16];
+  if (threadIdx.x < 16) {
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += (double)part[(size_t)b * 16 + threadIdx.x];
+    mean[threadIdx.x] = (float)(s * inv_n);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float total = 0.f;
+    for (int s = 0; s < 4; ++s) {
+      const float vg = mean[s * 4 + 0], ag = mean[s * 4 + 1], d = mean[s * 4 + 2], gd = mean[s * 4 + 3];
+      out[s * 5 + 0] = vg; out[s * 5 + 1] = ag; out[s * 5 + 2] = d; out[s * 5 + 3] = gd;
+      const float ls = ((d + vg) + ag) + gd;   // losses.py:80-83 order
+      out[s * 5 + 4] = ls;
+      total += ls;
+    }
+    out[20] = total / 4.f;                      // losses.py:87
+  }
+}
+
+int loss_blocks(int64_t npix) {
+  int64_t b = fp_ceil_div(npix, 256 * 4);
+  if (b > 2048) b = 2048;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Adam (torch.optim.Adam single-tensor math: lerp, addcmul, sqrt/bc2_sqrt + eps, addcdiv)
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, size_t n, float one_minus_b1, float b2,
+                                                   float one_minus_b2, float step_size, float inv_bc2_sqrt, float eps,
+                                                   float gscale) {
+  const size_t n4 = n >> 2;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n4; e += (size_t)gridDim.x * 256) {
+    float4 P = reinterpret_cast<float4*>(p)[e], G = reinterpret_cast<const float4*>(g)[e];
+    float4 Mv = reinterpret_cast<float4*>(m)[e], V = reinterpret_cast<float4*>(v)[e];
+    float* pp = &P.x; float* gg = &G.x; float* mm = &Mv.x; float* vv = &V.x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float gr = gg[j] * gscale;
+      mm[j] = mm[j] + (gr - mm[j]) * one_minus_b1;
+      vv[j] = vv[j] * b2 + one_minus_b2 * gr * gr;
+      const float denom = sqrtf(vv[j]) * inv_bc2_sqrt + eps;
+      pp[j] = pp[j] - step_size * (mm[j] / denom);
+    }
+    reinterpret_cast<float4*>(p)[e] = P;
+    reinterpret_cast<float4*>(m)[e] = Mv;
+    reinterpret_cast<float4*>(v)[e] = V;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const size_t e = (n4 << 2) + threadIdx.x;
+    const float gr = g[e] * gscale;
+    const float mn = m[e] + (gr - m[e]) * one_minus_b1;
+    const float vn = v[e] * b2 + one_minus_b2 * gr * gr;
+    m[e] = mn; v[e] = vn;
+    p[e] = p[e] - step_size * (mn / (sqrtf(vn) * inv_bc2_sqrt + eps));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Weight packing for the implicit-GEMM kernels: Wp[tap][ceil(K/16)][Ncols][16]
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) pack_fwd_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin,
+                                                       int T, int KC16) {
+  const size_t total = (size_t)T * KC16 * Cout * 16;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int kr = (int)(e & 15);
+    size_t r = e >> 4;
+    const int n = (int)(r % Cout); r /= Cout;
+    const int kc = (int)(r % KC16);
+    const int tap = (int)(r / KC16);
+    const int k = kc * 16 + kr;
+    wp[e] = k < Cin ? w[((size_t)n * Cin + k) * T + tap] : 0.f;
+  }
+}
+__global__ void __launch_bounds__(256) pack_stem_kernel(const float* __restrict__ w, float* __restrict__ wp) {
+  const int total = 10 * 64 * 16;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+    const int kr = e & 15, n = (e >> 4) % 64, kc = (e >> 4) / 64;
+    const int kk = kc * 16 + kr;
+    float v = 0.f;
+    if (kk < 147) {
+      const int ky = kk / 21, rem = kk - ky * 21, kx = rem / 3, ci = rem - kx * 3;
+      v = w[((n * 3 + ci) * 7 + ky) * 7 + kx];
+    }
+    wp[e] = v;
+  }
+}
+__global__ void __launch_bounds__(256) pack_dgrad_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin,
+                                                         int T, int KC16) {
+  const size_t total = (size_t)T * KC16 * Cin * 16;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int kr = (int)(e & 15);
+    size_t r = e >> 4;
+    const int ci = (int)(r % Cin); r /= Cin;
+    const int kc = (int)(r % KC16);
+    const int tap = (int)(r / KC16);
+    const int co = kc * 16 + kr;
+    wp[e] = co < Cout ? w[((size_t)co * Cin + ci) * T + tap] : 0.f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Column sums (bias gradients)
+// ------------------------------------------------------------------------------------------------------------
+int colsum_blocks(int64_t M, int C) {
+  const int rows = 256 / (C / 4);
+  int64_t b = fp_ceil_div(M, (int64_t)rows * 16);
+  if (b > 512) b = 512;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+__global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ x, int M, int C, float* __restrict__ part) {
+  __shared__ float sm[256 * 4];
+  const int C4 = C >> 2, R = 256 / C4;   // threads >= R*C4 idle when C4 does not divide 256
+  const int cq = threadIdx.x % C4, rr = threadIdx.x / C4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int m = blockIdx.x * R + rr; rr < R && m < M; m += gridDim.x * R) {
+    const float4 v = *reinterpret_cast<const float4*>(x + (size_t)m * C + cq * 4);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  reinterpret_cast<float4*>(sm)[threadIdx.x] = s;
+  __syncthreads();
+  if (rr == 0) {
+    for (int r = 1; r < R; ++r) {
+      const float4 o = reinterpret_cast<float4*>(sm)[r * C4 + cq];
+      s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+    }
+    *reinterpret_cast<float4*>(part + (size_t)blockIdx.x * C + cq * 4) = s;
+  }
+}
+__global__ void __launch_bounds__(256) colsum_final_kernel(const float* __restrict__ part, int nblk, int C, float* out, int accumulate) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int b = 0; b < nblk; ++b) s += part[(size_t)b * C + c];
+  out[c] = accumulate ? out[c] + s : s;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// backward of cat[nearest_x2(low), skip]  (network.py:154-155, :98)
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) up2cat_bwd_kernel(const float* __restrict__ dxv, int N, int h, int w, int C0, int C1,
+                                                         const float* __restrict__ addend, const float* __restrict__ ylow,
+                                                         float* __restrict__ dlow, float* __restrict__ dskip, int acc_skip) {
+  const int C = C0 + C1, Q0 = C0 >> 2, Q1 = C1 >> 2, W2 = 2 * w;
+  const size_t nlow = (size_t)N * h * w * Q0;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < nlow; e += (size_t)gridDim.x * 256) {
+    const int q = (int)(e % Q0);
+    size_t r = e / Q0;
+    const int x = (int)(r % w); r /= w;
+    const int y = (int)(r % h);
+    const int n = (int)(r / h);
+    const float* p = dxv + (((size_t)(n * 2 * h + 2 * y)) * W2 + 2 * x) * C + q * 4;
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + C);
+    const float4 c = *reinterpret_cast<const float4*>(p + (size_t)W2 * C), d = *reinterpret_cast<const float4*>(p + (size_t)W2 * C + C);
+    float4 g = make_float4((a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y), (a.z + b.z) + (c.z + d.z), (a.w + b.w) + (c.w + d.w));
+    const size_t o = (e / Q0) * C0 + q * 4;
+    if (addend) {
+      const float4 ad = *reinterpret_cast<const float4*>(addend + o);
+      g.x += ad.x; g.y += ad.y; g.z += ad.z; g.w += ad.w;
+    }
+    if (ylow) {
+      const float4 s = *reinterpret_cast<const float4*>(ylow + o);
+      g.x *= (s.x > 0.f ? 1.f : s.x + 1.f); g.y *= (s.y > 0.f ? 1.f : s.y + 1.f);
+      g.z *= (s.z > 0.f ? 1.f : s.z + 1.f); g.w *= (s.w > 0.f ? 1.f : s.w + 1.f);
+    }
+    *reinterpret_cast<float4*>(dlow + o) = g;
+  }
+  if (C1 > 0) {
+    const size_t nskip = (size_t)N * 4 * h * w * Q1;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < nskip; e += (size_t)gridDim.x * 256) {
+      const int q = (int)(e % Q1);
+      const size_t pixel = e / Q1;
+      float4 g = *reinterpret_cast<const float4*>(dxv + pixel * C + C0 + q * 4);
+      float4* o = reinterpret_cast<float4*>(dskip + pixel * C1 + q * 4);
+      if (acc_skip) { const float4 v = *o; g.x += v.x; g.y += v.y; g.z += v.z; g.w += v.w; }
+      *o = g;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int C, int H, int W) {
+  const size_t total = (size_t)N * C * H * W, HW = (size_t)H * W;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int c = (int)(e % C);
+    const size_t r = e / C;
+    const size_t hw = r % HW, n = r / HW;
+    y[e] = x[(n * C + c) * HW + hw];
+  }
+}
+__global__ void __launch_bounds__(256) nhwc_to_nchw_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int C, int H, int W) {
+  const size_t total = (size_t)N * C * H * W, HW = (size_t)H * W;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const size_t hw = e % HW;
+    const size_t r = e / HW;
+    const int c = (int)(r % C);
+    const size_t n = r / C;
+    y[e] = x[(n * HW + hw) * C + c];
+  }
+}
+__global__ void __launch_bounds__(256) fill_kernel(float* x, size_t n, float v) {
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) x[e] = v;
+}
+
+}  // namespace
+
+extern "C" int64_t fp_loss_workspace(int32_t B, int32_t H, int32_t W) {
+  return (int64_t)loss_blocks((int64_t)B * H * W) * 16 * (int64_t)sizeof(float);
+}
+
+extern "C" int fp_loss_fwd_bwd(const float* const preds[4], const float* visible_ground, const float* all_ground, const float* depth,
+                               const float* ground_depth, const float* moving_object_mask, const float* depth_mask, float min_depth,
+                               float max_depth, float prior_weight, float* const dpreds[4], float* losses_out, int32_t B, int32_t H,
+                               int32_t W, void* workspace, int64_t workspace_bytes, fp_stream_t stream) {
+  FP_REQUIRE(preds && visible_ground && all_ground && depth && ground_depth && moving_object_mask && depth_mask && losses_out && workspace,
+             "fp_loss_fwd_bwd: null pointer");
+  FP_REQUIRE(workspace_bytes >= fp_loss_workspace(B, H, W), "fp_loss_fwd_bwd: workspace too small");
+  LossArgs a;
+  for (int s = 0; s < 4; ++s) {
+    FP_REQUIRE(preds[s], "fp_loss_fwd_bwd: null prediction");
+    a.pred[s] = preds[s];
+    a.dpred[s] = dpreds ? dpreds[s] : nullptr;
+  }
+  if (dpreds) FP_REQUIRE(dpreds[0] && dpreds[1] && dpreds[2] && dpreds[3], "fp_loss_fwd_bwd: null gradient buffer");
+  a.vg = visible_ground; a.ag = all_ground; a.depth = depth; a.gdepth = ground_depth; a.mov = moving_object_mask; a.dm = depth_mask;
+  // utils.py:38-41: python doubles, cast to float32 when they meet the float32 tensor
+  const double min_disp = 1.0 / (double)max_depth, max_disp = 1.0 / (double)min_depth;
+  a.min_disp = (float)min_disp;
+  a.disp_range = (float)(max_disp - min_disp);
+  a.prior = prior_weight;
+  const int64_t npix = (int64_t)B * H * W;
+  a.gscale = (float)(1.0 / (4.0 * (double)npix));
+  a.B = B; a.HW = H * W;
+  a.part = (float*)workspace;
+  const int nblk = loss_blocks(npix);
+  hipLaunchKernelGGL(loss_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float*)workspace, nblk, 1.0 / (double)npix,
+                     losses_out);
+  return fp_check_launch("fp_loss_fwd_bwd");
+}
+
+extern "C" int fp_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                            float beta2, float eps, int32_t step, float grad_scale, fp_stream_t stream) {
+  FP_REQUIRE(param && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1, "fp_adam_step: bad arguments");
+  FP_REQUIRE(((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) % 16 == 0, "fp_adam_step: buffers must be 16-byte aligned");
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  const float step_size = (float)((double)lr / bc1);
+  const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+  hipLaunchKernelGGL(adam_kernel, dim3(ew_grid((size_t)n / 4 + 1, 4096)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
+                     exp_avg_sq, (size_t)n, 1.f - beta1, beta2, 1.f - beta2, step_size, inv_bc2_sqrt, eps, grad_scale);
+  return fp_check_launch("fp_adam_step");
+}
+
+extern "C" int64_t fp_packed_weight_elems(int32_t Cout, int32_t Cin, int32_t KH, int32_t KW, int32_t for_dgrad, int32_t stem) {
+  if (stem) return 10 * 64 * 16;
+  const int64_t T = (int64_t)KH * KW;
+  return for_dgrad ? T * ((Cout + 15) / 16) * Cin * 16 : T * ((Cin + 15) / 16) * Cout * 16;
+}
+
+extern "C" int fp_pack_conv_weight(const float* w_oihw, float* wp, int32_t Cout, int32_t Cin, int32_t KH, int32_t KW, int32_t stem,
+                                   fp_stream_t stream) {
+  FP_REQUIRE(w_oihw && wp, "fp_pack_conv_weight: null pointer");
+  if (stem) {
+    FP_REQUIRE(Cout == 64 && Cin == 3 && KH == 7 && KW == 7, "fp_pack_conv_weight: stem must be [64,3,7,7]");
+    hipLaunchKernelGGL(pack_stem_kernel, dim3(40), dim3(256), 0, (hipStream_t)stream, w_oihw, wp);
+  } else {
+    const int KC16 = (Cin + 15) / 16, T = KH * KW;
+    hipLaunchKernelGGL(pack_fwd_kernel, dim3(ew_grid((size_t)T * KC16 * Cout * 16)), dim3(256), 0, (hipStream_t)stream, w_oihw, wp,
+                       Cout, Cin, T, KC16);
+  }
+  return fp_check_launch("fp_pack_conv_weight");
+}
+
+extern "C" int fp_pack_conv_weight_dgrad(const float* w_oihw, float* wp, int32_t Cout, int32_t Cin, int32_t KH, int32_t KW,
+                                         fp_stream_t stream) {
+  FP_REQUIRE(w_oihw && wp, "fp_pack_conv_weight_dgrad: null pointer");
+  const int KC16 = (Cout + 15) / 16, T = KH * KW;
+  hipLaunchKernelGGL(pack_dgrad_kernel, dim3(ew_grid((size_t)T * KC16 * Cin * 16)), dim3(256), 0, (hipStream_t)stream, w_oihw, wp,
+                     Cout, Cin, T, KC16);
+  return fp_check_launch("fp_pack_conv_weight_dgrad");
+}
+
+extern "C" int64_t fp_colsum_workspace(int64_t M, int32_t C) {
+  if (C < 4 || C % 4 || C > 1024) return 0;
+  return (int64_t)colsum_blocks(M, C) * C * (int64_t)sizeof(float);
+}
+
+extern "C" int fp_colsum(const float* x, int64_t M, int32_t C, float* out, int accumulate, void* workspace, int64_t workspace_bytes,
+                         fp_stream_t stream) {
+  FP_REQUIRE(x && out && workspace, "fp_colsum: null pointer");
+  FP_REQUIRE(C >= 4 && C % 4 == 0 && C <= 1024 && M > 0 && M < ((int64_t)1 << 31), "fp_colsum: unsupported C=%d", C);
+  FP_REQUIRE(workspace_bytes >= fp_colsum_workspace(M, C), "fp_colsum: workspace too small");
+  const int nblk = colsum_blocks(M, C);
+  hipLaunchKernelGGL(colsum_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, (int)M, C, (float*)workspace);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, nblk, C,
+                     out, accumulate);
+  return fp_check_launch("fp_colsum");
+}
+
+extern "C" int fp_up2cat_bwd(const float* dxv, int32_t N, int32_t h, int32_t w, int32_t C0, int32_t C1, const float* addend,
+                             const float* ylow_elu, float* dlow, float* dskip, int accumulate_skip, fp_stream_t stream) {
+  FP_REQUIRE(dxv && dlow && C0 > 0 && C0 % 4 == 0 && C1 % 4 == 0 && (C1 == 0 || dskip), "fp_up2cat_bwd: bad arguments");
+  const size_t nlow = (size_t)N * h * w * (C0 / 4), nskip = (size_t)N * 4 * h * w * (C1 / 4);
+  const size_t total = nlow > nskip ? nlow : nskip;
+  hipLaunchKernelGGL(up2cat_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dxv, N, h, w, C0, C1, addend,
+                     ylow_elu, dlow, dskip, accumulate_skip);
+  return fp_check_launch("fp_up2cat_bwd");
+}
+
+extern "C" int fp_nchw_to_nhwc(const float* x, float* y, int32_t N, int32_t C, int32_t H, int32_t W, fp_stream_t stream) {
+  FP_REQUIRE(x && y, "fp_nchw_to_nhwc: null pointer");
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(ew_grid((size_t)N * C * H * W)), dim3(256), 0, (hipStream_t)stream, x, y, N, C, H, W);
+  return fp_check_launch("fp_nchw_to_nhwc");
+}
+extern "C" int fp_nhwc_to_nchw(const float* x, float* y, int32_t N, int32_t C, int32_t H, int32_t W, fp_stream_t stream) {
+  FP_REQUIRE(x && y, "fp_nhwc_to_nchw: null pointer");
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(ew_grid((size_t)N * C * H * W)), dim3(256), 0, (hipStream_t)stream, x, y, N, C, H, W);
+  return fp_check_launch("fp_nhwc_to_nchw");
+}
+extern "C" int fp_fill(float* x, int64_t n, float value, fp_stream_t stream) {
+  FP_REQUIRE(x && n >= 0, "fp_fill: bad arguments");
+  if (n == 0) return FP_OK;
+  hipLaunchKernelGGL(fill_kernel, dim3(ew_grid((size_t)n)), dim3(256), 0, (hipStream_t)stream, x, (size_t)n, value);
+  return fp_check_launch("fp_fill");
+}

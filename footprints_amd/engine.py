@@ -1,0 +1,528 @@
+"""HIP execution engine for FootprintNetwork: explicit forward / backward schedules over the C ABI.
+
+Design (MI355X-first, not an autograd graph):
+  * activations NHWC fp32, resident in a named arena that is allocated once and reused every step (static
+    addresses => the whole step is capturable in a hipGraph);
+  * nearest-x2 upsample, skip concat, reflection / zero padding, ELU / ReLU, residual adds and their
+    gradients never exist as tensors -- they are loader / epilogue modes of the implicit-GEMM kernels;
+  * all live parameters are views of ONE flat fp32 buffer (same for gradients) in forward order, so Adam is
+    one kernel launch and the data-parallel all-reduce works on contiguous buckets;
+  * backward is a hand-written schedule (decoders, then encoder, reverse order); gradients of tensors with
+    several consumers are accumulated in a fixed order by epilogue flags (deterministic, no atomics).
+
+Reference call stack being replaced: FootprintNetwork.forward (network.py:21-30) and autograd's backward of
+it (training/train.py:155).
+"""
+import torch
+
+from . import _lib as L
+from . import ops
+
+SCALE_KEYS = ("1/8", "1/4", "1/2", "1/1")
+
+
+class ConvRec:
+    """One convolution: parameters + packed copies for the implicit-GEMM kernels."""
+
+    def __init__(self, name, conv, stem=False, head=False):
+        self.name = name
+        self.w = conv.weight
+        self.b = conv.bias
+        self.Cout, self.Cin, self.K, _ = conv.weight.shape
+        self.stride = conv.stride[0]
+        self.pad = self.K // 2
+        self.stem, self.head = stem, head
+        self.wp = None    # forward packing
+        self.wpd = None   # dgrad packing
+        self.gw = None    # gradient views (flat grad buffer)
+        self.gb = None
+
+
+class BNRec:
+    def __init__(self, name, bn, device):
+        self.name = name
+        self.bn = bn
+        self.C = bn.num_features
+        self.scale = torch.empty(self.C, device=device)
+        self.shift = torch.empty(self.C, device=device)
+        self.mean = torch.empty(self.C, device=device)
+        self.invstd = torch.empty(self.C, device=device)
+        self.gg = None
+        self.gb = None
+
+
+class BlockRec:
+    def __init__(self, prefix, blk, device):
+        self.prefix = prefix
+        self.stride = blk.stride
+        self.c1 = ConvRec(prefix + ".conv1", blk.conv1)
+        self.bn1 = BNRec(prefix + ".bn1", blk.bn1, device)
+        self.c2 = ConvRec(prefix + ".conv2", blk.conv2)
+        self.bn2 = BNRec(prefix + ".bn2", blk.bn2, device)
+        self.ds = self.bnd = None
+        if blk.downsample is not None:
+            self.ds = ConvRec(prefix + ".downsample.0", blk.downsample[0])
+            self.bnd = BNRec(prefix + ".downsample.1", blk.downsample[1], device)
+        self.Cin, self.Cout = self.c1.Cin, self.c1.Cout
+
+
+class DecoderRec:
+    def __init__(self, name, dec):
+        self.name = name
+        self.sig = dec.apply_sigmoid
+        self.c0 = 2 if name == "depth_decoder" else 0
+        self.blocks = []
+        for i in (1, 2, 3, 4):
+            b = getattr(dec, "block%d" % i)
+            p = "%s.block%d" % (name, i)
+            self.blocks.append(dict(
+                pre1=ConvRec(p + ".pre_concat_conv.conv1", b.pre_concat_conv.conv1),
+                pre2=ConvRec(p + ".pre_concat_conv.conv2", b.pre_concat_conv.conv2),
+                post1=ConvRec(p + ".post_concat_conv.conv1", b.post_concat_conv.conv1),
+                post2=ConvRec(p + ".post_concat_conv.conv2", b.post_concat_conv.conv2)))
+        self.heads = [ConvRec("%s.outconv%d.conv1" % (name, i), getattr(dec, "outconv%d" % i).conv1, head=True) for i in (1, 2, 3)]
+        self.heads.append(ConvRec("%s.outconv4.1.conv1" % name, dec.outconv4[1].conv1, head=True))
+        self.o41 = ConvRec("%s.outconv4.0.conv1" % name, dec.outconv4[0].conv1)
+        self.o42 = ConvRec("%s.outconv4.0.conv2" % name, dec.outconv4[0].conv2)
+
+    def convs(self):
+        out = []
+        for b in self.blocks:
+            out += [b["pre1"], b["pre2"], b["post1"], b["post2"]]
+        return out + [self.o41, self.o42]
+
+
+class Engine:
+    def __init__(self, model):
+        self.model = model
+        self.device = next(model.parameters()).device
+        if self.device.type != "cuda":
+            raise RuntimeError("footprints_amd.Engine needs the model on a CUDA (HIP) device")
+        L.load()
+        dev = self.device
+        enc = model.encoder
+        self.stem = ConvRec("encoder.layer0.0", enc.layer0[0], stem=True)
+        self.bn0 = BNRec("encoder.layer0.1", enc.layer0[1], dev)
+        self.blocks = [BlockRec(p, b, dev) for p, b in enc.blocks()]
+        self.decoders = [DecoderRec("mask_decoder", model.mask_decoder), DecoderRec("depth_decoder", model.depth_decoder)]
+        self._bufs = {}
+        self._flatten()
+        self._alloc_packed()
+        self.weights_dirty = True
+        self._versions = None
+        self.saved = None
+
+    # ------------------------------------------------------------------------------------------------
+    # parameters: one flat buffer, one flat gradient buffer (forward order, 16-byte aligned slots)
+    # ------------------------------------------------------------------------------------------------
+    def _flatten(self):
+        named = self.model.live_named_parameters()
+        self.live_names = [n for n, _ in named]
+        self.live_params = [p for _, p in named]
+        offs, total = [], 0
+        for p in self.live_params:
+            offs.append(total)
+            total += (p.numel() + 3) // 4 * 4
+        self.flat_param = torch.zeros(total, device=self.device)
+        self.flat_grad = torch.zeros(total, device=self.device)
+        self.offsets = offs
+        self.grad_views = []
+        with torch.no_grad():
+            for p, o in zip(self.live_params, offs):
+                v = self.flat_param[o:o + p.numel()].view(p.shape)
+                v.copy_(p.data)
+                p.data = v
+                self.grad_views.append(self.flat_grad[o:o + p.numel()].view(p.shape))
+        gv = dict(zip(self.live_names, self.grad_views))
+
+        def bind_conv(c):
+            c.gw = gv[c.name + ".weight"]
+            c.gb = gv[c.name + ".bias"] if c.b is not None else None
+
+        def bind_bn(b):
+            b.gg, b.gb = gv[b.name + ".weight"], gv[b.name + ".bias"]
+
+        bind_conv(self.stem)
+        bind_bn(self.bn0)
+        for blk in self.blocks:
+            for c in (blk.c1, blk.c2, blk.ds):
+                if c is not None:
+                    bind_conv(c)
+            for b in (blk.bn1, blk.bn2, blk.bnd):
+                if b is not None:
+                    bind_bn(b)
+        for d in self.decoders:
+            for c in d.convs() + d.heads:
+                bind_conv(c)
+
+    def params_alias_flat(self):
+        p0 = self.live_params[0]
+        return p0.data_ptr() == self.flat_param.data_ptr()
+
+    def all_convs(self):
+        out = [self.stem]
+        for blk in self.blocks:
+            out += [c for c in (blk.c1, blk.c2, blk.ds) if c is not None]
+        for d in self.decoders:
+            out += d.convs()
+        return out
+
+    def _alloc_packed(self):
+        total = 0
+        plan = []
+        for c in self.all_convs():
+            nf = ops.packed_weight_elems(c.Cout, c.Cin, c.K, False, c.stem)
+            nd = 0 if c.stem else ops.packed_weight_elems(c.Cout, c.Cin, c.K, True, False)
+            plan.append((c, total, nf, nd))
+            total += nf + nd
+        self.packed = torch.empty(total, device=self.device)
+        for c, o, nf, nd in plan:
+            c.wp = self.packed[o:o + nf]
+            c.wpd = self.packed[o + nf:o + nf + nd] if nd else None
+
+    def refresh_packed(self, force=False):
+        vers = tuple(c.w._version for c in self.all_convs())
+        if not (force or self.weights_dirty or vers != self._versions):
+            return
+        for c in self.all_convs():
+            ops.pack_conv_weight(c.w.data, c.wp, c.stem)
+            if c.wpd is not None:
+                ops.pack_conv_weight_dgrad(c.w.data, c.wpd)
+        self._versions = vers
+        self.weights_dirty = False
+
+    # ------------------------------------------------------------------------------------------------
+    # activation arena
+    # ------------------------------------------------------------------------------------------------
+    def buf(self, name, shape, dtype=torch.float32):
+        n = 1
+        for s in shape:
+            n *= s
+        t = self._bufs.get(name)
+        if t is None or t.numel() < n or t.dtype != dtype:
+            t = torch.empty(max(n, 1), dtype=dtype, device=self.device)
+            self._bufs[name] = t
+        return t[:n].view(shape)
+
+    # ------------------------------------------------------------------------------------------------
+    # small helpers over the ops
+    # ------------------------------------------------------------------------------------------------
+    def _bn_coeffs(self, rec, z, training):
+        bn = rec.bn
+        M = z.numel() // rec.C
+        if training:
+            ops.bn_train_stats(z.view(M, rec.C), bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var,
+                               bn.num_batches_tracked, rec.mean, rec.invstd, rec.scale, rec.shift, bn.eps,
+                               bn.momentum if bn.momentum is not None else 0.1)
+        else:
+            ops.bn_eval_coeffs(bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, rec.scale, rec.shift, bn.eps)
+
+    def _bn_apply(self, rec, z, out, residual=None, relu=True):
+        M = z.numel() // rec.C
+        ops.bn_apply(z.view(M, rec.C), rec.scale, rec.shift, out.view(M, rec.C),
+                     residual=None if residual is None else residual.view(M, rec.C), relu=relu)
+        return out
+
+    def _conv_enc(self, c, x, N, H, W, out):
+        OH, OW = (H + 2 * c.pad - c.K) // c.stride + 1, (W + 2 * c.pad - c.K) // c.stride + 1
+        d = ops.make_desc(N, OH, OW, H, W, c.Cin, 0, c.Cout, c.K, c.stride, c.pad, L.GATHER_FWD_ZERO)
+        return ops.conv_igemm(d, x, None, c.wp, out)
+
+    def _conv_dec(self, c, x0, x1, N, H, W, C0, C1, up2, out):
+        gather = L.GATHER_FWD_REFLECT_UP2 if up2 else L.GATHER_FWD_REFLECT
+        d = ops.make_desc(N, H, W, H, W, C0, C1, c.Cout, 3, 1, 1, gather, act=L.ACT_ELU)
+        return ops.conv_igemm(d, x0, x1, c.wp, out, bias=c.b.data)
+
+    # ------------------------------------------------------------------------------------------------
+    # forward
+    # ------------------------------------------------------------------------------------------------
+    def forward(self, image, training=True, save_for_backward=True, outputs=None):
+        if image.dim() != 4 or image.shape[1] != 3:
+            raise ValueError("expected image [B,3,H,W]")
+        N, _, H, W = image.shape
+        if H % 32 or W % 32 or H < 64 or W < 64:
+            raise ValueError("H and W must be multiples of 32 and >= 64 (5 stride-2 stages + ReflectionPad2d(1))")
+        if not self.params_alias_flat():
+            self._flatten()
+            self.weights_dirty = True
+        self.refresh_packed()
+        image = image.contiguous().float()
+        S = {"N": N, "H": H, "W": W, "image": image, "training": training}
+        buf = self.buf
+        # ---- encoder --------------------------------------------------------------------------------
+        h, w = H // 2, W // 2
+        z0 = buf("z0", (N, h, w, 64))
+        ops.conv_igemm(ops.make_desc(N, h, w, H, W, 3, 0, 64, 7, 2, 3, L.GATHER_STEM), image, None, self.stem.wp, z0)
+        self._bn_coeffs(self.bn0, z0, training)
+        f0 = self._bn_apply(self.bn0, z0, buf("f0", (N, h, w, 64)))
+        hp, wp_ = (h + 1) // 2, (w + 1) // 2
+        pool = buf("pool", (N, hp, wp_, 64))
+        am = buf("pool.argmax", (N, hp, wp_, 64), torch.uint8)
+        ops.maxpool_fwd(f0, pool, am)
+        feats = [f0]
+        dims = [(h, w)]
+        x, h, w = pool, hp, wp_
+        S["blocks"] = []
+        for i, blk in enumerate(self.blocks):
+            s = blk.stride
+            oh, ow = (h - 1) // s + 1, (w - 1) // s + 1
+            z1 = self._conv_enc(blk.c1, x, N, h, w, buf("b%d.z1" % i, (N, oh, ow, blk.Cout)))
+            self._bn_coeffs(blk.bn1, z1, training)
+            a1 = self._bn_apply(blk.bn1, z1, buf("b%d.a1" % i, (N, oh, ow, blk.Cout)))
+            z2 = self._conv_enc(blk.c2, a1, N, oh, ow, buf("b%d.z2" % i, (N, oh, ow, blk.Cout)))
+            self._bn_coeffs(blk.bn2, z2, training)
+            zd = None
+            if blk.ds is not None:
+                zd = self._conv_enc(blk.ds, x, N, h, w, buf("b%d.zd" % i, (N, oh, ow, blk.Cout)))
+                self._bn_coeffs(blk.bnd, zd, training)
+                idt = self._bn_apply(blk.bnd, zd, buf("b%d.idt" % i, (N, oh, ow, blk.Cout)), relu=False)
+            else:
+                idt = x
+            out = self._bn_apply(blk.bn2, z2, buf("b%d.out" % i, (N, oh, ow, blk.Cout)), residual=idt)
+            S["blocks"].append(dict(x=x, z1=z1, a1=a1, z2=z2, zd=zd, out=out, hin=h, win=w, h=oh, w=ow))
+            x, h, w = out, oh, ow
+            last_of_layer = (i + 1 == len(self.blocks)) or (self.blocks[i + 1].stride == 2)
+            if last_of_layer:
+                feats.append(out)
+                dims.append((h, w))
+        S["feats"], S["dims"] = feats, dims
+        # ---- decoders -------------------------------------------------------------------------------
+        if outputs is None:
+            outputs = [torch.empty((N, 4, H, W), device=self.device) for _ in range(4)]
+        S["dec"] = []
+        for dec in self.decoders:
+            S["dec"].append(self._decoder_forward(dec, S, outputs))
+        self.saved = S if save_for_backward else None
+        return outputs
+
+    def _decoder_forward(self, dec, S, outputs):
+        N, feats, dims = S["N"], S["feats"], S["dims"]
+        buf = self.buf
+        D = {"y": [], "x": [], "low": []}
+        x = feats[4]
+        h, w = dims[4]
+        chans = [(512, 256), (256, 128), (128, 64), (64, 64)]
+        for bi, (blk, (cin, cout)) in enumerate(zip(dec.blocks, chans)):
+            tag = "%s.b%d." % (dec.name, bi + 1)
+            skip = feats[3 - bi]
+            y1 = self._conv_dec(blk["pre1"], x, None, N, h, w, cin, 0, False, buf(tag + "y1", (N, h, w, cout)))
+            y2 = self._conv_dec(blk["pre2"], y1, None, N, h, w, cout, 0, False, buf(tag + "y2", (N, h, w, cout)))
+            h, w = 2 * h, 2 * w
+            assert (h, w) == dims[3 - bi] and skip.shape[3] == cout
+            y3 = self._conv_dec(blk["post1"], y2, skip, N, h, w, cout, cout, True, buf(tag + "y3", (N, h, w, cout)))
+            xo = self._conv_dec(blk["post2"], y3, None, N, h, w, cout, 0, False, buf(tag + "x", (N, h, w, cout)))
+            D["y"].append((y1, y2, y3))
+            D["x"].append(xo)
+            x = xo
+            if bi >= 1:                       # heads on block2/3/4 outputs: scales 8, 4, 2
+                scale = (8, 4, 2)[bi - 1]
+                low = buf("%s.low%d" % (dec.name, bi), (N, h, w, 2))
+                hd = dec.heads[bi - 1]
+                ops.head_fwd(x, hd.w.data, hd.b.data, low, dec.sig)
+                ops.head_upsample(low, outputs[bi - 1], scale, dec.c0)
+                D["low"].append(low)
+        # outconv4: nearest x2 (virtual) -> ConvBlock(64->32) -> head, scale 1
+        h, w = 2 * h, 2 * w
+        y51 = self._conv_dec(dec.o41, x, None, N, h, w, 64, 0, True, buf(dec.name + ".y51", (N, h, w, 32)))
+        x5 = self._conv_dec(dec.o42, y51, None, N, h, w, 32, 0, False, buf(dec.name + ".x5", (N, h, w, 32)))
+        low = buf(dec.name + ".low4", (N, h, w, 2))
+        ops.head_fwd(x5, dec.heads[3].w.data, dec.heads[3].b.data, low, dec.sig)
+        ops.head_upsample(low, outputs[3], 1, dec.c0)
+        D["low"].append(low)
+        D["y51"], D["x5"] = y51, x5
+        return D
+
+    # ------------------------------------------------------------------------------------------------
+    # backward
+    # ------------------------------------------------------------------------------------------------
+    def _wgrad(self, c, gather, src0, src1, dz, N, OH, OW, IH, IW, C0, C1, acc):
+        d = ops.make_desc(N, OH, OW, IH, IW, C0, C1, c.Cout, c.K, c.stride, c.pad, gather)
+        ops.conv_wgrad(d, src0, src1, dz, c.gw, accumulate=acc)
+        if c.gb is not None:
+            ops.colsum(dz.view(-1, c.Cout), c.gb, accumulate=acc)
+
+    def _dgrad_dec(self, c, dz, N, H, W, out, actsrc=None, addend=None, accum=False):
+        epi = (L.EPI_ACTGRAD_ELU if actsrc is not None else 0) | (L.EPI_ACCUM if accum else 0)
+        d = ops.make_desc(N, H, W, H, W, c.Cout, 0, c.Cin, 3, 1, 1, L.GATHER_DGRAD_REFLECT, epi=epi)
+        return ops.conv_igemm(d, dz, None, c.wpd, out, actsrc=actsrc, addend=addend)
+
+    def backward(self, grad_outputs, accumulate=False, on_stage=None):
+        """grad_outputs: 4 tensors [B,4,H,W] (d loss / d outputs['1/8','1/4','1/2','1/1']).
+        Writes every live parameter gradient into self.flat_grad (views: self.grad_views).
+        on_stage(name) is called as soon as all gradients of a flat-buffer stage ('mask_decoder', 'depth_decoder',
+        'encoder.layer4' .. 'encoder.layer0') have been launched -- the data-parallel reducer hooks in here."""
+        S = self.saved
+        if S is None:
+            raise RuntimeError("backward called without a saved forward")
+        if not S["training"]:
+            raise RuntimeError("backward through eval-mode BatchNorm is not supported by the HIP engine")
+        N = S["N"]
+        feats, dims = S["feats"], S["dims"]
+        buf = self.buf
+        gouts = [g.contiguous() for g in grad_outputs]
+        dF = [buf("dF%d" % i, tuple(f.shape)) for i, f in enumerate(feats)]
+        for di, dec in enumerate(self.decoders):
+            self._decoder_backward(dec, S["dec"][di], S, gouts, dF, first=(di == 0), acc=accumulate)
+            if on_stage is not None:
+                on_stage(dec.name)
+        # ---- encoder ----------------------------------------------------------------------------------
+        nblk = len(self.blocks)
+        feat_of_block = {}
+        fi = 1
+        for i in range(nblk):
+            if (i + 1 == nblk) or (self.blocks[i + 1].stride == 2):
+                feat_of_block[i] = fi
+                fi += 1
+        dnext = None       # gradient wrt this block's output coming from the next block (same layer)
+        for i in range(nblk - 1, -1, -1):
+            blk, B = self.blocks[i], S["blocks"][i]
+            h, w, hin, win = B["h"], B["w"], B["hin"], B["win"]
+            C, Cin = blk.Cout, blk.Cin
+            M = N * h * w
+            dout = dF[feat_of_block[i]] if i in feat_of_block else dnext
+            dz2 = buf("g.dz2", (N, h, w, C))
+            g = buf("g.g", (N, h, w, C))
+            ops.bn_bwd(dout.view(M, C), B["out"].view(M, C), B["z2"].view(M, C), blk.bn2.mean, blk.bn2.invstd, blk.bn2.bn.weight.data,
+                       dz2.view(M, C), blk.bn2.gg, blk.bn2.gb, g_out=g.view(M, C), accumulate=accumulate)
+            self._wgrad(blk.c2, L.GATHER_FWD_ZERO, B["a1"], None, dz2, N, h, w, h, w, C, 0, accumulate)
+            da1 = buf("g.da1", (N, h, w, C))
+            ops.conv_igemm(ops.make_desc(N, h, w, h, w, C, 0, C, 3, 1, 1, L.GATHER_DGRAD_ZERO), dz2, None, blk.c2.wpd, da1)
+            dz1 = buf("g.dz1", (N, h, w, C))
+            ops.bn_bwd(da1.view(M, C), B["a1"].view(M, C), B["z1"].view(M, C), blk.bn1.mean, blk.bn1.invstd, blk.bn1.bn.weight.data,
+                       dz1.view(M, C), blk.bn1.gg, blk.bn1.gb, accumulate=accumulate)
+            self._wgrad(blk.c1, L.GATHER_FWD_ZERO, B["x"], None, dz1, N, h, w, hin, win, Cin, 0, accumulate)
+            first_of_layer = (i == 0) or blk.stride == 2
+            dgd = ops.make_desc(N, hin, win, h, w, C, 0, Cin, 3, blk.stride, 1, L.GATHER_DGRAD_ZERO)
+            if blk.ds is not None:
+                dzd = buf("g.dzd", (N, h, w, C))
+                ops.bn_bwd(g.view(M, C), None, B["zd"].view(M, C), blk.bnd.mean, blk.bnd.invstd, blk.bnd.bn.weight.data,
+                           dzd.view(M, C), blk.bnd.gg, blk.bnd.gb, accumulate=accumulate)
+                self._wgrad(blk.ds, L.GATHER_FWD_ZERO, B["x"], None, dzd, N, h, w, hin, win, Cin, 0, accumulate)
+                tgt = dF[feat_of_block[i - 1]]          # block input is the previous layer's feature (already holds decoder grads)
+                dgd.epi = L.EPI_ACCUM
+                ops.conv_igemm(dgd, dz1, None, blk.c1.wpd, tgt)
+                d1 = ops.make_desc(N, hin, win, h, w, C, 0, Cin, 1, blk.stride, 0, L.GATHER_DGRAD_ZERO, epi=L.EPI_ACCUM)
+                ops.conv_igemm(d1, dzd, None, blk.ds.wpd, tgt)
+                dnext = None
+            elif first_of_layer:                        # layer1 block 0: input is the max-pool output
+                dpool = buf("g.dpool", (N, hin, win, Cin))
+                ops.conv_igemm(dgd, dz1, None, blk.c1.wpd, dpool, addend=g)
+                ops.maxpool_bwd(dpool, self._bufs["pool.argmax"][:dpool.numel()].view(dpool.shape), dF[0], accumulate=True)
+                dnext = None
+            else:
+                dx = buf("g.dx%d" % (i & 1), (N, hin, win, Cin))
+                ops.conv_igemm(dgd, dz1, None, blk.c1.wpd, dx, addend=g)
+                dnext = dx
+            if first_of_layer and on_stage is not None:
+                on_stage("encoder.layer%d" % (feat_of_block[min(k for k in feat_of_block if k >= i)]))
+        # ---- stem ---------------------------------------------------------------------------------------
+        h0, w0 = dims[0]
+        M0 = N * h0 * w0
+        z0 = self._bufs["z0"][:M0 * 64].view(M0, 64)
+        dz0 = buf("g.dz0", (N, h0, w0, 64))
+        ops.bn_bwd(dF[0].view(M0, 64), feats[0].view(M0, 64), z0, self.bn0.mean, self.bn0.invstd, self.bn0.bn.weight.data,
+                   dz0.view(M0, 64), self.bn0.gg, self.bn0.gb, accumulate=accumulate)
+        d = ops.make_desc(N, h0, w0, S["H"], S["W"], 3, 0, 64, 7, 2, 3, L.GATHER_STEM)
+        ops.conv_wgrad(d, S["image"], None, dz0, self.stem.gw, accumulate=accumulate)
+        if on_stage is not None:
+            on_stage("encoder.layer0")
+
+    def _decoder_backward(self, dec, D, S, gouts, dF, first, acc):
+        N, feats, dims = S["N"], S["feats"], S["dims"]
+        buf = self.buf
+        H, W = S["H"], S["W"]
+        accum_feat = not first                      # the second decoder accumulates into the feature gradients
+        # ---- full-resolution tail: head4 <- o42 <- o41 <- up2(x4) ------------------------------------
+        x4 = D["x"][3]
+        h0, w0 = dims[0]
+        dzl = buf("g.dzl", (N, H, W, 2))
+        ops.head_upsample_bwd(gouts[3], D["low"][3], dzl, 1, dec.c0, dec.sig)
+        hd = dec.heads[3]
+        ops.head_wgrad(D["x5"], dzl, hd.gw, hd.gb, accumulate=acc)
+        A = buf("g.A", (N, H, W, 32))
+        ops.head_dgrad(dzl, hd.w.data, A, elu_src=D["x5"])
+        self._wgrad(dec.o42, L.GATHER_FWD_REFLECT, D["y51"], None, A, N, H, W, H, W, 32, 0, acc)
+        Bz = self._dgrad_dec(dec.o42, A, N, H, W, buf("g.B", (N, H, W, 32)), actsrc=D["y51"])
+        self._wgrad(dec.o41, L.GATHER_FWD_REFLECT_UP2, x4, None, Bz, N, H, W, H, W, 64, 0, acc)
+        XV = self._dgrad_dec(dec.o41, Bz, N, H, W, buf("g.XV", (N, H, W, 64)))
+        # head3 on x4
+        dzl = buf("g.dzl", (N, h0, w0, 2))
+        ops.head_upsample_bwd(gouts[2], D["low"][2], dzl, 2, dec.c0, dec.sig)
+        hd = dec.heads[2]
+        ops.head_wgrad(x4, dzl, hd.gw, hd.gb, accumulate=acc)
+        XH = buf("g.XH", (N, h0, w0, 64))
+        ops.head_dgrad(dzl, hd.w.data, XH)
+        A = buf("g.A", (N, h0, w0, 64))
+        ops.up2cat_bwd(XV, N, h0, w0, 64, 0, A, addend=XH, ylow=x4)
+        # ---- blocks 4..1 ----------------------------------------------------------------------------------
+        chans = [(512, 256), (256, 128), (128, 64), (64, 64)]
+        for bi in (3, 2, 1, 0):
+            blk = dec.blocks[bi]
+            cin, cout = chans[bi]
+            y1, y2, y3 = D["y"][bi]
+            hh, ww = dims[3 - bi]                   # resolution of the post-concat convs
+            hl, wl = hh // 2, ww // 2               # resolution of the pre-concat convs
+            skip = feats[3 - bi]
+            xin = D["x"][bi - 1] if bi > 0 else feats[4]
+            # A = dZ of post2 at (hh, ww)
+            self._wgrad(blk["post2"], L.GATHER_FWD_REFLECT, y3, None, A, N, hh, ww, hh, ww, cout, 0, acc)
+            Bz = self._dgrad_dec(blk["post2"], A, N, hh, ww, buf("g.B", (N, hh, ww, cout)), actsrc=y3)
+            self._wgrad(blk["post1"], L.GATHER_FWD_REFLECT_UP2, y2, skip, Bz, N, hh, ww, hh, ww, cout, cout, acc)
+            XV = self._dgrad_dec(blk["post1"], Bz, N, hh, ww, buf("g.XV", (N, hh, ww, 2 * cout)))
+            A = buf("g.A", (N, hl, wl, cout))
+            ops.up2cat_bwd(XV, N, hl, wl, cout, cout, A, ylow=y2, dskip=dF[3 - bi], accumulate_skip=accum_feat)
+            self._wgrad(blk["pre2"], L.GATHER_FWD_REFLECT, y1, None, A, N, hl, wl, hl, wl, cout, 0, acc)
+            Bz = self._dgrad_dec(blk["pre2"], A, N, hl, wl, buf("g.B", (N, hl, wl, cout)), actsrc=y1)
+            self._wgrad(blk["pre1"], L.GATHER_FWD_REFLECT, xin, None, Bz, N, hl, wl, hl, wl, cin, 0, acc)
+            if bi == 0:
+                self._dgrad_dec(blk["pre1"], Bz, N, hl, wl, dF[4], accum=accum_feat)
+            else:
+                XH = None
+                if bi >= 2:                          # heads on block2 / block3 outputs (x2: scale 8, x3: scale 4)
+                    k = bi - 2
+                    dzl = buf("g.dzl", (N, hl, wl, 2))
+                    ops.head_upsample_bwd(gouts[k], D["low"][k], dzl, (8, 4)[k], dec.c0, dec.sig)
+                    hd = dec.heads[k]
+                    ops.head_wgrad(xin, dzl, hd.gw, hd.gb, accumulate=acc)
+                    XH = buf("g.XH", (N, hl, wl, cin))
+                    ops.head_dgrad(dzl, hd.w.data, XH)
+                A = self._dgrad_dec(blk["pre1"], Bz, N, hl, wl, buf("g.A2", (N, hl, wl, cin)), actsrc=xin, addend=XH)
+
+    # ------------------------------------------------------------------------------------------------
+    def bind_grads(self, accumulate_existing=True):
+        """Point every live parameter's .grad at its view of the flat gradient buffer."""
+        for p, v in zip(self.live_params, self.grad_views):
+            p.grad = v
+
+
+class NetFunction(torch.autograd.Function):
+    """One autograd node for the whole network (drop-in `loss.backward()` support)."""
+
+    @staticmethod
+    def forward(ctx, eng, image, *params):
+        ctx.eng = eng
+        outs = eng.forward(image, training=eng.model.training, save_for_backward=True)
+        ctx.token = eng.saved
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        eng = ctx.eng
+        if eng.saved is not ctx.token:
+            raise RuntimeError("footprints_amd: activations of this forward were overwritten by a later forward; "
+                               "call backward before the next forward (the arena is reused every step)")
+        grads = []
+        shape = gouts[0].shape if gouts[0] is not None else None
+        for g in gouts:
+            if g is None:
+                g = torch.zeros(shape, device=eng.device)
+            grads.append(g.contiguous())
+        aliased = all(p.grad is not None and p.grad.data_ptr() == v.data_ptr() for p, v in zip(eng.live_params, eng.grad_views))
+        stale = [p.grad for p in eng.live_params] if not aliased else None
+        eng.backward(grads, accumulate=aliased)
+        # gradients live in the flat buffer; hand them to the parameters without a copy
+        for i, (p, v) in enumerate(zip(eng.live_params, eng.grad_views)):
+            if stale is not None and stale[i] is not None:
+                v.add_(stale[i])          # rare path: user accumulated into foreign .grad tensors
+            p.grad = v
+        return (None, None) + tuple(None for _ in eng.live_params)

@@ -1,0 +1,152 @@
+"""FootprintNetwork -- drop-in nn.Module surface of the reference model (footprints/network.py:13-183),
+executed by hand-written HIP kernels (footprints_amd/engine.py).
+
+The module tree exists to own parameters/buffers under the reference's exact ``state_dict`` keys and OIHW
+shapes, so released checkpoints load unchanged.  No sub-module's ``forward`` is ever
+used for compute: ``FootprintNetwork.forward`` hands the image to the HIP engine.  There is no CPU compute
+path in the product (the CPU restatement lives in ``oracle/`` for tests only) -- a non-CUDA input raises.
+"""
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+
+class _NoForward(nn.Module):
+    def forward(self, *a, **k):
+        raise RuntimeError("footprints_amd: sub-modules are parameter containers; call FootprintNetwork.forward")
+
+
+class _BasicBlock(_NoForward):
+    """Parameter container of a torchvision BasicBlock (keys conv1,bn1,conv2,bn2,downsample.{0,1})."""
+
+    def __init__(self, cin, cout, stride):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, cout, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(cout)
+        self.conv2 = nn.Conv2d(cout, cout, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(cout)
+        self.stride = stride
+        self.downsample = None
+        if stride != 1 or cin != cout:
+            self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
+
+
+def _make_layer(cin, cout, n, stride):
+    blocks = [_BasicBlock(cin, cout, stride)] + [_BasicBlock(cout, cout, 1) for _ in range(n - 1)]
+    return nn.Sequential(*blocks)
+
+
+class ResnetEncoder(_NoForward):
+    """Reference network.py:33-59: ResNet-34 re-wrapped as layer0..layer4 (keys 'layer0.0', 'layer1.1.<b>', ...)."""
+
+    def __init__(self, pretrained=True):
+        super().__init__()
+        # pretrained=True in the reference downloads ImageNet weights (network.py:38); there is no network here and
+        # every caller overwrites them via load_state_dict anyway -> degrade to random init.
+        self.layer0 = nn.Sequential(nn.Conv2d(3, 64, 7, 2, 3, bias=False), nn.BatchNorm2d(64), nn.ReLU(inplace=True))
+        self.layer1 = nn.Sequential(nn.MaxPool2d(3, 2, 1), _make_layer(64, 64, 3, 1))
+        self.layer2 = _make_layer(64, 128, 4, 2)
+        self.layer3 = _make_layer(128, 256, 6, 2)
+        self.layer4 = _make_layer(256, 512, 3, 2)
+
+    def blocks(self):
+        """The 16 BasicBlocks in forward order, with their state_dict prefixes."""
+        out = [("encoder.layer1.1.%d" % i, b) for i, b in enumerate(self.layer1[1])]
+        for li in (2, 3, 4):
+            out += [("encoder.layer%d.%d" % (li, i), b) for i, b in enumerate(getattr(self, "layer%d" % li))]
+        return out
+
+
+class ConvBlock(_NoForward):
+    """Reference network.py:104-138 (use_bn=False: bn1/bn2 are dead parameters kept for state_dict parity)."""
+
+    def __init__(self, in_ch, out_ch, use_elu=True, use_bn=False):
+        super().__init__()
+        assert use_elu and not use_bn, "the Footprints decoders use ELU without BN (network.py:69-72)"
+        self.conv1 = nn.Conv2d(in_ch, out_ch, 3)
+        self.bn1 = nn.BatchNorm2d(out_ch)
+        self.conv2 = nn.Conv2d(out_ch, out_ch, 3)
+        self.bn2 = nn.BatchNorm2d(out_ch)
+
+
+class ConvUpsampleAndConcatBlock(_NoForward):
+    """Reference network.py:141-158."""
+
+    def __init__(self, in_ch, out_ch, use_elu=True, use_bn=False):
+        super().__init__()
+        self.pre_concat_conv = ConvBlock(in_ch, out_ch, use_elu, use_bn)
+        self.post_concat_conv = ConvBlock(out_ch * 2, out_ch, use_elu, use_bn)
+
+
+class OutConvBlock(_NoForward):
+    """Reference network.py:161-183."""
+
+    def __init__(self, in_ch, out_ch, scale, apply_sigmoid=True):
+        super().__init__()
+        assert out_ch == 2
+        self.apply_sigmoid = apply_sigmoid
+        self.scale = scale
+        self.conv1 = nn.Conv2d(in_ch, out_ch, 3)
+
+
+class SkipDecoder(_NoForward):
+    """Reference network.py:62-101."""
+
+    def __init__(self, apply_sigmoid=True):
+        super().__init__()
+        self.apply_sigmoid = apply_sigmoid
+        self.block1 = ConvUpsampleAndConcatBlock(512, 256)
+        self.block2 = ConvUpsampleAndConcatBlock(256, 128)
+        self.block3 = ConvUpsampleAndConcatBlock(128, 64)
+        self.block4 = ConvUpsampleAndConcatBlock(64, 64)
+        self.outconv1 = OutConvBlock(128, 2, 8, apply_sigmoid)
+        self.outconv2 = OutConvBlock(64, 2, 4, apply_sigmoid)
+        self.outconv3 = OutConvBlock(64, 2, 2, apply_sigmoid)
+        self.outconv4 = nn.Sequential(ConvBlock(64, 32), OutConvBlock(32, 2, 1, apply_sigmoid))
+
+
+def is_dead_param(name):
+    """Decoder bn1/bn2 affine params are never used (network.py:128,134): grad stays None, Adam never sees them."""
+    return "decoder" in name and (".bn1." in name or ".bn2." in name)
+
+
+class FootprintNetwork(nn.Module):
+    """forward(x: float32 [B,3,H,W] in [0,1], H,W % 32 == 0) -> {'1/8','1/4','1/2','1/1': [B,4,H,W]} (network.py:21-30).
+
+    Channels: 0 visible-ground logit, 1 all-ground logit, 2 depth sigmoid-disparity, 3 ground-depth
+    sigmoid-disparity.  Outputs participate in autograd (one Function for the whole net, backward = the HIP
+    backward schedule).
+    """
+
+    def __init__(self, pretrained=True):
+        super().__init__()
+        self.encoder = ResnetEncoder(pretrained=pretrained)
+        self.mask_decoder = SkipDecoder(apply_sigmoid=False)   # logits, for BCE stability (network.py:18)
+        self.depth_decoder = SkipDecoder(apply_sigmoid=True)
+        self._engine = None
+
+    # -- engine plumbing ---------------------------------------------------------------------------------
+    def engine(self):
+        from .engine import Engine
+        dev = next(self.parameters()).device
+        if self._engine is None or self._engine.device != dev:
+            self._engine = Engine(self)
+        return self._engine
+
+    def live_named_parameters(self):
+        return [(n, p) for n, p in self.named_parameters() if not is_dead_param(n)]
+
+    def forward(self, input_image):
+        if not input_image.is_cuda:
+            raise RuntimeError(
+                "footprints_amd.FootprintNetwork has no CPU compute path: move the model and the input to a "
+                "MI355X (`.cuda()`). The CPU restatement under oracle/ is test infrastructure only.")
+        eng = self.engine()
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if need_grad:
+            from .engine import NetFunction
+            outs = NetFunction.apply(eng, input_image, *eng.live_params)
+        else:
+            outs = eng.forward(input_image, training=self.training, save_for_backward=False)
+        return OrderedDict(zip(("1/8", "1/4", "1/2", "1/1"), outs))

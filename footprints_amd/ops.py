@@ -1,0 +1,219 @@
+"""Tensor-level wrappers over the C ABI (include/footprints_hip.h).
+
+Every function takes contiguous float32 CUDA tensors, launches on torch's
+current stream and returns immediately (async).  PyTorch only owns memory and
+streams here; there is no torch compute op and no fallback in this module.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc
+
+_workspaces = {}
+
+
+def _chk(t, name="tensor"):
+    if t is None:
+        return 0
+    if not (t.is_cuda and t.is_contiguous()):
+        raise RuntimeError("footprints_amd.ops: %s must be a contiguous CUDA tensor (no CPU path in the product)" % name)
+    return t.data_ptr()
+
+
+def _f32(t, name="tensor"):
+    if t is not None and t.dtype != torch.float32:
+        raise RuntimeError("footprints_amd.ops: %s must be float32" % name)
+    return _chk(t, name)
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def workspace(nbytes, device):
+    """Grow-only scratch buffer per device; safe because all kernels of a step are stream-ordered."""
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def make_desc(N, OH, OW, IH, IW, C0, C1, Nout, K, stride, pad, gather, act=0, epi=0):
+    return ConvDesc(N, OH, OW, IH, IW, C0, C1, Nout, K, K, stride, pad, gather, act, epi)
+
+
+def conv_igemm(desc, src0, src1, wpacked, y, bias=None, addend=None, addend_mask=None, actsrc=None):
+    lib = _lib.load()
+    epi = desc.epi
+    if bias is not None:
+        epi |= _lib.EPI_BIAS
+    if addend is not None:
+        epi |= _lib.EPI_ADDEND
+    if addend_mask is not None:
+        epi |= _lib.EPI_ADDEND_MASK
+    d = ConvDesc.from_buffer_copy(desc)
+    d.epi = epi
+    _lib.check(lib.fp_conv_igemm(C.byref(d), _f32(src0, "src0"), _f32(src1, "src1"), _f32(wpacked, "wpacked"), _f32(bias),
+                                 _f32(addend), _f32(addend_mask), _f32(actsrc), _f32(y, "y"), stream()), "fp_conv_igemm")
+    return y
+
+
+def conv_wgrad(desc, src0, src1, dz, dw, accumulate=False):
+    lib = _lib.load()
+    need = lib.fp_conv_wgrad_workspace(C.byref(desc))
+    ws = workspace(need, dz.device)
+    _lib.check(lib.fp_conv_wgrad(C.byref(desc), _f32(src0), _f32(src1), _f32(dz), _f32(dw), int(bool(accumulate)),
+                                 ws.data_ptr(), ws.numel(), stream()), "fp_conv_wgrad")
+    return dw
+
+
+def packed_weight_elems(Cout, Cin, K, for_dgrad=False, stem=False):
+    return int(_lib.load().fp_packed_weight_elems(Cout, Cin, K, K, int(for_dgrad), int(stem)))
+
+
+def pack_conv_weight(w, wp, stem=False):
+    Cout, Cin, KH, KW = w.shape
+    _lib.check(_lib.load().fp_pack_conv_weight(_f32(w), _f32(wp), Cout, Cin, KH, KW, int(stem), stream()), "fp_pack_conv_weight")
+    return wp
+
+
+def pack_conv_weight_dgrad(w, wp):
+    Cout, Cin, KH, KW = w.shape
+    _lib.check(_lib.load().fp_pack_conv_weight_dgrad(_f32(w), _f32(wp), Cout, Cin, KH, KW, stream()), "fp_pack_conv_weight_dgrad")
+    return wp
+
+
+def colsum(x2d, out, accumulate=False):
+    lib = _lib.load()
+    M, Cn = x2d.shape
+    ws = workspace(lib.fp_colsum_workspace(M, Cn), x2d.device)
+    _lib.check(lib.fp_colsum(_f32(x2d), M, Cn, _f32(out), int(bool(accumulate)), ws.data_ptr(), ws.numel(), stream()), "fp_colsum")
+    return out
+
+
+def up2cat_bwd(dxv, N, h, w, C0, C1, dlow, addend=None, ylow=None, dskip=None, accumulate_skip=False):
+    _lib.check(_lib.load().fp_up2cat_bwd(_f32(dxv), N, h, w, C0, C1, _f32(addend), _f32(ylow), _f32(dlow), _f32(dskip),
+                                         int(bool(accumulate_skip)), stream()), "fp_up2cat_bwd")
+    return dlow
+
+
+def head_fwd(x, w, b, low, sigmoid):
+    N, h, wd, Cin = x.shape
+    _lib.check(_lib.load().fp_head_fwd(_f32(x), _f32(w), _f32(b), _f32(low), N, h, wd, Cin, int(bool(sigmoid)), stream()), "fp_head_fwd")
+    return low
+
+
+def head_upsample(low, out_nchw, scale, c0):
+    N, h, w, _ = low.shape
+    _lib.check(_lib.load().fp_head_upsample(_f32(low), _f32(out_nchw), N, h, w, scale, out_nchw.shape[1], c0, stream()), "fp_head_upsample")
+    return out_nchw
+
+
+def head_upsample_bwd(dout_nchw, low, dzlow, scale, c0, sigmoid):
+    N, h, w, _ = dzlow.shape
+    _lib.check(_lib.load().fp_head_upsample_bwd(_f32(dout_nchw), _f32(low), _f32(dzlow), N, h, w, scale, dout_nchw.shape[1], c0,
+                                                int(bool(sigmoid)), stream()), "fp_head_upsample_bwd")
+    return dzlow
+
+
+def head_dgrad(dzlow, w, dx, elu_src=None):
+    N, h, wd, Cin = dx.shape
+    _lib.check(_lib.load().fp_head_dgrad(_f32(dzlow), _f32(w), _f32(elu_src), _f32(dx), N, h, wd, Cin, stream()), "fp_head_dgrad")
+    return dx
+
+
+def head_wgrad(x, dzlow, dw, db, accumulate=False):
+    lib = _lib.load()
+    N, h, wd, Cin = x.shape
+    ws = workspace(lib.fp_head_wgrad_workspace(N, h, wd, Cin), x.device)
+    _lib.check(lib.fp_head_wgrad(_f32(x), _f32(dzlow), _f32(dw), _f32(db), N, h, wd, Cin, int(bool(accumulate)), ws.data_ptr(),
+                                 ws.numel(), stream()), "fp_head_wgrad")
+
+
+def bn_train_stats(z2d, gamma, beta, running_mean, running_var, nbt, save_mean, save_invstd, scale, shift, eps=1e-5, momentum=0.1):
+    lib = _lib.load()
+    M, Cn = z2d.shape
+    ws = workspace(lib.fp_bn_workspace(M, Cn), z2d.device)
+    if nbt is not None and nbt.dtype != torch.int64:
+        raise RuntimeError("num_batches_tracked must be int64")
+    _lib.check(lib.fp_bn_train_stats(_f32(z2d), M, Cn, _f32(gamma), _f32(beta), eps, momentum, _f32(running_mean), _f32(running_var),
+                                     _chk(nbt), _f32(save_mean), _f32(save_invstd), _f32(scale), _f32(shift), ws.data_ptr(),
+                                     ws.numel(), stream()), "fp_bn_train_stats")
+
+
+def bn_eval_coeffs(gamma, beta, rm, rv, scale, shift, eps=1e-5):
+    _lib.check(_lib.load().fp_bn_eval_coeffs(_f32(gamma), _f32(beta), _f32(rm), _f32(rv), eps, gamma.numel(), _f32(scale), _f32(shift),
+                                             stream()), "fp_bn_eval_coeffs")
+
+
+def bn_apply(z2d, scale, shift, y2d, residual=None, relu=True):
+    M, Cn = z2d.shape
+    _lib.check(_lib.load().fp_bn_apply(_f32(z2d), _f32(scale), _f32(shift), _f32(residual), _f32(y2d), M, Cn, int(bool(relu)), stream()),
+               "fp_bn_apply")
+    return y2d
+
+
+def bn_bwd(dy2d, relu_out, z2d, save_mean, save_invstd, gamma, dz2d, dgamma, dbeta, g_out=None, accumulate=False):
+    lib = _lib.load()
+    M, Cn = z2d.shape
+    ws = workspace(lib.fp_bn_workspace(M, Cn), z2d.device)
+    _lib.check(lib.fp_bn_bwd(_f32(dy2d), _f32(relu_out), _f32(z2d), _f32(save_mean), _f32(save_invstd), _f32(gamma), _f32(dz2d),
+                             _f32(g_out), _f32(dgamma), _f32(dbeta), int(bool(accumulate)), M, Cn, ws.data_ptr(), ws.numel(), stream()),
+               "fp_bn_bwd")
+    return dz2d
+
+
+def maxpool_fwd(x, y, argmax):
+    N, H, W, Cn = x.shape
+    _lib.check(_lib.load().fp_maxpool_fwd(_f32(x), _f32(y), _chk(argmax), N, H, W, Cn, stream()), "fp_maxpool_fwd")
+    return y
+
+
+def maxpool_bwd(dy, argmax, dx, accumulate=False):
+    N, H, W, Cn = dx.shape
+    _lib.check(_lib.load().fp_maxpool_bwd(_f32(dy), _chk(argmax), _f32(dx), N, H, W, Cn, int(bool(accumulate)), stream()), "fp_maxpool_bwd")
+    return dx
+
+
+def loss_fwd_bwd(preds, targets, losses_out, dpreds=None, depth_range=(0.1, 100.0), prior=0.25):
+    """preds: 4 tensors [B,4,H,W] in order '1/8','1/4','1/2','1/1'; targets: dict with the reference batch keys."""
+    lib = _lib.load()
+    B, _, H, W = preds[0].shape
+    ws = workspace(lib.fp_loss_workspace(B, H, W), preds[0].device)
+    P = (C.c_void_p * 4)(*[_f32(p, "pred") for p in preds])
+    D = (C.c_void_p * 4)(*[_f32(p, "dpred") for p in dpreds]) if dpreds is not None else None
+    _lib.check(lib.fp_loss_fwd_bwd(P, _f32(targets["visible_ground"]), _f32(targets["all_ground"]), _f32(targets["depth"]),
+                                   _f32(targets["ground_depth"]), _f32(targets["moving_object_mask"]), _f32(targets["depth_mask"]),
+                                   float(depth_range[0]), float(depth_range[1]), float(prior), D, _f32(losses_out), B, H, W,
+                                   ws.data_ptr(), ws.numel(), stream()), "fp_loss_fwd_bwd")
+    return losses_out
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, grad_scale=1.0):
+    _lib.check(_lib.load().fp_adam_step(_f32(param), _f32(grad), _f32(exp_avg), _f32(exp_avg_sq), param.numel(), lr, beta1, beta2, eps,
+                                        int(step), grad_scale, stream()), "fp_adam_step")
+
+
+def nchw_to_nhwc(x, y=None):
+    N, Cn, H, W = x.shape
+    if y is None:
+        y = torch.empty((N, H, W, Cn), dtype=x.dtype, device=x.device)
+    _lib.check(_lib.load().fp_nchw_to_nhwc(_f32(x), _f32(y), N, Cn, H, W, stream()), "fp_nchw_to_nhwc")
+    return y
+
+
+def nhwc_to_nchw(x, y=None):
+    N, H, W, Cn = x.shape
+    if y is None:
+        y = torch.empty((N, Cn, H, W), dtype=x.dtype, device=x.device)
+    _lib.check(_lib.load().fp_nhwc_to_nchw(_f32(x), _f32(y), N, Cn, H, W, stream()), "fp_nhwc_to_nchw")
+    return y
+
+
+def fill(x, value):
+    _lib.check(_lib.load().fp_fill(_f32(x), x.numel(), float(value), stream()), "fp_fill")
+    return x

@@ -1,0 +1,103 @@
+"""Data-parallel gradient exchange: one process per GPU, RCCL all-reduce over xGMI, overlapped with backward.
+
+The reference is single-GPU; this is the new N-GPU path of BASELINE.json's north_star.
+Semantics: every rank runs the same step on its own per-GPU batch with per-replica
+BatchNorm statistics; the live gradients (31 012 944 fp32 = 124 MB, one flat buffer) are SUMMED across ranks
+and the 1/world factor is folded into the fused Adam update (grad_scale), so all ranks hold bit-identical
+weights after every step.  The flat gradient buffer is cut into contiguous buckets in the order backward
+produces them (mask decoder, depth decoder, encoder layer4 .. layer0); each bucket's all-reduce is issued on a
+side stream as soon as the engine reports it ready, so communication hides under the remaining backward.
+`torch.distributed` (backend "nccl" == RCCL on ROCm; "gloo" in the CPU tests) is plumbing only.
+"""
+import torch
+import torch.distributed as dist
+
+
+def bucket_ranges(names, offsets, total, max_elems=8 << 20):
+    """Contiguous [lo, hi) ranges of the flat buffer, grouped by top-level stage, listed in backward order.
+
+    Stages in forward/flat order: encoder.layer0..4, mask_decoder, depth_decoder.  Large stages are further cut
+    into <= max_elems pieces so the first all-reduce can start early and ring steps stay pipelined.
+    """
+    def stage(n):
+        parts = n.split(".")
+        return parts[0] + "." + parts[1] if parts[0] == "encoder" else parts[0]
+
+    stages = []
+    for n, o in zip(names, offsets):
+        s = stage(n)
+        if not stages or stages[-1][0] != s:
+            stages.append([s, o, o])
+    for i, st in enumerate(stages):
+        st[2] = stages[i + 1][1] if i + 1 < len(stages) else total
+    by_name = {s: (lo, hi) for s, lo, hi in stages}
+    order = ["mask_decoder", "depth_decoder", "encoder.layer4", "encoder.layer3", "encoder.layer2", "encoder.layer1", "encoder.layer0"]
+    out = []
+    for s in order:
+        lo, hi = by_name[s]
+        # backward produces a stage's gradients from its END towards its start -> emit pieces high to low
+        pieces = []
+        p = hi
+        while p > lo:
+            q = max(lo, p - max_elems)
+            pieces.append((s, q, p))
+            p = q
+        out.extend(pieces)
+    return out
+
+
+class GradReducer:
+    """Bucketed, stream-overlapped all-reduce of a flat gradient buffer."""
+
+    def __init__(self, flat_grad, names, offsets, group=None, max_elems=8 << 20):
+        self.flat = flat_grad
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.buckets = bucket_ranges(names, offsets, flat_grad.numel(), max_elems)
+        self.cuda = flat_grad.is_cuda
+        self.stream = torch.cuda.Stream() if self.cuda else None
+        self._pending = []
+        self._done_stage = set()
+
+    @property
+    def grad_scale(self):
+        return 1.0 / self.world
+
+    def stage_ready(self, stage):
+        """Called by the backward schedule when every gradient of `stage` has been written."""
+        if self.world == 1 or stage in self._done_stage:
+            return
+        self._done_stage.add(stage)
+        if self.cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self.stream.wait_event(ev)
+            with torch.cuda.stream(self.stream):
+                for s, lo, hi in self.buckets:
+                    if s == stage:
+                        self._pending.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            for s, lo, hi in self.buckets:
+                if s == stage:
+                    dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
+
+    def finish(self):
+        """Make the compute stream wait for every outstanding bucket (call before the optimiser step)."""
+        if self.world > 1:
+            for s in ("mask_decoder", "depth_decoder", "encoder.layer4", "encoder.layer3", "encoder.layer2", "encoder.layer1",
+                      "encoder.layer0"):
+                self.stage_ready(s)          # anything the schedule did not report explicitly
+            for w in self._pending:
+                w.wait()
+            if self.cuda:
+                torch.cuda.current_stream().wait_stream(self.stream)
+        self._pending = []
+        self._done_stage = set()
+
+
+def broadcast_state(model, src=0, group=None):
+    """Initial weight/buffer sync so every replica starts identical (rank `src` wins)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    for t in list(model.parameters()) + list(model.buffers()):
+        dist.broadcast(t.data, src=src, group=group)

@@ -1,0 +1,175 @@
+/*
+ * footprints_hip.h -- flat C ABI of libfootprints_hip.so (gfx950 / MI355X).
+ *
+ * The reference (nianticlabs/footprints) has no FFI: its hot path is implicit
+ * ATen/cuDNN ops behind nn.Modules.  Each entry point below replaces the ATen op
+ * family named in its comment (reference file:line = where the op is issued).
+ * Conventions:
+ *   - raw device pointers (tensor.data_ptr()), explicit int32 dims, fp32 only;
+ *   - activations NHWC [N][H][W][C]; network input image and the four network
+ *     outputs NCHW (the reference's layout at the nn.Module boundary);
+ *   - the caller (PyTorch) owns every buffer, workspace included; the library
+ *     never allocates or frees device memory and keeps no pointer after return;
+ *   - every function returns 0 on success, else a negative FP_E* code or a
+ *     positive hipError_t; fp_last_error_string() describes the last failure of
+ *     the calling thread; nothing throws or aborts across the ABI;
+ *   - kernels are asynchronous on the hipStream_t passed as the last argument
+ *     (torch.cuda.current_stream().cuda_stream), so calls are graph-capturable.
+ */
+#ifndef FOOTPRINTS_HIP_H
+#define FOOTPRINTS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* fp_stream_t; /* hipStream_t */
+
+#define FP_OK 0
+#define FP_EINVAL (-1)     /* bad descriptor / unsupported shape */
+#define FP_EWORKSPACE (-2) /* workspace too small */
+
+/* ---- implicit-GEMM convolution family ---------------------------------- */
+
+/* how the GEMM A-operand (one row per output pixel, one K-slice per tap) is gathered */
+enum fp_gather {
+  FP_GATHER_FWD_ZERO = 0,        /* conv fwd, zero padding, any stride  (torchvision resnet convs; network.py:38-44) */
+  FP_GATHER_FWD_REFLECT = 1,     /* conv fwd, ReflectionPad2d(1), stride 1 (network.py:115,126,132) */
+  FP_GATHER_FWD_REFLECT_UP2 = 2, /* same, input = cat[nearest_x2(src0), src1] never materialised (network.py:154-155,98) */
+  FP_GATHER_DGRAD_ZERO = 3,      /* data-gradient of FWD_ZERO (gather form, stride parity skipped) */
+  FP_GATHER_DGRAD_REFLECT = 4,   /* data-gradient of FWD_REFLECT: halo gradients folded back onto rows/cols 1 and H-2 */
+  FP_GATHER_STEM = 5             /* 7x7/2 pad 3 on the NCHW image with (x-0.45)/0.225 folded into the load (network.py:50) */
+};
+
+enum fp_act { FP_ACT_NONE = 0, FP_ACT_ELU = 1, FP_ACT_RELU = 2 };
+
+/* epilogue: v = acc + bias[n] + addend[m][n]*(addend_mask>0) ; v *= actgrad(actsrc[m][n]) ; v = act(v) ; y = v (+ y) */
+#define FP_EPI_BIAS 1u
+#define FP_EPI_ADDEND 2u
+#define FP_EPI_ADDEND_MASK 4u  /* addend is multiplied by (addend_mask[m][n] > 0) */
+#define FP_EPI_ACTGRAD_ELU 8u  /* v *= (s > 0 ? 1 : s + 1), s = actsrc = saved ELU OUTPUT (nn.ELU(inplace=True), network.py:118) */
+#define FP_EPI_ACTGRAD_RELU 16u /* v *= (actsrc > 0) */
+#define FP_EPI_ACCUM 32u       /* y += v (second decoder / second consumer accumulating into the same gradient) */
+
+typedef struct fp_conv_desc {
+  int32_t N;          /* batch */
+  int32_t OH, OW;     /* spatial domain of the GEMM rows (fwd: conv output; dgrad: conv input) */
+  int32_t IH, IW;     /* spatial dims of the gathered tensor's virtual domain (fwd: conv input, hi-res for UP2; dgrad: dZ) */
+  int32_t C0, C1;     /* K channels per tap taken from src0 / src1 (C1 = 0 unless UP2 concat); multiples of 4 */
+  int32_t Nout;       /* GEMM N (fwd: Cout; dgrad: Cin) */
+  int32_t KH, KW, stride, pad;
+  int32_t gather;     /* enum fp_gather */
+  int32_t act;        /* enum fp_act */
+  uint32_t epi;       /* FP_EPI_* */
+} fp_conv_desc;
+
+/* Y[m][n] = epilogue( sum_{tap,k} A[m][tap,k] * Wp[tap][k][n] ).
+ * Wp is the packed weight produced by fp_pack_conv_weight (fwd) / fp_pack_conv_weight_dgrad.
+ * Replaces aten::convolution (+reflection_pad2d, upsample_nearest2d, cat, elu_) and the
+ * data-gradient half of aten::convolution_backward (+elu_backward, relu mask, residual add). */
+int fp_conv_igemm(const fp_conv_desc* d, const float* src0, const float* src1, const float* wpacked,
+                  const float* bias, const float* addend, const float* addend_mask, const float* actsrc,
+                  float* y, fp_stream_t stream);
+
+/* Weight gradient: dW (OIHW [Nout][C0+C1][KH][KW]) = sum_m A[m][tap,k] * dZ[m][n]; A gathered as the
+ * matching forward conv (desc.gather is a FWD_* / STEM mode, desc.OH/OW = conv output dims).
+ * Deterministic two-stage reduction through `workspace` (>= fp_conv_wgrad_workspace(d) bytes).
+ * accumulate != 0 => dW += result.  Replaces the weight half of aten::convolution_backward. */
+int64_t fp_conv_wgrad_workspace(const fp_conv_desc* d);
+int fp_conv_wgrad(const fp_conv_desc* d, const float* src0, const float* src1, const float* dz,
+                  float* dw_oihw, int accumulate, void* workspace, int64_t workspace_bytes, fp_stream_t stream);
+
+/* packed-weight sizes (floats) and packers; w_oihw is the torch Conv2d.weight [Cout][Cin][KH][KW] */
+int64_t fp_packed_weight_elems(int32_t Cout, int32_t Cin, int32_t KH, int32_t KW, int32_t for_dgrad, int32_t stem);
+int fp_pack_conv_weight(const float* w_oihw, float* wp, int32_t Cout, int32_t Cin, int32_t KH, int32_t KW,
+                        int32_t stem, fp_stream_t stream);
+int fp_pack_conv_weight_dgrad(const float* w_oihw, float* wp, int32_t Cout, int32_t Cin, int32_t KH, int32_t KW,
+                              fp_stream_t stream);
+
+/* column sums: out[c] (+)= sum_m x[m][c]  -- conv bias gradient (weight half of convolution_backward) */
+int64_t fp_colsum_workspace(int64_t M, int32_t C);
+int fp_colsum(const float* x, int64_t M, int32_t C, float* out, int accumulate, void* workspace,
+              int64_t workspace_bytes, fp_stream_t stream);
+
+/* backward of cat[nearest_x2(low), skip] feeding a conv: dxv is the conv's input gradient at hi-res
+ * [N][2h][2w][C0+C1]; dlow[N][h][w][C0] = (sum2x2(dxv[..:C0]) + addend) * elu'(ylow) ; dskip (+)= dxv[..C0:].
+ * Replaces upsample_nearest2d_backward + cat backward + elu_backward (network.py:154-155,98). */
+int fp_up2cat_bwd(const float* dxv, int32_t N, int32_t h, int32_t w, int32_t C0, int32_t C1,
+                  const float* addend, const float* ylow_elu, float* dlow, float* dskip, int accumulate_skip,
+                  fp_stream_t stream);
+
+/* ---- 2-channel output heads (OutConvBlock, network.py:161-183) --------- */
+/* low[N][h][w][2] = [sigmoid](reflect-pad 3x3 conv Cin->2 + bias); w_oihw [2][Cin][3][3] */
+int fp_head_fwd(const float* x, const float* w_oihw, const float* bias, float* low, int32_t N, int32_t h, int32_t w,
+                int32_t Cin, int32_t apply_sigmoid, fp_stream_t stream);
+/* out[N][out_channels][H][W] channels c0,c0+1 = bilinear_xS(low), align_corners=False (S=1: copy) */
+int fp_head_upsample(const float* low, float* out_nchw, int32_t N, int32_t h, int32_t w, int32_t scale,
+                     int32_t out_channels, int32_t c0, fp_stream_t stream);
+/* dzlow[N][h][w][2] = bilinear^T(dout[:, c0:c0+2]) [* s(1-s), s = low when apply_sigmoid] */
+int fp_head_upsample_bwd(const float* dout_nchw, const float* low, float* dzlow, int32_t N, int32_t h, int32_t w,
+                         int32_t scale, int32_t out_channels, int32_t c0, int32_t apply_sigmoid, fp_stream_t stream);
+/* dx[N][h][w][Cin] = conv^T(dzlow) with the reflection halo folded back (plain store);
+ * elu_src != NULL: dx *= elu'(elu_src) (the head is the only consumer of an ELU output: outconv4, network.py:78-80) */
+int fp_head_dgrad(const float* dzlow, const float* w_oihw, const float* elu_src, float* dx, int32_t N, int32_t h, int32_t w,
+                  int32_t Cin, fp_stream_t stream);
+/* dw_oihw[2][Cin][3][3], db[2] (+)= ... ; deterministic two-stage */
+int64_t fp_head_wgrad_workspace(int32_t N, int32_t h, int32_t w, int32_t Cin);
+int fp_head_wgrad(const float* x, const float* dzlow, float* dw_oihw, float* db, int32_t N, int32_t h, int32_t w,
+                  int32_t Cin, int accumulate, void* workspace, int64_t workspace_bytes, fp_stream_t stream);
+
+/* ---- BatchNorm (train-mode batch statistics; torchvision BN in the encoder) ---- */
+/* stats over z[M][C]: save_mean, save_invstd, fused scale = gamma*invstd, shift = beta - mean*scale;
+ * running stats updated in place with momentum (unbiased var), num_batches_tracked += 1 (int64).
+ * Replaces aten::native_batch_norm (training=True). workspace >= fp_bn_workspace(M, C). */
+int64_t fp_bn_workspace(int64_t M, int32_t C);
+int fp_bn_train_stats(const float* z, int64_t M, int32_t C, const float* gamma, const float* beta, float eps,
+                      float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                      float* save_mean, float* save_invstd, float* scale, float* shift, void* workspace,
+                      int64_t workspace_bytes, fp_stream_t stream);
+/* eval mode: scale/shift from running statistics */
+int fp_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                      float eps, int32_t C, float* scale, float* shift, fp_stream_t stream);
+/* y = [relu](z*scale + shift [+ residual]) */
+int fp_bn_apply(const float* z, const float* scale, const float* shift, const float* residual, float* y, int64_t M,
+                int32_t C, int32_t relu, fp_stream_t stream);
+/* backward: g = dy * (relu_out > 0 if relu_out) ; dgamma (+)= sum g*xhat ; dbeta (+)= sum g ;
+ * dz = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)) ; g_out (optional) = g. */
+int fp_bn_bwd(const float* dy, const float* relu_out, const float* z, const float* save_mean, const float* save_invstd,
+              const float* gamma, float* dz, float* g_out, float* dgamma, float* dbeta, int accumulate, int64_t M,
+              int32_t C, void* workspace, int64_t workspace_bytes, fp_stream_t stream);
+
+/* ---- maxpool 3x3 stride 2 pad 1 (encoder.maxpool, network.py:41) ---------- */
+int fp_maxpool_fwd(const float* x, float* y, uint8_t* argmax, int32_t N, int32_t H, int32_t W, int32_t C,
+                   fp_stream_t stream);
+int fp_maxpool_bwd(const float* dy, const uint8_t* argmax, float* dx, int32_t N, int32_t H, int32_t W, int32_t C,
+                   int accumulate, fp_stream_t stream);
+
+/* ---- fused multi-head loss, forward + backward (training/losses.py:31-152) ---- */
+/* preds[4]: '1/8','1/4','1/2','1/1' each [B][4][H][W]; targets [B][H][W];
+ * losses_out[21] in the order of LossManager's dict (5 per scale: visible_ground, all_ground, depth,
+ * ground_depth, loss; then total 'loss'); dpreds[4] = d(total loss)/d(pred) (may be NULL => forward only). */
+int64_t fp_loss_workspace(int32_t B, int32_t H, int32_t W);
+int fp_loss_fwd_bwd(const float* const preds[4], const float* visible_ground, const float* all_ground,
+                    const float* depth, const float* ground_depth, const float* moving_object_mask,
+                    const float* depth_mask, float min_depth, float max_depth, float prior_weight,
+                    float* const dpreds[4], float* losses_out, int32_t B, int32_t H, int32_t W, void* workspace,
+                    int64_t workspace_bytes, fp_stream_t stream);
+
+/* ---- fused Adam over a flat parameter buffer (torch.optim.Adam, model_manager.py:27) ---- */
+int fp_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                 float beta2, float eps, int32_t step, float grad_scale, fp_stream_t stream);
+
+/* ---- misc ---- */
+int fp_nchw_to_nhwc(const float* x, float* y, int32_t N, int32_t C, int32_t H, int32_t W, fp_stream_t stream);
+int fp_nhwc_to_nchw(const float* x, float* y, int32_t N, int32_t C, int32_t H, int32_t W, fp_stream_t stream);
+int fp_fill(float* x, int64_t n, float value, fp_stream_t stream);
+
+int fp_version(void);
+const char* fp_last_error_string(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FOOTPRINTS_HIP_H */

@@ -1,0 +1,77 @@
+"""CPU, world_size 2, gloo: the data-parallel gradient exchange (footprints_amd/parallel.py) against the
+N-shard oracle: rank-summed buckets x 1/world == mean of per-shard gradients with
+per-shard BatchNorm statistics, and both ranks end up with identical buffers."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _layout():
+    from footprints_amd import FootprintNetwork
+    m = FootprintNetwork(pretrained=False)
+    names, offs, total = [], [], 0
+    for n, p in m.live_named_parameters():
+        names.append(n)
+        offs.append(total)
+        total += (p.numel() + 3) // 4 * 4
+    return names, offs, total
+
+
+def _shard_grads(rank):
+    from oracle import restatement as R
+    torch.set_num_threads(2)
+    P, B = R.make_state(tag="dp")
+    tr = R.OracleTrainer(P, B)
+    tr.forward_backward(R.make_batch(1, 64, 64, tag="dp.shard%d" % rank))
+    return {k: p.grad for k, p in tr.P.items() if p.grad is not None}
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from footprints_amd.parallel import GradReducer
+    names, offs, total = _layout()
+    g = _shard_grads(rank)
+    flat = torch.zeros(total)
+    for n, o in zip(names, offs):
+        flat[o:o + g[n].numel()] = g[n].flatten()
+    red = GradReducer(flat, names, offs, max_elems=2 << 20)
+    assert red.world == 2 and abs(red.grad_scale - 0.5) < 1e-12
+    for stage in ("mask_decoder", "depth_decoder", "encoder.layer4", "encoder.layer3"):   # reported by the schedule
+        red.stage_ready(stage)
+    red.finish()                                                                           # flushes the rest
+    q.put((rank, (flat * red.grad_scale).clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_mean_matches_shard_oracle():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert torch.equal(res[0], res[1])                       # identical on every rank => identical weights after Adam
+    names, offs, total = _layout()
+    g0, g1 = _shard_grads(0), _shard_grads(1)
+    for n, o in zip(names, offs):
+        ref = 0.5 * (g0[n] + g1[n]).flatten()
+        got = res[0][o:o + ref.numel()]
+        assert torch.allclose(got, ref, rtol=1e-6, atol=1e-9), n

@@ -1,0 +1,413 @@
+"""GPU: every HIP kernel of libfootprints_hip.so, called through the C ABI, against a plain PyTorch fp32 CPU
+reference of the same op (the oracle's building blocks).  Tolerance 1e-4 relative to the tensor's max
+(north_star: "within 1e-4 rel fp32"); index/byte outputs (argmax, counters) bit-exact.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def _ops():
+    from footprints_amd import ops, _lib
+    return ops, _lib
+
+
+def rnd(shape, seed, lo=-1.0, hi=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand(shape, generator=g) * (hi - lo) + lo
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous().cpu()
+
+
+def relerr(got, ref):
+    ref = ref.double()
+    return ((got.double().cpu() - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
+
+
+def check(got, ref, what, tol=TOL):
+    e = relerr(got, ref)
+    assert e <= tol, "%s: rel-to-max error %.3e > %.1e" % (what, e, tol)
+    return e
+
+
+def pack(w, dgrad=False, stem=False):
+    ops, _ = _ops()
+    Cout, Cin, K, _k = w.shape
+    n = ops.packed_weight_elems(Cout, Cin, K, dgrad, stem)
+    wp = torch.empty(n, device="cuda")
+    wd = w.contiguous().cuda()
+    return ops.pack_conv_weight_dgrad(wd, wp) if dgrad else ops.pack_conv_weight(wd, wp, stem)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# forward convolutions
+# ----------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,H,W,Cin,Cout,K,stride", [
+    (2, 8, 12, 16, 8, 3, 1), (2, 9, 13, 16, 24, 3, 2), (3, 16, 20, 64, 64, 3, 1), (2, 12, 40, 64, 128, 3, 2),
+    (2, 12, 40, 64, 128, 1, 2), (1, 6, 20, 512, 512, 3, 1), (2, 48, 160, 64, 64, 3, 1), (1, 24, 80, 128, 256, 3, 2)])
+def test_conv_fwd_zero(N, H, W, Cin, Cout, K, stride):
+    ops, L = _ops()
+    pad = K // 2
+    x, w = rnd((N, Cin, H, W), 1), rnd((Cout, Cin, K, K), 2, -0.1, 0.1)
+    ref = F.conv2d(x, w, None, stride, pad)
+    OH, OW = ref.shape[2:]
+    y = torch.empty((N, OH, OW, Cout), device="cuda")
+    d = ops.make_desc(N, OH, OW, H, W, Cin, 0, Cout, K, stride, pad, L.GATHER_FWD_ZERO)
+    ops.conv_igemm(d, nhwc(x), None, pack(w), y)
+    check(nchw(y), ref, "conv_fwd_zero")
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 6, 10, 16, 8), (2, 2, 3, 512, 256), (1, 24, 80, 128, 64), (1, 64, 96, 64, 32),
+                                            (2, 12, 40, 256, 128), (1, 192, 640, 32, 32)])
+def test_conv_fwd_reflect_bias_elu(N, H, W, Cin, Cout):
+    ops, L = _ops()
+    x, w, b = rnd((N, Cin, H, W), 3), rnd((Cout, Cin, 3, 3), 4, -0.1, 0.1), rnd((Cout,), 5)
+    ref = F.elu(F.conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect"), w, b))
+    y = torch.empty((N, H, W, Cout), device="cuda")
+    d = ops.make_desc(N, H, W, H, W, Cin, 0, Cout, 3, 1, 1, L.GATHER_FWD_REFLECT, act=L.ACT_ELU)
+    ops.conv_igemm(d, nhwc(x), None, pack(w), y, bias=b.cuda())
+    check(nchw(y), ref, "conv_fwd_reflect")
+
+
+@pytest.mark.parametrize("N,h,w,C0,C1,Cout", [(2, 4, 6, 8, 8, 8), (1, 6, 20, 256, 256, 256), (1, 48, 160, 64, 64, 64),
+                                              (1, 32, 48, 64, 0, 32), (2, 3, 5, 16, 4, 12)])
+def test_conv_fwd_up2_concat(N, h, w, C0, C1, Cout):
+    ops, L = _ops()
+    lo, w_ = rnd((N, C0, h, w), 6), rnd((Cout, C0 + C1, 3, 3), 7, -0.1, 0.1)
+    b = rnd((Cout,), 8)
+    up = F.interpolate(lo, scale_factor=2, mode="nearest")
+    skip = rnd((N, C1, 2 * h, 2 * w), 9) if C1 else None
+    xin = torch.cat([up, skip], 1) if C1 else up
+    ref = F.elu(F.conv2d(F.pad(xin, (1, 1, 1, 1), mode="reflect"), w_, b))
+    y = torch.empty((N, 2 * h, 2 * w, Cout), device="cuda")
+    d = ops.make_desc(N, 2 * h, 2 * w, 2 * h, 2 * w, C0, C1, Cout, 3, 1, 1, L.GATHER_FWD_REFLECT_UP2, act=L.ACT_ELU)
+    ops.conv_igemm(d, nhwc(lo), nhwc(skip) if C1 else None, pack(w_), y, bias=b.cuda())
+    check(nchw(y), ref, "conv_fwd_up2cat")
+
+
+@pytest.mark.parametrize("N,H,W", [(2, 64, 96), (1, 192, 640), (3, 34, 50)])
+def test_conv_stem(N, H, W):
+    ops, L = _ops()
+    img, w = rnd((N, 3, H, W), 10, 0.0, 1.0), rnd((64, 3, 7, 7), 11, -0.1, 0.1)
+    ref = F.conv2d((img - 0.45) / 0.225, w, None, 2, 3)
+    OH, OW = ref.shape[2:]
+    y = torch.empty((N, OH, OW, 64), device="cuda")
+    d = ops.make_desc(N, OH, OW, H, W, 3, 0, 64, 7, 2, 3, L.GATHER_STEM)
+    ops.conv_igemm(d, img.cuda(), None, pack(w, stem=True), y)
+    check(nchw(y), ref, "conv_stem")
+
+
+# ----------------------------------------------------------------------------------------------------------
+# data gradients
+# ----------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,H,W,Cin,Cout,K,stride", [(2, 8, 12, 16, 8, 3, 1), (2, 9, 13, 16, 24, 3, 2), (2, 12, 40, 64, 128, 3, 2),
+                                                     (2, 12, 40, 64, 128, 1, 2), (1, 24, 80, 128, 128, 3, 1), (2, 7, 9, 32, 16, 1, 2)])
+def test_conv_dgrad_zero(N, H, W, Cin, Cout, K, stride):
+    ops, L = _ops()
+    pad = K // 2
+    x = rnd((N, Cin, H, W), 12).requires_grad_(True)
+    w = rnd((Cout, Cin, K, K), 13, -0.1, 0.1)
+    yref = F.conv2d(x, w, None, stride, pad)
+    g = rnd(tuple(yref.shape), 14)
+    yref.backward(g)
+    OH, OW = yref.shape[2:]
+    dx = torch.empty((N, H, W, Cin), device="cuda")
+    d = ops.make_desc(N, H, W, OH, OW, Cout, 0, Cin, K, stride, pad, L.GATHER_DGRAD_ZERO)
+    ops.conv_igemm(d, nhwc(g), None, pack(w, dgrad=True), dx)
+    check(nchw(dx), x.grad, "conv_dgrad_zero")
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 6, 10, 16, 8), (2, 2, 3, 64, 32), (1, 3, 5, 16, 16), (1, 24, 80, 128, 64),
+                                            (1, 64, 96, 64, 32), (2, 2, 2, 16, 8)])
+def test_conv_dgrad_reflect_with_elu_grad(N, H, W, Cin, Cout):
+    ops, L = _ops()
+    # x = elu(pre) is the saved activation feeding the conv; we want dL/dpre = dgrad * elu'(x)
+    pre = rnd((N, Cin, H, W), 15, -2.0, 2.0).requires_grad_(True)
+    w = rnd((Cout, Cin, 3, 3), 16, -0.1, 0.1)
+    x = F.elu(pre)
+    y = F.conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect"), w)
+    g = rnd(tuple(y.shape), 17)
+    extra = rnd(tuple(x.shape), 18)                 # a second consumer's gradient (addend)
+    (y * g).sum().backward(retain_graph=True)
+    ref = pre.grad.clone()
+    pre.grad = None
+    ((y * g).sum() + (x * extra).sum()).backward()
+    ref_add = pre.grad
+    dz = torch.empty((N, H, W, Cin), device="cuda")
+    d = ops.make_desc(N, H, W, H, W, Cout, 0, Cin, 3, 1, 1, L.GATHER_DGRAD_REFLECT, epi=L.EPI_ACTGRAD_ELU)
+    xs = nhwc(x.detach())
+    ops.conv_igemm(d, nhwc(g), None, pack(w, dgrad=True), dz, actsrc=xs)
+    check(nchw(dz), ref, "conv_dgrad_reflect")
+    ops.conv_igemm(d, nhwc(g), None, pack(w, dgrad=True), dz, actsrc=xs, addend=nhwc(extra))
+    check(nchw(dz), ref_add, "conv_dgrad_reflect+addend")
+
+
+def test_conv_epilogue_relu_mask_and_accum():
+    ops, L = _ops()
+    N, H, W, Cin, Cout = 2, 8, 12, 32, 16
+    x, w = rnd((N, Cin, H, W), 19), rnd((Cout, Cin, 3, 3), 20, -0.1, 0.1)
+    base = F.conv2d(x, w, None, 1, 1)
+    add, mask, prev, act = rnd(tuple(base.shape), 21), rnd(tuple(base.shape), 22), rnd(tuple(base.shape), 23), rnd(tuple(base.shape), 24)
+    ref = (base + add * (mask > 0).float()) * (act > 0).float() + prev
+    y = nhwc(prev)
+    d = ops.make_desc(N, H, W, H, W, Cin, 0, Cout, 3, 1, 1, L.GATHER_FWD_ZERO, epi=L.EPI_ACTGRAD_RELU | L.EPI_ACCUM)
+    ops.conv_igemm(d, nhwc(x), None, pack(w), y, addend=nhwc(add), addend_mask=nhwc(mask), actsrc=nhwc(act))
+    check(nchw(y), ref, "epilogue")
+    d2 = ops.make_desc(N, H, W, H, W, Cin, 0, Cout, 3, 1, 1, L.GATHER_FWD_ZERO, act=L.ACT_RELU)
+    y2 = torch.empty_like(y)
+    ops.conv_igemm(d2, nhwc(x), None, pack(w), y2)
+    check(nchw(y2), F.relu(base), "epilogue relu")
+
+
+# ----------------------------------------------------------------------------------------------------------
+# weight gradients
+# ----------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,H,W,Cin,Cout,K,stride,mode", [
+    (2, 8, 12, 16, 8, 3, 1, "zero"), (2, 9, 13, 16, 24, 3, 2, "zero"), (2, 12, 40, 64, 128, 1, 2, "zero"),
+    (2, 24, 80, 128, 128, 3, 1, "zero"), (2, 6, 10, 16, 8, 3, 1, "reflect"), (1, 48, 160, 64, 32, 3, 1, "reflect"),
+    (1, 12, 40, 256, 128, 3, 1, "reflect"), (3, 6, 20, 512, 256, 3, 1, "reflect")])
+def test_conv_wgrad(N, H, W, Cin, Cout, K, stride, mode):
+    ops, L = _ops()
+    pad = K // 2
+    x = rnd((N, Cin, H, W), 25)
+    w = rnd((Cout, Cin, K, K), 26, -0.1, 0.1).requires_grad_(True)
+    if mode == "zero":
+        y = F.conv2d(x, w, None, stride, pad)
+        gather = L.GATHER_FWD_ZERO
+    else:
+        y = F.conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect"), w)
+        gather = L.GATHER_FWD_REFLECT
+    g = rnd(tuple(y.shape), 27)
+    y.backward(g)
+    OH, OW = y.shape[2:]
+    d = ops.make_desc(N, OH, OW, H, W, Cin, 0, Cout, K, stride, pad, gather)
+    dw = torch.empty((Cout, Cin, K, K), device="cuda")
+    ops.conv_wgrad(d, nhwc(x), None, nhwc(g), dw)
+    check(dw, w.grad, "conv_wgrad")
+    ops.conv_wgrad(d, nhwc(x), None, nhwc(g), dw, accumulate=True)
+    check(dw, 2 * w.grad, "conv_wgrad accumulate")
+    db = torch.empty((Cout,), device="cuda")
+    ops.colsum(nhwc(g).view(-1, Cout), db)
+    check(db, g.sum((0, 2, 3)), "colsum")
+
+
+@pytest.mark.parametrize("N,h,w,C0,C1,Cout", [(2, 4, 6, 8, 8, 8), (1, 24, 80, 64, 64, 64), (1, 32, 48, 64, 0, 32)])
+def test_conv_wgrad_up2cat_and_bwd(N, h, w, C0, C1, Cout):
+    ops, L = _ops()
+    pre = rnd((N, C0, h, w), 28, -2.0, 2.0).requires_grad_(True)
+    lo = F.elu(pre)
+    skip = rnd((N, C1, 2 * h, 2 * w), 29).requires_grad_(True) if C1 else None
+    wt = rnd((Cout, C0 + C1, 3, 3), 30, -0.1, 0.1).requires_grad_(True)
+    up = F.interpolate(lo, scale_factor=2, mode="nearest")
+    xin = torch.cat([up, skip], 1) if C1 else up
+    y = F.conv2d(F.pad(xin, (1, 1, 1, 1), mode="reflect"), wt)
+    g = rnd(tuple(y.shape), 31)
+    extra = rnd(tuple(lo.shape), 32)
+    ((y * g).sum() + (lo * extra).sum()).backward()
+    H, W = 2 * h, 2 * w
+    d = ops.make_desc(N, H, W, H, W, C0, C1, Cout, 3, 1, 1, L.GATHER_FWD_REFLECT_UP2)
+    dw = torch.empty((Cout, C0 + C1, 3, 3), device="cuda")
+    gz = nhwc(g)
+    ops.conv_wgrad(d, nhwc(lo.detach()), nhwc(skip.detach()) if C1 else None, gz, dw)
+    check(dw, wt.grad, "wgrad up2cat")
+    # dgrad at hi-res over all C0+C1 channels, then split/pool
+    dd = ops.make_desc(N, H, W, H, W, Cout, 0, C0 + C1, 3, 1, 1, L.GATHER_DGRAD_REFLECT)
+    dxv = torch.empty((N, H, W, C0 + C1), device="cuda")
+    ops.conv_igemm(dd, gz, None, pack(wt.detach(), dgrad=True), dxv)
+    dlow = torch.empty((N, h, w, C0), device="cuda")
+    dskip = torch.ones((N, H, W, C1), device="cuda") if C1 else None
+    ops.up2cat_bwd(dxv, N, h, w, C0, C1, dlow, addend=nhwc(extra), ylow=nhwc(lo.detach()), dskip=dskip, accumulate_skip=True)
+    check(nchw(dlow), pre.grad, "up2cat_bwd dlow")
+    if C1:
+        check(nchw(dskip), skip.grad + 1.0, "up2cat_bwd dskip(accumulate)")
+
+
+def test_stem_wgrad():
+    ops, L = _ops()
+    N, H, W = 2, 64, 96
+    img = rnd((N, 3, H, W), 33, 0.0, 1.0)
+    w = rnd((64, 3, 7, 7), 34, -0.1, 0.1).requires_grad_(True)
+    y = F.conv2d((img - 0.45) / 0.225, w, None, 2, 3)
+    g = rnd(tuple(y.shape), 35)
+    y.backward(g)
+    d = ops.make_desc(N, H // 2, W // 2, H, W, 3, 0, 64, 7, 2, 3, L.GATHER_STEM)
+    dw = torch.empty((64, 3, 7, 7), device="cuda")
+    ops.conv_wgrad(d, img.cuda(), None, nhwc(g), dw)
+    check(dw, w.grad, "stem wgrad")
+
+
+# ----------------------------------------------------------------------------------------------------------
+# heads
+# ----------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("Cin,scale,sig", [(16, 1, False), (16, 2, True), (32, 1, True), (64, 4, False), (128, 8, True), (64, 2, True)])
+def test_head_fwd_bwd(Cin, scale, sig):
+    ops, L = _ops()
+    N, h, w = 2, 6, 10
+    x = rnd((N, Cin, h, w), 36).requires_grad_(True)
+    wt = rnd((2, Cin, 3, 3), 37, -0.2, 0.2).requires_grad_(True)
+    b = rnd((2,), 38).requires_grad_(True)
+    z = F.conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect"), wt, b)
+    s = torch.sigmoid(z) if sig else z
+    o = F.interpolate(s, scale_factor=scale, mode="bilinear", align_corners=False) if scale != 1 else s
+    g = rnd(tuple(o.shape), 39)
+    o.backward(g)
+    H, W = h * scale, w * scale
+    xs = nhwc(x.detach())
+    low = torch.empty((N, h, w, 2), device="cuda")
+    ops.head_fwd(xs, wt.detach().cuda(), b.detach().cuda(), low, sig)
+    check(nchw(low), s.detach(), "head_fwd")
+    out = torch.zeros((N, 4, H, W), device="cuda")
+    ops.head_upsample(low, out, scale, 2)
+    check(out[:, 2:4], o.detach(), "head_upsample")
+    assert float(out[:, :2].abs().max()) == 0.0
+    gout = torch.zeros((N, 4, H, W), device="cuda")
+    gout[:, 2:4] = g.cuda()
+    dz = torch.empty((N, h, w, 2), device="cuda")
+    ops.head_upsample_bwd(gout, low, dz, scale, 2, sig)
+    dx = torch.empty((N, h, w, Cin), device="cuda")
+    ops.head_dgrad(dz, wt.detach().cuda(), dx)
+    check(nchw(dx), x.grad, "head_dgrad")
+    dw, db = torch.empty((2, Cin, 3, 3), device="cuda"), torch.empty((2,), device="cuda")
+    ops.head_wgrad(xs, dz, dw, db)
+    check(dw, wt.grad, "head_wgrad")
+    check(db, b.grad, "head_bgrad")
+
+
+# ----------------------------------------------------------------------------------------------------------
+# batch norm, max-pool
+# ----------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,H,W,Cn", [(2, 8, 12, 16), (3, 48, 160, 64), (2, 6, 20, 512), (12, 12, 40, 256)])
+def test_bn_train_fwd_bwd(N, H, W, Cn):
+    ops, L = _ops()
+    z = (rnd((N, Cn, H, W), 40) * 2 + rnd((1, Cn, 1, 1), 41) * 3).requires_grad_(True)
+    gamma, beta = rnd((Cn,), 42, 0.5, 1.5).requires_grad_(True), rnd((Cn,), 43).requires_grad_(True)
+    rm, rv = rnd((Cn,), 44), rnd((Cn,), 45, 0.5, 2.0)
+    res = rnd((N, Cn, H, W), 46)
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    y = F.relu(F.batch_norm(z, rm_ref, rv_ref, gamma, beta, True, 0.1, 1e-5) + res)
+    g = rnd(tuple(y.shape), 47)
+    y.backward(g)
+    M = N * H * W
+    zs = nhwc(z.detach())
+    dev = lambda t: t.detach().clone().cuda()
+    rmd, rvd, nbt = dev(rm), dev(rv), torch.zeros((), dtype=torch.int64, device="cuda")
+    mean, invstd, scale, shift = (torch.empty(Cn, device="cuda") for _ in range(4))
+    ops.bn_train_stats(zs.view(M, Cn), dev(gamma), dev(beta), rmd, rvd, nbt, mean, invstd, scale, shift)
+    check(rmd, rm_ref, "running_mean", 1e-5)
+    check(rvd, rv_ref, "running_var", 1e-5)
+    assert int(nbt) == 1
+    ys = torch.empty_like(zs)
+    ops.bn_apply(zs.view(M, Cn), scale, shift, ys.view(M, Cn), residual=nhwc(res).view(M, Cn), relu=True)
+    check(nchw(ys), y.detach(), "bn_apply")
+    dz, gout = torch.empty_like(zs), torch.empty_like(zs)
+    dgam, dbet = torch.empty(Cn, device="cuda"), torch.empty(Cn, device="cuda")
+    ops.bn_bwd(nhwc(g).view(M, Cn), ys.view(M, Cn), zs.view(M, Cn), mean, invstd, dev(gamma), dz.view(M, Cn), dgam, dbet,
+               g_out=gout.view(M, Cn))
+    check(nchw(dz), z.grad, "bn_bwd dz")
+    check(dgam, gamma.grad, "bn_bwd dgamma")
+    check(dbet, beta.grad, "bn_bwd dbeta")
+    check(nchw(gout), g * (y.detach() > 0).float(), "bn_bwd g_out")
+    # eval coefficients
+    ops.bn_eval_coeffs(dev(gamma), dev(beta), dev(rm), dev(rv), scale, shift)
+    ops.bn_apply(zs.view(M, Cn), scale, shift, ys.view(M, Cn), relu=False)
+    check(nchw(ys), F.batch_norm(z.detach(), rm, rv, gamma.detach(), beta.detach(), False, 0.1, 1e-5), "bn eval")
+
+
+@pytest.mark.parametrize("N,H,W,Cn", [(2, 8, 12, 16), (2, 96, 320, 64), (1, 7, 9, 8)])
+def test_maxpool(N, H, W, Cn):
+    ops, L = _ops()
+    x = F.relu(rnd((N, Cn, H, W), 48)).requires_grad_(True)       # many exact ties at 0, like the real input
+    y = F.max_pool2d(x, 3, 2, 1)
+    g = rnd(tuple(y.shape), 49)
+    y.backward(g)
+    OH, OW = y.shape[2:]
+    ys = torch.empty((N, OH, OW, Cn), device="cuda")
+    am = torch.empty((N, OH, OW, Cn), dtype=torch.uint8, device="cuda")
+    ops.maxpool_fwd(nhwc(x.detach()), ys, am)
+    assert torch.equal(nchw(ys), y.detach())
+    dx = torch.empty((N, H, W, Cn), device="cuda")
+    ops.maxpool_bwd(nhwc(g), am, dx)
+    check(nchw(dx), x.grad, "maxpool_bwd", 1e-6)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# loss, Adam, layout
+# ----------------------------------------------------------------------------------------------------------
+def test_loss_against_oracle_and_golden():
+    ops, L = _ops()
+    from oracle import restatement as R
+    from tests.golden.digest import load
+    from tests.test_oracle_golden import g4_inputs
+    gold = load("g4_loss")
+    preds, batch = g4_inputs()
+    pd = [preds[k].detach().cuda() for k in R.SCALES]
+    tg = {k: v.cuda() for k, v in batch.items()}
+    out = torch.empty(21, device="cuda")
+    dp = [torch.empty_like(p) for p in pd]
+    ops.loss_fwd_bwd(pd, tg, out, dp)
+    np.testing.assert_allclose(out.cpu().double().numpy(), gold["loss.values"], rtol=2e-5)
+    for k, d in zip(R.SCALES, dp):
+        check(d, torch.from_numpy(gold["loss.dpred" + k]), "dpred" + k, 1e-5)
+    # a second, larger, case against the oracle (forward only + backward)
+    B, H, W = 3, 40, 72
+    batch = R.make_batch(B, H, W, tag="lossbig")
+    pr = {k: rnd((B, 4, H, W), 50 + i, -4.0, 4.0) for i, k in enumerate(R.SCALES)}
+    for k in pr:
+        pr[k][:, 2:] = torch.sigmoid(pr[k][:, 2:])
+        pr[k].requires_grad_(True)
+    losses, _ = R.loss_manager(pr, batch)
+    losses["loss"].backward()
+    pd = [pr[k].detach().cuda() for k in R.SCALES]
+    dp = [torch.empty_like(p) for p in pd]
+    ops.loss_fwd_bwd(pd, {k: v.cuda() for k, v in batch.items()}, out, dp)
+    ref = np.array([float(losses[k]) for k in R.LOSS_KEYS])
+    np.testing.assert_allclose(out.cpu().double().numpy(), ref, rtol=2e-5)
+    for k, d in zip(R.SCALES, dp):
+        check(d, pr[k].grad, "dpred big " + k, 1e-5)
+    out2 = torch.empty(21, device="cuda")
+    ops.loss_fwd_bwd(pd, {k: v.cuda() for k, v in batch.items()}, out2, None)      # forward-only, bit-stable
+    assert torch.equal(out, out2)
+
+
+def test_adam_matches_torch():
+    ops, L = _ops()
+    n = 100003
+    p0, g1, g2 = rnd((n,), 60), rnd((n,), 61, -0.01, 0.01), rnd((n,), 62, -0.01, 0.01)
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr], lr=1e-4)
+    n_pad = (n + 3) // 4 * 4
+    p, m, v = torch.zeros(n_pad, device="cuda"), torch.zeros(n_pad, device="cuda"), torch.zeros(n_pad, device="cuda")
+    p[:n] = p0.cuda()
+    for step, g in enumerate((g1, g2), start=1):
+        pr.grad = g.clone()
+        opt.step()
+        gd = torch.zeros(n_pad, device="cuda")
+        gd[:n] = g.cuda()
+        ops.adam_step(p[:n], gd[:n], m[:n], v[:n], 1e-4, 0.9, 0.999, 1e-8, step)
+        err = (p[:n].cpu() - pr.detach()).abs().max().item()
+        assert err <= 2e-9 + 1e-6 * 1e-4, "adam step %d: %.3e" % (step, err)
+    st = opt.state[pr]
+    check(m[:n], st["exp_avg"], "exp_avg", 1e-6)
+    check(v[:n], st["exp_avg_sq"], "exp_avg_sq", 1e-6)
+
+
+def test_layout_roundtrip():
+    ops, L = _ops()
+    x = rnd((2, 5, 7, 9), 63).cuda()
+    y = ops.nchw_to_nhwc(x)
+    assert torch.equal(y, x.permute(0, 2, 3, 1).contiguous())
+    assert torch.equal(ops.nhwc_to_nchw(y), x)
+    z = torch.empty(1001, device="cuda")
+    ops.fill(z, 2.5)
+    assert float(z.min()) == 2.5 and float(z.max()) == 2.5

@@ -1,0 +1,312 @@
+"""GPU: the HIP engine end to end (through the nn.Module / LossManager / optimiser surface and the C ABI)
+against (a) the committed golden fixtures produced by the reference's own code and (b) the CPU oracle.
+
+Tolerances: 1e-4 relative to the tensor's max for activations / outputs / losses (north_star), 1e-3 for
+gradient digests (a backward through 58 convs + 36 train-mode BNs amplifies fp32 round-off; the oracle vs
+reference difference on the same quantity is itself ~1e-6..1e-5); thresholded masks bit-exact outside a
+documented |logit - threshold| < 1e-4 tie band.
+"""
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _load_state(model, P, B):
+    model.load_state_dict({**P, **B})
+    return model
+
+
+def _new_model(P, B):
+    from footprints_amd import FootprintNetwork
+    return _load_state(FootprintNetwork(pretrained=False), P, B).cuda()
+
+
+def relerr(got, ref):
+    ref = ref.double().cpu()
+    return ((got.double().cpu() - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous().cpu()
+
+
+# ----------------------------------------------------------------------------------------------------------
+def test_g2_decoder_golden_through_engine():
+    """SkipDecoder fwd + bwd (reference-authored golden vectors, real channel counts, 64x96 pyramid)."""
+    from footprints_amd import FootprintNetwork
+    from tests.golden.digest import compare, fill, load
+    from tests.test_oracle_golden import G2_SHAPES, decoder_state
+    gold = load("g2_decoder")
+    for sig, decname in ((False, "mask_decoder"), (True, "depth_decoder")):
+        tag = "dec.%s" % ("sig" if sig else "lin")
+        model = FootprintNetwork(pretrained=False)
+        P = decoder_state(prefix=decname)
+        sd = model.state_dict()
+        sd.update({k: v.detach() for k, v in P.items()})
+        model.load_state_dict(sd)
+        model.cuda()
+        eng = model.engine()
+        eng.refresh_packed(force=True)
+        dec = eng.decoders[1 if sig else 0]
+        feats_nchw = [fill("g2.feat%d" % i, s) for i, s in enumerate(G2_SHAPES)]
+        feats = [nhwc(f) for f in feats_nchw]
+        S = {"N": 2, "H": 64, "W": 96, "feats": feats, "dims": [tuple(f.shape[1:3]) for f in feats], "training": True}
+        outs = [torch.zeros((2, 4, 64, 96), device="cuda") for _ in range(4)]
+        D = eng._decoder_forward(dec, S, outs)
+        c0 = dec.c0
+        for k, o in zip(("1/8", "1/4", "1/2", "1/1"), outs):
+            compare(gold, tag + ".out" + k, o[:, c0:c0 + 2])
+        gouts = []
+        for k in ("1/8", "1/4", "1/2", "1/1"):
+            g = torch.zeros((2, 4, 64, 96), device="cuda")
+            g[:, c0:c0 + 2] = fill("g2.g" + k, (2, 2, 64, 96)).cuda()
+            gouts.append(g)
+        dF = [torch.empty_like(f) for f in feats]
+        eng._decoder_backward(dec, D, S, gouts, dF, first=True, acc=False)
+        for i in range(5):
+            compare(gold, tag + ".dfeat%d" % i, nchw(dF[i]), rtol=2e-4)
+        gv = dict(zip(eng.live_names, eng.grad_views))
+        for name in ("block1.pre_concat_conv.conv1.weight", "block4.post_concat_conv.conv2.weight", "outconv1.conv1.weight",
+                     "outconv4.0.conv1.weight", "outconv4.1.conv1.bias", "block2.post_concat_conv.conv1.bias"):
+            compare(gold, tag + ".d." + name, gv[decname + "." + name], rtol=2e-4)
+
+
+def test_g3_network_forward_train_and_eval_golden():
+    from oracle import restatement as R
+    from tests.golden.digest import compare, load
+    gold = load("g3_network")
+    P, B = R.make_state()
+    batch = R.make_batch(2, 64, 96)
+    for mode in ("train", "eval"):
+        model = _new_model(P, B)
+        model.train(mode == "train")
+        with torch.no_grad():
+            o = model(batch["image"].cuda())
+        assert list(o.keys()) == ["1/8", "1/4", "1/2", "1/1"]
+        for k in o:
+            assert tuple(o[k].shape) == (2, 4, 64, 96)
+            compare(gold, "net.%s.out%s" % (mode, k), o[k])
+        if mode == "train":
+            sd = model.state_dict()
+            rm = torch.cat([sd[k].flatten() for k in sd if k.endswith("running_mean") and "encoder" in k])
+            rv = torch.cat([sd[k].flatten() for k in sd if k.endswith("running_var") and "encoder" in k])
+            compare(gold, "net.train.running_mean", rm)
+            compare(gold, "net.train.running_var", rv)
+            nbt = [int(sd[k]) for k in sd if k.endswith("num_batches_tracked") and "encoder" in k]
+            assert all(v == 1 for v in nbt)
+
+
+def test_g5_two_train_steps_golden_dropin_surface():
+    """model(x) -> LossManager -> zero_grad -> backward -> optimiser.step, exactly as train.py:150-156."""
+    from footprints_amd.model_manager import ModelManager
+    from footprints_amd.training.losses import LossManager
+    from oracle import restatement as R
+    from tests.golden.digest import compare, load
+    gold = load("g5_train")
+    P, B = R.make_state()
+    mm = ModelManager(use_cuda=True, learning_rate=1e-4)
+    _load_state(mm.model, P, B)
+    model, opt = mm.model, mm.optimiser
+    model.train()
+    lm = LossManager((0.1, 100), 0.25)
+    names = [k for k, _ in model.named_parameters()]
+    assert names == list(gold["train.param_names"])
+    for step in range(2):
+        batch = {k: v.cuda() for k, v in R.make_batch(2, 64, 96, tag="g5.step%d" % step).items()}
+        outputs = model(batch["image"])
+        losses = lm(outputs, batch)
+        assert len(losses) == 21 and len(outputs) == 24             # 4 outputs + 20 viz tensors (losses.py:90)
+        model.zero_grad()
+        losses["loss"].backward()
+        g = dict(model.named_parameters())
+        if step == 0:
+            dead = [k for k in names if g[k].grad is None]
+            assert dead == list(gold["train.dead_params"])
+            gs = np.array([float(g[k].grad.double().sum()) if g[k].grad is not None else 0.0 for k in names])
+            ga = gold["train.grad_abs"]
+            bad = np.abs(gs - gold["train.grad_sums"]) > 1e-3 * np.maximum(ga, 1e-12)
+            assert not bad.any(), [(names[i], gs[i], gold["train.grad_sums"][i], ga[i]) for i in np.nonzero(bad)[0][:5]]
+            for k in ("encoder.layer0.0.weight", "encoder.layer4.2.conv2.weight", "encoder.layer2.0.downsample.0.weight",
+                      "encoder.layer1.1.0.bn1.weight", "encoder.layer3.5.bn2.bias", "mask_decoder.block1.pre_concat_conv.conv1.weight",
+                      "depth_decoder.outconv4.1.conv1.weight", "depth_decoder.block4.post_concat_conv.conv1.weight"):
+                compare(gold, "train.grad." + k, g[k].grad, rtol=1e-3, atol_scale=1e-3)
+        opt.step()
+        vals = np.array([float(losses[k]) for k in R.LOSS_KEYS])
+        np.testing.assert_allclose(vals, gold["train.losses%d" % step], rtol=1e-4)
+        sd = model.state_dict()
+        ps = np.array([float(sd[k].double().sum()) for k in names])
+        pa = gold["train.param_abs%d" % step]
+        bad = np.abs(ps - gold["train.param_sums%d" % step]) > 1e-4 * np.maximum(pa, 1e-12)
+        assert not bad.any(), [(names[i], ps[i], gold["train.param_sums%d" % step][i]) for i in np.nonzero(bad)[0][:5]]
+    st = opt.state_dict()["state"]
+    steps = np.array([float(st[i]["step"]) if i in st else -1.0 for i in range(len(names))])
+    assert np.array_equal(steps, gold["train.adam_steps"])
+    ea = np.array([float(st[i]["exp_avg"].double().abs().sum()) if i in st else 0.0 for i in range(len(names))])
+    assert np.all(np.abs(ea - gold["train.exp_avg_abs"]) <= 2e-3 * np.maximum(gold["train.exp_avg_abs"], 1e-12))
+    sd = model.state_dict()
+    assert np.array_equal(np.array([int(sd[k]) for k in sd if k.endswith("num_batches_tracked")]), gold["train.nbt"])
+
+
+def test_trainstep_fast_path_equals_dropin_path():
+    from footprints_amd.model_manager import ModelManager
+    from footprints_amd.training.losses import LossManager
+    from footprints_amd.training.train import TrainStep
+    from oracle import restatement as R
+    P, B = R.make_state(tag="ts")
+    batch = {k: v.cuda() for k, v in R.make_batch(2, 64, 64, tag="ts").items()}
+    a, b = ModelManager(), ModelManager()
+    _load_state(a.model, P, B)
+    _load_state(b.model, P, B)
+    ts = TrainStep(a.model, a.optimiser)
+    lm = LossManager((0.1, 100), 0.25, compute_viz=False)
+    for _ in range(2):
+        la = ts(batch).clone()
+        b.model.train()
+        out = b.model(batch["image"])
+        lb = lm(out, batch)
+        b.model.zero_grad()
+        lb["loss"].backward()
+        b.optimiser.step()
+        assert torch.equal(la[20], lb["loss"].detach())
+    for (ka, va), (kb, vb) in zip(a.model.state_dict().items(), b.model.state_dict().items()):
+        assert torch.equal(va, vb), ka                           # same kernels, same order => bit-identical
+
+
+def test_full_train_step_against_oracle_and_masks():
+    """One full fwd+loss+bwd at a non-fixture size against the CPU oracle; thresholded masks bit-exact."""
+    from footprints_amd.training.losses import LossManager
+    from oracle import restatement as R
+    P, B = R.make_state(tag="full")
+    cpu_batch = R.make_batch(2, 96, 128, tag="full")
+    tr = R.OracleTrainer(P, B)
+    out_ref, l_ref = tr.forward_backward(cpu_batch)
+    model = _new_model(P, B)
+    model.train()
+    batch = {k: v.cuda() for k, v in cpu_batch.items()}
+    out = model(batch["image"])
+    losses = LossManager((0.1, 100), 0.25)(out, batch)
+    losses["loss"].backward()
+    for k in R.SCALES:
+        assert relerr(out[k], out_ref[k].detach()) <= 1e-4, k
+        ref = out_ref[k].detach()
+        # masks: sigmoid(logit) > 0.5 (losses.py:78) == logit > 0; predict_simple thresholds the logit at 0.5 (quirk)
+        for thr in (0.0, 0.5):
+            got_m, ref_m = (out[k][:, :2].cpu() > thr), (ref[:, :2] > thr)
+            band = (ref[:, :2] - thr).abs() < 1e-4 * ref[:, :2].abs().max()
+            assert torch.equal(got_m | band, ref_m | band), "mask mismatch outside the tie band (%s, thr %.1f)" % (k, thr)
+    for key in R.LOSS_KEYS:
+        assert abs(float(losses[key]) - float(l_ref[key])) <= 1e-4 * max(1.0, abs(float(l_ref[key]))), key
+    worst = 0.0
+    for (n, p) in model.named_parameters():
+        gr = tr.P[n].grad
+        if gr is None:
+            assert p.grad is None, n
+            continue
+        e = relerr(p.grad, gr)
+        worst = max(worst, e)
+        assert e <= 2e-3, "%s grad rel err %.3e" % (n, e)
+    print("worst parameter-gradient rel-to-max error: %.3e" % worst)
+
+
+def test_g6_predict_simple_plumbing(tmp_path):
+    from PIL import Image
+    from footprints_amd.model_manager import ModelManager
+    from footprints_amd.predict_simple import InferenceManager
+    from oracle import filler, restatement as R
+    from tests.golden.digest import compare, load
+    gold = load("g6_predict")
+    P, B = R.make_state()
+    mm = ModelManager(is_inference=True)
+    _load_state(mm.model, P, B)
+    img = (filler.uniform("g6.image", (269, 477, 3)) * 255).astype(np.uint8)
+    path = tmp_path / "synthetic.png"
+    Image.fromarray(img, "RGB").save(path)
+    im = InferenceManager("kitti", str(tmp_path / "pred"), model_manager=mm)
+    im.predict(str(path))
+    pred = np.load(tmp_path / "pred" / "outputs" / "synthetic.npy")
+    assert pred.shape == (4, 192, 640) and pred.dtype == np.float32
+    compare(gold, "predict.npy", torch.from_numpy(pred))
+    ref_bits = np.unpackbits(gold["predict.mask_logit_gt_half"])[:192 * 640].reshape(192, 640).astype(bool)
+    sample_scale = np.abs(gold["predict.npy#sample"]).max()
+    band = np.abs(pred[1] - 0.5) < 1e-4 * sample_scale
+    assert np.array_equal((pred[1] > 0.5) | band, ref_bits | band)
+    assert (tmp_path / "pred" / "visualisations" / "synthetic.jpg").exists()
+
+
+def test_checkpoint_roundtrip_reference_format(tmp_path):
+    from footprints_amd.model_manager import ModelManager
+    from oracle import restatement as R
+    P, B = R.make_state(tag="ckpt")
+    mm = ModelManager(save_folder=str(tmp_path))
+    _load_state(mm.model, P, B)
+    from footprints_amd.training.train import TrainStep
+    batch = {k: v.cuda() for k, v in R.make_batch(2, 64, 64, tag="ckpt").items()}
+    ts = TrainStep(mm.model, mm.optimiser)
+    ts(batch)
+    mm.save_model("weights_0")
+    sd = torch.load(tmp_path / "weights_0" / "model.pth", map_location="cpu")
+    assert [k for k in sd] == [s[0] for s in R.state_spec()]
+    assert all(tuple(sd[s[0]].shape) == tuple(s[1]) for s in R.state_spec())
+    osd = torch.load(tmp_path / "weights_0" / "optimiser.pth", map_location="cpu")
+    assert len(osd["state"]) == 196 and len(osd["param_groups"][0]["params"]) == 268
+    # the oracle (== reference format) can consume the checkpoint, and we can reload it
+    P2 = OrderedDict((k, sd[k]) for k in P)
+    ref_opt = torch.optim.Adam([p.clone().requires_grad_(True) for p in P2.values()], lr=1e-4)
+    ref_opt.load_state_dict(osd)
+    mm2 = ModelManager(save_folder=str(tmp_path))
+    mm2.load_model(str(tmp_path / "weights_0"), load_optimiser=True)
+    l1 = ts(batch).clone()
+    l2 = TrainStep(mm2.model, mm2.optimiser)(batch)
+    assert torch.equal(l1, l2)
+    for va, vb in zip(mm.model.state_dict().values(), mm2.model.state_dict().values()):
+        assert torch.equal(va, vb)
+
+
+def test_cpu_input_is_refused():
+    from footprints_amd import FootprintNetwork
+    m = FootprintNetwork(pretrained=False).cuda()
+    with pytest.raises(RuntimeError, match="no CPU compute path"):
+        m(torch.zeros(1, 3, 64, 64))
+
+
+# ----------------------------------------------------------------------------------------------------------
+# BASELINE.json full sizes: size-independent properties
+# ----------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,H,W", [(12, 192, 640), (4, 512, 640)])
+def test_full_size_properties(B, H, W):
+    """KITTI bs=12 192x640 and Matterport bs=4 512x640: (1) bit-reproducible step, (2) eval forward of a batch ==
+    per-image forwards (images are independent in eval mode), (3) image 0 against the CPU oracle (eval)."""
+    from footprints_amd.model_manager import ModelManager
+    from footprints_amd.training.train import TrainStep, synthetic_batch
+    from oracle import restatement as R
+    P, Bf = R.make_state(tag="fs")
+    batch = synthetic_batch(B, H, W, "cuda")
+    runs = []
+    for _ in range(2):
+        mm = ModelManager()
+        _load_state(mm.model, P, Bf)
+        ts = TrainStep(mm.model, mm.optimiser)
+        l = [ts(batch).clone() for _ in range(2)]
+        runs.append((l, [v.clone() for v in mm.model.state_dict().values()]))
+    assert all(torch.equal(a, b) for a, b in zip(runs[0][0], runs[1][0]))
+    assert all(torch.equal(a, b) for a, b in zip(runs[0][1], runs[1][1]))
+    assert torch.isfinite(runs[0][0][1]).all() and float(runs[0][0][1][20]) < float(runs[0][0][0][20]) * 1.5
+    model = _new_model(P, Bf)
+    model.eval()
+    with torch.no_grad():
+        full = {k: v.clone() for k, v in model(batch["image"]).items()}
+        for i in (0, B - 1):
+            one = model(batch["image"][i:i + 1])
+            for k in full:
+                assert torch.equal(one[k][0], full[k][i]), (k, i)
+        ref = R.footprint_network(batch["image"][:1].cpu(), P, OrderedDict((k, v.clone()) for k, v in Bf.items()), False)
+    for k in full:
+        assert relerr(full[k][:1], ref[k]) <= 1e-4, k
