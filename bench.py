@@ -45,14 +45,33 @@ class KernelTimer:
             s.record()
             r = fn(desc, *a, **k)
             e.record()
-            self.records.append((s, e, flops_of(desc)))
+            self.records.append((s, e, flops_of(desc), desc_key(desc)))
             return r
         return wrapped
 
     def summary(self):
-        ms = sum(s.elapsed_time(e) for s, e, _ in self.records)
-        fl = sum(f for _, _, f in self.records)
+        ms = sum(r[0].elapsed_time(r[1]) for r in self.records)
+        fl = sum(r[2] for r in self.records)
         return len(self.records), ms, fl
+
+    def table(self):
+        """Per distinct launch shape: count, mean microseconds, algorithmic TFLOP/s."""
+        agg = {}
+        for s, e, f, key in self.records:
+            a = agg.setdefault(key, [0, 0.0, f])
+            a[0] += 1
+            a[1] += s.elapsed_time(e)
+        rows = [{"shape": k, "launches": n, "avg_us": round(ms / n * 1e3, 1), "gflop": round(f / 1e9, 3),
+                 "tflops": round(f * n / (ms * 1e-3) / 1e12, 1) if ms > 0 else 0.0, "total_ms": round(ms, 3)} for k, (n, ms, f) in agg.items()]
+        return sorted(rows, key=lambda r: -r["total_ms"])
+
+
+GATHER_NAMES = ("fwd_zero", "fwd_reflect", "fwd_up2", "dgrad_zero", "dgrad_reflect", "stem")
+
+
+def desc_key(d):
+    return "%s N%d %dx%d<-%dx%d C%d+%d->%d k%d s%d" % (GATHER_NAMES[d.gather], d.N, d.OH, d.OW, d.IH, d.IW, d.C0, d.C1, d.Nout,
+                                                      d.KH, d.stride)
 
 
 def conv_flops(d):
@@ -61,9 +80,30 @@ def conv_flops(d):
     return 2.0 * d.N * d.OH * d.OW * d.Nout * taps * k
 
 
-def cpu_baseline(sample_b=4, steps=2):
+def _pick_threads():
+    """Fastest intra-op thread count among {8, 16, 32, 64, all effective cores} on a representative conv fwd+bwd
+    (os.cpu_count() over-reports under cgroup quotas, and oneDNN stops scaling long before 256 threads)."""
+    import torch.nn.functional as F
+    from oracle.cpu_threads import effective_cores
+    eff = effective_cores()
+    x = torch.rand(2, 64, 96, 320)
+    w = torch.rand(64, 64, 3, 3, requires_grad=True)
+    best, best_t = 1, float("inf")
+    for n in sorted({min(c, eff) for c in (8, 16, 32, 64, eff)}):
+        torch.set_num_threads(n)
+        F.conv2d(x, w, padding=1).sum().backward()
+        t0 = time.time()
+        for _ in range(2):
+            F.conv2d(x, w, padding=1).sum().backward()
+        dt = time.time() - t0
+        if dt < best_t:
+            best, best_t = n, dt
+    return best, eff
+
+
+def cpu_baseline(sample_b=2, steps=2):
     from oracle import restatement as R
-    cores = os.cpu_count() or 1
+    cores, eff = _pick_threads()
     torch.set_num_threads(cores)
     P, Bf = R.make_state(tag="bench")
     tr = R.OracleTrainer(P, Bf)
@@ -75,8 +115,9 @@ def cpu_baseline(sample_b=4, steps=2):
     dt = (time.time() - t0) / steps
     return {"value": round(sample_b / dt, 4), "unit": "img/s", "cores": cores, "kind": "port",
             "sample": "%d timed full train steps (fwd+loss+bwd+Adam) of the CPU oracle at %dx%d, batch %d of the 12-image "
-                      "workload, torch.set_num_threads(%d), after 1 warm-up step" % (steps, H, W, sample_b, cores),
-            "s_per_step": round(dt, 3)}
+                      "workload, torch.set_num_threads(%d) = fastest of {8,16,32,64,%d} on this host (%d effective cores), "
+                      "after 1 warm-up step" % (steps, H, W, sample_b, cores, eff, eff),
+            "s_per_step": round(dt, 3), "host_cores": eff}
 
 
 def main():
@@ -86,6 +127,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--dump-kernels", type=str, default=None, help="write the per-launch-shape timing tables (JSON) here")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -118,19 +160,21 @@ def main():
 
     for _ in range(args.warmup):
         step(batch)
-    timer = None
-    orig = ops.conv_igemm
+    timer = wtimer = None
+    orig, orig_w = ops.conv_igemm, ops.conv_wgrad
     if rank == 0 and not args.no_kernel_events:
         timer = KernelTimer()
-        import footprints_amd.engine as engine_mod
-        engine_mod.ops.conv_igemm = timer.wrap(orig, conv_flops)
+        ops.conv_igemm = timer.wrap(orig, conv_flops)
+        if args.dump_kernels:
+            wtimer = KernelTimer()
+            ops.conv_wgrad = wtimer.wrap(orig_w, conv_flops)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(batch)
     barrier()
     dt = time.perf_counter() - t0
-    ops.conv_igemm = orig
+    ops.conv_igemm, ops.conv_wgrad = orig, orig_w
     t = torch.tensor([dt], device="cuda", dtype=torch.float64)
     if distributed:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -167,6 +211,9 @@ def main():
                                "launches_per_step": n // max(args.steps, 1), "avg_launch_us": round(ms / max(n, 1) * 1e3, 2),
                                "algorithmic_gflop_per_launch": round(fl / max(n, 1) / 1e9, 3),
                                "kernel_ms_per_step": round(ms / max(args.steps, 1), 3)}
+        if args.dump_kernels and timer is not None:
+            with open(args.dump_kernels, "w") as fh:
+                json.dump({"igemm": timer.table(), "wgrad": wtimer.table()}, fh, indent=1)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -21,12 +21,13 @@ class ConvDesc(C.Structure):
                                          "gather", "act")] + [("epi", C.c_uint32)]
 
 
-_P, _I32, _I64, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+_P, _I32, _I64, _F, _D = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double
 _DESC = C.POINTER(ConvDesc)
 
 # name -> (restype, argtypes); mirrors include/footprints_hip.h one to one
 SIGNATURES = {
-    "fp_conv_igemm": (C.c_int, [_DESC, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "fp_conv_igemm_workspace": (_I64, [_DESC]),
+    "fp_conv_igemm": (C.c_int, [_DESC, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
     "fp_conv_wgrad_workspace": (_I64, [_DESC]),
     "fp_conv_wgrad": (C.c_int, [_DESC, _P, _P, _P, _P, C.c_int, _P, _I64, _P]),
     "fp_packed_weight_elems": (_I64, [_I32, _I32, _I32, _I32, _I32, _I32]),
@@ -51,7 +52,7 @@ SIGNATURES = {
     "fp_loss_workspace": (_I64, [_I32, _I32, _I32]),
     "fp_loss_fwd_bwd": (C.c_int, [C.POINTER(_P), _P, _P, _P, _P, _P, _P, _F, _F, _F, C.POINTER(_P), _P, _I32, _I32, _I32,
                                   _P, _I64, _P]),
-    "fp_adam_step": (C.c_int, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _I32, _F, _P]),
+    "fp_adam_step": (C.c_int, [_P, _P, _P, _P, _I64, _D, _D, _D, _D, _I32, _D, _P]),
     "fp_nchw_to_nhwc": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P]),
     "fp_nhwc_to_nchw": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P]),
     "fp_fill": (C.c_int, [_P, _I64, _F, _P]),
@@ -80,7 +81,13 @@ def load():
     return lib
 
 
+_SYNC = bool(int(os.environ.get("FP_SYNC", "0")))     # debugging aid: device-synchronise after every C-ABI call
+
+
 def check(rc, what=""):
+    if _SYNC:
+        import torch
+        torch.cuda.synchronize()
     if rc != 0:
         msg = load().fp_last_error_string()
         raise RuntimeError("footprints_hip %s failed (code %d): %s" % (what, rc, msg.decode() if msg else "?"))

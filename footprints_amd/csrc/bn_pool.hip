@@ -72,20 +72,28 @@ __global__ void __launch_bounds__(256) bn_stats_kernel(const float* __restrict__
   }
 }
 
+// one wave per channel: lane l merges partials l, l+64, ... in order, then a fixed shuffle tree merges the lanes
 __global__ void __launch_bounds__(256) bn_stats_final_kernel(const float* __restrict__ part, int nblk, int C,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              float eps, float momentum, float* running_mean, float* running_var,
                                                              long long* nbt, float* save_mean, float* save_invstd, float* scale,
                                                              float* shift) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c == 0 && nbt) *nbt += 1;
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
   if (c >= C) return;
   Wf w{0, 0, 0};
-  for (int b = 0; b < nblk; ++b) {
+  for (int b = lane; b < nblk; b += 64) {
     const float* p = part + ((size_t)b * C + c) * 3;
     Wf o{p[0], p[1], p[2]};
     wf_merge(w, o);
   }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    Wf t{__shfl_down(w.n, o, 64), __shfl_down(w.mean, o, 64), __shfl_down(w.m2, o, 64)};
+    wf_merge(w, t);
+  }
+  if (lane != 0) return;
   const float var = w.m2 / w.n;                       // biased: used for normalisation
   const float invstd = 1.f / sqrtf(var + eps);
   save_mean[c] = w.mean;
@@ -174,16 +182,20 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const float* __restr
   }
 }
 
-// coef[c] = (sum g / M, sum g*xhat / M); dgamma/dbeta written
+// coef[c] = (sum g / M, sum g*xhat / M); dgamma/dbeta written.  One wave per channel, fixed reduction tree.
 __global__ void __launch_bounds__(256) bn_bwd_final_kernel(const float* __restrict__ part, int nblk, int C, float invM,
                                                            float* coef, float* dgamma, float* dbeta, int accumulate) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= C) return;
   float s1 = 0.f, s2 = 0.f;
-  for (int b = 0; b < nblk; ++b) {
+  for (int b = lane; b < nblk; b += 64) {
     const float* p = part + ((size_t)b * C + c) * 2;
     s1 += p[0]; s2 += p[1];
   }
+  s1 = fp_wave_sum(s1);
+  s2 = fp_wave_sum(s2);
+  if (lane != 0) return;
   coef[c * 2 + 0] = s1 * invM;
   coef[c * 2 + 1] = s2 * invM;
   if (dgamma) dgamma[c] = accumulate ? dgamma[c] + s2 : s2;
@@ -317,7 +329,7 @@ extern "C" int fp_bn_train_stats(const float* z, int64_t M, int32_t C, const flo
   FP_REQUIRE(workspace_bytes >= fp_bn_workspace(M, C), "fp_bn_train_stats: workspace too small");
   const int nblk = bn_blocks(M, C);
   hipLaunchKernelGGL(bn_stats_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, z, (int)M, C, (float*)workspace);
-  hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, nblk,
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, nblk,
                      C, gamma, beta, eps, momentum, running_mean, running_var, (long long*)num_batches_tracked, save_mean,
                      save_invstd, scale, shift);
   return fp_check_launch("fp_bn_train_stats");
@@ -351,7 +363,7 @@ extern "C" int fp_bn_bwd(const float* dy, const float* relu_out, const float* z,
   float* coef = part + (size_t)nblk * C * 3;   // 16-byte aligned: nblk*C*3 floats with C%4==0
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, dy, relu_out, z, save_mean, save_invstd,
                      (int)M, C, part);
-  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)part, nblk, C,
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const float*)part, nblk, C,
                      1.f / (float)M, coef, dgamma, dbeta, accumulate);
   const size_t total4 = (size_t)M * (C / 4);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, dy, relu_out, z, save_mean,

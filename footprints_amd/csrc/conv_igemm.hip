@@ -34,7 +34,28 @@ struct IgemmArgs {
   int Nout, act;
   unsigned epi;
   int M, KC16, T, tilesN, nwg;
+  int SK, stepsPerSplit;  // split-K over the flattened (tap, 16-channel) step range; SK > 1 => raw partials to `part`
+  float* part;            // [SK][M][Nout]
 };
+
+// v = acc (+bias) -> addend -> activation gradient -> activation -> accumulate (see FP_EPI_* in the header)
+__device__ __forceinline__ float igemm_epilogue(const IgemmArgs& a, size_t o, int n, float v) {
+  if (a.epi & FP_EPI_BIAS) v += a.bias[n];
+  if (a.epi & FP_EPI_ADDEND) {
+    float ad = a.addend[o];
+    if (a.epi & FP_EPI_ADDEND_MASK) ad = a.addend_mask[o] > 0.f ? ad : 0.f;
+    v += ad;
+  }
+  if (a.epi & FP_EPI_ACTGRAD_ELU) {
+    const float sv = a.actsrc[o];
+    v *= (sv > 0.f ? 1.f : sv + 1.f);
+  }
+  if (a.epi & FP_EPI_ACTGRAD_RELU) v = a.actsrc[o] > 0.f ? v : 0.f;
+  if (a.act == FP_ACT_ELU) v = v > 0.f ? v : expm1f(v);
+  if (a.act == FP_ACT_RELU) v = fmaxf(v, 0.f);
+  if (a.epi & FP_EPI_ACCUM) v += a.y[o];
+  return v;
+}
 
 constexpr int LD = 20;
 
@@ -52,7 +73,8 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmArgs a) {
   const int lane = t & 63, wave = t >> 6;
   const int idx = lane & 31, h = lane >> 5;
   const int wm = wave / WN, wn = wave % WN;
-  const int tile = fp_xcd_remap(blockIdx.x, a.nwg);
+  const int wg = fp_xcd_remap(blockIdx.x, a.nwg);
+  const int split = wg % a.SK, tile = wg / a.SK;
   const int tile_n = tile % a.tilesN, tile_m = tile / a.tilesN;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const FpGeom& g = a.g;
@@ -128,10 +150,12 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int steps = a.T * a.KC16;
-  int ltap = 0, lcc = 0;
-  set_tap(0);
-  load_step(0, 0);
+  const int total_steps = a.T * a.KC16;
+  const int s_begin = split * a.stepsPerSplit;
+  const int steps = min(a.stepsPerSplit, total_steps - s_begin);
+  int ltap = s_begin / a.KC16, lcc = s_begin - ltap * a.KC16;
+  set_tap(ltap);
+  load_step(ltap, lcc);
   store_step(0);
   __syncthreads();
 
@@ -171,45 +195,69 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmArgs a) {
     for (int j = 0; j < TN; ++j) {
       const int n = n0 + (wn * TN + j) * 32 + idx;
       if (n >= a.Nout) continue;
-      const float bias = (a.epi & FP_EPI_BIAS) ? a.bias[n] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (m >= a.M) continue;
         const size_t o = (size_t)m * a.Nout + n;
-        float v = acc[i][j][r] + bias;
-        if (a.epi & FP_EPI_ADDEND) {
-          float ad = a.addend[o];
-          if (a.epi & FP_EPI_ADDEND_MASK) ad = a.addend_mask[o] > 0.f ? ad : 0.f;
-          v += ad;
-        }
-        if (a.epi & FP_EPI_ACTGRAD_ELU) {
-          const float sv = a.actsrc[o];
-          v *= (sv > 0.f ? 1.f : sv + 1.f);
-        }
-        if (a.epi & FP_EPI_ACTGRAD_RELU) v = a.actsrc[o] > 0.f ? v : 0.f;
-        if (a.act == FP_ACT_ELU) v = v > 0.f ? v : expm1f(v);
-        if (a.act == FP_ACT_RELU) v = fmaxf(v, 0.f);
-        if (a.epi & FP_EPI_ACCUM) v += a.y[o];
-        a.y[o] = v;
+        if (a.SK > 1) a.part[(size_t)split * a.M * a.Nout + o] = acc[i][j][r];
+        else a.y[o] = igemm_epilogue(a, o, n, acc[i][j][r]);
       }
     }
 }
 
+// y = epilogue(sum_s part[s]) -- fixed summation order
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const IgemmArgs a) {
+  const size_t total = (size_t)a.M * a.Nout;
+  for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (size_t)gridDim.x * 256) {
+    float v = 0.f;
+    for (int s = 0; s < a.SK; ++s) v += a.part[(size_t)s * total + o];
+    a.y[o] = igemm_epilogue(a, o, (int)(o % a.Nout), v);
+  }
+}
+
+// split-K factor for a grid of `tiles` workgroups over `steps` K-steps: fill ~3 workgroups per CU, >= 8 steps each
+int pick_splitk(int64_t tiles, int steps, int64_t MN, int64_t ws_floats) {
+  if (tiles >= 384 || ws_floats <= 0) return 1;
+  int64_t sk = fp_ceil_div(768, tiles);
+  if (sk > steps / 8) sk = steps / 8;
+  if (sk * MN > ws_floats) sk = ws_floats / MN;
+  return sk < 2 ? 1 : (int)sk;
+}
+
 template <int BM, int BN, int WM, int WN, bool STEM>
-int launch(IgemmArgs& a, hipStream_t stream) {
+int launch(IgemmArgs& a, hipStream_t stream, int64_t ws_floats) {
   const int tilesM = (int)fp_ceil_div(a.M, BM);
   a.tilesN = (int)fp_ceil_div(a.Nout, BN);
-  a.nwg = tilesM * a.tilesN;
+  const int steps = a.T * a.KC16;
+  const int sk = pick_splitk((int64_t)tilesM * a.tilesN, steps, (int64_t)a.M * a.Nout, ws_floats);
+  a.stepsPerSplit = (int)fp_ceil_div(steps, sk);
+  a.SK = (int)fp_ceil_div(steps, a.stepsPerSplit);
+  a.nwg = tilesM * a.tilesN * a.SK;
   hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, STEM>), dim3(a.nwg), dim3(256), 0, stream, a);
+  if (a.SK > 1) {
+    int64_t g = fp_ceil_div((int64_t)a.M * a.Nout, 256);
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)g), dim3(256), 0, stream, a);
+  }
   return fp_check_launch("fp_conv_igemm");
 }
 
+// worst-case split-K workspace: the launcher never uses more than 24 partial copies of the output
+constexpr int64_t MAX_SK = 24;
+
 }  // namespace
+
+extern "C" int64_t fp_conv_igemm_workspace(const fp_conv_desc* d) {
+  if (!d) return 0;
+  const int64_t M = (int64_t)d->N * d->OH * d->OW;
+  if (fp_ceil_div(M, 128) * fp_ceil_div(d->Nout, 64) >= 384) return 0;   // big grids never split
+  return MAX_SK * M * d->Nout * (int64_t)sizeof(float);
+}
 
 extern "C" int fp_conv_igemm(const fp_conv_desc* d, const float* src0, const float* src1, const float* wpacked,
                              const float* bias, const float* addend, const float* addend_mask, const float* actsrc,
-                             float* y, fp_stream_t stream_) {
+                             float* y, void* workspace, int64_t workspace_bytes, fp_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   FP_REQUIRE(d && src0 && wpacked && y, "fp_conv_igemm: null pointer");
   FP_REQUIRE(d->N > 0 && d->OH > 0 && d->OW > 0 && d->Nout > 0, "fp_conv_igemm: empty problem");
@@ -243,15 +291,19 @@ extern "C" int fp_conv_igemm(const fp_conv_desc* d, const float* src0, const flo
   a.M = (int)M64;
   a.T = stem ? 1 : d->KH * d->KW;
   a.KC16 = stem ? 10 : (d->C0 + d->C1 + 15) / 16;
+  a.part = (float*)workspace;
+  a.SK = 1;
+  int64_t ws = workspace ? workspace_bytes / (int64_t)sizeof(float) : 0;
+  if (ws > MAX_SK * M64 * d->Nout) ws = MAX_SK * M64 * d->Nout;
 
-  if (stem) return launch<128, 64, 2, 2, true>(a, stream);
+  if (stem) return launch<128, 64, 2, 2, true>(a, stream, 0);
   const int64_t M = a.M;
   if (d->Nout <= 32) {
-    if (fp_ceil_div(M, 256) >= 512) return launch<256, 32, 4, 1, false>(a, stream);
-    return launch<128, 32, 4, 1, false>(a, stream);
+    if (fp_ceil_div(M, 256) >= 512) return launch<256, 32, 4, 1, false>(a, stream, ws);
+    return launch<128, 32, 4, 1, false>(a, stream, ws);
   }
   const int64_t t128 = fp_ceil_div(M, 128);
-  if (d->Nout % 128 == 0 && t128 * (d->Nout / 128) >= 512) return launch<128, 128, 2, 2, false>(a, stream);
-  if (t128 * fp_ceil_div(d->Nout, 64) >= 384) return launch<128, 64, 2, 2, false>(a, stream);
-  return launch<64, 64, 2, 2, false>(a, stream);
+  if (d->Nout % 128 == 0 && t128 * (d->Nout / 128) >= 256) return launch<128, 128, 2, 2, false>(a, stream, ws);
+  if (M >= 256) return launch<128, 64, 2, 2, false>(a, stream, ws);   // small grids are filled by split-K
+  return launch<64, 64, 2, 2, false>(a, stream, ws);
 }

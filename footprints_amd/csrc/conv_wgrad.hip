@@ -228,7 +228,7 @@ Plan make_plan(const fp_conv_desc* d) {
   p.T = stem ? 1 : d->KH * d->KW;
   p.Kc = stem ? 147 : d->C0 + d->C1;
   p.BJ = d->Nout <= 32 ? 32 : 64;
-  p.BI = (p.BJ == 64 && p.Kc >= 128) ? 128 : 64;
+  p.BI = (!stem && p.BJ == 64 && p.Kc >= 128) ? 128 : 64;   // the stem instantiation is <64,64>
   p.kblocks = (int)fp_ceil_div(p.Kc, p.BI);
   p.nblocks = (int)fp_ceil_div(d->Nout, p.BJ);
   const int64_t M = (int64_t)d->N * d->OH * d->OW;

@@ -271,17 +271,20 @@ __global__ void __launch_bounds__(256) head_wgrad_kernel(const float* __restrict
 __global__ void __launch_bounds__(256) head_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
                                                                 float* __restrict__ db, int nblk, int Cin, int accumulate) {
   const int per = 9 * Cin * 2 + 2;
-  for (int e = blockIdx.x * 256 + threadIdx.x; e < per; e += gridDim.x * 256) {
-    float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += part[(size_t)b * per + e];
-    if (e < 9 * Cin * 2) {
-      const int o = e & 1, tc = e >> 1, c = tc % Cin, t = tc / Cin;
-      float* p = dw + ((size_t)o * Cin + c) * 9 + t;
-      *p = accumulate ? *p + s : s;
-    } else {
-      float* p = db + (e - 9 * Cin * 2);
-      *p = accumulate ? *p + s : s;
-    }
+  const int lane = threadIdx.x & 63;                      // one wave per output element, fixed reduction tree
+  const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (e >= per) return;
+  float s = 0.f;
+  for (int b = lane; b < nblk; b += 64) s += part[(size_t)b * per + e];
+  s = fp_wave_sum(s);
+  if (lane != 0) return;
+  if (e < 9 * Cin * 2) {
+    const int o = e & 1, tc = e >> 1, c = tc % Cin, t = tc / Cin;
+    float* p = dw + ((size_t)o * Cin + c) * 9 + t;
+    *p = accumulate ? *p + s : s;
+  } else {
+    float* p = db + (e - 9 * Cin * 2);
+    *p = accumulate ? *p + s : s;
   }
 }
 
@@ -358,7 +361,7 @@ extern "C" int fp_head_wgrad(const float* x, const float* dzlow, float* dw_oihw,
   int rc = fp_check_launch("fp_head_wgrad");
   if (rc) return rc;
   const int per = 9 * Cin * 2 + 2;
-  hipLaunchKernelGGL(head_wgrad_reduce_kernel, dim3((int)fp_ceil_div(per, 256)), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(head_wgrad_reduce_kernel, dim3((int)fp_ceil_div(per, 4)), dim3(256), 0, (hipStream_t)stream,
                      (const float*)workspace, dw_oihw, db, nblk, Cin, accumulate);
   return fp_check_launch("fp_head_wgrad(reduce)");
 }

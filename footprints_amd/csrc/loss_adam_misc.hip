@@ -79,12 +79,15 @@ __global__ void __launch_bounds__(256) loss_kernel(const LossArgs a) {
   if (threadIdx.x < 16) a.part[(size_t)blockIdx.x * 16 + threadIdx.x] = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
 }
 
-__global__ void loss_final_kernel(const float* __restrict__ part, int nblk, double inv_n, float* __restrict__ out) {
+__global__ void __launch_bounds__(1024) loss_final_kernel(const float* __restrict__ part, int nblk, double inv_n, float* __restrict__ out) {
   __shared__ float mean[16];
-  if (threadIdx.x < 16) {
+  {  // wave w reduces loss term w (16 waves), double accumulation, fixed order
+    const int lane = threadIdx.x & 63, term = threadIdx.x >> 6;
     double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += (double)part[(size_t)b * 16 + threadIdx.x];
-    mean[threadIdx.x] = (float)(s * inv_n);
+    for (int b = lane; b < nblk; b += 64) s += (double)part[(size_t)b * 16 + term];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if (lane == 0) mean[term] = (float)(s * inv_n);
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -214,11 +217,13 @@ __global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ x
   }
 }
 __global__ void __launch_bounds__(256) colsum_final_kernel(const float* __restrict__ part, int nblk, int C, float* out, int accumulate) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63;                      // one wave per channel, fixed reduction tree
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= C) return;
   float s = 0.f;
-  for (int b = 0; b < nblk; ++b) s += part[(size_t)b * C + c];
-  out[c] = accumulate ? out[c] + s : s;
+  for (int b = lane; b < nblk; b += 64) s += part[(size_t)b * C + c];
+  s = fp_wave_sum(s);
+  if (lane == 0) out[c] = accumulate ? out[c] + s : s;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -319,20 +324,23 @@ extern "C" int fp_loss_fwd_bwd(const float* const preds[4], const float* visible
   a.part = (float*)workspace;
   const int nblk = loss_blocks(npix);
   hipLaunchKernelGGL(loss_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, a);
-  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float*)workspace, nblk, 1.0 / (double)npix,
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const float*)workspace, nblk, 1.0 / (double)npix,
                      losses_out);
   return fp_check_launch("fp_loss_fwd_bwd");
 }
 
-extern "C" int fp_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
-                            float beta2, float eps, int32_t step, float grad_scale, fp_stream_t stream) {
+extern "C" int fp_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double beta1,
+                            double beta2, double eps, int32_t step, double grad_scale, fp_stream_t stream) {
   FP_REQUIRE(param && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1, "fp_adam_step: bad arguments");
   FP_REQUIRE(((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) % 16 == 0, "fp_adam_step: buffers must be 16-byte aligned");
-  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-  const float step_size = (float)((double)lr / bc1);
+  // hyper-parameters arrive as the python doubles torch.optim.Adam uses; every derived scalar is formed in double and
+  // rounded to float once, exactly like torch's scalar arguments (1 - beta2 = 0.001, not 1.f - 0.999f)
+  const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+  const float step_size = (float)(lr / bc1);
   const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
   hipLaunchKernelGGL(adam_kernel, dim3(ew_grid((size_t)n / 4 + 1, 4096)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
-                     exp_avg_sq, (size_t)n, 1.f - beta1, beta2, 1.f - beta2, step_size, inv_bc2_sqrt, eps, grad_scale);
+                     exp_avg_sq, (size_t)n, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), step_size, inv_bc2_sqrt, (float)eps,
+                     (float)grad_scale);
   return fp_check_launch("fp_adam_step");
 }
 
@@ -377,7 +385,7 @@ extern "C" int fp_colsum(const float* x, int64_t M, int32_t C, float* out, int a
   FP_REQUIRE(workspace_bytes >= fp_colsum_workspace(M, C), "fp_colsum: workspace too small");
   const int nblk = colsum_blocks(M, C);
   hipLaunchKernelGGL(colsum_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, (int)M, C, (float*)workspace);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, nblk, C,
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, nblk, C,
                      out, accumulate);
   return fp_check_launch("fp_colsum");
 }

@@ -111,6 +111,7 @@ class Engine:
         self.weights_dirty = True
         self._versions = None
         self.saved = None
+        self.debug_hook = None      # tests/debugging: called after every encoder block of the backward schedule
 
     # ------------------------------------------------------------------------------------------------
     # parameters: one flat buffer, one flat gradient buffer (forward order, 16-byte aligned slots)
@@ -413,6 +414,8 @@ class Engine:
                 dx = buf("g.dx%d" % (i & 1), (N, hin, win, Cin))
                 ops.conv_igemm(dgd, dz1, None, blk.c1.wpd, dx, addend=g)
                 dnext = dx
+            if self.debug_hook is not None:
+                self.debug_hook(i, dict(dout=dout, g=g, dz2=dz2, da1=da1, dz1=dz1, dnext=dnext, B=B))
             if first_of_layer and on_stage is not None:
                 on_stage("encoder.layer%d" % (feat_of_block[min(k for k in feat_of_block if k >= i)]))
         # ---- stem ---------------------------------------------------------------------------------------

@@ -12,6 +12,7 @@ from . import _lib
 from ._lib import ConvDesc
 
 _workspaces = {}
+_NO_SPLITK = bool(int(__import__("os").environ.get("FP_NO_SPLITK", "0")))   # debugging aid: never split small grids along K
 
 
 def _chk(t, name="tensor"):
@@ -32,9 +33,9 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-def workspace(nbytes, device):
-    """Grow-only scratch buffer per device; safe because all kernels of a step are stream-ordered."""
-    key = (device.index if device.index is not None else torch.cuda.current_device())
+def workspace(nbytes, device, tag="main"):
+    """Grow-only scratch buffer per (device, tag); safe because all kernels of a step are stream-ordered."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), tag)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
@@ -57,8 +58,13 @@ def conv_igemm(desc, src0, src1, wpacked, y, bias=None, addend=None, addend_mask
         epi |= _lib.EPI_ADDEND_MASK
     d = ConvDesc.from_buffer_copy(desc)
     d.epi = epi
+    need = 0 if _NO_SPLITK else lib.fp_conv_igemm_workspace(C.byref(d))
+    ws_ptr, ws_n = 0, 0
+    if need > 0:
+        ws = workspace(need, y.device, "igemm")
+        ws_ptr, ws_n = ws.data_ptr(), ws.numel()
     _lib.check(lib.fp_conv_igemm(C.byref(d), _f32(src0, "src0"), _f32(src1, "src1"), _f32(wpacked, "wpacked"), _f32(bias),
-                                 _f32(addend), _f32(addend_mask), _f32(actsrc), _f32(y, "y"), stream()), "fp_conv_igemm")
+                                 _f32(addend), _f32(addend_mask), _f32(actsrc), _f32(y, "y"), ws_ptr, ws_n, stream()), "fp_conv_igemm")
     return y
 
 

@@ -68,10 +68,13 @@ typedef struct fp_conv_desc {
 /* Y[m][n] = epilogue( sum_{tap,k} A[m][tap,k] * Wp[tap][k][n] ).
  * Wp is the packed weight produced by fp_pack_conv_weight (fwd) / fp_pack_conv_weight_dgrad.
  * Replaces aten::convolution (+reflection_pad2d, upsample_nearest2d, cat, elu_) and the
- * data-gradient half of aten::convolution_backward (+elu_backward, relu mask, residual add). */
+ * data-gradient half of aten::convolution_backward (+elu_backward, relu mask, residual add).
+ * Small problems (few output tiles) are split along K across workgroups when `workspace` (>=
+ * fp_conv_igemm_workspace(d) bytes; may be NULL = never split) is given; partials are summed in a fixed order. */
+int64_t fp_conv_igemm_workspace(const fp_conv_desc* d);
 int fp_conv_igemm(const fp_conv_desc* d, const float* src0, const float* src1, const float* wpacked,
                   const float* bias, const float* addend, const float* addend_mask, const float* actsrc,
-                  float* y, fp_stream_t stream);
+                  float* y, void* workspace, int64_t workspace_bytes, fp_stream_t stream);
 
 /* Weight gradient: dW (OIHW [Nout][C0+C1][KH][KW]) = sum_m A[m][tap,k] * dZ[m][n]; A gathered as the
  * matching forward conv (desc.gather is a FWD_* / STEM mode, desc.OH/OW = conv output dims).
@@ -158,8 +161,9 @@ int fp_loss_fwd_bwd(const float* const preds[4], const float* visible_ground, co
                     int64_t workspace_bytes, fp_stream_t stream);
 
 /* ---- fused Adam over a flat parameter buffer (torch.optim.Adam, model_manager.py:27) ---- */
-int fp_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
-                 float beta2, float eps, int32_t step, float grad_scale, fp_stream_t stream);
+/* hyper-parameters are doubles (python floats) like torch's; gradients are multiplied by grad_scale (1/world under DP) */
+int fp_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double beta1,
+                 double beta2, double eps, int32_t step, double grad_scale, fp_stream_t stream);
 
 /* ---- misc ---- */
 int fp_nchw_to_nhwc(const float* x, float* y, int32_t N, int32_t C, int32_t H, int32_t W, fp_stream_t stream);

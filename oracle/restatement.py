@@ -153,8 +153,9 @@ def _basic_block(x, P, B, prefix, stride, has_ds, training):
     return F.relu(out + idt)
 
 
-def resnet_encoder(image, P, B, training):
-    """network.py:48-59 -- normalise, layer0 (conv7x7/2+BN+ReLU), layer1 (maxpool + 3 blocks), layer2..4."""
+def resnet_encoder(image, P, B, training, record=None):
+    """network.py:48-59 -- normalise, layer0 (conv7x7/2+BN+ReLU), layer1 (maxpool + 3 blocks), layer2..4.
+    record (optional list): receives every BasicBlock output (grad retained) for block-level debugging."""
     x = (image - 0.45) / 0.225                                            # network.py:50
     x = F.conv2d(x, P["encoder.layer0.0.weight"], None, 2, 3)
     x = F.relu(_bn(x, P, B, "encoder.layer0.1", training))
@@ -167,6 +168,10 @@ def resnet_encoder(image, P, B, training):
         for _ in range(nblk):
             prefix, cin, cout, stride, ds = blocks[bi]
             x = _basic_block(x, P, B, prefix, stride, ds, training)
+            if record is not None:
+                if x.requires_grad:
+                    x.retain_grad()
+                record.append(x)
             bi += 1
         feats.append(x)
     return feats
@@ -217,9 +222,9 @@ def skip_decoder(feats, P, prefix, apply_sigmoid):
     return out
 
 
-def footprint_network(image, P, B, training=True, return_features=False):
+def footprint_network(image, P, B, training=True, return_features=False, record=None):
     """FootprintNetwork.forward network.py:21-30."""
-    feats = resnet_encoder(image, P, B, training)
+    feats = resnet_encoder(image, P, B, training, record)
     m = skip_decoder(feats, P, "mask_decoder", False)       # network.py:18
     d = skip_decoder(feats, P, "depth_decoder", True)       # network.py:19
     out = OrderedDict((k, torch.cat([m[k], d[k]], 1)) for k in m)

@@ -46,11 +46,14 @@ def test_workspace_queries_and_argument_validation_without_gpu():
     lib = _lib.load()
     d = ops.make_desc(2, 8, 8, 8, 8, 16, 0, 8, 3, 1, 1, _lib.GATHER_FWD_REFLECT)
     assert lib.fp_conv_wgrad_workspace(C.byref(d)) > 0
+    assert lib.fp_conv_igemm_workspace(C.byref(d)) == 24 * 2 * 8 * 8 * 8 * 4      # small grid: split-K partials
+    big = ops.make_desc(12, 96, 320, 96, 320, 64, 0, 64, 3, 1, 1, _lib.GATHER_FWD_REFLECT)
+    assert lib.fp_conv_igemm_workspace(C.byref(big)) == 0
     assert lib.fp_packed_weight_elems(64, 3, 7, 7, 0, 1) == 10 * 64 * 16
     assert lib.fp_packed_weight_elems(8, 20, 3, 3, 0, 0) == 9 * 2 * 8 * 16
     assert lib.fp_loss_workspace(12, 192, 640) > 0
     bad = ops.make_desc(2, 8, 8, 8, 8, 6, 0, 8, 3, 1, 1, _lib.GATHER_FWD_REFLECT)     # C0 not a multiple of 4
-    rc = lib.fp_conv_igemm(C.byref(bad), 1, 0, 1, 0, 0, 0, 0, 1, None)
+    rc = lib.fp_conv_igemm(C.byref(bad), 1, 0, 1, 0, 0, 0, 0, 1, None, 0, None)
     assert rc == -1 and b"multiples of 4" in lib.fp_last_error_string()
 
 
