@@ -13,10 +13,17 @@ Design (MI355X-first, not an autograd graph):
 Reference call stack being replaced: FootprintNetwork.forward (network.py:21-30) and autograd's backward of
 it (training/train.py:155).
 """
+import os
+
 import torch
 
 from . import _lib as L
 from . import ops
+
+# Concurrency: the two decoders are independent, and every weight gradient is off the critical dgrad chain.
+# Running them on side streams lets workgroups of 2-3 kernels share the CUs, which fills the occupancy ramp /
+# tail of each launch (a conv launch is only ~2-3 "rounds" of workgroups per CU).  FP_SERIAL=1 disables it.
+_CONCURRENT = not bool(int(os.environ.get("FP_SERIAL", "0")))
 
 SCALE_KEYS = ("1/8", "1/4", "1/2", "1/1")
 
@@ -112,6 +119,10 @@ class Engine:
         self._versions = None
         self.saved = None
         self.debug_hook = None      # tests/debugging: called after every encoder block of the backward schedule
+        self.concurrent = _CONCURRENT
+        self.aux = torch.cuda.Stream(device=self.device)    # second decoder
+        self.wg = torch.cuda.Stream(device=self.device)     # encoder weight gradients
+        self._ev_dF = [None] * 5
 
     # ------------------------------------------------------------------------------------------------
     # parameters: one flat buffer, one flat gradient buffer (forward order, 16-byte aligned slots)
@@ -208,6 +219,12 @@ class Engine:
     # ------------------------------------------------------------------------------------------------
     # small helpers over the ops
     # ------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _record(stream):
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        return ev
+
     def _bn_coeffs(self, rec, z, training):
         bn = rec.bn
         M = z.numel() // rec.C
@@ -290,9 +307,17 @@ class Engine:
         # ---- decoders -------------------------------------------------------------------------------
         if outputs is None:
             outputs = [torch.empty((N, 4, H, W), device=self.device) for _ in range(4)]
-        S["dec"] = []
-        for dec in self.decoders:
-            S["dec"].append(self._decoder_forward(dec, S, outputs))
+        S["dec"] = [None, None]
+        main = torch.cuda.current_stream()
+        if self.concurrent:
+            self.aux.wait_event(self._record(main))                 # encoder features ready
+            with torch.cuda.stream(self.aux):
+                S["dec"][1] = self._decoder_forward(self.decoders[1], S, outputs)
+            S["dec"][0] = self._decoder_forward(self.decoders[0], S, outputs)
+            main.wait_stream(self.aux)                              # join: both decoders wrote their output channels
+        else:
+            for di, dec in enumerate(self.decoders):
+                S["dec"][di] = self._decoder_forward(dec, S, outputs)
         self.saved = S if save_for_backward else None
         return outputs
 
@@ -336,8 +361,17 @@ class Engine:
     # ------------------------------------------------------------------------------------------------
     # backward
     # ------------------------------------------------------------------------------------------------
-    def _wgrad(self, c, gather, src0, src1, dz, N, OH, OW, IH, IW, C0, C1, acc):
+    def _wgrad(self, c, gather, src0, src1, dz, N, OH, OW, IH, IW, C0, C1, acc, side=None):
+        """Weight (+bias) gradient of one conv.  side = a stream: launch there, ordered after everything already
+        queued on the current stream (dz is ready) -- the caller guarantees dz / src stay untouched until the join."""
         d = ops.make_desc(N, OH, OW, IH, IW, C0, C1, c.Cout, c.K, c.stride, c.pad, gather)
+        if side is not None:
+            side.wait_event(self._record(torch.cuda.current_stream()))
+            with torch.cuda.stream(side):
+                ops.conv_wgrad(d, src0, src1, dz, c.gw, accumulate=acc)
+                if c.gb is not None:
+                    ops.colsum(dz.view(-1, c.Cout), c.gb, accumulate=acc)
+            return
         ops.conv_wgrad(d, src0, src1, dz, c.gw, accumulate=acc)
         if c.gb is not None:
             ops.colsum(dz.view(-1, c.Cout), c.gb, accumulate=acc)
@@ -362,10 +396,25 @@ class Engine:
         buf = self.buf
         gouts = [g.contiguous() for g in grad_outputs]
         dF = [buf("dF%d" % i, tuple(f.shape)) for i, f in enumerate(feats)]
-        for di, dec in enumerate(self.decoders):
-            self._decoder_backward(dec, S["dec"][di], S, gouts, dF, first=(di == 0), acc=accumulate)
+        main = torch.cuda.current_stream()
+        if self.concurrent:
+            # mask decoder on the main stream, depth decoder on the aux stream; the depth decoder ACCUMULATES into the
+            # feature gradients, so each of its accumulate launches waits for the mask decoder's write of that level
+            self._ev_dF = [None] * 5
+            self.aux.wait_event(self._record(main))
+            self._decoder_backward(self.decoders[0], S["dec"][0], S, gouts, dF, first=True, acc=accumulate)
+            with torch.cuda.stream(self.aux):
+                self._decoder_backward(self.decoders[1], S["dec"][1], S, gouts, dF, first=False, acc=accumulate)
+            main.wait_stream(self.aux)
             if on_stage is not None:
-                on_stage(dec.name)
+                on_stage(self.decoders[0].name)
+                on_stage(self.decoders[1].name)
+        else:
+            for di, dec in enumerate(self.decoders):
+                self._decoder_backward(dec, S["dec"][di], S, gouts, dF, first=(di == 0), acc=accumulate)
+                if on_stage is not None:
+                    on_stage(dec.name)
+        side = self.wg if self.concurrent else None
         # ---- encoder ----------------------------------------------------------------------------------
         nblk = len(self.blocks)
         feat_of_block = {}
@@ -381,24 +430,24 @@ class Engine:
             C, Cin = blk.Cout, blk.Cin
             M = N * h * w
             dout = dF[feat_of_block[i]] if i in feat_of_block else dnext
-            dz2 = buf("g.dz2", (N, h, w, C))
+            dz2 = buf("g.dz2.%d" % i, (N, h, w, C))      # per-block: read later by the side-stream wgrad
             g = buf("g.g", (N, h, w, C))
             ops.bn_bwd(dout.view(M, C), B["out"].view(M, C), B["z2"].view(M, C), blk.bn2.mean, blk.bn2.invstd, blk.bn2.bn.weight.data,
                        dz2.view(M, C), blk.bn2.gg, blk.bn2.gb, g_out=g.view(M, C), accumulate=accumulate)
-            self._wgrad(blk.c2, L.GATHER_FWD_ZERO, B["a1"], None, dz2, N, h, w, h, w, C, 0, accumulate)
+            self._wgrad(blk.c2, L.GATHER_FWD_ZERO, B["a1"], None, dz2, N, h, w, h, w, C, 0, accumulate, side)
             da1 = buf("g.da1", (N, h, w, C))
             ops.conv_igemm(ops.make_desc(N, h, w, h, w, C, 0, C, 3, 1, 1, L.GATHER_DGRAD_ZERO), dz2, None, blk.c2.wpd, da1)
-            dz1 = buf("g.dz1", (N, h, w, C))
+            dz1 = buf("g.dz1.%d" % i, (N, h, w, C))
             ops.bn_bwd(da1.view(M, C), B["a1"].view(M, C), B["z1"].view(M, C), blk.bn1.mean, blk.bn1.invstd, blk.bn1.bn.weight.data,
                        dz1.view(M, C), blk.bn1.gg, blk.bn1.gb, accumulate=accumulate)
-            self._wgrad(blk.c1, L.GATHER_FWD_ZERO, B["x"], None, dz1, N, h, w, hin, win, Cin, 0, accumulate)
+            self._wgrad(blk.c1, L.GATHER_FWD_ZERO, B["x"], None, dz1, N, h, w, hin, win, Cin, 0, accumulate, side)
             first_of_layer = (i == 0) or blk.stride == 2
             dgd = ops.make_desc(N, hin, win, h, w, C, 0, Cin, 3, blk.stride, 1, L.GATHER_DGRAD_ZERO)
             if blk.ds is not None:
-                dzd = buf("g.dzd", (N, h, w, C))
+                dzd = buf("g.dzd.%d" % i, (N, h, w, C))
                 ops.bn_bwd(g.view(M, C), None, B["zd"].view(M, C), blk.bnd.mean, blk.bnd.invstd, blk.bnd.bn.weight.data,
                            dzd.view(M, C), blk.bnd.gg, blk.bnd.gb, accumulate=accumulate)
-                self._wgrad(blk.ds, L.GATHER_FWD_ZERO, B["x"], None, dzd, N, h, w, hin, win, Cin, 0, accumulate)
+                self._wgrad(blk.ds, L.GATHER_FWD_ZERO, B["x"], None, dzd, N, h, w, hin, win, Cin, 0, accumulate, side)
                 tgt = dF[feat_of_block[i - 1]]          # block input is the previous layer's feature (already holds decoder grads)
                 dgd.epi = L.EPI_ACCUM
                 ops.conv_igemm(dgd, dz1, None, blk.c1.wpd, tgt)
@@ -417,6 +466,8 @@ class Engine:
             if self.debug_hook is not None:
                 self.debug_hook(i, dict(dout=dout, g=g, dz2=dz2, da1=da1, dz1=dz1, dnext=dnext, B=B))
             if first_of_layer and on_stage is not None:
+                if side is not None:
+                    main.wait_stream(side)        # this layer's weight gradients live on the side stream
                 on_stage("encoder.layer%d" % (feat_of_block[min(k for k in feat_of_block if k >= i)]))
         # ---- stem ---------------------------------------------------------------------------------------
         h0, w0 = dims[0]
@@ -427,35 +478,48 @@ class Engine:
                    dz0.view(M0, 64), self.bn0.gg, self.bn0.gb, accumulate=accumulate)
         d = ops.make_desc(N, h0, w0, S["H"], S["W"], 3, 0, 64, 7, 2, 3, L.GATHER_STEM)
         ops.conv_wgrad(d, S["image"], None, dz0, self.stem.gw, accumulate=accumulate)
+        if side is not None:
+            main.wait_stream(side)                # join: every weight gradient is complete
         if on_stage is not None:
             on_stage("encoder.layer0")
 
     def _decoder_backward(self, dec, D, S, gouts, dF, first, acc):
         N, feats, dims = S["N"], S["feats"], S["dims"]
         buf = self.buf
+        pfx = "g.%s." % dec.name                    # per-decoder temporaries: the two decoders may run concurrently
         H, W = S["H"], S["W"]
         accum_feat = not first                      # the second decoder accumulates into the feature gradients
+        cur = torch.cuda.current_stream()
+
+        def order_dF(k):
+            """first decoder: publish its write of dF[k]; second: wait for it before accumulating (fixed order)."""
+            if not self.concurrent:
+                return
+            if first:
+                self._ev_dF[k] = self._record(cur)
+            elif self._ev_dF[k] is not None:
+                cur.wait_event(self._ev_dF[k])
         # ---- full-resolution tail: head4 <- o42 <- o41 <- up2(x4) ------------------------------------
         x4 = D["x"][3]
         h0, w0 = dims[0]
-        dzl = buf("g.dzl", (N, H, W, 2))
+        dzl = buf(pfx + "dzl", (N, H, W, 2))
         ops.head_upsample_bwd(gouts[3], D["low"][3], dzl, 1, dec.c0, dec.sig)
         hd = dec.heads[3]
         ops.head_wgrad(D["x5"], dzl, hd.gw, hd.gb, accumulate=acc)
-        A = buf("g.A", (N, H, W, 32))
+        A = buf(pfx + "A", (N, H, W, 32))
         ops.head_dgrad(dzl, hd.w.data, A, elu_src=D["x5"])
         self._wgrad(dec.o42, L.GATHER_FWD_REFLECT, D["y51"], None, A, N, H, W, H, W, 32, 0, acc)
-        Bz = self._dgrad_dec(dec.o42, A, N, H, W, buf("g.B", (N, H, W, 32)), actsrc=D["y51"])
+        Bz = self._dgrad_dec(dec.o42, A, N, H, W, buf(pfx + "B", (N, H, W, 32)), actsrc=D["y51"])
         self._wgrad(dec.o41, L.GATHER_FWD_REFLECT_UP2, x4, None, Bz, N, H, W, H, W, 64, 0, acc)
-        XV = self._dgrad_dec(dec.o41, Bz, N, H, W, buf("g.XV", (N, H, W, 64)))
+        XV = self._dgrad_dec(dec.o41, Bz, N, H, W, buf(pfx + "XV", (N, H, W, 64)))
         # head3 on x4
-        dzl = buf("g.dzl", (N, h0, w0, 2))
+        dzl = buf(pfx + "dzl", (N, h0, w0, 2))
         ops.head_upsample_bwd(gouts[2], D["low"][2], dzl, 2, dec.c0, dec.sig)
         hd = dec.heads[2]
         ops.head_wgrad(x4, dzl, hd.gw, hd.gb, accumulate=acc)
-        XH = buf("g.XH", (N, h0, w0, 64))
+        XH = buf(pfx + "XH", (N, h0, w0, 64))
         ops.head_dgrad(dzl, hd.w.data, XH)
-        A = buf("g.A", (N, h0, w0, 64))
+        A = buf(pfx + "A", (N, h0, w0, 64))
         ops.up2cat_bwd(XV, N, h0, w0, 64, 0, A, addend=XH, ylow=x4)
         # ---- blocks 4..1 ----------------------------------------------------------------------------------
         chans = [(512, 256), (256, 128), (128, 64), (64, 64)]
@@ -469,27 +533,35 @@ class Engine:
             xin = D["x"][bi - 1] if bi > 0 else feats[4]
             # A = dZ of post2 at (hh, ww)
             self._wgrad(blk["post2"], L.GATHER_FWD_REFLECT, y3, None, A, N, hh, ww, hh, ww, cout, 0, acc)
-            Bz = self._dgrad_dec(blk["post2"], A, N, hh, ww, buf("g.B", (N, hh, ww, cout)), actsrc=y3)
+            Bz = self._dgrad_dec(blk["post2"], A, N, hh, ww, buf(pfx + "B", (N, hh, ww, cout)), actsrc=y3)
             self._wgrad(blk["post1"], L.GATHER_FWD_REFLECT_UP2, y2, skip, Bz, N, hh, ww, hh, ww, cout, cout, acc)
-            XV = self._dgrad_dec(blk["post1"], Bz, N, hh, ww, buf("g.XV", (N, hh, ww, 2 * cout)))
-            A = buf("g.A", (N, hl, wl, cout))
+            XV = self._dgrad_dec(blk["post1"], Bz, N, hh, ww, buf(pfx + "XV", (N, hh, ww, 2 * cout)))
+            A = buf(pfx + "A", (N, hl, wl, cout))
+            if not first:
+                order_dF(3 - bi)
             ops.up2cat_bwd(XV, N, hl, wl, cout, cout, A, ylow=y2, dskip=dF[3 - bi], accumulate_skip=accum_feat)
+            if first:
+                order_dF(3 - bi)
             self._wgrad(blk["pre2"], L.GATHER_FWD_REFLECT, y1, None, A, N, hl, wl, hl, wl, cout, 0, acc)
-            Bz = self._dgrad_dec(blk["pre2"], A, N, hl, wl, buf("g.B", (N, hl, wl, cout)), actsrc=y1)
+            Bz = self._dgrad_dec(blk["pre2"], A, N, hl, wl, buf(pfx + "B", (N, hl, wl, cout)), actsrc=y1)
             self._wgrad(blk["pre1"], L.GATHER_FWD_REFLECT, xin, None, Bz, N, hl, wl, hl, wl, cin, 0, acc)
             if bi == 0:
+                if not first:
+                    order_dF(4)
                 self._dgrad_dec(blk["pre1"], Bz, N, hl, wl, dF[4], accum=accum_feat)
+                if first:
+                    order_dF(4)
             else:
                 XH = None
                 if bi >= 2:                          # heads on block2 / block3 outputs (x2: scale 8, x3: scale 4)
                     k = bi - 2
-                    dzl = buf("g.dzl", (N, hl, wl, 2))
+                    dzl = buf(pfx + "dzl", (N, hl, wl, 2))
                     ops.head_upsample_bwd(gouts[k], D["low"][k], dzl, (8, 4)[k], dec.c0, dec.sig)
                     hd = dec.heads[k]
                     ops.head_wgrad(xin, dzl, hd.gw, hd.gb, accumulate=acc)
-                    XH = buf("g.XH", (N, hl, wl, cin))
+                    XH = buf(pfx + "XH", (N, hl, wl, cin))
                     ops.head_dgrad(dzl, hd.w.data, XH)
-                A = self._dgrad_dec(blk["pre1"], Bz, N, hl, wl, buf("g.A2", (N, hl, wl, cin)), actsrc=xin, addend=XH)
+                A = self._dgrad_dec(blk["pre1"], Bz, N, hl, wl, buf(pfx + "A2", (N, hl, wl, cin)), actsrc=xin, addend=XH)
 
     # ------------------------------------------------------------------------------------------------
     def bind_grads(self, accumulate_existing=True):

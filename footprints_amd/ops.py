@@ -35,7 +35,8 @@ def stream():
 
 def workspace(nbytes, device, tag="main"):
     """Grow-only scratch buffer per (device, tag); safe because all kernels of a step are stream-ordered."""
-    key = (device.index if device.index is not None else torch.cuda.current_device(), tag)
+    # one scratch buffer per (device, stream, tag): kernels on concurrent streams must not share partials
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream, tag)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)

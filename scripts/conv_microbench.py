@@ -4,7 +4,7 @@
 """
 import sys
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from footprints_amd import ops, _lib as L
 
 which = sys.argv[1] if len(sys.argv) > 1 else "igemm"

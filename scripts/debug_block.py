@@ -2,7 +2,7 @@
 import sys
 import torch
 import torch.nn.functional as F
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from oracle import restatement as R
 from oracle.cpu_threads import effective_cores
 from footprints_amd import FootprintNetwork

@@ -1,7 +1,7 @@
 """Debug helper (GPU box): engine feature gradients dF[k] (total gradient wrt encoder features) vs the oracle."""
 import sys
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from oracle import restatement as R
 from oracle.cpu_threads import effective_cores
 from footprints_amd import FootprintNetwork
