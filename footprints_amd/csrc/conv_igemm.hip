@@ -17,7 +17,12 @@
 // v_mfma_f32_32x32x2_f32 is an exact k-ordered fmaf chain (64 cycles/SIMD, 157 TF peak), so the kernel is
 // MFMA-issue bound by design; global->LDS staging is software-pipelined through registers with two LDS
 // buffers and a single barrier per K-step.
+#include <stdlib.h>
+
 #include "fp_common.h"
+
+int fp_conv3x3_tile_dispatch(const fp_conv_desc* d, const float* src0, const float* src1, const float* wpacked, const float* bias,
+                             const float* addend, const float* addend_mask, const float* actsrc, float* y, hipStream_t stream);
 
 namespace {
 
@@ -283,6 +288,13 @@ extern "C" int fp_conv_igemm(const fp_conv_desc* d, const float* src0, const flo
   FP_REQUIRE(M64 * (int64_t)(d->Nout > d->C0 + d->C1 ? d->Nout : d->C0 + d->C1) < (int64_t)1 << 40 && M64 < (int64_t)1 << 31,
              "fp_conv_igemm: problem too large");
 
+  if (!stem) {   // 3x3 stride-1 convs on large grids: halo-tile kernel (conv3x3_tile.hip)
+    static const bool no_tile = getenv("FP_NO_TILE") && atoi(getenv("FP_NO_TILE"));
+    if (!no_tile) {
+      const int rc = fp_conv3x3_tile_dispatch(d, src0, src1, wpacked, bias, addend, addend_mask, actsrc, y, stream);
+      if (rc != -1000) return rc;
+    }
+  }
   IgemmArgs a;
   a.src0 = src0; a.src1 = src1; a.w = wpacked; a.bias = bias; a.addend = addend; a.addend_mask = addend_mask;
   a.actsrc = actsrc; a.y = y;

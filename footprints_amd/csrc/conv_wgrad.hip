@@ -12,7 +12,13 @@
 // and writes one partial tile; fp_wgrad_reduce then sums the S partials in a fixed order and writes the
 // torch OIHW gradient.  Replaces the weight half of aten::convolution_backward (reference call site:
 // footprints/training/train.py:155 `batch_loss.backward()`).
+#include <stdlib.h>
+
 #include "fp_common.h"
+
+int64_t fp_wgrad3x3_tile_workspace(const fp_conv_desc* d);
+int fp_wgrad3x3_tile_dispatch(const fp_conv_desc* d, const float* src0, const float* src1, const float* dz, float* dw_oihw,
+                              int accumulate, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 
 namespace {
 
@@ -243,12 +249,30 @@ Plan make_plan(const fp_conv_desc* d) {
   return p;
 }
 
+bool use_tile() {
+  static const bool off = getenv("FP_NO_WTILE") && atoi(getenv("FP_NO_WTILE"));
+  return !off;
+}
+
 }  // namespace
+
+int fp_wgrad_reduce_launch(const float* part, float* dw, int S, int T, int Kc, int Nout, int stem, int accumulate, hipStream_t stream) {
+  const int64_t total = (int64_t)T * Kc * Nout;
+  int rgrid = (int)fp_ceil_div(total, 256);
+  if (rgrid > 4096) rgrid = 4096;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rgrid), dim3(256), 0, stream, part, dw, S, T, Kc, Nout, stem, accumulate);
+  return fp_check_launch("fp_conv_wgrad(reduce)");
+}
 
 extern "C" int64_t fp_conv_wgrad_workspace(const fp_conv_desc* d) {
   if (!d) return 0;
   const Plan p = make_plan(d);
-  return (int64_t)p.S * p.T * p.Kc * d->Nout * (int64_t)sizeof(float);
+  int64_t need = (int64_t)p.S * p.T * p.Kc * d->Nout * (int64_t)sizeof(float);
+  if (d->gather != FP_GATHER_STEM && use_tile()) {
+    const int64_t t = fp_wgrad3x3_tile_workspace(d);
+    if (t > need) need = t;
+  }
+  return need;
 }
 
 extern "C" int fp_conv_wgrad(const fp_conv_desc* d, const float* src0, const float* src1, const float* dz, float* dw_oihw,
@@ -262,6 +286,10 @@ extern "C" int fp_conv_wgrad(const fp_conv_desc* d, const float* src0, const flo
   FP_REQUIRE(d->C1 == 0 || src1, "fp_conv_wgrad: src1 missing");
   const Plan p = make_plan(d);
   FP_REQUIRE(workspace_bytes >= fp_conv_wgrad_workspace(d), "fp_conv_wgrad: workspace too small");
+  if (!stem && use_tile()) {    // 3x3 stride-1 convs with 32-aligned channels: all-taps LDS-DMA kernel (wgrad3x3_tile.hip)
+    const int rc = fp_wgrad3x3_tile_dispatch(d, src0, src1, dz, dw_oihw, accumulate, workspace, workspace_bytes, stream);
+    if (rc != -1000) return rc;
+  }
   WgradArgs a;
   a.src0 = src0; a.src1 = src1; a.dz = dz; a.part = (float*)workspace;
   a.g = FpGeom{d->N, d->OH, d->OW, d->IH, d->IW, d->C0, d->C1, d->KH, d->KW, d->stride, d->pad, d->gather};
@@ -279,10 +307,5 @@ extern "C" int fp_conv_wgrad(const fp_conv_desc* d, const float* src0, const flo
   }
   int rc = fp_check_launch("fp_conv_wgrad");
   if (rc) return rc;
-  const int64_t total = (int64_t)p.T * p.Kc * d->Nout;
-  int rgrid = (int)fp_ceil_div(total, 256);
-  if (rgrid > 4096) rgrid = 4096;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rgrid), dim3(256), 0, stream, (const float*)workspace, dw_oihw, p.S, p.T, p.Kc,
-                     d->Nout, stem ? 1 : 0, accumulate);
-  return fp_check_launch("fp_conv_wgrad(reduce)");
+  return fp_wgrad_reduce_launch((const float*)workspace, dw_oihw, p.S, p.T, p.Kc, d->Nout, stem ? 1 : 0, accumulate, stream);
 }

@@ -109,6 +109,64 @@ def test_conv_stem(N, H, W):
 
 
 # ----------------------------------------------------------------------------------------------------------
+# halo-tile 3x3 kernel (conv3x3_tile.hip): shapes large enough (>= 384 workgroups) to be dispatched to it
+# ----------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode,N,H,W,C0,C1,Cout", [
+    ("zero", 12, 48, 160, 64, 0, 64), ("reflect", 4, 96, 320, 64, 0, 64), ("reflect", 2, 192, 640, 32, 0, 32),
+    ("up2", 4, 96, 320, 64, 64, 64), ("up2", 2, 192, 640, 64, 0, 32), ("reflect", 12, 24, 80, 128, 0, 128),
+    ("zero", 6, 40, 176, 32, 0, 96), ("dgrad", 12, 48, 160, 64, 0, 64), ("dgrad", 6, 24, 80, 128, 0, 128),
+    ("dgrad_reflect", 12, 48, 160, 64, 0, 64), ("dgrad_reflect", 2, 192, 640, 32, 0, 32), ("dgrad_reflect", 4, 40, 144, 64, 0, 128),
+    ("dgrad_reflect", 12, 24, 80, 128, 0, 64)])
+def test_conv3x3_tile_kernel(mode, N, H, W, C0, C1, Cout):
+    ops, L = _ops()
+    if mode == "dgrad_reflect":       # data-gradient of a reflection-padded conv + ELU' + second-consumer addend
+        pre = rnd((N, C0, H, W), 92, -2.0, 2.0).requires_grad_(True)
+        w = rnd((Cout, C0, 3, 3), 93, -0.1, 0.1)
+        x = F.elu(pre)
+        yr = F.conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect"), w)
+        g, extra = rnd(tuple(yr.shape), 94), rnd(tuple(x.shape), 95)
+        ((yr * g).sum() + (x * extra).sum()).backward()
+        dz = torch.empty((N, H, W, C0), device="cuda")
+        d = ops.make_desc(N, H, W, H, W, Cout, 0, C0, 3, 1, 1, L.GATHER_DGRAD_REFLECT, epi=L.EPI_ACTGRAD_ELU)
+        ops.conv_igemm(d, nhwc(g), None, pack(w, dgrad=True), dz, actsrc=nhwc(x.detach()), addend=nhwc(extra))
+        check(nchw(dz), pre.grad, "tile dgrad_reflect (fold) + epilogue")
+        return
+    if mode == "dgrad":
+        x = rnd((N, C0, H, W), 80).requires_grad_(True)
+        w = rnd((Cout, C0, 3, 3), 81, -0.1, 0.1)
+        yr = F.conv2d(x, w, None, 1, 1)
+        g = rnd(tuple(yr.shape), 82)
+        add, msk, act = rnd(tuple(x.shape), 83), rnd(tuple(x.shape), 84), rnd(tuple(x.shape), 85)
+        yr.backward(g)
+        ref = (x.grad + add * (msk > 0).float()) * (act > 0).float()
+        dx = torch.empty((N, H, W, C0), device="cuda")
+        d = ops.make_desc(N, H, W, H, W, Cout, 0, C0, 3, 1, 1, L.GATHER_DGRAD_ZERO, epi=L.EPI_ACTGRAD_RELU)
+        ops.conv_igemm(d, nhwc(g), None, pack(w, dgrad=True), dx, addend=nhwc(add), addend_mask=nhwc(msk), actsrc=nhwc(act))
+        check(nchw(dx), ref, "tile dgrad_zero + epilogue")
+        return
+    w, b = rnd((Cout, C0 + C1, 3, 3), 86, -0.1, 0.1), rnd((Cout,), 87)
+    if mode == "up2":
+        lo = rnd((N, C0, H // 2, W // 2), 88)
+        skip = rnd((N, C1, H, W), 89) if C1 else None
+        up = F.interpolate(lo, scale_factor=2, mode="nearest")
+        xin = torch.cat([up, skip], 1) if C1 else up
+        ref = F.elu(F.conv2d(F.pad(xin, (1, 1, 1, 1), mode="reflect"), w, b))
+        src0, src1, gather = nhwc(lo), (nhwc(skip) if C1 else None), L.GATHER_FWD_REFLECT_UP2
+    elif mode == "reflect":
+        x = rnd((N, C0, H, W), 90)
+        ref = F.elu(F.conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect"), w, b))
+        src0, src1, gather = nhwc(x), None, L.GATHER_FWD_REFLECT
+    else:
+        x = rnd((N, C0, H, W), 91)
+        ref = F.elu(F.conv2d(x, w, b, 1, 1))
+        src0, src1, gather = nhwc(x), None, L.GATHER_FWD_ZERO
+    y = torch.empty((N, H, W, Cout), device="cuda")
+    d = ops.make_desc(N, H, W, H, W, C0, C1, Cout, 3, 1, 1, gather, act=L.ACT_ELU)
+    ops.conv_igemm(d, src0, src1, pack(w), y, bias=b.cuda())
+    check(nchw(y), ref, "tile conv " + mode)
+
+
+# ----------------------------------------------------------------------------------------------------------
 # data gradients
 # ----------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("N,H,W,Cin,Cout,K,stride", [(2, 8, 12, 16, 8, 3, 1), (2, 9, 13, 16, 24, 3, 2), (2, 12, 40, 64, 128, 3, 2),
@@ -252,6 +310,39 @@ def test_conv_wgrad_up2cat_and_bwd(N, h, w, C0, C1, Cout):
     check(nchw(dlow), pre.grad, "up2cat_bwd dlow")
     if C1:
         check(nchw(dskip), skip.grad + 1.0, "up2cat_bwd dskip(accumulate)")
+
+
+@pytest.mark.parametrize("mode,N,H,W,C0,C1,Cout", [
+    ("zero", 12, 48, 160, 64, 0, 64), ("reflect", 4, 96, 320, 64, 0, 32), ("reflect", 2, 192, 640, 32, 0, 32),
+    ("up2", 4, 96, 320, 64, 64, 64), ("up2", 2, 192, 640, 64, 0, 32), ("reflect", 12, 24, 80, 128, 0, 128),
+    ("zero", 6, 12, 40, 256, 0, 256), ("reflect", 3, 10, 44, 32, 0, 96), ("up2", 2, 24, 80, 128, 128, 128)])
+def test_wgrad3x3_tile_kernel(mode, N, H, W, C0, C1, Cout):
+    """All-taps LDS-DMA weight-gradient kernel (wgrad3x3_tile.hip): 32-aligned channels, 3x3 stride 1."""
+    ops, L = _ops()
+    w = rnd((Cout, C0 + C1, 3, 3), 96, -0.1, 0.1).requires_grad_(True)
+    if mode == "up2":
+        lo = rnd((N, C0, H // 2, W // 2), 97)
+        skip = rnd((N, C1, H, W), 98) if C1 else None
+        up = F.interpolate(lo, scale_factor=2, mode="nearest")
+        xin = torch.cat([up, skip], 1) if C1 else up
+        y = F.conv2d(F.pad(xin, (1, 1, 1, 1), mode="reflect"), w)
+        src0, src1, gather = nhwc(lo), (nhwc(skip) if C1 else None), L.GATHER_FWD_REFLECT_UP2
+    elif mode == "reflect":
+        x = rnd((N, C0, H, W), 99)
+        y = F.conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect"), w)
+        src0, src1, gather = nhwc(x), None, L.GATHER_FWD_REFLECT
+    else:
+        x = rnd((N, C0, H, W), 100)
+        y = F.conv2d(x, w, None, 1, 1)
+        src0, src1, gather = nhwc(x), None, L.GATHER_FWD_ZERO
+    g = rnd(tuple(y.shape), 101)
+    y.backward(g)
+    d = ops.make_desc(N, H, W, H, W, C0, C1, Cout, 3, 1, 1, gather)
+    dw = torch.empty((Cout, C0 + C1, 3, 3), device="cuda")
+    ops.conv_wgrad(d, src0, src1, nhwc(g), dw)
+    check(dw, w.grad, "wgrad tile " + mode)
+    ops.conv_wgrad(d, src0, src1, nhwc(g), dw, accumulate=True)
+    check(dw, 2 * w.grad, "wgrad tile accumulate " + mode)
 
 
 def test_stem_wgrad():
