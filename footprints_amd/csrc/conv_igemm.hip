@@ -215,9 +215,14 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmArgs a) {
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(const IgemmArgs a) {
   const size_t total = (size_t)a.M * a.Nout;
   for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (size_t)gridDim.x * 256) {
-    float v = 0.f;
-    for (int s = 0; s < a.SK; ++s) v += a.part[(size_t)s * total + o];
-    a.y[o] = igemm_epilogue(a, o, (int)(o % a.Nout), v);
+    float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;              // four loads in flight, fixed combination order
+    int s = 0;
+    for (; s + 4 <= a.SK; s += 4) {
+      const float* q = a.part + (size_t)s * total + o;
+      p0 += q[0]; p1 += q[total]; p2 += q[2 * total]; p3 += q[3 * total];
+    }
+    for (; s < a.SK; ++s) p0 += a.part[(size_t)s * total + o];
+    a.y[o] = igemm_epilogue(a, o, (int)(o % a.Nout), (p0 + p1) + (p2 + p3));
   }
 }
 

@@ -208,8 +208,16 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
                                                            int Kc, int Nout, int stem, int accumulate) {
   const size_t total = (size_t)T * Kc * Nout;
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
-    float sum = 0.f;
-    for (int s = 0; s < S; ++s) sum += part[(size_t)s * total + e];
+    // eight independent partial sums keep eight loads in flight (fixed combination order => deterministic)
+    float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f, p4 = 0.f, p5 = 0.f, p6 = 0.f, p7 = 0.f;
+    int s = 0;
+    for (; s + 8 <= S; s += 8) {
+      const float* q = part + (size_t)s * total + e;
+      p0 += q[0]; p1 += q[total]; p2 += q[2 * total]; p3 += q[3 * total];
+      p4 += q[4 * total]; p5 += q[5 * total]; p6 += q[6 * total]; p7 += q[7 * total];
+    }
+    for (; s < S; ++s) p0 += part[(size_t)s * total + e];
+    const float sum = ((p0 + p1) + (p2 + p3)) + ((p4 + p5) + (p6 + p7));
     const int n = (int)(e % Nout);
     const size_t r = e / Nout;
     const int k = (int)(r % Kc), tap = (int)(r / Kc);
