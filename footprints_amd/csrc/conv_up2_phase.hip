@@ -1,0 +1,360 @@
+// 3x3 reflection-padded convolution on a nearest-x2 upsampled input, WITHOUT the upsample and with 2.25x fewer MACs.
+//
+// nearest-x2 repeats every low-resolution pixel 2x2 times, so the nine taps of a hi-res output pixel only ever see
+// 2x2 distinct low-res pixels.  For output phase (dy, dx) = (row parity, column parity):
+//
+//     out[2y+dy][2x+dx] = sum_{a,b in {0,1}}  Wc[dy,dx][a][b] . low[clamp(y + dy - 1 + a)][clamp(x + dx - 1 + b)]
+//
+// with collapsed weights  Wc[0][0] = W[ky=0], Wc[0][1] = W[1] + W[2],  Wc[1][0] = W[0] + W[1], Wc[1][1] = W[2]
+// (same along x), and ReflectionPad2d(1) at hi-res == replicate (clamp) padding at low-res (hi-res row -1 mirrors to
+// row 1 -> low-res row 0; row H mirrors to H-2 -> low-res row h-1).  Exact same mathematics as
+// F.interpolate(nearest, x2) -> ReflectionPad2d(1) -> conv3x3 (reference footprints/network.py:98,154,126-134); only
+// the floating-point association of the weight sums differs (1 ulp-level).
+//
+// Kernel = the halo-tile scheme of conv3x3_tile.hip on the LOW-RES grid: a workgroup owns one phase of an 8 x 16 tile of
+// low-res positions (128 strided hi-res output pixels), stages the 10 x 18 low-res halo once per 16-channel chunk and
+// runs the phase's four taps from LDS; weights [phase][tap][chunk][n][16] come straight from L1/L2.
+// The skip half of a concat conv is done by conv3x3_tile.hip on the skip tensor alone; this kernel then adds its
+// partial sums through the `addend` epilogue input (addend == y, in place) before bias / ELU.
+#include "fp_common.h"
+
+namespace {
+
+constexpr int LD = 20, TH = 8, TW = 16, HW2 = TW + 2, HP = (TH + 2) * HW2;
+
+struct PhaseArgs {
+  const float* low;     // [N][h][w][C0]
+  const float* w;       // [4 phases][4 taps][KC16][Nout][16]
+  const float* bias;
+  const float* addend;  // [N][2h][2w][Nout] or null
+  float* y;             // [N][2h][2w][Nout]
+  int N, h, w_, C0, Nout, KC16, act, tilesX, tilesY, tilesN, nwg;
+  unsigned epi;
+};
+
+template <int BN, int WM, int WN>
+__global__ void __launch_bounds__(256) up2_phase_fwd_kernel(const PhaseArgs a) {
+  constexpr int BM = TH * TW;
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int NS = (HP * 4 + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float lds[2 * HP * LD];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, idx = lane & 31, h = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+  int wg = fp_xcd_remap(blockIdx.x, a.nwg);
+  const int phase = wg & 3; wg >>= 2;                      // the four phases of a tile are adjacent (share the halo in L2)
+  const int tile_n = wg % a.tilesN; wg /= a.tilesN;
+  const int tile_x = wg % a.tilesX; wg /= a.tilesX;
+  const int tile_y = wg % a.tilesY;
+  const int n_img = wg / a.tilesY;
+  const int dy = phase >> 1, dx = phase & 1;
+  const int y0 = tile_y * TH, x0 = tile_x * TW, n0 = tile_n * BN;
+
+  int pix[NS], lds_off[NS];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    const int lin = t + 256 * k, hp = lin >> 2;
+    lds_off[k] = hp < HP ? hp * LD + (lin & 3) * 4 : -1;
+    const int hy = hp / HW2, hx = hp - hy * HW2;
+    const int sy = min(max(y0 + hy - 1, 0), a.h - 1), sx = min(max(x0 + hx - 1, 0), a.w_ - 1);   // replicate padding
+    pix[k] = (n_img * a.h + sy) * a.w_ + sx;
+  }
+  float4 hreg[NS];
+  auto load_halo = [&](int cc) {
+    const int c4 = cc * 16 + (t & 3) * 4;
+#pragma unroll
+    for (int k = 0; k < NS; ++k)
+      hreg[k] = (lds_off[k] >= 0 && c4 < a.C0) ? *reinterpret_cast<const float4*>(a.low + (size_t)pix[k] * a.C0 + c4)
+                                               : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  auto store_halo = [&](int buf) {
+#pragma unroll
+    for (int k = 0; k < NS; ++k)
+      if (lds_off[k] >= 0) *reinterpret_cast<float4*>(lds + buf * HP * LD + lds_off[k]) = hreg[k];
+  };
+  float4 bcur[TN][2], bnext[TN][2];
+  auto load_b = [&](int tap, int cc, float4 (&bf)[TN][2]) {
+    const float* ws = a.w + (size_t)((phase * 4 + tap) * a.KC16 + cc) * a.Nout * 16 + h * 4;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + (wn * TN + j) * 32 + idx;
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh)
+        bf[j][kh] = n < a.Nout ? *reinterpret_cast<const float4*>(ws + (size_t)n * 16 + kh * 8) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  int abase[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int pt = (wm * TM + i) * 32 + idx;
+    abase[i] = ((pt / TW + dy) * HW2 + (pt % TW) + dx) * LD + h * 4;   // phase offset folded into the base
+  }
+  f32x16 acc[TM][TN][2];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][0][r] = acc[i][j][1][r] = 0.f;
+
+  load_halo(0);
+  store_halo(0);
+  load_b(0, 0, bcur);
+  if (a.KC16 > 1) load_halo(1);
+  __syncthreads();
+  for (int cc = 0; cc < a.KC16; ++cc) {
+    const float* Hb = lds + (cc & 1) * HP * LD;
+#pragma unroll
+    for (int tap = 0; tap < 4; ++tap) {
+      const int toff = ((tap >> 1) * HW2 + (tap & 1)) * LD;      // tap (a, b): halo offset (dy + a, dx + b)
+      float4 af[TM][2];
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i][kh] = *reinterpret_cast<const float4*>(Hb + abase[i] + toff + kh * 8);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (c == 1) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (tap < 3) load_b(tap + 1, cc, bnext);
+          else if (cc + 1 < a.KC16) load_b(0, cc + 1, bnext);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              const float av = c == 0 ? af[i][kh].x : c == 1 ? af[i][kh].y : c == 2 ? af[i][kh].z : af[i][kh].w;
+              const float bv = c == 0 ? bcur[j][kh].x : c == 1 ? bcur[j][kh].y : c == 2 ? bcur[j][kh].z : bcur[j][kh].w;
+              acc[i][j][kh] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j][kh], 0, 0, 0);
+            }
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) { bcur[j][0] = bnext[j][0]; bcur[j][1] = bnext[j][1]; }
+    }
+    if (cc + 1 < a.KC16) {
+      store_halo((cc + 1) & 1);
+      if (cc + 2 < a.KC16) load_halo(cc + 2);
+      __syncthreads();
+    }
+  }
+  const int OH = 2 * a.h, OW = 2 * a.w_;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + (wn * TN + j) * 32 + idx;
+      if (n >= a.Nout) continue;
+      const float bias = (a.epi & FP_EPI_BIAS) ? a.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int pt = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int ly = y0 + pt / TW, lx = x0 + pt % TW;
+        if (ly >= a.h || lx >= a.w_) continue;
+        const size_t o = ((size_t)(n_img * OH + 2 * ly + dy) * OW + 2 * lx + dx) * a.Nout + n;
+        float v = acc[i][j][0][r] + acc[i][j][1][r] + bias;
+        if (a.epi & FP_EPI_ADDEND) v += a.addend[o];
+        if (a.act == FP_ACT_ELU) v = v > 0.f ? v : expm1f(v);
+        a.y[o] = v;
+      }
+    }
+}
+
+// wp[phase][tap(a,b)][kc][n][16]: collapsed weights of input channels [c_begin, c_begin + c_count) of w_oihw [Cout][Cin][3][3]
+__global__ void __launch_bounds__(256) pack_up2_fwd_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin,
+                                                           int c_begin, int c_count, int KC16) {
+  const size_t total = (size_t)16 * KC16 * Cout * 16;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int kr = (int)(e & 15);
+    size_t r = e >> 4;
+    const int n = (int)(r % Cout); r /= Cout;
+    const int kc = (int)(r % KC16); r /= KC16;
+    const int tap = (int)(r & 3), phase = (int)(r >> 2);
+    const int dy = phase >> 1, dx = phase & 1, ta = tap >> 1, tb = tap & 1;
+    const int k = kc * 16 + kr;
+    float v = 0.f;
+    if (k < c_count) {
+      const float* wk = w + ((size_t)n * Cin + c_begin + k) * 9;
+      // rows collapsed into (dy, a): dy=0: a=0 <- {0}, a=1 <- {1,2};  dy=1: a=0 <- {0,1}, a=1 <- {2}
+      const int ky_lo = dy == 0 ? (ta == 0 ? 0 : 1) : (ta == 0 ? 0 : 2), ky_hi = dy == 0 ? (ta == 0 ? 0 : 2) : (ta == 0 ? 1 : 2);
+      const int kx_lo = dx == 0 ? (tb == 0 ? 0 : 1) : (tb == 0 ? 0 : 2), kx_hi = dx == 0 ? (tb == 0 ? 0 : 2) : (tb == 0 ? 1 : 2);
+      for (int ky = ky_lo; ky <= ky_hi; ++ky)
+        for (int kx = kx_lo; kx <= kx_hi; ++kx) v += wk[ky * 3 + kx];
+    }
+    wp[e] = v;
+  }
+}
+
+// plain packing of an input-channel slice (the skip half of a concat conv): wp[tap][kc][n][16]
+__global__ void __launch_bounds__(256) pack_slice_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin,
+                                                         int c_begin, int c_count, int KC16) {
+  const size_t total = (size_t)9 * KC16 * Cout * 16;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int kr = (int)(e & 15);
+    size_t r = e >> 4;
+    const int n = (int)(r % Cout); r /= Cout;
+    const int kc = (int)(r % KC16);
+    const int tap = (int)(r / KC16);
+    const int k = kc * 16 + kr;
+    wp[e] = k < c_count ? w[((size_t)n * Cin + c_begin + k) * 9 + tap] : 0.f;
+  }
+}
+
+// ---- backward ----------------------------------------------------------------------------------------------------
+// d(low) of the phase decomposition is a 4x4 stride-2 convolution over dZ (taps r = hi-res row - (2Y - 1)):
+//     K4[0] = W[2], K4[1] = W[1] + W[2], K4[2] = W[0] + W[1], K4[3] = W[0]         (rows; same for columns)
+// plus the replicate-padding fold: the virtual low-res rows -1 / h (columns -1 / w) receive gradient too and belong to
+// rows 0 / h-1.  fp_conv_igemm (FWD_ZERO gather, K=4, stride 2, pad 3) evaluates the conv on the (h+2) x (w+2) extended grid
+// with these packed weights; up2_fold_bwd_kernel folds the border back, adds the second consumer's gradient and applies ELU'.
+// wp[tap r*4+s][kc over Cout][c][16]
+__global__ void __launch_bounds__(256) pack_up2_dgrad_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin,
+                                                             int c_begin, int c_count, int KC16) {
+  const size_t total = (size_t)16 * KC16 * c_count * 16;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int kr = (int)(e & 15);
+    size_t r = e >> 4;
+    const int c = (int)(r % c_count); r /= c_count;
+    const int kc = (int)(r % KC16);
+    const int tap = (int)(r / KC16);
+    const int tr = tap >> 2, ts = tap & 3;
+    const int n = kc * 16 + kr;
+    float v = 0.f;
+    if (n < Cout) {
+      const float* wk = w + ((size_t)n * Cin + c_begin + c) * 9;
+      const int ky_lo = tr == 0 ? 2 : (tr == 1 ? 1 : 0), ky_hi = tr == 0 ? 2 : (tr == 1 ? 2 : (tr == 2 ? 1 : 0));
+      const int kx_lo = ts == 0 ? 2 : (ts == 1 ? 1 : 0), kx_hi = ts == 0 ? 2 : (ts == 1 ? 2 : (ts == 2 ? 1 : 0));
+      for (int ky = ky_lo; ky <= ky_hi; ++ky)
+        for (int kx = kx_lo; kx <= kx_hi; ++kx) v += wk[ky * 3 + kx];
+    }
+    wp[e] = v;
+  }
+}
+
+// dgrad packing of an input-channel slice: wp[tap][kc over Cout][ci][16]
+__global__ void __launch_bounds__(256) pack_dgrad_slice_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin,
+                                                               int c_begin, int c_count, int KC16) {
+  const size_t total = (size_t)9 * KC16 * c_count * 16;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int kr = (int)(e & 15);
+    size_t r = e >> 4;
+    const int ci = (int)(r % c_count); r /= c_count;
+    const int kc = (int)(r % KC16);
+    const int tap = (int)(r / KC16);
+    const int co = kc * 16 + kr;
+    wp[e] = co < Cout ? w[((size_t)co * Cin + c_begin + ci) * 9 + tap] : 0.f;
+  }
+}
+
+__global__ void __launch_bounds__(256) up2_fold_bwd_kernel(const float* __restrict__ ext, int N, int h, int w, int C,
+                                                           const float* __restrict__ addend, const float* __restrict__ ylow,
+                                                           float* __restrict__ dlow) {
+  const int Q = C >> 2, we = w + 2;
+  const size_t total = (size_t)N * h * w * Q;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int q = (int)(e % Q);
+    size_t r = e / Q;
+    const int x = (int)(r % w); r /= w;
+    const int y = (int)(r % h);
+    const int n = (int)(r / h);
+    // extended rows / columns folded onto this pixel (fixed order: centre, then the border copies)
+    int ys[3], xs[3], ny = 1, nx = 1;
+    ys[0] = y + 1; xs[0] = x + 1;
+    if (y == 0) ys[ny++] = 0;
+    if (y == h - 1) ys[ny++] = h + 1;
+    if (x == 0) xs[nx++] = 0;
+    if (x == w - 1) xs[nx++] = w + 1;
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < ny; ++i)
+      for (int j = 0; j < nx; ++j) {
+        const float4 v = *reinterpret_cast<const float4*>(ext + (((size_t)n * (h + 2) + ys[i]) * we + xs[j]) * C + q * 4);
+        g.x += v.x; g.y += v.y; g.z += v.z; g.w += v.w;
+      }
+    const size_t o = (e / Q) * C + q * 4;
+    if (addend) {
+      const float4 ad = *reinterpret_cast<const float4*>(addend + o);
+      g.x += ad.x; g.y += ad.y; g.z += ad.z; g.w += ad.w;
+    }
+    if (ylow) {
+      const float4 s = *reinterpret_cast<const float4*>(ylow + o);
+      g.x *= (s.x > 0.f ? 1.f : s.x + 1.f); g.y *= (s.y > 0.f ? 1.f : s.y + 1.f);
+      g.z *= (s.z > 0.f ? 1.f : s.z + 1.f); g.w *= (s.w > 0.f ? 1.f : s.w + 1.f);
+    }
+    *reinterpret_cast<float4*>(dlow + o) = g;
+  }
+}
+
+int grid_for(size_t total) {
+  size_t g = (total + 255) / 256;
+  return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
+}
+
+}  // namespace
+
+extern "C" int64_t fp_up2_packed_weight_elems(int32_t Cout, int32_t c_count) {
+  return (int64_t)16 * ((c_count + 15) / 16) * Cout * 16;
+}
+
+extern "C" int fp_pack_up2_weight(const float* w_oihw, float* wp, int32_t Cout, int32_t Cin, int32_t c_begin, int32_t c_count,
+                                  fp_stream_t stream) {
+  FP_REQUIRE(w_oihw && wp && c_begin >= 0 && c_count > 0 && c_begin + c_count <= Cin, "fp_pack_up2_weight: bad arguments");
+  const int KC16 = (c_count + 15) / 16;
+  hipLaunchKernelGGL(pack_up2_fwd_kernel, dim3(grid_for((size_t)16 * KC16 * Cout * 16)), dim3(256), 0, (hipStream_t)stream, w_oihw, wp,
+                     Cout, Cin, c_begin, c_count, KC16);
+  return fp_check_launch("fp_pack_up2_weight");
+}
+
+extern "C" int fp_pack_conv_weight_slice(const float* w_oihw, float* wp, int32_t Cout, int32_t Cin, int32_t c_begin, int32_t c_count,
+                                         fp_stream_t stream) {
+  FP_REQUIRE(w_oihw && wp && c_begin >= 0 && c_count > 0 && c_begin + c_count <= Cin, "fp_pack_conv_weight_slice: bad arguments");
+  const int KC16 = (c_count + 15) / 16;
+  hipLaunchKernelGGL(pack_slice_kernel, dim3(grid_for((size_t)9 * KC16 * Cout * 16)), dim3(256), 0, (hipStream_t)stream, w_oihw, wp,
+                     Cout, Cin, c_begin, c_count, KC16);
+  return fp_check_launch("fp_pack_conv_weight_slice");
+}
+
+extern "C" int fp_conv_up2_phase_fwd(const float* low, const float* wphase, const float* bias, const float* addend, float* y,
+                                     int32_t N, int32_t h, int32_t w, int32_t C0, int32_t Nout, int32_t act, fp_stream_t stream) {
+  FP_REQUIRE(low && wphase && y && N > 0 && h >= 1 && w >= 1 && C0 > 0 && C0 % 4 == 0 && Nout > 0, "fp_conv_up2_phase_fwd: bad arguments");
+  PhaseArgs a;
+  a.low = low; a.w = wphase; a.bias = bias; a.addend = addend; a.y = y;
+  a.N = N; a.h = h; a.w_ = w; a.C0 = C0; a.Nout = Nout; a.KC16 = (C0 + 15) / 16; a.act = act;
+  a.epi = (bias ? FP_EPI_BIAS : 0u) | (addend ? FP_EPI_ADDEND : 0u);
+  a.tilesX = (int)fp_ceil_div(w, TW); a.tilesY = (int)fp_ceil_div(h, TH);
+  if (Nout <= 32) {
+    a.tilesN = (int)fp_ceil_div(Nout, 32);
+    a.nwg = N * a.tilesY * a.tilesX * a.tilesN * 4;
+    hipLaunchKernelGGL((up2_phase_fwd_kernel<32, 4, 1>), dim3(a.nwg), dim3(256), 0, (hipStream_t)stream, a);
+  } else {
+    a.tilesN = (int)fp_ceil_div(Nout, 64);
+    a.nwg = N * a.tilesY * a.tilesX * a.tilesN * 4;
+    hipLaunchKernelGGL((up2_phase_fwd_kernel<64, 2, 2>), dim3(a.nwg), dim3(256), 0, (hipStream_t)stream, a);
+  }
+  return fp_check_launch("fp_conv_up2_phase_fwd");
+}
+
+extern "C" int fp_pack_up2_weight_dgrad(const float* w_oihw, float* wp, int32_t Cout, int32_t Cin, int32_t c_begin, int32_t c_count,
+                                        fp_stream_t stream) {
+  FP_REQUIRE(w_oihw && wp && c_begin >= 0 && c_count > 0 && c_begin + c_count <= Cin, "fp_pack_up2_weight_dgrad: bad arguments");
+  const int KC16 = (Cout + 15) / 16;
+  hipLaunchKernelGGL(pack_up2_dgrad_kernel, dim3(grid_for((size_t)16 * KC16 * c_count * 16)), dim3(256), 0, (hipStream_t)stream, w_oihw,
+                     wp, Cout, Cin, c_begin, c_count, KC16);
+  return fp_check_launch("fp_pack_up2_weight_dgrad");
+}
+
+extern "C" int fp_pack_conv_weight_dgrad_slice(const float* w_oihw, float* wp, int32_t Cout, int32_t Cin, int32_t c_begin,
+                                               int32_t c_count, fp_stream_t stream) {
+  FP_REQUIRE(w_oihw && wp && c_begin >= 0 && c_count > 0 && c_begin + c_count <= Cin, "fp_pack_conv_weight_dgrad_slice: bad arguments");
+  const int KC16 = (Cout + 15) / 16;
+  hipLaunchKernelGGL(pack_dgrad_slice_kernel, dim3(grid_for((size_t)9 * KC16 * c_count * 16)), dim3(256), 0, (hipStream_t)stream, w_oihw,
+                     wp, Cout, Cin, c_begin, c_count, KC16);
+  return fp_check_launch("fp_pack_conv_weight_dgrad_slice");
+}
+
+extern "C" int fp_up2_fold_bwd(const float* ext, int32_t N, int32_t h, int32_t w, int32_t C, const float* addend, const float* ylow_elu,
+                               float* dlow, fp_stream_t stream) {
+  FP_REQUIRE(ext && dlow && N > 0 && h > 0 && w > 0 && C > 0 && C % 4 == 0, "fp_up2_fold_bwd: bad arguments");
+  hipLaunchKernelGGL(up2_fold_bwd_kernel, dim3(grid_for((size_t)N * h * w * (C / 4))), dim3(256), 0, (hipStream_t)stream, ext, N, h, w, C,
+                     addend, ylow_elu, dlow);
+  return fp_check_launch("fp_up2_fold_bwd");
+}

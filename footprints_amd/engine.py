@@ -24,6 +24,8 @@ from . import ops
 # Running them on side streams lets workgroups of 2-3 kernels share the CUs, which fills the occupancy ramp /
 # tail of each launch (a conv launch is only ~2-3 "rounds" of workgroups per CU).  FP_SERIAL=1 disables it.
 _CONCURRENT = not bool(int(os.environ.get("FP_SERIAL", "0")))
+# nearest-x2 phase decomposition of the upsample convs (conv_up2_phase.hip); FP_NO_PHASE=1 keeps the fused-gather path.
+_PHASE = not bool(int(os.environ.get("FP_NO_PHASE", "0")))
 
 SCALE_KEYS = ("1/8", "1/4", "1/2", "1/1")
 
@@ -41,6 +43,8 @@ class ConvRec:
         self.stem, self.head = stem, head
         self.wp = None    # forward packing
         self.wpd = None   # dgrad packing
+        self.up2 = None   # (C0, C1) for convs fed by cat[nearest_x2(low C0), skip C1]: phase-decomposed packings below
+        self.wph = self.wsk = self.wdu = self.wds = None   # fwd phase / fwd skip slice / dgrad 4x4 s2 / dgrad skip slice
         self.gw = None    # gradient views (flat grad buffer)
         self.gb = None
 
@@ -91,6 +95,10 @@ class DecoderRec:
         self.heads.append(ConvRec("%s.outconv4.1.conv1" % name, dec.outconv4[1].conv1, head=True))
         self.o41 = ConvRec("%s.outconv4.0.conv1" % name, dec.outconv4[0].conv1)
         self.o42 = ConvRec("%s.outconv4.0.conv2" % name, dec.outconv4[0].conv2)
+        if _PHASE:
+            for b in self.blocks:
+                b["post1"].up2 = (b["post1"].Cin // 2, b["post1"].Cin // 2)
+            self.o41.up2 = (self.o41.Cin, 0)
 
     def convs(self):
         out = []
@@ -185,12 +193,23 @@ class Engine:
         for c in self.all_convs():
             nf = ops.packed_weight_elems(c.Cout, c.Cin, c.K, False, c.stem)
             nd = 0 if c.stem else ops.packed_weight_elems(c.Cout, c.Cin, c.K, True, False)
-            plan.append((c, total, nf, nd))
-            total += nf + nd
+            ex = [0, 0, 0, 0]
+            if c.up2 is not None:
+                C0, C1 = c.up2
+                ex = [ops.up2_packed_weight_elems(c.Cout, C0), ops.packed_weight_elems(c.Cout, C1, 3) if C1 else 0,
+                      ops.up2_packed_weight_elems(C0, c.Cout), ops.packed_weight_elems(c.Cout, C1, 3, True) if C1 else 0]
+            plan.append((c, total, nf, nd, ex))
+            total += nf + nd + sum(ex)
         self.packed = torch.empty(total, device=self.device)
-        for c, o, nf, nd in plan:
+        for c, o, nf, nd, ex in plan:
             c.wp = self.packed[o:o + nf]
             c.wpd = self.packed[o + nf:o + nf + nd] if nd else None
+            o += nf + nd
+            views = []
+            for n in ex:
+                views.append(self.packed[o:o + n] if n else None)
+                o += n
+            c.wph, c.wsk, c.wdu, c.wds = views
 
     def refresh_packed(self, force=False):
         vers = tuple(c.w._version for c in self.all_convs())
@@ -200,6 +219,13 @@ class Engine:
             ops.pack_conv_weight(c.w.data, c.wp, c.stem)
             if c.wpd is not None:
                 ops.pack_conv_weight_dgrad(c.w.data, c.wpd)
+            if c.up2 is not None:
+                C0, C1 = c.up2
+                ops.pack_up2_weight(c.w.data, c.wph, 0, C0)
+                ops.pack_up2_weight_dgrad(c.w.data, c.wdu, 0, C0)
+                if C1:
+                    ops.pack_conv_weight_slice(c.w.data, c.wsk, C0, C1)
+                    ops.pack_conv_weight_dgrad_slice(c.w.data, c.wds, C0, C1)
         self._versions = vers
         self.weights_dirty = False
 
@@ -246,7 +272,18 @@ class Engine:
         d = ops.make_desc(N, OH, OW, H, W, c.Cin, 0, c.Cout, c.K, c.stride, c.pad, L.GATHER_FWD_ZERO)
         return ops.conv_igemm(d, x, None, c.wp, out)
 
+    @staticmethod
+    def _phase_ok(h, w):
+        """phase kernels tile the low-res grid 8 x 16: keep the fused-gather path when most of a tile would be padding"""
+        return h * w * 10 >= ((h + 7) // 8 * 8) * ((w + 15) // 16 * 16) * 6
+
     def _conv_dec(self, c, x0, x1, N, H, W, C0, C1, up2, out):
+        if up2 and c.up2 is not None and self._phase_ok(H // 2, W // 2):
+            if C1:      # skip half at full resolution (raw partial sums), then the four phases of the upsampled half on top
+                d = ops.make_desc(N, H, W, H, W, C1, 0, c.Cout, 3, 1, 1, L.GATHER_FWD_REFLECT)
+                ops.conv_igemm(d, x1, None, c.wsk, out)
+                return ops.conv_up2_phase_fwd(x0, c.wph, c.b.data, out, act=L.ACT_ELU, addend=out)
+            return ops.conv_up2_phase_fwd(x0, c.wph, c.b.data, out, act=L.ACT_ELU)
         gather = L.GATHER_FWD_REFLECT_UP2 if up2 else L.GATHER_FWD_REFLECT
         d = ops.make_desc(N, H, W, H, W, C0, C1, c.Cout, 3, 1, 1, gather, act=L.ACT_ELU)
         return ops.conv_igemm(d, x0, x1, c.wp, out, bias=c.b.data)
@@ -381,6 +418,12 @@ class Engine:
         d = ops.make_desc(N, H, W, H, W, c.Cout, 0, c.Cin, 3, 1, 1, L.GATHER_DGRAD_REFLECT, epi=epi)
         return ops.conv_igemm(d, dz, None, c.wpd, out, actsrc=actsrc, addend=addend)
 
+    def _dgrad_up2_ext(self, c, dz, N, hl, wl, C0, pfx):
+        """gradient wrt the low-res input of an upsample conv on the (hl+2) x (wl+2) extended grid (ops.up2_fold_bwd folds it)"""
+        ext = self.buf(pfx + "XV", (N, hl + 2, wl + 2, C0))
+        d = ops.make_desc(N, hl + 2, wl + 2, 2 * hl, 2 * wl, c.Cout, 0, C0, 4, 2, 3, L.GATHER_FWD_ZERO)
+        return ops.conv_igemm(d, dz, None, c.wdu, ext)
+
     def backward(self, grad_outputs, accumulate=False, on_stage=None):
         """grad_outputs: 4 tensors [B,4,H,W] (d loss / d outputs['1/8','1/4','1/2','1/1']).
         Writes every live parameter gradient into self.flat_grad (views: self.grad_views).
@@ -511,7 +554,11 @@ class Engine:
         self._wgrad(dec.o42, L.GATHER_FWD_REFLECT, D["y51"], None, A, N, H, W, H, W, 32, 0, acc)
         Bz = self._dgrad_dec(dec.o42, A, N, H, W, buf(pfx + "B", (N, H, W, 32)), actsrc=D["y51"])
         self._wgrad(dec.o41, L.GATHER_FWD_REFLECT_UP2, x4, None, Bz, N, H, W, H, W, 64, 0, acc)
-        XV = self._dgrad_dec(dec.o41, Bz, N, H, W, buf(pfx + "XV", (N, H, W, 64)))
+        phase41 = dec.o41.up2 is not None
+        if phase41:
+            XV = self._dgrad_up2_ext(dec.o41, Bz, N, h0, w0, 64, pfx)
+        else:
+            XV = self._dgrad_dec(dec.o41, Bz, N, H, W, buf(pfx + "XV", (N, H, W, 64)))
         # head3 on x4
         dzl = buf(pfx + "dzl", (N, h0, w0, 2))
         ops.head_upsample_bwd(gouts[2], D["low"][2], dzl, 2, dec.c0, dec.sig)
@@ -520,7 +567,10 @@ class Engine:
         XH = buf(pfx + "XH", (N, h0, w0, 64))
         ops.head_dgrad(dzl, hd.w.data, XH)
         A = buf(pfx + "A", (N, h0, w0, 64))
-        ops.up2cat_bwd(XV, N, h0, w0, 64, 0, A, addend=XH, ylow=x4)
+        if phase41:
+            ops.up2_fold_bwd(XV, A, addend=XH, ylow=x4)
+        else:
+            ops.up2cat_bwd(XV, N, h0, w0, 64, 0, A, addend=XH, ylow=x4)
         # ---- blocks 4..1 ----------------------------------------------------------------------------------
         chans = [(512, 256), (256, 128), (128, 64), (64, 64)]
         for bi in (3, 2, 1, 0):
@@ -535,11 +585,20 @@ class Engine:
             self._wgrad(blk["post2"], L.GATHER_FWD_REFLECT, y3, None, A, N, hh, ww, hh, ww, cout, 0, acc)
             Bz = self._dgrad_dec(blk["post2"], A, N, hh, ww, buf(pfx + "B", (N, hh, ww, cout)), actsrc=y3)
             self._wgrad(blk["post1"], L.GATHER_FWD_REFLECT_UP2, y2, skip, Bz, N, hh, ww, hh, ww, cout, cout, acc)
-            XV = self._dgrad_dec(blk["post1"], Bz, N, hh, ww, buf(pfx + "XV", (N, hh, ww, 2 * cout)))
             A = buf(pfx + "A", (N, hl, wl, cout))
-            if not first:
-                order_dF(3 - bi)
-            ops.up2cat_bwd(XV, N, hl, wl, cout, cout, A, ylow=y2, dskip=dF[3 - bi], accumulate_skip=accum_feat)
+            if blk["post1"].up2 is not None:
+                # d(low) = 4x4 stride-2 conv over dZ + border fold (* ELU'); d(skip) straight into the feature gradient
+                ops.up2_fold_bwd(self._dgrad_up2_ext(blk["post1"], Bz, N, hl, wl, cout, pfx), A, ylow=y2)
+                if not first:
+                    order_dF(3 - bi)
+                ds = ops.make_desc(N, hh, ww, hh, ww, cout, 0, cout, 3, 1, 1, L.GATHER_DGRAD_REFLECT,
+                                   epi=L.EPI_ACCUM if accum_feat else 0)
+                ops.conv_igemm(ds, Bz, None, blk["post1"].wds, dF[3 - bi])
+            else:
+                XV = self._dgrad_dec(blk["post1"], Bz, N, hh, ww, buf(pfx + "XV", (N, hh, ww, 2 * cout)))
+                if not first:
+                    order_dF(3 - bi)
+                ops.up2cat_bwd(XV, N, hl, wl, cout, cout, A, ylow=y2, dskip=dF[3 - bi], accumulate_skip=accum_feat)
             if first:
                 order_dF(3 - bi)
             self._wgrad(blk["pre2"], L.GATHER_FWD_REFLECT, y1, None, A, N, hl, wl, hl, wl, cout, 0, acc)

@@ -94,6 +94,48 @@ def pack_conv_weight_dgrad(w, wp):
     return wp
 
 
+def up2_packed_weight_elems(Cout, c_count):
+    return _lib.load().fp_up2_packed_weight_elems(Cout, c_count)
+
+
+def pack_up2_weight(w, wp, c_begin, c_count):
+    Cout, Cin = w.shape[:2]
+    _lib.check(_lib.load().fp_pack_up2_weight(_f32(w), _f32(wp), Cout, Cin, c_begin, c_count, stream()), "fp_pack_up2_weight")
+    return wp
+
+
+def pack_conv_weight_slice(w, wp, c_begin, c_count):
+    Cout, Cin = w.shape[:2]
+    _lib.check(_lib.load().fp_pack_conv_weight_slice(_f32(w), _f32(wp), Cout, Cin, c_begin, c_count, stream()), "fp_pack_conv_weight_slice")
+    return wp
+
+
+def conv_up2_phase_fwd(low, wphase, bias, y, act=0, addend=None):
+    N, h, w, C0 = low.shape
+    _lib.check(_lib.load().fp_conv_up2_phase_fwd(_f32(low), _f32(wphase), _f32(bias), _f32(addend), _f32(y), N, h, w, C0, y.shape[3],
+                                                 int(act), stream()), "fp_conv_up2_phase_fwd")
+    return y
+
+
+def pack_up2_weight_dgrad(w, wp, c_begin, c_count):
+    Cout, Cin = w.shape[:2]
+    _lib.check(_lib.load().fp_pack_up2_weight_dgrad(_f32(w), _f32(wp), Cout, Cin, c_begin, c_count, stream()), "fp_pack_up2_weight_dgrad")
+    return wp
+
+
+def pack_conv_weight_dgrad_slice(w, wp, c_begin, c_count):
+    Cout, Cin = w.shape[:2]
+    _lib.check(_lib.load().fp_pack_conv_weight_dgrad_slice(_f32(w), _f32(wp), Cout, Cin, c_begin, c_count, stream()),
+               "fp_pack_conv_weight_dgrad_slice")
+    return wp
+
+
+def up2_fold_bwd(ext, dlow, addend=None, ylow=None):
+    N, h, w, Cn = dlow.shape
+    _lib.check(_lib.load().fp_up2_fold_bwd(_f32(ext), N, h, w, Cn, _f32(addend), _f32(ylow), _f32(dlow), stream()), "fp_up2_fold_bwd")
+    return dlow
+
+
 def colsum(x2d, out, accumulate=False):
     lib = _lib.load()
     M, Cn = x2d.shape

@@ -91,6 +91,32 @@ int fp_pack_conv_weight(const float* w_oihw, float* wp, int32_t Cout, int32_t Ci
 int fp_pack_conv_weight_dgrad(const float* w_oihw, float* wp, int32_t Cout, int32_t Cin, int32_t KH, int32_t KW,
                               fp_stream_t stream);
 
+/* ---- nearest-x2 phase decomposition (reference footprints/network.py:98,126-134,154: upsample -> [cat skip] ->
+ * ReflectionPad2d(1) -> Conv2d 3x3).  A 3x3 conv over the x2-upsampled `low` equals four 2x2 convs (one per output
+ * parity phase) over `low` itself with row/column-collapsed weights and replicate padding: 2.25x fewer MACs and no
+ * upsampled temporary.  fp_pack_up2_weight collapses input channels [c_begin, c_begin+c_count) of w_oihw
+ * [Cout][Cin][3][3] into wp[phase 4][tap 4][ceil(c_count/16)][Cout][16]; fp_pack_conv_weight_slice packs the remaining
+ * (skip) channels in the ordinary fp_pack_conv_weight layout.  fp_conv_up2_phase_fwd:
+ *   y[n][2y+dy][2x+dx][:] = act( sum_taps Wc . low + bias + addend )      (addend may alias y: skip-half partial sums) */
+int64_t fp_up2_packed_weight_elems(int32_t Cout, int32_t c_count);
+int fp_pack_up2_weight(const float* w_oihw, float* wp, int32_t Cout, int32_t Cin, int32_t c_begin, int32_t c_count,
+                       fp_stream_t stream);
+int fp_pack_conv_weight_slice(const float* w_oihw, float* wp, int32_t Cout, int32_t Cin, int32_t c_begin,
+                              int32_t c_count, fp_stream_t stream);
+int fp_conv_up2_phase_fwd(const float* low, const float* wphase, const float* bias, const float* addend, float* y,
+                          int32_t N, int32_t h, int32_t w, int32_t C0, int32_t Nout, int32_t act, fp_stream_t stream);
+/* Backward (the upsample_nearest2d_backward + reflection_pad2d_backward + convolution_backward(data) chain): d(low) is a
+ * 4x4 stride-2 convolution over dZ.  Pack with fp_pack_up2_weight_dgrad (fp_up2_packed_weight_elems(c_count, Cout)
+ * floats), run fp_conv_igemm{FWD_ZERO, K=4, stride 2, pad 3, IH=2h, OH=h+2} into ext[N][h+2][w+2][c_count], then
+ * fp_up2_fold_bwd folds the replicate-padding border back:  dlow = (fold(ext) + addend) * ELU'(ylow_elu)  (both optional).
+ * The skip half of a concat conv takes the ordinary DGRAD_REFLECT path with fp_pack_conv_weight_dgrad_slice weights. */
+int fp_pack_up2_weight_dgrad(const float* w_oihw, float* wp, int32_t Cout, int32_t Cin, int32_t c_begin, int32_t c_count,
+                             fp_stream_t stream);
+int fp_pack_conv_weight_dgrad_slice(const float* w_oihw, float* wp, int32_t Cout, int32_t Cin, int32_t c_begin,
+                                    int32_t c_count, fp_stream_t stream);
+int fp_up2_fold_bwd(const float* ext, int32_t N, int32_t h, int32_t w, int32_t C, const float* addend,
+                    const float* ylow_elu, float* dlow, fp_stream_t stream);
+
 /* column sums: out[c] (+)= sum_m x[m][c]  -- conv bias gradient (weight half of convolution_backward) */
 int64_t fp_colsum_workspace(int64_t M, int32_t C);
 int fp_colsum(const float* x, int64_t M, int32_t C, float* out, int accumulate, void* workspace,

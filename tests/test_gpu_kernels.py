@@ -109,6 +109,65 @@ def test_conv_stem(N, H, W):
 
 
 # ----------------------------------------------------------------------------------------------------------
+# nearest-x2 phase decomposition (conv_up2_phase.hip): upsample -> [cat skip] -> reflect-pad conv3x3 -> ELU
+# ----------------------------------------------------------------------------------------------------------
+def _up2_ref(lo, skip, w, b):
+    up = F.interpolate(lo, scale_factor=2, mode="nearest")
+    xin = torch.cat([up, skip], 1) if skip is not None else up
+    return F.conv2d(F.pad(xin, (1, 1, 1, 1), mode="reflect"), w, b)
+
+
+@pytest.mark.parametrize("N,h,w,C0,C1,Cout", [
+    (2, 6, 20, 256, 256, 256), (2, 12, 40, 128, 128, 128), (3, 24, 80, 64, 64, 64), (2, 48, 160, 32, 64, 32),
+    (2, 96, 320, 16, 0, 16), (1, 5, 7, 32, 0, 16), (2, 1, 1, 16, 0, 16), (1, 3, 2, 24, 40, 48), (2, 9, 17, 20, 0, 72)])
+def test_up2_phase_fwd(N, h, w, C0, C1, Cout):
+    ops, L = _ops()
+    wt, b = rnd((Cout, C0 + C1, 3, 3), 300, -0.1, 0.1), rnd((Cout,), 301)
+    lo = rnd((N, C0, h, w), 302)
+    skip = rnd((N, C1, 2 * h, 2 * w), 303) if C1 else None
+    ref = F.elu(_up2_ref(lo, skip, wt, b))
+    wd = wt.cuda()
+    wph = ops.pack_up2_weight(wd, torch.empty(ops.up2_packed_weight_elems(Cout, C0), device="cuda"), 0, C0)
+    y = torch.empty((N, 2 * h, 2 * w, Cout), device="cuda")
+    if C1:                                           # skip half first (no bias / act), phase kernel adds in place
+        wsk = ops.pack_conv_weight_slice(wd, torch.empty(ops.packed_weight_elems(Cout, C1, 3, False, False), device="cuda"), C0, C1)
+        d = ops.make_desc(N, 2 * h, 2 * w, 2 * h, 2 * w, C1, 0, Cout, 3, 1, 1, L.GATHER_FWD_REFLECT)
+        ops.conv_igemm(d, nhwc(skip), None, wsk, y)
+        ops.conv_up2_phase_fwd(nhwc(lo), wph, b.cuda(), y, act=L.ACT_ELU, addend=y)
+    else:
+        ops.conv_up2_phase_fwd(nhwc(lo), wph, b.cuda(), y, act=L.ACT_ELU)
+    check(nchw(y), ref, "up2 phase fwd")
+
+
+@pytest.mark.parametrize("N,h,w,C0,C1,Cout", [
+    (2, 6, 20, 64, 64, 64), (2, 12, 40, 32, 32, 48), (1, 24, 80, 64, 0, 32), (2, 1, 1, 16, 0, 16), (1, 1, 5, 16, 16, 16),
+    (2, 3, 2, 24, 40, 48), (1, 48, 160, 64, 64, 64)])
+def test_up2_phase_dgrad(N, h, w, C0, C1, Cout):
+    """d(low) through the 4x4 stride-2 conv + border fold (+ addend, ELU'), d(skip) through the sliced DGRAD_REFLECT."""
+    ops, L = _ops()
+    wt = rnd((Cout, C0 + C1, 3, 3), 310, -0.1, 0.1)
+    pre = rnd((N, C0, h, w), 311, -2.0, 2.0).requires_grad_(True)
+    skip = rnd((N, C1, 2 * h, 2 * w), 312).requires_grad_(True) if C1 else None
+    lo = F.elu(pre)
+    extra = rnd((N, C0, h, w), 313)
+    yr = _up2_ref(lo, skip, wt, None)
+    g = rnd(tuple(yr.shape), 314)
+    ((yr * g).sum() + (lo * extra).sum()).backward()
+    wd, gz = wt.cuda(), nhwc(g)
+    wpu = ops.pack_up2_weight_dgrad(wd, torch.empty(ops.up2_packed_weight_elems(C0, Cout), device="cuda"), 0, C0)
+    ext = torch.empty((N, h + 2, w + 2, C0), device="cuda")
+    d = ops.make_desc(N, h + 2, w + 2, 2 * h, 2 * w, Cout, 0, C0, 4, 2, 3, L.GATHER_FWD_ZERO)
+    ops.conv_igemm(d, gz, None, wpu, ext)
+    dlow = ops.up2_fold_bwd(ext, torch.empty((N, h, w, C0), device="cuda"), addend=nhwc(extra), ylow=nhwc(lo.detach()))
+    check(nchw(dlow), pre.grad, "up2 phase dgrad (low)")
+    if C1:
+        wps = ops.pack_conv_weight_dgrad_slice(wd, torch.empty(ops.packed_weight_elems(Cout, C1, 3, True), device="cuda"), C0, C1)
+        ds = ops.make_desc(N, 2 * h, 2 * w, 2 * h, 2 * w, Cout, 0, C1, 3, 1, 1, L.GATHER_DGRAD_REFLECT)
+        dsk = ops.conv_igemm(ds, gz, None, wps, torch.empty((N, 2 * h, 2 * w, C1), device="cuda"))
+        check(nchw(dsk), skip.grad, "up2 phase dgrad (skip)")
+
+
+# ----------------------------------------------------------------------------------------------------------
 # halo-tile 3x3 kernel (conv3x3_tile.hip): shapes large enough (>= 384 workgroups) to be dispatched to it
 # ----------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("mode,N,H,W,C0,C1,Cout", [
