@@ -40,6 +40,9 @@ SIGNATURES = {
     "fp_pack_up2_weight_dgrad": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P]),
     "fp_pack_conv_weight_dgrad_slice": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P]),
     "fp_up2_fold_bwd": (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _P, _P, _P]),
+    "fp_conv_wgrad_slice": (C.c_int, [_DESC, _P, _P, _P, _P, _I32, _I32, C.c_int, _P, _I64, _P]),
+    "fp_conv_up2_phase_wgrad_workspace": (_I64, [_I32, _I32, _I32, _I32, _I32]),
+    "fp_conv_up2_phase_wgrad": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, C.c_int, _P, _I64, _P]),
     "fp_colsum_workspace": (_I64, [_I64, _I32]),
     "fp_colsum": (C.c_int, [_P, _I64, _I32, _P, C.c_int, _P, _I64, _P]),
     "fp_up2cat_bwd": (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, C.c_int, _P]),

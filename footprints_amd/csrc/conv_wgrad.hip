@@ -18,7 +18,7 @@
 
 int64_t fp_wgrad3x3_tile_workspace(const fp_conv_desc* d);
 int fp_wgrad3x3_tile_dispatch(const fp_conv_desc* d, const float* src0, const float* src1, const float* dz, float* dw_oihw,
-                              int accumulate, void* workspace, int64_t workspace_bytes, hipStream_t stream);
+                              int accumulate, int kc_total, int k_begin, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 
 namespace {
 
@@ -204,8 +204,9 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs a) {
 }
 
 // dW_oihw[n][k][tap] (+)= sum_s part[s][tap][k][n]; STEM: part k index = (ky*7+kx)*3+ci -> OIHW [n][ci][ky][kx]
+// The destination may be an input-channel slice [k_begin, k_begin + Kc) of a wider [Nout][kc_total][KH][KW] gradient.
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int S, int T,
-                                                           int Kc, int Nout, int stem, int accumulate) {
+                                                           int Kc, int Nout, int stem, int accumulate, int kc_total, int k_begin) {
   const size_t total = (size_t)T * Kc * Nout;
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
     // eight independent partial sums keep eight loads in flight (fixed combination order => deterministic)
@@ -226,7 +227,7 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
       const int ci = k % 3, kpos = k / 3;
       o = ((size_t)n * 3 + ci) * 49 + kpos;
     } else {
-      o = ((size_t)n * Kc + k) * T + tap;
+      o = ((size_t)n * kc_total + k_begin + k) * T + tap;
     }
     dw[o] = accumulate ? dw[o] + sum : sum;
   }
@@ -264,11 +265,13 @@ bool use_tile() {
 
 }  // namespace
 
-int fp_wgrad_reduce_launch(const float* part, float* dw, int S, int T, int Kc, int Nout, int stem, int accumulate, hipStream_t stream) {
+int fp_wgrad_reduce_launch(const float* part, float* dw, int S, int T, int Kc, int Nout, int stem, int accumulate, int kc_total,
+                           int k_begin, hipStream_t stream) {
   const int64_t total = (int64_t)T * Kc * Nout;
   int rgrid = (int)fp_ceil_div(total, 256);
   if (rgrid > 4096) rgrid = 4096;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rgrid), dim3(256), 0, stream, part, dw, S, T, Kc, Nout, stem, accumulate);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rgrid), dim3(256), 0, stream, part, dw, S, T, Kc, Nout, stem, accumulate,
+                     kc_total, k_begin);
   return fp_check_launch("fp_conv_wgrad(reduce)");
 }
 
@@ -285,8 +288,18 @@ extern "C" int64_t fp_conv_wgrad_workspace(const fp_conv_desc* d) {
 
 extern "C" int fp_conv_wgrad(const fp_conv_desc* d, const float* src0, const float* src1, const float* dz, float* dw_oihw,
                              int accumulate, void* workspace, int64_t workspace_bytes, fp_stream_t stream_) {
+  FP_REQUIRE(d, "fp_conv_wgrad: null pointer");
+  const int kc = d->gather == FP_GATHER_STEM ? 3 : d->C0 + d->C1;
+  return fp_conv_wgrad_slice(d, src0, src1, dz, dw_oihw, kc, 0, accumulate, workspace, workspace_bytes, stream_);
+}
+
+extern "C" int fp_conv_wgrad_slice(const fp_conv_desc* d, const float* src0, const float* src1, const float* dz, float* dw_oihw,
+                                   int32_t kc_total, int32_t k_begin, int accumulate, void* workspace, int64_t workspace_bytes,
+                                   fp_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   FP_REQUIRE(d && src0 && dz && dw_oihw && workspace, "fp_conv_wgrad: null pointer");
+  FP_REQUIRE(d->gather == FP_GATHER_STEM ? (kc_total == 3 && k_begin == 0) : (k_begin >= 0 && k_begin + d->C0 + d->C1 <= kc_total),
+             "fp_conv_wgrad: input-channel slice out of range");
   const bool stem = d->gather == FP_GATHER_STEM;
   FP_REQUIRE(stem || d->gather == FP_GATHER_FWD_ZERO || d->gather == FP_GATHER_FWD_REFLECT || d->gather == FP_GATHER_FWD_REFLECT_UP2,
              "fp_conv_wgrad: gather must be a forward mode");
@@ -295,7 +308,7 @@ extern "C" int fp_conv_wgrad(const fp_conv_desc* d, const float* src0, const flo
   const Plan p = make_plan(d);
   FP_REQUIRE(workspace_bytes >= fp_conv_wgrad_workspace(d), "fp_conv_wgrad: workspace too small");
   if (!stem && use_tile()) {    // 3x3 stride-1 convs with 32-aligned channels: all-taps LDS-DMA kernel (wgrad3x3_tile.hip)
-    const int rc = fp_wgrad3x3_tile_dispatch(d, src0, src1, dz, dw_oihw, accumulate, workspace, workspace_bytes, stream);
+    const int rc = fp_wgrad3x3_tile_dispatch(d, src0, src1, dz, dw_oihw, accumulate, kc_total, k_begin, workspace, workspace_bytes, stream);
     if (rc != -1000) return rc;
   }
   WgradArgs a;
@@ -315,5 +328,6 @@ extern "C" int fp_conv_wgrad(const fp_conv_desc* d, const float* src0, const flo
   }
   int rc = fp_check_launch("fp_conv_wgrad");
   if (rc) return rc;
-  return fp_wgrad_reduce_launch((const float*)workspace, dw_oihw, p.S, p.T, p.Kc, d->Nout, stem ? 1 : 0, accumulate, stream);
+  return fp_wgrad_reduce_launch((const float*)workspace, dw_oihw, p.S, p.T, p.Kc, d->Nout, stem ? 1 : 0, accumulate, kc_total, k_begin,
+                                stream);
 }

@@ -16,7 +16,8 @@
 // per-split partials in a fixed order => deterministic.
 #include "fp_common.h"
 
-int fp_wgrad_reduce_launch(const float* part, float* dw, int S, int T, int Kc, int Nout, int stem, int accumulate, hipStream_t stream);
+int fp_wgrad_reduce_launch(const float* part, float* dw, int S, int T, int Kc, int Nout, int stem, int accumulate, int kc_total,
+                           int k_begin, hipStream_t stream);
 
 namespace {
 
@@ -190,7 +191,7 @@ int64_t fp_wgrad3x3_tile_workspace(const fp_conv_desc* d) {
 }
 
 int fp_wgrad3x3_tile_dispatch(const fp_conv_desc* d, const float* src0, const float* src1, const float* dz, float* dw_oihw,
-                              int accumulate, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
+                              int accumulate, int kc_total, int k_begin, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
   if (!eligible(d)) return -1000;
   const WPlan p = plan(d);
   if (workspace_bytes < fp_wgrad3x3_tile_workspace(d)) return fp_set_error(FP_EWORKSPACE, "fp_conv_wgrad(tile): workspace too small");
@@ -204,5 +205,5 @@ int fp_wgrad3x3_tile_dispatch(const fp_conv_desc* d, const float* src0, const fl
   hipLaunchKernelGGL(wgrad3x3_tile_kernel, dim3(p.S * p.citiles * p.cotiles), dim3(256), 0, stream, a);
   int rc = fp_check_launch("fp_conv_wgrad(tile)");
   if (rc) return rc;
-  return fp_wgrad_reduce_launch((const float*)workspace, dw_oihw, p.S, 9, a.Kc, d->Nout, 0, accumulate, stream);
+  return fp_wgrad_reduce_launch((const float*)workspace, dw_oihw, p.S, 9, a.Kc, d->Nout, 0, accumulate, kc_total, k_begin, stream);
 }

@@ -413,6 +413,19 @@ class Engine:
         if c.gb is not None:
             ops.colsum(dz.view(-1, c.Cout), c.gb, accumulate=acc)
 
+    def _wgrad_up2(self, c, low, skip, dz, N, hl, wl, C0, C1, acc):
+        """weight (+bias) gradient of a conv over cat[nearest_x2(low), skip]: upsampled half by output phase, skip half as a
+        channel slice of the same gradient tensor; shapes the phase kernel does not take keep the fused-gather kernel."""
+        H, W = 2 * hl, 2 * wl
+        if c.up2 is None or not ops.up2_phase_wgrad_supported(N, hl, wl, C0, c.Cout):
+            return self._wgrad(c, L.GATHER_FWD_REFLECT_UP2, low, skip, dz, N, H, W, H, W, C0, C1, acc)
+        ops.conv_up2_phase_wgrad(low, dz, c.gw, 0, accumulate=acc)
+        if C1:
+            d = ops.make_desc(N, H, W, H, W, C1, 0, c.Cout, 3, 1, 1, L.GATHER_FWD_REFLECT)
+            ops.conv_wgrad_slice(d, skip, None, dz, c.gw, C0, accumulate=acc)
+        if c.gb is not None:
+            ops.colsum(dz.view(-1, c.Cout), c.gb, accumulate=acc)
+
     def _dgrad_dec(self, c, dz, N, H, W, out, actsrc=None, addend=None, accum=False):
         epi = (L.EPI_ACTGRAD_ELU if actsrc is not None else 0) | (L.EPI_ACCUM if accum else 0)
         d = ops.make_desc(N, H, W, H, W, c.Cout, 0, c.Cin, 3, 1, 1, L.GATHER_DGRAD_REFLECT, epi=epi)
@@ -553,7 +566,7 @@ class Engine:
         ops.head_dgrad(dzl, hd.w.data, A, elu_src=D["x5"])
         self._wgrad(dec.o42, L.GATHER_FWD_REFLECT, D["y51"], None, A, N, H, W, H, W, 32, 0, acc)
         Bz = self._dgrad_dec(dec.o42, A, N, H, W, buf(pfx + "B", (N, H, W, 32)), actsrc=D["y51"])
-        self._wgrad(dec.o41, L.GATHER_FWD_REFLECT_UP2, x4, None, Bz, N, H, W, H, W, 64, 0, acc)
+        self._wgrad_up2(dec.o41, x4, None, Bz, N, h0, w0, 64, 0, acc)
         phase41 = dec.o41.up2 is not None
         if phase41:
             XV = self._dgrad_up2_ext(dec.o41, Bz, N, h0, w0, 64, pfx)
@@ -584,7 +597,7 @@ class Engine:
             # A = dZ of post2 at (hh, ww)
             self._wgrad(blk["post2"], L.GATHER_FWD_REFLECT, y3, None, A, N, hh, ww, hh, ww, cout, 0, acc)
             Bz = self._dgrad_dec(blk["post2"], A, N, hh, ww, buf(pfx + "B", (N, hh, ww, cout)), actsrc=y3)
-            self._wgrad(blk["post1"], L.GATHER_FWD_REFLECT_UP2, y2, skip, Bz, N, hh, ww, hh, ww, cout, cout, acc)
+            self._wgrad_up2(blk["post1"], y2, skip, Bz, N, hl, wl, cout, cout, acc)
             A = buf(pfx + "A", (N, hl, wl, cout))
             if blk["post1"].up2 is not None:
                 # d(low) = 4x4 stride-2 conv over dZ + border fold (* ELU'); d(skip) straight into the feature gradient

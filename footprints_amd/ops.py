@@ -78,6 +78,32 @@ def conv_wgrad(desc, src0, src1, dz, dw, accumulate=False):
     return dw
 
 
+def conv_wgrad_slice(desc, src0, src1, dz, dw, k_begin, accumulate=False):
+    """weight gradient of the input-channel slice [k_begin, k_begin + C0 + C1) of the wider gradient dw [Nout][Cin][K][K]"""
+    lib = _lib.load()
+    ws = workspace(lib.fp_conv_wgrad_workspace(C.byref(desc)), dz.device)
+    _lib.check(lib.fp_conv_wgrad_slice(C.byref(desc), _f32(src0), _f32(src1), _f32(dz), _f32(dw), dw.shape[1], k_begin,
+                                       int(bool(accumulate)), ws.data_ptr(), ws.numel(), stream()), "fp_conv_wgrad_slice")
+    return dw
+
+
+def up2_phase_wgrad_supported(N, h, w, C0, Nout):
+    return _lib.load().fp_conv_up2_phase_wgrad_workspace(N, h, w, C0, Nout) >= 0
+
+
+def conv_up2_phase_wgrad(low, dz, dw, k_begin=0, accumulate=False):
+    lib = _lib.load()
+    N, h, w, C0 = low.shape
+    Nout = dz.shape[3]
+    need = lib.fp_conv_up2_phase_wgrad_workspace(N, h, w, C0, Nout)
+    if need < 0:
+        raise RuntimeError("fp_conv_up2_phase_wgrad: shape not supported")
+    ws = workspace(need, dz.device)
+    _lib.check(lib.fp_conv_up2_phase_wgrad(_f32(low), _f32(dz), _f32(dw), N, h, w, C0, Nout, dw.shape[1], k_begin,
+                                           int(bool(accumulate)), ws.data_ptr(), ws.numel(), stream()), "fp_conv_up2_phase_wgrad")
+    return dw
+
+
 def packed_weight_elems(Cout, Cin, K, for_dgrad=False, stem=False):
     return int(_lib.load().fp_packed_weight_elems(Cout, Cin, K, K, int(for_dgrad), int(stem)))
 

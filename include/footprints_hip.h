@@ -81,6 +81,11 @@ int fp_conv_igemm(const fp_conv_desc* d, const float* src0, const float* src1, c
  * Deterministic two-stage reduction through `workspace` (>= fp_conv_wgrad_workspace(d) bytes).
  * accumulate != 0 => dW += result.  Replaces the weight half of aten::convolution_backward. */
 int64_t fp_conv_wgrad_workspace(const fp_conv_desc* d);
+/* fp_conv_wgrad_slice: same, but the C0+C1 input channels of `d` are the slice [k_begin, k_begin+C0+C1) of a wider
+ * gradient dw_oihw[Nout][kc_total][KH][KW] (the skip half of a concat conv). */
+int fp_conv_wgrad_slice(const fp_conv_desc* d, const float* src0, const float* src1, const float* dz, float* dw_oihw,
+                        int32_t kc_total, int32_t k_begin, int accumulate, void* workspace, int64_t workspace_bytes,
+                        fp_stream_t stream);
 int fp_conv_wgrad(const fp_conv_desc* d, const float* src0, const float* src1, const float* dz,
                   float* dw_oihw, int accumulate, void* workspace, int64_t workspace_bytes, fp_stream_t stream);
 
@@ -116,6 +121,14 @@ int fp_pack_conv_weight_dgrad_slice(const float* w_oihw, float* wp, int32_t Cout
                                     int32_t c_count, fp_stream_t stream);
 int fp_up2_fold_bwd(const float* ext, int32_t N, int32_t h, int32_t w, int32_t C, const float* addend,
                     const float* ylow_elu, float* dlow, fp_stream_t stream);
+/* Weight gradient of the upsampled half: dw_oihw[:, k_begin:k_begin+C0] (+)= un-collapse of the 16 per-phase products
+ * (dw_oihw is [Nout][kc_total][3][3]).  fp_conv_up2_phase_wgrad_workspace returns -1 for shapes it does not take
+ * (C0, Nout multiples of 32; <= 30 % padded 2x16 chunks) -- use fp_conv_wgrad{FWD_REFLECT_UP2} there.  The skip half is
+ * fp_conv_wgrad_slice{FWD_REFLECT} into dw_oihw[:, C0:]. */
+int64_t fp_conv_up2_phase_wgrad_workspace(int32_t N, int32_t h, int32_t w, int32_t C0, int32_t Nout);
+int fp_conv_up2_phase_wgrad(const float* low, const float* dz, float* dw_oihw, int32_t N, int32_t h, int32_t w, int32_t C0,
+                            int32_t Nout, int32_t kc_total, int32_t k_begin, int accumulate, void* workspace,
+                            int64_t workspace_bytes, fp_stream_t stream);
 
 /* column sums: out[c] (+)= sum_m x[m][c]  -- conv bias gradient (weight half of convolution_backward) */
 int64_t fp_colsum_workspace(int64_t M, int32_t C);
