@@ -21,6 +21,15 @@ class ConvDesc(C.Structure):
                                          "gather", "act")] + [("epi", C.c_uint32)]
 
 
+PACK_FWD, PACK_DGRAD, PACK_STEM, PACK_UP2_FWD, PACK_UP2_DGRAD = range(5)
+
+
+class PackJob(C.Structure):
+    """fp_pack_job (include/footprints_hip.h): one entry of the device-resident table of fp_pack_weights_batched"""
+    _fields_ = [("w", C.c_void_p), ("wp", C.c_void_p)] + [(n, C.c_int32) for n in (
+        "Cout", "Cin", "KH", "KW", "kind", "c_begin", "c_count", "block_begin", "block_count")]
+
+
 _P, _I32, _I64, _F, _D = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double
 _DESC = C.POINTER(ConvDesc)
 
@@ -43,6 +52,8 @@ SIGNATURES = {
     "fp_conv_wgrad_slice": (C.c_int, [_DESC, _P, _P, _P, _P, _I32, _I32, C.c_int, _P, _I64, _P]),
     "fp_conv_up2_phase_wgrad_workspace": (_I64, [_I32, _I32, _I32, _I32, _I32]),
     "fp_conv_up2_phase_wgrad": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, C.c_int, _P, _I64, _P]),
+    "fp_pack_job_blocks": (_I32, [_I32, _I32, _I32, _I32, _I32]),
+    "fp_pack_weights_batched": (C.c_int, [_P, _P, _I32, _P]),
     "fp_colsum_workspace": (_I64, [_I64, _I32]),
     "fp_colsum": (C.c_int, [_P, _I64, _I32, _P, C.c_int, _P, _I64, _P]),
     "fp_up2cat_bwd": (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, C.c_int, _P]),

@@ -94,59 +94,70 @@ __global__ void __launch_bounds__(256) conv3x3_tile_kernel(const TileArgs a) {
   const int y0 = tile_y * TH, x0 = tile_x * TW, n0 = tile_n * BN;
 
   // ---- halo staging slots: source pixel of every halo pixel, computed once per workgroup ----------------------
+  // Loads are UNCONDITIONAL (invalid slots read pixel 0 and are zeroed on the way into LDS): straight-line loads let hipcc
+  // count vmcnt exactly, so waiting for a weight slice does not also wait for the younger halo prefetch.
   int pix0[NS], pix1[NS], lds_off[NS];
+  bool hvalid[NS];
 #pragma unroll
   for (int k = 0; k < NS; ++k) {
     const int lin = t + 256 * k, hp = lin >> 2;
-    pix0[k] = pix1[k] = -1;
+    pix0[k] = pix1[k] = 0;
+    hvalid[k] = false;
     lds_off[k] = hp < HP ? hp * LD + (lin & 3) * 4 : -1;
     if (hp < HP) {
       const int hy = hp / HW2, hx = hp - hy * HW2;
       int sy = y0 + hy - a.off, sx = x0 + hx - a.off;
       if (a.mode == 0) {
-        if (sy >= 0 && sy < a.IH && sx >= 0 && sx < a.IW) pix0[k] = (n_img * a.IH + sy) * a.IW + sx;
-      } else if (sy >= -1 && sy <= a.IH && sx >= -1 && sx <= a.IW) {
+        hvalid[k] = sy >= 0 && sy < a.IH && sx >= 0 && sx < a.IW;
+      } else {
+        hvalid[k] = sy >= -1 && sy <= a.IH && sx >= -1 && sx <= a.IW;
         sy = fp_reflect(sy, a.IH);
         sx = fp_reflect(sx, a.IW);
-        if (a.mode == 1) {
-          pix0[k] = (n_img * a.IH + sy) * a.IW + sx;
-        } else {
-          pix0[k] = (n_img * (a.IH >> 1) + (sy >> 1)) * (a.IW >> 1) + (sx >> 1);
-          pix1[k] = (n_img * a.IH + sy) * a.IW + sx;
-        }
+      }
+      // invalid slots read the nearest in-image pixel (distinct, cache-friendly addresses) and are zeroed on the way into LDS
+      sy = min(max(sy, 0), a.IH - 1);
+      sx = min(max(sx, 0), a.IW - 1);
+      if (a.mode != 2) {
+        pix0[k] = (n_img * a.IH + sy) * a.IW + sx;
+      } else {
+        pix0[k] = (n_img * (a.IH >> 1) + (sy >> 1)) * (a.IW >> 1) + (sx >> 1);
+        pix1[k] = (n_img * a.IH + sy) * a.IW + sx;
       }
     }
   }
   float4 hreg[NS];
+  bool hzero = false;     // this thread's channel quad lies beyond C0 + C1 (last, partial chunk)
   auto load_halo = [&](int cc) {
     const int c4 = cc * 16 + (t & 3) * 4;
+    const bool from1 = c4 >= a.C0;
+    hzero = c4 >= a.C0 + a.C1;
+    const float* base = from1 ? a.src1 : a.src0;
+    const int cstride = from1 ? a.C1 : a.C0;
+    const int coff = hzero ? 0 : (from1 ? c4 - a.C0 : c4);
+    if (from1 && a.C1 == 0) { base = a.src0; }            // (hzero) any valid address
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (c4 < a.C0) {
-        if (pix0[k] >= 0) v = *reinterpret_cast<const float4*>(a.src0 + (size_t)pix0[k] * a.C0 + c4);
-      } else if (c4 < a.C0 + a.C1) {
-        if (pix1[k] >= 0) v = *reinterpret_cast<const float4*>(a.src1 + (size_t)pix1[k] * a.C1 + (c4 - a.C0));
-      }
-      hreg[k] = v;
+      const int px = (from1 && a.C1 > 0) ? pix1[k] : pix0[k];
+      hreg[k] = *reinterpret_cast<const float4*>(base + (size_t)px * ((from1 && a.C1 == 0) ? a.C0 : cstride) + coff);
     }
   };
   auto store_halo = [&](int buf) {
 #pragma unroll
     for (int k = 0; k < NS; ++k)
-      if (lds_off[k] >= 0) *reinterpret_cast<float4*>(lds + buf * HP * LD + lds_off[k]) = hreg[k];
+      if (lds_off[k] >= 0)
+        *reinterpret_cast<float4*>(lds + buf * HP * LD + lds_off[k]) = (hvalid[k] && !hzero) ? hreg[k] : make_float4(0.f, 0.f, 0.f, 0.f);
   };
 
-  // ---- B fragments straight from global (L1/L2-resident weight slices), one tap ahead -------------------------
-  float4 bcur[TN][2], bnext[TN][2];
+  // ---- B fragments straight from global (L1/L2-resident weight slices), TWO taps ahead in three rotating register sets
+  // (9 taps per chunk = 3 full rotations, so the set index is static).  Columns beyond Nout re-read column Nout-1 (never stored).
+  float4 bq[3][TN][2];
   auto load_b = [&](int tap, int cc, float4 (&bf)[TN][2]) {
     const float* ws = a.w + (size_t)(tap * a.KC16 + cc) * a.Nout * 16 + h * 4;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      const int n = n0 + (wn * TN + j) * 32 + idx;
+      const int n = min(n0 + (wn * TN + j) * 32 + idx, a.Nout - 1);
 #pragma unroll
-      for (int kh = 0; kh < 2; ++kh)
-        bf[j][kh] = n < a.Nout ? *reinterpret_cast<const float4*>(ws + (size_t)n * 16 + kh * 8) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int kh = 0; kh < 2; ++kh) bf[j][kh] = *reinterpret_cast<const float4*>(ws + (size_t)n * 16 + kh * 8);
     }
   };
 
@@ -187,12 +198,14 @@ __global__ void __launch_bounds__(256) conv3x3_tile_kernel(const TileArgs a) {
 
   load_halo(0);
   store_halo(0);
-  load_b(0, 0, bcur);
-  if (a.KC16 > 1) load_halo(1);
+  load_b(0, 0, bq[0]);
+  load_b(1, 0, bq[1]);
+  load_halo(min(1, a.KC16 - 1));     // halo tiles are fetched two chunks ahead (unconditionally: the tail re-reads the last chunk)
   __syncthreads();
 
   for (int cc = 0; cc < a.KC16; ++cc) {
     const float* Hb = lds + (cc & 1) * HP * LD;
+    const int ccn = min(cc + 1, a.KC16 - 1);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int ky = tap / 3, kx = tap % 3;
@@ -205,12 +218,13 @@ __global__ void __launch_bounds__(256) conv3x3_tile_kernel(const TileArgs a) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         if (c == 1) {
-          // Prefetch the next weight slice (next tap, or tap 0 of the next chunk) one quarter into this tap's MFMA
-          // burst: hipcc waits for it with vmcnt(0) at the top of the next tap, so issuing it here (pinned by the
-          // sched_barriers) leaves ~12 MFMAs = ~770 cycles of cover instead of none.
+          // Prefetch the weight slice of tap + 2 (wrapping into the next chunk).  All loads of this loop are unconditional and
+          // in straight-line code, so hipcc emits exact vmcnt(N) waits: a tap waits for ITS slice only, never for the younger
+          // slice or the halo prefetch behind it (measured: +4-5 % on the 96x320 / 192x640 layers over vmcnt(0) waits).
           __builtin_amdgcn_sched_barrier(0);
-          if (tap < 8) load_b(tap + 1, cc, bnext);
-          else if (cc + 1 < a.KC16) load_b(0, cc + 1, bnext);
+          // (unconditional: the last chunk re-reads itself, so the wait counts are the same on every path)
+          if (tap < 7) load_b(tap + 2, cc, bq[(tap + 2) % 3]);
+          else load_b(tap - 7, ccn, bq[(tap + 2) % 3]);
           __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
@@ -219,13 +233,12 @@ __global__ void __launch_bounds__(256) conv3x3_tile_kernel(const TileArgs a) {
           for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
+              const float4 bb = bq[tap % 3][j][kh];
               const float av = c == 0 ? af[i][kh].x : c == 1 ? af[i][kh].y : c == 2 ? af[i][kh].z : af[i][kh].w;
-              const float bv = c == 0 ? bcur[j][kh].x : c == 1 ? bcur[j][kh].y : c == 2 ? bcur[j][kh].z : bcur[j][kh].w;
+              const float bv = c == 0 ? bb.x : c == 1 ? bb.y : c == 2 ? bb.z : bb.w;
               acc[i][j][kh] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j][kh], 0, 0, 0);
             }
       }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) { bcur[j][0] = bnext[j][0]; bcur[j][1] = bnext[j][1]; }
     }
     if (FOLD && border_tile) {
       // reflection fold: dX[y][x] += sum over the extra (row, col) source choices of tap (ky, kx):
@@ -262,8 +275,8 @@ __global__ void __launch_bounds__(256) conv3x3_tile_kernel(const TileArgs a) {
       }
     }
     if (cc + 1 < a.KC16) {
-      store_halo((cc + 1) & 1);           // chunk cc+1 was loaded during chunk cc (or in the prologue)
-      if (cc + 2 < a.KC16) load_halo(cc + 2);
+      store_halo((cc + 1) & 1);           // chunk cc+1 was fetched during chunk cc-1 (or in the prologue)
+      load_halo(min(cc + 2, a.KC16 - 1));
       __syncthreads();                    // one barrier per 9 taps
     }
   }

@@ -49,37 +49,39 @@ __global__ void __launch_bounds__(256) up2_phase_fwd_kernel(const PhaseArgs a) {
   const int dy = phase >> 1, dx = phase & 1;
   const int y0 = tile_y * TH, x0 = tile_x * TW, n0 = tile_n * BN;
 
+  // all loads unconditional + straight-line (exact vmcnt waits, see conv3x3_tile.hip); replicate padding has no invalid pixels,
+  // only the slots beyond the halo tile (not stored) and channel quads beyond C0 (stored as zero).
   int pix[NS], lds_off[NS];
 #pragma unroll
   for (int k = 0; k < NS; ++k) {
-    const int lin = t + 256 * k, hp = lin >> 2;
-    lds_off[k] = hp < HP ? hp * LD + (lin & 3) * 4 : -1;
+    const int lin = t + 256 * k, hp = min(lin >> 2, HP - 1);
+    lds_off[k] = (lin >> 2) < HP ? hp * LD + (lin & 3) * 4 : -1;
     const int hy = hp / HW2, hx = hp - hy * HW2;
     const int sy = min(max(y0 + hy - 1, 0), a.h - 1), sx = min(max(x0 + hx - 1, 0), a.w_ - 1);   // replicate padding
     pix[k] = (n_img * a.h + sy) * a.w_ + sx;
   }
   float4 hreg[NS];
+  bool hzero = false;
   auto load_halo = [&](int cc) {
     const int c4 = cc * 16 + (t & 3) * 4;
+    hzero = c4 >= a.C0;
+    const int coff = hzero ? 0 : c4;
 #pragma unroll
-    for (int k = 0; k < NS; ++k)
-      hreg[k] = (lds_off[k] >= 0 && c4 < a.C0) ? *reinterpret_cast<const float4*>(a.low + (size_t)pix[k] * a.C0 + c4)
-                                               : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < NS; ++k) hreg[k] = *reinterpret_cast<const float4*>(a.low + (size_t)pix[k] * a.C0 + coff);
   };
   auto store_halo = [&](int buf) {
 #pragma unroll
     for (int k = 0; k < NS; ++k)
-      if (lds_off[k] >= 0) *reinterpret_cast<float4*>(lds + buf * HP * LD + lds_off[k]) = hreg[k];
+      if (lds_off[k] >= 0) *reinterpret_cast<float4*>(lds + buf * HP * LD + lds_off[k]) = hzero ? make_float4(0.f, 0.f, 0.f, 0.f) : hreg[k];
   };
-  float4 bcur[TN][2], bnext[TN][2];
+  float4 bq[4][TN][2];     // weight slices two taps ahead; 4 taps per chunk => the register set of a tap is static
   auto load_b = [&](int tap, int cc, float4 (&bf)[TN][2]) {
     const float* ws = a.w + (size_t)((phase * 4 + tap) * a.KC16 + cc) * a.Nout * 16 + h * 4;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      const int n = n0 + (wn * TN + j) * 32 + idx;
+      const int n = min(n0 + (wn * TN + j) * 32 + idx, a.Nout - 1);
 #pragma unroll
-      for (int kh = 0; kh < 2; ++kh)
-        bf[j][kh] = n < a.Nout ? *reinterpret_cast<const float4*>(ws + (size_t)n * 16 + kh * 8) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int kh = 0; kh < 2; ++kh) bf[j][kh] = *reinterpret_cast<const float4*>(ws + (size_t)n * 16 + kh * 8);
     }
   };
   int abase[TM];
@@ -98,11 +100,13 @@ __global__ void __launch_bounds__(256) up2_phase_fwd_kernel(const PhaseArgs a) {
 
   load_halo(0);
   store_halo(0);
-  load_b(0, 0, bcur);
-  if (a.KC16 > 1) load_halo(1);
+  load_b(0, 0, bq[0]);
+  load_b(1, 0, bq[1]);
+  load_halo(min(1, a.KC16 - 1));
   __syncthreads();
   for (int cc = 0; cc < a.KC16; ++cc) {
     const float* Hb = lds + (cc & 1) * HP * LD;
+    const int ccn = min(cc + 1, a.KC16 - 1);
 #pragma unroll
     for (int tap = 0; tap < 4; ++tap) {
       const int toff = ((tap >> 1) * HW2 + (tap & 1)) * LD;      // tap (a, b): halo offset (dy + a, dx + b)
@@ -115,8 +119,8 @@ __global__ void __launch_bounds__(256) up2_phase_fwd_kernel(const PhaseArgs a) {
       for (int c = 0; c < 4; ++c) {
         if (c == 1) {
           __builtin_amdgcn_sched_barrier(0);
-          if (tap < 3) load_b(tap + 1, cc, bnext);
-          else if (cc + 1 < a.KC16) load_b(0, cc + 1, bnext);
+          if (tap < 2) load_b(tap + 2, cc, bq[tap + 2]);
+          else load_b(tap - 2, ccn, bq[tap - 2]);
           __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
@@ -125,17 +129,16 @@ __global__ void __launch_bounds__(256) up2_phase_fwd_kernel(const PhaseArgs a) {
           for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
+              const float4 bb = bq[tap][j][kh];
               const float av = c == 0 ? af[i][kh].x : c == 1 ? af[i][kh].y : c == 2 ? af[i][kh].z : af[i][kh].w;
-              const float bv = c == 0 ? bcur[j][kh].x : c == 1 ? bcur[j][kh].y : c == 2 ? bcur[j][kh].z : bcur[j][kh].w;
+              const float bv = c == 0 ? bb.x : c == 1 ? bb.y : c == 2 ? bb.z : bb.w;
               acc[i][j][kh] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j][kh], 0, 0, 0);
             }
       }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) { bcur[j][0] = bnext[j][0]; bcur[j][1] = bnext[j][1]; }
     }
     if (cc + 1 < a.KC16) {
       store_halo((cc + 1) & 1);
-      if (cc + 2 < a.KC16) load_halo(cc + 2);
+      load_halo(min(cc + 2, a.KC16 - 1));
       __syncthreads();
     }
   }
@@ -161,91 +164,13 @@ __global__ void __launch_bounds__(256) up2_phase_fwd_kernel(const PhaseArgs a) {
     }
 }
 
-// wp[phase][tap(a,b)][kc][n][16]: collapsed weights of input channels [c_begin, c_begin + c_count) of w_oihw [Cout][Cin][3][3]
-__global__ void __launch_bounds__(256) pack_up2_fwd_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin,
-                                                           int c_begin, int c_count, int KC16) {
-  const size_t total = (size_t)16 * KC16 * Cout * 16;
-  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
-    const int kr = (int)(e & 15);
-    size_t r = e >> 4;
-    const int n = (int)(r % Cout); r /= Cout;
-    const int kc = (int)(r % KC16); r /= KC16;
-    const int tap = (int)(r & 3), phase = (int)(r >> 2);
-    const int dy = phase >> 1, dx = phase & 1, ta = tap >> 1, tb = tap & 1;
-    const int k = kc * 16 + kr;
-    float v = 0.f;
-    if (k < c_count) {
-      const float* wk = w + ((size_t)n * Cin + c_begin + k) * 9;
-      // rows collapsed into (dy, a): dy=0: a=0 <- {0}, a=1 <- {1,2};  dy=1: a=0 <- {0,1}, a=1 <- {2}
-      const int ky_lo = dy == 0 ? (ta == 0 ? 0 : 1) : (ta == 0 ? 0 : 2), ky_hi = dy == 0 ? (ta == 0 ? 0 : 2) : (ta == 0 ? 1 : 2);
-      const int kx_lo = dx == 0 ? (tb == 0 ? 0 : 1) : (tb == 0 ? 0 : 2), kx_hi = dx == 0 ? (tb == 0 ? 0 : 2) : (tb == 0 ? 1 : 2);
-      for (int ky = ky_lo; ky <= ky_hi; ++ky)
-        for (int kx = kx_lo; kx <= kx_hi; ++kx) v += wk[ky * 3 + kx];
-    }
-    wp[e] = v;
-  }
-}
-
-// plain packing of an input-channel slice (the skip half of a concat conv): wp[tap][kc][n][16]
-__global__ void __launch_bounds__(256) pack_slice_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin,
-                                                         int c_begin, int c_count, int KC16) {
-  const size_t total = (size_t)9 * KC16 * Cout * 16;
-  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
-    const int kr = (int)(e & 15);
-    size_t r = e >> 4;
-    const int n = (int)(r % Cout); r /= Cout;
-    const int kc = (int)(r % KC16);
-    const int tap = (int)(r / KC16);
-    const int k = kc * 16 + kr;
-    wp[e] = k < c_count ? w[((size_t)n * Cin + c_begin + k) * 9 + tap] : 0.f;
-  }
-}
-
 // ---- backward ----------------------------------------------------------------------------------------------------
 // d(low) of the phase decomposition is a 4x4 stride-2 convolution over dZ (taps r = hi-res row - (2Y - 1)):
 //     K4[0] = W[2], K4[1] = W[1] + W[2], K4[2] = W[0] + W[1], K4[3] = W[0]         (rows; same for columns)
 // plus the replicate-padding fold: the virtual low-res rows -1 / h (columns -1 / w) receive gradient too and belong to
 // rows 0 / h-1.  fp_conv_igemm (FWD_ZERO gather, K=4, stride 2, pad 3) evaluates the conv on the (h+2) x (w+2) extended grid
 // with these packed weights; up2_fold_bwd_kernel folds the border back, adds the second consumer's gradient and applies ELU'.
-// wp[tap r*4+s][kc over Cout][c][16]
-__global__ void __launch_bounds__(256) pack_up2_dgrad_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin,
-                                                             int c_begin, int c_count, int KC16) {
-  const size_t total = (size_t)16 * KC16 * c_count * 16;
-  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
-    const int kr = (int)(e & 15);
-    size_t r = e >> 4;
-    const int c = (int)(r % c_count); r /= c_count;
-    const int kc = (int)(r % KC16);
-    const int tap = (int)(r / KC16);
-    const int tr = tap >> 2, ts = tap & 3;
-    const int n = kc * 16 + kr;
-    float v = 0.f;
-    if (n < Cout) {
-      const float* wk = w + ((size_t)n * Cin + c_begin + c) * 9;
-      const int ky_lo = tr == 0 ? 2 : (tr == 1 ? 1 : 0), ky_hi = tr == 0 ? 2 : (tr == 1 ? 2 : (tr == 2 ? 1 : 0));
-      const int kx_lo = ts == 0 ? 2 : (ts == 1 ? 1 : 0), kx_hi = ts == 0 ? 2 : (ts == 1 ? 2 : (ts == 2 ? 1 : 0));
-      for (int ky = ky_lo; ky <= ky_hi; ++ky)
-        for (int kx = kx_lo; kx <= kx_hi; ++kx) v += wk[ky * 3 + kx];
-    }
-    wp[e] = v;
-  }
-}
-
-// dgrad packing of an input-channel slice: wp[tap][kc over Cout][ci][16]
-__global__ void __launch_bounds__(256) pack_dgrad_slice_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin,
-                                                               int c_begin, int c_count, int KC16) {
-  const size_t total = (size_t)9 * KC16 * c_count * 16;
-  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
-    const int kr = (int)(e & 15);
-    size_t r = e >> 4;
-    const int ci = (int)(r % c_count); r /= c_count;
-    const int kc = (int)(r % KC16);
-    const int tap = (int)(r / KC16);
-    const int co = kc * 16 + kr;
-    wp[e] = co < Cout ? w[((size_t)co * Cin + c_begin + ci) * 9 + tap] : 0.f;
-  }
-}
-
+// (packing: pack.hip, FP_PACK_UP2_DGRAD)
 __global__ void __launch_bounds__(256) up2_fold_bwd_kernel(const float* __restrict__ ext, int N, int h, int w, int C,
                                                            const float* __restrict__ addend, const float* __restrict__ ylow,
                                                            float* __restrict__ dlow) {
@@ -291,28 +216,6 @@ int grid_for(size_t total) {
 
 }  // namespace
 
-extern "C" int64_t fp_up2_packed_weight_elems(int32_t Cout, int32_t c_count) {
-  return (int64_t)16 * ((c_count + 15) / 16) * Cout * 16;
-}
-
-extern "C" int fp_pack_up2_weight(const float* w_oihw, float* wp, int32_t Cout, int32_t Cin, int32_t c_begin, int32_t c_count,
-                                  fp_stream_t stream) {
-  FP_REQUIRE(w_oihw && wp && c_begin >= 0 && c_count > 0 && c_begin + c_count <= Cin, "fp_pack_up2_weight: bad arguments");
-  const int KC16 = (c_count + 15) / 16;
-  hipLaunchKernelGGL(pack_up2_fwd_kernel, dim3(grid_for((size_t)16 * KC16 * Cout * 16)), dim3(256), 0, (hipStream_t)stream, w_oihw, wp,
-                     Cout, Cin, c_begin, c_count, KC16);
-  return fp_check_launch("fp_pack_up2_weight");
-}
-
-extern "C" int fp_pack_conv_weight_slice(const float* w_oihw, float* wp, int32_t Cout, int32_t Cin, int32_t c_begin, int32_t c_count,
-                                         fp_stream_t stream) {
-  FP_REQUIRE(w_oihw && wp && c_begin >= 0 && c_count > 0 && c_begin + c_count <= Cin, "fp_pack_conv_weight_slice: bad arguments");
-  const int KC16 = (c_count + 15) / 16;
-  hipLaunchKernelGGL(pack_slice_kernel, dim3(grid_for((size_t)9 * KC16 * Cout * 16)), dim3(256), 0, (hipStream_t)stream, w_oihw, wp,
-                     Cout, Cin, c_begin, c_count, KC16);
-  return fp_check_launch("fp_pack_conv_weight_slice");
-}
-
 extern "C" int fp_conv_up2_phase_fwd(const float* low, const float* wphase, const float* bias, const float* addend, float* y,
                                      int32_t N, int32_t h, int32_t w, int32_t C0, int32_t Nout, int32_t act, fp_stream_t stream) {
   FP_REQUIRE(low && wphase && y && N > 0 && h >= 1 && w >= 1 && C0 > 0 && C0 % 4 == 0 && Nout > 0, "fp_conv_up2_phase_fwd: bad arguments");
@@ -331,24 +234,6 @@ extern "C" int fp_conv_up2_phase_fwd(const float* low, const float* wphase, cons
     hipLaunchKernelGGL((up2_phase_fwd_kernel<64, 2, 2>), dim3(a.nwg), dim3(256), 0, (hipStream_t)stream, a);
   }
   return fp_check_launch("fp_conv_up2_phase_fwd");
-}
-
-extern "C" int fp_pack_up2_weight_dgrad(const float* w_oihw, float* wp, int32_t Cout, int32_t Cin, int32_t c_begin, int32_t c_count,
-                                        fp_stream_t stream) {
-  FP_REQUIRE(w_oihw && wp && c_begin >= 0 && c_count > 0 && c_begin + c_count <= Cin, "fp_pack_up2_weight_dgrad: bad arguments");
-  const int KC16 = (Cout + 15) / 16;
-  hipLaunchKernelGGL(pack_up2_dgrad_kernel, dim3(grid_for((size_t)16 * KC16 * c_count * 16)), dim3(256), 0, (hipStream_t)stream, w_oihw,
-                     wp, Cout, Cin, c_begin, c_count, KC16);
-  return fp_check_launch("fp_pack_up2_weight_dgrad");
-}
-
-extern "C" int fp_pack_conv_weight_dgrad_slice(const float* w_oihw, float* wp, int32_t Cout, int32_t Cin, int32_t c_begin,
-                                               int32_t c_count, fp_stream_t stream) {
-  FP_REQUIRE(w_oihw && wp && c_begin >= 0 && c_count > 0 && c_begin + c_count <= Cin, "fp_pack_conv_weight_dgrad_slice: bad arguments");
-  const int KC16 = (Cout + 15) / 16;
-  hipLaunchKernelGGL(pack_dgrad_slice_kernel, dim3(grid_for((size_t)9 * KC16 * c_count * 16)), dim3(256), 0, (hipStream_t)stream, w_oihw,
-                     wp, Cout, Cin, c_begin, c_count, KC16);
-  return fp_check_launch("fp_pack_conv_weight_dgrad_slice");
 }
 
 extern "C" int fp_up2_fold_bwd(const float* ext, int32_t N, int32_t h, int32_t w, int32_t C, const float* addend, const float* ylow_elu,

@@ -145,49 +145,6 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const 
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Weight packing for the implicit-GEMM kernels: Wp[tap][ceil(K/16)][Ncols][16]
-// ------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) pack_fwd_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin,
-                                                       int T, int KC16) {
-  const size_t total = (size_t)T * KC16 * Cout * 16;
-  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
-    const int kr = (int)(e & 15);
-    size_t r = e >> 4;
-    const int n = (int)(r % Cout); r /= Cout;
-    const int kc = (int)(r % KC16);
-    const int tap = (int)(r / KC16);
-    const int k = kc * 16 + kr;
-    wp[e] = k < Cin ? w[((size_t)n * Cin + k) * T + tap] : 0.f;
-  }
-}
-__global__ void __launch_bounds__(256) pack_stem_kernel(const float* __restrict__ w, float* __restrict__ wp) {
-  const int total = 10 * 64 * 16;
-  for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
-    const int kr = e & 15, n = (e >> 4) % 64, kc = (e >> 4) / 64;
-    const int kk = kc * 16 + kr;
-    float v = 0.f;
-    if (kk < 147) {
-      const int ky = kk / 21, rem = kk - ky * 21, kx = rem / 3, ci = rem - kx * 3;
-      v = w[((n * 3 + ci) * 7 + ky) * 7 + kx];
-    }
-    wp[e] = v;
-  }
-}
-__global__ void __launch_bounds__(256) pack_dgrad_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin,
-                                                         int T, int KC16) {
-  const size_t total = (size_t)T * KC16 * Cin * 16;
-  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
-    const int kr = (int)(e & 15);
-    size_t r = e >> 4;
-    const int ci = (int)(r % Cin); r /= Cin;
-    const int kc = (int)(r % KC16);
-    const int tap = (int)(r / KC16);
-    const int co = kc * 16 + kr;
-    wp[e] = co < Cout ? w[((size_t)co * Cin + ci) * T + tap] : 0.f;
-  }
-}
-
-// ------------------------------------------------------------------------------------------------------------
 // Column sums (bias gradients)
 // ------------------------------------------------------------------------------------------------------------
 int colsum_blocks(int64_t M, int C) {
@@ -342,35 +299,6 @@ extern "C" int fp_adam_step(float* param, const float* grad, float* exp_avg, flo
                      exp_avg_sq, (size_t)n, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), step_size, inv_bc2_sqrt, (float)eps,
                      (float)grad_scale);
   return fp_check_launch("fp_adam_step");
-}
-
-extern "C" int64_t fp_packed_weight_elems(int32_t Cout, int32_t Cin, int32_t KH, int32_t KW, int32_t for_dgrad, int32_t stem) {
-  if (stem) return 10 * 64 * 16;
-  const int64_t T = (int64_t)KH * KW;
-  return for_dgrad ? T * ((Cout + 15) / 16) * Cin * 16 : T * ((Cin + 15) / 16) * Cout * 16;
-}
-
-extern "C" int fp_pack_conv_weight(const float* w_oihw, float* wp, int32_t Cout, int32_t Cin, int32_t KH, int32_t KW, int32_t stem,
-                                   fp_stream_t stream) {
-  FP_REQUIRE(w_oihw && wp, "fp_pack_conv_weight: null pointer");
-  if (stem) {
-    FP_REQUIRE(Cout == 64 && Cin == 3 && KH == 7 && KW == 7, "fp_pack_conv_weight: stem must be [64,3,7,7]");
-    hipLaunchKernelGGL(pack_stem_kernel, dim3(40), dim3(256), 0, (hipStream_t)stream, w_oihw, wp);
-  } else {
-    const int KC16 = (Cin + 15) / 16, T = KH * KW;
-    hipLaunchKernelGGL(pack_fwd_kernel, dim3(ew_grid((size_t)T * KC16 * Cout * 16)), dim3(256), 0, (hipStream_t)stream, w_oihw, wp,
-                       Cout, Cin, T, KC16);
-  }
-  return fp_check_launch("fp_pack_conv_weight");
-}
-
-extern "C" int fp_pack_conv_weight_dgrad(const float* w_oihw, float* wp, int32_t Cout, int32_t Cin, int32_t KH, int32_t KW,
-                                         fp_stream_t stream) {
-  FP_REQUIRE(w_oihw && wp, "fp_pack_conv_weight_dgrad: null pointer");
-  const int KC16 = (Cout + 15) / 16, T = KH * KW;
-  hipLaunchKernelGGL(pack_dgrad_kernel, dim3(ew_grid((size_t)T * KC16 * Cin * 16)), dim3(256), 0, (hipStream_t)stream, w_oihw, wp,
-                     Cout, Cin, T, KC16);
-  return fp_check_launch("fp_pack_conv_weight_dgrad");
 }
 
 extern "C" int64_t fp_colsum_workspace(int64_t M, int32_t C) {

@@ -1,0 +1,168 @@
+// Weight packing for the implicit-GEMM kernels (gfx950).  One element function per layout, one generic kernel for a single
+// tensor, and a batched kernel that repacks EVERY convolution of the network in one launch after the optimizer step
+// (the per-tensor launches were ~200 x 4.5 us of GPU time and, worse, ~2 ms of host launch time per training step).
+//
+//   FWD        wp[tap][ceil(Cs/16)][Cout][16]      = W[n][c_begin + k][tap]                       (k < Cs input-channel slice)
+//   DGRAD      wp[tap][ceil(Cout/16)][Cs][16]      = W[co][c_begin + ci][tap]
+//   STEM       wp[10][64][16]: k = (ky*7 + kx)*3 + ci over the 7x7x3 stem
+//   UP2_FWD    wp[phase 4][tap 4][ceil(Cs/16)][Cout][16]: row/column-collapsed weights of the nearest-x2 phase decomposition
+//   UP2_DGRAD  wp[16 taps r*4+s][ceil(Cout/16)][Cs][16]: the 4x4 stride-2 kernel of its data gradient   (conv_up2_phase.hip)
+#include "fp_common.h"
+
+namespace {
+
+__device__ __forceinline__ float pack_elem(const fp_pack_job& j, size_t e) {
+  const float* __restrict__ w = j.w;
+  const int kr = (int)(e & 15);
+  size_t r = e >> 4;
+  switch (j.kind) {
+    case FP_PACK_FWD: {
+      const int T = j.KH * j.KW, KC16 = (j.c_count + 15) / 16;
+      const int n = (int)(r % j.Cout); r /= j.Cout;
+      const int kc = (int)(r % KC16), tap = (int)(r / KC16);
+      const int k = kc * 16 + kr;
+      return k < j.c_count ? w[((size_t)n * j.Cin + j.c_begin + k) * T + tap] : 0.f;
+    }
+    case FP_PACK_DGRAD: {
+      const int T = j.KH * j.KW, KC16 = (j.Cout + 15) / 16;
+      const int ci = (int)(r % j.c_count); r /= j.c_count;
+      const int kc = (int)(r % KC16), tap = (int)(r / KC16);
+      const int co = kc * 16 + kr;
+      return co < j.Cout ? w[((size_t)co * j.Cin + j.c_begin + ci) * T + tap] : 0.f;
+    }
+    case FP_PACK_STEM: {
+      const int n = (int)(r % 64), kc = (int)(r / 64);
+      const int kk = kc * 16 + kr;
+      if (kk >= 147) return 0.f;
+      const int ky = kk / 21, rem = kk - ky * 21, kx = rem / 3, ci = rem - kx * 3;
+      return w[((n * 3 + ci) * 7 + ky) * 7 + kx];
+    }
+    case FP_PACK_UP2_FWD: {
+      const int KC16 = (j.c_count + 15) / 16;
+      const int n = (int)(r % j.Cout); r /= j.Cout;
+      const int kc = (int)(r % KC16); r /= KC16;
+      const int tap = (int)(r & 3), phase = (int)(r >> 2);
+      const int dy = phase >> 1, dx = phase & 1, ta = tap >> 1, tb = tap & 1;
+      const int k = kc * 16 + kr;
+      if (k >= j.c_count) return 0.f;
+      const float* wk = w + ((size_t)n * j.Cin + j.c_begin + k) * 9;
+      // rows collapsed into (dy, a): dy=0: a=0 <- {0}, a=1 <- {1,2};  dy=1: a=0 <- {0,1}, a=1 <- {2}   (same for columns)
+      const int ky_lo = dy == 0 ? (ta == 0 ? 0 : 1) : (ta == 0 ? 0 : 2), ky_hi = dy == 0 ? (ta == 0 ? 0 : 2) : (ta == 0 ? 1 : 2);
+      const int kx_lo = dx == 0 ? (tb == 0 ? 0 : 1) : (tb == 0 ? 0 : 2), kx_hi = dx == 0 ? (tb == 0 ? 0 : 2) : (tb == 0 ? 1 : 2);
+      float v = 0.f;
+      for (int ky = ky_lo; ky <= ky_hi; ++ky)
+        for (int kx = kx_lo; kx <= kx_hi; ++kx) v += wk[ky * 3 + kx];
+      return v;
+    }
+    case FP_PACK_UP2_DGRAD: {
+      const int KC16 = (j.Cout + 15) / 16;
+      const int c = (int)(r % j.c_count); r /= j.c_count;
+      const int kc = (int)(r % KC16), tap = (int)(r / KC16);
+      const int tr = tap >> 2, ts = tap & 3;
+      const int n = kc * 16 + kr;
+      if (n >= j.Cout) return 0.f;
+      const float* wk = w + ((size_t)n * j.Cin + j.c_begin + c) * 9;
+      // K4[0] = W[2], K4[1] = W[1] + W[2], K4[2] = W[0] + W[1], K4[3] = W[0]
+      const int ky_lo = tr == 0 ? 2 : (tr == 1 ? 1 : 0), ky_hi = tr == 0 ? 2 : (tr == 1 ? 2 : (tr == 2 ? 1 : 0));
+      const int kx_lo = ts == 0 ? 2 : (ts == 1 ? 1 : 0), kx_hi = ts == 0 ? 2 : (ts == 1 ? 2 : (ts == 2 ? 1 : 0));
+      float v = 0.f;
+      for (int ky = ky_lo; ky <= ky_hi; ++ky)
+        for (int kx = kx_lo; kx <= kx_hi; ++kx) v += wk[ky * 3 + kx];
+      return v;
+    }
+    default: return 0.f;
+  }
+}
+
+__host__ __device__ inline int64_t pack_elems(int kind, int Cout, int KH, int KW, int c_count) {
+  const int64_t T = (int64_t)KH * KW;
+  switch (kind) {
+    case FP_PACK_FWD: return T * ((c_count + 15) / 16) * Cout * 16;
+    case FP_PACK_DGRAD: return T * ((Cout + 15) / 16) * c_count * 16;
+    case FP_PACK_STEM: return 10 * 64 * 16;
+    case FP_PACK_UP2_FWD: return (int64_t)16 * ((c_count + 15) / 16) * Cout * 16;
+    case FP_PACK_UP2_DGRAD: return (int64_t)16 * ((Cout + 15) / 16) * c_count * 16;
+    default: return 0;
+  }
+}
+
+__global__ void __launch_bounds__(256) pack_one_kernel(const fp_pack_job j, size_t total) {
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) j.wp[e] = pack_elem(j, e);
+}
+
+// block b serves job blk2job[b]; a job's blocks are contiguous starting at jobs[job].block_begin
+__global__ void __launch_bounds__(256) pack_batched_kernel(const fp_pack_job* __restrict__ jobs, const int32_t* __restrict__ blk2job) {
+  const int ji = blk2job[blockIdx.x];
+  const fp_pack_job j = jobs[ji];
+  const size_t total = (size_t)pack_elems(j.kind, j.Cout, j.KH, j.KW, j.c_count);
+  const size_t stride = (size_t)j.block_count * 256;
+  for (size_t e = (size_t)(blockIdx.x - j.block_begin) * 256 + threadIdx.x; e < total; e += stride) j.wp[e] = pack_elem(j, e);
+}
+
+int launch_one(int kind, const float* w, float* wp, int Cout, int Cin, int KH, int KW, int c_begin, int c_count, hipStream_t stream,
+               const char* what) {
+  fp_pack_job j;
+  j.w = w; j.wp = wp; j.Cout = Cout; j.Cin = Cin; j.KH = KH; j.KW = KW; j.kind = kind; j.c_begin = c_begin; j.c_count = c_count;
+  j.block_begin = 0; j.block_count = 0;
+  const size_t total = (size_t)pack_elems(kind, Cout, KH, KW, c_count);
+  size_t g = (total + 255) / 256;
+  if (g > 4096) g = 4096;
+  if (g < 1) g = 1;
+  hipLaunchKernelGGL(pack_one_kernel, dim3((unsigned)g), dim3(256), 0, stream, j, total);
+  return fp_check_launch(what);
+}
+
+}  // namespace
+
+extern "C" int64_t fp_packed_weight_elems(int32_t Cout, int32_t Cin, int32_t KH, int32_t KW, int32_t for_dgrad, int32_t stem) {
+  if (stem) return pack_elems(FP_PACK_STEM, 64, 7, 7, 3);
+  return pack_elems(for_dgrad ? FP_PACK_DGRAD : FP_PACK_FWD, Cout, KH, KW, Cin);
+}
+extern "C" int64_t fp_up2_packed_weight_elems(int32_t Ncols, int32_t K) { return pack_elems(FP_PACK_UP2_FWD, Ncols, 3, 3, K); }
+
+extern "C" int fp_pack_conv_weight(const float* w_oihw, float* wp, int32_t Cout, int32_t Cin, int32_t KH, int32_t KW, int32_t stem,
+                                   fp_stream_t stream) {
+  FP_REQUIRE(w_oihw && wp, "fp_pack_conv_weight: null pointer");
+  if (stem) FP_REQUIRE(Cout == 64 && Cin == 3 && KH == 7 && KW == 7, "fp_pack_conv_weight: stem must be [64,3,7,7]");
+  return launch_one(stem ? FP_PACK_STEM : FP_PACK_FWD, w_oihw, wp, Cout, Cin, KH, KW, 0, Cin, (hipStream_t)stream, "fp_pack_conv_weight");
+}
+extern "C" int fp_pack_conv_weight_dgrad(const float* w_oihw, float* wp, int32_t Cout, int32_t Cin, int32_t KH, int32_t KW,
+                                         fp_stream_t stream) {
+  FP_REQUIRE(w_oihw && wp, "fp_pack_conv_weight_dgrad: null pointer");
+  return launch_one(FP_PACK_DGRAD, w_oihw, wp, Cout, Cin, KH, KW, 0, Cin, (hipStream_t)stream, "fp_pack_conv_weight_dgrad");
+}
+
+#define FP_SLICE_OK(name) FP_REQUIRE(w_oihw && wp && c_begin >= 0 && c_count > 0 && c_begin + c_count <= Cin, name ": bad arguments")
+extern "C" int fp_pack_conv_weight_slice(const float* w_oihw, float* wp, int32_t Cout, int32_t Cin, int32_t c_begin, int32_t c_count,
+                                         fp_stream_t stream) {
+  FP_SLICE_OK("fp_pack_conv_weight_slice");
+  return launch_one(FP_PACK_FWD, w_oihw, wp, Cout, Cin, 3, 3, c_begin, c_count, (hipStream_t)stream, "fp_pack_conv_weight_slice");
+}
+extern "C" int fp_pack_conv_weight_dgrad_slice(const float* w_oihw, float* wp, int32_t Cout, int32_t Cin, int32_t c_begin,
+                                               int32_t c_count, fp_stream_t stream) {
+  FP_SLICE_OK("fp_pack_conv_weight_dgrad_slice");
+  return launch_one(FP_PACK_DGRAD, w_oihw, wp, Cout, Cin, 3, 3, c_begin, c_count, (hipStream_t)stream, "fp_pack_conv_weight_dgrad_slice");
+}
+extern "C" int fp_pack_up2_weight(const float* w_oihw, float* wp, int32_t Cout, int32_t Cin, int32_t c_begin, int32_t c_count,
+                                  fp_stream_t stream) {
+  FP_SLICE_OK("fp_pack_up2_weight");
+  return launch_one(FP_PACK_UP2_FWD, w_oihw, wp, Cout, Cin, 3, 3, c_begin, c_count, (hipStream_t)stream, "fp_pack_up2_weight");
+}
+extern "C" int fp_pack_up2_weight_dgrad(const float* w_oihw, float* wp, int32_t Cout, int32_t Cin, int32_t c_begin, int32_t c_count,
+                                        fp_stream_t stream) {
+  FP_SLICE_OK("fp_pack_up2_weight_dgrad");
+  return launch_one(FP_PACK_UP2_DGRAD, w_oihw, wp, Cout, Cin, 3, 3, c_begin, c_count, (hipStream_t)stream, "fp_pack_up2_weight_dgrad");
+}
+
+extern "C" int32_t fp_pack_job_blocks(int32_t kind, int32_t Cout, int32_t KH, int32_t KW, int32_t c_count) {
+  int64_t b = (pack_elems(kind, Cout, KH, KW, c_count) + 2047) / 2048;     // ~8 elements per thread
+  if (b < 1) b = 1;
+  if (b > 256) b = 256;
+  return (int32_t)b;
+}
+
+extern "C" int fp_pack_weights_batched(const fp_pack_job* jobs_dev, const int32_t* blk2job_dev, int32_t nblocks, fp_stream_t stream) {
+  FP_REQUIRE(jobs_dev && blk2job_dev && nblocks > 0, "fp_pack_weights_batched: bad arguments");
+  hipLaunchKernelGGL(pack_batched_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, jobs_dev, blk2job_dev);
+  return fp_check_launch("fp_pack_weights_batched");
+}

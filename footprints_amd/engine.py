@@ -123,6 +123,8 @@ class Engine:
         self._bufs = {}
         self._flatten()
         self._alloc_packed()
+        self._pack_table = None
+        self._pack_table_key = None
         self.weights_dirty = True
         self._versions = None
         self.saved = None
@@ -215,17 +217,22 @@ class Engine:
         vers = tuple(c.w._version for c in self.all_convs())
         if not (force or self.weights_dirty or vers != self._versions):
             return
-        for c in self.all_convs():
-            ops.pack_conv_weight(c.w.data, c.wp, c.stem)
-            if c.wpd is not None:
-                ops.pack_conv_weight_dgrad(c.w.data, c.wpd)
-            if c.up2 is not None:
-                C0, C1 = c.up2
-                ops.pack_up2_weight(c.w.data, c.wph, 0, C0)
-                ops.pack_up2_weight_dgrad(c.w.data, c.wdu, 0, C0)
-                if C1:
-                    ops.pack_conv_weight_slice(c.w.data, c.wsk, C0, C1)
-                    ops.pack_conv_weight_dgrad_slice(c.w.data, c.wds, C0, C1)
+        if self._pack_table is None or self._pack_table_key != self.flat_param.data_ptr():
+            jobs = []
+            for c in self.all_convs():
+                jobs.append((L.PACK_STEM if c.stem else L.PACK_FWD, c.w.data, c.wp, 0, c.Cin))
+                if c.wpd is not None:
+                    jobs.append((L.PACK_DGRAD, c.w.data, c.wpd, 0, c.Cin))
+                if c.up2 is not None:
+                    C0, C1 = c.up2
+                    jobs.append((L.PACK_UP2_FWD, c.w.data, c.wph, 0, C0))
+                    jobs.append((L.PACK_UP2_DGRAD, c.w.data, c.wdu, 0, C0))
+                    if C1:
+                        jobs.append((L.PACK_FWD, c.w.data, c.wsk, C0, C1))
+                        jobs.append((L.PACK_DGRAD, c.w.data, c.wds, C0, C1))
+            self._pack_table = ops.build_pack_table(jobs, self.device)      # parameters live in self.flat: pointers are stable
+            self._pack_table_key = self.flat_param.data_ptr()
+        ops.pack_weights_batched(self._pack_table)
         self._versions = vers
         self.weights_dirty = False
 

@@ -162,6 +162,30 @@ def up2_fold_bwd(ext, dlow, addend=None, ylow=None):
     return dlow
 
 
+def build_pack_table(jobs, device):
+    """jobs: list of (kind, w, wp, c_begin, c_count) over torch tensors that never move.  Returns the device-resident table
+    (jobs, blk2job, nblocks) for pack_weights_batched."""
+    lib = _lib.load()
+    arr = (_lib.PackJob * len(jobs))()
+    blk2job = []
+    for i, (kind, w, wp, c_begin, c_count) in enumerate(jobs):
+        Cout, Cin, KH, KW = w.shape
+        nb = lib.fp_pack_job_blocks(kind, Cout, KH, KW, c_count)
+        j = arr[i]
+        j.w, j.wp = _f32(w), _f32(wp)
+        j.Cout, j.Cin, j.KH, j.KW, j.kind, j.c_begin, j.c_count = Cout, Cin, KH, KW, kind, c_begin, c_count
+        j.block_begin, j.block_count = len(blk2job), nb
+        blk2job += [i] * nb
+    raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+    b2j = torch.tensor(blk2job, dtype=torch.int32, device=device)
+    return raw, b2j, len(blk2job)
+
+
+def pack_weights_batched(table):
+    raw, b2j, nblocks = table
+    _lib.check(_lib.load().fp_pack_weights_batched(raw.data_ptr(), b2j.data_ptr(), nblocks, stream()), "fp_pack_weights_batched")
+
+
 def colsum(x2d, out, accumulate=False):
     lib = _lib.load()
     M, Cn = x2d.shape

@@ -89,6 +89,20 @@ int fp_conv_wgrad_slice(const fp_conv_desc* d, const float* src0, const float* s
 int fp_conv_wgrad(const fp_conv_desc* d, const float* src0, const float* src1, const float* dz,
                   float* dw_oihw, int accumulate, void* workspace, int64_t workspace_bytes, fp_stream_t stream);
 
+/* One repacking job of fp_pack_weights_batched: every convolution's packed copies are refreshed by ONE launch after the
+ * optimizer step (the table lives in device memory and is built once: parameter and packed buffers never move). */
+enum { FP_PACK_FWD = 0, FP_PACK_DGRAD = 1, FP_PACK_STEM = 2, FP_PACK_UP2_FWD = 3, FP_PACK_UP2_DGRAD = 4 };
+typedef struct fp_pack_job {
+  const float* w;  /* [Cout][Cin][KH][KW] */
+  float* wp;       /* packed destination */
+  int32_t Cout, Cin, KH, KW;
+  int32_t kind;             /* FP_PACK_* */
+  int32_t c_begin, c_count; /* input-channel slice (whole tensor: 0, Cin) */
+  int32_t block_begin, block_count; /* this job's contiguous range of workgroups in the batched launch */
+} fp_pack_job;
+int32_t fp_pack_job_blocks(int32_t kind, int32_t Cout, int32_t KH, int32_t KW, int32_t c_count);
+int fp_pack_weights_batched(const fp_pack_job* jobs_dev, const int32_t* blk2job_dev, int32_t nblocks, fp_stream_t stream);
+
 /* packed-weight sizes (floats) and packers; w_oihw is the torch Conv2d.weight [Cout][Cin][KH][KW] */
 int64_t fp_packed_weight_elems(int32_t Cout, int32_t Cin, int32_t KH, int32_t KW, int32_t for_dgrad, int32_t stem);
 int fp_pack_conv_weight(const float* w_oihw, float* wp, int32_t Cout, int32_t Cin, int32_t KH, int32_t KW,

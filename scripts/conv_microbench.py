@@ -6,6 +6,7 @@ import sys
 import torch
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from footprints_amd import ops, _lib as L
+L.LIB_PATH = __import__("os").environ.get("FP_LIB", L.LIB_PATH)
 
 which = sys.argv[1] if len(sys.argv) > 1 else "igemm"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10

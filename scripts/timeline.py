@@ -1,0 +1,59 @@
+"""Timeline analysis of a rocprofv3 --kernel-trace rocpd database: one steady-state training step (adam to adam).
+
+    python scripts/timeline.py gpurun_out/prof/x_results.db [step_index]
+Prints wall time of the step, GPU-busy union, time at concurrency 0/1/2/3+, the largest idle gaps and per-kernel sums.
+"""
+import sqlite3
+import sys
+from collections import defaultdict
+
+db = sys.argv[1]
+which = int(sys.argv[2]) if len(sys.argv) > 2 else -2
+cur = sqlite3.connect(db).cursor()
+rows = list(cur.execute("select name, start, end, stream_id from kernels order by start"))
+adam = [i for i, r in enumerate(rows) if "adam_kernel" in r[0]]
+if len(adam) < 3:
+    sys.exit("need >= 3 adam_kernel launches")
+a0, a1 = adam[which - 1], adam[which]
+step = rows[a0 + 1:a1 + 1]
+t0, t1 = rows[a0][2], rows[a1][2]
+wall = (t1 - t0) / 1e3
+print("step: %d kernels, wall %.1f us (adam end -> adam end)" % (len(step), wall))
+ev = []
+for n, s, e, st in step:
+    ev.append((max(s, t0), 1))
+    ev.append((min(e, t1), -1))
+ev.sort()
+conc = defaultdict(float)
+level, last = 0, t0
+for t, d in ev:
+    conc[min(level, 3)] += (t - last) / 1e3
+    level += d
+    last = t
+conc[min(level, 3)] += (t1 - last) / 1e3
+print("concurrency: " + "  ".join("%s: %.0f us (%.1f%%)" % (("3+" if k == 3 else k), v, 100 * v / wall) for k, v in sorted(conc.items())))
+# idle gaps
+gaps = []
+level, last = 0, t0
+for t, d in ev:
+    if level == 0 and t > last:
+        gaps.append((t - last) / 1e3)
+    level += d
+    last = t
+gaps.sort(reverse=True)
+print("idle gaps: n=%d total %.0f us; largest: %s" % (len(gaps), sum(gaps), ", ".join("%.1f" % g for g in gaps[:12])))
+print("gaps > 1us: %d (%.0f us);  gaps <= 1us: %d (%.0f us)" % (sum(g > 1 for g in gaps), sum(g for g in gaps if g > 1),
+                                                                 sum(g <= 1 for g in gaps), sum(g for g in gaps if g <= 1)))
+agg = defaultdict(lambda: [0, 0.0])
+for n, s, e, st in step:
+    n = n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+    agg[n][0] += 1
+    agg[n][1] += (e - s) / 1e3
+tot = sum(v[1] for v in agg.values())
+print("sum of kernel durations %.0f us" % tot)
+for n, (c, d) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:45]:
+    print("  %-70s %5d %9.0f us %6.1f avg  %5.1f%%" % (n[:70], c, d, d / c, 100 * d / tot))
+streams = defaultdict(float)
+for n, s, e, st in step:
+    streams[st] += (e - s) / 1e3
+print("per-stream busy: " + ", ".join("%s: %.0f us" % kv for kv in sorted(streams.items())))

@@ -197,6 +197,36 @@ def test_up2_phase_wgrad_unsupported_shapes():
     assert not ops.up2_phase_wgrad_supported(2, 24, 80, 16, 16)       # channels not multiples of 32
 
 
+def test_pack_weights_batched_matches_single_launches():
+    """one launch over a job table == the per-tensor packers, bit for bit (every layout, incl. channel slices)"""
+    ops, L = _ops()
+    ws = [rnd((64, 3, 7, 7), 330).cuda(), rnd((48, 40, 3, 3), 331).cuda(), rnd((32, 64, 1, 1), 332).cuda(), rnd((64, 128, 3, 3), 333).cuda()]
+    single, jobs = [], []
+
+    def add(kind, w, n, c_begin, c_count, fn):
+        a, b = torch.full((n,), float("nan"), device="cuda"), torch.full((n,), float("nan"), device="cuda")
+        fn(a)
+        single.append(a)
+        jobs.append((kind, w, b, c_begin, c_count))
+
+    add(L.PACK_STEM, ws[0], ops.packed_weight_elems(64, 3, 7, False, True), 0, 3, lambda o: ops.pack_conv_weight(ws[0], o, True))
+    for w in ws[1:]:
+        Cout, Cin, K, _ = w.shape
+        add(L.PACK_FWD, w, ops.packed_weight_elems(Cout, Cin, K), 0, Cin, lambda o, w=w: ops.pack_conv_weight(w, o))
+        add(L.PACK_DGRAD, w, ops.packed_weight_elems(Cout, Cin, K, True), 0, Cin, lambda o, w=w: ops.pack_conv_weight_dgrad(w, o))
+    w = ws[3]
+    add(L.PACK_UP2_FWD, w, ops.up2_packed_weight_elems(64, 64), 0, 64, lambda o: ops.pack_up2_weight(w, o, 0, 64))
+    add(L.PACK_UP2_DGRAD, w, ops.up2_packed_weight_elems(64, 64), 0, 64, lambda o: ops.pack_up2_weight_dgrad(w, o, 0, 64))
+    add(L.PACK_FWD, w, ops.packed_weight_elems(64, 64, 3), 64, 64, lambda o: ops.pack_conv_weight_slice(w, o, 64, 64))
+    add(L.PACK_DGRAD, w, ops.packed_weight_elems(64, 64, 3, True), 64, 64, lambda o: ops.pack_conv_weight_dgrad_slice(w, o, 64, 64))
+    w2 = ws[1]
+    add(L.PACK_UP2_FWD, w2, ops.up2_packed_weight_elems(48, 24), 8, 24, lambda o: ops.pack_up2_weight(w2, o, 8, 24))
+    table = ops.build_pack_table(jobs, "cuda")
+    ops.pack_weights_batched(table)
+    for a, (_, _, b, _, _) in zip(single, jobs):
+        assert not torch.isnan(a).any() and torch.equal(a, b)
+
+
 # ----------------------------------------------------------------------------------------------------------
 # halo-tile 3x3 kernel (conv3x3_tile.hip): shapes large enough (>= 384 workgroups) to be dispatched to it
 # ----------------------------------------------------------------------------------------------------------
