@@ -37,6 +37,37 @@ MFMA_F32_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dens
 B, H, W = 12, 192, 640
 
 
+def network_conv_gflop(n, h, w):
+    """algorithmic GFLOP of ONE training step's convolutions (reference graph: every conv counted as the dense
+    Conv2d the reference runs, 2*MACs, forward + data-gradient + weight-gradient; the stem has no data-gradient)."""
+    def conv(oh, ow, cin, cout, k):
+        return 2.0 * n * oh * ow * cout * cin * k * k
+    fwd = conv(h // 2, w // 2, 3, 64, 7)
+    tot = 2 * fwd                                            # stem: forward + weight gradient
+    res, cin = (h // 4, w // 4), 64
+    for cout, blocks, stride in ((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2)):
+        for b in range(blocks):
+            s = stride if b == 0 else 1
+            res = (res[0] // s, res[1] // s)
+            f = conv(res[0], res[1], cin, cout, 3) + conv(res[0], res[1], cout, cout, 3)
+            if s != 1 or cin != cout:
+                f += conv(res[0], res[1], cin, cout, 1)
+            fwd += f
+            tot += 3 * f
+            cin = cout
+    dec = 0.0
+    r = (h // 32, w // 32)
+    for ci, co in ((512, 256), (256, 128), (128, 64), (64, 64)):
+        dec += conv(r[0], r[1], ci, co, 3) + conv(r[0], r[1], co, co, 3)          # pre_concat_conv
+        r = (r[0] * 2, r[1] * 2)
+        dec += conv(r[0], r[1], 2 * co, co, 3) + conv(r[0], r[1], co, co, 3)      # post_concat_conv on cat[up, skip]
+    dec += conv(h, w, 64, 32, 3) + conv(h, w, 32, 32, 3)                          # outconv4 ConvBlock at full resolution
+    dec += sum(conv(h // s, w // s, c, 2, 3) for s, c in ((8, 128), (4, 64), (2, 64), (1, 32)))   # 2-channel heads
+    fwd += 2 * dec
+    tot += 3 * 2 * dec
+    return fwd / 1e9, tot / 1e9
+
+
 class KernelTimer:
     """HIP-event bracket around every launch of one kernel family (events go on torch's current stream, which
     is the stream the C ABI launches on)."""
@@ -224,6 +255,12 @@ def main():
                           "per_gpu_batch": B, "global_batch": B * world, "height": H, "width": W,
                           "parallelism": "dp%d" % world if world > 1 else "single"},
                "fwd_ms_per_img": round(fwd_ms_img, 4), "final_loss": round(final_loss, 5)}
+        gf_fwd, gf_step = network_conv_gflop(B, H, W)
+        # whole-step figure: the reference graph's conv FLOPs (fwd + dgrad + wgrad) over the measured step time, i.e. including
+        # every non-conv kernel, launch gap and the FLOPs the nearest-x2 phase decomposition does not execute
+        out["step_conv_tflops"] = {"algorithmic_gflop_per_step": round(gf_step, 1), "tflops": round(gf_step / ms_per_step, 2),
+                                   "frac_of_f32_mfma_peak": round(gf_step / ms_per_step / MFMA_F32_PEAK_TFLOPS, 4),
+                                   "fwd_algorithmic_gflop": round(gf_fwd, 1), "fwd_tflops": round(gf_fwd / (fwd_ms_img * B), 2)}
         if timer is not None:
             n, ms, fl = timer.summary()
             ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0

@@ -132,6 +132,7 @@ class Engine:
         self.concurrent = _CONCURRENT
         self.aux = torch.cuda.Stream(device=self.device)    # second decoder
         self.wg = torch.cuda.Stream(device=self.device)     # encoder weight gradients
+        self.dwg = [torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device)]   # decoder weight gradients
         self._ev_dF = [None] * 5
 
     # ------------------------------------------------------------------------------------------------
@@ -355,24 +356,29 @@ class Engine:
         main = torch.cuda.current_stream()
         if self.concurrent:
             self.aux.wait_event(self._record(main))                 # encoder features ready
-            with torch.cuda.stream(self.aux):
-                S["dec"][1] = self._decoder_forward(self.decoders[1], S, outputs)
-            S["dec"][0] = self._decoder_forward(self.decoders[0], S, outputs)
+            S["dec"] = [{}, {}]
+            self._interleave([(self.aux, self._decoder_forward(self.decoders[1], S, outputs, S["dec"][1])),
+                              (main, self._decoder_forward(self.decoders[0], S, outputs, S["dec"][0]))])
             main.wait_stream(self.aux)                              # join: both decoders wrote their output channels
         else:
+            S["dec"] = [{}, {}]
             for di, dec in enumerate(self.decoders):
-                S["dec"][di] = self._decoder_forward(dec, S, outputs)
+                for _ in self._decoder_forward(dec, S, outputs, S["dec"][di]):
+                    pass
         self.saved = S if save_for_backward else None
         return outputs
 
-    def _decoder_forward(self, dec, S, outputs):
+    def _decoder_forward(self, dec, S, outputs, D):
+        """generator (see _interleave): fills D with the activations the backward pass needs"""
         N, feats, dims = S["N"], S["feats"], S["dims"]
         buf = self.buf
-        D = {"y": [], "x": [], "low": []}
+        D.update({"y": [], "x": [], "low": []})
         x = feats[4]
         h, w = dims[4]
         chans = [(512, 256), (256, 128), (128, 64), (64, 64)]
         for bi, (blk, (cin, cout)) in enumerate(zip(dec.blocks, chans)):
+            if bi:
+                yield
             tag = "%s.b%d." % (dec.name, bi + 1)
             skip = feats[3 - bi]
             y1 = self._conv_dec(blk["pre1"], x, None, N, h, w, cin, 0, False, buf(tag + "y1", (N, h, w, cout)))
@@ -392,6 +398,7 @@ class Engine:
                 ops.head_upsample(low, outputs[bi - 1], scale, dec.c0)
                 D["low"].append(low)
         # outconv4: nearest x2 (virtual) -> ConvBlock(64->32) -> head, scale 1
+        yield
         h, w = 2 * h, 2 * w
         y51 = self._conv_dec(dec.o41, x, None, N, h, w, 64, 0, True, buf(dec.name + ".y51", (N, h, w, 32)))
         x5 = self._conv_dec(dec.o42, y51, None, N, h, w, 32, 0, False, buf(dec.name + ".x5", (N, h, w, 32)))
@@ -400,7 +407,6 @@ class Engine:
         ops.head_upsample(low, outputs[3], 1, dec.c0)
         D["low"].append(low)
         D["y51"], D["x5"] = y51, x5
-        return D
 
     # ------------------------------------------------------------------------------------------------
     # backward
@@ -420,18 +426,25 @@ class Engine:
         if c.gb is not None:
             ops.colsum(dz.view(-1, c.Cout), c.gb, accumulate=acc)
 
-    def _wgrad_up2(self, c, low, skip, dz, N, hl, wl, C0, C1, acc):
+    def _wgrad_up2(self, c, low, skip, dz, N, hl, wl, C0, C1, acc, side=None):
         """weight (+bias) gradient of a conv over cat[nearest_x2(low), skip]: upsampled half by output phase, skip half as a
         channel slice of the same gradient tensor; shapes the phase kernel does not take keep the fused-gather kernel."""
         H, W = 2 * hl, 2 * wl
         if c.up2 is None or not ops.up2_phase_wgrad_supported(N, hl, wl, C0, c.Cout):
-            return self._wgrad(c, L.GATHER_FWD_REFLECT_UP2, low, skip, dz, N, H, W, H, W, C0, C1, acc)
-        ops.conv_up2_phase_wgrad(low, dz, c.gw, 0, accumulate=acc)
-        if C1:
-            d = ops.make_desc(N, H, W, H, W, C1, 0, c.Cout, 3, 1, 1, L.GATHER_FWD_REFLECT)
-            ops.conv_wgrad_slice(d, skip, None, dz, c.gw, C0, accumulate=acc)
-        if c.gb is not None:
-            ops.colsum(dz.view(-1, c.Cout), c.gb, accumulate=acc)
+            return self._wgrad(c, L.GATHER_FWD_REFLECT_UP2, low, skip, dz, N, H, W, H, W, C0, C1, acc, side)
+
+        def launch():
+            ops.conv_up2_phase_wgrad(low, dz, c.gw, 0, accumulate=acc)
+            if C1:
+                d = ops.make_desc(N, H, W, H, W, C1, 0, c.Cout, 3, 1, 1, L.GATHER_FWD_REFLECT)
+                ops.conv_wgrad_slice(d, skip, None, dz, c.gw, C0, accumulate=acc)
+            if c.gb is not None:
+                ops.colsum(dz.view(-1, c.Cout), c.gb, accumulate=acc)
+        if side is None:
+            return launch()
+        side.wait_event(self._record(torch.cuda.current_stream()))
+        with torch.cuda.stream(side):
+            launch()
 
     def _dgrad_dec(self, c, dz, N, H, W, out, actsrc=None, addend=None, accum=False):
         epi = (L.EPI_ACTGRAD_ELU if actsrc is not None else 0) | (L.EPI_ACCUM if accum else 0)
@@ -465,16 +478,18 @@ class Engine:
             # feature gradients, so each of its accumulate launches waits for the mask decoder's write of that level
             self._ev_dF = [None] * 5
             self.aux.wait_event(self._record(main))
-            self._decoder_backward(self.decoders[0], S["dec"][0], S, gouts, dF, first=True, acc=accumulate)
-            with torch.cuda.stream(self.aux):
-                self._decoder_backward(self.decoders[1], S["dec"][1], S, gouts, dF, first=False, acc=accumulate)
+            self._interleave([(main, self._decoder_backward(self.decoders[0], S["dec"][0], S, gouts, dF, first=True, acc=accumulate)),
+                              (self.aux, self._decoder_backward(self.decoders[1], S["dec"][1], S, gouts, dF, first=False, acc=accumulate))])
             main.wait_stream(self.aux)
-            if on_stage is not None:
+            if on_stage is not None:                 # data-parallel: the decoder stages are reduced now => join their weight gradients
+                main.wait_stream(self.dwg[0])
+                main.wait_stream(self.dwg[1])
                 on_stage(self.decoders[0].name)
                 on_stage(self.decoders[1].name)
         else:
             for di, dec in enumerate(self.decoders):
-                self._decoder_backward(dec, S["dec"][di], S, gouts, dF, first=(di == 0), acc=accumulate)
+                for _ in self._decoder_backward(dec, S["dec"][di], S, gouts, dF, first=(di == 0), acc=accumulate):
+                    pass
                 if on_stage is not None:
                     on_stage(dec.name)
         side = self.wg if self.concurrent else None
@@ -543,16 +558,37 @@ class Engine:
         ops.conv_wgrad(d, S["image"], None, dz0, self.stem.gw, accumulate=accumulate)
         if side is not None:
             main.wait_stream(side)                # join: every weight gradient is complete
+            main.wait_stream(self.dwg[0])
+            main.wait_stream(self.dwg[1])
         if on_stage is not None:
             on_stage("encoder.layer0")
 
+    @staticmethod
+    def _interleave(jobs):
+        """Round-robin the sections of several (stream, generator) launch sequences.  The host runs ahead of the GPU until the
+        stream's queue back-pressures it, so a sequence issued only after another one has been issued completely does not start
+        until that one has almost drained: issue order has to alternate for the streams to overlap on the GPU."""
+        jobs = list(jobs)
+        while jobs:
+            for job in list(jobs):
+                stream, gen = job
+                with torch.cuda.stream(stream):
+                    try:
+                        next(gen)
+                    except StopIteration:
+                        jobs.remove(job)
+
     def _decoder_backward(self, dec, D, S, gouts, dF, first, acc):
+        """generator: yields between sections (see _interleave); must be resumed under the same stream context"""
         N, feats, dims = S["N"], S["feats"], S["dims"]
         buf = self.buf
         pfx = "g.%s." % dec.name                    # per-decoder temporaries: the two decoders may run concurrently
         H, W = S["H"], S["W"]
         accum_feat = not first                      # the second decoder accumulates into the feature gradients
         cur = torch.cuda.current_stream()
+        # weight gradients go to this decoder's side stream and are only joined at the end of Engine.backward (they overlap
+        # the rest of the decoder AND the encoder backward), so every dZ they read lives in its own buffer (never reused).
+        side = self.dwg[0 if first else 1] if self.concurrent else None
 
         def order_dF(k):
             """first decoder: publish its write of dF[k]; second: wait for it before accumulating (fixed order)."""
@@ -569,11 +605,12 @@ class Engine:
         ops.head_upsample_bwd(gouts[3], D["low"][3], dzl, 1, dec.c0, dec.sig)
         hd = dec.heads[3]
         ops.head_wgrad(D["x5"], dzl, hd.gw, hd.gb, accumulate=acc)
-        A = buf(pfx + "A", (N, H, W, 32))
+        A = buf(pfx + "dz.o42", (N, H, W, 32))
         ops.head_dgrad(dzl, hd.w.data, A, elu_src=D["x5"])
-        self._wgrad(dec.o42, L.GATHER_FWD_REFLECT, D["y51"], None, A, N, H, W, H, W, 32, 0, acc)
-        Bz = self._dgrad_dec(dec.o42, A, N, H, W, buf(pfx + "B", (N, H, W, 32)), actsrc=D["y51"])
-        self._wgrad_up2(dec.o41, x4, None, Bz, N, h0, w0, 64, 0, acc)
+        self._wgrad(dec.o42, L.GATHER_FWD_REFLECT, D["y51"], None, A, N, H, W, H, W, 32, 0, acc, side)
+        Bz = self._dgrad_dec(dec.o42, A, N, H, W, buf(pfx + "dz.o41", (N, H, W, 32)), actsrc=D["y51"])
+        yield
+        self._wgrad_up2(dec.o41, x4, None, Bz, N, h0, w0, 64, 0, acc, side)
         phase41 = dec.o41.up2 is not None
         if phase41:
             XV = self._dgrad_up2_ext(dec.o41, Bz, N, h0, w0, 64, pfx)
@@ -586,7 +623,7 @@ class Engine:
         ops.head_wgrad(x4, dzl, hd.gw, hd.gb, accumulate=acc)
         XH = buf(pfx + "XH", (N, h0, w0, 64))
         ops.head_dgrad(dzl, hd.w.data, XH)
-        A = buf(pfx + "A", (N, h0, w0, 64))
+        A = buf(pfx + "dz.post2.3", (N, h0, w0, 64))
         if phase41:
             ops.up2_fold_bwd(XV, A, addend=XH, ylow=x4)
         else:
@@ -594,6 +631,7 @@ class Engine:
         # ---- blocks 4..1 ----------------------------------------------------------------------------------
         chans = [(512, 256), (256, 128), (128, 64), (64, 64)]
         for bi in (3, 2, 1, 0):
+            yield
             blk = dec.blocks[bi]
             cin, cout = chans[bi]
             y1, y2, y3 = D["y"][bi]
@@ -602,10 +640,10 @@ class Engine:
             skip = feats[3 - bi]
             xin = D["x"][bi - 1] if bi > 0 else feats[4]
             # A = dZ of post2 at (hh, ww)
-            self._wgrad(blk["post2"], L.GATHER_FWD_REFLECT, y3, None, A, N, hh, ww, hh, ww, cout, 0, acc)
-            Bz = self._dgrad_dec(blk["post2"], A, N, hh, ww, buf(pfx + "B", (N, hh, ww, cout)), actsrc=y3)
-            self._wgrad_up2(blk["post1"], y2, skip, Bz, N, hl, wl, cout, cout, acc)
-            A = buf(pfx + "A", (N, hl, wl, cout))
+            self._wgrad(blk["post2"], L.GATHER_FWD_REFLECT, y3, None, A, N, hh, ww, hh, ww, cout, 0, acc, side)
+            Bz = self._dgrad_dec(blk["post2"], A, N, hh, ww, buf(pfx + "dz.post1.%d" % bi, (N, hh, ww, cout)), actsrc=y3)
+            self._wgrad_up2(blk["post1"], y2, skip, Bz, N, hl, wl, cout, cout, acc, side)
+            A = buf(pfx + "dz.pre2.%d" % bi, (N, hl, wl, cout))
             if blk["post1"].up2 is not None:
                 # d(low) = 4x4 stride-2 conv over dZ + border fold (* ELU'); d(skip) straight into the feature gradient
                 ops.up2_fold_bwd(self._dgrad_up2_ext(blk["post1"], Bz, N, hl, wl, cout, pfx), A, ylow=y2)
@@ -621,9 +659,10 @@ class Engine:
                 ops.up2cat_bwd(XV, N, hl, wl, cout, cout, A, ylow=y2, dskip=dF[3 - bi], accumulate_skip=accum_feat)
             if first:
                 order_dF(3 - bi)
-            self._wgrad(blk["pre2"], L.GATHER_FWD_REFLECT, y1, None, A, N, hl, wl, hl, wl, cout, 0, acc)
-            Bz = self._dgrad_dec(blk["pre2"], A, N, hl, wl, buf(pfx + "B", (N, hl, wl, cout)), actsrc=y1)
-            self._wgrad(blk["pre1"], L.GATHER_FWD_REFLECT, xin, None, Bz, N, hl, wl, hl, wl, cin, 0, acc)
+            yield
+            self._wgrad(blk["pre2"], L.GATHER_FWD_REFLECT, y1, None, A, N, hl, wl, hl, wl, cout, 0, acc, side)
+            Bz = self._dgrad_dec(blk["pre2"], A, N, hl, wl, buf(pfx + "dz.pre1.%d" % bi, (N, hl, wl, cout)), actsrc=y1)
+            self._wgrad(blk["pre1"], L.GATHER_FWD_REFLECT, xin, None, Bz, N, hl, wl, hl, wl, cin, 0, acc, side)
             if bi == 0:
                 if not first:
                     order_dF(4)
@@ -640,7 +679,7 @@ class Engine:
                     ops.head_wgrad(xin, dzl, hd.gw, hd.gb, accumulate=acc)
                     XH = buf(pfx + "XH", (N, hl, wl, cin))
                     ops.head_dgrad(dzl, hd.w.data, XH)
-                A = self._dgrad_dec(blk["pre1"], Bz, N, hl, wl, buf(pfx + "A2", (N, hl, wl, cin)), actsrc=xin, addend=XH)
+                A = self._dgrad_dec(blk["pre1"], Bz, N, hl, wl, buf(pfx + "dz.post2.%d" % (bi - 1), (N, hl, wl, cin)), actsrc=xin, addend=XH)
 
     # ------------------------------------------------------------------------------------------------
     def bind_grads(self, accumulate_existing=True):

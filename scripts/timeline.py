@@ -57,3 +57,27 @@ streams = defaultdict(float)
 for n, s, e, st in step:
     streams[st] += (e - s) / 1e3
 print("per-stream busy: " + ", ".join("%s: %.0f us" % kv for kv in sorted(streams.items())))
+
+if len(sys.argv) > 3 and sys.argv[3] == "buckets":
+    nb = int(wall // 1000) + 1
+    print("\nper-ms buckets: [busy1 busy2+] top kernels")
+    for b in range(nb):
+        lo, hi = t0 + b * 1e6, t0 + (b + 1) * 1e6
+        names = defaultdict(float)
+        evs = []
+        for n, s, e, st in step:
+            ss, ee = max(s, lo), min(e, hi)
+            if ee > ss:
+                names[n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:34] + "@%d" % st] += (ee - ss) / 1e3
+                evs += [(ss, 1), (ee, -1)]
+        evs.sort()
+        lvl, last, c1, c2 = 0, lo, 0.0, 0.0
+        for t, d in evs:
+            if lvl == 1:
+                c1 += t - last
+            elif lvl >= 2:
+                c2 += t - last
+            lvl += d
+            last = t
+        top = sorted(names.items(), key=lambda kv: -kv[1])[:3]
+        print("%3d ms: [%3.0f%% %3.0f%%] %s" % (b, c1 / 1e4, c2 / 1e4, "  ".join("%s %.0f" % kv for kv in top)))

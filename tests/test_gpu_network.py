@@ -63,7 +63,9 @@ def test_g2_decoder_golden_through_engine():
         feats = [nhwc(f) for f in feats_nchw]
         S = {"N": 2, "H": 64, "W": 96, "feats": feats, "dims": [tuple(f.shape[1:3]) for f in feats], "training": True}
         outs = [torch.zeros((2, 4, 64, 96), device="cuda") for _ in range(4)]
-        D = eng._decoder_forward(dec, S, outs)
+        D = {}
+        for _ in eng._decoder_forward(dec, S, outs, D):       # generators: sections are interleaved across streams in Engine.forward
+            pass
         c0 = dec.c0
         for k, o in zip(("1/8", "1/4", "1/2", "1/1"), outs):
             compare(gold, tag + ".out" + k, o[:, c0:c0 + 2])
@@ -73,7 +75,8 @@ def test_g2_decoder_golden_through_engine():
             g[:, c0:c0 + 2] = fill("g2.g" + k, (2, 2, 64, 96)).cuda()
             gouts.append(g)
         dF = [torch.empty_like(f) for f in feats]
-        eng._decoder_backward(dec, D, S, gouts, dF, first=True, acc=False)
+        for _ in eng._decoder_backward(dec, D, S, gouts, dF, first=True, acc=False):
+            pass
         for i in range(5):
             compare(gold, tag + ".dfeat%d" % i, nchw(dF[i]), rtol=2e-4)
         gv = dict(zip(eng.live_names, eng.grad_views))
