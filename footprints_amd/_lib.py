@@ -21,7 +21,7 @@ class ConvDesc(C.Structure):
                                          "gather", "act")] + [("epi", C.c_uint32)]
 
 
-PACK_FWD, PACK_DGRAD, PACK_STEM, PACK_UP2_FWD, PACK_UP2_DGRAD = range(5)
+PACK_FWD, PACK_DGRAD, PACK_STEM, PACK_UP2_FWD, PACK_UP2_DGRAD, PACK_FWD_BF3, PACK_DGRAD_BF3 = range(7)
 
 
 class PackJob(C.Structure):
@@ -54,6 +54,10 @@ SIGNATURES = {
     "fp_conv_up2_phase_wgrad": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, C.c_int, _P, _I64, _P]),
     "fp_pack_job_blocks": (_I32, [_I32, _I32, _I32, _I32, _I32]),
     "fp_pack_weights_batched": (C.c_int, [_P, _P, _I32, _P]),
+    "fp_conv3x3_bf3_supported": (C.c_int, [_DESC]),
+    "fp_conv3x3_bf3": (C.c_int, [_DESC, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "fp_packed_weight_elems_bf3": (_I64, [_I32, _I32, _I32, _I32, _I32]),
+    "fp_pack_conv_weight_bf3": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _P]),
     "fp_colsum_workspace": (_I64, [_I64, _I32]),
     "fp_colsum": (C.c_int, [_P, _I64, _I32, _P, C.c_int, _P, _I64, _P]),
     "fp_up2cat_bwd": (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, C.c_int, _P]),
@@ -102,11 +106,12 @@ def load():
     return lib
 
 
+_SYNC_ONLY = os.environ.get("FP_SYNC_ONLY", "")      # debugging aid: synchronise only after calls whose name contains this
 _SYNC = bool(int(os.environ.get("FP_SYNC", "0")))     # debugging aid: device-synchronise after every C-ABI call
 
 
 def check(rc, what=""):
-    if _SYNC:
+    if _SYNC or (_SYNC_ONLY and _SYNC_ONLY in what):
         import torch
         torch.cuda.synchronize()
     if rc != 0:

@@ -1,0 +1,308 @@
+// Halo-tile 3x3 convolution (forward / data-gradient) with fp32 operands split EXACTLY into three bf16 terms (gfx950).
+//
+//   x = h + m + l   (h = bf16(x), m = bf16(x - h), l = bf16(x - h - m): 8 + 8 + 8 significant bits, the sum is exact)
+//   a*b ~= ah*bh + (ah*bm + am*bh) + (ah*bl + am*bm + al*bh)      -- the dropped terms (am*bl, al*bm, al*bl) are <= 2^-24 |a*b|
+//
+// Every bf16 x bf16 product is exact in the MFMA's fp32 accumulator, so the result carries LESS error than the fp32 MFMA of
+// conv3x3_tile.hip (measured 2.0e-7 vs 5.0e-7 of max|y| on K = 144..4608 dot products) while six v_mfma_f32_32x32x16_bf16
+// (32 cycles, K = 16) replace eight v_mfma_f32_32x32x2_f32 (64 cycles, K = 2): 192 instead of 512 MFMA cycles per 32x32x16 block.
+// Same tiling and pipeline as conv3x3_tile.hip (8 x 16 output pixels x 64 / 32 channels per workgroup, halo staged once per
+// 16-channel chunk, nine taps from LDS, weight slices from L1/L2 two taps ahead, unconditional straight-line loads => exact
+// vmcnt waits, one barrier per chunk); differences:
+//   * the halo is converted on its way into LDS: three bf16 planes [plane][pixel][16 ch + 8 pad] (48-byte pixel rows: the
+//     per-lane 16-byte A fragment "pixel = lane & 31, k-group = lane >> 5" is a conflict-free ds_read_b128);
+//   * weights are packed [tap][chunk][plane][n][16] bf16 (pack.hip, FP_PACK_*_BF3): a wave's B fragment of one plane is 1 KB contiguous.
+#include "fp_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct Tile3Args {
+  const float* src;
+  const unsigned short* w;   // bf16 [tap][KC16][3][ncols][16]
+  const float* bias;
+  const float* addend;
+  const float* addend_mask;
+  const float* actsrc;
+  float* y;
+  int N, OH, OW, IH, IW, C, Nout, KC16;
+  int mode;      // 0 zero padding, 1 reflection padding
+  int act;
+  unsigned epi;
+  int tilesX, tilesY, tilesN, nwg;
+};
+
+struct FoldTap { int wtap, ao, bo, rsel, csel; };
+__constant__ FoldTap kFoldTaps3[16] = {   // see conv3x3_tile.hip
+    {0, 0, 2, 1, 0}, {0, 2, 0, 0, 1}, {0, 0, 0, 1, 1}, {1, 0, 1, 1, 0}, {2, 0, 0, 1, 0}, {2, 2, 2, 0, 2}, {2, 0, 2, 1, 2}, {3, 1, 0, 0, 1},
+    {5, 1, 2, 0, 2}, {6, 2, 2, 2, 0}, {6, 0, 0, 0, 1}, {6, 2, 0, 2, 1}, {7, 2, 1, 2, 0}, {8, 2, 0, 2, 0}, {8, 0, 2, 0, 2}, {8, 2, 2, 2, 2},
+};
+
+__device__ __forceinline__ float tile3_epilogue(const Tile3Args& a, size_t o, int n, float v) {
+  if (a.epi & FP_EPI_BIAS) v += a.bias[n];
+  if (a.epi & FP_EPI_ADDEND) {
+    float ad = a.addend[o];
+    if (a.epi & FP_EPI_ADDEND_MASK) ad = a.addend_mask[o] > 0.f ? ad : 0.f;
+    v += ad;
+  }
+  if (a.epi & FP_EPI_ACTGRAD_ELU) {
+    const float sv = a.actsrc[o];
+    v *= (sv > 0.f ? 1.f : sv + 1.f);
+  }
+  if (a.epi & FP_EPI_ACTGRAD_RELU) v = a.actsrc[o] > 0.f ? v : 0.f;
+  if (a.act == FP_ACT_ELU) v = v > 0.f ? v : expm1f(v);
+  if (a.act == FP_ACT_RELU) v = fmaxf(v, 0.f);
+  if (a.epi & FP_EPI_ACCUM) v += a.y[o];
+  return v;
+}
+
+constexpr int PIXB = 48;   // bytes per halo pixel per plane (16 bf16 + 8 pad)
+
+template <int TH, int TW, int BN, int WM, int WN, bool FLIP, bool FOLD>
+__global__ void __launch_bounds__(256) conv3x3_tile_bf3_kernel(const Tile3Args a) {
+  constexpr int BM = TH * TW;
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int HW2 = TW + 2, HP = (TH + 2) * HW2;
+  constexpr int NS = (HP * 4 + 255) / 256;
+  constexpr int PLANE = HP * PIXB;                   // bytes per plane
+  constexpr int BUF = 3 * PLANE;                     // bytes per halo buffer
+  static_assert(WM * WN == 4 && TW == 16, "tile shape");
+  __shared__ __attribute__((aligned(16))) unsigned char lds[(2 * BUF + 1023) / 1024 * 1024];   // whole LDS allocation granules
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, idx = lane & 31, h = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+  int wg = fp_xcd_remap(blockIdx.x, a.nwg);
+  const int tile_n = wg % a.tilesN; wg /= a.tilesN;
+  const int tile_x = wg % a.tilesX; wg /= a.tilesX;
+  const int tile_y = wg % a.tilesY;
+  const int n_img = wg / a.tilesY;
+  const int y0 = tile_y * TH, x0 = tile_x * TW, n0 = tile_n * BN;
+
+  // ---- halo staging slots (unconditional loads; invalid slots read the nearest in-image pixel and are stored as zero) ----------
+  int pix[NS], lds_off[NS];
+  bool hvalid[NS];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    const int lin = t + 256 * k, hp = min(lin >> 2, HP - 1);
+    lds_off[k] = (lin >> 2) < HP ? hp * PIXB + (lin & 3) * 8 : -1;
+    const int hy = hp / HW2, hx = hp - hy * HW2;
+    int sy = y0 + hy - 1, sx = x0 + hx - 1;
+    if (a.mode == 0) {
+      hvalid[k] = sy >= 0 && sy < a.IH && sx >= 0 && sx < a.IW;
+    } else {
+      hvalid[k] = sy >= -1 && sy <= a.IH && sx >= -1 && sx <= a.IW;
+      sy = fp_reflect(sy, a.IH);
+      sx = fp_reflect(sx, a.IW);
+    }
+    sy = min(max(sy, 0), a.IH - 1);
+    sx = min(max(sx, 0), a.IW - 1);
+    pix[k] = (n_img * a.IH + sy) * a.IW + sx;
+  }
+  float4 hreg[NS];
+  bool hzero = false;
+  auto load_halo = [&](int cc) {
+    const int c4 = cc * 16 + (t & 3) * 4;
+    hzero = c4 >= a.C;
+    const int coff = hzero ? 0 : c4;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) hreg[k] = *reinterpret_cast<const float4*>(a.src + (size_t)pix[k] * a.C + coff);
+  };
+  // fp32 -> three bf16 planes, 4 channels (8 bytes) per plane per slot
+  auto store_halo = [&](int buf) {
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      if (lds_off[k] < 0) continue;
+      f32x4 v = {hreg[k].x, hreg[k].y, hreg[k].z, hreg[k].w};
+      if (!hvalid[k] || hzero) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      const bf16x4 vh = __builtin_convertvector(v, bf16x4);
+      const f32x4 r1 = v - __builtin_convertvector(vh, f32x4);
+      const bf16x4 vm = __builtin_convertvector(r1, bf16x4);
+      const f32x4 r2 = r1 - __builtin_convertvector(vm, f32x4);
+      const bf16x4 vl = __builtin_convertvector(r2, bf16x4);
+      unsigned char* p = lds + buf * BUF + lds_off[k];
+      *reinterpret_cast<uint2*>(p) = __builtin_bit_cast(uint2, vh);
+      *reinterpret_cast<uint2*>(p + PLANE) = __builtin_bit_cast(uint2, vm);
+      *reinterpret_cast<uint2*>(p + 2 * PLANE) = __builtin_bit_cast(uint2, vl);
+    }
+  };
+
+  // ---- weight slices: [tap][chunk][plane][n][16] bf16; lane (n = idx, k-group = h) reads 16 bytes per plane -----------------
+  uint4 bq[3][TN][3];
+  auto load_b = [&](int tap, int cc, uint4 (&bf)[TN][3]) {
+    const unsigned short* ws = a.w + (size_t)(tap * a.KC16 + cc) * 3 * a.Nout * 16 + h * 8;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = min(n0 + (wn * TN + j) * 32 + idx, a.Nout - 1);
+#pragma unroll
+      for (int p = 0; p < 3; ++p) bf[j][p] = *reinterpret_cast<const uint4*>(ws + ((size_t)p * a.Nout + n) * 16);
+    }
+  };
+
+  int abase[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int pt = (wm * TM + i) * 32 + idx;
+    abase[i] = ((pt / TW) * HW2 + (pt % TW)) * PIXB + h * 16;
+  }
+
+  const bool has_r1 = y0 <= 1 && 1 < y0 + TH, has_rH = y0 <= a.OH - 2 && a.OH - 2 < y0 + TH;
+  const bool has_c1 = x0 <= 1 && 1 < x0 + TW, has_cW = x0 <= a.OW - 2 && a.OW - 2 < x0 + TW;
+  const bool border_tile = has_r1 || has_rH || has_c1 || has_cW;
+  unsigned m_r1[TM], m_rH[TM], m_c1[TM], m_cW[TM];       // all-ones / zero lane masks
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int pt = (wm * TM + i) * 32 + idx;
+    const int yy = y0 + pt / TW, xx = x0 + pt % TW;
+    m_r1[i] = yy == 1 ? ~0u : 0u;
+    m_rH[i] = yy == a.OH - 2 ? ~0u : 0u;
+    m_c1[i] = xx == 1 ? ~0u : 0u;
+    m_cW[i] = xx == a.OW - 2 ? ~0u : 0u;
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // six products, smallest first; consecutive MFMAs alternate accumulators (i, j)
+  auto mma6 = [&](const uint4 (&af)[TM][3], const uint4 (&bf)[TN][3]) {
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[i][PA[q]]), __builtin_bit_cast(bf16x8, bf[j][PB[q]]),
+                                                              acc[i][j], 0, 0, 0);
+  };
+
+  load_halo(0);
+  store_halo(0);
+  load_b(0, 0, bq[0]);
+  load_b(1, 0, bq[1]);
+  load_halo(min(1, a.KC16 - 1));
+  __syncthreads();
+
+  for (int cc = 0; cc < a.KC16; ++cc) {
+    const unsigned char* Hb = lds + (cc & 1) * BUF;
+    const int ccn = min(cc + 1, a.KC16 - 1);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ky = tap / 3, kx = tap % 3;
+      const int toff = ((FLIP ? 2 - ky : ky) * HW2 + (FLIP ? 2 - kx : kx)) * PIXB;
+      uint4 af[TM][3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i][p] = *reinterpret_cast<const uint4*>(Hb + p * PLANE + abase[i] + toff);
+      __builtin_amdgcn_sched_barrier(0);
+      if (tap < 7) load_b(tap + 2, cc, bq[(tap + 2) % 3]);
+      else load_b(tap - 7, ccn, bq[(tap + 2) % 3]);
+      __builtin_amdgcn_sched_barrier(0);
+      mma6(af, bq[tap % 3]);
+    }
+    if (FOLD && border_tile) {
+#pragma unroll 1
+      for (int e = 0; e < 16; ++e) {
+        const FoldTap ft = kFoldTaps3[e];
+        const bool need_r = ft.rsel == 0 || (ft.rsel == 1 ? has_r1 : has_rH);
+        const bool need_c = ft.csel == 0 || (ft.csel == 1 ? has_c1 : has_cW);
+        if (!(need_r && need_c)) continue;                             // uniform per workgroup
+        const int toff = (ft.ao * HW2 + ft.bo) * PIXB;
+        uint4 bx[TN][3], ax[TM][3];
+        load_b(ft.wtap, cc, bx);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const unsigned mr = ft.rsel == 0 ? ~0u : (ft.rsel == 1 ? m_r1[i] : m_rH[i]);
+          const unsigned mc = ft.csel == 0 ? ~0u : (ft.csel == 1 ? m_c1[i] : m_cW[i]);
+          const unsigned mk = mr & mc;
+#pragma unroll
+          for (int p = 0; p < 3; ++p) {
+            uint4 v = *reinterpret_cast<const uint4*>(Hb + p * PLANE + abase[i] + toff);
+            v.x &= mk; v.y &= mk; v.z &= mk; v.w &= mk;
+            ax[i][p] = v;
+          }
+        }
+        mma6(ax, bx);
+      }
+    }
+    if (cc + 1 < a.KC16) {
+      store_halo((cc + 1) & 1);
+      load_halo(min(cc + 2, a.KC16 - 1));
+      __syncthreads();
+    }
+  }
+
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + (wn * TN + j) * 32 + idx;
+      if (n >= a.Nout) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int pt = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int oy = y0 + pt / TW, ox = x0 + pt % TW;
+        if (oy >= a.OH || ox >= a.OW) continue;
+        const size_t o = ((size_t)(n_img * a.OH + oy) * a.OW + ox) * a.Nout + n;
+        a.y[o] = tile3_epilogue(a, o, n, acc[i][j][r]);
+      }
+    }
+}
+
+template <int TH, int TW, int BN, int WM, int WN, bool FLIP, bool FOLD>
+int launch3(Tile3Args& a, hipStream_t stream) {
+  a.tilesX = (int)fp_ceil_div(a.OW, TW);
+  a.tilesY = (int)fp_ceil_div(a.OH, TH);
+  a.tilesN = (int)fp_ceil_div(a.Nout, BN);
+  a.nwg = a.N * a.tilesY * a.tilesX * a.tilesN;
+  hipLaunchKernelGGL((conv3x3_tile_bf3_kernel<TH, TW, BN, WM, WN, FLIP, FOLD>), dim3(a.nwg), dim3(256), 0, stream, a);
+  return fp_check_launch("fp_conv3x3_bf3");
+}
+
+bool eligible3(const fp_conv_desc* d) {
+  if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->C1 != 0 || d->C0 % 4) return false;
+  if (d->gather != FP_GATHER_FWD_ZERO && d->gather != FP_GATHER_FWD_REFLECT && d->gather != FP_GATHER_DGRAD_ZERO &&
+      d->gather != FP_GATHER_DGRAD_REFLECT)
+    return false;
+  if (d->OH != d->IH || d->OW != d->IW || d->IH < 2 || d->IW < 2) return false;
+  const int64_t ty = fp_ceil_div(d->OH, 8), tx = fp_ceil_div(d->OW, 16);
+  if (ty * 8 * tx * 16 * 4 > (int64_t)d->OH * d->OW * 5) return false;          // > 25 % padded work
+  return (int64_t)d->N * ty * tx * fp_ceil_div(d->Nout, d->Nout <= 32 ? 32 : 64) >= 256;
+}
+
+}  // namespace
+
+extern "C" int fp_conv3x3_bf3_supported(const fp_conv_desc* d) { return d && eligible3(d) ? 1 : 0; }
+
+extern "C" int fp_conv3x3_bf3(const fp_conv_desc* d, const float* src, const void* wpacked_bf3, const float* bias, const float* addend,
+                              const float* addend_mask, const float* actsrc, float* y, fp_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  FP_REQUIRE(d && src && wpacked_bf3 && y, "fp_conv3x3_bf3: null pointer");
+  FP_REQUIRE(eligible3(d), "fp_conv3x3_bf3: shape not supported (see fp_conv3x3_bf3_supported)");
+  FP_REQUIRE(!(d->epi & FP_EPI_BIAS) || bias, "fp_conv3x3_bf3: bias missing");
+  FP_REQUIRE(!(d->epi & FP_EPI_ADDEND) || addend, "fp_conv3x3_bf3: addend missing");
+  FP_REQUIRE(!(d->epi & FP_EPI_ADDEND_MASK) || addend_mask, "fp_conv3x3_bf3: addend_mask missing");
+  FP_REQUIRE(!(d->epi & (FP_EPI_ACTGRAD_ELU | FP_EPI_ACTGRAD_RELU)) || actsrc, "fp_conv3x3_bf3: actsrc missing");
+  Tile3Args a;
+  a.src = src; a.w = (const unsigned short*)wpacked_bf3; a.bias = bias; a.addend = addend; a.addend_mask = addend_mask; a.actsrc = actsrc;
+  a.y = y;
+  a.N = d->N; a.OH = d->OH; a.OW = d->OW; a.IH = d->IH; a.IW = d->IW; a.C = d->C0; a.Nout = d->Nout; a.KC16 = (d->C0 + 15) / 16;
+  const bool flip = d->gather == FP_GATHER_DGRAD_ZERO || d->gather == FP_GATHER_DGRAD_REFLECT;
+  const bool fold = d->gather == FP_GATHER_DGRAD_REFLECT;
+  a.mode = d->gather == FP_GATHER_FWD_REFLECT ? 1 : 0;
+  a.act = d->act; a.epi = d->epi;
+  if (d->Nout <= 32) {
+    if (fold) return launch3<8, 16, 32, 4, 1, true, true>(a, stream);
+    return flip ? launch3<8, 16, 32, 4, 1, true, false>(a, stream) : launch3<8, 16, 32, 4, 1, false, false>(a, stream);
+  }
+  if (fold) return launch3<8, 16, 64, 2, 2, true, true>(a, stream);
+  return flip ? launch3<8, 16, 64, 2, 2, true, false>(a, stream) : launch3<8, 16, 64, 2, 2, false, false>(a, stream);
+}

@@ -16,6 +16,7 @@ __device__ __forceinline__ float pack_elem(const fp_pack_job& j, size_t e) {
   const int kr = (int)(e & 15);
   size_t r = e >> 4;
   switch (j.kind) {
+    case FP_PACK_FWD_BF3:
     case FP_PACK_FWD: {
       const int T = j.KH * j.KW, KC16 = (j.c_count + 15) / 16;
       const int n = (int)(r % j.Cout); r /= j.Cout;
@@ -23,6 +24,7 @@ __device__ __forceinline__ float pack_elem(const fp_pack_job& j, size_t e) {
       const int k = kc * 16 + kr;
       return k < j.c_count ? w[((size_t)n * j.Cin + j.c_begin + k) * T + tap] : 0.f;
     }
+    case FP_PACK_DGRAD_BF3:
     case FP_PACK_DGRAD: {
       const int T = j.KH * j.KW, KC16 = (j.Cout + 15) / 16;
       const int ci = (int)(r % j.c_count); r /= j.c_count;
@@ -77,7 +79,9 @@ __device__ __forceinline__ float pack_elem(const fp_pack_job& j, size_t e) {
 __host__ __device__ inline int64_t pack_elems(int kind, int Cout, int KH, int KW, int c_count) {
   const int64_t T = (int64_t)KH * KW;
   switch (kind) {
+    case FP_PACK_FWD_BF3:
     case FP_PACK_FWD: return T * ((c_count + 15) / 16) * Cout * 16;
+    case FP_PACK_DGRAD_BF3:
     case FP_PACK_DGRAD: return T * ((Cout + 15) / 16) * c_count * 16;
     case FP_PACK_STEM: return 10 * 64 * 16;
     case FP_PACK_UP2_FWD: return (int64_t)16 * ((c_count + 15) / 16) * Cout * 16;
@@ -86,8 +90,32 @@ __host__ __device__ inline int64_t pack_elems(int kind, int Cout, int KH, int KW
   }
 }
 
+// fp32 layouts: wp[e] = v.  *_BF3 layouts: v is split exactly into three bf16 terms (h = bf16(v), m = bf16(v - h), l = v - h - m)
+// stored as planes [tap][chunk][plane][ncols][16] (conv3x3_tile_bf3.hip); element e = ((tap*KC16 + kc)*ncols + n)*16 + k.
+__device__ __forceinline__ unsigned short bf16_rne(float x) {
+  unsigned u = __float_as_uint(x);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ void pack_store(const fp_pack_job& j, size_t e, float v) {
+  if (j.kind != FP_PACK_FWD_BF3 && j.kind != FP_PACK_DGRAD_BF3) {
+    j.wp[e] = v;
+    return;
+  }
+  const size_t ncols = j.kind == FP_PACK_FWD_BF3 ? j.Cout : j.c_count;
+  const size_t k = e & 15, n = (e >> 4) % ncols, blk = (e >> 4) / ncols;
+  unsigned short* o = reinterpret_cast<unsigned short*>(j.wp) + (blk * 3 * ncols + n) * 16 + k;
+  const unsigned short h = bf16_rne(v);
+  const float r1 = v - __uint_as_float((unsigned)h << 16);
+  const unsigned short m = bf16_rne(r1);
+  const float r2 = r1 - __uint_as_float((unsigned)m << 16);
+  o[0] = h;
+  o[ncols * 16] = m;
+  o[2 * ncols * 16] = bf16_rne(r2);
+}
+
 __global__ void __launch_bounds__(256) pack_one_kernel(const fp_pack_job j, size_t total) {
-  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) j.wp[e] = pack_elem(j, e);
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) pack_store(j, e, pack_elem(j, e));
 }
 
 // block b serves job blk2job[b]; a job's blocks are contiguous starting at jobs[job].block_begin
@@ -96,7 +124,7 @@ __global__ void __launch_bounds__(256) pack_batched_kernel(const fp_pack_job* __
   const fp_pack_job j = jobs[ji];
   const size_t total = (size_t)pack_elems(j.kind, j.Cout, j.KH, j.KW, j.c_count);
   const size_t stride = (size_t)j.block_count * 256;
-  for (size_t e = (size_t)(blockIdx.x - j.block_begin) * 256 + threadIdx.x; e < total; e += stride) j.wp[e] = pack_elem(j, e);
+  for (size_t e = (size_t)(blockIdx.x - j.block_begin) * 256 + threadIdx.x; e < total; e += stride) pack_store(j, e, pack_elem(j, e));
 }
 
 int launch_one(int kind, const float* w, float* wp, int Cout, int Cin, int KH, int KW, int c_begin, int c_count, hipStream_t stream,
@@ -117,6 +145,16 @@ int launch_one(int kind, const float* w, float* wp, int Cout, int Cin, int KH, i
 extern "C" int64_t fp_packed_weight_elems(int32_t Cout, int32_t Cin, int32_t KH, int32_t KW, int32_t for_dgrad, int32_t stem) {
   if (stem) return pack_elems(FP_PACK_STEM, 64, 7, 7, 3);
   return pack_elems(for_dgrad ? FP_PACK_DGRAD : FP_PACK_FWD, Cout, KH, KW, Cin);
+}
+// storage of the bf16x3 layouts, in floats (3 bf16 per weight = 1.5 floats)
+extern "C" int64_t fp_packed_weight_elems_bf3(int32_t Cout, int32_t Cin, int32_t KH, int32_t KW, int32_t for_dgrad) {
+  return pack_elems(for_dgrad ? FP_PACK_DGRAD_BF3 : FP_PACK_FWD_BF3, Cout, KH, KW, Cin) * 3 / 2;
+}
+extern "C" int fp_pack_conv_weight_bf3(const float* w_oihw, void* wp, int32_t Cout, int32_t Cin, int32_t KH, int32_t KW, int32_t for_dgrad,
+                                       fp_stream_t stream) {
+  FP_REQUIRE(w_oihw && wp, "fp_pack_conv_weight_bf3: null pointer");
+  return launch_one(for_dgrad ? FP_PACK_DGRAD_BF3 : FP_PACK_FWD_BF3, w_oihw, (float*)wp, Cout, Cin, KH, KW, 0, Cin, (hipStream_t)stream,
+                    "fp_pack_conv_weight_bf3");
 }
 extern "C" int64_t fp_up2_packed_weight_elems(int32_t Ncols, int32_t K) { return pack_elems(FP_PACK_UP2_FWD, Ncols, 3, 3, K); }
 

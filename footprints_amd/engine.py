@@ -24,6 +24,8 @@ from . import ops
 # Running them on side streams lets workgroups of 2-3 kernels share the CUs, which fills the occupancy ramp /
 # tail of each launch (a conv launch is only ~2-3 "rounds" of workgroups per CU).  FP_SERIAL=1 disables it.
 _CONCURRENT = not bool(int(os.environ.get("FP_SERIAL", "0")))
+# exactly split bf16x3 operands for the 3x3 stride-1 tile kernel (conv3x3_tile_bf3.hip); FP_NO_BF3=1 keeps the fp32 MFMA
+_BF3 = not bool(int(os.environ.get("FP_NO_BF3", "0")))
 # nearest-x2 phase decomposition of the upsample convs (conv_up2_phase.hip); FP_NO_PHASE=1 keeps the fused-gather path.
 _PHASE = not bool(int(os.environ.get("FP_NO_PHASE", "0")))
 
@@ -45,6 +47,9 @@ class ConvRec:
         self.wpd = None   # dgrad packing
         self.up2 = None   # (C0, C1) for convs fed by cat[nearest_x2(low C0), skip C1]: phase-decomposed packings below
         self.wph = self.wsk = self.wdu = self.wds = None   # fwd phase / fwd skip slice / dgrad 4x4 s2 / dgrad skip slice
+        # bf16x3-split copies (3x3 stride-1 convs): forward, dgrad, and the skip-slice pair of the upsample convs
+        self.bf3 = _BF3 and self.K == 3 and self.stride == 1 and not stem and not head
+        self.wp3 = self.wpd3 = self.wsk3 = self.wds3 = None
         self.gw = None    # gradient views (flat grad buffer)
         self.gb = None
 
@@ -201,6 +206,15 @@ class Engine:
                 C0, C1 = c.up2
                 ex = [ops.up2_packed_weight_elems(c.Cout, C0), ops.packed_weight_elems(c.Cout, C1, 3) if C1 else 0,
                       ops.up2_packed_weight_elems(C0, c.Cout), ops.packed_weight_elems(c.Cout, C1, 3, True) if C1 else 0]
+            if c.bf3:
+                if c.up2 is None:
+                    ex += [ops.packed_weight_elems_bf3(c.Cout, c.Cin, 3, False), ops.packed_weight_elems_bf3(c.Cout, c.Cin, 3, True), 0, 0]
+                else:
+                    C1 = c.up2[1]
+                    ex += [0, 0, ops.packed_weight_elems_bf3(c.Cout, C1, 3, False) if C1 else 0,
+                           ops.packed_weight_elems_bf3(c.Cout, C1, 3, True) if C1 else 0]
+            else:
+                ex += [0, 0, 0, 0]
             plan.append((c, total, nf, nd, ex))
             total += nf + nd + sum(ex)
         self.packed = torch.empty(total, device=self.device)
@@ -212,7 +226,7 @@ class Engine:
             for n in ex:
                 views.append(self.packed[o:o + n] if n else None)
                 o += n
-            c.wph, c.wsk, c.wdu, c.wds = views
+            c.wph, c.wsk, c.wdu, c.wds, c.wp3, c.wpd3, c.wsk3, c.wds3 = views
 
     def refresh_packed(self, force=False):
         vers = tuple(c.w._version for c in self.all_convs())
@@ -224,6 +238,12 @@ class Engine:
                 jobs.append((L.PACK_STEM if c.stem else L.PACK_FWD, c.w.data, c.wp, 0, c.Cin))
                 if c.wpd is not None:
                     jobs.append((L.PACK_DGRAD, c.w.data, c.wpd, 0, c.Cin))
+                if c.wp3 is not None:
+                    jobs.append((L.PACK_FWD_BF3, c.w.data, c.wp3, 0, c.Cin))
+                    jobs.append((L.PACK_DGRAD_BF3, c.w.data, c.wpd3, 0, c.Cin))
+                if c.wsk3 is not None:
+                    jobs.append((L.PACK_FWD_BF3, c.w.data, c.wsk3, c.up2[0], c.up2[1]))
+                    jobs.append((L.PACK_DGRAD_BF3, c.w.data, c.wds3, c.up2[0], c.up2[1]))
                 if c.up2 is not None:
                     C0, C1 = c.up2
                     jobs.append((L.PACK_UP2_FWD, c.w.data, c.wph, 0, C0))
@@ -275,10 +295,17 @@ class Engine:
                      residual=None if residual is None else residual.view(M, rec.C), relu=relu)
         return out
 
+    @staticmethod
+    def _cv(d, src, w32, w3, out, **kw):
+        """one 3x3 / 1x1 convolution or data-gradient launch: the bf16x3-split tile kernel where it applies, else fp_conv_igemm"""
+        if w3 is not None and ops.conv3x3_bf3_supported(d):
+            return ops.conv3x3_bf3(d, src, w3, out, **kw)
+        return ops.conv_igemm(d, src, None, w32, out, **kw)
+
     def _conv_enc(self, c, x, N, H, W, out):
         OH, OW = (H + 2 * c.pad - c.K) // c.stride + 1, (W + 2 * c.pad - c.K) // c.stride + 1
         d = ops.make_desc(N, OH, OW, H, W, c.Cin, 0, c.Cout, c.K, c.stride, c.pad, L.GATHER_FWD_ZERO)
-        return ops.conv_igemm(d, x, None, c.wp, out)
+        return self._cv(d, x, c.wp, c.wp3, out)
 
     @staticmethod
     def _phase_ok(h, w):
@@ -289,11 +316,13 @@ class Engine:
         if up2 and c.up2 is not None and self._phase_ok(H // 2, W // 2):
             if C1:      # skip half at full resolution (raw partial sums), then the four phases of the upsampled half on top
                 d = ops.make_desc(N, H, W, H, W, C1, 0, c.Cout, 3, 1, 1, L.GATHER_FWD_REFLECT)
-                ops.conv_igemm(d, x1, None, c.wsk, out)
+                self._cv(d, x1, c.wsk, c.wsk3, out)
                 return ops.conv_up2_phase_fwd(x0, c.wph, c.b.data, out, act=L.ACT_ELU, addend=out)
             return ops.conv_up2_phase_fwd(x0, c.wph, c.b.data, out, act=L.ACT_ELU)
         gather = L.GATHER_FWD_REFLECT_UP2 if up2 else L.GATHER_FWD_REFLECT
         d = ops.make_desc(N, H, W, H, W, C0, C1, c.Cout, 3, 1, 1, gather, act=L.ACT_ELU)
+        if x1 is None and not up2:
+            return self._cv(d, x0, c.wp, c.wp3, out, bias=c.b.data)
         return ops.conv_igemm(d, x0, x1, c.wp, out, bias=c.b.data)
 
     # ------------------------------------------------------------------------------------------------
@@ -449,7 +478,7 @@ class Engine:
     def _dgrad_dec(self, c, dz, N, H, W, out, actsrc=None, addend=None, accum=False):
         epi = (L.EPI_ACTGRAD_ELU if actsrc is not None else 0) | (L.EPI_ACCUM if accum else 0)
         d = ops.make_desc(N, H, W, H, W, c.Cout, 0, c.Cin, 3, 1, 1, L.GATHER_DGRAD_REFLECT, epi=epi)
-        return ops.conv_igemm(d, dz, None, c.wpd, out, actsrc=actsrc, addend=addend)
+        return self._cv(d, dz, c.wpd, c.wpd3, out, actsrc=actsrc, addend=addend)
 
     def _dgrad_up2_ext(self, c, dz, N, hl, wl, C0, pfx):
         """gradient wrt the low-res input of an upsample conv on the (hl+2) x (wl+2) extended grid (ops.up2_fold_bwd folds it)"""
@@ -514,7 +543,7 @@ class Engine:
                        dz2.view(M, C), blk.bn2.gg, blk.bn2.gb, g_out=g.view(M, C), accumulate=accumulate)
             self._wgrad(blk.c2, L.GATHER_FWD_ZERO, B["a1"], None, dz2, N, h, w, h, w, C, 0, accumulate, side)
             da1 = buf("g.da1", (N, h, w, C))
-            ops.conv_igemm(ops.make_desc(N, h, w, h, w, C, 0, C, 3, 1, 1, L.GATHER_DGRAD_ZERO), dz2, None, blk.c2.wpd, da1)
+            self._cv(ops.make_desc(N, h, w, h, w, C, 0, C, 3, 1, 1, L.GATHER_DGRAD_ZERO), dz2, blk.c2.wpd, blk.c2.wpd3, da1)
             dz1 = buf("g.dz1.%d" % i, (N, h, w, C))
             ops.bn_bwd(da1.view(M, C), B["a1"].view(M, C), B["z1"].view(M, C), blk.bn1.mean, blk.bn1.invstd, blk.bn1.bn.weight.data,
                        dz1.view(M, C), blk.bn1.gg, blk.bn1.gb, accumulate=accumulate)
@@ -528,18 +557,18 @@ class Engine:
                 self._wgrad(blk.ds, L.GATHER_FWD_ZERO, B["x"], None, dzd, N, h, w, hin, win, Cin, 0, accumulate, side)
                 tgt = dF[feat_of_block[i - 1]]          # block input is the previous layer's feature (already holds decoder grads)
                 dgd.epi = L.EPI_ACCUM
-                ops.conv_igemm(dgd, dz1, None, blk.c1.wpd, tgt)
+                self._cv(dgd, dz1, blk.c1.wpd, blk.c1.wpd3, tgt)
                 d1 = ops.make_desc(N, hin, win, h, w, C, 0, Cin, 1, blk.stride, 0, L.GATHER_DGRAD_ZERO, epi=L.EPI_ACCUM)
                 ops.conv_igemm(d1, dzd, None, blk.ds.wpd, tgt)
                 dnext = None
             elif first_of_layer:                        # layer1 block 0: input is the max-pool output
                 dpool = buf("g.dpool", (N, hin, win, Cin))
-                ops.conv_igemm(dgd, dz1, None, blk.c1.wpd, dpool, addend=g)
+                self._cv(dgd, dz1, blk.c1.wpd, blk.c1.wpd3, dpool, addend=g)
                 ops.maxpool_bwd(dpool, self._bufs["pool.argmax"][:dpool.numel()].view(dpool.shape), dF[0], accumulate=True)
                 dnext = None
             else:
                 dx = buf("g.dx%d" % (i & 1), (N, hin, win, Cin))
-                ops.conv_igemm(dgd, dz1, None, blk.c1.wpd, dx, addend=g)
+                self._cv(dgd, dz1, blk.c1.wpd, blk.c1.wpd3, dx, addend=g)
                 dnext = dx
             if self.debug_hook is not None:
                 self.debug_hook(i, dict(dout=dout, g=g, dz2=dz2, da1=da1, dz1=dz1, dnext=dnext, B=B))
@@ -651,7 +680,7 @@ class Engine:
                     order_dF(3 - bi)
                 ds = ops.make_desc(N, hh, ww, hh, ww, cout, 0, cout, 3, 1, 1, L.GATHER_DGRAD_REFLECT,
                                    epi=L.EPI_ACCUM if accum_feat else 0)
-                ops.conv_igemm(ds, Bz, None, blk["post1"].wds, dF[3 - bi])
+                self._cv(ds, Bz, blk["post1"].wds, blk["post1"].wds3, dF[3 - bi])
             else:
                 XV = self._dgrad_dec(blk["post1"], Bz, N, hh, ww, buf(pfx + "XV", (N, hh, ww, 2 * cout)))
                 if not first:

@@ -6,6 +6,8 @@ streams here; there is no torch compute op and no fallback in this module.
 """
 import ctypes as C
 
+import os
+
 import torch
 
 from . import _lib
@@ -67,6 +69,31 @@ def conv_igemm(desc, src0, src1, wpacked, y, bias=None, addend=None, addend_mask
     _lib.check(lib.fp_conv_igemm(C.byref(d), _f32(src0, "src0"), _f32(src1, "src1"), _f32(wpacked, "wpacked"), _f32(bias),
                                  _f32(addend), _f32(addend_mask), _f32(actsrc), _f32(y, "y"), ws_ptr, ws_n, stream()), "fp_conv_igemm")
     return y
+
+
+def conv3x3_bf3_supported(desc):
+    return bool(_lib.load().fp_conv3x3_bf3_supported(C.byref(desc)))
+
+
+def conv3x3_bf3(desc, src, wpacked_bf3, y, bias=None, addend=None, addend_mask=None, actsrc=None):
+    """3x3 stride-1 conv / data-gradient with exactly split bf16x3 operands (same semantics as conv_igemm)"""
+    epi = desc.epi | (_lib.EPI_BIAS if bias is not None else 0) | (_lib.EPI_ADDEND if addend is not None else 0) | \
+        (_lib.EPI_ADDEND_MASK if addend_mask is not None else 0)
+    d = ConvDesc.from_buffer_copy(desc)
+    d.epi = epi
+    _lib.check(_lib.load().fp_conv3x3_bf3(C.byref(d), _f32(src, "src"), _f32(wpacked_bf3, "wpacked"), _f32(bias), _f32(addend),
+                                          _f32(addend_mask), _f32(actsrc), _f32(y, "y"), stream()), "fp_conv3x3_bf3")
+    return y
+
+
+def packed_weight_elems_bf3(Cout, Cin, K, for_dgrad=False):
+    return int(_lib.load().fp_packed_weight_elems_bf3(Cout, Cin, K, K, int(for_dgrad)))
+
+
+def pack_conv_weight_bf3(w, wp, for_dgrad=False):
+    Cout, Cin, KH, KW = w.shape
+    _lib.check(_lib.load().fp_pack_conv_weight_bf3(_f32(w), _f32(wp), Cout, Cin, KH, KW, int(for_dgrad), stream()), "fp_pack_conv_weight_bf3")
+    return wp
 
 
 def conv_wgrad(desc, src0, src1, dz, dw, accumulate=False):

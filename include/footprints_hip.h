@@ -91,7 +91,8 @@ int fp_conv_wgrad(const fp_conv_desc* d, const float* src0, const float* src1, c
 
 /* One repacking job of fp_pack_weights_batched: every convolution's packed copies are refreshed by ONE launch after the
  * optimizer step (the table lives in device memory and is built once: parameter and packed buffers never move). */
-enum { FP_PACK_FWD = 0, FP_PACK_DGRAD = 1, FP_PACK_STEM = 2, FP_PACK_UP2_FWD = 3, FP_PACK_UP2_DGRAD = 4 };
+enum { FP_PACK_FWD = 0, FP_PACK_DGRAD = 1, FP_PACK_STEM = 2, FP_PACK_UP2_FWD = 3, FP_PACK_UP2_DGRAD = 4,
+       FP_PACK_FWD_BF3 = 5, FP_PACK_DGRAD_BF3 = 6 /* bf16x3 split planes, see fp_conv3x3_bf3 */ };
 typedef struct fp_pack_job {
   const float* w;  /* [Cout][Cin][KH][KW] */
   float* wp;       /* packed destination */
@@ -109,6 +110,21 @@ int fp_pack_conv_weight(const float* w_oihw, float* wp, int32_t Cout, int32_t Ci
                         int32_t stem, fp_stream_t stream);
 int fp_pack_conv_weight_dgrad(const float* w_oihw, float* wp, int32_t Cout, int32_t Cin, int32_t KH, int32_t KW,
                               fp_stream_t stream);
+
+/* ---- 3x3 stride-1 convolution with exactly split operands (conv3x3_tile_bf3.hip).
+ * Every fp32 operand is split into three bf16 terms whose sum is exact (8+8+8 significant bits); six of the nine bf16 x bf16
+ * products (all those >= 2^-16 of the leading one) are accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  The result is
+ * closer to the exact dot product than the fp32 MFMA path (the dropped terms are <= 2^-24 relative, below fp32 rounding) and
+ * runs at up to 2.7x its MFMA rate.  Same operation, arguments and epilogue flags as fp_conv_igemm for
+ * FP_GATHER_{FWD_ZERO, FWD_REFLECT, DGRAD_ZERO, DGRAD_REFLECT} (C1 = 0), for the shapes fp_conv3x3_bf3_supported accepts
+ * (3x3 / stride 1 / pad 1, >= 256 workgroups of 8x16 pixels, <= 25 % tile padding); weights packed by
+ * fp_pack_conv_weight_bf3 (fp_packed_weight_elems_bf3 floats of storage) or FP_PACK_{FWD,DGRAD}_BF3 jobs. */
+int fp_conv3x3_bf3_supported(const fp_conv_desc* d);
+int fp_conv3x3_bf3(const fp_conv_desc* d, const float* src, const void* wpacked_bf3, const float* bias,
+                   const float* addend, const float* addend_mask, const float* actsrc, float* y, fp_stream_t stream);
+int64_t fp_packed_weight_elems_bf3(int32_t Cout, int32_t Cin, int32_t KH, int32_t KW, int32_t for_dgrad);
+int fp_pack_conv_weight_bf3(const float* w_oihw, void* wp, int32_t Cout, int32_t Cin, int32_t KH, int32_t KW,
+                            int32_t for_dgrad, fp_stream_t stream);
 
 /* ---- nearest-x2 phase decomposition (reference footprints/network.py:98,126-134,154: upsample -> [cat skip] ->
  * ReflectionPad2d(1) -> Conv2d 3x3).  A 3x3 conv over the x2-upsampled `low` equals four 2x2 convs (one per output

@@ -36,6 +36,19 @@ for name, gather, OH, OW, IH, IW, C0, C1, Nout, K, stride in (SHAPES if which in
         y = torch.empty((N, OH, OW, Nout), device=dev)
         b = torch.zeros(Nout, device=dev)
         run = lambda: ops.conv_igemm(d, src0, src1, wp, y, bias=b if gather != L.GATHER_FWD_ZERO else None)
+        if which == "igemm" and not up2 and ops.conv3x3_bf3_supported(d):
+            wp3 = ops.pack_conv_weight_bf3(w, torch.empty(ops.packed_weight_elems_bf3(Nout, C0, K), device=dev))
+            run3 = lambda: ops.conv3x3_bf3(d, src0, wp3, y, bias=b if gather != L.GATHER_FWD_ZERO else None)
+            run3()
+            torch.cuda.synchronize()
+            s3, e3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s3.record()
+            for _ in range(reps):
+                run3()
+            e3.record()
+            torch.cuda.synchronize()
+            us3 = s3.elapsed_time(e3) / reps * 1e3
+            print("%-42s %9.1f us  %6.1f TF/s  (bf16x3 split)" % (name, us3, flops / us3 / 1e6), flush=True)
     else:
         d.act = 0
         dz = torch.rand((N, OH, OW, Nout), device=dev) - 0.5

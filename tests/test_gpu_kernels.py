@@ -228,6 +228,65 @@ def test_pack_weights_batched_matches_single_launches():
 
 
 # ----------------------------------------------------------------------------------------------------------
+# exactly split bf16x3 operands (conv3x3_tile_bf3.hip): same operation as the fp32-MFMA tile kernel, tighter tolerance
+# ----------------------------------------------------------------------------------------------------------
+def pack_bf3(w, dgrad=False):
+    ops, _ = _ops()
+    Cout, Cin, K, _k = w.shape
+    wp = torch.empty(ops.packed_weight_elems_bf3(Cout, Cin, K, dgrad), device="cuda")
+    return ops.pack_conv_weight_bf3(w.contiguous().cuda(), wp, dgrad)
+
+
+@pytest.mark.parametrize("mode,N,H,W,C0,Cout", [
+    ("zero", 12, 48, 160, 64, 64), ("reflect", 4, 96, 320, 64, 64), ("reflect", 2, 192, 640, 32, 32), ("reflect", 12, 24, 80, 128, 128),
+    ("zero", 6, 40, 176, 32, 96), ("zero", 20, 24, 80, 24, 40), ("dgrad", 12, 48, 160, 64, 64), ("dgrad", 12, 24, 80, 128, 128),
+    ("dgrad_reflect", 12, 48, 160, 64, 64), ("dgrad_reflect", 2, 192, 640, 32, 32), ("dgrad_reflect", 6, 40, 144, 64, 128),
+    ("dgrad_reflect", 12, 24, 80, 128, 64)])
+def test_conv3x3_bf3_kernel(mode, N, H, W, C0, Cout):
+    ops, L = _ops()
+    tol = 2e-6        # split operands are exact; six products + fp32 accumulation: tighter than the fp32 MFMA itself
+    if mode == "dgrad_reflect":
+        pre = rnd((N, C0, H, W), 92, -2.0, 2.0).requires_grad_(True)
+        w = rnd((Cout, C0, 3, 3), 93, -0.1, 0.1)
+        x = F.elu(pre)
+        yr = F.conv2d(F.pad(x.double(), (1, 1, 1, 1), mode="reflect"), w.double())
+        g, extra = rnd(tuple(yr.shape), 94), rnd(tuple(x.shape), 95)
+        ((yr * g.double()).sum() + (x.double() * extra.double()).sum()).backward()
+        dz = torch.empty((N, H, W, C0), device="cuda")
+        d = ops.make_desc(N, H, W, H, W, Cout, 0, C0, 3, 1, 1, L.GATHER_DGRAD_REFLECT, epi=L.EPI_ACTGRAD_ELU)
+        assert ops.conv3x3_bf3_supported(d)
+        ops.conv3x3_bf3(d, nhwc(g), pack_bf3(w, dgrad=True), dz, actsrc=nhwc(x.detach()), addend=nhwc(extra))
+        check(nchw(dz), pre.grad, "bf3 dgrad_reflect (fold) + epilogue", tol)
+        return
+    if mode == "dgrad":
+        x = rnd((N, C0, H, W), 80).double().requires_grad_(True)
+        w = rnd((Cout, C0, 3, 3), 81, -0.1, 0.1)
+        yr = F.conv2d(x, w.double(), None, 1, 1)
+        g = rnd(tuple(yr.shape), 82)
+        add, msk, act = rnd(tuple(x.shape), 83), rnd(tuple(x.shape), 84), rnd(tuple(x.shape), 85)
+        yr.backward(g.double())
+        ref = (x.grad + add * (msk > 0).float()) * (act > 0).float()
+        dx = torch.empty((N, H, W, C0), device="cuda")
+        d = ops.make_desc(N, H, W, H, W, Cout, 0, C0, 3, 1, 1, L.GATHER_DGRAD_ZERO, epi=L.EPI_ACTGRAD_RELU)
+        ops.conv3x3_bf3(d, nhwc(g), pack_bf3(w, dgrad=True), dx, addend=nhwc(add), addend_mask=nhwc(msk), actsrc=nhwc(act))
+        check(nchw(dx), ref, "bf3 dgrad_zero + epilogue", tol)
+        return
+    w, b = rnd((Cout, C0, 3, 3), 86, -0.1, 0.1), rnd((Cout,), 87)
+    x = rnd((N, C0, H, W), 90)
+    if mode == "reflect":
+        ref = F.elu(F.conv2d(F.pad(x.double(), (1, 1, 1, 1), mode="reflect"), w.double(), b.double()))
+        gather = L.GATHER_FWD_REFLECT
+    else:
+        ref = F.elu(F.conv2d(x.double(), w.double(), b.double(), 1, 1))
+        gather = L.GATHER_FWD_ZERO
+    y = torch.empty((N, H, W, Cout), device="cuda")
+    d = ops.make_desc(N, H, W, H, W, C0, 0, Cout, 3, 1, 1, gather, act=L.ACT_ELU)
+    assert ops.conv3x3_bf3_supported(d)
+    ops.conv3x3_bf3(d, nhwc(x), pack_bf3(w), y, bias=b.cuda())
+    check(nchw(y), ref, "bf3 forward " + mode, tol)
+
+
+# ----------------------------------------------------------------------------------------------------------
 # halo-tile 3x3 kernel (conv3x3_tile.hip): shapes large enough (>= 384 workgroups) to be dispatched to it
 # ----------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("mode,N,H,W,C0,C1,Cout", [

@@ -125,3 +125,26 @@ def test_bucket_ranges_cover_flat_buffer_in_backward_order():
     order = [s for s, _, _ in b]
     assert order[0] == "mask_decoder" and order[-1] == "encoder.layer0"
     assert order.index("depth_decoder") < order.index("encoder.layer4") < order.index("encoder.layer1")
+
+
+def test_no_packed_fp32_valu_in_device_code(tmp_path):
+    """Hardware hazard found on MI355X (profiles/round1_notes.md): a wave running v_pk_fma_f32 / v_pk_add_f32 next to another
+    wave's v_mfma_f32_32x32x16_bf16 silently gets wrong sums.  The library is built with -fno-slp-vectorize -fno-vectorize;
+    this disassembles every gfx950 code object of the built .so and fails on any packed-fp32 VALU instruction."""
+    import shutil
+    import subprocess
+    from footprints_amd import _lib
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump) or not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("llvm-objdump or the built library is not available")
+    so = shutil.copy(_lib.LIB_PATH, tmp_path / "lib.so")
+    subprocess.run([objdump, "--offloading", str(so)], cwd=tmp_path, check=True, capture_output=True)
+    objs = [p for p in tmp_path.iterdir() if p.name.endswith("gfx950")]
+    assert objs, "no gfx950 code objects found in the library"
+    mfma = 0
+    for p in objs:
+        asm = subprocess.run([objdump, "-d", str(p)], check=True, capture_output=True, text=True).stdout
+        bad = [l for l in asm.splitlines() if re.search(r"\bv_pk_(fma|add|mul)_f32\b", l)]
+        assert not bad, "%s: packed fp32 VALU in device code: %s" % (p.name, bad[:3])
+        mfma += asm.count("v_mfma_f32_32x32x16_bf16")
+    assert mfma > 0            # the disassembly really covered the MFMA kernels
