@@ -9,8 +9,15 @@ produces them (mask decoder, depth decoder, encoder layer4 .. layer0); each buck
 side stream as soon as the engine reports it ready, so communication hides under the remaining backward.
 `torch.distributed` (backend "nccl" == RCCL on ROCm; "gloo" in the CPU tests) is plumbing only.
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+# RCCL's reduction kernels are ordinary VALU code (packed fp32 adds); on this part packed-fp32 VALU next to bf16 MFMAs was
+# observed to produce wrong sums (profiles/round1_notes.md), so by default the buckets are reduced AFTER the backward pass
+# (124 MB over xGMI: ~1 ms of a 23 ms step).  FP_DP_OVERLAP=1 restores the overlapped schedule.
+_OVERLAP = bool(int(os.environ.get("FP_DP_OVERLAP", "0")))
 
 
 def bucket_ranges(names, offsets, total, max_elems=8 << 20):
@@ -49,8 +56,10 @@ def bucket_ranges(names, offsets, total, max_elems=8 << 20):
 class GradReducer:
     """Bucketed, stream-overlapped all-reduce of a flat gradient buffer."""
 
-    def __init__(self, flat_grad, names, offsets, group=None, max_elems=8 << 20):
+    def __init__(self, flat_grad, names, offsets, group=None, max_elems=8 << 20, overlap=None):
         self.flat = flat_grad
+        # overlap: issue each bucket as soon as its stage is complete (default on CPU/gloo; on GPUs see _OVERLAP above)
+        self.overlap = (_OVERLAP or not flat_grad.is_cuda) if overlap is None else bool(overlap)
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.buckets = bucket_ranges(names, offsets, flat_grad.numel(), max_elems)

@@ -45,7 +45,7 @@ class TrainStep:
         eng.forward(img, training=True, save_for_backward=True, outputs=self.outputs)
         ops.loss_fwd_bwd(self.outputs, batch, self.losses, self.dpreds, self.depth_range, self.prior)
         # zero_grad + backward: gradients are overwritten; buckets are all-reduced as soon as they are complete
-        eng.backward(self.dpreds, accumulate=False, on_stage=None if self.reducer is None else self.reducer.stage_ready)
+        eng.backward(self.dpreds, accumulate=False, on_stage=self.reducer.stage_ready if (self.reducer is not None and self.reducer.overlap) else None)
         if self.reducer is not None:
             self.reducer.finish()
         self.optimiser.fused_step(eng)
