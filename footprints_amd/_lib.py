@@ -21,7 +21,7 @@ class ConvDesc(C.Structure):
                                          "gather", "act")] + [("epi", C.c_uint32)]
 
 
-PACK_FWD, PACK_DGRAD, PACK_STEM, PACK_UP2_FWD, PACK_UP2_DGRAD, PACK_FWD_BF3, PACK_DGRAD_BF3 = range(7)
+PACK_FWD, PACK_DGRAD, PACK_STEM, PACK_UP2_FWD, PACK_UP2_DGRAD, PACK_FWD_BF3, PACK_DGRAD_BF3, PACK_UP2_FWD_BF3 = range(8)
 
 
 class PackJob(C.Structure):
@@ -54,6 +54,8 @@ SIGNATURES = {
     "fp_conv_up2_phase_wgrad": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, C.c_int, _P, _I64, _P]),
     "fp_pack_job_blocks": (_I32, [_I32, _I32, _I32, _I32, _I32]),
     "fp_pack_weights_batched": (C.c_int, [_P, _P, _I32, _P]),
+    "fp_pack_up2_weight_bf3": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P]),
+    "fp_conv_up2_phase_fwd_bf3": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
     "fp_conv3x3_bf3_supported": (C.c_int, [_DESC]),
     "fp_conv3x3_bf3": (C.c_int, [_DESC, _P, _P, _P, _P, _P, _P, _P, _P]),
     "fp_packed_weight_elems_bf3": (_I64, [_I32, _I32, _I32, _I32, _I32]),

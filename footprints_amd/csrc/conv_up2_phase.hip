@@ -164,6 +164,149 @@ __global__ void __launch_bounds__(256) up2_phase_fwd_kernel(const PhaseArgs a) {
     }
 }
 
+// ---- bf16x3-split variant (operands split exactly into three bf16 terms, six v_mfma_f32_32x32x16_bf16 products; see
+// conv3x3_tile_bf3.hip).  Halo in LDS as three bf16 planes [plane][pixel][16 ch + 8 pad]; weights [phase][tap][chunk][plane][n][16].
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+constexpr int PIXB = 48, PLANE3 = HP * PIXB, BUF3 = 3 * PLANE3;
+
+template <int BN, int WM, int WN>
+__global__ void __launch_bounds__(256) up2_phase_fwd_bf3_kernel(const PhaseArgs a) {
+  constexpr int BM = TH * TW;
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int NS = (HP * 4 + 255) / 256;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF3];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, idx = lane & 31, h = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+  int wg = fp_xcd_remap(blockIdx.x, a.nwg);
+  const int phase = wg & 3; wg >>= 2;
+  const int tile_n = wg % a.tilesN; wg /= a.tilesN;
+  const int tile_x = wg % a.tilesX; wg /= a.tilesX;
+  const int tile_y = wg % a.tilesY;
+  const int n_img = wg / a.tilesY;
+  const int dy = phase >> 1, dx = phase & 1;
+  const int y0 = tile_y * TH, x0 = tile_x * TW, n0 = tile_n * BN;
+  const unsigned short* wq = reinterpret_cast<const unsigned short*>(a.w);
+
+  int pix[NS], lds_off[NS];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    const int lin = t + 256 * k, hp = min(lin >> 2, HP - 1);
+    lds_off[k] = (lin >> 2) < HP ? hp * PIXB + (lin & 3) * 8 : -1;
+    const int hy = hp / HW2, hx = hp - hy * HW2;
+    const int sy = min(max(y0 + hy - 1, 0), a.h - 1), sx = min(max(x0 + hx - 1, 0), a.w_ - 1);   // replicate padding
+    pix[k] = (n_img * a.h + sy) * a.w_ + sx;
+  }
+  float4 hreg[NS];
+  bool hzero = false;
+  auto load_halo = [&](int cc) {
+    const int c4 = cc * 16 + (t & 3) * 4;
+    hzero = c4 >= a.C0;
+    const int coff = hzero ? 0 : c4;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) hreg[k] = *reinterpret_cast<const float4*>(a.low + (size_t)pix[k] * a.C0 + coff);
+  };
+  auto store_halo = [&](int buf) {
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      if (lds_off[k] < 0) continue;
+      f32x4_t v = {hreg[k].x, hreg[k].y, hreg[k].z, hreg[k].w};
+      if (hzero) v = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      const bf16x4_t vh = __builtin_convertvector(v, bf16x4_t);
+      const f32x4_t r1 = v - __builtin_convertvector(vh, f32x4_t);
+      const bf16x4_t vm = __builtin_convertvector(r1, bf16x4_t);
+      const f32x4_t r2 = r1 - __builtin_convertvector(vm, f32x4_t);
+      const bf16x4_t vl = __builtin_convertvector(r2, bf16x4_t);
+      unsigned char* p = lds + buf * BUF3 + lds_off[k];
+      *reinterpret_cast<uint2*>(p) = __builtin_bit_cast(uint2, vh);
+      *reinterpret_cast<uint2*>(p + PLANE3) = __builtin_bit_cast(uint2, vm);
+      *reinterpret_cast<uint2*>(p + 2 * PLANE3) = __builtin_bit_cast(uint2, vl);
+    }
+  };
+  uint4 bq[4][TN][3];
+  auto load_b = [&](int tap, int cc, uint4 (&bf)[TN][3]) {
+    const unsigned short* ws = wq + (size_t)((phase * 4 + tap) * a.KC16 + cc) * 3 * a.Nout * 16 + h * 8;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = min(n0 + (wn * TN + j) * 32 + idx, a.Nout - 1);
+#pragma unroll
+      for (int p = 0; p < 3; ++p) bf[j][p] = *reinterpret_cast<const uint4*>(ws + ((size_t)p * a.Nout + n) * 16);
+    }
+  };
+  int abase[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int pt = (wm * TM + i) * 32 + idx;
+    abase[i] = ((pt / TW + dy) * HW2 + (pt % TW) + dx) * PIXB + h * 16;
+  }
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  load_halo(0);
+  store_halo(0);
+  load_b(0, 0, bq[0]);
+  load_b(1, 0, bq[1]);
+  load_halo(min(1, a.KC16 - 1));
+  __syncthreads();
+  for (int cc = 0; cc < a.KC16; ++cc) {
+    const unsigned char* Hb = lds + (cc & 1) * BUF3;
+    const int ccn = min(cc + 1, a.KC16 - 1);
+#pragma unroll
+    for (int tap = 0; tap < 4; ++tap) {
+      const int toff = ((tap >> 1) * HW2 + (tap & 1)) * PIXB;
+      uint4 af[TM][3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i][p] = *reinterpret_cast<const uint4*>(Hb + p * PLANE3 + abase[i] + toff);
+      __builtin_amdgcn_sched_barrier(0);
+      if (tap < 2) load_b(tap + 2, cc, bq[tap + 2]);
+      else load_b(tap - 2, ccn, bq[tap - 2]);
+      __builtin_amdgcn_sched_barrier(0);
+      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+      for (int q = 0; q < 6; ++q)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[i][PA[q]]),
+                                                                __builtin_bit_cast(bf16x8_t, bq[tap][j][PB[q]]), acc[i][j], 0, 0, 0);
+    }
+    if (cc + 1 < a.KC16) {
+      store_halo((cc + 1) & 1);
+      load_halo(min(cc + 2, a.KC16 - 1));
+      __syncthreads();
+    }
+  }
+  const int OH = 2 * a.h, OW = 2 * a.w_;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + (wn * TN + j) * 32 + idx;
+      if (n >= a.Nout) continue;
+      const float bias = (a.epi & FP_EPI_BIAS) ? a.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int pt = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int ly = y0 + pt / TW, lx = x0 + pt % TW;
+        if (ly >= a.h || lx >= a.w_) continue;
+        const size_t o = ((size_t)(n_img * OH + 2 * ly + dy) * OW + 2 * lx + dx) * a.Nout + n;
+        float v = acc[i][j][r] + bias;
+        if (a.epi & FP_EPI_ADDEND) v += a.addend[o];
+        if (a.act == FP_ACT_ELU) v = v > 0.f ? v : expm1f(v);
+        a.y[o] = v;
+      }
+    }
+}
+
 // ---- backward ----------------------------------------------------------------------------------------------------
 // d(low) of the phase decomposition is a 4x4 stride-2 convolution over dZ (taps r = hi-res row - (2Y - 1)):
 //     K4[0] = W[2], K4[1] = W[1] + W[2], K4[2] = W[0] + W[1], K4[3] = W[0]         (rows; same for columns)
@@ -234,6 +377,27 @@ extern "C" int fp_conv_up2_phase_fwd(const float* low, const float* wphase, cons
     hipLaunchKernelGGL((up2_phase_fwd_kernel<64, 2, 2>), dim3(a.nwg), dim3(256), 0, (hipStream_t)stream, a);
   }
   return fp_check_launch("fp_conv_up2_phase_fwd");
+}
+
+extern "C" int fp_conv_up2_phase_fwd_bf3(const float* low, const void* wphase_bf3, const float* bias, const float* addend, float* y,
+                                         int32_t N, int32_t h, int32_t w, int32_t C0, int32_t Nout, int32_t act, fp_stream_t stream) {
+  FP_REQUIRE(low && wphase_bf3 && y && N > 0 && h >= 1 && w >= 1 && C0 > 0 && C0 % 4 == 0 && Nout > 0,
+             "fp_conv_up2_phase_fwd_bf3: bad arguments");
+  PhaseArgs a;
+  a.low = low; a.w = (const float*)wphase_bf3; a.bias = bias; a.addend = addend; a.y = y;
+  a.N = N; a.h = h; a.w_ = w; a.C0 = C0; a.Nout = Nout; a.KC16 = (C0 + 15) / 16; a.act = act;
+  a.epi = (bias ? FP_EPI_BIAS : 0u) | (addend ? FP_EPI_ADDEND : 0u);
+  a.tilesX = (int)fp_ceil_div(w, TW); a.tilesY = (int)fp_ceil_div(h, TH);
+  if (Nout <= 32) {
+    a.tilesN = (int)fp_ceil_div(Nout, 32);
+    a.nwg = N * a.tilesY * a.tilesX * a.tilesN * 4;
+    hipLaunchKernelGGL((up2_phase_fwd_bf3_kernel<32, 4, 1>), dim3(a.nwg), dim3(256), 0, (hipStream_t)stream, a);
+  } else {
+    a.tilesN = (int)fp_ceil_div(Nout, 64);
+    a.nwg = N * a.tilesY * a.tilesX * a.tilesN * 4;
+    hipLaunchKernelGGL((up2_phase_fwd_bf3_kernel<64, 2, 2>), dim3(a.nwg), dim3(256), 0, (hipStream_t)stream, a);
+  }
+  return fp_check_launch("fp_conv_up2_phase_fwd_bf3");
 }
 
 extern "C" int fp_up2_fold_bwd(const float* ext, int32_t N, int32_t h, int32_t w, int32_t C, const float* addend, const float* ylow_elu,

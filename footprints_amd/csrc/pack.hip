@@ -39,6 +39,7 @@ __device__ __forceinline__ float pack_elem(const fp_pack_job& j, size_t e) {
       const int ky = kk / 21, rem = kk - ky * 21, kx = rem / 3, ci = rem - kx * 3;
       return w[((n * 3 + ci) * 7 + ky) * 7 + kx];
     }
+    case FP_PACK_UP2_FWD_BF3:
     case FP_PACK_UP2_FWD: {
       const int KC16 = (j.c_count + 15) / 16;
       const int n = (int)(r % j.Cout); r /= j.Cout;
@@ -84,6 +85,7 @@ __host__ __device__ inline int64_t pack_elems(int kind, int Cout, int KH, int KW
     case FP_PACK_DGRAD_BF3:
     case FP_PACK_DGRAD: return T * ((Cout + 15) / 16) * c_count * 16;
     case FP_PACK_STEM: return 10 * 64 * 16;
+    case FP_PACK_UP2_FWD_BF3:
     case FP_PACK_UP2_FWD: return (int64_t)16 * ((c_count + 15) / 16) * Cout * 16;
     case FP_PACK_UP2_DGRAD: return (int64_t)16 * ((Cout + 15) / 16) * c_count * 16;
     default: return 0;
@@ -98,11 +100,11 @@ __device__ __forceinline__ unsigned short bf16_rne(float x) {
   return (unsigned short)(u >> 16);
 }
 __device__ __forceinline__ void pack_store(const fp_pack_job& j, size_t e, float v) {
-  if (j.kind != FP_PACK_FWD_BF3 && j.kind != FP_PACK_DGRAD_BF3) {
+  if (j.kind != FP_PACK_FWD_BF3 && j.kind != FP_PACK_DGRAD_BF3 && j.kind != FP_PACK_UP2_FWD_BF3) {
     j.wp[e] = v;
     return;
   }
-  const size_t ncols = j.kind == FP_PACK_FWD_BF3 ? j.Cout : j.c_count;
+  const size_t ncols = j.kind == FP_PACK_DGRAD_BF3 ? j.c_count : j.Cout;
   const size_t k = e & 15, n = (e >> 4) % ncols, blk = (e >> 4) / ncols;
   unsigned short* o = reinterpret_cast<unsigned short*>(j.wp) + (blk * 3 * ncols + n) * 16 + k;
   const unsigned short h = bf16_rne(v);
@@ -157,6 +159,11 @@ extern "C" int fp_pack_conv_weight_bf3(const float* w_oihw, void* wp, int32_t Co
                     "fp_pack_conv_weight_bf3");
 }
 extern "C" int64_t fp_up2_packed_weight_elems(int32_t Ncols, int32_t K) { return pack_elems(FP_PACK_UP2_FWD, Ncols, 3, 3, K); }
+extern "C" int fp_pack_up2_weight_bf3(const float* w_oihw, void* wp, int32_t Cout, int32_t Cin, int32_t c_begin, int32_t c_count,
+                                      fp_stream_t stream) {
+  FP_REQUIRE(w_oihw && wp && c_begin >= 0 && c_count > 0 && c_begin + c_count <= Cin, "fp_pack_up2_weight_bf3: bad arguments");
+  return launch_one(FP_PACK_UP2_FWD_BF3, w_oihw, (float*)wp, Cout, Cin, 3, 3, c_begin, c_count, (hipStream_t)stream, "fp_pack_up2_weight_bf3");
+}
 
 extern "C" int fp_pack_conv_weight(const float* w_oihw, float* wp, int32_t Cout, int32_t Cin, int32_t KH, int32_t KW, int32_t stem,
                                    fp_stream_t stream) {

@@ -49,7 +49,7 @@ class ConvRec:
         self.wph = self.wsk = self.wdu = self.wds = None   # fwd phase / fwd skip slice / dgrad 4x4 s2 / dgrad skip slice
         # bf16x3-split copies (3x3 stride-1 convs): forward, dgrad, and the skip-slice pair of the upsample convs
         self.bf3 = _BF3 and self.K == 3 and self.stride == 1 and not stem and not head
-        self.wp3 = self.wpd3 = self.wsk3 = self.wds3 = None
+        self.wp3 = self.wpd3 = self.wsk3 = self.wds3 = self.wph3 = None
         self.gw = None    # gradient views (flat grad buffer)
         self.gb = None
 
@@ -208,13 +208,13 @@ class Engine:
                       ops.up2_packed_weight_elems(C0, c.Cout), ops.packed_weight_elems(c.Cout, C1, 3, True) if C1 else 0]
             if c.bf3:
                 if c.up2 is None:
-                    ex += [ops.packed_weight_elems_bf3(c.Cout, c.Cin, 3, False), ops.packed_weight_elems_bf3(c.Cout, c.Cin, 3, True), 0, 0]
+                    ex += [ops.packed_weight_elems_bf3(c.Cout, c.Cin, 3, False), ops.packed_weight_elems_bf3(c.Cout, c.Cin, 3, True), 0, 0, 0]
                 else:
-                    C1 = c.up2[1]
+                    C0, C1 = c.up2
                     ex += [0, 0, ops.packed_weight_elems_bf3(c.Cout, C1, 3, False) if C1 else 0,
-                           ops.packed_weight_elems_bf3(c.Cout, C1, 3, True) if C1 else 0]
+                           ops.packed_weight_elems_bf3(c.Cout, C1, 3, True) if C1 else 0, ops.up2_packed_weight_elems(c.Cout, C0) * 3 // 2]
             else:
-                ex += [0, 0, 0, 0]
+                ex += [0, 0, 0, 0, 0]
             plan.append((c, total, nf, nd, ex))
             total += nf + nd + sum(ex)
         self.packed = torch.empty(total, device=self.device)
@@ -226,7 +226,7 @@ class Engine:
             for n in ex:
                 views.append(self.packed[o:o + n] if n else None)
                 o += n
-            c.wph, c.wsk, c.wdu, c.wds, c.wp3, c.wpd3, c.wsk3, c.wds3 = views
+            c.wph, c.wsk, c.wdu, c.wds, c.wp3, c.wpd3, c.wsk3, c.wds3, c.wph3 = views
 
     def refresh_packed(self, force=False):
         vers = tuple(c.w._version for c in self.all_convs())
@@ -244,6 +244,8 @@ class Engine:
                 if c.wsk3 is not None:
                     jobs.append((L.PACK_FWD_BF3, c.w.data, c.wsk3, c.up2[0], c.up2[1]))
                     jobs.append((L.PACK_DGRAD_BF3, c.w.data, c.wds3, c.up2[0], c.up2[1]))
+                if c.wph3 is not None:
+                    jobs.append((L.PACK_UP2_FWD_BF3, c.w.data, c.wph3, 0, c.up2[0]))
                 if c.up2 is not None:
                     C0, C1 = c.up2
                     jobs.append((L.PACK_UP2_FWD, c.w.data, c.wph, 0, C0))
@@ -317,8 +319,8 @@ class Engine:
             if C1:      # skip half at full resolution (raw partial sums), then the four phases of the upsampled half on top
                 d = ops.make_desc(N, H, W, H, W, C1, 0, c.Cout, 3, 1, 1, L.GATHER_FWD_REFLECT)
                 self._cv(d, x1, c.wsk, c.wsk3, out)
-                return ops.conv_up2_phase_fwd(x0, c.wph, c.b.data, out, act=L.ACT_ELU, addend=out)
-            return ops.conv_up2_phase_fwd(x0, c.wph, c.b.data, out, act=L.ACT_ELU)
+            phase_fwd = ops.conv_up2_phase_fwd_bf3 if c.wph3 is not None else ops.conv_up2_phase_fwd
+            return phase_fwd(x0, c.wph3 if c.wph3 is not None else c.wph, c.b.data, out, act=L.ACT_ELU, addend=out if C1 else None)
         gather = L.GATHER_FWD_REFLECT_UP2 if up2 else L.GATHER_FWD_REFLECT
         d = ops.make_desc(N, H, W, H, W, C0, C1, c.Cout, 3, 1, 1, gather, act=L.ACT_ELU)
         if x1 is None and not up2:

@@ -163,6 +163,19 @@ def pack_conv_weight_slice(w, wp, c_begin, c_count):
     return wp
 
 
+def pack_up2_weight_bf3(w, wp, c_begin, c_count):
+    Cout, Cin = w.shape[:2]
+    _lib.check(_lib.load().fp_pack_up2_weight_bf3(_f32(w), _f32(wp), Cout, Cin, c_begin, c_count, stream()), "fp_pack_up2_weight_bf3")
+    return wp
+
+
+def conv_up2_phase_fwd_bf3(low, wphase_bf3, bias, y, act=0, addend=None):
+    N, h, w, C0 = low.shape
+    _lib.check(_lib.load().fp_conv_up2_phase_fwd_bf3(_f32(low), _f32(wphase_bf3), _f32(bias), _f32(addend), _f32(y), N, h, w, C0, y.shape[3],
+                                                     int(act), stream()), "fp_conv_up2_phase_fwd_bf3")
+    return y
+
+
 def conv_up2_phase_fwd(low, wphase, bias, y, act=0, addend=None):
     N, h, w, C0 = low.shape
     _lib.check(_lib.load().fp_conv_up2_phase_fwd(_f32(low), _f32(wphase), _f32(bias), _f32(addend), _f32(y), N, h, w, C0, y.shape[3],

@@ -92,7 +92,7 @@ int fp_conv_wgrad(const fp_conv_desc* d, const float* src0, const float* src1, c
 /* One repacking job of fp_pack_weights_batched: every convolution's packed copies are refreshed by ONE launch after the
  * optimizer step (the table lives in device memory and is built once: parameter and packed buffers never move). */
 enum { FP_PACK_FWD = 0, FP_PACK_DGRAD = 1, FP_PACK_STEM = 2, FP_PACK_UP2_FWD = 3, FP_PACK_UP2_DGRAD = 4,
-       FP_PACK_FWD_BF3 = 5, FP_PACK_DGRAD_BF3 = 6 /* bf16x3 split planes, see fp_conv3x3_bf3 */ };
+       FP_PACK_FWD_BF3 = 5, FP_PACK_DGRAD_BF3 = 6, FP_PACK_UP2_FWD_BF3 = 7 /* bf16x3 split planes, see fp_conv3x3_bf3 */ };
 typedef struct fp_pack_job {
   const float* w;  /* [Cout][Cin][KH][KW] */
   float* wp;       /* packed destination */
@@ -140,6 +140,12 @@ int fp_pack_conv_weight_slice(const float* w_oihw, float* wp, int32_t Cout, int3
                               int32_t c_count, fp_stream_t stream);
 int fp_conv_up2_phase_fwd(const float* low, const float* wphase, const float* bias, const float* addend, float* y,
                           int32_t N, int32_t h, int32_t w, int32_t C0, int32_t Nout, int32_t act, fp_stream_t stream);
+/* bf16x3-split variant (see fp_conv3x3_bf3): same operation, weights from fp_pack_up2_weight_bf3 / FP_PACK_UP2_FWD_BF3
+ * (fp_up2_packed_weight_elems(Cout, c_count) * 3 / 2 floats of storage). */
+int fp_pack_up2_weight_bf3(const float* w_oihw, void* wp, int32_t Cout, int32_t Cin, int32_t c_begin, int32_t c_count,
+                           fp_stream_t stream);
+int fp_conv_up2_phase_fwd_bf3(const float* low, const void* wphase_bf3, const float* bias, const float* addend, float* y,
+                              int32_t N, int32_t h, int32_t w, int32_t C0, int32_t Nout, int32_t act, fp_stream_t stream);
 /* Backward (the upsample_nearest2d_backward + reflection_pad2d_backward + convolution_backward(data) chain): d(low) is a
  * 4x4 stride-2 convolution over dZ.  Pack with fp_pack_up2_weight_dgrad (fp_up2_packed_weight_elems(c_count, Cout)
  * floats), run fp_conv_igemm{FWD_ZERO, K=4, stride 2, pad 3, IH=2h, OH=h+2} into ext[N][h+2][w+2][c_count], then

@@ -88,7 +88,8 @@ if which == "up2":
                 ops.conv_up2_phase_fwd(lo, wph, b, y, act=L.ACT_ELU, addend=y)
         else:
             new = lambda: ops.conv_up2_phase_fwd(lo, wph, b, y, act=L.ACT_ELU)
-        runs = [("old", old), ("phase", new)]
+        wph3 = ops.pack_up2_weight_bf3(wt, torch.empty(ops.up2_packed_weight_elems(Nout, C0) * 3 // 2, device=dev), 0, C0)
+        runs = [("old", old), ("phase", new), ("ph-bf3", lambda: ops.conv_up2_phase_fwd_bf3(lo, wph3, b, y, act=L.ACT_ELU, addend=y if C1 else None))]
         if C1:
             runs += [("skip", lambda: ops.conv_igemm(d_sk, sk, None, wsk, y)),
                      ("ph-only", lambda: ops.conv_up2_phase_fwd(lo, wph, b, y, act=L.ACT_ELU, addend=y))]

@@ -117,6 +117,18 @@ def _up2_ref(lo, skip, w, b):
     return F.conv2d(F.pad(xin, (1, 1, 1, 1), mode="reflect"), w, b)
 
 
+@pytest.mark.parametrize("N,h,w,C0,Cout", [(2, 24, 80, 64, 64), (2, 96, 320, 64, 32), (1, 5, 7, 32, 16), (2, 1, 1, 16, 16), (2, 9, 17, 20, 72)])
+def test_up2_phase_fwd_bf3(N, h, w, C0, Cout):
+    ops, L = _ops()
+    wt, b = rnd((Cout, C0, 3, 3), 304, -0.1, 0.1), rnd((Cout,), 305)
+    lo, prev = rnd((N, C0, h, w), 306), rnd((N, Cout, 2 * h, 2 * w), 307)
+    ref = F.elu(_up2_ref(lo.double(), None, wt.double(), b.double()) + prev.double())
+    wph = ops.pack_up2_weight_bf3(wt.cuda(), torch.empty(ops.up2_packed_weight_elems(Cout, C0) * 3 // 2, device="cuda"), 0, C0)
+    y = nhwc(prev)
+    ops.conv_up2_phase_fwd_bf3(nhwc(lo), wph, b.cuda(), y, act=L.ACT_ELU, addend=y)
+    check(nchw(y), ref, "up2 phase fwd bf3", 3e-6)      # the collapsed weights are fp32 sums of the 3x3 taps: one extra rounding
+
+
 @pytest.mark.parametrize("N,h,w,C0,C1,Cout", [
     (2, 6, 20, 256, 256, 256), (2, 12, 40, 128, 128, 128), (3, 24, 80, 64, 64, 64), (2, 48, 160, 32, 64, 32),
     (2, 96, 320, 16, 0, 16), (1, 5, 7, 32, 0, 16), (2, 1, 1, 16, 0, 16), (1, 3, 2, 24, 40, 48), (2, 9, 17, 20, 0, 72)])
