@@ -14,6 +14,9 @@
 //   * weights are packed [tap][chunk][plane][n][16] bf16 (pack.hip, FP_PACK_*_BF3): a wave's B fragment of one plane is 1 KB contiguous.
 #include "fp_common.h"
 
+int fp_splitk_reduce_launch(const float* part, int SK, int64_t M, int Nout, const float* bias, const float* addend, const float* addend_mask,
+                            const float* actsrc, float* y, int act, unsigned epi, hipStream_t stream);
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -33,6 +36,8 @@ struct Tile3Args {
   int act;
   unsigned epi;
   int tilesX, tilesY, tilesN, nwg;
+  int SK, chunksPerSplit;   // split-K over 16-channel chunks for small grids: raw partials [SK][N*OH*OW][Nout] -> fp_splitk_reduce_launch
+  float* part;
 };
 
 struct FoldTap { int wtap, ao, bo, rsel, csel; };
@@ -63,18 +68,20 @@ constexpr int PIXB = 48;   // bytes per halo pixel per plane (16 bf16 + 8 pad)
 
 template <int TH, int TW, int BN, int WM, int WN, bool FLIP, bool FOLD>
 __global__ void __launch_bounds__(256) conv3x3_tile_bf3_kernel(const Tile3Args a) {
-  constexpr int BM = TH * TW;
-  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int BM128 = 128;
+  constexpr int TM = BM128 / WM / 32, TN = BN / WN / 32;
   constexpr int HW2 = TW + 2, HP = (TH + 2) * HW2;
   constexpr int NS = (HP * 4 + 255) / 256;
   constexpr int PLANE = HP * PIXB;                   // bytes per plane
   constexpr int BUF = 3 * PLANE;                     // bytes per halo buffer
-  static_assert(WM * WN == 4 && TW == 16, "tile shape");
+  constexpr int NPIX = TH * TW;                      // valid rows of the 128-row M tile (8x16 = 128; 6x20 = 120, rows 120..127 idle)
+  static_assert(WM * WN == 4 && NPIX <= BM128 && BM128 == 128, "tile shape");
   __shared__ __attribute__((aligned(16))) unsigned char lds[(2 * BUF + 1023) / 1024 * 1024];   // whole LDS allocation granules
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, idx = lane & 31, h = lane >> 5;
   const int wm = wave / WN, wn = wave % WN;
   int wg = fp_xcd_remap(blockIdx.x, a.nwg);
+  const int split = wg % a.SK; wg /= a.SK;
   const int tile_n = wg % a.tilesN; wg /= a.tilesN;
   const int tile_x = wg % a.tilesX; wg /= a.tilesX;
   const int tile_y = wg % a.tilesY;
@@ -144,7 +151,7 @@ __global__ void __launch_bounds__(256) conv3x3_tile_bf3_kernel(const Tile3Args a
   int abase[TM];
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
-    const int pt = (wm * TM + i) * 32 + idx;
+    const int pt = min((wm * TM + i) * 32 + idx, NPIX - 1);
     abase[i] = ((pt / TW) * HW2 + (pt % TW)) * PIXB + h * 16;
   }
 
@@ -154,7 +161,7 @@ __global__ void __launch_bounds__(256) conv3x3_tile_bf3_kernel(const Tile3Args a
   unsigned m_r1[TM], m_rH[TM], m_c1[TM], m_cW[TM];       // all-ones / zero lane masks
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
-    const int pt = (wm * TM + i) * 32 + idx;
+    const int pt = min((wm * TM + i) * 32 + idx, NPIX - 1);
     const int yy = y0 + pt / TW, xx = x0 + pt % TW;
     m_r1[i] = yy == 1 ? ~0u : 0u;
     m_rH[i] = yy == a.OH - 2 ? ~0u : 0u;
@@ -183,16 +190,17 @@ __global__ void __launch_bounds__(256) conv3x3_tile_bf3_kernel(const Tile3Args a
                                                               acc[i][j], 0, 0, 0);
   };
 
-  load_halo(0);
+  const int c_begin = split * a.chunksPerSplit, c_end = min(a.KC16, c_begin + a.chunksPerSplit);
+  load_halo(c_begin);
   store_halo(0);
-  load_b(0, 0, bq[0]);
-  load_b(1, 0, bq[1]);
-  load_halo(min(1, a.KC16 - 1));
+  load_b(0, c_begin, bq[0]);
+  load_b(1, c_begin, bq[1]);
+  load_halo(min(c_begin + 1, c_end - 1));
   __syncthreads();
 
-  for (int cc = 0; cc < a.KC16; ++cc) {
-    const unsigned char* Hb = lds + (cc & 1) * BUF;
-    const int ccn = min(cc + 1, a.KC16 - 1);
+  for (int cc = c_begin; cc < c_end; ++cc) {
+    const unsigned char* Hb = lds + ((cc - c_begin) & 1) * BUF;
+    const int ccn = min(cc + 1, c_end - 1);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int ky = tap / 3, kx = tap % 3;
@@ -233,9 +241,9 @@ __global__ void __launch_bounds__(256) conv3x3_tile_bf3_kernel(const Tile3Args a
         mma6(ax, bx);
       }
     }
-    if (cc + 1 < a.KC16) {
-      store_halo((cc + 1) & 1);
-      load_halo(min(cc + 2, a.KC16 - 1));
+    if (cc + 1 < c_end) {
+      store_halo((cc + 1 - c_begin) & 1);
+      load_halo(min(cc + 2, c_end - 1));
       __syncthreads();
     }
   }
@@ -250,47 +258,80 @@ __global__ void __launch_bounds__(256) conv3x3_tile_bf3_kernel(const Tile3Args a
       for (int r = 0; r < 16; ++r) {
         const int pt = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         const int oy = y0 + pt / TW, ox = x0 + pt % TW;
-        if (oy >= a.OH || ox >= a.OW) continue;
+        if (pt >= NPIX || oy >= a.OH || ox >= a.OW) continue;
         const size_t o = ((size_t)(n_img * a.OH + oy) * a.OW + ox) * a.Nout + n;
-        a.y[o] = tile3_epilogue(a, o, n, acc[i][j][r]);
+        if (a.SK > 1) a.part[(size_t)split * a.N * a.OH * a.OW * a.Nout + o] = acc[i][j][r];
+        else a.y[o] = tile3_epilogue(a, o, n, acc[i][j][r]);
       }
     }
 }
 
 template <int TH, int TW, int BN, int WM, int WN, bool FLIP, bool FOLD>
 int launch3(Tile3Args& a, hipStream_t stream) {
-  a.tilesX = (int)fp_ceil_div(a.OW, TW);
-  a.tilesY = (int)fp_ceil_div(a.OH, TH);
-  a.tilesN = (int)fp_ceil_div(a.Nout, BN);
-  a.nwg = a.N * a.tilesY * a.tilesX * a.tilesN;
   hipLaunchKernelGGL((conv3x3_tile_bf3_kernel<TH, TW, BN, WM, WN, FLIP, FOLD>), dim3(a.nwg), dim3(256), 0, stream, a);
   return fp_check_launch("fp_conv3x3_bf3");
 }
 
-bool eligible3(const fp_conv_desc* d) {
-  if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->C1 != 0 || d->C0 % 4) return false;
+// tile geometry + split factor for a problem, or ok = false
+struct Plan3 { bool ok; int th, tw, bn, tilesX, tilesY, tilesN, SK, chunksPerSplit; };
+Plan3 plan3(const fp_conv_desc* d) {
+  Plan3 p = {};
+  if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->C1 != 0 || d->C0 % 4) return p;
   if (d->gather != FP_GATHER_FWD_ZERO && d->gather != FP_GATHER_FWD_REFLECT && d->gather != FP_GATHER_DGRAD_ZERO &&
       d->gather != FP_GATHER_DGRAD_REFLECT)
-    return false;
-  if (d->OH != d->IH || d->OW != d->IW || d->IH < 2 || d->IW < 2) return false;
-  const int64_t ty = fp_ceil_div(d->OH, 8), tx = fp_ceil_div(d->OW, 16);
-  if (ty * 8 * tx * 16 * 4 > (int64_t)d->OH * d->OW * 5) return false;          // > 25 % padded work
-  return (int64_t)d->N * ty * tx * fp_ceil_div(d->Nout, d->Nout <= 32 ? 32 : 64) >= 256;
+    return p;
+  if (d->OH != d->IH || d->OW != d->IW || d->IH < 2 || d->IW < 2) return p;
+  // 8x16 tiles, or 6x20 tiles for the 6x20 / 12x40 levels of a 192x640 pyramid; <= 25 % padded work
+  auto waste_ok = [&](int th, int tw, int rows) {
+    const int64_t ty = fp_ceil_div(d->OH, th), tx = fp_ceil_div(d->OW, tw);
+    return ty * tx * rows * 4 <= (int64_t)d->OH * d->OW * 5;
+  };
+  if (waste_ok(8, 16, 128)) { p.th = 8; p.tw = 16; }
+  else if (waste_ok(6, 20, 128)) { p.th = 6; p.tw = 20; }
+  else return p;
+  p.bn = d->Nout <= 32 ? 32 : 64;
+  p.tilesX = (int)fp_ceil_div(d->OW, p.tw); p.tilesY = (int)fp_ceil_div(d->OH, p.th); p.tilesN = (int)fp_ceil_div(d->Nout, p.bn);
+  const int64_t tiles = (int64_t)d->N * p.tilesY * p.tilesX * p.tilesN;
+  const int KC16 = (d->C0 + 15) / 16;
+  // small grids: split the channel chunks until ~2 workgroups per CU, >= 2 chunks per split, <= 16 partial copies
+  int64_t sk = 1;
+  if (tiles < 384) {
+    sk = fp_ceil_div(512, tiles);
+    if (sk > KC16 / 2) sk = KC16 / 2;
+    if (sk > 16) sk = 16;
+    if (sk < 1) sk = 1;
+  }
+  p.chunksPerSplit = (int)fp_ceil_div(KC16, sk);
+  p.SK = (int)fp_ceil_div(KC16, p.chunksPerSplit);
+  if (tiles * p.SK < 128) return p;                  // still far too small to fill the chip: leave it to the flattened kernel
+  p.ok = true;
+  return p;
 }
 
 }  // namespace
 
-extern "C" int fp_conv3x3_bf3_supported(const fp_conv_desc* d) { return d && eligible3(d) ? 1 : 0; }
+extern "C" int fp_conv3x3_bf3_supported(const fp_conv_desc* d) { return d && plan3(d).ok ? 1 : 0; }
+
+// bytes of split-K scratch fp_conv3x3_bf3 needs for this problem (0 = none)
+extern "C" int64_t fp_conv3x3_bf3_workspace(const fp_conv_desc* d) {
+  if (!d) return 0;
+  const Plan3 p = plan3(d);
+  if (!p.ok || p.SK <= 1) return 0;
+  return (int64_t)p.SK * d->N * d->OH * d->OW * d->Nout * (int64_t)sizeof(float);
+}
 
 extern "C" int fp_conv3x3_bf3(const fp_conv_desc* d, const float* src, const void* wpacked_bf3, const float* bias, const float* addend,
-                              const float* addend_mask, const float* actsrc, float* y, fp_stream_t stream_) {
+                              const float* addend_mask, const float* actsrc, float* y, void* workspace, int64_t workspace_bytes,
+                              fp_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   FP_REQUIRE(d && src && wpacked_bf3 && y, "fp_conv3x3_bf3: null pointer");
-  FP_REQUIRE(eligible3(d), "fp_conv3x3_bf3: shape not supported (see fp_conv3x3_bf3_supported)");
+  const Plan3 p = plan3(d);
+  FP_REQUIRE(p.ok, "fp_conv3x3_bf3: shape not supported (see fp_conv3x3_bf3_supported)");
   FP_REQUIRE(!(d->epi & FP_EPI_BIAS) || bias, "fp_conv3x3_bf3: bias missing");
   FP_REQUIRE(!(d->epi & FP_EPI_ADDEND) || addend, "fp_conv3x3_bf3: addend missing");
   FP_REQUIRE(!(d->epi & FP_EPI_ADDEND_MASK) || addend_mask, "fp_conv3x3_bf3: addend_mask missing");
   FP_REQUIRE(!(d->epi & (FP_EPI_ACTGRAD_ELU | FP_EPI_ACTGRAD_RELU)) || actsrc, "fp_conv3x3_bf3: actsrc missing");
+  FP_REQUIRE(p.SK <= 1 || (workspace && workspace_bytes >= fp_conv3x3_bf3_workspace(d)), "fp_conv3x3_bf3: workspace too small");
   Tile3Args a;
   a.src = src; a.w = (const unsigned short*)wpacked_bf3; a.bias = bias; a.addend = addend; a.addend_mask = addend_mask; a.actsrc = actsrc;
   a.y = y;
@@ -299,10 +340,18 @@ extern "C" int fp_conv3x3_bf3(const fp_conv_desc* d, const float* src, const voi
   const bool fold = d->gather == FP_GATHER_DGRAD_REFLECT;
   a.mode = d->gather == FP_GATHER_FWD_REFLECT ? 1 : 0;
   a.act = d->act; a.epi = d->epi;
-  if (d->Nout <= 32) {
-    if (fold) return launch3<8, 16, 32, 4, 1, true, true>(a, stream);
-    return flip ? launch3<8, 16, 32, 4, 1, true, false>(a, stream) : launch3<8, 16, 32, 4, 1, false, false>(a, stream);
-  }
-  if (fold) return launch3<8, 16, 64, 2, 2, true, true>(a, stream);
-  return flip ? launch3<8, 16, 64, 2, 2, true, false>(a, stream) : launch3<8, 16, 64, 2, 2, false, false>(a, stream);
+  a.tilesX = p.tilesX; a.tilesY = p.tilesY; a.tilesN = p.tilesN; a.SK = p.SK; a.chunksPerSplit = p.chunksPerSplit;
+  a.part = (float*)workspace;
+  a.nwg = d->N * p.tilesY * p.tilesX * p.tilesN * p.SK;
+  int rc;
+#define FP_L3(TH_, TW_)                                                                                                       \
+  (p.bn == 32 ? (fold ? launch3<TH_, TW_, 32, 4, 1, true, true>(a, stream)                                                    \
+                      : (flip ? launch3<TH_, TW_, 32, 4, 1, true, false>(a, stream) : launch3<TH_, TW_, 32, 4, 1, false, false>(a, stream))) \
+              : (fold ? launch3<TH_, TW_, 64, 2, 2, true, true>(a, stream)                                                    \
+                      : (flip ? launch3<TH_, TW_, 64, 2, 2, true, false>(a, stream) : launch3<TH_, TW_, 64, 2, 2, false, false>(a, stream))))
+  rc = p.th == 8 ? FP_L3(8, 16) : FP_L3(6, 20);
+#undef FP_L3
+  if (rc || p.SK <= 1) return rc;
+  return fp_splitk_reduce_launch(a.part, p.SK, (int64_t)d->N * d->OH * d->OW, d->Nout, bias, addend, addend_mask, actsrc, y, d->act, d->epi,
+                                 stream);
 }

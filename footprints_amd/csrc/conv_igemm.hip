@@ -258,6 +258,18 @@ constexpr int64_t MAX_SK = 24;
 
 }  // namespace
 
+// y = epilogue(sum over `SK` raw partial copies [SK][M][Nout]) in a fixed order -- shared with conv3x3_tile_bf3.hip
+int fp_splitk_reduce_launch(const float* part, int SK, int64_t M, int Nout, const float* bias, const float* addend, const float* addend_mask,
+                            const float* actsrc, float* y, int act, unsigned epi, hipStream_t stream) {
+  IgemmArgs a = {};
+  a.part = const_cast<float*>(part); a.SK = SK; a.M = (int)M; a.Nout = Nout;
+  a.bias = bias; a.addend = addend; a.addend_mask = addend_mask; a.actsrc = actsrc; a.y = y; a.act = act; a.epi = epi;
+  int64_t g = fp_ceil_div(M * Nout, 256);
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)g), dim3(256), 0, stream, a);
+  return fp_check_launch("splitk_reduce");
+}
+
 extern "C" int64_t fp_conv_igemm_workspace(const fp_conv_desc* d) {
   if (!d) return 0;
   const int64_t M = (int64_t)d->N * d->OH * d->OW;

@@ -79,10 +79,16 @@ def conv3x3_bf3(desc, src, wpacked_bf3, y, bias=None, addend=None, addend_mask=N
     """3x3 stride-1 conv / data-gradient with exactly split bf16x3 operands (same semantics as conv_igemm)"""
     epi = desc.epi | (_lib.EPI_BIAS if bias is not None else 0) | (_lib.EPI_ADDEND if addend is not None else 0) | \
         (_lib.EPI_ADDEND_MASK if addend_mask is not None else 0)
+    lib = _lib.load()
     d = ConvDesc.from_buffer_copy(desc)
     d.epi = epi
-    _lib.check(_lib.load().fp_conv3x3_bf3(C.byref(d), _f32(src, "src"), _f32(wpacked_bf3, "wpacked"), _f32(bias), _f32(addend),
-                                          _f32(addend_mask), _f32(actsrc), _f32(y, "y"), stream()), "fp_conv3x3_bf3")
+    need = lib.fp_conv3x3_bf3_workspace(C.byref(d))
+    ws_ptr, ws_n = 0, 0
+    if need > 0:
+        ws = workspace(need, y.device, "igemm")
+        ws_ptr, ws_n = ws.data_ptr(), ws.numel()
+    _lib.check(lib.fp_conv3x3_bf3(C.byref(d), _f32(src, "src"), _f32(wpacked_bf3, "wpacked"), _f32(bias), _f32(addend),
+                                  _f32(addend_mask), _f32(actsrc), _f32(y, "y"), ws_ptr, ws_n, stream()), "fp_conv3x3_bf3")
     return y
 
 

@@ -253,7 +253,11 @@ def pack_bf3(w, dgrad=False):
     ("zero", 12, 48, 160, 64, 64), ("reflect", 4, 96, 320, 64, 64), ("reflect", 2, 192, 640, 32, 32), ("reflect", 12, 24, 80, 128, 128),
     ("zero", 6, 40, 176, 32, 96), ("zero", 20, 24, 80, 24, 40), ("dgrad", 12, 48, 160, 64, 64), ("dgrad", 12, 24, 80, 128, 128),
     ("dgrad_reflect", 12, 48, 160, 64, 64), ("dgrad_reflect", 2, 192, 640, 32, 32), ("dgrad_reflect", 6, 40, 144, 64, 128),
-    ("dgrad_reflect", 12, 24, 80, 128, 64)])
+    ("dgrad_reflect", 12, 24, 80, 128, 64),
+    # small grids: 6x20 tiles and / or split-K over the channel chunks
+    ("zero", 12, 12, 40, 256, 256), ("zero", 12, 6, 20, 512, 512), ("reflect", 12, 12, 40, 256, 128), ("reflect", 12, 24, 80, 64, 64),
+    ("dgrad", 12, 12, 40, 256, 256), ("dgrad", 12, 6, 20, 512, 512), ("dgrad_reflect", 12, 6, 20, 256, 512),
+    ("dgrad_reflect", 12, 12, 40, 128, 256), ("zero", 8, 18, 60, 48, 80)])
 def test_conv3x3_bf3_kernel(mode, N, H, W, C0, Cout):
     ops, L = _ops()
     tol = 2e-6        # split operands are exact; six products + fp32 accumulation: tighter than the fp32 MFMA itself
