@@ -56,6 +56,8 @@ SIGNATURES = {
     "fp_pack_weights_batched": (C.c_int, [_P, _P, _I32, _P]),
     "fp_pack_up2_weight_bf3": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P]),
     "fp_conv_up2_phase_fwd_bf3": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
+    "fp_conv_wgrad_bf3_workspace": (_I64, [_DESC]),
+    "fp_conv_wgrad_bf3": (C.c_int, [_DESC, _P, _P, _P, _I32, _I32, C.c_int, _P, _I64, _P]),
     "fp_conv3x3_bf3_supported": (C.c_int, [_DESC]),
     "fp_conv3x3_bf3_workspace": (_I64, [_DESC]),
     "fp_conv3x3_bf3": (C.c_int, [_DESC, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),

@@ -26,6 +26,7 @@ from . import ops
 _CONCURRENT = not bool(int(os.environ.get("FP_SERIAL", "0")))
 # exactly split bf16x3 operands for the 3x3 stride-1 tile kernel (conv3x3_tile_bf3.hip); FP_NO_BF3=1 keeps the fp32 MFMA
 _BF3 = not bool(int(os.environ.get("FP_NO_BF3", "0")))
+_WBF3 = _BF3 and not bool(int(os.environ.get("FP_NO_WBF3", "0")))      # ... and for the weight-gradient kernel
 # nearest-x2 phase decomposition of the upsample convs (conv_up2_phase.hip); FP_NO_PHASE=1 keeps the fused-gather path.
 _PHASE = not bool(int(os.environ.get("FP_NO_PHASE", "0")))
 
@@ -446,16 +447,19 @@ class Engine:
         """Weight (+bias) gradient of one conv.  side = a stream: launch there, ordered after everything already
         queued on the current stream (dz is ready) -- the caller guarantees dz / src stay untouched until the join."""
         d = ops.make_desc(N, OH, OW, IH, IW, C0, C1, c.Cout, c.K, c.stride, c.pad, gather)
-        if side is not None:
-            side.wait_event(self._record(torch.cuda.current_stream()))
-            with torch.cuda.stream(side):
+
+        def launch():
+            if _WBF3 and src1 is None and ops.conv_wgrad_bf3_supported(d):
+                ops.conv_wgrad_bf3(d, src0, dz, c.gw, 0, accumulate=acc)
+            else:
                 ops.conv_wgrad(d, src0, src1, dz, c.gw, accumulate=acc)
-                if c.gb is not None:
-                    ops.colsum(dz.view(-1, c.Cout), c.gb, accumulate=acc)
-            return
-        ops.conv_wgrad(d, src0, src1, dz, c.gw, accumulate=acc)
-        if c.gb is not None:
-            ops.colsum(dz.view(-1, c.Cout), c.gb, accumulate=acc)
+            if c.gb is not None:
+                ops.colsum(dz.view(-1, c.Cout), c.gb, accumulate=acc)
+        if side is None:
+            return launch()
+        side.wait_event(self._record(torch.cuda.current_stream()))
+        with torch.cuda.stream(side):
+            launch()
 
     def _wgrad_up2(self, c, low, skip, dz, N, hl, wl, C0, C1, acc, side=None):
         """weight (+bias) gradient of a conv over cat[nearest_x2(low), skip]: upsampled half by output phase, skip half as a
@@ -468,7 +472,10 @@ class Engine:
             ops.conv_up2_phase_wgrad(low, dz, c.gw, 0, accumulate=acc)
             if C1:
                 d = ops.make_desc(N, H, W, H, W, C1, 0, c.Cout, 3, 1, 1, L.GATHER_FWD_REFLECT)
-                ops.conv_wgrad_slice(d, skip, None, dz, c.gw, C0, accumulate=acc)
+                if _WBF3 and ops.conv_wgrad_bf3_supported(d):
+                    ops.conv_wgrad_bf3(d, skip, dz, c.gw, C0, accumulate=acc)
+                else:
+                    ops.conv_wgrad_slice(d, skip, None, dz, c.gw, C0, accumulate=acc)
             if c.gb is not None:
                 ops.colsum(dz.view(-1, c.Cout), c.gb, accumulate=acc)
         if side is None:

@@ -111,6 +111,22 @@ def conv_wgrad(desc, src0, src1, dz, dw, accumulate=False):
     return dw
 
 
+def conv_wgrad_bf3_supported(desc):
+    return _lib.load().fp_conv_wgrad_bf3_workspace(C.byref(desc)) >= 0
+
+
+def conv_wgrad_bf3(desc, x, dz, dw, k_begin=0, accumulate=False):
+    """3x3 stride-1 weight gradient with exactly split bf16x3 operands, into dw[:, k_begin:k_begin + C0]"""
+    lib = _lib.load()
+    need = lib.fp_conv_wgrad_bf3_workspace(C.byref(desc))
+    if need < 0:
+        raise RuntimeError("fp_conv_wgrad_bf3: shape not supported")
+    ws = workspace(need, dz.device)
+    _lib.check(lib.fp_conv_wgrad_bf3(C.byref(desc), _f32(x), _f32(dz), _f32(dw), dw.shape[1], k_begin, int(bool(accumulate)),
+                                     ws.data_ptr(), ws.numel(), stream()), "fp_conv_wgrad_bf3")
+    return dw
+
+
 def conv_wgrad_slice(desc, src0, src1, dz, dw, k_begin, accumulate=False):
     """weight gradient of the input-channel slice [k_begin, k_begin + C0 + C1) of the wider gradient dw [Nout][Cin][K][K]"""
     lib = _lib.load()

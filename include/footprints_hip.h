@@ -129,6 +129,13 @@ int64_t fp_packed_weight_elems_bf3(int32_t Cout, int32_t Cin, int32_t KH, int32_
 int fp_pack_conv_weight_bf3(const float* w_oihw, void* wp, int32_t Cout, int32_t Cin, int32_t KH, int32_t KW,
                             int32_t for_dgrad, fp_stream_t stream);
 
+/* Weight gradient with the same exactly split operands (wgrad3x3_bf3.hip): 3x3 / stride 1 / pad 1, FWD_ZERO or FWD_REFLECT
+ * gather, C1 = 0, C0 and Nout multiples of 32; fp_conv_wgrad_bf3_workspace returns -1 for anything else (use fp_conv_wgrad).
+ * dw_oihw is [Nout][kc_total][3][3]; the C0 input channels of `d` are its slice [k_begin, k_begin + C0). */
+int64_t fp_conv_wgrad_bf3_workspace(const fp_conv_desc* d);
+int fp_conv_wgrad_bf3(const fp_conv_desc* d, const float* x, const float* dz, float* dw_oihw, int32_t kc_total,
+                      int32_t k_begin, int accumulate, void* workspace, int64_t workspace_bytes, fp_stream_t stream);
+
 /* ---- nearest-x2 phase decomposition (reference footprints/network.py:98,126-134,154: upsample -> [cat skip] ->
  * ReflectionPad2d(1) -> Conv2d 3x3).  A 3x3 conv over the x2-upsampled `low` equals four 2x2 convs (one per output
  * parity phase) over `low` itself with row/column-collapsed weights and replicate padding: 2.25x fewer MACs and no

@@ -54,6 +54,18 @@ for name, gather, OH, OW, IH, IW, C0, C1, Nout, K, stride in (SHAPES if which in
         dz = torch.rand((N, OH, OW, Nout), device=dev) - 0.5
         dw = torch.empty_like(w)
         run = lambda: ops.conv_wgrad(d, src0, src1, dz, dw)
+        if not up2 and ops.conv_wgrad_bf3_supported(d):
+            run3 = lambda: ops.conv_wgrad_bf3(d, src0, dz, dw)
+            run3()
+            torch.cuda.synchronize()
+            s3, e3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s3.record()
+            for _ in range(reps):
+                run3()
+            e3.record()
+            torch.cuda.synchronize()
+            us3 = s3.elapsed_time(e3) / reps * 1e3
+            print("%-42s %9.1f us  %6.1f TF/s  (bf16x3 split)" % (name, us3, flops / us3 / 1e6), flush=True)
     run()
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -717,3 +717,30 @@ def test_layout_roundtrip():
     z = torch.empty(1001, device="cuda")
     ops.fill(z, 2.5)
     assert float(z.min()) == 2.5 and float(z.max()) == 2.5
+
+
+@pytest.mark.parametrize("mode,N,H,W,C0,Cout", [
+    ("zero", 12, 48, 160, 64, 64), ("reflect", 4, 96, 320, 64, 32), ("reflect", 2, 192, 640, 32, 32), ("reflect", 12, 24, 80, 128, 128),
+    ("zero", 6, 12, 40, 256, 256), ("reflect", 3, 10, 46, 32, 96), ("zero", 12, 8, 32, 64, 32), ("reflect", 5, 7, 32, 32, 32)])
+def test_wgrad3x3_bf3_kernel(mode, N, H, W, C0, Cout):
+    """weight gradient with exactly split bf16x3 operands (wgrad3x3_bf3.hip), float64 reference, slice destination + accumulate"""
+    ops, L = _ops()
+    w = rnd((Cout, C0, 3, 3), 96, -0.1, 0.1).double().requires_grad_(True)
+    x = rnd((N, C0, H, W), 99)
+    if mode == "reflect":
+        y = F.conv2d(F.pad(x.double(), (1, 1, 1, 1), mode="reflect"), w)
+        gather = L.GATHER_FWD_REFLECT
+    else:
+        y = F.conv2d(x.double(), w, None, 1, 1)
+        gather = L.GATHER_FWD_ZERO
+    g = rnd(tuple(y.shape), 101)
+    y.backward(g.double())
+    d = ops.make_desc(N, H, W, H, W, C0, 0, Cout, 3, 1, 1, gather)
+    assert ops.conv_wgrad_bf3_supported(d)
+    pad = 32                                                     # destination = channel slice [pad, pad + C0) of a wider gradient
+    dw = torch.full((Cout, C0 + 2 * pad, 3, 3), 7.0, device="cuda")
+    ops.conv_wgrad_bf3(d, nhwc(x), nhwc(g), dw, pad)
+    check(dw[:, pad:pad + C0], w.grad, "wgrad bf3 " + mode, 3e-6)
+    assert bool((dw[:, :pad] == 7.0).all()) and bool((dw[:, pad + C0:] == 7.0).all())
+    ops.conv_wgrad_bf3(d, nhwc(x), nhwc(g), dw, pad, accumulate=True)
+    check(dw[:, pad:pad + C0], 2 * w.grad, "wgrad bf3 accumulate " + mode, 3e-6)
