@@ -332,6 +332,10 @@ class Engine:
     # forward
     # ------------------------------------------------------------------------------------------------
     def forward(self, image, training=True, save_for_backward=True, outputs=None):
+        with ops.on_stream(torch.cuda.current_stream()):      # caches the raw stream handle for the launch wrappers
+            return self._forward(image, training, save_for_backward, outputs)
+
+    def _forward(self, image, training, save_for_backward, outputs):
         if image.dim() != 4 or image.shape[1] != 3:
             raise ValueError("expected image [B,3,H,W]")
         N, _, H, W = image.shape
@@ -385,7 +389,7 @@ class Engine:
         if outputs is None:
             outputs = [torch.empty((N, 4, H, W), device=self.device) for _ in range(4)]
         S["dec"] = [None, None]
-        main = torch.cuda.current_stream()
+        main = ops.current_stream()
         if self.concurrent:
             self.aux.wait_event(self._record(main))                 # encoder features ready
             S["dec"] = [{}, {}]
@@ -457,8 +461,8 @@ class Engine:
                 ops.colsum(dz.view(-1, c.Cout), c.gb, accumulate=acc)
         if side is None:
             return launch()
-        side.wait_event(self._record(torch.cuda.current_stream()))
-        with torch.cuda.stream(side):
+        side.wait_event(self._record(ops.current_stream()))
+        with ops.on_stream(side):
             launch()
 
     def _wgrad_up2(self, c, low, skip, dz, N, hl, wl, C0, C1, acc, side=None):
@@ -480,8 +484,8 @@ class Engine:
                 ops.colsum(dz.view(-1, c.Cout), c.gb, accumulate=acc)
         if side is None:
             return launch()
-        side.wait_event(self._record(torch.cuda.current_stream()))
-        with torch.cuda.stream(side):
+        side.wait_event(self._record(ops.current_stream()))
+        with ops.on_stream(side):
             launch()
 
     def _dgrad_dec(self, c, dz, N, H, W, out, actsrc=None, addend=None, accum=False):
@@ -496,6 +500,10 @@ class Engine:
         return ops.conv_igemm(d, dz, None, c.wdu, ext)
 
     def backward(self, grad_outputs, accumulate=False, on_stage=None):
+        with ops.on_stream(torch.cuda.current_stream()):
+            return self._backward(grad_outputs, accumulate, on_stage)
+
+    def _backward(self, grad_outputs, accumulate, on_stage):
         """grad_outputs: 4 tensors [B,4,H,W] (d loss / d outputs['1/8','1/4','1/2','1/1']).
         Writes every live parameter gradient into self.flat_grad (views: self.grad_views).
         on_stage(name) is called as soon as all gradients of a flat-buffer stage ('mask_decoder', 'depth_decoder',
@@ -510,7 +518,7 @@ class Engine:
         buf = self.buf
         gouts = [g.contiguous() for g in grad_outputs]
         dF = [buf("dF%d" % i, tuple(f.shape)) for i, f in enumerate(feats)]
-        main = torch.cuda.current_stream()
+        main = ops.current_stream()
         if self.concurrent:
             # mask decoder on the main stream, depth decoder on the aux stream; the depth decoder ACCUMULATES into the
             # feature gradients, so each of its accumulate launches waits for the mask decoder's write of that level
@@ -610,7 +618,7 @@ class Engine:
         while jobs:
             for job in list(jobs):
                 stream, gen = job
-                with torch.cuda.stream(stream):
+                with ops.on_stream(stream):
                     try:
                         next(gen)
                     except StopIteration:
@@ -623,7 +631,7 @@ class Engine:
         pfx = "g.%s." % dec.name                    # per-decoder temporaries: the two decoders may run concurrently
         H, W = S["H"], S["W"]
         accum_feat = not first                      # the second decoder accumulates into the feature gradients
-        cur = torch.cuda.current_stream()
+        cur = ops.current_stream()
         # weight gradients go to this decoder's side stream and are only joined at the end of Engine.backward (they overlap
         # the rest of the decoder AND the encoder backward), so every dZ they read lives in its own buffer (never reused).
         side = self.dwg[0 if first else 1] if self.concurrent else None

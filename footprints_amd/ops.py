@@ -31,14 +31,53 @@ def _f32(t, name="tensor"):
     return _chk(t, name)
 
 
+_cur_stream = None      # (torch stream, raw handle) while inside on_stream(): saves ~900 torch.cuda.current_stream() calls per step
+
+
 def stream():
-    return torch.cuda.current_stream().cuda_stream
+    return _cur_stream[1] if _cur_stream is not None else torch.cuda.current_stream().cuda_stream
+
+
+class on_stream:
+    """`with torch.cuda.stream(s)` that also caches the raw handle for the launch wrappers of this module"""
+
+    def __init__(self, s):
+        self.s = s
+        self.ctx = torch.cuda.stream(s)
+
+    def __enter__(self):
+        global _cur_stream
+        self.prev = _cur_stream
+        self.ctx.__enter__()
+        _cur_stream = (self.s, self.s.cuda_stream)
+        return self.s
+
+    def __exit__(self, *exc):
+        global _cur_stream
+        _cur_stream = self.prev
+        return self.ctx.__exit__(*exc)
+
+
+def current_stream():
+    return _cur_stream[0] if _cur_stream is not None else torch.cuda.current_stream()
+
+
+_query_cache = {}
+
+
+def _cached_query(fn, desc):
+    """shape predicates / workspace sizes are pure functions of the descriptor: ask the library once per distinct shape"""
+    key = (fn, bytes(desc))
+    v = _query_cache.get(key)
+    if v is None:
+        v = _query_cache[key] = getattr(_lib.load(), fn)(C.byref(desc))
+    return v
 
 
 def workspace(nbytes, device, tag="main"):
     """Grow-only scratch buffer per (device, tag); safe because all kernels of a step are stream-ordered."""
     # one scratch buffer per (device, stream, tag): kernels on concurrent streams must not share partials
-    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream, tag)
+    key = (device.index, stream(), tag)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
@@ -61,7 +100,7 @@ def conv_igemm(desc, src0, src1, wpacked, y, bias=None, addend=None, addend_mask
         epi |= _lib.EPI_ADDEND_MASK
     d = ConvDesc.from_buffer_copy(desc)
     d.epi = epi
-    need = 0 if _NO_SPLITK else lib.fp_conv_igemm_workspace(C.byref(d))
+    need = 0 if _NO_SPLITK else _cached_query("fp_conv_igemm_workspace", d)
     ws_ptr, ws_n = 0, 0
     if need > 0:
         ws = workspace(need, y.device, "igemm")
@@ -72,7 +111,7 @@ def conv_igemm(desc, src0, src1, wpacked, y, bias=None, addend=None, addend_mask
 
 
 def conv3x3_bf3_supported(desc):
-    return bool(_lib.load().fp_conv3x3_bf3_supported(C.byref(desc)))
+    return bool(_cached_query("fp_conv3x3_bf3_supported", desc))
 
 
 def conv3x3_bf3(desc, src, wpacked_bf3, y, bias=None, addend=None, addend_mask=None, actsrc=None):
@@ -82,7 +121,7 @@ def conv3x3_bf3(desc, src, wpacked_bf3, y, bias=None, addend=None, addend_mask=N
     lib = _lib.load()
     d = ConvDesc.from_buffer_copy(desc)
     d.epi = epi
-    need = lib.fp_conv3x3_bf3_workspace(C.byref(d))
+    need = _cached_query("fp_conv3x3_bf3_workspace", d)
     ws_ptr, ws_n = 0, 0
     if need > 0:
         ws = workspace(need, y.device, "igemm")
@@ -104,7 +143,7 @@ def pack_conv_weight_bf3(w, wp, for_dgrad=False):
 
 def conv_wgrad(desc, src0, src1, dz, dw, accumulate=False):
     lib = _lib.load()
-    need = lib.fp_conv_wgrad_workspace(C.byref(desc))
+    need = _cached_query("fp_conv_wgrad_workspace", desc)
     ws = workspace(need, dz.device)
     _lib.check(lib.fp_conv_wgrad(C.byref(desc), _f32(src0), _f32(src1), _f32(dz), _f32(dw), int(bool(accumulate)),
                                  ws.data_ptr(), ws.numel(), stream()), "fp_conv_wgrad")
@@ -112,13 +151,13 @@ def conv_wgrad(desc, src0, src1, dz, dw, accumulate=False):
 
 
 def conv_wgrad_bf3_supported(desc):
-    return _lib.load().fp_conv_wgrad_bf3_workspace(C.byref(desc)) >= 0
+    return _cached_query("fp_conv_wgrad_bf3_workspace", desc) >= 0
 
 
 def conv_wgrad_bf3(desc, x, dz, dw, k_begin=0, accumulate=False):
     """3x3 stride-1 weight gradient with exactly split bf16x3 operands, into dw[:, k_begin:k_begin + C0]"""
     lib = _lib.load()
-    need = lib.fp_conv_wgrad_bf3_workspace(C.byref(desc))
+    need = _cached_query("fp_conv_wgrad_bf3_workspace", desc)
     if need < 0:
         raise RuntimeError("fp_conv_wgrad_bf3: shape not supported")
     ws = workspace(need, dz.device)

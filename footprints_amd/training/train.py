@@ -41,7 +41,8 @@ class TrainStep:
             B, _, H, W = img.shape
             self.outputs = [torch.empty((B, 4, H, W), device=eng.device) for _ in range(4)]
             self.dpreds = [torch.empty((B, 4, H, W), device=eng.device) for _ in range(4)]
-        self.model.train()
+        if not self.model.training:
+            self.model.train()
         eng.forward(img, training=True, save_for_backward=True, outputs=self.outputs)
         ops.loss_fwd_bwd(self.outputs, batch, self.losses, self.dpreds, self.depth_range, self.prior)
         # zero_grad + backward: gradients are overwritten; buckets are all-reduced as soon as they are complete
