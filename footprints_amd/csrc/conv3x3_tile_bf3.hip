@@ -201,20 +201,26 @@ __global__ void __launch_bounds__(256) conv3x3_tile_bf3_kernel(const Tile3Args a
   for (int cc = c_begin; cc < c_end; ++cc) {
     const unsigned char* Hb = lds + ((cc - c_begin) & 1) * BUF;
     const int ccn = min(cc + 1, c_end - 1);
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
+    // A fragments are read one tap ahead (two register sets): with 32-cycle MFMAs an LDS read issued right before its
+    // consumer costs ~150 cycles per 384-cycle tap
+    uint4 af[2][TM][3];
+    auto load_a = [&](int tap, uint4 (&dst)[TM][3]) {
       const int ky = tap / 3, kx = tap % 3;
       const int toff = ((FLIP ? 2 - ky : ky) * HW2 + (FLIP ? 2 - kx : kx)) * PIXB;
-      uint4 af[TM][3];
 #pragma unroll
       for (int p = 0; p < 3; ++p)
 #pragma unroll
-        for (int i = 0; i < TM; ++i) af[i][p] = *reinterpret_cast<const uint4*>(Hb + p * PLANE + abase[i] + toff);
+        for (int i = 0; i < TM; ++i) dst[i][p] = *reinterpret_cast<const uint4*>(Hb + p * PLANE + abase[i] + toff);
+    };
+    load_a(0, af[0]);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
       __builtin_amdgcn_sched_barrier(0);
+      if (tap < 8) load_a(tap + 1, af[(tap + 1) & 1]);
       if (tap < 7) load_b(tap + 2, cc, bq[(tap + 2) % 3]);
       else load_b(tap - 7, ccn, bq[(tap + 2) % 3]);
       __builtin_amdgcn_sched_barrier(0);
-      mma6(af, bq[tap % 3]);
+      mma6(af[tap & 1], bq[tap % 3]);
     }
     if (FOLD && border_tile) {
 #pragma unroll 1

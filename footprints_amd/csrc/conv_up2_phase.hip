@@ -257,15 +257,19 @@ __global__ void __launch_bounds__(256) up2_phase_fwd_bf3_kernel(const PhaseArgs 
   for (int cc = 0; cc < a.KC16; ++cc) {
     const unsigned char* Hb = lds + (cc & 1) * BUF3;
     const int ccn = min(cc + 1, a.KC16 - 1);
-#pragma unroll
-    for (int tap = 0; tap < 4; ++tap) {
+    uint4 af[2][TM][3];                                     // A fragments one tap ahead (see conv3x3_tile_bf3.hip)
+    auto load_a = [&](int tap, uint4 (&dst)[TM][3]) {
       const int toff = ((tap >> 1) * HW2 + (tap & 1)) * PIXB;
-      uint4 af[TM][3];
 #pragma unroll
       for (int p = 0; p < 3; ++p)
 #pragma unroll
-        for (int i = 0; i < TM; ++i) af[i][p] = *reinterpret_cast<const uint4*>(Hb + p * PLANE3 + abase[i] + toff);
+        for (int i = 0; i < TM; ++i) dst[i][p] = *reinterpret_cast<const uint4*>(Hb + p * PLANE3 + abase[i] + toff);
+    };
+    load_a(0, af[0]);
+#pragma unroll
+    for (int tap = 0; tap < 4; ++tap) {
       __builtin_amdgcn_sched_barrier(0);
+      if (tap < 3) load_a(tap + 1, af[(tap + 1) & 1]);
       if (tap < 2) load_b(tap + 2, cc, bq[tap + 2]);
       else load_b(tap - 2, ccn, bq[tap - 2]);
       __builtin_amdgcn_sched_barrier(0);
@@ -276,7 +280,7 @@ __global__ void __launch_bounds__(256) up2_phase_fwd_bf3_kernel(const PhaseArgs 
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[i][PA[q]]),
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[tap & 1][i][PA[q]]),
                                                                 __builtin_bit_cast(bf16x8_t, bq[tap][j][PB[q]]), acc[i][j], 0, 0, 0);
     }
     if (cc + 1 < a.KC16) {
