@@ -10,14 +10,17 @@ in HBM before the timed region (configs[2] of BASELINE.json; configs[1], the inf
 beside it as fwd_ms_per_img).  Weak scaling: every rank keeps batch 12.  Rank 0 prints ONE JSON line.
 
 Extra objects in the line:
-  roofline      dominant kernel family = the fp32-MFMA implicit-GEMM convolution (fp_conv_igemm: forward + data-gradient
-                launches; conv3x3_tile_kernel for large 3x3 grids, igemm_kernel otherwise).
-                achieved = sum of algorithmic FLOPs of its launches / sum of their durations, measured with HIP
-                events recorded around every launch, on the stream it is launched on, during the timed steps.
-                The timed steps run the two decoders and the weight gradients on concurrent streams, so a launch
-                shares the chip with one or two other kernels and its event-to-event duration is longer than its
-                exclusive duration; `achieved_exclusive` / `frac_exclusive` are the same quantity from extra steps
-                (outside the timed region) with concurrency switched off -- the kernel's own speed.
+  roofline      dominant kernel family = the convolution forward + data-gradient launches: fp_conv3x3_bf3 (halo-tile kernel with
+                fp32 operands split EXACTLY into three bf16 terms, six bf16 MFMA products, fp32 accumulation -- error below the
+                fp32 MFMA's own), its phase-decomposed upsample variant, and fp_conv_igemm (fp32 MFMA) for the rest.
+                achieved = sum of ALGORITHMIC FLOPs of the launches (the dense convolution of the reference graph, also where
+                the phase decomposition executes 4/9 of it) / sum of their durations, measured with HIP events recorded around
+                every launch, on the stream it is launched on, during the first timed steps.  `peak` is the native fp32 MFMA
+                peak (the dtype is f32); `peak_bf16x6` = dense bf16 peak / 6 is the split kernels' own roof.
+                The timed steps run up to five streams concurrently, so a launch shares the chip and its event-to-event
+                duration is longer than its exclusive duration; `achieved_exclusive` / `frac_exclusive` are the same quantity
+                from extra steps (outside the timed region) with concurrency switched off -- the kernels' own speed.
+  step_conv_tflops  the reference graph's conv FLOPs of one step (fwd + dgrad + wgrad) over the measured step time.
   cpu_baseline  the CPU oracle (a restatement of the reference's PyTorch CPU path, kind "port") timed on this
                 box's host cores on a bounded sample of the same workload (rank 0, N = 1 only).
 """
@@ -33,7 +36,8 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-MFMA_F32_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix peak
+MFMA_F32_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
+BF16X6_PEAK_TFLOPS = 2500.0 / 6   # dense bf16 MFMA peak / 6 products per fp32-equivalent multiply-add (the split kernels' own roof)
 B, H, W = 12, 192, 640
 
 
@@ -75,13 +79,14 @@ class KernelTimer:
     def __init__(self):
         self.records = []
 
-    def wrap(self, fn, flops_of):
-        def wrapped(desc, *a, **k):
+    def wrap(self, fn, flops_of, key_of=None, name=""):
+        def wrapped(first, *a, **k):
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
-            r = fn(desc, *a, **k)
+            r = fn(first, *a, **k)
             e.record()
-            self.records.append((s, e, flops_of(desc), desc_key(desc)))
+            key = key_of(first, *a, **k) if key_of is not None else name + " " + desc_key(first)
+            self.records.append((s, e, flops_of(first, *a, **k), key))
             return r
         return wrapped
 
@@ -110,10 +115,50 @@ def desc_key(d):
                                                       d.KH, d.stride)
 
 
-def conv_flops(d):
+def conv_flops(d, *a, **k):
     taps = 1 if d.gather == 5 else d.KH * d.KW
-    k = 147 if d.gather == 5 else d.C0 + d.C1
-    return 2.0 * d.N * d.OH * d.OW * d.Nout * taps * k
+    kk = 147 if d.gather == 5 else d.C0 + d.C1
+    return 2.0 * d.N * d.OH * d.OW * d.Nout * taps * kk
+
+
+def phase_fwd_flops(low, wphase, bias, y, *a, **k):
+    """algorithmic FLOPs of the dense 3x3 conv over the x2-upsampled tensor that the phase kernel replaces"""
+    N, h, w, C0 = low.shape
+    return 2.0 * N * (2 * h) * (2 * w) * y.shape[3] * 9 * C0
+
+
+def phase_wgrad_flops(low, dz, *a, **k):
+    N, h, w, C0 = low.shape
+    return 2.0 * N * (2 * h) * (2 * w) * dz.shape[3] * 9 * C0
+
+
+def phase_key(tag):
+    return lambda low, *a, **k: "%s N%d low %dx%d C%d" % (tag, low.shape[0], low.shape[1], low.shape[2], low.shape[3])
+
+
+# op name -> (flop function, key function): the forward + data-gradient convolution family (roofline) and the weight gradients
+FWD_DGRAD_OPS = {"conv_igemm": (conv_flops, None), "conv3x3_bf3": (conv_flops, None),
+                 "conv_up2_phase_fwd": (phase_fwd_flops, phase_key("phase_fwd")),
+                 "conv_up2_phase_fwd_bf3": (phase_fwd_flops, phase_key("phase_fwd_bf3"))}
+WGRAD_OPS = {"conv_wgrad": (conv_flops, None), "conv_wgrad_slice": (conv_flops, None), "conv_wgrad_bf3": (conv_flops, None),
+             "conv_up2_phase_wgrad": (phase_wgrad_flops, phase_key("phase_wgrad"))}
+
+
+class Instrument:
+    """swap a family of footprints_amd.ops entry points for event-timed wrappers, and back"""
+
+    def __init__(self, ops, table):
+        self.ops, self.table = ops, table
+        self.orig = {n: getattr(ops, n) for n in table}
+        self.timer = KernelTimer()
+
+    def install(self):
+        for n, (ff, kf) in self.table.items():
+            setattr(self.ops, n, self.timer.wrap(self.orig[n], ff, kf, n))
+
+    def remove(self):
+        for n, f in self.orig.items():
+            setattr(self.ops, n, f)
 
 
 def _pick_threads():
@@ -196,37 +241,42 @@ def main():
 
     for _ in range(args.warmup):
         step(batch)
-    timer = wtimer = None
-    orig, orig_w = ops.conv_igemm, ops.conv_wgrad
+    inst = winst = None
     if rank == 0 and not args.no_kernel_events:
-        timer = KernelTimer()
-        ops.conv_igemm = timer.wrap(orig, conv_flops)
+        inst = Instrument(ops, FWD_DGRAD_OPS)
+        inst.install()
         if args.dump_kernels:
-            wtimer = KernelTimer()
-            ops.conv_wgrad = wtimer.wrap(orig_w, conv_flops)
-    timed = (ops.conv_igemm, ops.conv_wgrad)
+            winst = Instrument(ops, WGRAD_OPS)
+            winst.install()
     ev_steps = min(args.steps, 4)          # event brackets on the first steps of the timed region only (host cost of
     barrier()                              # ~300 event records per step would otherwise perturb `value`)
     t0 = time.perf_counter()
     for i in range(args.steps):
         if i == ev_steps:
-            ops.conv_igemm, ops.conv_wgrad = orig, orig_w
+            for x in (inst, winst):
+                if x is not None:
+                    x.remove()
         step(batch)
     barrier()
     dt = time.perf_counter() - t0
-    ops.conv_igemm, ops.conv_wgrad = orig, orig_w
+    for x in (inst, winst):
+        if x is not None:
+            x.remove()
+    timer = inst.timer if inst is not None else None
+    wtimer = winst.timer if winst is not None else None
     # kernel-exclusive pass (outside the timed region): same steps, one stream, so launches do not overlap
     xtimer = None
     if timer is not None and step.eng.concurrent:
         step.eng.concurrent = False
         step(batch)
-        xtimer = KernelTimer()
-        ops.conv_igemm = xtimer.wrap(orig, conv_flops)
+        xinst = Instrument(ops, FWD_DGRAD_OPS)
+        xinst.install()
         torch.cuda.synchronize()
         for _ in range(min(3, args.steps)):
             step(batch)
         torch.cuda.synchronize()
-        ops.conv_igemm = orig
+        xinst.remove()
+        xtimer = xinst.timer
         step.eng.concurrent = True
     t = torch.tensor([dt], device="cuda", dtype=torch.float64)
     if distributed:
@@ -251,6 +301,8 @@ def main():
         out = {"metric": "training images/sec at 192x640 bs=12", "value": round(world * B * args.steps / dt, 2), "unit": "img/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "arithmetic": "fp32 tensors and accumulation; 3x3 stride-1 convs (fwd, dgrad, wgrad) multiply exactly split operands "
+                             "(x = h + m + l in bf16, 6 of 9 bf16 MFMA products: error <= fp32 MFMA); remaining convs native fp32 MFMA",
                "config": {"workload": "KITTI 192x640 bs=12 full train step (fwd+loss+bwd+Adam), random-init weights, synthetic RGB + masks",
                           "per_gpu_batch": B, "global_batch": B * world, "height": H, "width": W,
                           "parallelism": "dp%d" % world if world > 1 else "single"},
@@ -266,7 +318,10 @@ def main():
             ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
-                               "kernel": "fp_conv_igemm: conv3x3_tile_kernel / igemm_kernel (implicit-GEMM conv fwd + dgrad, v_mfma_f32_32x32x2_f32)",
+                               "peak_bf16x6": BF16X6_PEAK_TFLOPS, "frac_bf16x6": round(ach / BF16X6_PEAK_TFLOPS, 4),
+                               "kernel": "convolution forward + data-gradient launches: fp_conv3x3_bf3 (conv3x3_tile_bf3_kernel: fp32 operands split "
+                                         "exactly into 3 bf16 terms, 6 v_mfma_f32_32x32x16_bf16 products, fp32 accumulate), fp_conv_up2_phase_fwd_bf3, "
+                                         "fp_conv_igemm (igemm_kernel, v_mfma_f32_32x32x2_f32: stride 2, 1x1, 4x4/2 phase dgrad, stem)",
                                "launches_per_step": n // max(ev_steps, 1), "avg_launch_us": round(ms / max(n, 1) * 1e3, 2),
                                "algorithmic_gflop_per_launch": round(fl / max(n, 1) / 1e9, 3),
                                "kernel_ms_per_step": round(ms / max(ev_steps, 1), 3), "event_steps": ev_steps,
@@ -275,6 +330,7 @@ def main():
                 xn, xms, xfl = xtimer.summary()
                 xach = xfl / (xms * 1e-3) / 1e12 if xms > 0 else 0.0
                 out["roofline"].update({"achieved_exclusive": round(xach, 2), "frac_exclusive": round(xach / MFMA_F32_PEAK_TFLOPS, 4),
+                                        "frac_exclusive_bf16x6": round(xach / BF16X6_PEAK_TFLOPS, 4),
                                         "avg_launch_us_exclusive": round(xms / max(xn, 1) * 1e3, 2)})
         if args.dump_kernels and timer is not None:
             with open(args.dump_kernels, "w") as fh:
