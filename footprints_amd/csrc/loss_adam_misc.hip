@@ -301,6 +301,50 @@ extern "C" int fp_adam_step(float* param, const float* grad, float* exp_avg, flo
   return fp_check_launch("fp_adam_step");
 }
 
+// Same update with the seven per-step scalars read from device memory (hipGraph replay: the launch arguments are frozen at
+// capture time, the scalars are refreshed by a small host-to-device copy before every replay).
+__global__ void __launch_bounds__(256) adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                       float* __restrict__ v, size_t n, const float* __restrict__ hyper) {
+  const float one_minus_b1 = hyper[0], b2 = hyper[1], one_minus_b2 = hyper[2], step_size = hyper[3], inv_bc2_sqrt = hyper[4],
+              eps = hyper[5], gscale = hyper[6];
+  const size_t n4 = n >> 2;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n4; e += (size_t)gridDim.x * 256) {
+    float4 P = reinterpret_cast<float4*>(p)[e], G = reinterpret_cast<const float4*>(g)[e];
+    float4 Mv = reinterpret_cast<float4*>(m)[e], V = reinterpret_cast<float4*>(v)[e];
+    float* pp = &P.x; float* gg = &G.x; float* mm = &Mv.x; float* vv = &V.x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float gr = gg[j] * gscale;
+      mm[j] = mm[j] + (gr - mm[j]) * one_minus_b1;
+      vv[j] = vv[j] * b2 + one_minus_b2 * gr * gr;
+      const float denom = sqrtf(vv[j]) * inv_bc2_sqrt + eps;
+      pp[j] = pp[j] - step_size * (mm[j] / denom);
+    }
+    reinterpret_cast<float4*>(p)[e] = P;
+    reinterpret_cast<float4*>(m)[e] = Mv;
+    reinterpret_cast<float4*>(v)[e] = V;
+  }
+}
+
+// host side of the above: the seven floats fp_adam_step would pass to its kernel for this step
+extern "C" int fp_adam_hyper(double lr, double beta1, double beta2, double eps, int32_t step, double grad_scale, float* hyper7_host) {
+  FP_REQUIRE(hyper7_host && step >= 1, "fp_adam_hyper: bad arguments");
+  const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+  hyper7_host[0] = (float)(1.0 - beta1); hyper7_host[1] = (float)beta2; hyper7_host[2] = (float)(1.0 - beta2);
+  hyper7_host[3] = (float)(lr / bc1); hyper7_host[4] = (float)(1.0 / sqrt(bc2)); hyper7_host[5] = (float)eps;
+  hyper7_host[6] = (float)grad_scale;
+  return FP_OK;
+}
+
+extern "C" int fp_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, const float* hyper7_dev,
+                                fp_stream_t stream) {
+  FP_REQUIRE(param && grad && exp_avg && exp_avg_sq && hyper7_dev && n > 0 && n % 4 == 0, "fp_adam_step_dev: bad arguments");
+  FP_REQUIRE(((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) % 16 == 0, "fp_adam_step_dev: buffers must be 16-byte aligned");
+  hipLaunchKernelGGL(adam_dev_kernel, dim3(ew_grid((size_t)n / 4 + 1, 4096)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
+                     exp_avg_sq, (size_t)n, hyper7_dev);
+  return fp_check_launch("fp_adam_step_dev");
+}
+
 extern "C" int64_t fp_colsum_workspace(int64_t M, int32_t C) {
   if (C < 4 || C % 4 || C > 1024) return 0;
   return (int64_t)colsum_blocks(M, C) * C * (int64_t)sizeof(float);

@@ -398,6 +398,18 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, gra
                                         int(step), grad_scale, stream()), "fp_adam_step")
 
 
+def adam_hyper(lr, beta1, beta2, eps, step, grad_scale=1.0):
+    """the seven float scalars of one Adam step (host tensor), derived exactly like fp_adam_step does"""
+    h = torch.empty(7, dtype=torch.float32)
+    _lib.check(_lib.load().fp_adam_hyper(lr, beta1, beta2, eps, int(step), grad_scale, h.data_ptr()), "fp_adam_hyper")
+    return h
+
+
+def adam_step_dev(param, grad, exp_avg, exp_avg_sq, hyper_dev):
+    _lib.check(_lib.load().fp_adam_step_dev(_f32(param), _f32(grad), _f32(exp_avg), _f32(exp_avg_sq), param.numel(), _f32(hyper_dev),
+                                            stream()), "fp_adam_step_dev")
+
+
 def nchw_to_nhwc(x, y=None):
     N, Cn, H, W = x.shape
     if y is None:

@@ -55,6 +55,19 @@ class FusedAdam(torch.optim.Optimizer):
                       self.grad_scale)
         eng.weights_dirty = True
 
+    # ---- graph replay: launch with device-resident scalars, refreshed by the host before each replay ----------
+    def graph_step(self, eng, hyper_dev):
+        """captured once by TrainStep: the update with its scalars read from `hyper_dev`"""
+        m, v = self._buffers(eng)
+        ops.adam_step_dev(eng.flat_param, eng.flat_grad, m, v, hyper_dev)
+        eng.weights_dirty = True
+
+    def next_hyper(self):
+        """advance the step counter and return the host scalars of that step (same values fused_step would use)"""
+        g = self.param_groups[0]
+        self._step += 1
+        return ops.adam_hyper(g["lr"], g["betas"][0], g["betas"][1], g["eps"], self._step, self.grad_scale)
+
     # ---- torch.optim.Adam-compatible checkpoint format ---------------------------------------------------
     def state_dict(self):
         sd = super().state_dict()

@@ -7,6 +7,7 @@ buffers (no autograd graph, no per-step allocation, one D2H copy of the 21 losse
 `TrainManager` keeps the reference's loop structure (step counter, 100-step console line, epoch-end
 checkpoint + StepLR) around it for synthetic or user-provided loaders.
 """
+import os
 import time
 
 import torch
@@ -20,9 +21,25 @@ from .losses import LOSS_KEYS, SCALES, TARGET_KEYS
 SEED = 10   # train.py:33
 
 
+_GRAPH = bool(int(os.environ.get("FP_GRAPH", "0")))     # hipGraph replay of the whole step (single-GPU TrainStep); opt-in, see below
+
+
 class TrainStep:
-    def __init__(self, model, optimiser, depth_range=(0.1, 100.0), footprint_prior=0.25, distributed=False):
+    """One full training step (forward + fused loss + backward + Adam) on static buffers, no autograd graph.
+
+    graph=True (or FP_GRAPH=1; single-GPU only): after two eager steps the whole step -- ~770 launches on five streams -- is
+    captured once into a hipGraph and replayed; the batch is copied into static input buffers and the seven Adam scalars of the
+    step are uploaded before each replay, so results are bit-identical to eager (tested).  It is OFF by default: measured on
+    ROCm 7.2 / MI355X the replay costs the host as much as the eager launches (16.4 vs 14.9 ms per step), does not shorten the
+    dependent-launch gaps (one stream: 497 img/s both ways) and runs the forked streams with less overlap (509 vs 578 img/s)."""
+
+    def __init__(self, model, optimiser, depth_range=(0.1, 100.0), footprint_prior=0.25, distributed=False, graph=None):
         self.model, self.optimiser = model, optimiser
+        self.use_graph = (_GRAPH and not distributed) if graph is None else bool(graph)
+        self._graph = None
+        self._eager_steps = 0
+        self._static = None
+        self._hyper = None
         self.depth_range, self.prior = depth_range, footprint_prior
         self.eng = model.engine()
         self.losses = torch.zeros(21, device=self.eng.device)
@@ -35,6 +52,35 @@ class TrainStep:
 
     def __call__(self, batch):
         """batch: dict with the reference schema (image [B,3,H,W] + six [B,H,W] label maps), already on the GPU."""
+        if not self.use_graph:
+            return self._eager(batch, None)
+        if self._graph is not None and all(batch[k].shape == v.shape for k, v in self._static.items()):
+            for k, v in self._static.items():
+                if batch[k].data_ptr() != v.data_ptr():
+                    v.copy_(batch[k], non_blocking=True)
+            self._hyper.copy_(self.optimiser.next_hyper(), non_blocking=True)
+            self._graph.replay()
+            self.eng.weights_dirty = True                           # for eager forwards (evaluation) between replays
+            return self.losses
+        if self._graph is not None:                                 # new batch shape: start over
+            self._graph, self._eager_steps = None, 0
+        if self._eager_steps < 2:                                   # warm-up: arena / workspace allocations, packing tables
+            self._eager_steps += 1
+            return self._eager(batch, None)
+        # capture: same schedule, Adam scalars from device memory
+        self._static = {k: v.clone() for k, v in batch.items() if torch.is_tensor(v)}
+        self._hyper = torch.zeros(7, device=self.eng.device)
+        self._hyper.copy_(self.optimiser.next_hyper())
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._eager(self._static, self._hyper)
+        self._graph = g
+        g.replay()                                                  # capture does not execute: run the step it recorded
+        self.eng.weights_dirty = True
+        return self.losses
+
+    def _eager(self, batch, hyper_dev):
         eng = self.eng
         img = batch["image"]
         if self.outputs is None or self.outputs[0].shape[0] != img.shape[0] or self.outputs[0].shape[2:] != img.shape[2:]:
@@ -49,7 +95,10 @@ class TrainStep:
         eng.backward(self.dpreds, accumulate=False, on_stage=self.reducer.stage_ready if (self.reducer is not None and self.reducer.overlap) else None)
         if self.reducer is not None:
             self.reducer.finish()
-        self.optimiser.fused_step(eng)
+        if hyper_dev is None:
+            self.optimiser.fused_step(eng)
+        else:
+            self.optimiser.graph_step(eng, hyper_dev)
         return self.losses
 
     def losses_dict(self):

@@ -249,6 +249,11 @@ int fp_loss_fwd_bwd(const float* const preds[4], const float* visible_ground, co
 /* hyper-parameters are doubles (python floats) like torch's; gradients are multiplied by grad_scale (1/world under DP) */
 int fp_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double beta1,
                  double beta2, double eps, int32_t step, double grad_scale, fp_stream_t stream);
+/* Graph-replay variant: the seven per-step scalars (fp_adam_hyper fills them on the host exactly as fp_adam_step derives
+ * them) live in device memory, so a captured launch stays valid across steps; n must be a multiple of 4. */
+int fp_adam_hyper(double lr, double beta1, double beta2, double eps, int32_t step, double grad_scale, float* hyper7_host);
+int fp_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                     const float* hyper7_dev, fp_stream_t stream);
 
 /* ---- misc ---- */
 int fp_nchw_to_nhwc(const float* x, float* y, int32_t N, int32_t C, int32_t H, int32_t W, fp_stream_t stream);

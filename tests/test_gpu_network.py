@@ -345,3 +345,25 @@ def test_full_size_properties(B, H, W):
         ref = R.footprint_network(batch["image"][:1].cpu(), P, OrderedDict((k, v.clone()) for k, v in Bf.items()), False)
     for k in full:
         assert relerr(full[k][:1], ref[k]) <= 1e-4, k
+
+
+def test_trainstep_graph_replay_is_bit_identical_to_eager():
+    """opt-in hipGraph replay of the whole step (TrainStep(graph=True)): same losses and weights as the eager schedule"""
+    from footprints_amd.model_manager import ModelManager
+    from footprints_amd.training.train import TrainStep, synthetic_batch
+    from oracle import restatement as R
+    P, Bf = R.make_state(tag="gr")
+    batch = synthetic_batch(2, 96, 128, "cuda")
+    res = []
+    for graph in (False, True):
+        mm = ModelManager()
+        _load_state(mm.model, P, Bf)
+        ts = TrainStep(mm.model, mm.optimiser, graph=graph)
+        losses = [ts(batch).clone() for _ in range(5)]           # graph mode: 2 eager + capture + 2 replays
+        res.append((losses, [v.clone() for v in mm.model.state_dict().values()]))
+        if graph:
+            assert ts._graph is not None
+    for a, b in zip(res[0][0], res[1][0]):
+        assert torch.equal(a, b)
+    for a, b in zip(res[0][1], res[1][1]):
+        assert torch.equal(a, b)
