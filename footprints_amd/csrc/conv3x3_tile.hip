@@ -68,7 +68,7 @@ __device__ __forceinline__ float tile_epilogue(const TileArgs& a, size_t o, int 
     v *= (sv > 0.f ? 1.f : sv + 1.f);
   }
   if (a.epi & FP_EPI_ACTGRAD_RELU) v = a.actsrc[o] > 0.f ? v : 0.f;
-  if (a.act == FP_ACT_ELU) v = v > 0.f ? v : expm1f(v);
+  if (a.act == FP_ACT_ELU) v = fp_elu(v);
   if (a.act == FP_ACT_RELU) v = fmaxf(v, 0.f);
   if (a.epi & FP_EPI_ACCUM) v += a.y[o];
   return v;

@@ -58,13 +58,25 @@ __device__ __forceinline__ float tile3_epilogue(const Tile3Args& a, size_t o, in
     v *= (sv > 0.f ? 1.f : sv + 1.f);
   }
   if (a.epi & FP_EPI_ACTGRAD_RELU) v = a.actsrc[o] > 0.f ? v : 0.f;
-  if (a.act == FP_ACT_ELU) v = v > 0.f ? v : expm1f(v);
+  if (a.act == FP_ACT_ELU) v = fp_elu(v);
   if (a.act == FP_ACT_RELU) v = fmaxf(v, 0.f);
   if (a.epi & FP_EPI_ACCUM) v += a.y[o];
   return v;
 }
 
 constexpr int PIXB = 48;   // bytes per halo pixel per plane (16 bf16 + 8 pad)
+
+// MFMA row -> tile pixel.  ds_read_b128 is serviced in four fixed 16-lane groups (lanes {0-3,12-15,20-27}, ...), conflict-free
+// when the 16 lanes hit 16 distinct 16-byte slots mod 256 B.  With 48-byte pixels a lane's slot is 3 * halo_pixel mod 16; a
+// 32-row block spans two tile rows and the 18-pixel halo pitch shifts the second row by 6 slots, which collides inside the
+// groups (SQ_LDS_BANK_CONFLICT was half of all LDS cycles).  Rotating the columns of odd tile rows by two pixels cancels the
+// shift: slot = 3 * (row & 15) for every lane.  (16-wide tiles only; the mapping is private to this kernel.)
+template <int TW>
+__device__ __forceinline__ void fp_tile_pixel(int pt, int& py, int& px) {
+  py = pt / TW;
+  px = pt - py * TW;
+  if (TW == 16) px = (px - 2 * (py & 1)) & 15;
+}
 
 template <int TH, int TW, int BN, int WM, int WN, bool FLIP, bool FOLD>
 __global__ void __launch_bounds__(256) conv3x3_tile_bf3_kernel(const Tile3Args a) {
@@ -152,7 +164,9 @@ __global__ void __launch_bounds__(256) conv3x3_tile_bf3_kernel(const Tile3Args a
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int pt = min((wm * TM + i) * 32 + idx, NPIX - 1);
-    abase[i] = ((pt / TW) * HW2 + (pt % TW)) * PIXB + h * 16;
+    int py, px;
+    fp_tile_pixel<TW>(pt, py, px);
+    abase[i] = (py * HW2 + px) * PIXB + h * 16;
   }
 
   const bool has_r1 = y0 <= 1 && 1 < y0 + TH, has_rH = y0 <= a.OH - 2 && a.OH - 2 < y0 + TH;
@@ -162,7 +176,9 @@ __global__ void __launch_bounds__(256) conv3x3_tile_bf3_kernel(const Tile3Args a
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int pt = min((wm * TM + i) * 32 + idx, NPIX - 1);
-    const int yy = y0 + pt / TW, xx = x0 + pt % TW;
+    int py, px;
+    fp_tile_pixel<TW>(pt, py, px);
+    const int yy = y0 + py, xx = x0 + px;
     m_r1[i] = yy == 1 ? ~0u : 0u;
     m_rH[i] = yy == a.OH - 2 ? ~0u : 0u;
     m_c1[i] = xx == 1 ? ~0u : 0u;
@@ -254,20 +270,61 @@ __global__ void __launch_bounds__(256) conv3x3_tile_bf3_kernel(const Tile3Args a
     }
   }
 
+  // ---- epilogue.  The flag tests are hoisted and every optional operand (addend, its mask, the activation source, the old
+  // output) is loaded for all 16 rows BEFORE any arithmetic: element-at-a-time code serialised 16 dependent load latencies per
+  // 32x32 block (and reloaded the bias 16 times), which had become 10-30 % of the kernel once the MFMA phase shrank.
+  const unsigned epi = a.SK > 1 ? 0u : a.epi;
+  const int act = a.SK > 1 ? 0 : a.act;
+  float* const dst = a.SK > 1 ? a.part + (size_t)split * a.N * a.OH * a.OW * a.Nout : a.y;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int n = n0 + (wn * TN + j) * 32 + idx;
       if (n >= a.Nout) continue;
+      const float bias = (epi & FP_EPI_BIAS) ? a.bias[n] : 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int pt = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        const int oy = y0 + pt / TW, ox = x0 + pt % TW;
-        if (pt >= NPIX || oy >= a.OH || ox >= a.OW) continue;
-        const size_t o = ((size_t)(n_img * a.OH + oy) * a.OW + ox) * a.Nout + n;
-        if (a.SK > 1) a.part[(size_t)split * a.N * a.OH * a.OW * a.Nout + o] = acc[i][j][r];
-        else a.y[o] = tile3_epilogue(a, o, n, acc[i][j][r]);
+      for (int half = 0; half < 2; ++half) {                 // eight rows at a time (register budget)
+        int off[8];                                          // element offsets (the launcher checks the tensor is < 2^31 elements)
+        bool ok[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int r = half * 8 + k;
+          const int pt = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          int py, px;
+          fp_tile_pixel<TW>(pt, py, px);
+          const int oy = y0 + py, ox = x0 + px;
+          ok[k] = pt < NPIX && oy < a.OH && ox < a.OW;
+          off[k] = ((n_img * a.OH + min(oy, a.OH - 1)) * a.OW + min(ox, a.OW - 1)) * a.Nout + n;   // clamped: always loadable
+        }
+        float ad[8], mk[8], sv[8], yo[8];
+        if (epi & FP_EPI_ADDEND) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) ad[k] = a.addend[off[k]];
+        }
+        if (epi & FP_EPI_ADDEND_MASK) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) mk[k] = a.addend_mask[off[k]];
+        }
+        if (epi & (FP_EPI_ACTGRAD_ELU | FP_EPI_ACTGRAD_RELU)) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) sv[k] = a.actsrc[off[k]];
+        }
+        if (epi & FP_EPI_ACCUM) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) yo[k] = a.y[off[k]];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          float v = acc[i][j][half * 8 + k] + bias;
+          if (epi & FP_EPI_ADDEND) v += (epi & FP_EPI_ADDEND_MASK) ? (mk[k] > 0.f ? ad[k] : 0.f) : ad[k];
+          if (epi & FP_EPI_ACTGRAD_ELU) v *= (sv[k] > 0.f ? 1.f : sv[k] + 1.f);
+          if (epi & FP_EPI_ACTGRAD_RELU) v = sv[k] > 0.f ? v : 0.f;
+          if (act == FP_ACT_ELU) v = fp_elu(v);
+          if (act == FP_ACT_RELU) v = fmaxf(v, 0.f);
+          if (epi & FP_EPI_ACCUM) v += yo[k];
+          if (ok[k]) dst[off[k]] = v;
+        }
       }
     }
 }
@@ -338,6 +395,7 @@ extern "C" int fp_conv3x3_bf3(const fp_conv_desc* d, const float* src, const voi
   FP_REQUIRE(!(d->epi & FP_EPI_ADDEND_MASK) || addend_mask, "fp_conv3x3_bf3: addend_mask missing");
   FP_REQUIRE(!(d->epi & (FP_EPI_ACTGRAD_ELU | FP_EPI_ACTGRAD_RELU)) || actsrc, "fp_conv3x3_bf3: actsrc missing");
   FP_REQUIRE(p.SK <= 1 || (workspace && workspace_bytes >= fp_conv3x3_bf3_workspace(d)), "fp_conv3x3_bf3: workspace too small");
+  FP_REQUIRE((int64_t)d->N * d->OH * d->OW * d->Nout < ((int64_t)1 << 31), "fp_conv3x3_bf3: output larger than 2^31 elements");
   Tile3Args a;
   a.src = src; a.w = (const unsigned short*)wpacked_bf3; a.bias = bias; a.addend = addend; a.addend_mask = addend_mask; a.actsrc = actsrc;
   a.y = y;

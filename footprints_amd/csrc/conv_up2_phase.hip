@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(256) up2_phase_fwd_kernel(const PhaseArgs a) {
         const size_t o = ((size_t)(n_img * OH + 2 * ly + dy) * OW + 2 * lx + dx) * a.Nout + n;
         float v = acc[i][j][0][r] + acc[i][j][1][r] + bias;
         if (a.epi & FP_EPI_ADDEND) v += a.addend[o];
-        if (a.act == FP_ACT_ELU) v = v > 0.f ? v : expm1f(v);
+        if (a.act == FP_ACT_ELU) v = fp_elu(v);
         a.y[o] = v;
       }
     }
@@ -305,7 +305,7 @@ __global__ void __launch_bounds__(256) up2_phase_fwd_bf3_kernel(const PhaseArgs 
         const size_t o = ((size_t)(n_img * OH + 2 * ly + dy) * OW + 2 * lx + dx) * a.Nout + n;
         float v = acc[i][j][r] + bias;
         if (a.epi & FP_EPI_ADDEND) v += a.addend[o];
-        if (a.act == FP_ACT_ELU) v = v > 0.f ? v : expm1f(v);
+        if (a.act == FP_ACT_ELU) v = fp_elu(v);
         a.y[o] = v;
       }
     }

@@ -114,6 +114,16 @@ __device__ __forceinline__ float fp_stem_load(const FpGeom& g, const float* __re
   return (x - 0.45f) / 0.225f;
 }
 
+// ---- ELU (alpha = 1) for the conv epilogues ---------------------------------------------------------------
+// expm1f (ocml) is ~40 instructions and made the epilogue 10-20 % of the bf16x3 conv kernels.  For -0.25 < v <= 0 a degree-7
+// Taylor polynomial (relative error < 2e-9); below that e^v - 1 has no cancellation and the hardware exponential is accurate to
+// ~1e-7 absolute (argument rounding + 1 ulp), i.e. < 5e-7 of the result.  Same value is stored and later used for ELU'.
+__device__ __forceinline__ float fp_elu(float v) {
+  if (v > 0.f) return v;
+  const float p = v * (1.f + v * (0.5f + v * (1.f / 6.f + v * (1.f / 24.f + v * (1.f / 120.f + v * (1.f / 720.f + v * (1.f / 5040.f)))))));
+  return v > -0.25f ? p : __expf(v) - 1.f;
+}
+
 // ---- wave / block reductions (wave = 64) ---------------------------------------------------------------
 __device__ __forceinline__ float fp_wave_sum(float v) {
 #pragma unroll
