@@ -194,19 +194,57 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmArgs a) {
   }
 
   // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
+  // flag tests hoisted, optional operands of eight rows loaded before any arithmetic (element-at-a-time code serialises the
+  // load latencies; see conv3x3_tile_bf3.hip)
+  const unsigned epi = a.SK > 1 ? 0u : a.epi;
+  const int act = a.SK > 1 ? 0 : a.act;
+  float* const dst = a.SK > 1 ? a.part + (size_t)split * a.M * a.Nout : a.y;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int n = n0 + (wn * TN + j) * 32 + idx;
       if (n >= a.Nout) continue;
+      const float bias = (epi & FP_EPI_BIAS) ? a.bias[n] : 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (m >= a.M) continue;
-        const size_t o = (size_t)m * a.Nout + n;
-        if (a.SK > 1) a.part[(size_t)split * a.M * a.Nout + o] = acc[i][j][r];
-        else a.y[o] = igemm_epilogue(a, o, n, acc[i][j][r]);
+      for (int half = 0; half < 2; ++half) {
+        size_t off[8];
+        bool ok[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int r = half * 8 + k;
+          const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          ok[k] = m < a.M;
+          off[k] = (size_t)min(m, a.M - 1) * a.Nout + n;
+        }
+        float ad[8], mk[8], sv[8], yo[8];
+        if (epi & FP_EPI_ADDEND) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) ad[k] = a.addend[off[k]];
+        }
+        if (epi & FP_EPI_ADDEND_MASK) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) mk[k] = a.addend_mask[off[k]];
+        }
+        if (epi & (FP_EPI_ACTGRAD_ELU | FP_EPI_ACTGRAD_RELU)) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) sv[k] = a.actsrc[off[k]];
+        }
+        if (epi & FP_EPI_ACCUM) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) yo[k] = a.y[off[k]];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          float v = acc[i][j][half * 8 + k] + bias;
+          if (epi & FP_EPI_ADDEND) v += (epi & FP_EPI_ADDEND_MASK) ? (mk[k] > 0.f ? ad[k] : 0.f) : ad[k];
+          if (epi & FP_EPI_ACTGRAD_ELU) v *= (sv[k] > 0.f ? 1.f : sv[k] + 1.f);
+          if (epi & FP_EPI_ACTGRAD_RELU) v = sv[k] > 0.f ? v : 0.f;
+          if (act == FP_ACT_ELU) v = fp_elu(v);
+          if (act == FP_ACT_RELU) v = fmaxf(v, 0.f);
+          if (epi & FP_EPI_ACCUM) v += yo[k];
+          if (ok[k]) dst[off[k]] = v;
+        }
       }
     }
 }

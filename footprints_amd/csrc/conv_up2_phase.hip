@@ -297,16 +297,27 @@ __global__ void __launch_bounds__(256) up2_phase_fwd_bf3_kernel(const PhaseArgs 
       const int n = n0 + (wn * TN + j) * 32 + idx;
       if (n >= a.Nout) continue;
       const float bias = (a.epi & FP_EPI_BIAS) ? a.bias[n] : 0.f;
+      // addend loads of all 16 rows first, then the arithmetic and the stores (see conv3x3_tile_bf3.hip)
+      int off[16];
+      bool ok[16];
+      float ad[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int pt = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         const int ly = y0 + pt / TW, lx = x0 + pt % TW;
-        if (ly >= a.h || lx >= a.w_) continue;
-        const size_t o = ((size_t)(n_img * OH + 2 * ly + dy) * OW + 2 * lx + dx) * a.Nout + n;
+        ok[r] = ly < a.h && lx < a.w_;
+        off[r] = ((n_img * OH + 2 * min(ly, a.h - 1) + dy) * OW + 2 * min(lx, a.w_ - 1) + dx) * a.Nout + n;
+      }
+      if (a.epi & FP_EPI_ADDEND) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ad[r] = a.addend[off[r]];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
         float v = acc[i][j][r] + bias;
-        if (a.epi & FP_EPI_ADDEND) v += a.addend[o];
+        if (a.epi & FP_EPI_ADDEND) v += ad[r];
         if (a.act == FP_ACT_ELU) v = fp_elu(v);
-        a.y[o] = v;
+        if (ok[r]) a.y[off[r]] = v;
       }
     }
 }
@@ -387,6 +398,7 @@ extern "C" int fp_conv_up2_phase_fwd_bf3(const float* low, const void* wphase_bf
                                          int32_t N, int32_t h, int32_t w, int32_t C0, int32_t Nout, int32_t act, fp_stream_t stream) {
   FP_REQUIRE(low && wphase_bf3 && y && N > 0 && h >= 1 && w >= 1 && C0 > 0 && C0 % 4 == 0 && Nout > 0,
              "fp_conv_up2_phase_fwd_bf3: bad arguments");
+  FP_REQUIRE((int64_t)N * 4 * h * w * Nout < ((int64_t)1 << 31), "fp_conv_up2_phase_fwd_bf3: output larger than 2^31 elements");
   PhaseArgs a;
   a.low = low; a.w = (const float*)wphase_bf3; a.bias = bias; a.addend = addend; a.y = y;
   a.N = N; a.h = h; a.w_ = w; a.C0 = C0; a.Nout = Nout; a.KC16 = (C0 + 15) / 16; a.act = act;
