@@ -318,6 +318,8 @@ def main():
             ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                               "traffic_note": "PMC FETCH_SIZE x2 / WRITE_SIZE per launch = 1.0-1.04x the algorithmic input / output bytes "
+                                               "(profiles/round1_pmc_hbm_conv_bf3.txt; collected with rocprofv3 --pmc, not inside bench.py)",
                                "peak_bf16x6": BF16X6_PEAK_TFLOPS, "frac_bf16x6": round(ach / BF16X6_PEAK_TFLOPS, 4),
                                "kernel": "convolution forward + data-gradient launches: fp_conv3x3_bf3 (conv3x3_tile_bf3_kernel: fp32 operands split "
                                          "exactly into 3 bf16 terms, 6 v_mfma_f32_32x32x16_bf16 products, fp32 accumulate), fp_conv_up2_phase_fwd_bf3, "
