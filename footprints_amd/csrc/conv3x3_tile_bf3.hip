@@ -12,6 +12,8 @@
 //   * the halo is converted on its way into LDS: three bf16 planes [plane][pixel][16 ch + 8 pad] (48-byte pixel rows: the
 //     per-lane 16-byte A fragment "pixel = lane & 31, k-group = lane >> 5" is a conflict-free ds_read_b128);
 //   * weights are packed [tap][chunk][plane][n][16] bf16 (pack.hip, FP_PACK_*_BF3): a wave's B fragment of one plane is 1 KB contiguous.
+#include <type_traits>
+
 #include "fp_common.h"
 
 int fp_splitk_reduce_launch(const float* part, int SK, int64_t M, int Nout, const float* bias, const float* addend, const float* addend_mask,
@@ -208,9 +210,9 @@ __global__ void __launch_bounds__(256) conv3x3_tile_bf3_kernel(const Tile3Args a
 
   const int c_begin = split * a.chunksPerSplit, c_end = min(a.KC16, c_begin + a.chunksPerSplit);
   load_halo(c_begin);
-  store_halo(0);
-  load_b(0, c_begin, bq[0]);
+  load_b(0, c_begin, bq[0]);                 // issued before the halo is consumed: one exposed load latency in the prologue, not two
   load_b(1, c_begin, bq[1]);
+  store_halo(0);
   load_halo(min(c_begin + 1, c_end - 1));
   __syncthreads();
 
@@ -271,11 +273,85 @@ __global__ void __launch_bounds__(256) conv3x3_tile_bf3_kernel(const Tile3Args a
   }
 
   // ---- epilogue.  The flag tests are hoisted and every optional operand (addend, its mask, the activation source, the old
-  // output) is loaded for all 16 rows BEFORE any arithmetic: element-at-a-time code serialised 16 dependent load latencies per
-  // 32x32 block (and reloaded the bias 16 times), which had become 10-30 % of the kernel once the MFMA phase shrank.
+  // output) is loaded for eight rows BEFORE any arithmetic: element-at-a-time code serialised 16 dependent load latencies per
+  // 32x32 block (and reloaded the bias 16 times).  Tiles that lie completely inside the image (all but the last row / column of
+  // tiles) take a path without per-element bounds predication; for 16-wide tiles the row -> pixel map folds to constants.
   const unsigned epi = a.SK > 1 ? 0u : a.epi;
   const int act = a.SK > 1 ? 0 : a.act;
   float* const dst = a.SK > 1 ? a.part + (size_t)split * a.N * a.OH * a.OW * a.Nout : a.y;
+  const bool interior = NPIX == 128 && y0 + TH <= a.OH && x0 + TW <= a.OW;
+  auto rows8 = [&](auto full_tag, int i, int j, int n, float bias, int half) {
+    constexpr bool FULL = decltype(full_tag)::value;
+    int off[8];
+    bool ok[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int r = half * 8 + k;
+      int py, px;
+      if (TW == 16) {            // pt = blk*32 + (r&3) + 8*(r>>2) + 4h  =>  row = 2*blk + (r>>3), column from constants and h
+        py = 2 * (wm * TM + i) + (r >> 3);
+        px = ((r & 3) + 8 * ((r >> 2) & 1) + 4 * h - 2 * ((r >> 3) & 1)) & 15;
+      } else {
+        fp_tile_pixel<TW>((wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, py, px);
+      }
+      const int oy = y0 + py, ox = x0 + px;
+      ok[k] = FULL || ((wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h < NPIX && oy < a.OH && ox < a.OW);
+      off[k] = ((n_img * a.OH + (FULL ? oy : min(oy, a.OH - 1))) * a.OW + (FULL ? ox : min(ox, a.OW - 1))) * a.Nout + n;
+    }
+    float ad[8], mk[8], sv[8], yo[8];
+    if (epi & FP_EPI_ADDEND) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) ad[k] = a.addend[off[k]];
+    }
+    if (epi & FP_EPI_ADDEND_MASK) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) mk[k] = a.addend_mask[off[k]];
+    }
+    if (epi & (FP_EPI_ACTGRAD_ELU | FP_EPI_ACTGRAD_RELU)) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) sv[k] = a.actsrc[off[k]];
+    }
+    if (epi & FP_EPI_ACCUM) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) yo[k] = a.y[off[k]];
+    }
+    // one wave-uniform branch per flag around an 8-element body (per-element tests get if-converted into selects that execute
+    // every option for every element)
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = acc[i][j][half * 8 + k] + bias;
+    if (epi & FP_EPI_ADDEND) {
+      if (epi & FP_EPI_ADDEND_MASK) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] += mk[k] > 0.f ? ad[k] : 0.f;
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] += ad[k];
+      }
+    }
+    if (epi & FP_EPI_ACTGRAD_ELU) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] *= (sv[k] > 0.f ? 1.f : sv[k] + 1.f);
+    }
+    if (epi & FP_EPI_ACTGRAD_RELU) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = sv[k] > 0.f ? v[k] : 0.f;
+    }
+    if (act == FP_ACT_ELU) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = fp_elu(v[k]);
+    } else if (act == FP_ACT_RELU) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+    }
+    if (epi & FP_EPI_ACCUM) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] += yo[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (FULL || ok[k]) dst[off[k]] = v[k];
+  };
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -283,48 +359,12 @@ __global__ void __launch_bounds__(256) conv3x3_tile_bf3_kernel(const Tile3Args a
       const int n = n0 + (wn * TN + j) * 32 + idx;
       if (n >= a.Nout) continue;
       const float bias = (epi & FP_EPI_BIAS) ? a.bias[n] : 0.f;
-#pragma unroll
-      for (int half = 0; half < 2; ++half) {                 // eight rows at a time (register budget)
-        int off[8];                                          // element offsets (the launcher checks the tensor is < 2^31 elements)
-        bool ok[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const int r = half * 8 + k;
-          const int pt = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          int py, px;
-          fp_tile_pixel<TW>(pt, py, px);
-          const int oy = y0 + py, ox = x0 + px;
-          ok[k] = pt < NPIX && oy < a.OH && ox < a.OW;
-          off[k] = ((n_img * a.OH + min(oy, a.OH - 1)) * a.OW + min(ox, a.OW - 1)) * a.Nout + n;   // clamped: always loadable
-        }
-        float ad[8], mk[8], sv[8], yo[8];
-        if (epi & FP_EPI_ADDEND) {
-#pragma unroll
-          for (int k = 0; k < 8; ++k) ad[k] = a.addend[off[k]];
-        }
-        if (epi & FP_EPI_ADDEND_MASK) {
-#pragma unroll
-          for (int k = 0; k < 8; ++k) mk[k] = a.addend_mask[off[k]];
-        }
-        if (epi & (FP_EPI_ACTGRAD_ELU | FP_EPI_ACTGRAD_RELU)) {
-#pragma unroll
-          for (int k = 0; k < 8; ++k) sv[k] = a.actsrc[off[k]];
-        }
-        if (epi & FP_EPI_ACCUM) {
-#pragma unroll
-          for (int k = 0; k < 8; ++k) yo[k] = a.y[off[k]];
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          float v = acc[i][j][half * 8 + k] + bias;
-          if (epi & FP_EPI_ADDEND) v += (epi & FP_EPI_ADDEND_MASK) ? (mk[k] > 0.f ? ad[k] : 0.f) : ad[k];
-          if (epi & FP_EPI_ACTGRAD_ELU) v *= (sv[k] > 0.f ? 1.f : sv[k] + 1.f);
-          if (epi & FP_EPI_ACTGRAD_RELU) v = sv[k] > 0.f ? v : 0.f;
-          if (act == FP_ACT_ELU) v = fp_elu(v);
-          if (act == FP_ACT_RELU) v = fmaxf(v, 0.f);
-          if (epi & FP_EPI_ACCUM) v += yo[k];
-          if (ok[k]) dst[off[k]] = v;
-        }
+      if (interior) {
+        rows8(std::true_type{}, i, j, n, bias, 0);
+        rows8(std::true_type{}, i, j, n, bias, 1);
+      } else {
+        rows8(std::false_type{}, i, j, n, bias, 0);
+        rows8(std::false_type{}, i, j, n, bias, 1);
       }
     }
 }

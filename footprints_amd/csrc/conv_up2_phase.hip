@@ -249,9 +249,9 @@ __global__ void __launch_bounds__(256) up2_phase_fwd_bf3_kernel(const PhaseArgs 
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   load_halo(0);
-  store_halo(0);
   load_b(0, 0, bq[0]);
   load_b(1, 0, bq[1]);
+  store_halo(0);
   load_halo(min(1, a.KC16 - 1));
   __syncthreads();
   for (int cc = 0; cc < a.KC16; ++cc) {

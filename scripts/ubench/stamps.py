@@ -18,13 +18,6 @@ buf = (ctypes.c_longlong * 8192)()
 lib.fp_dbg_read.argtypes = [ctypes.c_void_p, ctypes.c_int]
 print("rc", lib.fp_dbg_read(buf, 8192))
 for base, name in ((0, "wg0"), (1024, "wg1500"), (2048, "wg2800")):
-    print(name)
-    for cc in range(4):
-        st = [buf[base + cc * 32 + i] for i in range(32)]
-        t0 = st[0]
-        taps = []
-        for tap in range(9):
-            a, b2, c = st[1 + tap * 3], st[2 + tap * 3], st[3 + tap * 3]
-            taps.append("%d/%d" % (b2 - a, c - b2))
-        print("  chunk %d: total %6d  taps(issue loads / wait+mfma issue): %s  | store %d barrier %d" % (cc, st[28] - t0, " ".join(taps), st[29] - st[28], st[30] - st[29]))
-    print("  kernel span from chunk0 start: %d" % (buf[base + 1000] - buf[base]))
+    e = [buf[base + 900 + i] for i in range(6)]
+    print("%s: entry->setup done %d | prologue loads issued+halo stored %d | barrier %d | main loop %d | epilogue %d | total %d cycles" % (
+        name, e[1] - e[0], e[2] - e[1], e[3] - e[2], e[4] - e[3], e[5] - e[4], e[5] - e[0]))
