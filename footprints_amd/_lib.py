@@ -100,11 +100,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("FP_LIB", LIB_PATH)           # FP_LIB: another build of the same ABI (A/B measurements)
+    if not os.path.exists(path):
         raise RuntimeError(
             "footprints_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C footprints_amd/csrc`). There is no CPU / PyTorch fallback." % LIB_PATH)
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = res

@@ -234,17 +234,40 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmArgs a) {
 #pragma unroll
           for (int k = 0; k < 8; ++k) yo[k] = a.y[off[k]];
         }
+        float v[8];                                   // one wave-uniform branch per flag around an 8-element body
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          float v = acc[i][j][half * 8 + k] + bias;
-          if (epi & FP_EPI_ADDEND) v += (epi & FP_EPI_ADDEND_MASK) ? (mk[k] > 0.f ? ad[k] : 0.f) : ad[k];
-          if (epi & FP_EPI_ACTGRAD_ELU) v *= (sv[k] > 0.f ? 1.f : sv[k] + 1.f);
-          if (epi & FP_EPI_ACTGRAD_RELU) v = sv[k] > 0.f ? v : 0.f;
-          if (act == FP_ACT_ELU) v = fp_elu(v);
-          if (act == FP_ACT_RELU) v = fmaxf(v, 0.f);
-          if (epi & FP_EPI_ACCUM) v += yo[k];
-          if (ok[k]) dst[off[k]] = v;
+        for (int k = 0; k < 8; ++k) v[k] = acc[i][j][half * 8 + k] + bias;
+        if (epi & FP_EPI_ADDEND) {
+          if (epi & FP_EPI_ADDEND_MASK) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] += mk[k] > 0.f ? ad[k] : 0.f;
+          } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] += ad[k];
+          }
         }
+        if (epi & FP_EPI_ACTGRAD_ELU) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] *= (sv[k] > 0.f ? 1.f : sv[k] + 1.f);
+        }
+        if (epi & FP_EPI_ACTGRAD_RELU) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] = sv[k] > 0.f ? v[k] : 0.f;
+        }
+        if (act == FP_ACT_ELU) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] = fp_elu(v[k]);
+        } else if (act == FP_ACT_RELU) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+        }
+        if (epi & FP_EPI_ACCUM) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] += yo[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (ok[k]) dst[off[k]] = v[k];
       }
     }
 }
