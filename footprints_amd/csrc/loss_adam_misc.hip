@@ -345,6 +345,19 @@ extern "C" int fp_adam_step_dev(float* param, const float* grad, float* exp_avg,
   return fp_check_launch("fp_adam_step_dev");
 }
 
+// out[r][k] = w[r][k] * scale[r]  (folding eval-mode BatchNorm into the preceding conv's OIHW weights)
+__global__ void __launch_bounds__(256) scale_rows_kernel(const float* __restrict__ w, const float* __restrict__ scale,
+                                                         float* __restrict__ out, size_t total, int inner) {
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) out[e] = w[e] * scale[e / inner];
+}
+
+extern "C" int fp_scale_rows(const float* w, const float* scale, float* out, int64_t rows, int64_t inner, fp_stream_t stream) {
+  FP_REQUIRE(w && scale && out && rows > 0 && inner > 0 && inner < ((int64_t)1 << 31), "fp_scale_rows: bad arguments");
+  hipLaunchKernelGGL(scale_rows_kernel, dim3(ew_grid((size_t)rows * inner)), dim3(256), 0, (hipStream_t)stream, w, scale, out,
+                     (size_t)rows * inner, (int)inner);
+  return fp_check_launch("fp_scale_rows");
+}
+
 extern "C" int64_t fp_colsum_workspace(int64_t M, int32_t C) {
   if (C < 4 || C % 4 || C > 1024) return 0;
   return (int64_t)colsum_blocks(M, C) * C * (int64_t)sizeof(float);

@@ -24,6 +24,8 @@ from . import ops
 # Running them on side streams lets workgroups of 2-3 kernels share the CUs, which fills the occupancy ramp /
 # tail of each launch (a conv launch is only ~2-3 "rounds" of workgroups per CU).  FP_SERIAL=1 disables it.
 _CONCURRENT = not bool(int(os.environ.get("FP_SERIAL", "0")))
+# inference: fold the encoder's eval-mode BatchNorm into the conv weights; FP_NO_FOLD=1 keeps conv + BN launches
+_FOLD = not bool(int(os.environ.get("FP_NO_FOLD", "0")))
 # exactly split bf16x3 operands for the 3x3 stride-1 tile kernel (conv3x3_tile_bf3.hip); FP_NO_BF3=1 keeps the fp32 MFMA
 _BF3 = not bool(int(os.environ.get("FP_NO_BF3", "0")))
 _WBF3 = _BF3 and not bool(int(os.environ.get("FP_NO_WBF3", "0")))      # ... and for the weight-gradient kernel
@@ -131,6 +133,10 @@ class Engine:
         self._alloc_packed()
         self._pack_table = None
         self._pack_table_key = None
+        self.fold_eval = _FOLD
+        self._fold_ready = False        # folded (conv * BN scale, BN shift) copies of the encoder are current
+        self._fold_buf = None
+        self._fold_vers = None
         self.weights_dirty = True
         self._versions = None
         self.saved = None
@@ -257,6 +263,7 @@ class Engine:
             self._pack_table = ops.build_pack_table(jobs, self.device)      # parameters live in self.flat: pointers are stable
             self._pack_table_key = self.flat_param.data_ptr()
         ops.pack_weights_batched(self._pack_table)
+        self._fold_ready = False
         self._versions = vers
         self.weights_dirty = False
 
@@ -305,6 +312,83 @@ class Engine:
             return ops.conv3x3_bf3(d, src, w3, out, **kw)
         return ops.conv_igemm(d, src, None, w32, out, **kw)
 
+    # ------------------------------------------------------------------------------------------------
+    # inference fast path: eval-mode BatchNorm folded into the encoder convs
+    # ------------------------------------------------------------------------------------------------
+    def _enc_pairs(self):
+        pairs = [(self.stem, self.bn0)]
+        for blk in self.blocks:
+            pairs += [(blk.c1, blk.bn1), (blk.c2, blk.bn2)]
+            if blk.ds is not None:
+                pairs.append((blk.ds, blk.bnd))
+        return pairs
+
+    def _build_fold(self):
+        """W' = W * gamma / sqrt(running_var + eps) per output channel, bias' = beta - running_mean * that: one conv launch with
+        bias (+ residual) + ReLU replaces conv -> coefficients -> apply.  Rebuilt when weights or running statistics changed."""
+        pairs = self._enc_pairs()
+        if self._fold_buf is None:
+            total = 0
+            for c, _ in pairs:
+                n3 = ops.packed_weight_elems_bf3(c.Cout, c.Cin, 3, False) if c.bf3 else 0
+                total += c.w.numel() + ops.packed_weight_elems(c.Cout, c.Cin, c.K, False, c.stem) + n3 + c.Cout
+            self._fold_buf = torch.empty(total, device=self.device)
+            o = 0
+            for c, rec in pairs:
+                n = c.w.numel()
+                c.fw = self._fold_buf[o:o + n].view(c.w.shape)
+                o += n
+                n = ops.packed_weight_elems(c.Cout, c.Cin, c.K, False, c.stem)
+                c.fwp = self._fold_buf[o:o + n]
+                o += n
+                n = ops.packed_weight_elems_bf3(c.Cout, c.Cin, 3, False) if c.bf3 else 0
+                c.fwp3 = self._fold_buf[o:o + n] if n else None
+                o += n
+                rec.fshift = self._fold_buf[o:o + c.Cout]
+                o += c.Cout
+        for c, rec in pairs:
+            bn = rec.bn
+            ops.bn_eval_coeffs(bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, rec.scale, rec.fshift, bn.eps)
+            ops.scale_rows(c.w.data, rec.scale, c.fw)
+            ops.pack_conv_weight(c.fw, c.fwp, c.stem)
+            if c.fwp3 is not None:
+                ops.pack_conv_weight_bf3(c.fw, c.fwp3, False)
+        self._fold_ready = True
+
+    def _encoder_eval_folded(self, image, N, H, W, S):
+        buf = self.buf
+        vers = tuple(t._version for _, rec in self._enc_pairs() for t in (rec.bn.running_mean, rec.bn.running_var, rec.bn.weight, rec.bn.bias))
+        if not self._fold_ready or vers != self._fold_vers:
+            self._build_fold()
+            self._fold_vers = vers
+        h, w = H // 2, W // 2
+        f0 = buf("f0", (N, h, w, 64))
+        ops.conv_igemm(ops.make_desc(N, h, w, H, W, 3, 0, 64, 7, 2, 3, L.GATHER_STEM, act=L.ACT_RELU), image, None, self.stem.fwp, f0,
+                       bias=self.bn0.fshift)
+        hp, wp_ = (h + 1) // 2, (w + 1) // 2
+        pool = buf("pool", (N, hp, wp_, 64))
+        ops.maxpool_fwd(f0, pool, buf("pool.argmax", (N, hp, wp_, 64), torch.uint8))
+        feats, dims = [f0], [(h, w)]
+        x, h, w = pool, hp, wp_
+        for i, blk in enumerate(self.blocks):
+            s = blk.stride
+            oh, ow = (h - 1) // s + 1, (w - 1) // s + 1
+            d1 = ops.make_desc(N, oh, ow, h, w, blk.c1.Cin, 0, blk.Cout, 3, s, 1, L.GATHER_FWD_ZERO, act=L.ACT_RELU)
+            a1 = self._cv(d1, x, blk.c1.fwp, blk.c1.fwp3, buf("b%d.a1" % i, (N, oh, ow, blk.Cout)), bias=blk.bn1.fshift)
+            if blk.ds is not None:
+                dd = ops.make_desc(N, oh, ow, h, w, blk.ds.Cin, 0, blk.Cout, 1, s, 0, L.GATHER_FWD_ZERO)
+                idt = self._cv(dd, x, blk.ds.fwp, None, buf("b%d.idt" % i, (N, oh, ow, blk.Cout)), bias=blk.bnd.fshift)
+            else:
+                idt = x
+            d2 = ops.make_desc(N, oh, ow, oh, ow, blk.Cout, 0, blk.Cout, 3, 1, 1, L.GATHER_FWD_ZERO, act=L.ACT_RELU)
+            out = self._cv(d2, a1, blk.c2.fwp, blk.c2.fwp3, buf("b%d.out" % i, (N, oh, ow, blk.Cout)), bias=blk.bn2.fshift, addend=idt)
+            x, h, w = out, oh, ow
+            if (i + 1 == len(self.blocks)) or (self.blocks[i + 1].stride == 2):
+                feats.append(out)
+                dims.append((h, w))
+        S["blocks"] = []
+        S["feats"], S["dims"] = feats, dims
+
     def _conv_enc(self, c, x, N, H, W, out):
         OH, OW = (H + 2 * c.pad - c.K) // c.stride + 1, (W + 2 * c.pad - c.K) // c.stride + 1
         d = ops.make_desc(N, OH, OW, H, W, c.Cin, 0, c.Cout, c.K, c.stride, c.pad, L.GATHER_FWD_ZERO)
@@ -348,6 +432,12 @@ class Engine:
         image = image.contiguous().float()
         S = {"N": N, "H": H, "W": W, "image": image, "training": training}
         buf = self.buf
+        if training:
+            self._fold_ready = False          # running statistics are about to change
+        folded = (not training) and self.fold_eval and not save_for_backward
+        if folded:
+            self._encoder_eval_folded(image, N, H, W, S)
+            return self._decoders_forward(S, outputs, save_for_backward)
         # ---- encoder --------------------------------------------------------------------------------
         h, w = H // 2, W // 2
         z0 = buf("z0", (N, h, w, 64))
@@ -385,7 +475,10 @@ class Engine:
                 feats.append(out)
                 dims.append((h, w))
         S["feats"], S["dims"] = feats, dims
-        # ---- decoders -------------------------------------------------------------------------------
+        return self._decoders_forward(S, outputs, save_for_backward)
+
+    def _decoders_forward(self, S, outputs, save_for_backward):
+        N, H, W = S["N"], S["H"], S["W"]
         if outputs is None:
             outputs = [torch.empty((N, 4, H, W), device=self.device) for _ in range(4)]
         S["dec"] = [None, None]

@@ -350,6 +350,12 @@ def bn_eval_coeffs(gamma, beta, rm, rv, scale, shift, eps=1e-5):
                                              stream()), "fp_bn_eval_coeffs")
 
 
+def scale_rows(w, scale, out):
+    rows = w.shape[0]
+    _lib.check(_lib.load().fp_scale_rows(_f32(w), _f32(scale), _f32(out), rows, w.numel() // rows, stream()), "fp_scale_rows")
+    return out
+
+
 def bn_apply(z2d, scale, shift, y2d, residual=None, relu=True):
     M, Cn = z2d.shape
     _lib.check(_lib.load().fp_bn_apply(_f32(z2d), _f32(scale), _f32(shift), _f32(residual), _f32(y2d), M, Cn, int(bool(relu)), stream()),

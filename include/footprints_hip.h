@@ -219,6 +219,9 @@ int fp_bn_train_stats(const float* z, int64_t M, int32_t C, const float* gamma, 
 /* eval mode: scale/shift from running statistics */
 int fp_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                       float eps, int32_t C, float* scale, float* shift, fp_stream_t stream);
+/* out[r][:] = w[r][:] * scale[r]: folds the eval-mode scale into the preceding conv's OIHW weights (the shift becomes the
+ * conv's bias), so inference runs conv + bias + ReLU (+ residual) in one launch -- SURVEY.md section 8(f) N1. */
+int fp_scale_rows(const float* w, const float* scale, float* out, int64_t rows, int64_t inner, fp_stream_t stream);
 /* y = [relu](z*scale + shift [+ residual]) */
 int fp_bn_apply(const float* z, const float* scale, const float* shift, const float* residual, float* y, int64_t M,
                 int32_t C, int32_t relu, fp_stream_t stream);

@@ -367,3 +367,30 @@ def test_trainstep_graph_replay_is_bit_identical_to_eager():
         assert torch.equal(a, b)
     for a, b in zip(res[0][1], res[1][1]):
         assert torch.equal(a, b)
+
+
+def test_eval_forward_with_folded_batchnorm_matches_unfolded():
+    """inference fast path: encoder BN folded into the conv weights == conv -> BN launches, after training steps
+    have moved the running statistics, and again after they move once more (the fold is rebuilt)"""
+    from footprints_amd.model_manager import ModelManager
+    from footprints_amd.training.train import TrainStep, synthetic_batch
+    from oracle import restatement as R
+    P, Bf = R.make_state(tag="fold")
+    mm = ModelManager()
+    _load_state(mm.model, P, Bf)
+    batch = synthetic_batch(2, 192, 640, "cuda")
+    ts = TrainStep(mm.model, mm.optimiser)
+    eng = mm.model.engine()
+    for rnd in range(2):
+        ts(batch)
+        mm.model.eval()
+        with torch.no_grad():
+            eng.fold_eval = True
+            a = [v.clone() for v in mm.model(batch["image"]).values()]
+            assert eng._fold_ready
+            eng.fold_eval = False
+            b = [v.clone() for v in mm.model(batch["image"]).values()]
+            eng.fold_eval = True
+        for x, y in zip(a, b):
+            assert relerr(x, y) <= 2e-5, rnd
+        mm.model.train()
