@@ -33,6 +33,7 @@ _WBF3 = _BF3 and not bool(int(os.environ.get("FP_NO_WBF3", "0")))      # ... and
 _PHASE = not bool(int(os.environ.get("FP_NO_PHASE", "0")))
 
 SCALE_KEYS = ("1/8", "1/4", "1/2", "1/1")
+_ALL_SCALES = frozenset(range(4))
 
 
 class ConvRec:
@@ -415,11 +416,14 @@ class Engine:
     # ------------------------------------------------------------------------------------------------
     # forward
     # ------------------------------------------------------------------------------------------------
-    def forward(self, image, training=True, save_for_backward=True, outputs=None):
+    def forward(self, image, training=True, save_for_backward=True, outputs=None, scales=None):
+        """scales: indices into ('1/8','1/4','1/2','1/1') whose heads are evaluated (inference only; None = all four)"""
+        if scales is not None and save_for_backward:
+            raise ValueError("a subset of output scales is an inference-only option")
         with ops.on_stream(torch.cuda.current_stream()):      # caches the raw stream handle for the launch wrappers
-            return self._forward(image, training, save_for_backward, outputs)
+            return self._forward(image, training, save_for_backward, outputs, scales)
 
-    def _forward(self, image, training, save_for_backward, outputs):
+    def _forward(self, image, training, save_for_backward, outputs, scales=None):
         if image.dim() != 4 or image.shape[1] != 3:
             raise ValueError("expected image [B,3,H,W]")
         N, _, H, W = image.shape
@@ -430,7 +434,8 @@ class Engine:
             self.weights_dirty = True
         self.refresh_packed()
         image = image.contiguous().float()
-        S = {"N": N, "H": H, "W": W, "image": image, "training": training}
+        S = {"N": N, "H": H, "W": W, "image": image, "training": training,
+             "scales": set(range(4)) if scales is None else set(scales)}
         buf = self.buf
         if training:
             self._fold_ready = False          # running statistics are about to change
@@ -519,7 +524,7 @@ class Engine:
             D["y"].append((y1, y2, y3))
             D["x"].append(xo)
             x = xo
-            if bi >= 1:                       # heads on block2/3/4 outputs: scales 8, 4, 2
+            if bi >= 1 and (bi - 1) in S.get("scales", _ALL_SCALES):     # heads on block2/3/4 outputs: scales 8, 4, 2
                 scale = (8, 4, 2)[bi - 1]
                 low = buf("%s.low%d" % (dec.name, bi), (N, h, w, 2))
                 hd = dec.heads[bi - 1]
@@ -531,10 +536,11 @@ class Engine:
         h, w = 2 * h, 2 * w
         y51 = self._conv_dec(dec.o41, x, None, N, h, w, 64, 0, True, buf(dec.name + ".y51", (N, h, w, 32)))
         x5 = self._conv_dec(dec.o42, y51, None, N, h, w, 32, 0, False, buf(dec.name + ".x5", (N, h, w, 32)))
-        low = buf(dec.name + ".low4", (N, h, w, 2))
-        ops.head_fwd(x5, dec.heads[3].w.data, dec.heads[3].b.data, low, dec.sig)
-        ops.head_upsample(low, outputs[3], 1, dec.c0)
-        D["low"].append(low)
+        if 3 in S.get("scales", _ALL_SCALES):
+            low = buf(dec.name + ".low4", (N, h, w, 2))
+            ops.head_fwd(x5, dec.heads[3].w.data, dec.heads[3].b.data, low, dec.sig)
+            ops.head_upsample(low, outputs[3], 1, dec.c0)
+            D["low"].append(low)
         D["y51"], D["x5"] = y51, x5
 
     # ------------------------------------------------------------------------------------------------

@@ -148,5 +148,12 @@ class FootprintNetwork(nn.Module):
             from .engine import NetFunction
             outs = NetFunction.apply(eng, input_image, *eng.live_params)
         else:
-            outs = eng.forward(input_image, training=self.training, save_for_backward=False)
+            # inference_scales (optional attribute, e.g. ("1/1",)): evaluate only those heads and return only those keys --
+            # predict_simple and the reference's test-set inference consume '1/1' alone (predict_simple.py:68)
+            keys = ("1/8", "1/4", "1/2", "1/1")
+            want = getattr(self, "inference_scales", None)
+            idx = None if want is None else sorted(keys.index(k) for k in want)
+            outs = eng.forward(input_image, training=self.training, save_for_backward=False, scales=idx)
+            if idx is not None:
+                return OrderedDict((keys[i], outs[i]) for i in idx)
         return OrderedDict(zip(("1/8", "1/4", "1/2", "1/1"), outs))

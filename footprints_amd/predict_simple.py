@@ -45,6 +45,7 @@ class InferenceManager:
             model_manager.load_model(weights_path=weights_path or model_folder(model_name))
         self.model_manager = model_manager
         self.model_manager.model.eval()
+        self.model_manager.model.inference_scales = ("1/1",)      # only the full-resolution prediction is consumed below
         self.save_dir = save_dir
         os.makedirs(os.path.join(save_dir, "outputs"), exist_ok=True)
         self.save_visualisations = save_visualisations

@@ -394,3 +394,16 @@ def test_eval_forward_with_folded_batchnorm_matches_unfolded():
         for x, y in zip(a, b):
             assert relerr(x, y) <= 2e-5, rnd
         mm.model.train()
+
+
+def test_inference_scales_subset():
+    from footprints_amd.model_manager import ModelManager
+    from footprints_amd.training.train import synthetic_batch
+    mm = ModelManager()
+    mm.model.eval()
+    img = synthetic_batch(2, 64, 96, "cuda")["image"]
+    with torch.no_grad():
+        full = {k: v.clone() for k, v in mm.model(img).items()}
+        mm.model.inference_scales = ("1/1",)
+        only = mm.model(img)
+    assert list(only.keys()) == ["1/1"] and torch.equal(only["1/1"], full["1/1"])
