@@ -127,6 +127,12 @@ def phase_fwd_flops(low, wphase, bias, y, *a, **k):
     return 2.0 * N * (2 * h) * (2 * w) * y.shape[3] * 9 * C0
 
 
+def phase_dgrad_flops(dz, wpacked, ext, *a, **k):
+    """algorithmic FLOPs of the dense data gradient (3x3 over the hi-res grid) the phase kernel replaces"""
+    N, H2, W2, Cout = dz.shape
+    return 2.0 * N * H2 * W2 * Cout * 9 * ext.shape[3]
+
+
 def phase_wgrad_flops(low, dz, *a, **k):
     N, h, w, C0 = low.shape
     return 2.0 * N * (2 * h) * (2 * w) * dz.shape[3] * 9 * C0
@@ -139,7 +145,9 @@ def phase_key(tag):
 # op name -> (flop function, key function): the forward + data-gradient convolution family (roofline) and the weight gradients
 FWD_DGRAD_OPS = {"conv_igemm": (conv_flops, None), "conv3x3_bf3": (conv_flops, None),
                  "conv_up2_phase_fwd": (phase_fwd_flops, phase_key("phase_fwd")),
-                 "conv_up2_phase_fwd_bf3": (phase_fwd_flops, phase_key("phase_fwd_bf3"))}
+                 "conv_up2_phase_fwd_bf3": (phase_fwd_flops, phase_key("phase_fwd_bf3")),
+                 "conv_up2_phase_dgrad_bf3": (phase_dgrad_flops, lambda dz, *a, **k: "phase_dgrad_bf3 N%d dz %dx%d C%d" % (
+                     dz.shape[0], dz.shape[1], dz.shape[2], dz.shape[3]))}
 WGRAD_OPS = {"conv_wgrad": (conv_flops, None), "conv_wgrad_slice": (conv_flops, None), "conv_wgrad_bf3": (conv_flops, None),
              "conv_up2_phase_wgrad": (phase_wgrad_flops, phase_key("phase_wgrad"))}
 

@@ -21,7 +21,7 @@ class ConvDesc(C.Structure):
                                          "gather", "act")] + [("epi", C.c_uint32)]
 
 
-PACK_FWD, PACK_DGRAD, PACK_STEM, PACK_UP2_FWD, PACK_UP2_DGRAD, PACK_FWD_BF3, PACK_DGRAD_BF3, PACK_UP2_FWD_BF3 = range(8)
+PACK_FWD, PACK_DGRAD, PACK_STEM, PACK_UP2_FWD, PACK_UP2_DGRAD, PACK_FWD_BF3, PACK_DGRAD_BF3, PACK_UP2_FWD_BF3, PACK_UP2_DGRAD_BF3 = range(9)
 
 
 class PackJob(C.Structure):
@@ -55,6 +55,8 @@ SIGNATURES = {
     "fp_pack_job_blocks": (_I32, [_I32, _I32, _I32, _I32, _I32]),
     "fp_pack_weights_batched": (C.c_int, [_P, _P, _I32, _P]),
     "fp_pack_up2_weight_bf3": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P]),
+    "fp_pack_up2_weight_dgrad_bf3": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P]),
+    "fp_conv_up2_phase_dgrad_bf3": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P]),
     "fp_conv_up2_phase_fwd_bf3": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
     "fp_conv_wgrad_bf3_workspace": (_I64, [_DESC]),
     "fp_conv_wgrad_bf3": (C.c_int, [_DESC, _P, _P, _P, _I32, _I32, C.c_int, _P, _I64, _P]),

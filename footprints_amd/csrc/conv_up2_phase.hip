@@ -322,6 +322,157 @@ __global__ void __launch_bounds__(256) up2_phase_fwd_bf3_kernel(const PhaseArgs 
     }
 }
 
+// ---- data gradient of the upsampled half, bf16x3: the 4x4 stride-2 convolution over dZ (see the comment further down), phase by
+// phase.  For dZ phase (py, px) (hi-res pixel (2yp + py, 2xp + px)) only the taps r = (py+1)%2 + 2a, s = (px+1)%2 + 2b (a, b in
+// {0,1}) hit it, at phase-plane position yp = Y' - 2 + a + (1 - py): per phase a 2x2 convolution over the zero-padded phase plane.
+// A workgroup owns 8 x 16 positions of the extended (h+2) x (w+2) output grid x BN input channels and runs 4 phases x Cout/16
+// chunks, each like a chunk of up2_phase_fwd_bf3_kernel (halo = 10 x 18 phase-plane pixels, four taps from LDS).
+struct PhaseDgradArgs {
+  const float* dz;      // [N][2h][2w][Cout]
+  const unsigned short* w;   // bf16 [phase 4][tap 4][KC16 over Cout][3][C0][16]
+  float* ext;           // [N][h+2][w+2][C0]
+  int N, h, w_, Cout, C0, KC16, tilesX, tilesY, tilesN, nwg;
+};
+
+template <int BN, int WM, int WN>
+__global__ void __launch_bounds__(256) up2_phase_dgrad_bf3_kernel(const PhaseDgradArgs a) {
+  constexpr int BM = TH * TW;
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int NS = (HP * 4 + 255) / 256;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF3];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, idx = lane & 31, h = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+  int wg = fp_xcd_remap(blockIdx.x, a.nwg);
+  const int tile_n = wg % a.tilesN; wg /= a.tilesN;
+  const int tile_x = wg % a.tilesX; wg /= a.tilesX;
+  const int tile_y = wg % a.tilesY;
+  const int n_img = wg / a.tilesY;
+  const int y0 = tile_y * TH, x0 = tile_x * TW, n0 = tile_n * BN;
+  const int H2 = 2 * a.h, W2 = 2 * a.w_, EH = a.h + 2, EW = a.w_ + 2;
+  const int nsteps = 4 * a.KC16;
+
+  int pix[NS], lds_off[NS];
+  bool hvalid[NS];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    const int lin = t + 256 * k, hp = min(lin >> 2, HP - 1);
+    lds_off[k] = (lin >> 2) < HP ? hp * PIXB + (lin & 3) * 8 : -1;
+    const int hy = hp / HW2, hx = hp - hy * HW2;
+    const int yp = y0 + hy - 2, xp = x0 + hx - 2;                      // phase-plane coordinates
+    hvalid[k] = yp >= 0 && yp < a.h && xp >= 0 && xp < a.w_;
+    pix[k] = (n_img * H2 + 2 * min(max(yp, 0), a.h - 1)) * W2 + 2 * min(max(xp, 0), a.w_ - 1);   // + py * W2 + px per phase
+  }
+  float4 hreg[NS];
+  bool hzero = false;
+  auto load_halo = [&](int step) {
+    const int ph = step / a.KC16, cc = step - ph * a.KC16;
+    const int poff = (ph >> 1) * W2 + (ph & 1);
+    const int c4 = cc * 16 + (t & 3) * 4;
+    hzero = c4 >= a.Cout;
+    const int coff = hzero ? 0 : c4;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) hreg[k] = *reinterpret_cast<const float4*>(a.dz + (size_t)(pix[k] + poff) * a.Cout + coff);
+  };
+  auto store_halo = [&](int buf) {
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      if (lds_off[k] < 0) continue;
+      f32x4_t v = {hreg[k].x, hreg[k].y, hreg[k].z, hreg[k].w};
+      if (hzero || !hvalid[k]) v = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      const bf16x4_t vh = __builtin_convertvector(v, bf16x4_t);
+      const f32x4_t r1 = v - __builtin_convertvector(vh, f32x4_t);
+      const bf16x4_t vm = __builtin_convertvector(r1, bf16x4_t);
+      const f32x4_t r2 = r1 - __builtin_convertvector(vm, f32x4_t);
+      const bf16x4_t vl = __builtin_convertvector(r2, bf16x4_t);
+      unsigned char* p = lds + buf * BUF3 + lds_off[k];
+      *reinterpret_cast<uint2*>(p) = __builtin_bit_cast(uint2, vh);
+      *reinterpret_cast<uint2*>(p + PLANE3) = __builtin_bit_cast(uint2, vm);
+      *reinterpret_cast<uint2*>(p + 2 * PLANE3) = __builtin_bit_cast(uint2, vl);
+    }
+  };
+  uint4 bq[4][TN][3];
+  auto load_b = [&](int tap, int step, uint4 (&bf)[TN][3]) {
+    const int ph = step / a.KC16, cc = step - ph * a.KC16;
+    const unsigned short* ws = a.w + (size_t)((ph * 4 + tap) * a.KC16 + cc) * 3 * a.C0 * 16 + h * 8;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = min(n0 + (wn * TN + j) * 32 + idx, a.C0 - 1);
+#pragma unroll
+      for (int p = 0; p < 3; ++p) bf[j][p] = *reinterpret_cast<const uint4*>(ws + ((size_t)p * a.C0 + n) * 16);
+    }
+  };
+  int abase[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int pt = (wm * TM + i) * 32 + idx;
+    abase[i] = ((pt / TW) * HW2 + (pt % TW)) * PIXB + h * 16;
+  }
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  load_halo(0);
+  load_b(0, 0, bq[0]);
+  load_b(1, 0, bq[1]);
+  store_halo(0);
+  load_halo(min(1, nsteps - 1));
+  __syncthreads();
+  for (int step = 0; step < nsteps; ++step) {
+    const unsigned char* Hb = lds + (step & 1) * BUF3;
+    const int stepn = min(step + 1, nsteps - 1);
+    const int ph = step / a.KC16;
+    const int poff = ((1 - (ph >> 1)) * HW2 + (1 - (ph & 1))) * PIXB;     // tap (a, b) reads halo offset (a + 1 - py, b + 1 - px)
+    uint4 af[2][TM][3];
+    auto load_a = [&](int tap, uint4 (&dst)[TM][3]) {
+      const int toff = poff + ((tap >> 1) * HW2 + (tap & 1)) * PIXB;
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) dst[i][p] = *reinterpret_cast<const uint4*>(Hb + p * PLANE3 + abase[i] + toff);
+    };
+    load_a(0, af[0]);
+#pragma unroll
+    for (int tap = 0; tap < 4; ++tap) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (tap < 3) load_a(tap + 1, af[(tap + 1) & 1]);
+      if (tap < 2) load_b(tap + 2, step, bq[tap + 2]);
+      else load_b(tap - 2, stepn, bq[tap - 2]);
+      __builtin_amdgcn_sched_barrier(0);
+      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+      for (int q = 0; q < 6; ++q)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[tap & 1][i][PA[q]]),
+                                                                __builtin_bit_cast(bf16x8_t, bq[tap][j][PB[q]]), acc[i][j], 0, 0, 0);
+    }
+    if (step + 1 < nsteps) {
+      store_halo((step + 1) & 1);
+      load_halo(min(step + 2, nsteps - 1));
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + (wn * TN + j) * 32 + idx;
+      if (n >= a.C0) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int pt = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int ey = y0 + pt / TW, ex = x0 + pt % TW;
+        if (ey < EH && ex < EW) a.ext[((size_t)(n_img * EH + ey) * EW + ex) * a.C0 + n] = acc[i][j][r];
+      }
+    }
+}
+
 // ---- backward ----------------------------------------------------------------------------------------------------
 // d(low) of the phase decomposition is a 4x4 stride-2 convolution over dZ (taps r = hi-res row - (2Y - 1)):
 //     K4[0] = W[2], K4[1] = W[1] + W[2], K4[2] = W[0] + W[1], K4[3] = W[0]         (rows; same for columns)
@@ -414,6 +565,27 @@ extern "C" int fp_conv_up2_phase_fwd_bf3(const float* low, const void* wphase_bf
     hipLaunchKernelGGL((up2_phase_fwd_bf3_kernel<64, 2, 2>), dim3(a.nwg), dim3(256), 0, (hipStream_t)stream, a);
   }
   return fp_check_launch("fp_conv_up2_phase_fwd_bf3");
+}
+
+extern "C" int fp_conv_up2_phase_dgrad_bf3(const float* dz, const void* wpacked_bf3, float* ext, int32_t N, int32_t h, int32_t w,
+                                           int32_t Cout, int32_t C0, fp_stream_t stream) {
+  FP_REQUIRE(dz && wpacked_bf3 && ext && N > 0 && h >= 1 && w >= 1 && Cout > 0 && Cout % 4 == 0 && C0 > 0,
+             "fp_conv_up2_phase_dgrad_bf3: bad arguments");
+  FP_REQUIRE((int64_t)N * 4 * h * w * Cout < ((int64_t)1 << 31), "fp_conv_up2_phase_dgrad_bf3: dZ larger than 2^31 elements");
+  PhaseDgradArgs a;
+  a.dz = dz; a.w = (const unsigned short*)wpacked_bf3; a.ext = ext;
+  a.N = N; a.h = h; a.w_ = w; a.Cout = Cout; a.C0 = C0; a.KC16 = (Cout + 15) / 16;
+  a.tilesX = (int)fp_ceil_div(w + 2, TW); a.tilesY = (int)fp_ceil_div(h + 2, TH);
+  if (C0 <= 32) {
+    a.tilesN = (int)fp_ceil_div(C0, 32);
+    a.nwg = N * a.tilesY * a.tilesX * a.tilesN;
+    hipLaunchKernelGGL((up2_phase_dgrad_bf3_kernel<32, 4, 1>), dim3(a.nwg), dim3(256), 0, (hipStream_t)stream, a);
+  } else {
+    a.tilesN = (int)fp_ceil_div(C0, 64);
+    a.nwg = N * a.tilesY * a.tilesX * a.tilesN;
+    hipLaunchKernelGGL((up2_phase_dgrad_bf3_kernel<64, 2, 2>), dim3(a.nwg), dim3(256), 0, (hipStream_t)stream, a);
+  }
+  return fp_check_launch("fp_conv_up2_phase_dgrad_bf3");
 }
 
 extern "C" int fp_up2_fold_bwd(const float* ext, int32_t N, int32_t h, int32_t w, int32_t C, const float* addend, const float* ylow_elu,

@@ -73,6 +73,22 @@ __device__ __forceinline__ float pack_elem(const fp_pack_job& j, size_t e) {
         for (int kx = kx_lo; kx <= kx_hi; ++kx) v += wk[ky * 3 + kx];
       return v;
     }
+    case FP_PACK_UP2_DGRAD_BF3: {   // [phase 4][tap 4][KC16 over Cout][c][16 n]: K4[(py+1)%2 + 2a][(px+1)%2 + 2b][n][c]
+      const int KC16 = (j.Cout + 15) / 16;
+      const int c = (int)(r % j.c_count); r /= j.c_count;
+      const int kc = (int)(r % KC16); r /= KC16;
+      const int tap = (int)(r & 3), ph = (int)(r >> 2);
+      const int tr = ((ph >> 1) + 1) % 2 + 2 * (tap >> 1), ts = ((ph & 1) + 1) % 2 + 2 * (tap & 1);
+      const int n = kc * 16 + kr;
+      if (n >= j.Cout) return 0.f;
+      const float* wk = w + ((size_t)n * j.Cin + j.c_begin + c) * 9;
+      const int ky_lo = tr == 0 ? 2 : (tr == 1 ? 1 : 0), ky_hi = tr == 0 ? 2 : (tr == 1 ? 2 : (tr == 2 ? 1 : 0));
+      const int kx_lo = ts == 0 ? 2 : (ts == 1 ? 1 : 0), kx_hi = ts == 0 ? 2 : (ts == 1 ? 2 : (ts == 2 ? 1 : 0));
+      float v = 0.f;
+      for (int ky = ky_lo; ky <= ky_hi; ++ky)
+        for (int kx = kx_lo; kx <= kx_hi; ++kx) v += wk[ky * 3 + kx];
+      return v;
+    }
     default: return 0.f;
   }
 }
@@ -87,6 +103,7 @@ __host__ __device__ inline int64_t pack_elems(int kind, int Cout, int KH, int KW
     case FP_PACK_STEM: return 10 * 64 * 16;
     case FP_PACK_UP2_FWD_BF3:
     case FP_PACK_UP2_FWD: return (int64_t)16 * ((c_count + 15) / 16) * Cout * 16;
+    case FP_PACK_UP2_DGRAD_BF3:
     case FP_PACK_UP2_DGRAD: return (int64_t)16 * ((Cout + 15) / 16) * c_count * 16;
     default: return 0;
   }
@@ -100,11 +117,11 @@ __device__ __forceinline__ unsigned short bf16_rne(float x) {
   return (unsigned short)(u >> 16);
 }
 __device__ __forceinline__ void pack_store(const fp_pack_job& j, size_t e, float v) {
-  if (j.kind != FP_PACK_FWD_BF3 && j.kind != FP_PACK_DGRAD_BF3 && j.kind != FP_PACK_UP2_FWD_BF3) {
+  if (j.kind != FP_PACK_FWD_BF3 && j.kind != FP_PACK_DGRAD_BF3 && j.kind != FP_PACK_UP2_FWD_BF3 && j.kind != FP_PACK_UP2_DGRAD_BF3) {
     j.wp[e] = v;
     return;
   }
-  const size_t ncols = j.kind == FP_PACK_DGRAD_BF3 ? j.c_count : j.Cout;
+  const size_t ncols = (j.kind == FP_PACK_DGRAD_BF3 || j.kind == FP_PACK_UP2_DGRAD_BF3) ? j.c_count : j.Cout;
   const size_t k = e & 15, n = (e >> 4) % ncols, blk = (e >> 4) / ncols;
   unsigned short* o = reinterpret_cast<unsigned short*>(j.wp) + (blk * 3 * ncols + n) * 16 + k;
   const unsigned short h = bf16_rne(v);
@@ -159,6 +176,12 @@ extern "C" int fp_pack_conv_weight_bf3(const float* w_oihw, void* wp, int32_t Co
                     "fp_pack_conv_weight_bf3");
 }
 extern "C" int64_t fp_up2_packed_weight_elems(int32_t Ncols, int32_t K) { return pack_elems(FP_PACK_UP2_FWD, Ncols, 3, 3, K); }
+extern "C" int fp_pack_up2_weight_dgrad_bf3(const float* w_oihw, void* wp, int32_t Cout, int32_t Cin, int32_t c_begin, int32_t c_count,
+                                            fp_stream_t stream) {
+  FP_REQUIRE(w_oihw && wp && c_begin >= 0 && c_count > 0 && c_begin + c_count <= Cin, "fp_pack_up2_weight_dgrad_bf3: bad arguments");
+  return launch_one(FP_PACK_UP2_DGRAD_BF3, w_oihw, (float*)wp, Cout, Cin, 3, 3, c_begin, c_count, (hipStream_t)stream,
+                    "fp_pack_up2_weight_dgrad_bf3");
+}
 extern "C" int fp_pack_up2_weight_bf3(const float* w_oihw, void* wp, int32_t Cout, int32_t Cin, int32_t c_begin, int32_t c_count,
                                       fp_stream_t stream) {
   FP_REQUIRE(w_oihw && wp && c_begin >= 0 && c_count > 0 && c_begin + c_count <= Cin, "fp_pack_up2_weight_bf3: bad arguments");

@@ -53,7 +53,7 @@ class ConvRec:
         self.wph = self.wsk = self.wdu = self.wds = None   # fwd phase / fwd skip slice / dgrad 4x4 s2 / dgrad skip slice
         # bf16x3-split copies (3x3 stride-1 convs): forward, dgrad, and the skip-slice pair of the upsample convs
         self.bf3 = _BF3 and self.K == 3 and self.stride == 1 and not stem and not head
-        self.wp3 = self.wpd3 = self.wsk3 = self.wds3 = self.wph3 = None
+        self.wp3 = self.wpd3 = self.wsk3 = self.wds3 = self.wph3 = self.wdu3 = None
         self.gw = None    # gradient views (flat grad buffer)
         self.gb = None
 
@@ -216,13 +216,14 @@ class Engine:
                       ops.up2_packed_weight_elems(C0, c.Cout), ops.packed_weight_elems(c.Cout, C1, 3, True) if C1 else 0]
             if c.bf3:
                 if c.up2 is None:
-                    ex += [ops.packed_weight_elems_bf3(c.Cout, c.Cin, 3, False), ops.packed_weight_elems_bf3(c.Cout, c.Cin, 3, True), 0, 0, 0]
+                    ex += [ops.packed_weight_elems_bf3(c.Cout, c.Cin, 3, False), ops.packed_weight_elems_bf3(c.Cout, c.Cin, 3, True), 0, 0, 0, 0]
                 else:
                     C0, C1 = c.up2
                     ex += [0, 0, ops.packed_weight_elems_bf3(c.Cout, C1, 3, False) if C1 else 0,
-                           ops.packed_weight_elems_bf3(c.Cout, C1, 3, True) if C1 else 0, ops.up2_packed_weight_elems(c.Cout, C0) * 3 // 2]
+                           ops.packed_weight_elems_bf3(c.Cout, C1, 3, True) if C1 else 0, ops.up2_packed_weight_elems(c.Cout, C0) * 3 // 2,
+                           ops.up2_packed_weight_elems(C0, c.Cout) * 3 // 2]
             else:
-                ex += [0, 0, 0, 0, 0]
+                ex += [0, 0, 0, 0, 0, 0]
             plan.append((c, total, nf, nd, ex))
             total += nf + nd + sum(ex)
         self.packed = torch.empty(total, device=self.device)
@@ -234,7 +235,7 @@ class Engine:
             for n in ex:
                 views.append(self.packed[o:o + n] if n else None)
                 o += n
-            c.wph, c.wsk, c.wdu, c.wds, c.wp3, c.wpd3, c.wsk3, c.wds3, c.wph3 = views
+            c.wph, c.wsk, c.wdu, c.wds, c.wp3, c.wpd3, c.wsk3, c.wds3, c.wph3, c.wdu3 = views
 
     def refresh_packed(self, force=False):
         vers = tuple(c.w._version for c in self.all_convs())
@@ -254,6 +255,7 @@ class Engine:
                     jobs.append((L.PACK_DGRAD_BF3, c.w.data, c.wds3, c.up2[0], c.up2[1]))
                 if c.wph3 is not None:
                     jobs.append((L.PACK_UP2_FWD_BF3, c.w.data, c.wph3, 0, c.up2[0]))
+                    jobs.append((L.PACK_UP2_DGRAD_BF3, c.w.data, c.wdu3, 0, c.up2[0]))
                 if c.up2 is not None:
                     C0, C1 = c.up2
                     jobs.append((L.PACK_UP2_FWD, c.w.data, c.wph, 0, C0))
@@ -595,6 +597,8 @@ class Engine:
     def _dgrad_up2_ext(self, c, dz, N, hl, wl, C0, pfx):
         """gradient wrt the low-res input of an upsample conv on the (hl+2) x (wl+2) extended grid (ops.up2_fold_bwd folds it)"""
         ext = self.buf(pfx + "XV", (N, hl + 2, wl + 2, C0))
+        if c.wdu3 is not None and self._phase_ok(hl + 2, wl + 2) and not os.environ.get("FP_NO_PDGRAD3"):      # bf16x3 phase kernel (8x16 tiles of the extended grid)
+            return ops.conv_up2_phase_dgrad_bf3(dz, c.wdu3, ext)
         d = ops.make_desc(N, hl + 2, wl + 2, 2 * hl, 2 * wl, c.Cout, 0, C0, 4, 2, 3, L.GATHER_FWD_ZERO)
         return ops.conv_igemm(d, dz, None, c.wdu, ext)
 

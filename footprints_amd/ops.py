@@ -237,6 +237,21 @@ def conv_up2_phase_fwd_bf3(low, wphase_bf3, bias, y, act=0, addend=None):
     return y
 
 
+def pack_up2_weight_dgrad_bf3(w, wp, c_begin, c_count):
+    Cout, Cin = w.shape[:2]
+    _lib.check(_lib.load().fp_pack_up2_weight_dgrad_bf3(_f32(w), _f32(wp), Cout, Cin, c_begin, c_count, stream()),
+               "fp_pack_up2_weight_dgrad_bf3")
+    return wp
+
+
+def conv_up2_phase_dgrad_bf3(dz, wpacked_bf3, ext):
+    """gradient wrt the low-res input of an upsample conv on the (h+2) x (w+2) extended grid (up2_fold_bwd folds it)"""
+    N, H2, W2, Cout = dz.shape
+    _lib.check(_lib.load().fp_conv_up2_phase_dgrad_bf3(_f32(dz), _f32(wpacked_bf3), _f32(ext), N, H2 // 2, W2 // 2, Cout, ext.shape[3],
+                                                       stream()), "fp_conv_up2_phase_dgrad_bf3")
+    return ext
+
+
 def conv_up2_phase_fwd(low, wphase, bias, y, act=0, addend=None):
     N, h, w, C0 = low.shape
     _lib.check(_lib.load().fp_conv_up2_phase_fwd(_f32(low), _f32(wphase), _f32(bias), _f32(addend), _f32(y), N, h, w, C0, y.shape[3],

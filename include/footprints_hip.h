@@ -92,7 +92,7 @@ int fp_conv_wgrad(const fp_conv_desc* d, const float* src0, const float* src1, c
 /* One repacking job of fp_pack_weights_batched: every convolution's packed copies are refreshed by ONE launch after the
  * optimizer step (the table lives in device memory and is built once: parameter and packed buffers never move). */
 enum { FP_PACK_FWD = 0, FP_PACK_DGRAD = 1, FP_PACK_STEM = 2, FP_PACK_UP2_FWD = 3, FP_PACK_UP2_DGRAD = 4,
-       FP_PACK_FWD_BF3 = 5, FP_PACK_DGRAD_BF3 = 6, FP_PACK_UP2_FWD_BF3 = 7 /* bf16x3 split planes, see fp_conv3x3_bf3 */ };
+       FP_PACK_FWD_BF3 = 5, FP_PACK_DGRAD_BF3 = 6, FP_PACK_UP2_FWD_BF3 = 7, FP_PACK_UP2_DGRAD_BF3 = 8 /* bf16x3 split planes, see fp_conv3x3_bf3 */ };
 typedef struct fp_pack_job {
   const float* w;  /* [Cout][Cin][KH][KW] */
   float* wp;       /* packed destination */
@@ -165,6 +165,12 @@ int fp_pack_up2_weight_dgrad(const float* w_oihw, float* wp, int32_t Cout, int32
                              fp_stream_t stream);
 int fp_pack_conv_weight_dgrad_slice(const float* w_oihw, float* wp, int32_t Cout, int32_t Cin, int32_t c_begin,
                                     int32_t c_count, fp_stream_t stream);
+/* bf16x3 variant of the 4x4 stride-2 data-gradient convolution: writes the same ext[N][h+2][w+2][C0] as fp_conv_igemm would;
+ * weights from fp_pack_up2_weight_dgrad_bf3 / FP_PACK_UP2_DGRAD_BF3 (fp_up2_packed_weight_elems(c_count, Cout) * 3 / 2 floats). */
+int fp_pack_up2_weight_dgrad_bf3(const float* w_oihw, void* wp, int32_t Cout, int32_t Cin, int32_t c_begin,
+                                 int32_t c_count, fp_stream_t stream);
+int fp_conv_up2_phase_dgrad_bf3(const float* dz, const void* wpacked_bf3, float* ext, int32_t N, int32_t h, int32_t w,
+                                int32_t Cout, int32_t C0, fp_stream_t stream);
 int fp_up2_fold_bwd(const float* ext, int32_t N, int32_t h, int32_t w, int32_t C, const float* addend,
                     const float* ylow_elu, float* dlow, fp_stream_t stream);
 /* Weight gradient of the upsampled half: dw_oihw[:, k_begin:k_begin+C0] (+)= un-collapse of the 16 per-phase products

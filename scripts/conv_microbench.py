@@ -127,6 +127,7 @@ if which == "up2bwd":
         xv = torch.empty((N, 2 * h, 2 * w_, C0 + C1), device=dev)
         wo = (torch.rand((Nout, C0 + C1, 3, 3), device=dev) - 0.5) * 0.1
         wpo = ops.pack_conv_weight_dgrad(wo, torch.empty(ops.packed_weight_elems(Nout, C0 + C1, 3, True), device=dev))
+        wp3d = ops.pack_up2_weight_dgrad_bf3(wo, torch.empty(ops.up2_packed_weight_elems(C0, Nout) * 3 // 2, device=dev), 0, C0)
         d_old = ops.make_desc(N, 2 * h, 2 * w_, 2 * h, 2 * w_, Nout, 0, C0 + C1, 3, 1, 1, L.GATHER_DGRAD_REFLECT)
         dlow = torch.empty((N, h, w_, C0), device=dev)
         dsk = torch.empty((N, 2 * h, 2 * w_, C1), device=dev) if C1 else None
@@ -138,6 +139,7 @@ if which == "up2bwd":
         d_wold = ops.make_desc(N, 2 * h, 2 * w_, 2 * h, 2 * w_, C0, C1, Nout, 3, 1, 1, L.GATHER_FWD_REFLECT_UP2)
         runs = [("dgrad-old", lambda: (ops.conv_igemm(d_old, dz, None, wpo, xv), ops.up2cat_bwd(xv, N, h, w_, C0, C1, dlow, ylow=lo, dskip=dsk))),
                 ("dgrad-4x4s2", lambda: ops.conv_igemm(d, dz, None, wp, ext)),
+                ("dgrad-ph-bf3", lambda: ops.conv_up2_phase_dgrad_bf3(dz, wp3d, ext)),
                 ("wgrad-old", lambda: ops.conv_wgrad(d_wold, lo, sk, dz, dwo)),
                 ("wgrad-4x4s2", lambda: ops.conv_wgrad(d, dz, None, lowx, dk4))]
         if ops.up2_phase_wgrad_supported(N, h, w_, C0, Nout):

@@ -151,6 +151,30 @@ def test_up2_phase_fwd(N, h, w, C0, C1, Cout):
     check(nchw(y), ref, "up2 phase fwd")
 
 
+def test_up2_phase_dgrad_bf3_case(N, h, w, C0, Cout):
+    """bf16x3 phase data-gradient kernel: same ext grid as the 4x4 stride-2 fp32 convolution, then fold -> d(low) vs float64"""
+    ops, L = _ops()
+    wt = rnd((Cout, C0, 3, 3), 340, -0.1, 0.1)
+    lo = rnd((N, C0, h, w), 341).double().requires_grad_(True)
+    yr = _up2_ref(lo, None, wt.double(), None)
+    g = rnd(tuple(yr.shape), 342)
+    yr.backward(g.double())
+    wd, gz = wt.cuda(), nhwc(g)
+    wp3 = ops.pack_up2_weight_dgrad_bf3(wd, torch.empty(ops.up2_packed_weight_elems(C0, Cout) * 3 // 2, device="cuda"), 0, C0)
+    ext3 = ops.conv_up2_phase_dgrad_bf3(gz, wp3, torch.full((N, h + 2, w + 2, C0), float("nan"), device="cuda"))
+    wpu = ops.pack_up2_weight_dgrad(wd, torch.empty(ops.up2_packed_weight_elems(C0, Cout), device="cuda"), 0, C0)
+    d = ops.make_desc(N, h + 2, w + 2, 2 * h, 2 * w, Cout, 0, C0, 4, 2, 3, L.GATHER_FWD_ZERO)
+    ext = ops.conv_igemm(d, gz, None, wpu, torch.empty((N, h + 2, w + 2, C0), device="cuda"))
+    assert relerr(ext3, ext.cpu()) <= 2e-5
+    dlow = ops.up2_fold_bwd(ext3, torch.empty((N, h, w, C0), device="cuda"))
+    check(nchw(dlow), lo.grad, "up2 phase dgrad bf3", 3e-6)
+
+
+test_up2_phase_dgrad_bf3 = pytest.mark.parametrize("N,h,w,C0,Cout", [
+    (2, 24, 80, 64, 64), (1, 96, 320, 64, 32), (2, 6, 20, 256, 256), (2, 1, 1, 16, 16), (1, 3, 2, 24, 48), (3, 9, 17, 20, 72)])(
+        test_up2_phase_dgrad_bf3_case)
+
+
 @pytest.mark.parametrize("N,h,w,C0,C1,Cout", [
     (2, 6, 20, 64, 64, 64), (2, 12, 40, 32, 32, 48), (1, 24, 80, 64, 0, 32), (2, 1, 1, 16, 0, 16), (1, 1, 5, 16, 16, 16),
     (2, 3, 2, 24, 40, 48), (1, 48, 160, 64, 64, 64)])
