@@ -209,7 +209,7 @@ WPlan plan(const fp_conv_desc* d) {
   p.nchunks = d->N * p.cy * p.cx;
   p.citiles = d->C0 / 32; p.cotiles = d->Nout / 32;
   const int64_t base = (int64_t)p.citiles * p.cotiles;
-  int64_t S = fp_ceil_div(768, base);
+  int64_t S = fp_ceil_div(512, base);      // two workgroups per CU are resident (240 registers): one full round
   if (S > p.nchunks / 4) S = p.nchunks / 4;
   if (S < 1) S = 1;
   if (S > 512) S = 512;
