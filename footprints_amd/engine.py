@@ -2,7 +2,9 @@
 
 Design (MI355X-first, not an autograd graph):
   * activations NHWC fp32, resident in a named arena that is allocated once and reused every step (static
-    addresses => the whole step is capturable in a hipGraph);
+    addresses => the whole step is capturable in a hipGraph: TrainStep(graph=True));
+  * 3x3 stride-1 convolutions (forward, data- and weight-gradient) multiply exactly split operands (three bf16 terms per
+    fp32 value, six bf16 MFMA products, fp32 accumulation: conv3x3_tile_bf3.hip); the rest uses the fp32 MFMA kernels;
   * nearest-x2 upsample, skip concat, reflection / zero padding, ELU / ReLU, residual adds and their
     gradients never exist as tensors -- they are loader / epilogue modes of the implicit-GEMM kernels;
   * all live parameters are views of ONE flat fp32 buffer (same for gradients) in forward order, so Adam is
@@ -597,7 +599,7 @@ class Engine:
     def _dgrad_up2_ext(self, c, dz, N, hl, wl, C0, pfx):
         """gradient wrt the low-res input of an upsample conv on the (hl+2) x (wl+2) extended grid (ops.up2_fold_bwd folds it)"""
         ext = self.buf(pfx + "XV", (N, hl + 2, wl + 2, C0))
-        if c.wdu3 is not None and self._phase_ok(hl + 2, wl + 2) and not os.environ.get("FP_NO_PDGRAD3"):      # bf16x3 phase kernel (8x16 tiles of the extended grid)
+        if c.wdu3 is not None and self._phase_ok(hl + 2, wl + 2):      # bf16x3 phase kernel (8x16 tiles of the extended grid)
             return ops.conv_up2_phase_dgrad_bf3(dz, c.wdu3, ext)
         d = ops.make_desc(N, hl + 2, wl + 2, 2 * hl, 2 * wl, c.Cout, 0, C0, 4, 2, 3, L.GATHER_FWD_ZERO)
         return ops.conv_igemm(d, dz, None, c.wdu, ext)
