@@ -136,6 +136,7 @@ class Engine:
         self._alloc_packed()
         self._pack_table = None
         self._pack_table_key = None
+        self._pack_ev = None
         self.fold_eval = _FOLD
         self._fold_ready = False        # folded (conv * BN scale, BN shift) copies of the encoder are current
         self._fold_buf = None
@@ -239,35 +240,52 @@ class Engine:
                 o += n
             c.wph, c.wsk, c.wdu, c.wds, c.wp3, c.wpd3, c.wsk3, c.wds3, c.wph3, c.wdu3 = views
 
-    def refresh_packed(self, force=False):
+    def refresh_packed(self, force=False, overlap=False):
+        """repack every convolution's weights if they changed.  overlap=True (Engine.forward only): all but the stem / layer1
+        tables are packed on a side stream and the caller waits for self._pack_ev (self._wait_pack) before layer2."""
         vers = tuple(c.w._version for c in self.all_convs())
         if not (force or self.weights_dirty or vers != self._versions):
             return
         if self._pack_table is None or self._pack_table_key != self.flat_param.data_ptr():
-            jobs = []
-            for c in self.all_convs():
-                jobs.append((L.PACK_STEM if c.stem else L.PACK_FWD, c.w.data, c.wp, 0, c.Cin))
-                if c.wpd is not None:
-                    jobs.append((L.PACK_DGRAD, c.w.data, c.wpd, 0, c.Cin))
-                if c.wp3 is not None:
-                    jobs.append((L.PACK_FWD_BF3, c.w.data, c.wp3, 0, c.Cin))
-                    jobs.append((L.PACK_DGRAD_BF3, c.w.data, c.wpd3, 0, c.Cin))
-                if c.wsk3 is not None:
-                    jobs.append((L.PACK_FWD_BF3, c.w.data, c.wsk3, c.up2[0], c.up2[1]))
-                    jobs.append((L.PACK_DGRAD_BF3, c.w.data, c.wds3, c.up2[0], c.up2[1]))
-                if c.wph3 is not None:
-                    jobs.append((L.PACK_UP2_FWD_BF3, c.w.data, c.wph3, 0, c.up2[0]))
-                    jobs.append((L.PACK_UP2_DGRAD_BF3, c.w.data, c.wdu3, 0, c.up2[0]))
-                if c.up2 is not None:
-                    C0, C1 = c.up2
-                    jobs.append((L.PACK_UP2_FWD, c.w.data, c.wph, 0, C0))
-                    jobs.append((L.PACK_UP2_DGRAD, c.w.data, c.wdu, 0, C0))
-                    if C1:
-                        jobs.append((L.PACK_FWD, c.w.data, c.wsk, C0, C1))
-                        jobs.append((L.PACK_DGRAD, c.w.data, c.wds, C0, C1))
-            self._pack_table = ops.build_pack_table(jobs, self.device)      # parameters live in self.flat: pointers are stable
-            self._pack_table_key = self.flat_param.data_ptr()
-        ops.pack_weights_batched(self._pack_table)
+            def jobs_of(convs):
+                jobs = []
+                for c in convs:
+                    jobs.append((L.PACK_STEM if c.stem else L.PACK_FWD, c.w.data, c.wp, 0, c.Cin))
+                    if c.wpd is not None:
+                        jobs.append((L.PACK_DGRAD, c.w.data, c.wpd, 0, c.Cin))
+                    if c.wp3 is not None:
+                        jobs.append((L.PACK_FWD_BF3, c.w.data, c.wp3, 0, c.Cin))
+                        jobs.append((L.PACK_DGRAD_BF3, c.w.data, c.wpd3, 0, c.Cin))
+                    if c.wsk3 is not None:
+                        jobs.append((L.PACK_FWD_BF3, c.w.data, c.wsk3, c.up2[0], c.up2[1]))
+                        jobs.append((L.PACK_DGRAD_BF3, c.w.data, c.wds3, c.up2[0], c.up2[1]))
+                    if c.wph3 is not None:
+                        jobs.append((L.PACK_UP2_FWD_BF3, c.w.data, c.wph3, 0, c.up2[0]))
+                        jobs.append((L.PACK_UP2_DGRAD_BF3, c.w.data, c.wdu3, 0, c.up2[0]))
+                    if c.up2 is not None:
+                        C0, C1 = c.up2
+                        jobs.append((L.PACK_UP2_FWD, c.w.data, c.wph, 0, C0))
+                        jobs.append((L.PACK_UP2_DGRAD, c.w.data, c.wdu, 0, C0))
+                        if C1:
+                            jobs.append((L.PACK_FWD, c.w.data, c.wsk, C0, C1))
+                            jobs.append((L.PACK_DGRAD, c.w.data, c.wds, C0, C1))
+                return jobs
+            # two launches: the stem and layer1 (0.2 M parameters) on the calling stream, everything else (31 M) on a side
+            # stream under the stem / layer1 kernels; the forward waits for it where layer2 starts (self._pack_ev)
+            first = [self.stem] + [c for blk in self.blocks if blk.Cout == 64 and blk.stride == 1 for c in (blk.c1, blk.c2)]
+            rest = [c for c in self.all_convs() if not any(c is f for f in first)]
+            self._pack_table = (ops.build_pack_table(jobs_of(first), self.device), ops.build_pack_table(jobs_of(rest), self.device))
+            self._pack_table_key = self.flat_param.data_ptr()      # parameters live in self.flat_param: pointers are stable
+        ops.pack_weights_batched(self._pack_table[0])
+        cur = ops.current_stream()
+        if self.concurrent and overlap:
+            self.wg.wait_event(self._record(cur))
+            with ops.on_stream(self.wg):
+                ops.pack_weights_batched(self._pack_table[1])
+                self._pack_ev = self._record(self.wg)
+        else:
+            ops.pack_weights_batched(self._pack_table[1])
+            self._pack_ev = None
         self._fold_ready = False
         self._versions = vers
         self.weights_dirty = False
@@ -375,6 +393,7 @@ class Engine:
         ops.maxpool_fwd(f0, pool, buf("pool.argmax", (N, hp, wp_, 64), torch.uint8))
         feats, dims = [f0], [(h, w)]
         x, h, w = pool, hp, wp_
+        self._wait_pack()          # the decoders' packed weights (the folded encoder copies are packed by _build_fold)
         for i, blk in enumerate(self.blocks):
             s = blk.stride
             oh, ow = (h - 1) // s + 1, (w - 1) // s + 1
@@ -393,6 +412,12 @@ class Engine:
                 dims.append((h, w))
         S["blocks"] = []
         S["feats"], S["dims"] = feats, dims
+
+    def _wait_pack(self):
+        """the side-stream part of the weight repack (everything after layer1) must have landed"""
+        if self._pack_ev is not None:
+            ops.current_stream().wait_event(self._pack_ev)
+            self._pack_ev = None
 
     def _conv_enc(self, c, x, N, H, W, out):
         OH, OW = (H + 2 * c.pad - c.K) // c.stride + 1, (W + 2 * c.pad - c.K) // c.stride + 1
@@ -436,7 +461,7 @@ class Engine:
         if not self.params_alias_flat():
             self._flatten()
             self.weights_dirty = True
-        self.refresh_packed()
+        self.refresh_packed(overlap=True)
         image = image.contiguous().float()
         S = {"N": N, "H": H, "W": W, "image": image, "training": training,
              "scales": set(range(4)) if scales is None else set(scales)}
@@ -463,6 +488,8 @@ class Engine:
         S["blocks"] = []
         for i, blk in enumerate(self.blocks):
             s = blk.stride
+            if s == 2:
+                self._wait_pack()
             oh, ow = (h - 1) // s + 1, (w - 1) // s + 1
             z1 = self._conv_enc(blk.c1, x, N, h, w, buf("b%d.z1" % i, (N, oh, ow, blk.Cout)))
             self._bn_coeffs(blk.bn1, z1, training)
