@@ -1,6 +1,8 @@
 // Fused multi-head loss (forward + backward in one pass), fused Adam, weight packing, column sums, the backward
 // of the virtual nearest-x2 + concat, and layout transforms.  All HBM-bound streaming kernels: one pass over the
 // data, float4 where the layout allows, fixed-order reductions (no atomics) so reruns are bit-stable.
+#include <hip/hip_fp16.h>
+
 #include "fp_common.h"
 
 namespace {
@@ -356,6 +358,26 @@ extern "C" int fp_scale_rows(const float* w, const float* scale, float* out, int
   hipLaunchKernelGGL(scale_rows_kernel, dim3(ew_grid((size_t)rows * inner)), dim3(256), 0, (hipStream_t)stream, w, scale, out,
                      (size_t)rows * inner, (int)inner);
   return fp_check_launch("fp_scale_rows");
+}
+
+// Test-set inference output (reference evaluation/inference.py:105-108 + datasets/inference_dataset.py:35-38): sigmoid on the two
+// mask channels (0, 1), depth channels (2, 3) unchanged, everything rounded to float16 (round-to-nearest-even == numpy astype).
+__global__ void __launch_bounds__(256) pack_pred_fp16_kernel(const float* __restrict__ pred, __half* __restrict__ out, size_t plane,
+                                                             size_t total) {
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int c = (int)((e / plane) & 3);
+    float v = pred[e];
+    if (c < 2) v = 1.f / (1.f + expf(-v));
+    out[e] = __float2half_rn(v);
+  }
+}
+
+extern "C" int fp_pack_pred_fp16(const float* pred_nchw, void* out_half, int32_t B, int32_t H, int32_t W, fp_stream_t stream) {
+  FP_REQUIRE(pred_nchw && out_half && B > 0 && H > 0 && W > 0, "fp_pack_pred_fp16: bad arguments");
+  const size_t plane = (size_t)H * W, total = plane * 4 * B;
+  hipLaunchKernelGGL(pack_pred_fp16_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, pred_nchw, (__half*)out_half, plane,
+                     total);
+  return fp_check_launch("fp_pack_pred_fp16");
 }
 
 extern "C" int64_t fp_colsum_workspace(int64_t M, int32_t C) {

@@ -431,6 +431,17 @@ def adam_step_dev(param, grad, exp_avg, exp_avg_sq, hyper_dev):
                                             stream()), "fp_adam_step_dev")
 
 
+def pack_pred_fp16(pred, out=None):
+    """[B,4,H,W] fp32 network output -> float16 with sigmoid on the mask channels (the test-set inference file format)"""
+    B, Cn, H, W = pred.shape
+    if Cn != 4:
+        raise RuntimeError("pack_pred_fp16 expects the 4-channel network output")
+    if out is None:
+        out = torch.empty((B, 4, H, W), dtype=torch.float16, device=pred.device)
+    _lib.check(_lib.load().fp_pack_pred_fp16(_f32(pred), _chk(out), B, H, W, stream()), "fp_pack_pred_fp16")
+    return out
+
+
 def nchw_to_nhwc(x, y=None):
     N, Cn, H, W = x.shape
     if y is None:

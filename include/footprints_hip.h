@@ -237,6 +237,10 @@ int fp_bn_bwd(const float* dy, const float* relu_out, const float* z, const floa
               const float* gamma, float* dz, float* g_out, float* dgamma, float* dbeta, int accumulate, int64_t M,
               int32_t C, void* workspace, int64_t workspace_bytes, fp_stream_t stream);
 
+/* ---- test-set inference output: [B][4][H][W] fp32 predictions -> float16 with sigmoid on channels 0, 1
+ * (reference evaluation/inference.py:105-108, datasets/inference_dataset.py:35-38) ---- */
+int fp_pack_pred_fp16(const float* pred_nchw, void* out_half, int32_t B, int32_t H, int32_t W, fp_stream_t stream);
+
 /* ---- maxpool 3x3 stride 2 pad 1 (encoder.maxpool, network.py:41) ---------- */
 int fp_maxpool_fwd(const float* x, float* y, uint8_t* argmax, int32_t N, int32_t H, int32_t W, int32_t C,
                    fp_stream_t stream);

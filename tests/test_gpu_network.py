@@ -11,6 +11,8 @@ conditioning, while its losses and post-Adam parameter sums stay at 1e-4.
 """
 from collections import OrderedDict
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -407,3 +409,26 @@ def test_inference_scales_subset():
         mm.model.inference_scales = ("1/1",)
         only = mm.model(img)
     assert list(only.keys()) == ["1/1"] and torch.equal(only["1/1"], full["1/1"])
+
+
+def test_inference_manager_test_batch_matches_reference_postprocessing(tmp_path):
+    """evaluation/inference.py:99-108 + inference_dataset.py:35-38: model(x)['1/1'] -> sigmoid on channels 0:2 -> float16"""
+    from footprints_amd.evaluation.inference import InferenceManager
+    from footprints_amd.model_manager import ModelManager
+    from footprints_amd.training.train import synthetic_batch
+    mm = ModelManager()
+    img = synthetic_batch(2, 64, 96, "cuda")["image"]
+    mm.model.eval()
+    with torch.no_grad():
+        ref = mm.model(img)["1/1"].clone()
+    ref[:, 0:2] = torch.sigmoid(ref[:, 0:2])
+    ref16 = ref.cpu().numpy().astype(np.float16)
+    im = InferenceManager(model_manager=mm, save_path=str(tmp_path))
+    got = im.test_batch({"image": img.cpu()})
+    assert got.dtype == np.float16 and got.shape == ref16.shape
+    assert np.array_equal(got[:, 2:], ref16[:, 2:])                                    # pure rounding: bit-exact
+    ulp = np.abs(got[:, :2].view(np.int16).astype(np.int32) - ref16[:, :2].view(np.int16).astype(np.int32))
+    assert ulp.max() <= 1                                                              # sigmoid: within one float16 ulp
+    im.save_result("frame0", got[0])
+    back = np.load(os.path.join(str(tmp_path), "frame0.npy"))
+    assert back.dtype == np.float16 and np.array_equal(back, got[0])
