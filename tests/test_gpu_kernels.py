@@ -580,10 +580,13 @@ def test_stem_wgrad():
 # ----------------------------------------------------------------------------------------------------------
 # heads
 # ----------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("Cin,scale,sig", [(16, 1, False), (16, 2, True), (32, 1, True), (64, 4, False), (128, 8, True), (64, 2, True)])
-def test_head_fwd_bwd(Cin, scale, sig):
+@pytest.mark.parametrize("Cin,scale,sig,hw", [(16, 1, False, (6, 10)), (16, 2, True, (6, 10)), (32, 1, True, (6, 10)),
+                                              (64, 4, False, (6, 10)), (128, 8, True, (6, 10)), (64, 2, True, (6, 10)),
+                                              (32, 1, True, (37, 70)), (64, 2, False, (21, 19)), (128, 8, True, (3, 5)),
+                                              (4, 4, True, (2, 2)), (8, 2, False, (2, 3)), (32, 3, True, (5, 4))])
+def test_head_fwd_bwd(Cin, scale, sig, hw):
     ops, L = _ops()
-    N, h, w = 2, 6, 10
+    N, (h, w) = 2, hw
     x = rnd((N, Cin, h, w), 36).requires_grad_(True)
     wt = rnd((2, Cin, 3, 3), 37, -0.2, 0.2).requires_grad_(True)
     b = rnd((2,), 38).requires_grad_(True)
@@ -608,6 +611,9 @@ def test_head_fwd_bwd(Cin, scale, sig):
     dx = torch.empty((N, h, w, Cin), device="cuda")
     ops.head_dgrad(dz, wt.detach().cuda(), dx)
     check(nchw(dx), x.grad, "head_dgrad")
+    ops.head_dgrad(dz, wt.detach().cuda(), dx, elu_src=xs)                 # fused ELU backward from the layer's OUTPUT
+    xc = x.detach()
+    check(nchw(dx), x.grad * torch.where(xc > 0, torch.ones_like(xc), xc + 1), "head_dgrad+elu")
     dw, db = torch.empty((2, Cin, 3, 3), device="cuda"), torch.empty((2,), device="cuda")
     ops.head_wgrad(xs, dz, dw, db)
     check(dw, wt.grad, "head_wgrad")
