@@ -21,6 +21,10 @@ Extra objects in the line:
                 duration is longer than its exclusive duration; `achieved_exclusive` / `frac_exclusive` are the same quantity
                 from extra steps (outside the timed region) with concurrency switched off -- the kernels' own speed.
   step_conv_tflops  the reference graph's conv FLOPs of one step (fwd + dgrad + wgrad) over the measured step time.
+  decoder_backward  SURVEY.md section 8(d): both decoders' backward alone (d loss / d outputs -> d loss / d features + all decoder
+                weight gradients) timed with HIP events, as achieved_hbm = 7.018 GB / t against 8 TB/s and achieved_mfma =
+                1023.9 GFLOP / t against the fp32 MFMA peak (the convolutions are MFMA-bound: F/B 72-755 vs a ridge of ~20).
+  step_ms       median / p10 / p90 of the GPU-side step durations inside the timed region.
   cpu_baseline  the CPU oracle (a restatement of the reference's PyTorch CPU path, kind "port") timed on this
                 box's host cores on a bounded sample of the same workload (rank 0, N = 1 only).
 """
@@ -38,6 +42,8 @@ sys.path.insert(0, ROOT)
 
 MFMA_F32_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
 BF16X6_PEAK_TFLOPS = 2500.0 / 6   # dense bf16 MFMA peak / 6 products per fp32-equivalent multiply-add (the split kernels' own roof)
+HBM_PEAK_GBS = 8000.0             # same guide: HBM3E peak
+DEC_BWD_GB, DEC_BWD_GFLOP = 7.018, 1023.9   # decoder backward, both decoders, KITTI bs=12 (fused-minimum bytes; dgrad + wgrad FLOPs)
 B, H, W = 12, 192, 640
 
 
@@ -258,15 +264,19 @@ def main():
             winst.install()
     ev_steps = min(args.steps, 4)          # event brackets on the first steps of the timed region only (host cost of
     barrier()                              # ~300 event records per step would otherwise perturb `value`)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # one record per step: GPU-side step durations
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(args.steps):
         if i == ev_steps:
             for x in (inst, winst):
                 if x is not None:
                     x.remove()
         step(batch)
+        marks[i + 1].record()
     barrier()
     dt = time.perf_counter() - t0
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     for x in (inst, winst):
         if x is not None:
             x.remove()
@@ -292,6 +302,29 @@ def main():
     dt = float(t.item())
     final_loss = float(step.losses[20])
 
+    # decoder backward alone: both decoders, from d loss / d outputs to d loss / d features plus all decoder
+    # weight gradients, HIP events around repeated runs on one saved forward (all five streams, joined inside the bracket)
+    dec_bwd = None
+    if rank == 0:
+        eng = step.eng
+        eng.forward(batch["image"], training=True, save_for_backward=True, outputs=step.outputs)
+        ops.loss_fwd_bwd(step.outputs, batch, step.losses, step.dpreds, step.depth_range, step.prior)
+        for _ in range(2):
+            eng.decoders_backward(step.dpreds)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(10):
+            eng.decoders_backward(step.dpreds)
+        e1.record()
+        torch.cuda.synchronize()
+        dec_ms = e0.elapsed_time(e1) / 10
+        dec_bwd = {"ms": round(dec_ms, 3), "algorithmic_gb": DEC_BWD_GB, "algorithmic_gflop": DEC_BWD_GFLOP,
+                   "achieved_hbm_gbs": round(DEC_BWD_GB / dec_ms * 1e3, 1), "frac_hbm_peak": round(DEC_BWD_GB / dec_ms * 1e3 / HBM_PEAK_GBS, 4),
+                   "achieved_tflops": round(DEC_BWD_GFLOP / dec_ms, 2), "frac_f32_mfma_peak": round(DEC_BWD_GFLOP / dec_ms / MFMA_F32_PEAK_TFLOPS, 4),
+                   "note": "fused-minimum bytes and reference-graph FLOPs of both decoders' backward (SURVEY.md section 8d), KITTI bs=12; "
+                           "time = HIP events around 10 repetitions after 2 warm-ups"}
+
     # forward-only latency (configs[1]): eval-mode, no_grad, batch 12
     mm.model.eval()
     with torch.no_grad():
@@ -314,7 +347,11 @@ def main():
                "config": {"workload": "KITTI 192x640 bs=12 full train step (fwd+loss+bwd+Adam), random-init weights, synthetic RGB + masks",
                           "per_gpu_batch": B, "global_batch": B * world, "height": H, "width": W,
                           "parallelism": "dp%d" % world if world > 1 else "single"},
-               "fwd_ms_per_img": round(fwd_ms_img, 4), "final_loss": round(final_loss, 5)}
+               "fwd_ms_per_img": round(fwd_ms_img, 4), "final_loss": round(final_loss, 5),
+               "step_ms": {"median": round(step_ms[len(step_ms) // 2], 3), "p10": round(step_ms[len(step_ms) // 10], 3),
+                           "p90": round(step_ms[min(len(step_ms) - 1, (len(step_ms) * 9) // 10)], 3),
+                           "note": "GPU-side durations between per-step HIP events inside the timed region (rank 0)"},
+               "decoder_backward": dec_bwd}
         gf_fwd, gf_step = network_conv_gflop(B, H, W)
         # whole-step figure: the reference graph's conv FLOPs (fwd + dgrad + wgrad) over the measured step time, i.e. including
         # every non-conv kernel, launch gap and the FLOPs the nearest-x2 phase decomposition does not execute

@@ -651,25 +651,7 @@ class Engine:
         gouts = [g.contiguous() for g in grad_outputs]
         dF = [buf("dF%d" % i, tuple(f.shape)) for i, f in enumerate(feats)]
         main = ops.current_stream()
-        if self.concurrent:
-            # mask decoder on the main stream, depth decoder on the aux stream; the depth decoder ACCUMULATES into the
-            # feature gradients, so each of its accumulate launches waits for the mask decoder's write of that level
-            self._ev_dF = [None] * 5
-            self.aux.wait_event(self._record(main))
-            self._interleave([(main, self._decoder_backward(self.decoders[0], S["dec"][0], S, gouts, dF, first=True, acc=accumulate)),
-                              (self.aux, self._decoder_backward(self.decoders[1], S["dec"][1], S, gouts, dF, first=False, acc=accumulate))])
-            main.wait_stream(self.aux)
-            if on_stage is not None:                 # data-parallel: the decoder stages are reduced now => join their weight gradients
-                main.wait_stream(self.dwg[0])
-                main.wait_stream(self.dwg[1])
-                on_stage(self.decoders[0].name)
-                on_stage(self.decoders[1].name)
-        else:
-            for di, dec in enumerate(self.decoders):
-                for _ in self._decoder_backward(dec, S["dec"][di], S, gouts, dF, first=(di == 0), acc=accumulate):
-                    pass
-                if on_stage is not None:
-                    on_stage(dec.name)
+        self._decoders_backward(S, gouts, dF, accumulate, on_stage)
         side = self.wg if self.concurrent else None
         # ---- encoder ----------------------------------------------------------------------------------
         nblk = len(self.blocks)
@@ -740,6 +722,43 @@ class Engine:
             main.wait_stream(self.dwg[1])
         if on_stage is not None:
             on_stage("encoder.layer0")
+
+    def _decoders_backward(self, S, gouts, dF, accumulate, on_stage, join=False):
+        """both decoders, from d loss / d outputs to the feature gradients dF[0..4] plus every decoder weight gradient"""
+        main = ops.current_stream()
+        if self.concurrent:
+            # mask decoder on the main stream, depth decoder on the aux stream; the depth decoder ACCUMULATES into the
+            # feature gradients, so each of its accumulate launches waits for the mask decoder's write of that level
+            self._ev_dF = [None] * 5
+            self.aux.wait_event(self._record(main))
+            self._interleave([(main, self._decoder_backward(self.decoders[0], S["dec"][0], S, gouts, dF, first=True, acc=accumulate)),
+                              (self.aux, self._decoder_backward(self.decoders[1], S["dec"][1], S, gouts, dF, first=False, acc=accumulate))])
+            main.wait_stream(self.aux)
+            if on_stage is not None or join:         # data-parallel: the decoder stages are reduced now => join their weight gradients
+                main.wait_stream(self.dwg[0])
+                main.wait_stream(self.dwg[1])
+            if on_stage is not None:
+                on_stage(self.decoders[0].name)
+                on_stage(self.decoders[1].name)
+        else:
+            for di, dec in enumerate(self.decoders):
+                for _ in self._decoder_backward(dec, S["dec"][di], S, gouts, dF, first=(di == 0), acc=accumulate):
+                    pass
+                if on_stage is not None:
+                    on_stage(dec.name)
+
+    def decoders_backward(self, grad_outputs):
+        """Measurement hook: the decoder backward alone -- both decoders, from d loss / d outputs to
+        d loss / d features plus all decoder weight gradients -- on the saved forward; every side stream is joined before it
+        returns to the caller's stream.  Idempotent: can be repeated on one saved forward."""
+        with ops.on_stream(torch.cuda.current_stream()):
+            S = self.saved
+            if S is None or not S["training"]:
+                raise RuntimeError("decoders_backward needs a saved training-mode forward")
+            gouts = [g.contiguous() for g in grad_outputs]
+            dF = [self.buf("dF%d" % i, tuple(f.shape)) for i, f in enumerate(S["feats"])]
+            self._decoders_backward(S, gouts, dF, False, None, join=True)
+            return dF
 
     @staticmethod
     def _interleave(jobs):
