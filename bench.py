@@ -208,7 +208,15 @@ def cpu_baseline(sample_b=2, steps=2):
     for _ in range(steps):
         tr.step(batch)
     dt = (time.time() - t0) / steps
+    # what the shipped trainer does (reference training/train.py:12-14 pins OMP/MKL to one thread): one batch-1 step
+    torch.set_num_threads(1)
+    t1 = time.time()
+    tr.step(R.make_batch(1, H, W, tag="bench.warm"))
+    dt1 = time.time() - t1
+    torch.set_num_threads(cores)
     return {"value": round(sample_b / dt, 4), "unit": "img/s", "cores": cores, "kind": "port",
+            "single_thread": {"value": round(1.0 / dt1, 4), "unit": "img/s", "cores": 1,
+                              "sample": "1 full train step at batch 1 with torch.set_num_threads(1), the reference trainer's own setting"},
             "sample": "%d timed full train steps (fwd+loss+bwd+Adam) of the CPU oracle at %dx%d, batch %d of the 12-image "
                       "workload, torch.set_num_threads(%d) = fastest of {8,16,32,64,%d} on this host (%d effective cores), "
                       "after 1 warm-up step" % (steps, H, W, sample_b, cores, eff, eff),

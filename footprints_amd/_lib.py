@@ -68,6 +68,8 @@ SIGNATURES = {
     "fp_adam_hyper": (C.c_int, [_D, _D, _D, _D, _I32, _D, _P]),
     "fp_adam_step_dev": (C.c_int, [_P, _P, _P, _P, _I64, _P, _P]),
     "fp_scale_rows": (C.c_int, [_P, _P, _P, _I64, _I64, _P]),
+    "fp_eval_mask_counts": (C.c_int, [_P, _I32, _P, _P, _I32, _I32, _I64, _I64, _P, _P]),
+    "fp_eval_depth_sums": (C.c_int, [_P, _I32, _P, _I32, _I64, _I64, C.c_double, C.c_double, C.c_double, C.c_double, _P, _P]),
     "fp_pack_pred_fp16": (C.c_int, [_P, _P, _I32, _I32, _I32, _P]),
     "fp_colsum_workspace": (_I64, [_I64, _I32]),
     "fp_colsum": (C.c_int, [_P, _I64, _I32, _P, C.c_int, _P, _I64, _P]),

@@ -442,6 +442,37 @@ def pack_pred_fp16(pred, out=None):
     return out
 
 
+def eval_mask_counts(pred, gt, region=None, invert=False):
+    """pred [B,H,W] float16/float32 (may be a channel slice of [B,4,H,W]), gt [B,H,W] float32, region [B,H,W] uint8 or None
+    -> int64 [B,4] = n_true, tp, fp, fn (evaluate_model.py:72-99 thresholds)"""
+    B = pred.shape[0]
+    pixels = pred.shape[1] * pred.shape[2]
+    if pred.dtype not in (torch.float16, torch.float32) or pred.stride(2) != 1 or pred.stride(1) != pred.shape[2]:
+        raise RuntimeError("eval_mask_counts: pred must be float16/float32 with contiguous images")
+    if region is not None and (region.dtype != torch.uint8 or tuple(region.shape) != tuple(gt.shape)):
+        raise RuntimeError("eval_mask_counts: region must be uint8 with the ground truth's shape")
+    if not pred.is_cuda:
+        raise RuntimeError("eval_mask_counts: pred must be a CUDA tensor (no CPU path in the product)")
+    counts = torch.empty((B, 4), dtype=torch.int64, device=pred.device)
+    _lib.check(_lib.load().fp_eval_mask_counts(pred.data_ptr(), int(pred.dtype == torch.float16), _f32(gt), _chk(region) if region is not None else None,
+                                               int(bool(invert)), B, pixels, pred.stride(0), _chk(counts), stream()), "fp_eval_mask_counts")
+    return counts
+
+
+def eval_depth_sums(disp, gt, min_depth=0.1, max_depth=100.0, clip=(0.5, 20.0)):
+    """disp [B,H,W] float16/float32 sigmoid output, gt [B,H,W] float32 -> float64 [B,5] = n, n(a1), sum sq, sum abs_rel, sum sq_rel"""
+    B = disp.shape[0]
+    pixels = disp.shape[1] * disp.shape[2]
+    if disp.dtype not in (torch.float16, torch.float32) or disp.stride(2) != 1 or disp.stride(1) != disp.shape[2]:
+        raise RuntimeError("eval_depth_sums: disp must be float16/float32 with contiguous images")
+    if not disp.is_cuda:
+        raise RuntimeError("eval_depth_sums: disp must be a CUDA tensor (no CPU path in the product)")
+    sums = torch.empty((B, 5), dtype=torch.float64, device=disp.device)
+    _lib.check(_lib.load().fp_eval_depth_sums(disp.data_ptr(), int(disp.dtype == torch.float16), _f32(gt), B, pixels, disp.stride(0), float(min_depth),
+                                              float(max_depth), float(clip[0]), float(clip[1]), _chk(sums), stream()), "fp_eval_depth_sums")
+    return sums
+
+
 def nchw_to_nhwc(x, y=None):
     N, Cn, H, W = x.shape
     if y is None:

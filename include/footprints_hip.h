@@ -241,6 +241,15 @@ int fp_bn_bwd(const float* dy, const float* relu_out, const float* z, const floa
  * (reference evaluation/inference.py:105-108, datasets/inference_dataset.py:35-38) ---- */
 int fp_pack_pred_fp16(const float* pred_nchw, void* out_half, int32_t B, int32_t H, int32_t W, fp_stream_t stream);
 
+/* ---- test-set metrics (reference evaluation/evaluate_model.py:50-99 evaluate_depth / evaluate_mask, :160-177 call sites).
+ * pred: float32 or float16 (pred_is_half) images, image b at pred + b * pred_stride elements; gt: float32 [B][pixels];
+ * region: optional uint8 [B][pixels] (pixels with 0 are skipped); invert = 1 evaluates (1 - gt, 1 - pred) like the footprint score.
+ * counts: int64 [B][4] = n_true, tp, fp, fn.   sums: float64 [B][5] = n, n(thresh < 1.25), sum sq, sum abs_rel, sum sq_rel over gt > 0. */
+int fp_eval_mask_counts(const void* pred, int32_t pred_is_half, const float* gt, const uint8_t* region, int32_t invert, int32_t B,
+                        int64_t pixels, int64_t pred_stride, int64_t* counts, fp_stream_t stream);
+int fp_eval_depth_sums(const void* pred_disp, int32_t pred_is_half, const float* gt, int32_t B, int64_t pixels, int64_t pred_stride,
+                       double min_depth, double max_depth, double clip_min, double clip_max, double* sums, fp_stream_t stream);
+
 /* ---- maxpool 3x3 stride 2 pad 1 (encoder.maxpool, network.py:41) ---------- */
 int fp_maxpool_fwd(const float* x, float* y, uint8_t* argmax, int32_t N, int32_t H, int32_t W, int32_t C,
                    fp_stream_t stream);

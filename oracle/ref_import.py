@@ -50,3 +50,22 @@ def load_reference():
         else:
             os.environ[k] = v
     return network, losses
+
+
+def load_reference_metrics():
+    """-> the reference's footprints.evaluation.evaluate_model module, or None when /root/reference is absent.
+    Its import needs cv2 (stand-in above), tqdm (installed) and skimage.morphology.convex_hull_image (only used by the
+    Matterport convex-hull helper, never by evaluate_mask / evaluate_depth): a module object that raises if called."""
+    if load_reference() is None:
+        return None
+    if "skimage" not in sys.modules:
+        sk = types.ModuleType("skimage")
+        skm = types.ModuleType("skimage.morphology")
+
+        def convex_hull_image(im):
+            raise RuntimeError("skimage is not installed")
+        skm.convex_hull_image = convex_hull_image
+        sk.morphology = skm
+        sys.modules["skimage"] = sk
+        sys.modules["skimage.morphology"] = skm
+    return importlib.import_module("footprints.evaluation.evaluate_model")

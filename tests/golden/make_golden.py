@@ -199,15 +199,48 @@ def g6_predict(net):
     return out
 
 
+def g7_metrics():
+    """evaluation/evaluate_model.py: the per-image scores of evaluate() (:160-177) from the reference's own evaluate_mask /
+    evaluate_depth / sigmoid_to_depth, on float16 predictions (what the inference pass saves) and on float32 ones."""
+    from tests.golden.metrics_inputs import DEPTH_KEYS, MASK_KEYS, N, metrics_inputs
+    em = ref_import.load_reference_metrics()
+    out = {}
+    for dt in (np.float16, np.float32):
+        pred, gt_kitti, gt_mp, free, gt_depth = metrics_inputs(dt)
+        tag = np.dtype(dt).name
+        for flavour, gt in (("kitti", gt_kitti), ("matterport", gt_mp)):
+            fs = np.zeros((N, 4)); fpt = np.zeros((N, 4))
+            for i in range(N):
+                p = pred[i][em.HIDDEN_GROUND]                                           # evaluate_model.py:161-163
+                a = em.evaluate_mask(gt[i], p)                                          # :166
+                b = em.evaluate_mask(1 - gt[i][free[i]], 1 - p[free[i]])                # :167
+                fs[i] = [a[k] for k in MASK_KEYS]
+                fpt[i] = [b[k] for k in MASK_KEYS]
+            out["%s.%s.freespace" % (tag, flavour)] = fs
+            out["%s.%s.footprint" % (tag, flavour)] = fpt
+        dd = np.zeros((N, 4))
+        for i in range(N):
+            p = em.sigmoid_to_depth(pred[i][em.HIDDEN_DEPTH])                           # :171-172
+            mask = gt_depth[i] > 0                                                      # :174
+            r = em.evaluate_depth(gt_depth[i][mask], p[mask])                           # :175
+            dd[i] = [r[k] for k in DEPTH_KEYS]
+        out["%s.depth" % tag] = dd
+    return out
+
+
 def main():
     mods = ref_import.load_reference()
     assert mods is not None, "needs /root/reference"
     net, loss_mod = mods
     torch.set_num_threads(8)
     os.makedirs(GOLDEN_DIR, exist_ok=True)
+    only = sys.argv[1:]
     for name, fn in (("g1_blocks", lambda: g1_blocks(net)), ("g2_decoder", lambda: g2_decoder(net)),
                      ("g3_network", lambda: g3_network(net)), ("g4_loss", lambda: g4_loss(loss_mod)),
-                     ("g5_train", lambda: g5_train(net, loss_mod)), ("g6_predict", lambda: g6_predict(net))):
+                     ("g5_train", lambda: g5_train(net, loss_mod)), ("g6_predict", lambda: g6_predict(net)),
+                     ("g7_metrics", g7_metrics)):
+        if only and name not in only:
+            continue
         d = fn()
         path = os.path.join(GOLDEN_DIR, name + ".npz")
         np.savez_compressed(path, **d)

@@ -52,7 +52,7 @@ def _worker(rank, world, port, q):
     for stage in ("mask_decoder", "depth_decoder", "encoder.layer4", "encoder.layer3"):   # reported by the schedule
         red.stage_ready(stage)
     red.finish()                                                                           # flushes the rest
-    q.put((rank, (flat * red.grad_scale).clone()))
+    q.put((rank, (flat * red.grad_scale).numpy()))        # by value: a shared-memory tensor handle can outlive its sender (flaky ConnectionResetError)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -64,7 +64,7 @@ def test_two_rank_gradient_mean_matches_shard_oracle():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=300) for _ in range(2))
+    res = {r: torch.from_numpy(a) for r, a in (q.get(timeout=300) for _ in range(2))}
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0

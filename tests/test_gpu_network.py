@@ -432,3 +432,31 @@ def test_inference_manager_test_batch_matches_reference_postprocessing(tmp_path)
     im.save_result("frame0", got[0])
     back = np.load(os.path.join(str(tmp_path), "frame0.npy"))
     assert back.dtype == np.float16 and np.array_equal(back, got[0])
+
+
+@pytest.mark.parametrize("dt", [np.float16, np.float32])
+def test_g7_device_metrics_match_reference_scores(dt):
+    """evaluation/evaluate_model.py: per-image IoU / precision / recall / F1 from the device confusion counts are EXACTLY the
+    reference's (same integers), depth errors within float32-summation noise of the reference's numpy means"""
+    from footprints_amd.evaluation import evaluate_model as EM
+    from tests.golden.metrics_inputs import DEPTH_KEYS, MASK_KEYS, N, metrics_inputs
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g7_metrics.npz"))
+    pred, gt_kitti, gt_mp, free, gt_depth = metrics_inputs(dt)
+    tag = np.dtype(dt).name
+    for flavour, gt in (("kitti", gt_kitti), ("matterport", gt_mp)):
+        scores = EM.mask_scores(pred, gt, free)
+        for i in range(N):
+            np.testing.assert_array_equal(np.array([scores[i]["freespace"][k] for k in MASK_KEYS], np.float64), g["%s.%s.freespace" % (tag, flavour)][i])
+            np.testing.assert_array_equal(np.array([scores[i]["footprint"][k] for k in MASK_KEYS], np.float64), g["%s.%s.footprint" % (tag, flavour)][i])
+        ref = {"freespace_iou": np.nanmean(g["%s.%s.freespace" % (tag, flavour)][:, 0]), "footprint_f1": np.nanmean(g["%s.%s.footprint" % (tag, flavour)][:, 3])}
+        summ = EM.summarise(scores, "iou")
+        assert summ["freespace_iou"] == ref["freespace_iou"] and summ["footprint_f1"] == ref["footprint_f1"]
+    dscores = EM.depth_scores(pred, gt_depth)
+    want = g["%s.depth" % tag]
+    for i in range(N):
+        got = np.array([dscores[i][k] for k in DEPTH_KEYS], np.float64)
+        if np.isnan(want[i]).all():
+            assert np.isnan(got).all()
+        else:
+            assert got[0] == want[i][0]                                       # a1 is a count ratio: exact
+            np.testing.assert_allclose(got[1:], want[i][1:], rtol=1e-5)       # the reference's numpy means accumulate in float32, the device sums in float64

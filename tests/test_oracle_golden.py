@@ -4,6 +4,7 @@ Runs without /root/reference (the fixtures were generated from it by
 tests/golden/make_golden.py).  Tolerances: 1e-4 relative to the tensor's max
 (north_star: "within 1e-4 rel fp32"); in practice the restatement is bit-exact.
 """
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -179,3 +180,22 @@ def test_state_spec_counts():
     n_live = sum(int(np.prod(s[1])) for s in params if not R.is_dead_param(s[0]))
     assert n_all == 31021392 and n_live == 31012944
     assert sum(1 for s in params if not R.is_dead_param(s[0])) == 196
+
+
+def test_g7_metrics_oracle_reproduces_reference_scores():
+    """oracle/metrics.py (restatement of evaluation/evaluate_model.py) == the reference's own per-image scores, exactly"""
+    from oracle import metrics as M
+    from tests.golden.metrics_inputs import DEPTH_KEYS, MASK_KEYS, N, metrics_inputs
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g7_metrics.npz"))
+    for dt in (np.float16, np.float32):
+        pred, gt_kitti, gt_mp, free, gt_depth = metrics_inputs(dt)
+        tag = np.dtype(dt).name
+        for flavour, gt in (("kitti", gt_kitti), ("matterport", gt_mp)):
+            for i in range(N):
+                s = M.score_image(pred[i], gt[i], free[i], "iou")
+                np.testing.assert_array_equal(np.array([s["freespace"][k] for k in MASK_KEYS], np.float64), g["%s.%s.freespace" % (tag, flavour)][i])
+                np.testing.assert_array_equal(np.array([s["footprint"][k] for k in MASK_KEYS], np.float64), g["%s.%s.footprint" % (tag, flavour)][i])
+        for i in range(N):
+            s = M.score_image(pred[i], gt_depth[i], None, "depth")
+            np.testing.assert_array_equal(np.array([s[k] for k in DEPTH_KEYS], np.float64), g["%s.depth" % tag][i])
+    assert np.isnan(g["float16.kitti.freespace"][4]).all() and np.isnan(g["float16.depth"][5]).all()      # the nan cases are in the fixture
