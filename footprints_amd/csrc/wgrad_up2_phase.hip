@@ -113,6 +113,155 @@ __global__ void __launch_bounds__(256) wgrad_up2_phase_kernel(const PWArgs a) {
     }
 }
 
+// ---- the same gradient with exactly split bf16x3 operands (see wgrad3x3_bf3.hip for the scheme) -------------------------------
+// Contraction over pixels => both operands are transposed to "8 consecutive low-res columns of one channel" and split into three
+// bf16 planes on their way into LDS (thread = 4 columns x 4 channels).  Chunk = 2 x 16 low-res positions:
+//     Xs[plane][halo row 4][ci 32][20 cols, 48-byte lines]      Zs[plane][phase 4][row 2][co 32][16 cols, 32-byte lines]   (43 KB)
+// Wave p owns phase p = (dy, dx): per chunk row one 16-column k-step per tap (a, b), the tap's operand being halo row
+// r + dy + a shifted by dx + b columns (funnel shift of the aligned read), six v_mfma_f32_32x32x16_bf16 each: 48 MFMAs x 32 cycles
+// per wave per chunk instead of 64 x 64.  No cross-wave sum (a wave writes its own four tap tiles); same partial layout as above.
+typedef __bf16 pbf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 pbf16x4 __attribute__((ext_vector_type(4)));
+typedef float pf32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int PXROW = 48, PZROW = 32;
+constexpr int PXPLANE = XR * 32 * PXROW, PZPLANE = 4 * CHL * 32 * PZROW;      // 6144, 8192 bytes
+
+__device__ __forceinline__ void psplit_store(unsigned char* p, int plane_stride, const pf32x4 v) {
+  const pbf16x4 vh = __builtin_convertvector(v, pbf16x4);
+  const pf32x4 r1 = v - __builtin_convertvector(vh, pf32x4);
+  const pbf16x4 vm = __builtin_convertvector(r1, pbf16x4);
+  const pf32x4 r2 = r1 - __builtin_convertvector(vm, pf32x4);
+  const pbf16x4 vl = __builtin_convertvector(r2, pbf16x4);
+  *reinterpret_cast<uint2*>(p) = __builtin_bit_cast(uint2, vh);
+  *reinterpret_cast<uint2*>(p + plane_stride) = __builtin_bit_cast(uint2, vm);
+  *reinterpret_cast<uint2*>(p + 2 * plane_stride) = __builtin_bit_cast(uint2, vl);
+}
+
+__global__ void __launch_bounds__(256, 3) wgrad_up2_phase_bf3_kernel(const PWArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[3 * (PXPLANE + PZPLANE)];
+  unsigned char* const Xs = lds;
+  unsigned char* const Zs = lds + 3 * PXPLANE;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, idx = lane & 31, h = lane >> 5;
+  int b = blockIdx.x;
+  const int cot = b % a.cotiles; b /= a.cotiles;
+  const int cit = b % a.citiles; b /= a.citiles;
+  const int s = b;
+  const int ci0 = cit * 32, co0 = cot * 32;
+  const int c_begin = s * a.chunksPerSplit;
+  const int c_end = min(a.nchunks, c_begin + a.chunksPerSplit);
+  const int H2 = 2 * a.h, W2 = 2 * a.w;
+  const int dy = wave >> 1, dx = wave & 1;
+  const unsigned dxm = 0u - (unsigned)dx;
+
+  // staging items: X: (halo row, column group of 4, channel quad) for t < 160;  dZ: (phase = wave, row, column group, channel quad)
+  const int q = t & 7;
+  const int xcg = (t >> 3) % 5, xhr = t / 40;
+  const int zcg = (t >> 3) & 3, zr = (t >> 5) & 1;
+  const bool xitem = t < 160;
+  float4 xr[4], zv[4];
+  unsigned zmask = 0;                 // bit j: position j of the group lies inside the image (else its dZ is stored as zero)
+
+  auto issue = [&](int c) {
+    const int cx = c % a.chunksX;
+    const int r = c / a.chunksX;
+    const int cy = r % a.chunksY, n = r / a.chunksY;
+    const int y0 = cy * CHL, x0 = cx * CW;
+    {
+      const int sy = min(max(y0 + xhr - 1, 0), a.h - 1);                          // replicate padding (threads >= 160 load too, unused)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int sx = min(max(x0 + xcg * 4 + j - 1, 0), a.w - 1);
+        xr[j] = *reinterpret_cast<const float4*>(a.low + ((size_t)(n * a.h + sy) * a.w + sx) * a.C0 + ci0 + q * 4);
+      }
+    }
+    zmask = 0;
+    const int ly = y0 + zr;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int lx = x0 + zcg * 4 + j;
+      const bool ok = ly < a.h && lx < a.w;
+      const int hy = 2 * min(ly, a.h - 1) + dy, hx = 2 * min(lx, a.w - 1) + dx;
+      zv[j] = *reinterpret_cast<const float4*>(a.dz + ((size_t)(n * H2 + hy) * W2 + hx) * a.Nout + co0 + q * 4);
+      zmask |= ok ? (1u << j) : 0u;
+    }
+  };
+  auto stage = [&]() {
+    if (xitem) {
+      unsigned char* p = Xs + (xhr * 32 + q * 4) * PXROW + xcg * 8;
+      psplit_store(p, PXPLANE, pf32x4{xr[0].x, xr[1].x, xr[2].x, xr[3].x});
+      psplit_store(p + PXROW, PXPLANE, pf32x4{xr[0].y, xr[1].y, xr[2].y, xr[3].y});
+      psplit_store(p + 2 * PXROW, PXPLANE, pf32x4{xr[0].z, xr[1].z, xr[2].z, xr[3].z});
+      psplit_store(p + 3 * PXROW, PXPLANE, pf32x4{xr[0].w, xr[1].w, xr[2].w, xr[3].w});
+    }
+    {
+      unsigned char* p = Zs + ((wave * CHL + zr) * 32 + q * 4) * PZROW + zcg * 8;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (!(zmask & (1u << j))) zv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      psplit_store(p, PZPLANE, pf32x4{zv[0].x, zv[1].x, zv[2].x, zv[3].x});
+      psplit_store(p + PZROW, PZPLANE, pf32x4{zv[0].y, zv[1].y, zv[2].y, zv[3].y});
+      psplit_store(p + 2 * PZROW, PZPLANE, pf32x4{zv[0].z, zv[1].z, zv[2].z, zv[3].z});
+      psplit_store(p + 3 * PZROW, PZPLANE, pf32x4{zv[0].w, zv[1].w, zv[2].w, zv[3].w});
+    }
+  };
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int tp = 0; tp < 4; ++tp)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[tp][r] = 0.f;
+
+  if (c_begin < c_end) {
+    issue(c_begin);
+    stage();
+  }
+  __syncthreads();
+  for (int c = c_begin; c < c_end; ++c) {
+    if (c + 1 < c_end) issue(c + 1);                 // next chunk's global loads fly under this chunk's MFMAs
+#pragma unroll
+    for (int r = 0; r < CHL; ++r) {
+      uint4 bz[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) bz[p] = *reinterpret_cast<const uint4*>(Zs + p * PZPLANE + ((wave * CHL + r) * 32 + idx) * PZROW + h * 16);
+#pragma unroll
+      for (int ta = 0; ta < 2; ++ta) {
+        uint4 a0[3], a1[3];             // taps b = 0, 1: halo columns shifted by dx, dx + 1
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          const unsigned char* row = Xs + p * PXPLANE + ((r + dy + ta) * 32 + idx) * PXROW + h * 16;
+          const uint4 d = *reinterpret_cast<const uint4*>(row);                  // columns 8h .. 8h+7
+          const unsigned e = *reinterpret_cast<const unsigned*>(row + 16);       // columns 8h+8, 8h+9
+          const uint4 s1 = make_uint4(__builtin_amdgcn_alignbit(d.y, d.x, 16), __builtin_amdgcn_alignbit(d.z, d.y, 16),
+                                      __builtin_amdgcn_alignbit(d.w, d.z, 16), __builtin_amdgcn_alignbit(e, d.w, 16));
+          const uint4 s2 = make_uint4(d.y, d.z, d.w, e);
+          // wave-uniform choice by bit-select (a ?: on whole vectors was compiled to a scratch-memory indexed select)
+          a0[p] = make_uint4((s1.x & dxm) | (d.x & ~dxm), (s1.y & dxm) | (d.y & ~dxm), (s1.z & dxm) | (d.z & ~dxm), (s1.w & dxm) | (d.w & ~dxm));
+          a1[p] = make_uint4((s2.x & dxm) | (s1.x & ~dxm), (s2.y & dxm) | (s1.y & ~dxm), (s2.z & dxm) | (s1.z & ~dxm), (s2.w & dxm) | (s1.w & ~dxm));
+        }
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int qq = 0; qq < 6; ++qq) {
+          const pbf16x8 bb = __builtin_bit_cast(pbf16x8, bz[PB[qq]]);
+          acc[ta * 2 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(pbf16x8, a0[PA[qq]]), bb, acc[ta * 2 + 0], 0, 0, 0);
+          acc[ta * 2 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(pbf16x8, a1[PA[qq]]), bb, acc[ta * 2 + 1], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();                                  // every wave has read this chunk
+    if (c + 1 < c_end) stage();
+    __syncthreads();                                  // next chunk visible
+  }
+  float* out = a.part + ((size_t)s * 16 + wave * 4) * a.C0 * a.Nout;
+#pragma unroll
+  for (int tp = 0; tp < 4; ++tp)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ci = ci0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      out[((size_t)tp * a.C0 + ci) * a.Nout + co0 + idx] = acc[tp][r];
+    }
+}
+
 // stage 1: part[0][e] = sum_s part[s][e] (in place; a thread only ever touches its own e).  64 elements x 4 s-groups per block,
 // four loads in flight per thread, fixed combination order.
 __global__ void __launch_bounds__(256) up2_wgrad_sum_kernel(float* __restrict__ part, int S, size_t total) {
@@ -183,9 +332,9 @@ extern "C" int64_t fp_conv_up2_phase_wgrad_workspace(int32_t N, int32_t h, int32
   return (int64_t)p.S * 16 * C0 * Nout * (int64_t)sizeof(float);
 }
 
-extern "C" int fp_conv_up2_phase_wgrad(const float* low, const float* dz, float* dw_oihw, int32_t N, int32_t h, int32_t w, int32_t C0,
-                                       int32_t Nout, int32_t kc_total, int32_t k_begin, int accumulate, void* workspace,
-                                       int64_t workspace_bytes, fp_stream_t stream_) {
+static int phase_wgrad_launch(bool bf3, const float* low, const float* dz, float* dw_oihw, int32_t N, int32_t h, int32_t w, int32_t C0,
+                              int32_t Nout, int32_t kc_total, int32_t k_begin, int accumulate, void* workspace,
+                              int64_t workspace_bytes, fp_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   FP_REQUIRE(low && dz && dw_oihw && workspace, "fp_conv_up2_phase_wgrad: null pointer");
   FP_REQUIRE(eligible(N, h, w, C0, Nout), "fp_conv_up2_phase_wgrad: shape not supported (see fp_conv_up2_phase_wgrad_workspace)");
@@ -197,7 +346,8 @@ extern "C" int fp_conv_up2_phase_wgrad(const float* low, const float* dz, float*
   a.N = N; a.h = h; a.w = w; a.C0 = C0; a.Nout = Nout;
   a.chunksY = p.cy; a.chunksX = p.cx; a.nchunks = p.nchunks; a.chunksPerSplit = p.chunksPerSplit; a.S = p.S;
   a.citiles = p.citiles; a.cotiles = p.cotiles;
-  hipLaunchKernelGGL(wgrad_up2_phase_kernel, dim3(p.S * p.citiles * p.cotiles), dim3(256), 0, stream, a);
+  if (bf3) hipLaunchKernelGGL(wgrad_up2_phase_bf3_kernel, dim3(p.S * p.citiles * p.cotiles), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL(wgrad_up2_phase_kernel, dim3(p.S * p.citiles * p.cotiles), dim3(256), 0, stream, a);
   int rc = fp_check_launch("fp_conv_up2_phase_wgrad");
   if (rc) return rc;
   const size_t tot16 = (size_t)16 * C0 * Nout;
@@ -211,4 +361,17 @@ extern "C" int fp_conv_up2_phase_wgrad(const float* low, const float* dz, float*
   hipLaunchKernelGGL(up2_wgrad_uncollapse_kernel, dim3(rgrid), dim3(256), 0, stream, (const float*)workspace, dw_oihw, C0, Nout, kc_total,
                      k_begin, accumulate);
   return fp_check_launch("fp_conv_up2_phase_wgrad(uncollapse)");
+}
+
+extern "C" int fp_conv_up2_phase_wgrad(const float* low, const float* dz, float* dw_oihw, int32_t N, int32_t h, int32_t w, int32_t C0,
+                                       int32_t Nout, int32_t kc_total, int32_t k_begin, int accumulate, void* workspace,
+                                       int64_t workspace_bytes, fp_stream_t stream) {
+  return phase_wgrad_launch(false, low, dz, dw_oihw, N, h, w, C0, Nout, kc_total, k_begin, accumulate, workspace, workspace_bytes, stream);
+}
+
+// same contract, operands split exactly into three bf16 terms (six bf16 MFMA products, fp32 accumulate)
+extern "C" int fp_conv_up2_phase_wgrad_bf3(const float* low, const float* dz, float* dw_oihw, int32_t N, int32_t h, int32_t w, int32_t C0,
+                                           int32_t Nout, int32_t kc_total, int32_t k_begin, int accumulate, void* workspace,
+                                           int64_t workspace_bytes, fp_stream_t stream) {
+  return phase_wgrad_launch(true, low, dz, dw_oihw, N, h, w, C0, Nout, kc_total, k_begin, accumulate, workspace, workspace_bytes, stream);
 }

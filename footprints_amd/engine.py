@@ -31,6 +31,7 @@ _FOLD = not bool(int(os.environ.get("FP_NO_FOLD", "0")))
 # exactly split bf16x3 operands for the 3x3 stride-1 tile kernel (conv3x3_tile_bf3.hip); FP_NO_BF3=1 keeps the fp32 MFMA
 _BF3 = not bool(int(os.environ.get("FP_NO_BF3", "0")))
 _WBF3 = _BF3 and not bool(int(os.environ.get("FP_NO_WBF3", "0")))      # ... and for the weight-gradient kernel
+_PWBF3 = not bool(int(os.environ.get("FP_NO_PHASE_WBF3", "0")))           # ... and for the phase weight-gradient kernel (A/B switch)
 # nearest-x2 phase decomposition of the upsample convs (conv_up2_phase.hip); FP_NO_PHASE=1 keeps the fused-gather path.
 _PHASE = not bool(int(os.environ.get("FP_NO_PHASE", "0")))
 
@@ -603,7 +604,7 @@ class Engine:
             return self._wgrad(c, L.GATHER_FWD_REFLECT_UP2, low, skip, dz, N, H, W, H, W, C0, C1, acc, side)
 
         def launch():
-            ops.conv_up2_phase_wgrad(low, dz, c.gw, 0, accumulate=acc)
+            ops.conv_up2_phase_wgrad(low, dz, c.gw, 0, accumulate=acc, bf3=_WBF3 and _PWBF3)
             if C1:
                 d = ops.make_desc(N, H, W, H, W, C1, 0, c.Cout, 3, 1, 1, L.GATHER_FWD_REFLECT)
                 if _WBF3 and ops.conv_wgrad_bf3_supported(d):

@@ -179,7 +179,7 @@ def up2_phase_wgrad_supported(N, h, w, C0, Nout):
     return _lib.load().fp_conv_up2_phase_wgrad_workspace(N, h, w, C0, Nout) >= 0
 
 
-def conv_up2_phase_wgrad(low, dz, dw, k_begin=0, accumulate=False):
+def conv_up2_phase_wgrad(low, dz, dw, k_begin=0, accumulate=False, bf3=False):
     lib = _lib.load()
     N, h, w, C0 = low.shape
     Nout = dz.shape[3]
@@ -187,8 +187,9 @@ def conv_up2_phase_wgrad(low, dz, dw, k_begin=0, accumulate=False):
     if need < 0:
         raise RuntimeError("fp_conv_up2_phase_wgrad: shape not supported")
     ws = workspace(need, dz.device)
-    _lib.check(lib.fp_conv_up2_phase_wgrad(_f32(low), _f32(dz), _f32(dw), N, h, w, C0, Nout, dw.shape[1], k_begin,
-                                           int(bool(accumulate)), ws.data_ptr(), ws.numel(), stream()), "fp_conv_up2_phase_wgrad")
+    fn = lib.fp_conv_up2_phase_wgrad_bf3 if bf3 else lib.fp_conv_up2_phase_wgrad
+    _lib.check(fn(_f32(low), _f32(dz), _f32(dw), N, h, w, C0, Nout, dw.shape[1], k_begin, int(bool(accumulate)), ws.data_ptr(), ws.numel(),
+                  stream()), "fp_conv_up2_phase_wgrad")
     return dw
 
 

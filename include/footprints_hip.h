@@ -181,6 +181,10 @@ int64_t fp_conv_up2_phase_wgrad_workspace(int32_t N, int32_t h, int32_t w, int32
 int fp_conv_up2_phase_wgrad(const float* low, const float* dz, float* dw_oihw, int32_t N, int32_t h, int32_t w, int32_t C0,
                             int32_t Nout, int32_t kc_total, int32_t k_begin, int accumulate, void* workspace,
                             int64_t workspace_bytes, fp_stream_t stream);
+/* same contract and workspace; fp32 operands split exactly into three bf16 terms, six bf16 MFMA products (error below the fp32 MFMA's) */
+int fp_conv_up2_phase_wgrad_bf3(const float* low, const float* dz, float* dw_oihw, int32_t N, int32_t h, int32_t w, int32_t C0,
+                                int32_t Nout, int32_t kc_total, int32_t k_begin, int accumulate, void* workspace,
+                                int64_t workspace_bytes, fp_stream_t stream);
 
 /* column sums: out[c] (+)= sum_m x[m][c]  -- conv bias gradient (weight half of convolution_backward) */
 int64_t fp_colsum_workspace(int64_t M, int32_t C);

@@ -144,6 +144,8 @@ if which == "up2bwd":
                 ("wgrad-4x4s2", lambda: ops.conv_wgrad(d, dz, None, lowx, dk4))]
         if ops.up2_phase_wgrad_supported(N, h, w_, C0, Nout):
             runs.append(("wgrad-phase", lambda: ops.conv_up2_phase_wgrad(lo, dz, dwo, 0)))
+            if hasattr(ops._lib.load(), "fp_conv_up2_phase_wgrad_bf3"):
+                runs.append(("wgrad-phase-bf3", lambda: ops.conv_up2_phase_wgrad(lo, dz, dwo, 0, bf3=True)))
         if C1:
             wps = ops.pack_conv_weight_dgrad(wo[:, C0:].contiguous(), torch.empty(ops.packed_weight_elems(Nout, C1, 3, True), device=dev))
             d_s = ops.make_desc(N, 2 * h, 2 * w_, 2 * h, 2 * w_, Nout, 0, C1, 3, 1, 1, L.GATHER_DGRAD_REFLECT)

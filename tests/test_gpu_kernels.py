@@ -203,10 +203,11 @@ def test_up2_phase_dgrad(N, h, w, C0, C1, Cout):
         check(nchw(dsk), skip.grad, "up2 phase dgrad (skip)")
 
 
+@pytest.mark.parametrize("bf3", [False, True])
 @pytest.mark.parametrize("N,h,w,C0,C1,Cout,acc", [
     (2, 24, 80, 64, 64, 64, False), (2, 12, 48, 32, 32, 32, True), (1, 48, 160, 64, 0, 32, False), (4, 7, 16, 32, 64, 96, True),
-    (16, 2, 16, 32, 0, 32, False), (1, 96, 320, 64, 0, 32, True)])
-def test_up2_phase_wgrad(N, h, w, C0, C1, Cout, acc):
+    (16, 2, 16, 32, 0, 32, False), (1, 96, 320, 64, 0, 32, True), (3, 6, 27, 64, 0, 64, False)])
+def test_up2_phase_wgrad(N, h, w, C0, C1, Cout, acc, bf3):
     """weight gradient: upsampled half by phase (wgrad_up2_phase.hip), skip half as a slice of the same OIHW gradient"""
     ops, L = _ops()
     wt = rnd((Cout, C0 + C1, 3, 3), 320, -0.1, 0.1).requires_grad_(True)
@@ -219,7 +220,7 @@ def test_up2_phase_wgrad(N, h, w, C0, C1, Cout, acc):
     init = rnd((Cout, C0 + C1, 3, 3), 324) if acc else torch.full((Cout, C0 + C1, 3, 3), float("nan"))
     dw = init.clone().cuda()
     gz = nhwc(g)
-    ops.conv_up2_phase_wgrad(nhwc(lo), gz, dw, 0, accumulate=acc)
+    ops.conv_up2_phase_wgrad(nhwc(lo), gz, dw, 0, accumulate=acc, bf3=bf3)
     if C1:
         d = ops.make_desc(N, 2 * h, 2 * w, 2 * h, 2 * w, C1, 0, Cout, 3, 1, 1, L.GATHER_FWD_REFLECT)
         ops.conv_wgrad_slice(d, nhwc(skip), None, gz, dw, C0, accumulate=acc)
