@@ -52,7 +52,7 @@ SIGNATURES = {
     "fp_conv_wgrad_slice": (C.c_int, [_DESC, _P, _P, _P, _P, _I32, _I32, C.c_int, _P, _I64, _P]),
     "fp_conv_up2_phase_wgrad_workspace": (_I64, [_I32, _I32, _I32, _I32, _I32]),
     "fp_conv_up2_phase_wgrad": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, C.c_int, _P, _I64, _P]),
-    "fp_conv_up2_phase_wgrad_bf3": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, C.c_int, _P, _I64, _P]),
+    "fp_conv_up2_phase_wgrad_bf3": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, C.c_int, _P, _I64, _P]),
     "fp_pack_job_blocks": (_I32, [_I32, _I32, _I32, _I32, _I32]),
     "fp_pack_weights_batched": (C.c_int, [_P, _P, _I32, _P]),
     "fp_pack_up2_weight_bf3": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P]),
@@ -60,7 +60,7 @@ SIGNATURES = {
     "fp_conv_up2_phase_dgrad_bf3": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P]),
     "fp_conv_up2_phase_fwd_bf3": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
     "fp_conv_wgrad_bf3_workspace": (_I64, [_DESC]),
-    "fp_conv_wgrad_bf3": (C.c_int, [_DESC, _P, _P, _P, _I32, _I32, C.c_int, _P, _I64, _P]),
+    "fp_conv_wgrad_bf3": (C.c_int, [_DESC, _P, _P, _P, _P, _I32, _I32, C.c_int, _P, _I64, _P]),
     "fp_conv3x3_bf3_supported": (C.c_int, [_DESC]),
     "fp_conv3x3_bf3_workspace": (_I64, [_DESC]),
     "fp_conv3x3_bf3": (C.c_int, [_DESC, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),

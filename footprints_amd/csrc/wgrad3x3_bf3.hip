@@ -27,6 +27,7 @@ struct W3Args {
   const float* x;     // [N][H][W][C]
   const float* dz;    // [N][H][W][Nout]
   float* part;        // [S][9][C][Nout]
+  float* bpart;       // [S][Nout] column sums of dZ (bias gradient), or null: written by the ci-tile-0 workgroups
   int N, H, W, C, Nout;
   int mode;           // 0 zero padding, 1 reflection
   int chunksY, chunksX, nchunks, chunksPerSplit, S, citiles, cotiles;
@@ -68,6 +69,8 @@ __global__ void __launch_bounds__(256) wgrad3x3_bf3_kernel(const W3Args a) {
   const bool xitem = t < 240, zitem = t < 128;
   float4 xr[4], zv[4];
   unsigned xmask = 0, zmask = 0;      // bit j: pixel j of the group is real data (else zero)
+  const bool want_bias = a.bpart != nullptr && cit == 0;     // dZ passes through this workgroup's registers exactly once
+  float bs[4] = {0.f, 0.f, 0.f, 0.f};
 
   auto issue = [&](int c) {
     const int cx = c % a.chunksX;
@@ -121,6 +124,10 @@ __global__ void __launch_bounds__(256) wgrad3x3_bf3_kernel(const W3Args a) {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         if (!(zmask & (1u << j))) zv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (want_bias) {
+        bs[0] += (zv[0].x + zv[1].x) + (zv[2].x + zv[3].x); bs[1] += (zv[0].y + zv[1].y) + (zv[2].y + zv[3].y);
+        bs[2] += (zv[0].z + zv[1].z) + (zv[2].z + zv[3].z); bs[3] += (zv[0].w + zv[1].w) + (zv[2].w + zv[3].w);
+      }
       split_store(p, ZPLANE, f32x4{zv[0].x, zv[1].x, zv[2].x, zv[3].x});
       split_store(p + ZROW, ZPLANE, f32x4{zv[0].y, zv[1].y, zv[2].y, zv[3].y});
       split_store(p + 2 * ZROW, ZPLANE, f32x4{zv[0].z, zv[1].z, zv[2].z, zv[3].z});
@@ -175,6 +182,20 @@ __global__ void __launch_bounds__(256) wgrad3x3_bf3_kernel(const W3Args a) {
   // ---- sum the four waves' tiles through LDS (fixed order), one tap at a time ----------------------------------
   float* red = reinterpret_cast<float*>(lds);        // [4 waves][16 regs][64 lanes] = 16 KB
   float* out = a.part + (size_t)s * 9 * a.C * a.Nout;
+  if (want_bias) {                                   // 16 staging threads per channel quad -> one partial per output channel
+    if (zitem) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) red[(t >> 3) * 32 + q * 4 + k] = bs[k];
+    }
+    __syncthreads();
+    if (t < 32) {
+      float v = 0.f;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) v += red[g * 32 + t];
+      a.bpart[(size_t)s * a.Nout + co0 + t] = v;
+    }
+    __syncthreads();
+  }
 #pragma unroll
   for (int tp = 0; tp < 9; ++tp) {
 #pragma unroll
@@ -190,6 +211,22 @@ __global__ void __launch_bounds__(256) wgrad3x3_bf3_kernel(const W3Args a) {
     }
     __syncthreads();
   }
+}
+
+// db[n] (+)= sum_s bpart[s][n], fixed order
+__global__ void __launch_bounds__(256) wgrad_bias_reduce_kernel(const float* __restrict__ bpart, int S, int Nout, float* __restrict__ db,
+                                                                int accumulate) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= Nout) return;
+  float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+  int s = 0;
+  for (; s + 3 < S; s += 4) {
+    v0 += bpart[(size_t)s * Nout + n]; v1 += bpart[(size_t)(s + 1) * Nout + n];
+    v2 += bpart[(size_t)(s + 2) * Nout + n]; v3 += bpart[(size_t)(s + 3) * Nout + n];
+  }
+  for (; s < S; ++s) v0 += bpart[(size_t)s * Nout + n];
+  const float v = (v0 + v1) + (v2 + v3);
+  db[n] = accumulate ? db[n] + v : v;
 }
 
 bool eligible(const fp_conv_desc* d) {
@@ -224,11 +261,11 @@ WPlan plan(const fp_conv_desc* d) {
 extern "C" int64_t fp_conv_wgrad_bf3_workspace(const fp_conv_desc* d) {
   if (!d || !eligible(d)) return -1;
   const WPlan p = plan(d);
-  return (int64_t)p.S * 9 * d->C0 * d->Nout * (int64_t)sizeof(float);
+  return ((int64_t)p.S * 9 * d->C0 * d->Nout + (int64_t)p.S * d->Nout) * (int64_t)sizeof(float);
 }
 
-extern "C" int fp_conv_wgrad_bf3(const fp_conv_desc* d, const float* x, const float* dz, float* dw_oihw, int32_t kc_total, int32_t k_begin,
-                                 int accumulate, void* workspace, int64_t workspace_bytes, fp_stream_t stream_) {
+extern "C" int fp_conv_wgrad_bf3(const fp_conv_desc* d, const float* x, const float* dz, float* dw_oihw, float* db, int32_t kc_total,
+                                 int32_t k_begin, int accumulate, void* workspace, int64_t workspace_bytes, fp_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   FP_REQUIRE(d && x && dz && dw_oihw && workspace, "fp_conv_wgrad_bf3: null pointer");
   FP_REQUIRE(eligible(d), "fp_conv_wgrad_bf3: shape not supported (see fp_conv_wgrad_bf3_workspace)");
@@ -237,6 +274,7 @@ extern "C" int fp_conv_wgrad_bf3(const fp_conv_desc* d, const float* x, const fl
   FP_REQUIRE(workspace_bytes >= fp_conv_wgrad_bf3_workspace(d), "fp_conv_wgrad_bf3: workspace too small");
   W3Args a;
   a.x = x; a.dz = dz; a.part = (float*)workspace;
+  a.bpart = db ? (float*)workspace + (size_t)p.S * 9 * d->C0 * d->Nout : nullptr;
   a.N = d->N; a.H = d->OH; a.W = d->OW; a.C = d->C0; a.Nout = d->Nout;
   a.mode = d->gather == FP_GATHER_FWD_ZERO ? 0 : 1;
   a.chunksY = p.cy; a.chunksX = p.cx; a.nchunks = p.nchunks; a.chunksPerSplit = p.chunksPerSplit; a.S = p.S;
@@ -244,5 +282,11 @@ extern "C" int fp_conv_wgrad_bf3(const fp_conv_desc* d, const float* x, const fl
   hipLaunchKernelGGL(wgrad3x3_bf3_kernel, dim3(p.S * p.citiles * p.cotiles), dim3(256), 0, stream, a);
   int rc = fp_check_launch("fp_conv_wgrad_bf3");
   if (rc) return rc;
+  if (db) {
+    hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3((d->Nout + 255) / 256), dim3(256), 0, stream, (const float*)a.bpart, p.S, d->Nout, db,
+                       accumulate);
+    rc = fp_check_launch("fp_conv_wgrad_bf3(bias)");
+    if (rc) return rc;
+  }
   return fp_wgrad_reduce_launch((const float*)workspace, dw_oihw, p.S, 9, d->C0, d->Nout, 0, accumulate, kc_total, k_begin, stream);
 }

@@ -20,6 +20,7 @@ struct PWArgs {
   const float* low;   // [N][h][w][C0]
   const float* dz;    // [N][2h][2w][Nout]
   float* part;        // [S][16][C0][Nout]
+  float* bpart;       // [S][Nout] column sums of dZ (bias gradient) or null -- bf16x3 kernel only, written by the ci-tile-0 workgroups
   int N, h, w, C0, Nout;
   int chunksY, chunksX, nchunks, chunksPerSplit, S, citiles, cotiles;
 };
@@ -161,6 +162,8 @@ __global__ void __launch_bounds__(256, 3) wgrad_up2_phase_bf3_kernel(const PWArg
   const bool xitem = t < 160;
   float4 xr[4], zv[4];
   unsigned zmask = 0;                 // bit j: position j of the group lies inside the image (else its dZ is stored as zero)
+  const bool want_bias = a.bpart != nullptr && cit == 0;     // the four phases together stage every dZ pixel exactly once
+  float bs[4] = {0.f, 0.f, 0.f, 0.f};
 
   auto issue = [&](int c) {
     const int cx = c % a.chunksX;
@@ -199,6 +202,10 @@ __global__ void __launch_bounds__(256, 3) wgrad_up2_phase_bf3_kernel(const PWArg
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         if (!(zmask & (1u << j))) zv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (want_bias) {
+        bs[0] += (zv[0].x + zv[1].x) + (zv[2].x + zv[3].x); bs[1] += (zv[0].y + zv[1].y) + (zv[2].y + zv[3].y);
+        bs[2] += (zv[0].z + zv[1].z) + (zv[2].z + zv[3].z); bs[3] += (zv[0].w + zv[1].w) + (zv[2].w + zv[3].w);
+      }
       psplit_store(p, PZPLANE, pf32x4{zv[0].x, zv[1].x, zv[2].x, zv[3].x});
       psplit_store(p + PZROW, PZPLANE, pf32x4{zv[0].y, zv[1].y, zv[2].y, zv[3].y});
       psplit_store(p + 2 * PZROW, PZPLANE, pf32x4{zv[0].z, zv[1].z, zv[2].z, zv[3].z});
@@ -260,6 +267,34 @@ __global__ void __launch_bounds__(256, 3) wgrad_up2_phase_bf3_kernel(const PWArg
       const int ci = ci0 + (r & 3) + 8 * (r >> 2) + 4 * h;
       out[((size_t)tp * a.C0 + ci) * a.Nout + co0 + idx] = acc[tp][r];
     }
+  if (want_bias) {                                   // 32 staging threads per channel quad -> one partial per output channel
+    float* red = reinterpret_cast<float*>(lds);      // the main loop ended with a barrier: the planes are dead
+#pragma unroll
+    for (int k = 0; k < 4; ++k) red[(t >> 3) * 32 + q * 4 + k] = bs[k];
+    __syncthreads();
+    if (t < 32) {
+      float v = 0.f;
+#pragma unroll
+      for (int g = 0; g < 32; ++g) v += red[g * 32 + t];
+      a.bpart[(size_t)s * a.Nout + co0 + t] = v;
+    }
+  }
+}
+
+// db[n] (+)= sum_s bpart[s][n], fixed order
+__global__ void __launch_bounds__(256) up2_wgrad_bias_reduce_kernel(const float* __restrict__ bpart, int S, int Nout, float* __restrict__ db,
+                                                                    int accumulate) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= Nout) return;
+  float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+  int s = 0;
+  for (; s + 3 < S; s += 4) {
+    v0 += bpart[(size_t)s * Nout + n]; v1 += bpart[(size_t)(s + 1) * Nout + n];
+    v2 += bpart[(size_t)(s + 2) * Nout + n]; v3 += bpart[(size_t)(s + 3) * Nout + n];
+  }
+  for (; s < S; ++s) v0 += bpart[(size_t)s * Nout + n];
+  const float v = (v0 + v1) + (v2 + v3);
+  db[n] = accumulate ? db[n] + v : v;
 }
 
 // stage 1: part[0][e] = sum_s part[s][e] (in place; a thread only ever touches its own e).  64 elements x 4 s-groups per block,
@@ -329,10 +364,10 @@ PPlan plan(int N, int h, int w, int C0, int Nout) {
 extern "C" int64_t fp_conv_up2_phase_wgrad_workspace(int32_t N, int32_t h, int32_t w, int32_t C0, int32_t Nout) {
   if (!eligible(N, h, w, C0, Nout)) return -1;
   const PPlan p = plan(N, h, w, C0, Nout);
-  return (int64_t)p.S * 16 * C0 * Nout * (int64_t)sizeof(float);
+  return ((int64_t)p.S * 16 * C0 * Nout + (int64_t)p.S * Nout) * (int64_t)sizeof(float);
 }
 
-static int phase_wgrad_launch(bool bf3, const float* low, const float* dz, float* dw_oihw, int32_t N, int32_t h, int32_t w, int32_t C0,
+static int phase_wgrad_launch(bool bf3, const float* low, const float* dz, float* dw_oihw, float* db, int32_t N, int32_t h, int32_t w, int32_t C0,
                               int32_t Nout, int32_t kc_total, int32_t k_begin, int accumulate, void* workspace,
                               int64_t workspace_bytes, fp_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
@@ -340,9 +375,10 @@ static int phase_wgrad_launch(bool bf3, const float* low, const float* dz, float
   FP_REQUIRE(eligible(N, h, w, C0, Nout), "fp_conv_up2_phase_wgrad: shape not supported (see fp_conv_up2_phase_wgrad_workspace)");
   FP_REQUIRE(k_begin >= 0 && k_begin + C0 <= kc_total, "fp_conv_up2_phase_wgrad: input-channel slice out of range");
   const PPlan p = plan(N, h, w, C0, Nout);
-  FP_REQUIRE(workspace_bytes >= (int64_t)p.S * 16 * C0 * Nout * (int64_t)sizeof(float), "fp_conv_up2_phase_wgrad: workspace too small");
+  FP_REQUIRE(workspace_bytes >= fp_conv_up2_phase_wgrad_workspace(N, h, w, C0, Nout), "fp_conv_up2_phase_wgrad: workspace too small");
   PWArgs a;
   a.low = low; a.dz = dz; a.part = (float*)workspace;
+  a.bpart = db ? (float*)workspace + (size_t)p.S * 16 * C0 * Nout : nullptr;
   a.N = N; a.h = h; a.w = w; a.C0 = C0; a.Nout = Nout;
   a.chunksY = p.cy; a.chunksX = p.cx; a.nchunks = p.nchunks; a.chunksPerSplit = p.chunksPerSplit; a.S = p.S;
   a.citiles = p.citiles; a.cotiles = p.cotiles;
@@ -350,6 +386,12 @@ static int phase_wgrad_launch(bool bf3, const float* low, const float* dz, float
   else hipLaunchKernelGGL(wgrad_up2_phase_kernel, dim3(p.S * p.citiles * p.cotiles), dim3(256), 0, stream, a);
   int rc = fp_check_launch("fp_conv_up2_phase_wgrad");
   if (rc) return rc;
+  if (db) {
+    hipLaunchKernelGGL(up2_wgrad_bias_reduce_kernel, dim3((Nout + 255) / 256), dim3(256), 0, stream, (const float*)a.bpart, p.S, Nout, db,
+                       accumulate);
+    rc = fp_check_launch("fp_conv_up2_phase_wgrad(bias)");
+    if (rc) return rc;
+  }
   const size_t tot16 = (size_t)16 * C0 * Nout;
   if (p.S > 1) {
     hipLaunchKernelGGL(up2_wgrad_sum_kernel, dim3((unsigned)fp_ceil_div((int64_t)tot16, 64)), dim3(256), 0, stream, (float*)workspace, p.S, tot16);
@@ -366,12 +408,13 @@ static int phase_wgrad_launch(bool bf3, const float* low, const float* dz, float
 extern "C" int fp_conv_up2_phase_wgrad(const float* low, const float* dz, float* dw_oihw, int32_t N, int32_t h, int32_t w, int32_t C0,
                                        int32_t Nout, int32_t kc_total, int32_t k_begin, int accumulate, void* workspace,
                                        int64_t workspace_bytes, fp_stream_t stream) {
-  return phase_wgrad_launch(false, low, dz, dw_oihw, N, h, w, C0, Nout, kc_total, k_begin, accumulate, workspace, workspace_bytes, stream);
+  return phase_wgrad_launch(false, low, dz, dw_oihw, nullptr, N, h, w, C0, Nout, kc_total, k_begin, accumulate, workspace, workspace_bytes, stream);
 }
 
-// same contract, operands split exactly into three bf16 terms (six bf16 MFMA products, fp32 accumulate)
-extern "C" int fp_conv_up2_phase_wgrad_bf3(const float* low, const float* dz, float* dw_oihw, int32_t N, int32_t h, int32_t w, int32_t C0,
-                                           int32_t Nout, int32_t kc_total, int32_t k_begin, int accumulate, void* workspace,
+// same contract, operands split exactly into three bf16 terms (six bf16 MFMA products, fp32 accumulate); db (optional, [Nout]) receives
+// the bias gradient = column sums of dz from the same pass
+extern "C" int fp_conv_up2_phase_wgrad_bf3(const float* low, const float* dz, float* dw_oihw, float* db, int32_t N, int32_t h, int32_t w,
+                                           int32_t C0, int32_t Nout, int32_t kc_total, int32_t k_begin, int accumulate, void* workspace,
                                            int64_t workspace_bytes, fp_stream_t stream) {
-  return phase_wgrad_launch(true, low, dz, dw_oihw, N, h, w, C0, Nout, kc_total, k_begin, accumulate, workspace, workspace_bytes, stream);
+  return phase_wgrad_launch(true, low, dz, dw_oihw, db, N, h, w, C0, Nout, kc_total, k_begin, accumulate, workspace, workspace_bytes, stream);
 }

@@ -585,9 +585,9 @@ class Engine:
 
         def launch():
             if _WBF3 and src1 is None and ops.conv_wgrad_bf3_supported(d):
-                ops.conv_wgrad_bf3(d, src0, dz, c.gw, 0, accumulate=acc)
-            else:
-                ops.conv_wgrad(d, src0, src1, dz, c.gw, accumulate=acc)
+                ops.conv_wgrad_bf3(d, src0, dz, c.gw, 0, accumulate=acc, db=c.gb)       # bias gradient from the same pass over dz
+                return
+            ops.conv_wgrad(d, src0, src1, dz, c.gw, accumulate=acc)
             if c.gb is not None:
                 ops.colsum(dz.view(-1, c.Cout), c.gb, accumulate=acc)
         if side is None:
@@ -604,14 +604,17 @@ class Engine:
             return self._wgrad(c, L.GATHER_FWD_REFLECT_UP2, low, skip, dz, N, H, W, H, W, C0, C1, acc, side)
 
         def launch():
-            ops.conv_up2_phase_wgrad(low, dz, c.gw, 0, accumulate=acc, bf3=_WBF3 and _PWBF3)
+            pbf3 = _WBF3 and _PWBF3
+            ops.conv_up2_phase_wgrad(low, dz, c.gw, 0, accumulate=acc, bf3=pbf3, db=c.gb if pbf3 else None)   # + bias gradient
+            bias_done = pbf3 or c.gb is None
             if C1:
                 d = ops.make_desc(N, H, W, H, W, C1, 0, c.Cout, 3, 1, 1, L.GATHER_FWD_REFLECT)
                 if _WBF3 and ops.conv_wgrad_bf3_supported(d):
-                    ops.conv_wgrad_bf3(d, skip, dz, c.gw, C0, accumulate=acc)
+                    ops.conv_wgrad_bf3(d, skip, dz, c.gw, C0, accumulate=acc, db=None if bias_done else c.gb)
+                    bias_done = True
                 else:
                     ops.conv_wgrad_slice(d, skip, None, dz, c.gw, C0, accumulate=acc)
-            if c.gb is not None:
+            if not bias_done:
                 ops.colsum(dz.view(-1, c.Cout), c.gb, accumulate=acc)
         if side is None:
             return launch()

@@ -154,14 +154,15 @@ def conv_wgrad_bf3_supported(desc):
     return _cached_query("fp_conv_wgrad_bf3_workspace", desc) >= 0
 
 
-def conv_wgrad_bf3(desc, x, dz, dw, k_begin=0, accumulate=False):
-    """3x3 stride-1 weight gradient with exactly split bf16x3 operands, into dw[:, k_begin:k_begin + C0]"""
+def conv_wgrad_bf3(desc, x, dz, dw, k_begin=0, accumulate=False, db=None):
+    """3x3 stride-1 weight gradient with exactly split bf16x3 operands, into dw[:, k_begin:k_begin + C0]; db (optional) receives
+    the bias gradient (column sums of dz) from the same pass"""
     lib = _lib.load()
     need = _cached_query("fp_conv_wgrad_bf3_workspace", desc)
     if need < 0:
         raise RuntimeError("fp_conv_wgrad_bf3: shape not supported")
     ws = workspace(need, dz.device)
-    _lib.check(lib.fp_conv_wgrad_bf3(C.byref(desc), _f32(x), _f32(dz), _f32(dw), dw.shape[1], k_begin, int(bool(accumulate)),
+    _lib.check(lib.fp_conv_wgrad_bf3(C.byref(desc), _f32(x), _f32(dz), _f32(dw), _f32(db), dw.shape[1], k_begin, int(bool(accumulate)),
                                      ws.data_ptr(), ws.numel(), stream()), "fp_conv_wgrad_bf3")
     return dw
 
@@ -179,17 +180,22 @@ def up2_phase_wgrad_supported(N, h, w, C0, Nout):
     return _lib.load().fp_conv_up2_phase_wgrad_workspace(N, h, w, C0, Nout) >= 0
 
 
-def conv_up2_phase_wgrad(low, dz, dw, k_begin=0, accumulate=False, bf3=False):
+def conv_up2_phase_wgrad(low, dz, dw, k_begin=0, accumulate=False, bf3=False, db=None):
+    """db (bf3 only): also produce the bias gradient (column sums of dz) from the same pass"""
     lib = _lib.load()
+    if db is not None and not bf3:
+        raise RuntimeError("conv_up2_phase_wgrad: the fused bias gradient needs the bf16x3 kernel")
     N, h, w, C0 = low.shape
     Nout = dz.shape[3]
     need = lib.fp_conv_up2_phase_wgrad_workspace(N, h, w, C0, Nout)
     if need < 0:
         raise RuntimeError("fp_conv_up2_phase_wgrad: shape not supported")
     ws = workspace(need, dz.device)
-    fn = lib.fp_conv_up2_phase_wgrad_bf3 if bf3 else lib.fp_conv_up2_phase_wgrad
-    _lib.check(fn(_f32(low), _f32(dz), _f32(dw), N, h, w, C0, Nout, dw.shape[1], k_begin, int(bool(accumulate)), ws.data_ptr(), ws.numel(),
-                  stream()), "fp_conv_up2_phase_wgrad")
+    tail = (N, h, w, C0, Nout, dw.shape[1], k_begin, int(bool(accumulate)), ws.data_ptr(), ws.numel(), stream())
+    if bf3:
+        _lib.check(lib.fp_conv_up2_phase_wgrad_bf3(_f32(low), _f32(dz), _f32(dw), _f32(db), *tail), "fp_conv_up2_phase_wgrad_bf3")
+    else:
+        _lib.check(lib.fp_conv_up2_phase_wgrad(_f32(low), _f32(dz), _f32(dw), *tail), "fp_conv_up2_phase_wgrad")
     return dw
 
 

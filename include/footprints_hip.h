@@ -131,9 +131,11 @@ int fp_pack_conv_weight_bf3(const float* w_oihw, void* wp, int32_t Cout, int32_t
 
 /* Weight gradient with the same exactly split operands (wgrad3x3_bf3.hip): 3x3 / stride 1 / pad 1, FWD_ZERO or FWD_REFLECT
  * gather, C1 = 0, C0 and Nout multiples of 32; fp_conv_wgrad_bf3_workspace returns -1 for anything else (use fp_conv_wgrad).
- * dw_oihw is [Nout][kc_total][3][3]; the C0 input channels of `d` are its slice [k_begin, k_begin + C0). */
+ * dw_oihw is [Nout][kc_total][3][3]; the C0 input channels of `d` are its slice [k_begin, k_begin + C0).
+ * db (optional, [Nout]): the bias gradient = column sums of dz, produced from the dz tiles the kernel stages anyway
+ * (replaces a separate fp_colsum pass over dz); (+)= like dw_oihw. */
 int64_t fp_conv_wgrad_bf3_workspace(const fp_conv_desc* d);
-int fp_conv_wgrad_bf3(const fp_conv_desc* d, const float* x, const float* dz, float* dw_oihw, int32_t kc_total,
+int fp_conv_wgrad_bf3(const fp_conv_desc* d, const float* x, const float* dz, float* dw_oihw, float* db, int32_t kc_total,
                       int32_t k_begin, int accumulate, void* workspace, int64_t workspace_bytes, fp_stream_t stream);
 
 /* ---- nearest-x2 phase decomposition (reference footprints/network.py:98,126-134,154: upsample -> [cat skip] ->
@@ -181,8 +183,9 @@ int64_t fp_conv_up2_phase_wgrad_workspace(int32_t N, int32_t h, int32_t w, int32
 int fp_conv_up2_phase_wgrad(const float* low, const float* dz, float* dw_oihw, int32_t N, int32_t h, int32_t w, int32_t C0,
                             int32_t Nout, int32_t kc_total, int32_t k_begin, int accumulate, void* workspace,
                             int64_t workspace_bytes, fp_stream_t stream);
-/* same contract and workspace; fp32 operands split exactly into three bf16 terms, six bf16 MFMA products (error below the fp32 MFMA's) */
-int fp_conv_up2_phase_wgrad_bf3(const float* low, const float* dz, float* dw_oihw, int32_t N, int32_t h, int32_t w, int32_t C0,
+/* same contract and workspace; fp32 operands split exactly into three bf16 terms, six bf16 MFMA products (error below the fp32 MFMA's);
+ * db (optional, [Nout]) (+)= the bias gradient = column sums of dz, from the dz tiles the kernel stages anyway */
+int fp_conv_up2_phase_wgrad_bf3(const float* low, const float* dz, float* dw_oihw, float* db, int32_t N, int32_t h, int32_t w, int32_t C0,
                                 int32_t Nout, int32_t kc_total, int32_t k_begin, int accumulate, void* workspace,
                                 int64_t workspace_bytes, fp_stream_t stream);
 

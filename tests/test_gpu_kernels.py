@@ -220,7 +220,11 @@ def test_up2_phase_wgrad(N, h, w, C0, C1, Cout, acc, bf3):
     init = rnd((Cout, C0 + C1, 3, 3), 324) if acc else torch.full((Cout, C0 + C1, 3, 3), float("nan"))
     dw = init.clone().cuda()
     gz = nhwc(g)
-    ops.conv_up2_phase_wgrad(nhwc(lo), gz, dw, 0, accumulate=acc, bf3=bf3)
+    binit = rnd((Cout,), 325) if acc else torch.full((Cout,), float("nan"))
+    db = binit.clone().cuda() if bf3 else None
+    ops.conv_up2_phase_wgrad(nhwc(lo), gz, dw, 0, accumulate=acc, bf3=bf3, db=db)
+    if bf3:                                                          # bias gradient from the same pass over dz
+        check(db.cpu(), g.sum((0, 2, 3)) + (binit if acc else 0), "up2 phase wgrad bias", 1e-5)
     if C1:
         d = ops.make_desc(N, 2 * h, 2 * w, 2 * h, 2 * w, C1, 0, Cout, 3, 1, 1, L.GATHER_FWD_REFLECT)
         ops.conv_wgrad_slice(d, nhwc(skip), None, gz, dw, C0, accumulate=acc)
@@ -770,8 +774,12 @@ def test_wgrad3x3_bf3_kernel(mode, N, H, W, C0, Cout):
     assert ops.conv_wgrad_bf3_supported(d)
     pad = 32                                                     # destination = channel slice [pad, pad + C0) of a wider gradient
     dw = torch.full((Cout, C0 + 2 * pad, 3, 3), 7.0, device="cuda")
-    ops.conv_wgrad_bf3(d, nhwc(x), nhwc(g), dw, pad)
+    db = torch.full((Cout,), 3.0, device="cuda")
+    ops.conv_wgrad_bf3(d, nhwc(x), nhwc(g), dw, pad, db=db)
     check(dw[:, pad:pad + C0], w.grad, "wgrad bf3 " + mode, 3e-6)
     assert bool((dw[:, :pad] == 7.0).all()) and bool((dw[:, pad + C0:] == 7.0).all())
-    ops.conv_wgrad_bf3(d, nhwc(x), nhwc(g), dw, pad, accumulate=True)
+    bref = g.double().sum((0, 2, 3))                               # bias gradient = column sums of dz, from the same pass
+    check(db, bref, "wgrad bf3 bias " + mode, 2e-6)
+    ops.conv_wgrad_bf3(d, nhwc(x), nhwc(g), dw, pad, accumulate=True, db=db)
     check(dw[:, pad:pad + C0], 2 * w.grad, "wgrad bf3 accumulate " + mode, 3e-6)
+    check(db, 2 * bref, "wgrad bf3 bias accumulate " + mode, 2e-6)
