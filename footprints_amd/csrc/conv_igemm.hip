@@ -41,7 +41,25 @@ struct IgemmArgs {
   int M, KC16, T, tilesN, nwg;
   int SK, stepsPerSplit;  // split-K over the flattened (tap, 16-channel) step range; SK > 1 => raw partials to `part`
   float* part;            // [SK][M][Nout]
+  // Parity-major rows for the 3x3 stride-2 data gradient (pm = 1): an input-gradient pixel (y, x) receives only the taps with
+  // ky = y + pad and kx = x + pad (mod 2) -- 1, 2, 2 or 4 of the 9.  The M dimension is enumerated class by class ((y & 1, x & 1),
+  // heaviest first, each class padded to whole tiles: Mc real rows, McP padded), so a workgroup's rows share one class and it
+  // walks only that class's taps: 2.25 taps per pixel on average instead of 9 with three quarters of them all-zero.
+  int pm, Mc, McP;
 };
+
+// row of the parity-major enumeration -> class (cpy, cpx), validity, (n, oy, ox)
+__device__ __forceinline__ bool pm_decode(const IgemmArgs& a, int m, int& n, int& oy, int& ox) {
+  const int cls = m / a.McP, r = m - cls * a.McP;
+  const bool valid = r < a.Mc;
+  const int rr = valid ? r : 0;
+  const int hw = a.g.OW >> 1, hh = a.g.OH >> 1;
+  const int j = rr % hw, q = rr / hw;
+  ox = 2 * j + (1 - (cls & 1));
+  oy = 2 * (q % hh) + (1 - (cls >> 1));
+  n = q / hh;
+  return valid;
+}
 
 // v = acc (+bias) -> addend -> activation gradient -> activation -> accumulate (see FP_EPI_* in the header)
 __device__ __forceinline__ float igemm_epilogue(const IgemmArgs& a, size_t o, int n, float v) {
@@ -91,6 +109,10 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmArgs a) {
 #pragma unroll
   for (int i = 0; i < AV; ++i) {
     const int m = m0 + (t >> 2) + 64 * i;
+    if (a.pm) {
+      pvalid[i] = pm_decode(a, m, pn[i], py[i], px[i]);
+      continue;
+    }
     pvalid[i] = m < a.M;
     const int mm = pvalid[i] ? m : 0;
     const int ox = mm % g.OW, r = mm / g.OW;
@@ -98,6 +120,14 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmArgs a) {
     py[i] = r % g.OH;
     pn[i] = r / g.OH;
   }
+  // pm: this workgroup's tap list (class = m0 / McP, uniform): ky in {1} or {0, 2}, kx likewise
+  const int pm_cls = a.pm ? m0 / a.McP : 0;
+  const int pm_odd_y = (1 - (pm_cls >> 1) + g.pad) & 1, pm_odd_x = (1 - (pm_cls & 1) + g.pad) & 1;   // 1: only k = 1 matches
+  const int pm_ny = pm_odd_y ? 1 : 2, pm_nx = pm_odd_x ? 1 : 2;
+  auto pm_tap = [&](int lt) {
+    const int ly = lt / pm_nx, lx = lt - ly * pm_nx;
+    return (pm_odd_y ? 1 : 2 * ly) * 3 + (pm_odd_x ? 1 : 2 * lx);
+  };
   int pix[AV][4], pix1[AV];
   float4 areg[AV], breg[BV];
 
@@ -155,20 +185,21 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int total_steps = a.T * a.KC16;
+  const int total_steps = (a.pm ? pm_ny * pm_nx : a.T) * a.KC16;      // pm: never split (SK = 1)
   const int s_begin = split * a.stepsPerSplit;
-  const int steps = min(a.stepsPerSplit, total_steps - s_begin);
+  const int steps = a.pm ? total_steps : min(a.stepsPerSplit, total_steps - s_begin);
   int ltap = s_begin / a.KC16, lcc = s_begin - ltap * a.KC16;
-  set_tap(ltap);
-  load_step(ltap, lcc);
+  int tap = a.pm ? pm_tap(ltap) : ltap;
+  set_tap(tap);
+  load_step(tap, lcc);
   store_step(0);
   __syncthreads();
 
   for (int s = 0; s < steps; ++s) {
     const bool more = s + 1 < steps;
     if (more) {
-      if (++lcc == a.KC16) { lcc = 0; ++ltap; set_tap(ltap); }
-      load_step(ltap, lcc);  // global loads for step s+1 stay in flight under this step's MFMAs
+      if (++lcc == a.KC16) { lcc = 0; ++ltap; tap = a.pm ? pm_tap(ltap) : ltap; set_tap(tap); }
+      load_step(tap, lcc);  // global loads for step s+1 stay in flight under this step's MFMAs
     }
     const float* Ab = As + (s & 1) * BM * LD + (wm * TM * 32 + idx) * LD + h * 4;
     const float* Bb = Bs + (s & 1) * BN * LD + (wn * TN * 32 + idx) * LD + h * 4;
@@ -214,6 +245,12 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmArgs a) {
         for (int k = 0; k < 8; ++k) {
           const int r = half * 8 + k;
           const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (a.pm) {
+            int en, ey, ex;
+            ok[k] = pm_decode(a, m, en, ey, ex);
+            off[k] = ((size_t)(en * g.OH + ey) * g.OW + ex) * a.Nout + n;
+            continue;
+          }
           ok[k] = m < a.M;
           off[k] = (size_t)min(m, a.M - 1) * a.Nout + n;
         }
@@ -298,7 +335,12 @@ int pick_splitk(int64_t tiles, int steps, int64_t MN, int64_t ws_floats) {
 
 template <int BM, int BN, int WM, int WN, bool STEM>
 int launch(IgemmArgs& a, hipStream_t stream, int64_t ws_floats) {
-  const int tilesM = (int)fp_ceil_div(a.M, BM);
+  int tilesM = (int)fp_ceil_div(a.M, BM);
+  if (a.pm) {                       // four parity classes, each padded to whole BM-row tiles; never split
+    a.McP = (int)fp_ceil_div(a.Mc, BM) * BM;
+    tilesM = 4 * (a.McP / BM);
+    ws_floats = 0;
+  }
   a.tilesN = (int)fp_ceil_div(a.Nout, BN);
   const int steps = a.T * a.KC16;
   const int sk = pick_splitk((int64_t)tilesM * a.tilesN, steps, (int64_t)a.M * a.Nout, ws_floats);
@@ -383,6 +425,12 @@ extern "C" int fp_conv_igemm(const fp_conv_desc* d, const float* src0, const flo
   a.KC16 = stem ? 10 : (d->C0 + d->C1 + 15) / 16;
   a.part = (float*)workspace;
   a.SK = 1;
+  // 3x3 stride-2 data gradient on even dims: parity-major rows, only the taps a pixel class receives (see IgemmArgs)
+  static const bool no_pm = getenv("FP_NO_PM") && atoi(getenv("FP_NO_PM"));
+  a.pm = !no_pm && d->gather == FP_GATHER_DGRAD_ZERO && d->stride == 2 && d->KH == 3 && d->KW == 3 && d->OH % 2 == 0 && d->OW % 2 == 0 &&
+         d->IH * 2 == d->OH && d->IW * 2 == d->OW;
+  a.Mc = a.pm ? d->N * (d->OH / 2) * (d->OW / 2) : 0;
+  a.McP = a.Mc;
   int64_t ws = workspace ? workspace_bytes / (int64_t)sizeof(float) : 0;
   if (ws > MAX_SK * M64 * d->Nout) ws = MAX_SK * M64 * d->Nout;
 

@@ -393,7 +393,8 @@ def test_conv3x3_tile_kernel(mode, N, H, W, C0, C1, Cout):
 # data gradients
 # ----------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("N,H,W,Cin,Cout,K,stride", [(2, 8, 12, 16, 8, 3, 1), (2, 9, 13, 16, 24, 3, 2), (2, 12, 40, 64, 128, 3, 2),
-                                                     (2, 12, 40, 64, 128, 1, 2), (1, 24, 80, 128, 128, 3, 1), (2, 7, 9, 32, 16, 1, 2)])
+                                                     (2, 12, 40, 64, 128, 1, 2), (1, 24, 80, 128, 128, 3, 1), (2, 7, 9, 32, 16, 1, 2),
+                                                     (12, 12, 40, 256, 512, 3, 2), (3, 6, 10, 32, 48, 3, 2), (1, 2, 2, 16, 16, 3, 2)])
 def test_conv_dgrad_zero(N, H, W, Cin, Cout, K, stride):
     ops, L = _ops()
     pad = K // 2
