@@ -237,8 +237,10 @@ __global__ void __launch_bounds__(256) conv3x3_tile_bf3_kernel(const Tile3Args a
       if (tap < 8) load_a(tap + 1, af[(tap + 1) & 1]);
       if (tap < 7) load_b(tap + 2, cc, bq[(tap + 2) % 3]);
       else load_b(tap - 7, ccn, bq[(tap + 2) % 3]);
-      __builtin_amdgcn_sched_barrier(0);
       mma6(af[tap & 1], bq[tap % 3]);
+      // issue order: one LDS / global read between consecutive MFMAs (this tap's MFMAs only depend on older reads)
+      if (tap < 8) fp_sched_interleave<TM * 3, TN * 3, 6 * TM * TN>();
+      else fp_sched_interleave<0, TN * 3, 6 * TM * TN>();
     }
     if (FOLD && border_tile) {
 #pragma unroll 1

@@ -272,7 +272,6 @@ __global__ void __launch_bounds__(256) up2_phase_fwd_bf3_kernel(const PhaseArgs 
       if (tap < 3) load_a(tap + 1, af[(tap + 1) & 1]);
       if (tap < 2) load_b(tap + 2, cc, bq[tap + 2]);
       else load_b(tap - 2, ccn, bq[tap - 2]);
-      __builtin_amdgcn_sched_barrier(0);
       constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
       for (int q = 0; q < 6; ++q)
@@ -282,6 +281,8 @@ __global__ void __launch_bounds__(256) up2_phase_fwd_bf3_kernel(const PhaseArgs 
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[tap & 1][i][PA[q]]),
                                                                 __builtin_bit_cast(bf16x8_t, bq[tap][j][PB[q]]), acc[i][j], 0, 0, 0);
+      if (tap < 3) fp_sched_interleave<TM * 3, TN * 3, 6 * TM * TN>();      // one read between consecutive MFMAs (fp_common.h)
+      else fp_sched_interleave<0, TN * 3, 6 * TM * TN>();
     }
     if (cc + 1 < a.KC16) {
       store_halo((cc + 1) & 1);
@@ -441,7 +442,6 @@ __global__ void __launch_bounds__(256) up2_phase_dgrad_bf3_kernel(const PhaseDgr
       if (tap < 3) load_a(tap + 1, af[(tap + 1) & 1]);
       if (tap < 2) load_b(tap + 2, step, bq[tap + 2]);
       else load_b(tap - 2, stepn, bq[tap - 2]);
-      __builtin_amdgcn_sched_barrier(0);
       constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
       for (int q = 0; q < 6; ++q)
@@ -451,6 +451,8 @@ __global__ void __launch_bounds__(256) up2_phase_dgrad_bf3_kernel(const PhaseDgr
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[tap & 1][i][PA[q]]),
                                                                 __builtin_bit_cast(bf16x8_t, bq[tap][j][PB[q]]), acc[i][j], 0, 0, 0);
+      if (tap < 3) fp_sched_interleave<TM * 3, TN * 3, 6 * TM * TN>();      // one read between consecutive MFMAs (fp_common.h)
+      else fp_sched_interleave<0, TN * 3, 6 * TM * TN>();
     }
     if (step + 1 < nsteps) {
       store_halo((step + 1) & 1);
