@@ -39,6 +39,7 @@ struct Tile3Args {
   unsigned epi;
   int tilesX, tilesY, tilesN, nwg;
   int SK, chunksPerSplit;   // split-K over 16-channel chunks for small grids: raw partials [SK][N*OH*OW][Nout] -> fp_splitk_reduce_launch
+  int wmajor;               // workgroup ids enumerate pixel tiles fastest, (channel tile, split) slowest
   float* part;
 };
 
@@ -95,11 +96,24 @@ __global__ void __launch_bounds__(256) conv3x3_tile_bf3_kernel(const Tile3Args a
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, idx = lane & 31, h = lane >> 5;
   const int wm = wave / WN, wn = wave % WN;
   int wg = fp_xcd_remap(blockIdx.x, a.nwg);
-  const int split = wg % a.SK; wg /= a.SK;
-  const int tile_n = wg % a.tilesN; wg /= a.tilesN;
-  const int tile_x = wg % a.tilesX; wg /= a.tilesX;
-  const int tile_y = wg % a.tilesY;
-  const int n_img = wg / a.tilesY;
+  int split, tile_n, tile_x, tile_y, n_img;
+  if (a.wmajor) {
+    // layers whose bf16x3 weights do not fit an XCD's 4 MB L2 (512-channel 6x20 layers: 14 MB against 3 MB of activations):
+    // pixel tiles vary fastest and (output-channel tile, split) slowest, so the contiguous id range of an XCD covers a few weight
+    // slices for ALL pixel tiles and its private L2 keeps them -- with pixel-major ids every XCD streams every weight
+    // (512->512 @6x20: 56.2 -> 49.5 us; 256->256 @12x40, 3.5 MB of weights, is better off pixel-major: 53.8 vs 57.3 us)
+    tile_x = wg % a.tilesX; wg /= a.tilesX;
+    tile_y = wg % a.tilesY; wg /= a.tilesY;
+    n_img = wg % a.N; wg /= a.N;
+    split = wg % a.SK;
+    tile_n = wg / a.SK;
+  } else {
+    split = wg % a.SK; wg /= a.SK;
+    tile_n = wg % a.tilesN; wg /= a.tilesN;
+    tile_x = wg % a.tilesX; wg /= a.tilesX;
+    tile_y = wg % a.tilesY;
+    n_img = wg / a.tilesY;
+  }
   const int y0 = tile_y * TH, x0 = tile_x * TW, n0 = tile_n * BN;
 
   // ---- halo staging slots (unconditional loads; invalid slots read the nearest in-image pixel and are stored as zero) ----------
@@ -448,6 +462,7 @@ extern "C" int fp_conv3x3_bf3(const fp_conv_desc* d, const float* src, const voi
   a.act = d->act; a.epi = d->epi;
   a.tilesX = p.tilesX; a.tilesY = p.tilesY; a.tilesN = p.tilesN; a.SK = p.SK; a.chunksPerSplit = p.chunksPerSplit;
   a.part = (float*)workspace;
+  a.wmajor = (int64_t)9 * d->C0 * d->Nout * 6 > ((int64_t)4 << 20);
   a.nwg = d->N * p.tilesY * p.tilesX * p.tilesN * p.SK;
   int rc;
 #define FP_L3(TH_, TW_)                                                                                                       \
