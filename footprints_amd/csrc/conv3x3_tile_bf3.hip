@@ -44,27 +44,16 @@ struct Tile3Args {
 };
 
 struct FoldTap { int wtap, ao, bo, rsel, csel; };
-__constant__ FoldTap kFoldTaps3[16] = {   // see conv3x3_tile.hip
-    {0, 0, 2, 1, 0}, {0, 2, 0, 0, 1}, {0, 0, 0, 1, 1}, {1, 0, 1, 1, 0}, {2, 0, 0, 1, 0}, {2, 2, 2, 0, 2}, {2, 0, 2, 1, 2}, {3, 1, 0, 0, 1},
-    {5, 1, 2, 0, 2}, {6, 2, 2, 2, 0}, {6, 0, 0, 0, 1}, {6, 2, 0, 2, 1}, {7, 2, 1, 2, 0}, {8, 2, 0, 2, 0}, {8, 0, 2, 0, 2}, {8, 2, 2, 2, 2},
-};
-
-__device__ __forceinline__ float tile3_epilogue(const Tile3Args& a, size_t o, int n, float v) {
-  if (a.epi & FP_EPI_BIAS) v += a.bias[n];
-  if (a.epi & FP_EPI_ADDEND) {
-    float ad = a.addend[o];
-    if (a.epi & FP_EPI_ADDEND_MASK) ad = a.addend_mask[o] > 0.f ? ad : 0.f;
-    v += ad;
+// reflection-fold taps of the data gradient (derivation in conv3x3_tile.hip): weight tap, halo offset (ao, bo), row / column
+// selector (0: every pixel, 1: pixels on row / column 1, 2: pixels on row / column n-2)
+// (a function, so unrolled loops fold it at compile time)
+__device__ __forceinline__ constexpr FoldTap fold_tap3(int e) {
+  switch (e) {
+    case 0: return {0, 0, 2, 1, 0}; case 1: return {0, 2, 0, 0, 1}; case 2: return {0, 0, 0, 1, 1}; case 3: return {1, 0, 1, 1, 0};
+    case 4: return {2, 0, 0, 1, 0}; case 5: return {2, 2, 2, 0, 2}; case 6: return {2, 0, 2, 1, 2}; case 7: return {3, 1, 0, 0, 1};
+    case 8: return {5, 1, 2, 0, 2}; case 9: return {6, 2, 2, 2, 0}; case 10: return {6, 0, 0, 0, 1}; case 11: return {6, 2, 0, 2, 1};
+    case 12: return {7, 2, 1, 2, 0}; case 13: return {8, 2, 0, 2, 0}; case 14: return {8, 0, 2, 0, 2}; default: return {8, 2, 2, 2, 2};
   }
-  if (a.epi & FP_EPI_ACTGRAD_ELU) {
-    const float sv = a.actsrc[o];
-    v *= (sv > 0.f ? 1.f : sv + 1.f);
-  }
-  if (a.epi & FP_EPI_ACTGRAD_RELU) v = a.actsrc[o] > 0.f ? v : 0.f;
-  if (a.act == FP_ACT_ELU) v = fp_elu(v);
-  if (a.act == FP_ACT_RELU) v = fmaxf(v, 0.f);
-  if (a.epi & FP_EPI_ACCUM) v += a.y[o];
-  return v;
 }
 
 constexpr int PIXB = 48;   // bytes per halo pixel per plane (16 bf16 + 8 pad)
@@ -187,7 +176,6 @@ __global__ void __launch_bounds__(256) conv3x3_tile_bf3_kernel(const Tile3Args a
 
   const bool has_r1 = y0 <= 1 && 1 < y0 + TH, has_rH = y0 <= a.OH - 2 && a.OH - 2 < y0 + TH;
   const bool has_c1 = x0 <= 1 && 1 < x0 + TW, has_cW = x0 <= a.OW - 2 && a.OW - 2 < x0 + TW;
-  const bool border_tile = has_r1 || has_rH || has_c1 || has_cW;
   unsigned m_r1[TM], m_rH[TM], m_c1[TM], m_cW[TM];       // all-ones / zero lane masks
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
@@ -244,41 +232,47 @@ __global__ void __launch_bounds__(256) conv3x3_tile_bf3_kernel(const Tile3Args a
 #pragma unroll
         for (int i = 0; i < TM; ++i) dst[i][p] = *reinterpret_cast<const uint4*>(Hb + p * PLANE + abase[i] + toff);
     };
-    load_a(0, af[0]);
+    // Border tiles of the reflection data-gradient run their fold taps (masked halo rows / columns, see kFoldTaps3) right behind
+    // the regular tap that uses the SAME weight slice, from the registers it is already in: no extra weight loads (the former
+    // separate fold loop paid one exposed global-load latency per fold tap, up to 16 per chunk on corner tiles).
+    {
+      constexpr bool WF = FOLD;      // interior tiles skip every fold tap through the uniform `need` tests
+      load_a(0, af[0]);
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      __builtin_amdgcn_sched_barrier(0);
-      if (tap < 8) load_a(tap + 1, af[(tap + 1) & 1]);
-      if (tap < 7) load_b(tap + 2, cc, bq[(tap + 2) % 3]);
-      else load_b(tap - 7, ccn, bq[(tap + 2) % 3]);
-      mma6(af[tap & 1], bq[tap % 3]);
-      // issue order: one LDS / global read between consecutive MFMAs (this tap's MFMAs only depend on older reads)
-      if (tap < 8) fp_sched_interleave<TM * 3, TN * 3, 6 * TM * TN>();
-      else fp_sched_interleave<0, TN * 3, 6 * TM * TN>();
-    }
-    if (FOLD && border_tile) {
-#pragma unroll 1
-      for (int e = 0; e < 16; ++e) {
-        const FoldTap ft = kFoldTaps3[e];
-        const bool need_r = ft.rsel == 0 || (ft.rsel == 1 ? has_r1 : has_rH);
-        const bool need_c = ft.csel == 0 || (ft.csel == 1 ? has_c1 : has_cW);
-        if (!(need_r && need_c)) continue;                             // uniform per workgroup
-        const int toff = (ft.ao * HW2 + ft.bo) * PIXB;
-        uint4 bx[TN][3], ax[TM][3];
-        load_b(ft.wtap, cc, bx);
+      for (int tap = 0; tap < 9; ++tap) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (tap < 8) load_a(tap + 1, af[(tap + 1) & 1]);
+        if (tap < 7) load_b(tap + 2, cc, bq[(tap + 2) % 3]);
+        else load_b(tap - 7, ccn, bq[(tap + 2) % 3]);
+        mma6(af[tap & 1], bq[tap % 3]);
+        // issue order: one LDS / global read between consecutive MFMAs (this tap's MFMAs only depend on older reads)
+        if (tap < 8) fp_sched_interleave<TM * 3, TN * 3, 6 * TM * TN>();
+        else fp_sched_interleave<0, TN * 3, 6 * TM * TN>();
+        if (WF) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          const unsigned mr = ft.rsel == 0 ? ~0u : (ft.rsel == 1 ? m_r1[i] : m_rH[i]);
-          const unsigned mc = ft.csel == 0 ? ~0u : (ft.csel == 1 ? m_c1[i] : m_cW[i]);
-          const unsigned mk = mr & mc;
+          for (int e = 0; e < 16; ++e) {
+            const FoldTap ft = fold_tap3(e);
+            if (ft.wtap != tap) continue;                                  // compile time
+            const bool need_r = ft.rsel == 0 || (ft.rsel == 1 ? has_r1 : has_rH);
+            const bool need_c = ft.csel == 0 || (ft.csel == 1 ? has_c1 : has_cW);
+            if (!(need_r && need_c)) continue;                             // uniform per workgroup
+            const int toff = (ft.ao * HW2 + ft.bo) * PIXB;
+            uint4 ax[TM][3];
 #pragma unroll
-          for (int p = 0; p < 3; ++p) {
-            uint4 v = *reinterpret_cast<const uint4*>(Hb + p * PLANE + abase[i] + toff);
-            v.x &= mk; v.y &= mk; v.z &= mk; v.w &= mk;
-            ax[i][p] = v;
+            for (int i = 0; i < TM; ++i) {
+              const unsigned mr = ft.rsel == 0 ? ~0u : (ft.rsel == 1 ? m_r1[i] : m_rH[i]);
+              const unsigned mc = ft.csel == 0 ? ~0u : (ft.csel == 1 ? m_c1[i] : m_cW[i]);
+              const unsigned mk = mr & mc;
+#pragma unroll
+              for (int p = 0; p < 3; ++p) {
+                uint4 v = *reinterpret_cast<const uint4*>(Hb + p * PLANE + abase[i] + toff);
+                v.x &= mk; v.y &= mk; v.z &= mk; v.w &= mk;
+                ax[i][p] = v;
+              }
+            }
+            mma6(ax, bq[tap % 3]);
           }
         }
-        mma6(ax, bx);
       }
     }
     if (cc + 1 < c_end) {
