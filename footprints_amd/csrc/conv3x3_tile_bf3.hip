@@ -406,10 +406,10 @@ Plan3 plan3(const fp_conv_desc* d) {
   p.tilesX = (int)fp_ceil_div(d->OW, p.tw); p.tilesY = (int)fp_ceil_div(d->OH, p.th); p.tilesN = (int)fp_ceil_div(d->Nout, p.bn);
   const int64_t tiles = (int64_t)d->N * p.tilesY * p.tilesX * p.tilesN;
   const int KC16 = (d->C0 + 15) / 16;
-  // small grids: split the channel chunks until ~2 workgroups per CU, >= 2 chunks per split, <= 16 partial copies
+  // small grids: split the channel chunks up to one full round of resident workgroups, >= 2 chunks per split, <= 16 partial copies
   int64_t sk = 1;
   if (tiles < 384) {
-    sk = fp_ceil_div(512, tiles);
+    sk = 768 / tiles;                               // three workgroups per CU are resident: at most one full round of 768
     if (sk > KC16 / 2) sk = KC16 / 2;
     if (sk > 16) sk = 16;
     if (sk < 1) sk = 1;
