@@ -63,7 +63,7 @@ SIGNATURES = {
     "fp_conv_wgrad_bf3": (C.c_int, [_DESC, _P, _P, _P, _P, _I32, _I32, C.c_int, _P, _I64, _P]),
     "fp_conv3x3_bf3_supported": (C.c_int, [_DESC]),
     "fp_conv3x3_bf3_workspace": (_I64, [_DESC]),
-    "fp_conv3x3_bf3": (C.c_int, [_DESC, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
+    "fp_conv3x3_bf3": (C.c_int, [_DESC, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
     "fp_packed_weight_elems_bf3": (_I64, [_I32, _I32, _I32, _I32, _I32]),
     "fp_pack_conv_weight_bf3": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _P]),
     "fp_adam_hyper": (C.c_int, [_D, _D, _D, _D, _I32, _D, _P]),

@@ -26,6 +26,8 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct Tile3Args {
+  const float* src_lo;       // FWD_REFLECT_UP2: the half-resolution tensor whose nearest x2 upsampling forms input channels [0, Clo)
+  int Clo;                   // (0 otherwise); `src` then holds the remaining C - Clo channels at full resolution (the skip tensor)
   const float* src;
   const unsigned short* w;   // bf16 [tap][KC16][3][ncols][16]
   const float* bias;
@@ -106,7 +108,7 @@ __global__ void __launch_bounds__(256) conv3x3_tile_bf3_kernel(const Tile3Args a
   const int y0 = tile_y * TH, x0 = tile_x * TW, n0 = tile_n * BN;
 
   // ---- halo staging slots (unconditional loads; invalid slots read the nearest in-image pixel and are stored as zero) ----------
-  int pix[NS], lds_off[NS];
+  int pix[NS], pixlo[NS], lds_off[NS];
   bool hvalid[NS];
 #pragma unroll
   for (int k = 0; k < NS; ++k) {
@@ -124,15 +126,21 @@ __global__ void __launch_bounds__(256) conv3x3_tile_bf3_kernel(const Tile3Args a
     sy = min(max(sy, 0), a.IH - 1);
     sx = min(max(sx, 0), a.IW - 1);
     pix[k] = (n_img * a.IH + sy) * a.IW + sx;
+    pixlo[k] = (n_img * (a.IH >> 1) + (sy >> 1)) * (a.IW >> 1) + (sx >> 1);     // nearest x2: src = dst // 2 (after the reflection)
   }
   float4 hreg[NS];
   bool hzero = false;
   auto load_halo = [&](int cc) {
     const int c4 = cc * 16 + (t & 3) * 4;
     hzero = c4 >= a.C;
-    const int coff = hzero ? 0 : c4;
+    if (cc * 16 < a.Clo) {                 // uniform: chunks of the upsampled half (Clo is a multiple of 16)
 #pragma unroll
-    for (int k = 0; k < NS; ++k) hreg[k] = *reinterpret_cast<const float4*>(a.src + (size_t)pix[k] * a.C + coff);
+      for (int k = 0; k < NS; ++k) hreg[k] = *reinterpret_cast<const float4*>(a.src_lo + (size_t)pixlo[k] * a.Clo + c4);
+    } else {
+      const int cs = a.C - a.Clo, coff = hzero ? 0 : c4 - a.Clo;
+#pragma unroll
+      for (int k = 0; k < NS; ++k) hreg[k] = *reinterpret_cast<const float4*>(a.src + (size_t)pix[k] * cs + coff);
+    }
   };
   // fp32 -> three bf16 planes, 4 channels (8 bytes) per plane per slot
   auto store_halo = [&](int buf) {
@@ -389,10 +397,15 @@ int launch3(Tile3Args& a, hipStream_t stream) {
 struct Plan3 { bool ok; int th, tw, bn, tilesX, tilesY, tilesN, SK, chunksPerSplit; };
 Plan3 plan3(const fp_conv_desc* d) {
   Plan3 p = {};
-  if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->C1 != 0 || d->C0 % 4) return p;
-  if (d->gather != FP_GATHER_FWD_ZERO && d->gather != FP_GATHER_FWD_REFLECT && d->gather != FP_GATHER_DGRAD_ZERO &&
-      d->gather != FP_GATHER_DGRAD_REFLECT)
-    return p;
+  if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->C0 % 4) return p;
+  if (d->gather == FP_GATHER_FWD_REFLECT_UP2) {       // cat[nearest_x2(low), skip]: chunks switch source at C0
+    if (d->C0 % 16 || d->C1 % 4 || d->C1 < 0 || d->IH % 2 || d->IW % 2) return p;
+  } else {
+    if (d->C1 != 0) return p;
+    if (d->gather != FP_GATHER_FWD_ZERO && d->gather != FP_GATHER_FWD_REFLECT && d->gather != FP_GATHER_DGRAD_ZERO &&
+        d->gather != FP_GATHER_DGRAD_REFLECT)
+      return p;
+  }
   if (d->OH != d->IH || d->OW != d->IW || d->IH < 2 || d->IW < 2) return p;
   // 8x16 tiles, or 6x20 tiles for the 6x20 / 12x40 levels of a 192x640 pyramid; <= 25 % padded work
   auto waste_ok = [&](int th, int tw, int rows) {
@@ -405,7 +418,7 @@ Plan3 plan3(const fp_conv_desc* d) {
   p.bn = d->Nout <= 32 ? 32 : 64;
   p.tilesX = (int)fp_ceil_div(d->OW, p.tw); p.tilesY = (int)fp_ceil_div(d->OH, p.th); p.tilesN = (int)fp_ceil_div(d->Nout, p.bn);
   const int64_t tiles = (int64_t)d->N * p.tilesY * p.tilesX * p.tilesN;
-  const int KC16 = (d->C0 + 15) / 16;
+  const int KC16 = (d->C0 + d->C1 + 15) / 16;
   // small grids: split the channel chunks up to one full round of resident workgroups, >= 2 chunks per split, <= 16 partial copies
   int64_t sk = 1;
   if (tiles < 384) {
@@ -433,9 +446,9 @@ extern "C" int64_t fp_conv3x3_bf3_workspace(const fp_conv_desc* d) {
   return (int64_t)p.SK * d->N * d->OH * d->OW * d->Nout * (int64_t)sizeof(float);
 }
 
-extern "C" int fp_conv3x3_bf3(const fp_conv_desc* d, const float* src, const void* wpacked_bf3, const float* bias, const float* addend,
-                              const float* addend_mask, const float* actsrc, float* y, void* workspace, int64_t workspace_bytes,
-                              fp_stream_t stream_) {
+extern "C" int fp_conv3x3_bf3(const fp_conv_desc* d, const float* src, const float* src1, const void* wpacked_bf3, const float* bias,
+                              const float* addend, const float* addend_mask, const float* actsrc, float* y, void* workspace,
+                              int64_t workspace_bytes, fp_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   FP_REQUIRE(d && src && wpacked_bf3 && y, "fp_conv3x3_bf3: null pointer");
   const Plan3 p = plan3(d);
@@ -447,16 +460,20 @@ extern "C" int fp_conv3x3_bf3(const fp_conv_desc* d, const float* src, const voi
   FP_REQUIRE(p.SK <= 1 || (workspace && workspace_bytes >= fp_conv3x3_bf3_workspace(d)), "fp_conv3x3_bf3: workspace too small");
   FP_REQUIRE((int64_t)d->N * d->OH * d->OW * d->Nout < ((int64_t)1 << 31), "fp_conv3x3_bf3: output larger than 2^31 elements");
   Tile3Args a;
-  a.src = src; a.w = (const unsigned short*)wpacked_bf3; a.bias = bias; a.addend = addend; a.addend_mask = addend_mask; a.actsrc = actsrc;
+  const bool up2 = d->gather == FP_GATHER_FWD_REFLECT_UP2;
+  FP_REQUIRE(!up2 || d->C1 == 0 || src1, "fp_conv3x3_bf3: the concat gather needs the skip tensor (src1)");
+  a.src_lo = up2 ? src : nullptr; a.Clo = up2 ? d->C0 : 0;
+  a.src = up2 ? (d->C1 ? src1 : src) : src; a.w = (const unsigned short*)wpacked_bf3; a.bias = bias; a.addend = addend; a.addend_mask = addend_mask; a.actsrc = actsrc;
   a.y = y;
-  a.N = d->N; a.OH = d->OH; a.OW = d->OW; a.IH = d->IH; a.IW = d->IW; a.C = d->C0; a.Nout = d->Nout; a.KC16 = (d->C0 + 15) / 16;
+  a.N = d->N; a.OH = d->OH; a.OW = d->OW; a.IH = d->IH; a.IW = d->IW; a.C = d->C0 + d->C1; a.Nout = d->Nout;
+  a.KC16 = (d->C0 + d->C1 + 15) / 16;
   const bool flip = d->gather == FP_GATHER_DGRAD_ZERO || d->gather == FP_GATHER_DGRAD_REFLECT;
   const bool fold = d->gather == FP_GATHER_DGRAD_REFLECT;
-  a.mode = d->gather == FP_GATHER_FWD_REFLECT ? 1 : 0;
+  a.mode = (d->gather == FP_GATHER_FWD_REFLECT || up2) ? 1 : 0;
   a.act = d->act; a.epi = d->epi;
   a.tilesX = p.tilesX; a.tilesY = p.tilesY; a.tilesN = p.tilesN; a.SK = p.SK; a.chunksPerSplit = p.chunksPerSplit;
   a.part = (float*)workspace;
-  a.wmajor = (int64_t)9 * d->C0 * d->Nout * 6 > ((int64_t)4 << 20);
+  a.wmajor = (int64_t)9 * (d->C0 + d->C1) * d->Nout * 6 > ((int64_t)4 << 20);
   a.nwg = d->N * p.tilesY * p.tilesX * p.tilesN * p.SK;
   int rc;
 #define FP_L3(TH_, TW_)                                                                                                       \

@@ -223,7 +223,8 @@ class Engine:
                     ex += [ops.packed_weight_elems_bf3(c.Cout, c.Cin, 3, False), ops.packed_weight_elems_bf3(c.Cout, c.Cin, 3, True), 0, 0, 0, 0]
                 else:
                     C0, C1 = c.up2
-                    ex += [0, 0, ops.packed_weight_elems_bf3(c.Cout, C1, 3, False) if C1 else 0,
+                    ex += [ops.packed_weight_elems_bf3(c.Cout, c.Cin, 3, False) if C1 else 0, 0,      # full concat pack: small images
+                           ops.packed_weight_elems_bf3(c.Cout, C1, 3, False) if C1 else 0,
                            ops.packed_weight_elems_bf3(c.Cout, C1, 3, True) if C1 else 0, ops.up2_packed_weight_elems(c.Cout, C0) * 3 // 2,
                            ops.up2_packed_weight_elems(C0, c.Cout) * 3 // 2]
             else:
@@ -256,6 +257,7 @@ class Engine:
                         jobs.append((L.PACK_DGRAD, c.w.data, c.wpd, 0, c.Cin))
                     if c.wp3 is not None:
                         jobs.append((L.PACK_FWD_BF3, c.w.data, c.wp3, 0, c.Cin))
+                    if c.wpd3 is not None:
                         jobs.append((L.PACK_DGRAD_BF3, c.w.data, c.wpd3, 0, c.Cin))
                     if c.wsk3 is not None:
                         jobs.append((L.PACK_FWD_BF3, c.w.data, c.wsk3, c.up2[0], c.up2[1]))
@@ -441,6 +443,8 @@ class Engine:
         d = ops.make_desc(N, H, W, H, W, C0, C1, c.Cout, 3, 1, 1, gather, act=L.ACT_ELU)
         if x1 is None and not up2:
             return self._cv(d, x0, c.wp, c.wp3, out, bias=c.b.data)
+        if up2 and c.wp3 is not None and ops.conv3x3_bf3_supported(d):      # concat gather inside the bf16x3 tile kernel
+            return ops.conv3x3_bf3(d, x0, c.wp3, out, bias=c.b.data, src1=x1)
         return ops.conv_igemm(d, x0, x1, c.wp, out, bias=c.b.data)
 
     # ------------------------------------------------------------------------------------------------

@@ -114,8 +114,9 @@ def conv3x3_bf3_supported(desc):
     return bool(_cached_query("fp_conv3x3_bf3_supported", desc))
 
 
-def conv3x3_bf3(desc, src, wpacked_bf3, y, bias=None, addend=None, addend_mask=None, actsrc=None):
-    """3x3 stride-1 conv / data-gradient with exactly split bf16x3 operands (same semantics as conv_igemm)"""
+def conv3x3_bf3(desc, src, wpacked_bf3, y, bias=None, addend=None, addend_mask=None, actsrc=None, src1=None):
+    """3x3 stride-1 conv / data-gradient with exactly split bf16x3 operands (same semantics as conv_igemm; src1 = the skip tensor
+    of the GATHER_FWD_REFLECT_UP2 concat)"""
     epi = desc.epi | (_lib.EPI_BIAS if bias is not None else 0) | (_lib.EPI_ADDEND if addend is not None else 0) | \
         (_lib.EPI_ADDEND_MASK if addend_mask is not None else 0)
     lib = _lib.load()
@@ -126,7 +127,7 @@ def conv3x3_bf3(desc, src, wpacked_bf3, y, bias=None, addend=None, addend_mask=N
     if need > 0:
         ws = workspace(need, y.device, "igemm")
         ws_ptr, ws_n = ws.data_ptr(), ws.numel()
-    _lib.check(lib.fp_conv3x3_bf3(C.byref(d), _f32(src, "src"), _f32(wpacked_bf3, "wpacked"), _f32(bias), _f32(addend),
+    _lib.check(lib.fp_conv3x3_bf3(C.byref(d), _f32(src, "src"), _f32(src1, "src1"), _f32(wpacked_bf3, "wpacked"), _f32(bias), _f32(addend),
                                   _f32(addend_mask), _f32(actsrc), _f32(y, "y"), ws_ptr, ws_n, stream()), "fp_conv3x3_bf3")
     return y
 

@@ -116,13 +116,14 @@ int fp_pack_conv_weight_dgrad(const float* w_oihw, float* wp, int32_t Cout, int3
  * products (all those >= 2^-16 of the leading one) are accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  The result is
  * closer to the exact dot product than the fp32 MFMA path (the dropped terms are <= 2^-24 relative, below fp32 rounding) and
  * runs at up to 2.7x its MFMA rate.  Same operation, arguments and epilogue flags as fp_conv_igemm for
- * FP_GATHER_{FWD_ZERO, FWD_REFLECT, DGRAD_ZERO, DGRAD_REFLECT} (C1 = 0), for the shapes fp_conv3x3_bf3_supported accepts
+ * FP_GATHER_{FWD_ZERO, FWD_REFLECT, DGRAD_ZERO, DGRAD_REFLECT} (C1 = 0, src1 = NULL) and FP_GATHER_FWD_REFLECT_UP2 (src = the
+ * half-resolution tensor with C0 % 16 == 0 channels, src1 = the skip tensor with C1 channels), for the shapes fp_conv3x3_bf3_supported accepts
  * (3x3 / stride 1 / pad 1; 8x16- or 6x20-pixel tiles with <= 25 % padding; small grids are split along the input
  * channels into raw partials in `workspace`, summed in a fixed order before the epilogue); weights packed by
  * fp_pack_conv_weight_bf3 (fp_packed_weight_elems_bf3 floats of storage) or FP_PACK_{FWD,DGRAD}_BF3 jobs. */
 int fp_conv3x3_bf3_supported(const fp_conv_desc* d);
 int64_t fp_conv3x3_bf3_workspace(const fp_conv_desc* d);   /* split-K scratch for small grids (0 = none) */
-int fp_conv3x3_bf3(const fp_conv_desc* d, const float* src, const void* wpacked_bf3, const float* bias,
+int fp_conv3x3_bf3(const fp_conv_desc* d, const float* src, const float* src1, const void* wpacked_bf3, const float* bias,
                    const float* addend, const float* addend_mask, const float* actsrc, float* y, void* workspace,
                    int64_t workspace_bytes, fp_stream_t stream);
 int64_t fp_packed_weight_elems_bf3(int32_t Cout, int32_t Cin, int32_t KH, int32_t KW, int32_t for_dgrad);

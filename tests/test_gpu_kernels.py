@@ -755,6 +755,21 @@ def test_layout_roundtrip():
     assert float(z.min()) == 2.5 and float(z.max()) == 2.5
 
 
+@pytest.mark.parametrize("N,h,w,C0,C1,Cout", [(12, 6, 20, 256, 256, 256), (8, 24, 32, 32, 16, 32), (16, 16, 32, 32, 0, 64), (12, 4, 24, 64, 64, 96)])
+def test_conv3x3_bf3_up2_concat_gather(N, h, w, C0, C1, Cout):
+    """cat[nearest_x2(low), skip] -> reflect pad -> 3x3 conv + bias + ELU inside the bf16x3 tile kernel (float64 reference)"""
+    ops, L = _ops()
+    wt, b = rnd((Cout, C0 + C1, 3, 3), 340, -0.1, 0.1), rnd((Cout,), 341)
+    lo = rnd((N, C0, h, w), 342)
+    skip = rnd((N, C1, 2 * h, 2 * w), 343) if C1 else None
+    ref = F.elu(_up2_ref(lo.double(), skip.double() if C1 else None, wt.double(), b.double()))
+    d = ops.make_desc(N, 2 * h, 2 * w, 2 * h, 2 * w, C0, C1, Cout, 3, 1, 1, L.GATHER_FWD_REFLECT_UP2, act=L.ACT_ELU)
+    assert ops.conv3x3_bf3_supported(d)
+    y = torch.empty((N, 2 * h, 2 * w, Cout), device="cuda")
+    ops.conv3x3_bf3(d, nhwc(lo), pack_bf3(wt), y, bias=b.cuda(), src1=nhwc(skip) if C1 else None)
+    check(nchw(y), ref, "bf3 up2 concat", 2e-6)
+
+
 @pytest.mark.parametrize("mode,N,H,W,C0,Cout", [
     ("zero", 12, 48, 160, 64, 64), ("reflect", 4, 96, 320, 64, 32), ("reflect", 2, 192, 640, 32, 32), ("reflect", 12, 24, 80, 128, 128),
     ("zero", 6, 12, 40, 256, 256), ("reflect", 3, 10, 46, 32, 96), ("zero", 12, 8, 32, 64, 32), ("reflect", 5, 7, 32, 32, 32)])
