@@ -29,7 +29,7 @@ struct W3Args {
   float* part;        // [S][9][C][Nout]
   float* bpart;       // [S][Nout] column sums of dZ (bias gradient), or null: written by the ci-tile-0 workgroups
   int N, H, W, C, Nout;
-  int mode;           // 0 zero padding, 1 reflection
+  int mode;           // 0 zero padding, 1 reflection, 2 reflection over the nearest-x2 upsampling of x ([N][H/2][W/2][C])
   int chunksY, chunksX, nchunks, chunksPerSplit, S, citiles, cotiles;
 };
 
@@ -92,7 +92,8 @@ __global__ void __launch_bounds__(256) wgrad3x3_bf3_kernel(const W3Args a) {
         if (a.mode == 0) ok = ok && sx >= 0 && sx < a.W;
         else { ok = ok && sx >= -1 && sx <= a.W; sx = fp_reflect(sx, a.W); }
         sx = min(max(sx, 0), a.W - 1);
-        xr[j] = *reinterpret_cast<const float4*>(a.x + ((size_t)(n * a.H + sy) * a.W + sx) * a.C + ci0 + q * 4);
+        const size_t xpix = a.mode == 2 ? (size_t)(n * (a.H >> 1) + (sy >> 1)) * (a.W >> 1) + (sx >> 1) : (size_t)(n * a.H + sy) * a.W + sx;
+        xr[j] = *reinterpret_cast<const float4*>(a.x + xpix * a.C + ci0 + q * 4);
         xmask |= ok ? (1u << j) : 0u;
       }
     }
@@ -231,7 +232,8 @@ __global__ void __launch_bounds__(256) wgrad_bias_reduce_kernel(const float* __r
 
 bool eligible(const fp_conv_desc* d) {
   if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->C1 != 0) return false;
-  if (d->gather != FP_GATHER_FWD_ZERO && d->gather != FP_GATHER_FWD_REFLECT) return false;
+  if (d->gather != FP_GATHER_FWD_ZERO && d->gather != FP_GATHER_FWD_REFLECT && d->gather != FP_GATHER_FWD_REFLECT_UP2) return false;
+  if (d->gather == FP_GATHER_FWD_REFLECT_UP2 && (d->OH % 2 || d->OW % 2)) return false;
   if (d->OH != d->IH || d->OW != d->IW || d->IH < 2 || d->IW < 2) return false;
   if (d->C0 % 32 || d->Nout % 32) return false;
   const int64_t cy = fp_ceil_div(d->OH, CH), cx = fp_ceil_div(d->OW, CW);
@@ -276,7 +278,7 @@ extern "C" int fp_conv_wgrad_bf3(const fp_conv_desc* d, const float* x, const fl
   a.x = x; a.dz = dz; a.part = (float*)workspace;
   a.bpart = db ? (float*)workspace + (size_t)p.S * 9 * d->C0 * d->Nout : nullptr;
   a.N = d->N; a.H = d->OH; a.W = d->OW; a.C = d->C0; a.Nout = d->Nout;
-  a.mode = d->gather == FP_GATHER_FWD_ZERO ? 0 : 1;
+  a.mode = d->gather == FP_GATHER_FWD_ZERO ? 0 : (d->gather == FP_GATHER_FWD_REFLECT_UP2 ? 2 : 1);
   a.chunksY = p.cy; a.chunksX = p.cx; a.nchunks = p.nchunks; a.chunksPerSplit = p.chunksPerSplit; a.S = p.S;
   a.citiles = p.citiles; a.cotiles = p.cotiles;
   hipLaunchKernelGGL(wgrad3x3_bf3_kernel, dim3(p.S * p.citiles * p.cotiles), dim3(256), 0, stream, a);

@@ -605,7 +605,20 @@ class Engine:
         channel slice of the same gradient tensor; shapes the phase kernel does not take keep the fused-gather kernel."""
         H, W = 2 * hl, 2 * wl
         if c.up2 is None or not ops.up2_phase_wgrad_supported(N, hl, wl, C0, c.Cout):
-            return self._wgrad(c, L.GATHER_FWD_REFLECT_UP2, low, skip, dz, N, H, W, H, W, C0, C1, acc, side)
+            d_lo = ops.make_desc(N, H, W, H, W, C0, 0, c.Cout, 3, 1, 1, L.GATHER_FWD_REFLECT_UP2)
+            d_sk = ops.make_desc(N, H, W, H, W, C1, 0, c.Cout, 3, 1, 1, L.GATHER_FWD_REFLECT) if C1 else None
+            if not (_WBF3 and ops.conv_wgrad_bf3_supported(d_lo) and (d_sk is None or ops.conv_wgrad_bf3_supported(d_sk))):
+                return self._wgrad(c, L.GATHER_FWD_REFLECT_UP2, low, skip, dz, N, H, W, H, W, C0, C1, acc, side)
+
+            def launch_small():      # small images (12x40): both halves through the bf16x3 kernel, the upsampling folded into its gather
+                ops.conv_wgrad_bf3(d_lo, low, dz, c.gw, 0, accumulate=acc, db=c.gb)
+                if d_sk is not None:
+                    ops.conv_wgrad_bf3(d_sk, skip, dz, c.gw, C0, accumulate=acc)
+            if side is None:
+                return launch_small()
+            side.wait_event(self._record(ops.current_stream()))
+            with ops.on_stream(side):
+                return launch_small()
 
         def launch():
             pbf3 = _WBF3 and _PWBF3

@@ -130,8 +130,8 @@ int64_t fp_packed_weight_elems_bf3(int32_t Cout, int32_t Cin, int32_t KH, int32_
 int fp_pack_conv_weight_bf3(const float* w_oihw, void* wp, int32_t Cout, int32_t Cin, int32_t KH, int32_t KW,
                             int32_t for_dgrad, fp_stream_t stream);
 
-/* Weight gradient with the same exactly split operands (wgrad3x3_bf3.hip): 3x3 / stride 1 / pad 1, FWD_ZERO or FWD_REFLECT
- * gather, C1 = 0, C0 and Nout multiples of 32; fp_conv_wgrad_bf3_workspace returns -1 for anything else (use fp_conv_wgrad).
+/* Weight gradient with the same exactly split operands (wgrad3x3_bf3.hip): 3x3 / stride 1 / pad 1, FWD_ZERO, FWD_REFLECT or
+ * FWD_REFLECT_UP2 gather (then x is the half-resolution tensor [N][OH/2][OW/2][C0]: the upsampled half of a concat conv), C1 = 0, C0 and Nout multiples of 32; fp_conv_wgrad_bf3_workspace returns -1 for anything else (use fp_conv_wgrad).
  * dw_oihw is [Nout][kc_total][3][3]; the C0 input channels of `d` are its slice [k_begin, k_begin + C0).
  * db (optional, [Nout]): the bias gradient = column sums of dz, produced from the dz tiles the kernel stages anyway
  * (replaces a separate fp_colsum pass over dz); (+)= like dw_oihw. */

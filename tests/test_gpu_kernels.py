@@ -755,6 +755,24 @@ def test_layout_roundtrip():
     assert float(z.min()) == 2.5 and float(z.max()) == 2.5
 
 
+@pytest.mark.parametrize("N,h,w,C0,Cout", [(12, 6, 20, 256, 256), (4, 8, 24, 32, 64), (6, 6, 16, 64, 32)])
+def test_wgrad3x3_bf3_up2_gather(N, h, w, C0, Cout):
+    """weight gradient of the upsampled half of a concat conv with the nearest-x2 gather inside the bf16x3 kernel"""
+    ops, L = _ops()
+    wt = rnd((Cout, C0, 3, 3), 350, -0.1, 0.1).double().requires_grad_(True)
+    lo = rnd((N, C0, h, w), 351)
+    y = _up2_ref(lo.double(), None, wt, None)
+    g = rnd(tuple(y.shape), 352)
+    y.backward(g.double())
+    d = ops.make_desc(N, 2 * h, 2 * w, 2 * h, 2 * w, C0, 0, Cout, 3, 1, 1, L.GATHER_FWD_REFLECT_UP2)
+    assert ops.conv_wgrad_bf3_supported(d)
+    dw = torch.empty((Cout, C0, 3, 3), device="cuda")
+    db = torch.empty((Cout,), device="cuda")
+    ops.conv_wgrad_bf3(d, nhwc(lo), nhwc(g), dw, 0, db=db)
+    check(dw, wt.grad, "wgrad bf3 up2 gather", 3e-6)
+    check(db, g.double().sum((0, 2, 3)), "wgrad bf3 up2 gather bias", 2e-6)
+
+
 @pytest.mark.parametrize("N,h,w,C0,C1,Cout", [(12, 6, 20, 256, 256, 256), (8, 24, 32, 32, 16, 32), (16, 16, 32, 32, 0, 64), (12, 4, 24, 64, 64, 96)])
 def test_conv3x3_bf3_up2_concat_gather(N, h, w, C0, C1, Cout):
     """cat[nearest_x2(low), skip] -> reflect pad -> 3x3 conv + bias + ELU inside the bf16x3 tile kernel (float64 reference)"""
