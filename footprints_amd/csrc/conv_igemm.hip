@@ -21,6 +21,7 @@
 
 #include "fp_common.h"
 
+int fp_stem_tile_dispatch(const fp_conv_desc* d, const float* img, const float* wpacked, const float* bias, float* y, hipStream_t stream);
 int fp_conv3x3_tile_dispatch(const fp_conv_desc* d, const float* src0, const float* src1, const float* wpacked, const float* bias,
                              const float* addend, const float* addend_mask, const float* actsrc, float* y, hipStream_t stream);
 
@@ -408,6 +409,10 @@ extern "C" int fp_conv_igemm(const fp_conv_desc* d, const float* src0, const flo
   FP_REQUIRE(M64 * (int64_t)(d->Nout > d->C0 + d->C1 ? d->Nout : d->C0 + d->C1) < (int64_t)1 << 40 && M64 < (int64_t)1 << 31,
              "fp_conv_igemm: problem too large");
 
+  if (stem) {    // patch-in-LDS kernel (stem_tile.hip); shapes / epilogues it does not take stay on the flattened path
+    const int rc = fp_stem_tile_dispatch(d, src0, wpacked, bias, y, stream);
+    if (rc != -1000) return rc;
+  }
   if (!stem) {   // 3x3 stride-1 convs on large grids: halo-tile kernel (conv3x3_tile.hip)
     static const bool no_tile = getenv("FP_NO_TILE") && atoi(getenv("FP_NO_TILE"));
     if (!no_tile) {

@@ -1,0 +1,105 @@
+// Stem convolution 7x7 / stride 2 / pad 3 over the NCHW image, (x - 0.45) / 0.225 applied before the zero padding
+// (reference footprints/network.py:48-52 + torchvision resnet conv1), fp32 MFMA (v_mfma_f32_32x32x2_f32).
+//
+// The flattened kernel (conv_igemm.hip, STEM) gathers every A element from global memory, four scalar loads per float4 of its
+// K-step: 37 TFLOP/s.  Here a workgroup owns 8 x 16 output pixels x 64 channels and stages the 21 x 37 x 3 input patch it needs
+// ONCE, normalised and zero-padded, in LDS (10 KB); the A operand of every K-step is then one ds_read_b32 per lane
+// (pixel = lane & 31, k = 2 * step + (lane >> 5)), the B operand comes from the FP_PACK_STEM weights [10][64][16] (k = (ky*7 + kx)*3 + ci,
+// zero beyond 147).  Same arithmetic per element as the flattened kernel (fp32 products, fp32 MFMA accumulation, k ascending).
+#include <stdlib.h>
+
+#include "fp_common.h"
+
+namespace {
+
+struct StemArgs {
+  const float* img;    // [N][3][IH][IW]
+  const float* w;      // FP_PACK_STEM
+  const float* bias;   // optional (folded BatchNorm shift)
+  float* y;            // [N][OH][OW][64]
+  int N, IH, IW, OH, OW, tilesX, tilesY, act;
+};
+
+constexpr int TH = 8, TW = 16, PH = 2 * TH + 5, PW = 2 * TW + 5, PWS = 40;   // 21 x 37 patch, row stride 40
+
+__global__ void __launch_bounds__(256) stem_tile_kernel(const StemArgs a) {
+  __shared__ float P[3 * PH * PWS];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, idx = lane & 31, h = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  int b = blockIdx.x;
+  const int tx = b % a.tilesX; b /= a.tilesX;
+  const int ty = b % a.tilesY;
+  const int n = b / a.tilesY;
+  const int y0 = ty * TH, x0 = tx * TW;
+  for (int e = t; e < 3 * PH * PW; e += 256) {
+    const int ci = e / (PH * PW), r = e - ci * (PH * PW);
+    const int py = r / PW, px = r - py * PW;
+    const int iy = 2 * y0 + py - 3, ix = 2 * x0 + px - 3;
+    float v = 0.f;
+    if (iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW) v = (a.img[((size_t)(n * 3 + ci) * a.IH + iy) * a.IW + ix] - 0.45f) / 0.225f;
+    P[(ci * PH + py) * PWS + px] = v;
+  }
+  __syncthreads();
+
+  int pbase[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int pt = (wm * 2 + i) * 32 + idx;
+    pbase[i] = (2 * (pt / TW)) * PWS + 2 * (pt % TW);
+  }
+  f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  const float* wl = a.w + (size_t)(wn * 32 + idx) * 16;
+#pragma unroll 1
+  for (int cc = 0; cc < 10; ++cc) {
+    const float4 w0 = *reinterpret_cast<const float4*>(wl + (size_t)cc * 64 * 16);
+    const float4 w1 = *reinterpret_cast<const float4*>(wl + (size_t)cc * 64 * 16 + 4);
+    const float4 w2 = *reinterpret_cast<const float4*>(wl + (size_t)cc * 64 * 16 + 8);
+    const float4 w3 = *reinterpret_cast<const float4*>(wl + (size_t)cc * 64 * 16 + 12);
+    // lane-parity select of the weight pair of every K-step by bit-select (a ?: over an array element was lowered to scratch)
+    const unsigned hm = 0u - (unsigned)h;
+    auto step = [&](int s, float we, float wo) {
+      const int kk = cc * 16 + 2 * s + h;
+      const int kc = min(kk, 146);
+      const int ky = kc / 21, rem = kc - ky * 21, kx = rem / 3, ci = rem - kx * 3;
+      const int koff = (ci * PH + ky) * PWS + kx;
+      const float bv = __uint_as_float((__float_as_uint(wo) & hm) | (__float_as_uint(we) & ~hm));   // zero for kk >= 147 (packed zeros)
+      const float a0 = kk < 147 ? P[pbase[0] + koff] : 0.f, a1 = kk < 147 ? P[pbase[1] + koff] : 0.f;
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc[1], 0, 0, 0);
+    };
+    step(0, w0.x, w0.y); step(1, w0.z, w0.w); step(2, w1.x, w1.y); step(3, w1.z, w1.w);
+    step(4, w2.x, w2.y); step(5, w2.z, w2.w); step(6, w3.x, w3.y); step(7, w3.z, w3.w);
+  }
+  const int co = wn * 32 + idx;
+  const float bias = a.bias ? a.bias[co] : 0.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int pt = (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      const int oy = y0 + pt / TW, ox = x0 + pt % TW;
+      if (oy >= a.OH || ox >= a.OW) continue;
+      float v = acc[i][r] + bias;
+      if (a.act == FP_ACT_RELU) v = fmaxf(v, 0.f);
+      else if (a.act == FP_ACT_ELU) v = fp_elu(v);
+      a.y[((size_t)(n * a.OH + oy) * a.OW + ox) * 64 + co] = v;
+    }
+}
+
+}  // namespace
+
+// -1000 = not handled (caller falls back to the flattened kernel)
+int fp_stem_tile_dispatch(const fp_conv_desc* d, const float* img, const float* wpacked, const float* bias, float* y, hipStream_t stream) {
+  static const bool off = getenv("FP_NO_STEM_TILE") && atoi(getenv("FP_NO_STEM_TILE"));
+  if (off || d->Nout != 64 || (d->epi & ~(unsigned)FP_EPI_BIAS) || d->IH != 2 * d->OH || d->IW != 2 * d->OW) return -1000;
+  StemArgs a;
+  a.img = img; a.w = wpacked; a.bias = (d->epi & FP_EPI_BIAS) ? bias : nullptr; a.y = y;
+  a.N = d->N; a.IH = d->IH; a.IW = d->IW; a.OH = d->OH; a.OW = d->OW; a.act = d->act;
+  a.tilesX = (int)fp_ceil_div(d->OW, TW); a.tilesY = (int)fp_ceil_div(d->OH, TH);
+  hipLaunchKernelGGL(stem_tile_kernel, dim3(d->N * a.tilesX * a.tilesY), dim3(256), 0, stream, a);
+  return fp_check_launch("fp_conv_igemm(stem)");
+}
