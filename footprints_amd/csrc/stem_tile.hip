@@ -37,7 +37,7 @@ __global__ void __launch_bounds__(256) stem_tile_kernel(const StemArgs a) {
     const int iy = 2 * y0 + py - 3, ix = 2 * x0 + px - 3;
     float v = 0.f;
     if (iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW) v = (a.img[((size_t)(n * 3 + ci) * a.IH + iy) * a.IW + ix] - 0.45f) / 0.225f;
-    P[(ci * PH + py) * PWS + px] = v;
+    P[(ci * PH + py) * PWS + (px & 1) * (PWS / 2) + (px >> 1)] = v;      // columns de-interleaved by parity (see below)
   }
   __syncthreads();
 
@@ -45,7 +45,7 @@ __global__ void __launch_bounds__(256) stem_tile_kernel(const StemArgs a) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int pt = (wm * 2 + i) * 32 + idx;
-    pbase[i] = (2 * (pt / TW)) * PWS + 2 * (pt % TW);
+    pbase[i] = (2 * (pt / TW)) * PWS + (pt % TW);        // patch column 2 * px + kx lives at (kx & 1) * 20 + px + (kx >> 1)
   }
   f32x16 acc[2];
 #pragma unroll
@@ -65,7 +65,7 @@ __global__ void __launch_bounds__(256) stem_tile_kernel(const StemArgs a) {
       const int kk = cc * 16 + 2 * s + h;
       const int kc = min(kk, 146);
       const int ky = kc / 21, rem = kc - ky * 21, kx = rem / 3, ci = rem - kx * 3;
-      const int koff = (ci * PH + ky) * PWS + kx;
+      const int koff = (ci * PH + ky) * PWS + (kx & 1) * (PWS / 2) + (kx >> 1);   // adjacent lanes -> adjacent banks (stride-2 reads conflicted)
       const float bv = __uint_as_float((__float_as_uint(wo) & hm) | (__float_as_uint(we) & ~hm));   // zero for kk >= 147 (packed zeros)
       const float a0 = kk < 147 ? P[pbase[0] + koff] : 0.f, a1 = kk < 147 ? P[pbase[1] + koff] : 0.f;
       acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc[0], 0, 0, 0);
