@@ -9,24 +9,26 @@ forward + fused loss + backward + (bucketed gradient all-reduce when N > 1) + fu
 in HBM before the timed region (configs[2] of BASELINE.json; configs[1], the inference-only forward, is reported
 beside it as fwd_ms_per_img).  Weak scaling: every rank keeps batch 12.  Rank 0 prints ONE JSON line.
 
+`--workload matterport` runs configs[4] (512x640 bs=4) instead of the KITTI step; the metric name carries the workload.
+
 Extra objects in the line:
-  roofline      dominant kernel family = the convolution forward + data-gradient launches: fp_conv3x3_bf3 (halo-tile kernel with
-                fp32 operands split EXACTLY into three bf16 terms, six bf16 MFMA products, fp32 accumulation -- error below the
-                fp32 MFMA's own), its phase-decomposed upsample variant, and fp_conv_igemm (fp32 MFMA) for the rest.
-                achieved = sum of ALGORITHMIC FLOPs of the launches (the dense convolution of the reference graph, also where
-                the phase decomposition executes 4/9 of it) / sum of their durations, measured with HIP events recorded around
-                every launch, on the stream it is launched on, during the first timed steps.  `peak` is the native fp32 MFMA
-                peak (the dtype is f32); `peak_bf16x6` = dense bf16 peak / 6 is the split kernels' own roof.
-                The timed steps run up to five streams concurrently, so a launch shares the chip and its event-to-event
-                duration is longer than its exclusive duration; `achieved_exclusive` / `frac_exclusive` are the same quantity
-                from extra steps (outside the timed region) with concurrency switched off -- the kernels' own speed.
+  roofline      the DOMINANT kernel of the step = the convolution entry point with the largest exclusive time per step, found by an
+                extra pass outside the timed region with concurrency switched off (one stream; HIP events on that stream around
+                every convolution launch of 3 steps).  achieved = MFMA FLOPs the kernel EXECUTES per launch / its average launch
+                duration: for the exactly split bf16x3 kernels that is 6 bf16 products per multiply-add (x = h + m + l), priced
+                against the dense bf16 MFMA peak (2.5 PFLOP/s); the fp32-MFMA kernels (igemm / stem / flattened wgrad) are priced
+                against the fp32 matrix peak (157.3 TFLOP/s).  Phase-decomposed upsample convs count the 4/9 of the dense conv
+                they execute.  `fp32_equiv_tflops` is the same launch in multiply-adds of the reference graph.  `traffic` = HBM
+                bytes per launch from the committed PMC passes (profiles/round2_pmc_hbm_*.json: FETCH_SIZE x2 per the gfx950
+                note of MI355X_MICROARCH.md, WRITE_SIZE as reported) next to the algorithmic bytes, or null when not collected.
+                `groups` lists every convolution kernel family of the step the same way.
   step_conv_tflops  the reference graph's conv FLOPs of one step (fwd + dgrad + wgrad) over the measured step time.
   decoder_backward  SURVEY.md section 8(d): both decoders' backward alone (d loss / d outputs -> d loss / d features + all decoder
-                weight gradients) timed with HIP events, as achieved_hbm = 7.018 GB / t against 8 TB/s and achieved_mfma =
-                1023.9 GFLOP / t against the fp32 MFMA peak (the convolutions are MFMA-bound: F/B 72-755 vs a ridge of ~20).
+                weight gradients) timed with HIP events, as achieved_hbm = algorithmic GB / t against 8 TB/s and achieved_mfma =
+                GFLOP / t against the fp32 MFMA peak and the bf16x6 roof (the convolutions are MFMA-bound: F/B 72-755 vs a ridge of ~20).
   step_ms       median / p10 / p90 of the GPU-side step durations inside the timed region.
-  cpu_baseline  the CPU oracle (a restatement of the reference's PyTorch CPU path, kind "port") timed on this
-                box's host cores on a bounded sample of the same workload (rank 0, N = 1 only).
+  cpu_baseline  the CPU oracle (a restatement of the reference's PyTorch CPU path, kind "port") timed on this box's host cores on
+                ONE full train step of the same workload at the same batch size (rank 0, N = 1 only).
 """
 import argparse
 import json
@@ -43,8 +45,13 @@ sys.path.insert(0, ROOT)
 MFMA_F32_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
 BF16X6_PEAK_TFLOPS = 2500.0 / 6   # dense bf16 MFMA peak / 6 products per fp32-equivalent multiply-add (the split kernels' own roof)
 HBM_PEAK_GBS = 8000.0             # same guide: HBM3E peak
-DEC_BWD_GB, DEC_BWD_GFLOP = 7.018, 1023.9   # decoder backward, both decoders, KITTI bs=12 (fused-minimum bytes; dgrad + wgrad FLOPs)
-B, H, W = 12, 192, 640
+BF16_PEAK_TFLOPS = 2500.0         # same guide: dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16)
+# decoder backward, both decoders (fused-minimum bytes; dgrad + wgrad FLOPs of the reference graph)
+WORKLOADS = {"kitti": dict(B=12, H=192, W=640, dec_gb=7.018, dec_gflop=1023.9,
+                           name="KITTI 192x640 bs=12 full train step (fwd+loss+bwd+Adam), random-init weights, synthetic RGB + masks"),
+             "matterport": dict(B=4, H=512, W=640, dec_gb=6.247, dec_gflop=910.1,
+                                name="Matterport 512x640 bs=4 full train step (fwd+loss+bwd+Adam), random-init weights, synthetic RGB + masks")}
+B, H, W = 12, 192, 640            # set from --workload in main()
 
 
 def network_conv_gflop(n, h, w):
@@ -79,37 +86,57 @@ def network_conv_gflop(n, h, w):
 
 
 class KernelTimer:
-    """HIP-event bracket around every launch of one kernel family (events go on torch's current stream, which
-    is the stream the C ABI launches on)."""
+    """HIP-event bracket around every launch of a set of convolution entry points (events go on torch's current stream, which
+    is the stream the C ABI launches on; used with concurrency switched off, so a bracket is that launch's exclusive time)."""
 
     def __init__(self):
         self.records = []
 
-    def wrap(self, fn, flops_of, key_of=None, name=""):
+    def wrap(self, fn, spec, opname):
         def wrapped(first, *a, **k):
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             r = fn(first, *a, **k)
             e.record()
-            key = key_of(first, *a, **k) if key_of is not None else name + " " + desc_key(first)
-            self.records.append((s, e, flops_of(first, *a, **k), key))
+            g = spec["group"](first, *a, **k) if callable(spec["group"]) else spec["group"]
+            self.records.append((s, e, spec["dense"](first, *a, **k), spec["exec"](first, *a, **k), spec["bytes"](first, *a, **k), g,
+                                 spec["key"](first, *a, **k) if spec.get("key") else opname + " " + desc_key(first)))
             return r
         return wrapped
 
-    def summary(self):
-        ms = sum(r[0].elapsed_time(r[1]) for r in self.records)
-        fl = sum(r[2] for r in self.records)
-        return len(self.records), ms, fl
-
-    def table(self):
-        """Per distinct launch shape: count, mean microseconds, algorithmic TFLOP/s."""
+    def groups(self, steps):
+        """per kernel family: launches / step, exclusive ms / step, executed and reference-graph GFLOP per launch"""
         agg = {}
-        for s, e, f, key in self.records:
-            a = agg.setdefault(key, [0, 0.0, f])
+        for s, e, dense, ex, by, g, _ in self.records:
+            a = agg.setdefault(g, [0, 0.0, 0.0, 0.0, 0.0])
             a[0] += 1
             a[1] += s.elapsed_time(e)
-        rows = [{"shape": k, "launches": n, "avg_us": round(ms / n * 1e3, 1), "gflop": round(f / 1e9, 3),
-                 "tflops": round(f * n / (ms * 1e-3) / 1e12, 1) if ms > 0 else 0.0, "total_ms": round(ms, 3)} for k, (n, ms, f) in agg.items()]
+            a[2] += dense
+            a[3] += ex
+            a[4] += by
+        rows = []
+        for g, (n, ms, dense, ex, by) in agg.items():
+            info = GROUPS[g]
+            products = 6.0 if info["bf16x3"] else 1.0
+            peak = BF16_PEAK_TFLOPS if info["bf16x3"] else MFMA_F32_PEAK_TFLOPS
+            ach = products * ex / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            rows.append({"kernel": info["kernel"], "entry_point": g, "mfma": "bf16 x6 products (exact 3-way split)" if info["bf16x3"] else "fp32",
+                         "launches_per_step": round(n / steps, 1), "exclusive_ms_per_step": round(ms / steps, 3),
+                         "avg_launch_us": round(ms / n * 1e3, 2), "executed_mfma_gflop_per_launch": round(products * ex / n / 1e9, 3),
+                         "achieved": round(ach, 1), "peak": peak, "frac": round(ach / peak, 4),
+                         "fp32_equiv_tflops": round(dense / (ms * 1e-3) / 1e12, 1) if ms > 0 else 0.0,
+                         "algorithmic_mb_per_launch": round(by / n / 1e6, 2)})
+        return sorted(rows, key=lambda r: -r["exclusive_ms_per_step"])
+
+    def table(self):
+        """Per distinct launch shape: count, mean microseconds, reference-graph TFLOP/s."""
+        agg = {}
+        for s, e, dense, ex, by, g, key in self.records:
+            a = agg.setdefault(key, [0, 0.0, dense, g])
+            a[0] += 1
+            a[1] += s.elapsed_time(e)
+        rows = [{"shape": k, "group": g, "launches": n, "avg_us": round(ms / n * 1e3, 1), "gflop": round(f / 1e9, 3),
+                 "tflops": round(f * n / (ms * 1e-3) / 1e12, 1) if ms > 0 else 0.0, "total_ms": round(ms, 3)} for k, (n, ms, f, g) in agg.items()]
         return sorted(rows, key=lambda r: -r["total_ms"])
 
 
@@ -127,39 +154,90 @@ def conv_flops(d, *a, **k):
     return 2.0 * d.N * d.OH * d.OW * d.Nout * taps * kk
 
 
-def phase_fwd_flops(low, wphase, bias, y, *a, **k):
-    """algorithmic FLOPs of the dense 3x3 conv over the x2-upsampled tensor that the phase kernel replaces"""
+def conv_bytes(d, *a, **k):
+    """fused-minimum bytes of one forward / data-gradient / weight-gradient launch: every distinct fp32 element once"""
+    taps = 49 if d.gather == 5 else d.KH * d.KW
+    cin = 3 if d.gather == 5 else d.C0 + d.C1
+    x = d.N * d.IH * d.IW * cin
+    if d.gather == 2:                                            # nearest-x2 of C0 low-res channels + C1 skip channels
+        x = d.N * (d.IH // 2) * (d.IW // 2) * d.C0 + d.N * d.IH * d.IW * d.C1
+    return 4.0 * (x + d.N * d.OH * d.OW * d.Nout + taps * cin * d.Nout)
+
+
+# nearest-x2 phase decomposition: a 3x3 conv over the upsampled tensor = four 2x2 convs over the low-res tensor (4/9 of the MACs)
+def phase_fwd_dense(low, wphase, bias, y, *a, **k):
     N, h, w, C0 = low.shape
     return 2.0 * N * (2 * h) * (2 * w) * y.shape[3] * 9 * C0
 
 
-def phase_dgrad_flops(dz, wpacked, ext, *a, **k):
-    """algorithmic FLOPs of the dense data gradient (3x3 over the hi-res grid) the phase kernel replaces"""
+def phase_fwd_bytes(low, wphase, bias, y, *a, **k):
+    return 4.0 * (low.numel() + y.numel() * (2 if k.get("addend") is not None else 1) + 9 * low.shape[3] * y.shape[3])
+
+
+def phase_dgrad_dense(dz, wpacked, ext, *a, **k):
     N, H2, W2, Cout = dz.shape
     return 2.0 * N * H2 * W2 * Cout * 9 * ext.shape[3]
 
 
-def phase_wgrad_flops(low, dz, *a, **k):
+def phase_dgrad_exec(dz, wpacked, ext, *a, **k):
+    """4 phases x 2x2 taps at every position of the (h+2) x (w+2) extended low-res grid"""
+    N, he, we, C0 = ext.shape
+    return 2.0 * N * he * we * 16 * dz.shape[3] * C0
+
+
+def phase_dgrad_bytes(dz, wpacked, ext, *a, **k):
+    return 4.0 * (dz.numel() + ext.numel() + 9 * dz.shape[3] * ext.shape[3])
+
+
+def phase_wgrad_dense(low, dz, *a, **k):
     N, h, w, C0 = low.shape
     return 2.0 * N * (2 * h) * (2 * w) * dz.shape[3] * 9 * C0
+
+
+def phase_wgrad_bytes(low, dz, dw, *a, **k):
+    return 4.0 * (low.numel() + dz.numel() + 9 * low.shape[3] * dz.shape[3])
+
+
+def _frac(f, frac):
+    return lambda *a, **k: f(*a, **k) * frac
 
 
 def phase_key(tag):
     return lambda low, *a, **k: "%s N%d low %dx%d C%d" % (tag, low.shape[0], low.shape[1], low.shape[2], low.shape[3])
 
 
-# op name -> (flop function, key function): the forward + data-gradient convolution family (roofline) and the weight gradients
-FWD_DGRAD_OPS = {"conv_igemm": (conv_flops, None), "conv3x3_bf3": (conv_flops, None),
-                 "conv_up2_phase_fwd": (phase_fwd_flops, phase_key("phase_fwd")),
-                 "conv_up2_phase_fwd_bf3": (phase_fwd_flops, phase_key("phase_fwd_bf3")),
-                 "conv_up2_phase_dgrad_bf3": (phase_dgrad_flops, lambda dz, *a, **k: "phase_dgrad_bf3 N%d dz %dx%d C%d" % (
-                     dz.shape[0], dz.shape[1], dz.shape[2], dz.shape[3]))}
-WGRAD_OPS = {"conv_wgrad": (conv_flops, None), "conv_wgrad_slice": (conv_flops, None), "conv_wgrad_bf3": (conv_flops, None),
-             "conv_up2_phase_wgrad": (phase_wgrad_flops, phase_key("phase_wgrad"))}
+# entry point (footprints_amd.ops name) -> how its launches are counted.  `exec` = multiply-adds x2 the kernel really executes
+# (the phase kernels run 4/9 of the dense conv), `dense` = the reference graph's conv, `bytes` = fused-minimum HBM bytes.
+GROUPS = {
+    "conv3x3_bf3": dict(kernel="conv3x3_tile_bf3_kernel (+ splitk_reduce_kernel on small grids)", bf16x3=True),
+    "conv_igemm": dict(kernel="igemm_kernel / stem_tile_kernel (stride 2, 1x1, 7x7 stem, 4x4/2 phase dgrad of small levels)", bf16x3=False),
+    "conv_up2_phase_fwd_bf3": dict(kernel="up2_phase_fwd_bf3_kernel", bf16x3=True),
+    "conv_up2_phase_fwd": dict(kernel="up2_phase_fwd_kernel", bf16x3=False),
+    "conv_up2_phase_dgrad_bf3": dict(kernel="up2_phase_dgrad_bf3_kernel", bf16x3=True),
+    "conv_wgrad_bf3": dict(kernel="wgrad3x3_bf3_kernel (+ wgrad_reduce_kernel, wgrad_bias_reduce_kernel of the same entry point)", bf16x3=True),
+    "conv_up2_phase_wgrad_bf3": dict(kernel="wgrad_up2_phase_bf3_kernel (+ its sum / un-collapse / bias reduce launches)", bf16x3=True),
+    "conv_up2_phase_wgrad": dict(kernel="wgrad_up2_phase_kernel", bf16x3=False),
+    "conv_wgrad": dict(kernel="wgrad_kernel / wgrad3x3_tile_kernel (fp32 MFMA: stem, stride 2, 1x1, shapes the bf16x3 kernel rejects)", bf16x3=False),
+}
+CONV_OPS = {
+    "conv_igemm": dict(group="conv_igemm", dense=conv_flops, exec=conv_flops, bytes=conv_bytes),
+    "conv3x3_bf3": dict(group="conv3x3_bf3", dense=conv_flops, exec=conv_flops, bytes=conv_bytes),
+    "conv_up2_phase_fwd": dict(group="conv_up2_phase_fwd", dense=phase_fwd_dense, exec=_frac(phase_fwd_dense, 4.0 / 9.0), bytes=phase_fwd_bytes,
+                               key=phase_key("phase_fwd")),
+    "conv_up2_phase_fwd_bf3": dict(group="conv_up2_phase_fwd_bf3", dense=phase_fwd_dense, exec=_frac(phase_fwd_dense, 4.0 / 9.0),
+                                   bytes=phase_fwd_bytes, key=phase_key("phase_fwd_bf3")),
+    "conv_up2_phase_dgrad_bf3": dict(group="conv_up2_phase_dgrad_bf3", dense=phase_dgrad_dense, exec=phase_dgrad_exec, bytes=phase_dgrad_bytes,
+                                     key=lambda dz, *a, **k: "phase_dgrad_bf3 N%d dz %dx%d C%d" % (dz.shape[0], dz.shape[1], dz.shape[2], dz.shape[3])),
+    "conv_wgrad": dict(group="conv_wgrad", dense=conv_flops, exec=conv_flops, bytes=conv_bytes),
+    "conv_wgrad_slice": dict(group="conv_wgrad", dense=conv_flops, exec=conv_flops, bytes=conv_bytes),
+    "conv_wgrad_bf3": dict(group="conv_wgrad_bf3", dense=conv_flops, exec=conv_flops, bytes=conv_bytes),
+    "conv_up2_phase_wgrad": dict(group=lambda low, dz, dw, *a, **k: "conv_up2_phase_wgrad_bf3" if k.get("bf3") else "conv_up2_phase_wgrad",
+                                 dense=phase_wgrad_dense, exec=_frac(phase_wgrad_dense, 4.0 / 9.0), bytes=phase_wgrad_bytes, key=phase_key("phase_wgrad")),
+}
 
 
 class Instrument:
-    """swap a family of footprints_amd.ops entry points for event-timed wrappers, and back"""
+    """swap the convolution entry points of footprints_amd.ops for event-timed wrappers, and back"""
 
     def __init__(self, ops, table):
         self.ops, self.table = ops, table
@@ -167,12 +245,23 @@ class Instrument:
         self.timer = KernelTimer()
 
     def install(self):
-        for n, (ff, kf) in self.table.items():
-            setattr(self.ops, n, self.timer.wrap(self.orig[n], ff, kf, n))
+        for n, spec in self.table.items():
+            setattr(self.ops, n, self.timer.wrap(self.orig[n], spec, n))
 
     def remove(self):
         for n, f in self.orig.items():
             setattr(self.ops, n, f)
+
+
+def load_traffic(workload, entry_point):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (scripts/pmc_hbm.sh -> profiles/), or None"""
+    path = os.path.join(ROOT, "profiles", "round2_pmc_hbm_%s.json" % workload)
+    try:
+        with open(path) as fh:
+            t = json.load(fh).get(entry_point)
+    except (OSError, ValueError):
+        return None
+    return t
 
 
 def _pick_threads():
@@ -196,42 +285,50 @@ def _pick_threads():
     return best, eff
 
 
-def cpu_baseline(sample_b=2, steps=2):
+def cpu_baseline():
+    """ONE full train step (fwd + loss + bwd + Adam) of the CPU oracle on the SAME workload and batch size as the GPU line
+    (SURVEY.md section 8d / BASELINE.md section 4), after a batch-1 warm-up step; plus the shipped trainer's own setting
+    (one thread, training/train.py:12-14) on one batch-1 step."""
     from oracle import restatement as R
     cores, eff = _pick_threads()
     torch.set_num_threads(cores)
     P, Bf = R.make_state(tag="bench")
     tr = R.OracleTrainer(P, Bf)
     tr.step(R.make_batch(1, H, W, tag="bench.warm"))
-    batch = R.make_batch(sample_b, H, W, tag="bench.cpu")
+    batch = R.make_batch(B, H, W, tag="bench.cpu")
     t0 = time.time()
-    for _ in range(steps):
-        tr.step(batch)
-    dt = (time.time() - t0) / steps
-    # what the shipped trainer does (reference training/train.py:12-14 pins OMP/MKL to one thread): one batch-1 step
+    tr.step(batch)
+    dt = time.time() - t0
     torch.set_num_threads(1)
     t1 = time.time()
     tr.step(R.make_batch(1, H, W, tag="bench.warm"))
     dt1 = time.time() - t1
     torch.set_num_threads(cores)
-    return {"value": round(sample_b / dt, 4), "unit": "img/s", "cores": cores, "kind": "port",
+    return {"value": round(B / dt, 4), "unit": "img/s", "cores": cores, "kind": "port",
             "single_thread": {"value": round(1.0 / dt1, 4), "unit": "img/s", "cores": 1,
                               "sample": "1 full train step at batch 1 with torch.set_num_threads(1), the reference trainer's own setting"},
-            "sample": "%d timed full train steps (fwd+loss+bwd+Adam) of the CPU oracle at %dx%d, batch %d of the 12-image "
-                      "workload, torch.set_num_threads(%d) = fastest of {8,16,32,64,%d} on this host (%d effective cores), "
-                      "after 1 warm-up step" % (steps, H, W, sample_b, cores, eff, eff),
+            "sample": "1 timed full train step (fwd+loss+bwd+Adam) of the CPU oracle at %dx%d, batch %d (the GPU line's workload and batch "
+                      "size), torch.set_num_threads(%d) = fastest of {8,16,32,64,%d} on this host (%d effective cores), after 1 batch-1 "
+                      "warm-up step" % (H, W, B, cores, eff, eff),
             "s_per_step": round(dt, 3), "host_cores": eff}
 
 
 def main():
+    global B, H, W
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="kitti", help="kitti = BASELINE configs[2] (the metric's config); "
+                    "matterport = configs[4] (512x640 bs=4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="N = 1 only: run the data-parallel branch anyway (RCCL communicator, "
+                    "bucketed all-reduces in a world of one rank) -- a dry run of the code path the N > 1 launches take")
     ap.add_argument("--dump-kernels", type=str, default=None, help="write the per-launch-shape timing tables (JSON) here")
     args = ap.parse_args()
+    wl = WORKLOADS[args.workload]
+    B, H, W = wl["B"], wl["H"], wl["W"]
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -239,9 +336,12 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
     torch.cuda.set_device(local_rank)
-    distributed = world > 1
+    distributed = world > 1 or args.force_dist
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if args.force_dist:
+            os.environ["FP_DP_FORCE"] = "1"                        # read when footprints_amd.parallel is imported (below)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from footprints_amd import ops
@@ -263,52 +363,37 @@ def main():
 
     for _ in range(args.warmup):
         step(batch)
-    inst = winst = None
-    if rank == 0 and not args.no_kernel_events:
-        inst = Instrument(ops, FWD_DGRAD_OPS)
-        inst.install()
-        if args.dump_kernels:
-            winst = Instrument(ops, WGRAD_OPS)
-            winst.install()
-    ev_steps = min(args.steps, 4)          # event brackets on the first steps of the timed region only (host cost of
-    barrier()                              # ~300 event records per step would otherwise perturb `value`)
+    barrier()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # one record per step: GPU-side step durations
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(args.steps):
-        if i == ev_steps:
-            for x in (inst, winst):
-                if x is not None:
-                    x.remove()
         step(batch)
         marks[i + 1].record()
     barrier()
     dt = time.perf_counter() - t0
     step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
-    for x in (inst, winst):
-        if x is not None:
-            x.remove()
-    timer = inst.timer if inst is not None else None
-    wtimer = winst.timer if winst is not None else None
-    # kernel-exclusive pass (outside the timed region): same steps, one stream, so launches do not overlap
-    xtimer = None
-    if timer is not None and step.eng.concurrent:
+    t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    final_loss = float(step.losses[20])
+
+    # kernel-exclusive pass (outside the timed region): same steps on ONE stream, HIP events around every convolution launch
+    xtimer, xsteps = None, 3
+    if rank == 0 and not args.no_kernel_events:
+        was = step.eng.concurrent
         step.eng.concurrent = False
         step(batch)
-        xinst = Instrument(ops, FWD_DGRAD_OPS)
+        xinst = Instrument(ops, CONV_OPS)
         xinst.install()
         torch.cuda.synchronize()
-        for _ in range(min(3, args.steps)):
+        for _ in range(xsteps):
             step(batch)
         torch.cuda.synchronize()
         xinst.remove()
         xtimer = xinst.timer
-        step.eng.concurrent = True
-    t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-    if distributed:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
-    final_loss = float(step.losses[20])
+        step.eng.concurrent = was
 
     # decoder backward alone: both decoders, from d loss / d outputs to d loss / d features plus all decoder
     # weight gradients, HIP events around repeated runs on one saved forward (all five streams, joined inside the bracket)
@@ -327,13 +412,16 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         dec_ms = e0.elapsed_time(e1) / 10
-        dec_bwd = {"ms": round(dec_ms, 3), "algorithmic_gb": DEC_BWD_GB, "algorithmic_gflop": DEC_BWD_GFLOP,
-                   "achieved_hbm_gbs": round(DEC_BWD_GB / dec_ms * 1e3, 1), "frac_hbm_peak": round(DEC_BWD_GB / dec_ms * 1e3 / HBM_PEAK_GBS, 4),
-                   "achieved_tflops": round(DEC_BWD_GFLOP / dec_ms, 2), "frac_f32_mfma_peak": round(DEC_BWD_GFLOP / dec_ms / MFMA_F32_PEAK_TFLOPS, 4),
-                   "note": "fused-minimum bytes and reference-graph FLOPs of both decoders' backward (SURVEY.md section 8d), KITTI bs=12; "
-                           "time = HIP events around 10 repetitions after 2 warm-ups"}
+        gb, gf = wl["dec_gb"], wl["dec_gflop"]
+        dec_bwd = {"ms": round(dec_ms, 3), "algorithmic_gb": gb, "algorithmic_gflop": gf,
+                   "achieved_hbm_gbs": round(gb / dec_ms * 1e3, 1), "frac_hbm_peak": round(gb / dec_ms * 1e3 / HBM_PEAK_GBS, 4),
+                   "achieved_tflops": round(gf / dec_ms, 2), "frac_f32_mfma_peak": round(gf / dec_ms / MFMA_F32_PEAK_TFLOPS, 4),
+                   "frac_bf16x6_roof": round(gf / dec_ms / BF16X6_PEAK_TFLOPS, 4),
+                   "note": "fused-minimum bytes and reference-graph FLOPs of both decoders' backward (SURVEY.md section 8d) for this workload; "
+                           "time = HIP events around 10 repetitions after 2 warm-ups; the convolutions are MFMA-bound (72-755 flop/B), the "
+                           "phase decomposition executes 4/9 of the upsample convs' FLOPs"}
 
-    # forward-only latency (configs[1]): eval-mode, no_grad, batch 12
+    # forward-only latency (configs[1]): eval-mode, no_grad, same batch
     mm.model.eval()
     with torch.no_grad():
         for _ in range(2):
@@ -347,14 +435,13 @@ def main():
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
-        out = {"metric": "training images/sec at 192x640 bs=12", "value": round(world * B * args.steps / dt, 2), "unit": "img/s",
+        out = {"metric": "training images/sec at %dx%d bs=%d" % (H, W, B), "value": round(world * B * args.steps / dt, 2), "unit": "img/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "arithmetic": "fp32 tensors and accumulation; 3x3 stride-1 convs (fwd, dgrad, wgrad) multiply exactly split operands "
                              "(x = h + m + l in bf16, 6 of 9 bf16 MFMA products: error <= fp32 MFMA); remaining convs native fp32 MFMA",
-               "config": {"workload": "KITTI 192x640 bs=12 full train step (fwd+loss+bwd+Adam), random-init weights, synthetic RGB + masks",
-                          "per_gpu_batch": B, "global_batch": B * world, "height": H, "width": W,
-                          "parallelism": "dp%d" % world if world > 1 else "single"},
+               "config": {"workload": wl["name"], "per_gpu_batch": B, "global_batch": B * world, "height": H, "width": W,
+                          "parallelism": ("dp%d" % world if world > 1 else "single") + (" (forced data-parallel branch, world of one)" if args.force_dist and world == 1 else "")},
                "fwd_ms_per_img": round(fwd_ms_img, 4), "final_loss": round(final_loss, 5),
                "step_ms": {"median": round(step_ms[len(step_ms) // 2], 3), "p10": round(step_ms[len(step_ms) // 10], 3),
                            "p90": round(step_ms[min(len(step_ms) - 1, (len(step_ms) * 9) // 10)], 3),
@@ -365,31 +452,27 @@ def main():
         # every non-conv kernel, launch gap and the FLOPs the nearest-x2 phase decomposition does not execute
         out["step_conv_tflops"] = {"algorithmic_gflop_per_step": round(gf_step, 1), "tflops": round(gf_step / ms_per_step, 2),
                                    "frac_of_f32_mfma_peak": round(gf_step / ms_per_step / MFMA_F32_PEAK_TFLOPS, 4),
+                                   "frac_of_bf16x6_roof": round(gf_step / ms_per_step / BF16X6_PEAK_TFLOPS, 4),
                                    "fwd_algorithmic_gflop": round(gf_fwd, 1), "fwd_tflops": round(gf_fwd / (fwd_ms_img * B), 2)}
-        if timer is not None:
-            n, ms, fl = timer.summary()
-            ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-            out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
-                               "traffic_note": "PMC FETCH_SIZE x2 / WRITE_SIZE per launch = 1.0-1.04x the algorithmic input / output bytes "
-                                               "(profiles/round1_pmc_hbm_conv_bf3.txt; collected with rocprofv3 --pmc, not inside bench.py)",
-                               "peak_bf16x6": BF16X6_PEAK_TFLOPS, "frac_bf16x6": round(ach / BF16X6_PEAK_TFLOPS, 4),
-                               "kernel": "convolution forward + data-gradient launches: fp_conv3x3_bf3 (conv3x3_tile_bf3_kernel: fp32 operands split "
-                                         "exactly into 3 bf16 terms, 6 v_mfma_f32_32x32x16_bf16 products, fp32 accumulate), fp_conv_up2_phase_fwd_bf3, "
-                                         "fp_conv_igemm (igemm_kernel, v_mfma_f32_32x32x2_f32: stride 2, 1x1, 4x4/2 phase dgrad, stem)",
-                               "launches_per_step": n // max(ev_steps, 1), "avg_launch_us": round(ms / max(n, 1) * 1e3, 2),
-                               "algorithmic_gflop_per_launch": round(fl / max(n, 1) / 1e9, 3),
-                               "kernel_ms_per_step": round(ms / max(ev_steps, 1), 3), "event_steps": ev_steps,
-                               "concurrent_streams": bool(step.eng.concurrent)}
-            if xtimer is not None:
-                xn, xms, xfl = xtimer.summary()
-                xach = xfl / (xms * 1e-3) / 1e12 if xms > 0 else 0.0
-                out["roofline"].update({"achieved_exclusive": round(xach, 2), "frac_exclusive": round(xach / MFMA_F32_PEAK_TFLOPS, 4),
-                                        "frac_exclusive_bf16x6": round(xach / BF16X6_PEAK_TFLOPS, 4),
-                                        "avg_launch_us_exclusive": round(xms / max(xn, 1) * 1e3, 2)})
-        if args.dump_kernels and timer is not None:
+        if xtimer is not None:
+            groups = xtimer.groups(xsteps)
+            dom = groups[0]
+            tr = load_traffic(args.workload, dom["entry_point"])
+            out["roofline"] = {"bound": "mfma", "achieved": dom["achieved"], "peak": dom["peak"], "unit": "TFLOP/s", "frac": dom["frac"],
+                               "traffic": tr,
+                               "kernel": dom["kernel"], "entry_point": "fp_" + dom["entry_point"], "mfma": dom["mfma"],
+                               "launches_per_step": dom["launches_per_step"], "avg_launch_us": dom["avg_launch_us"],
+                               "exclusive_ms_per_step": dom["exclusive_ms_per_step"],
+                               "executed_mfma_gflop_per_launch": dom["executed_mfma_gflop_per_launch"],
+                               "fp32_equiv_tflops": dom["fp32_equiv_tflops"], "algorithmic_mb_per_launch": dom["algorithmic_mb_per_launch"],
+                               "how": "dominant = largest exclusive time per step among the convolution entry points; HIP events on the launch "
+                                      "stream around every launch of %d extra steps with concurrency off (one stream), outside the timed region; "
+                                      "achieved = executed MFMA FLOPs (6 bf16 products per multiply-add for the exact split) / duration" % xsteps,
+                               "conv_exclusive_ms_per_step": round(sum(g["exclusive_ms_per_step"] for g in groups), 3),
+                               "groups": groups}
+        if args.dump_kernels and xtimer is not None:
             with open(args.dump_kernels, "w") as fh:
-                json.dump({"igemm": timer.table(), "wgrad": wtimer.table()}, fh, indent=1)
+                json.dump({"groups": xtimer.groups(xsteps), "shapes": xtimer.table()}, fh, indent=1)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -195,6 +195,12 @@ class Engine:
             for c in d.convs() + d.heads:
                 bind_conv(c)
 
+    def invalidate(self):
+        """the parameters were written behind autograd's back (`p.data.copy_`, a broadcast, ...): `Parameter._version` does not
+        move for `.data` writes, so the packed / BN-folded weight copies must be told"""
+        self.weights_dirty = True
+        self._fold_ready = False
+
     def params_alias_flat(self):
         p0 = self.live_params[0]
         return p0.data_ptr() == self.flat_param.data_ptr()
@@ -666,6 +672,10 @@ class Engine:
             raise RuntimeError("backward called without a saved forward")
         if not S["training"]:
             raise RuntimeError("backward through eval-mode BatchNorm is not supported by the HIP engine")
+        if not all(p.requires_grad for p in self.live_params):
+            frozen = [n for n, p in zip(self.live_names, self.live_params) if not p.requires_grad]
+            raise RuntimeError("footprints_amd: frozen parameters (requires_grad=False) are not supported by the fused backward / "
+                               "Adam -- they would be trained silently: %s ..." % frozen[:3])
         N = S["N"]
         feats, dims = S["feats"], S["dims"]
         buf = self.buf
@@ -922,18 +932,21 @@ class NetFunction(torch.autograd.Function):
         if eng.saved is not ctx.token:
             raise RuntimeError("footprints_amd: activations of this forward were overwritten by a later forward; "
                                "call backward before the next forward (the arena is reused every step)")
-        grads = []
-        shape = gouts[0].shape if gouts[0] is not None else None
-        for g in gouts:
-            if g is None:
-                g = torch.zeros(shape, device=eng.device)
-            grads.append(g.contiguous())
-        aliased = all(p.grad is not None and p.grad.data_ptr() == v.data_ptr() for p, v in zip(eng.live_params, eng.grad_views))
-        stale = [p.grad for p in eng.live_params] if not aliased else None
-        eng.backward(grads, accumulate=aliased)
-        # gradients live in the flat buffer; hand them to the parameters without a copy
-        for i, (p, v) in enumerate(zip(eng.live_params, eng.grad_views)):
-            if stale is not None and stale[i] is not None:
-                v.add_(stale[i])          # rare path: user accumulated into foreign .grad tensors
+        shape = next(g.shape for g in gouts if g is not None)
+        grads = [torch.zeros(shape, device=eng.device) if g is None else g.contiguous() for g in gouts]
+        # .grad semantics of autograd: ACCUMULATE into existing gradients.  Gradients live in the flat buffer, so decide per
+        # parameter where its previous gradient is: nowhere (None), already in its flat slot (aliased), or in a foreign tensor.
+        state = [0 if p.grad is None else (1 if p.grad.data_ptr() == v.data_ptr() else 2) for p, v in zip(eng.live_params, eng.grad_views)]
+        if all(s == 0 for s in state):
+            eng.backward(grads, accumulate=False)           # the usual step: zero_grad(set_to_none=True) -> overwrite
+        else:
+            if not all(s == 1 for s in state):               # mixed: bring every previous gradient into its flat slot first
+                for p, v, s in zip(eng.live_params, eng.grad_views, state):
+                    if s == 0:
+                        v.zero_()
+                    elif s == 2:
+                        v.copy_(p.grad)
+            eng.backward(grads, accumulate=True)
+        for p, v in zip(eng.live_params, eng.grad_views):    # hand the flat views to the parameters without a copy
             p.grad = v
         return (None, None) + tuple(None for _ in eng.live_params)

@@ -1,0 +1,28 @@
+"""Entry point -- counterpart of footprints/main.py:8-26: `python -m footprints_amd.main --mode train ...`.
+
+The KITTI / Matterport dataset readers are outside this build's scope: training runs over any
+iterable of batches with the reference schema; with `--synthetic_steps N` it runs over the synthetic loader the benchmark
+uses.  Inference mode needs a loader of {'image', 'idx'} batches and is therefore only reachable programmatically
+(`footprints_amd.evaluation.inference.InferenceManager(...).run(loader)`)."""
+from .options import Options
+from .training.train import SyntheticLoader, TrainManager
+
+
+def main(argv=None):
+    opt = Options().parse(argv)
+    if opt.mode == "train":
+        print("In training mode!")
+        if opt.synthetic_steps <= 0:
+            raise SystemExit("no dataset readers in this build: pass --synthetic_steps N, or construct TrainManager(options, "
+                             "train_loader=..., val_loader=...) with your own loaders")
+        train = SyntheticLoader(opt.batch_size, opt.height, opt.width, opt.synthetic_steps)
+        val = SyntheticLoader(opt.batch_size, opt.height, opt.width, max(1, opt.val_batches), seed=11)
+        TrainManager(opt, train_loader=train, val_loader=val).train()
+    elif opt.mode == "inference":
+        raise SystemExit("inference mode needs a dataset loader: use footprints_amd.evaluation.inference.InferenceManager")
+    else:
+        raise NotImplementedError
+
+
+if __name__ == "__main__":
+    main()

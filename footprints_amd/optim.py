@@ -54,6 +54,7 @@ class FusedAdam(torch.optim.Optimizer):
         ops.adam_step(eng.flat_param, eng.flat_grad, m, v, g["lr"], g["betas"][0], g["betas"][1], g["eps"], self._step,
                       self.grad_scale)
         eng.weights_dirty = True
+        self._opt_called = True                      # what lr_scheduler's wrapper of step() records (no "scheduler before optimizer" warning)
 
     # ---- graph replay: launch with device-resident scalars, refreshed by the host before each replay ----------
     def graph_step(self, eng, hyper_dev):

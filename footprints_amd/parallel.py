@@ -18,6 +18,9 @@ import torch.distributed as dist
 # observed to produce wrong sums (profiles/round1_notes.md), so by default the buckets are reduced AFTER the backward pass
 # (124 MB over xGMI: ~1 ms of a 23 ms step).  FP_DP_OVERLAP=1 restores the overlapped schedule.
 _OVERLAP = bool(int(os.environ.get("FP_DP_OVERLAP", "0")))
+# FP_DP_FORCE=1: issue the bucket collectives even in a world of one rank (a 1-GPU box can then execute the RCCL code path:
+# communicator creation, bucket all-reduces on the comm stream, event gating -- tests/test_gpu_dp.py, `bench.py --force-dist`)
+_FORCE = bool(int(os.environ.get("FP_DP_FORCE", "0")))
 
 
 def bucket_ranges(names, offsets, total, max_elems=8 << 20):
@@ -56,8 +59,9 @@ def bucket_ranges(names, offsets, total, max_elems=8 << 20):
 class GradReducer:
     """Bucketed, stream-overlapped all-reduce of a flat gradient buffer."""
 
-    def __init__(self, flat_grad, names, offsets, group=None, max_elems=8 << 20, overlap=None):
+    def __init__(self, flat_grad, names, offsets, group=None, max_elems=8 << 20, overlap=None, force=None):
         self.flat = flat_grad
+        self.force = _FORCE if force is None else bool(force)
         # overlap: issue each bucket as soon as its stage is complete (default on CPU/gloo; on GPUs see _OVERLAP above)
         self.overlap = (_OVERLAP or not flat_grad.is_cuda) if overlap is None else bool(overlap)
         self.group = group
@@ -74,7 +78,7 @@ class GradReducer:
 
     def stage_ready(self, stage):
         """Called by the backward schedule when every gradient of `stage` has been written."""
-        if self.world == 1 or stage in self._done_stage:
+        if (self.world == 1 and not self.force) or stage in self._done_stage:
             return
         self._done_stage.add(stage)
         if self.cuda:
@@ -92,7 +96,7 @@ class GradReducer:
 
     def finish(self):
         """Make the compute stream wait for every outstanding bucket (call before the optimiser step)."""
-        if self.world > 1:
+        if self.world > 1 or self.force:
             for s in ("mask_decoder", "depth_decoder", "encoder.layer4", "encoder.layer3", "encoder.layer2", "encoder.layer1",
                       "encoder.layer0"):
                 self.stage_ready(s)          # anything the schedule did not report explicitly
@@ -105,8 +109,18 @@ class GradReducer:
 
 
 def broadcast_state(model, src=0, group=None):
-    """Initial weight/buffer sync so every replica starts identical (rank `src` wins)."""
+    """Initial weight/buffer sync so every replica starts identical (rank `src` wins).  With a HIP engine attached the live
+    parameters are ONE flat buffer: broadcast that (one collective instead of 196), then tell the engine its packed / BN-folded
+    weight copies are stale -- `.data` writes do not move `Parameter._version` (Engine.invalidate)."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
+    eng = getattr(model, "_engine", None)
+    done = set()
+    if eng is not None and eng.params_alias_flat():
+        dist.broadcast(eng.flat_param, src=src, group=group)
+        done = {id(p) for p in eng.live_params}
     for t in list(model.parameters()) + list(model.buffers()):
-        dist.broadcast(t.data, src=src, group=group)
+        if id(t) not in done:
+            dist.broadcast(t.data, src=src, group=group)
+    if eng is not None:
+        eng.invalidate()

@@ -120,36 +120,124 @@ def synthetic_batch(B, H, W, device, seed=SEED):
     return {k: v.to(device) for k, v in t.items()}
 
 
-class TrainManager:
-    """Reference loop structure (train.py:42-227) over any iterable of batches."""
+class SyntheticLoader:
+    """`steps` batches per epoch with the reference schema (datasets/footprint_dataset.py:55-65): a small pool of synthetic
+    batches resident on the device, cycled.  Stands in for the KITTI / Matterport DataLoaders, which are out of scope."""
 
-    def __init__(self, loader, epochs=10, learning_rate=1e-4, lr_step_size=10, depth_range=(0.1, 100.0), footprint_prior=0.25,
-                 save_folder=None, log=print):
-        torch.manual_seed(SEED)
-        self.loader, self.epochs, self.log = loader, epochs, log
-        self.model_manager = ModelManager(save_folder=save_folder, use_cuda=True, learning_rate=learning_rate,
-                                          lr_step_size=lr_step_size)
+    def __init__(self, batch_size, height, width, steps, seed=SEED, pool=2, device="cuda"):
+        self.steps = steps
+        self.batches = [synthetic_batch(batch_size, height, width, device, seed=seed + i) for i in range(pool)]
+        self.dataset = range(steps * batch_size)           # len(loader.dataset) is what the reference logs (train.py:76-77)
+
+    def __len__(self):
+        return self.steps
+
+    def __iter__(self):
+        for i in range(self.steps):
+            yield dict(self.batches[i % len(self.batches)])
+
+
+class _Opts:
+    """keyword-style construction of the options namespace (the reference passes an argparse namespace, options.py)"""
+
+    def __init__(self, **kw):
+        self.epochs, self.lr, self.depth_range, self.footprint_prior = 10, 1e-4, [0.1, 100], 0.25
+        self.log_freq, self.val_batches, self.log_path, self.model_name, self.load_path = 250, 10, None, "model", None
+        self.__dict__.update(kw)
+
+
+class TrainManager:
+    """Reference loop structure (training/train.py:42-215) over any iterable of batches with the reference schema.
+
+    `TrainManager(options, train_loader=..., val_loader=...)` with the namespace of `footprints_amd.options.Options` (same
+    flags as the reference), or `TrainManager(loader, epochs=..., ...)` keyword style.  Per step (train.py:147-159): the fused
+    `TrainStep` (forward + loss + zero_grad + backward + Adam in one schedule) and the 21 losses handed to the `Evaluator` as
+    one device vector (no synchronisation); every 100 steps the averaged-loss console line (train.py:161-166); every
+    `log_freq` steps a validation pass over `val_batches` batches in eval mode (train.py:174-185, 193-215: forward + loss
+    through the drop-in `model(x)` / `Evaluator.compute_losses` surface under no_grad); per epoch the checkpoint and
+    `scheduler.step()` (train.py:189-191).  Tensorboard writing is out of scope: `self.history` keeps
+    what `log(...)` would have received."""
+
+    def __init__(self, options=None, train_loader=None, val_loader=None, log=print, **kw):
+        if options is not None and not hasattr(options, "epochs"):       # keyword style: first positional is the loader
+            train_loader, options = options, None
+        self.opt = options if options is not None else _Opts(**kw)
+        if options is not None and kw:
+            self.opt.__dict__.update(kw)
+        if "learning_rate" in kw:
+            self.opt.lr = kw["learning_rate"]
+        if "loader" in kw:
+            train_loader = kw["loader"]
+        torch.manual_seed(SEED)                                          # train.py:33-35
+        self.train_loader, self.val_loader, self.log = train_loader, val_loader, log
+        self.loader = train_loader
+        save_folder = kw.get("save_folder")
+        if save_folder is None and getattr(self.opt, "log_path", None):
+            save_folder = os.path.join(self.opt.log_path, self.opt.model_name, "models")     # train.py:57-59
+        self.model_manager = ModelManager(save_folder=save_folder, use_cuda=True, learning_rate=self.opt.lr,
+                                          lr_step_size=kw.get("lr_step_size", 10))
+        if getattr(self.opt, "load_path", None) is not None:
+            self.model_manager.load_model(weights_path=self.opt.load_path, load_optimiser=True)   # train.py:63-64
         self.model = self.model_manager.model
         self.optimiser, self.scheduler = self.model_manager.optimiser, self.model_manager.scheduler
-        self.evaluator = Evaluator(depth_range, footprint_prior, compute_viz=False)
-        self.train_step = TrainStep(self.model, self.optimiser, depth_range, footprint_prior)
+        self.val_iter = iter(self.val_loader) if self.val_loader is not None else None
+        depth_range = tuple(self.opt.depth_range)
+        self.evaluator = Evaluator(depth_range, self.opt.footprint_prior, compute_viz=False)
+        self.train_step = TrainStep(self.model, self.optimiser, depth_range, self.opt.footprint_prior)
+        self.epochs = self.opt.epochs
         self.step = 0
-        self.train_network_time = 0.0
+        self.lr = self.opt.lr
+        self.num_total_steps = (len(train_loader) if hasattr(train_loader, "__len__") else 0) * self.epochs
+        self.train_network_time = self.val_time = 0.0
+        self.history = {"train": [], "val": []}                          # (step, averaged losses) per log event
 
     def train(self):
+        self.start_time = time.time()
         for self.epoch in range(self.epochs):
             self.run_epoch()
 
     def run_epoch(self):
-        for batch_idx, inputs in enumerate(self.loader):
+        for batch_idx, inputs in enumerate(self.train_loader):
             t0 = time.time()
-            inputs = {k: v.cuda(non_blocking=True) for k, v in inputs.items()}     # train.py:220-222
-            losses = self.train_step(inputs)
-            if self.step % 100 == 0:
-                torch.cuda.synchronize()
-                self.log("Epoch {} -- Batch {} -- Loss {}".format(self.epoch, batch_idx, float(losses[20])))
+            inputs = {k: v.cuda(non_blocking=True) for k, v in inputs.items()}     # process_batch: train.py:220-222
+            losses = self.train_step(inputs)                                       # train.py:150-156 in one schedule
+            self.evaluator.add_loss_vector(losses, mode="train")
+            self.lr = self.scheduler.get_last_lr()[0]
             self.train_network_time += time.time() - t0
+            if self.step % 100 == 0:                                               # train.py:161-185
+                avg = self.evaluator.get_averaged_losses(mode="train", reset=False)
+                self.log("Epoch {} -- Batch {} -- Loss {}".format(self.epoch, batch_idx, avg["loss"]))
+                if self.step % self.opt.log_freq == 0:
+                    avg = self.evaluator.get_averaged_losses(mode="train", reset=True)
+                    self.history["train"].append((self.step, avg))
+                    if self.val_loader is not None:
+                        self.model.eval()
+                        self.val()
+                        self.model.train()
             self.step += 1
         if self.model_manager.save_folder is not None:
             self.model_manager.save_model(folder_name="weights_{}".format(self.epoch))   # train.py:190
         self.scheduler.step()                                                             # train.py:191
+
+    def val(self):
+        """train.py:193-215 (with `next(it)`: the reference's `self.val_iter.next()` no longer exists in PyTorch)"""
+        t0 = time.time()
+        with torch.no_grad():
+            for _ in range(self.opt.val_batches):
+                try:
+                    inputs = next(self.val_iter)
+                except StopIteration:
+                    self.val_iter = iter(self.val_loader)
+                    inputs = next(self.val_iter)
+                self.process_batch(inputs, mode="val", return_batch_loss=False)
+        avg = self.evaluator.get_averaged_losses(mode="val", reset=True)
+        self.history["val"].append((self.step, avg))
+        self.val_time += time.time() - t0
+        return avg
+
+    def process_batch(self, inputs, mode="train", return_batch_loss=False):
+        """train.py:217-227: the drop-in surface -- model(x) then Evaluator.compute_losses"""
+        inputs = {k: v.cuda(non_blocking=True) for k, v in inputs.items()}
+        outputs = self.model(inputs["image"])
+        losses = self.evaluator.compute_losses(inputs, outputs, mode=mode, return_batch_loss=return_batch_loss)
+        return outputs, losses

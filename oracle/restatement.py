@@ -313,3 +313,28 @@ class OracleTrainer:
             p.grad = None
         losses["loss"].backward()
         return out, losses
+
+
+# --------------------------------------------------------------------------
+# Evaluator (training/evaluation.py:14-67)
+# --------------------------------------------------------------------------
+class OracleEvaluator:
+    """compute_losses / get_averaged_losses bookkeeping of training/evaluation.py:28-67 over `loss_manager`."""
+
+    def __init__(self, depth_range=(0.1, 100), prior=0.25):
+        self.depth_range, self.prior = depth_range, prior
+        self.acc = {"train": {}, "val": {}}
+
+    def compute_losses(self, inputs, outputs, mode="train", return_batch_loss=False):
+        losses, _ = loss_manager(outputs, inputs, self.depth_range, self.prior)
+        if mode in self.acc:
+            for k, v in losses.items():                                  # evaluation.py:38-43
+                self.acc[mode].setdefault(k, []).append(v.detach().cpu())
+        if return_batch_loss:                                            # evaluation.py:45-46
+            return losses
+
+    def get_averaged_losses(self, mode, reset=True):
+        out = {k: float(torch.stack(v).mean().numpy()) for k, v in self.acc.get(mode, {}).items()}   # evaluation.py:52-55
+        if reset and mode in self.acc:
+            self.acc[mode] = {}
+        return out

@@ -228,6 +228,39 @@ def g7_metrics():
     return out
 
 
+def g8_evaluator():
+    """training/evaluation.py:28-67: the reference's own Evaluator over three 'train' and two 'val' batches of random
+    predictions: averaged losses without reset, with reset, and the per-batch values of the last call (return_batch_loss)."""
+    import importlib
+    ev_mod = importlib.import_module("footprints.training.evaluation")
+    ev = ev_mod.Evaluator((0.1, 100), 0.25)
+    out = {}
+    B, H, W = 2, 16, 32
+
+    def preds(tag):
+        d = {}
+        for k in R.SCALES:
+            p = fill("g8.%s.pred%s" % (tag, k), (B, 4, H, W), -3.0, 3.0)
+            p[:, 2:] = torch.sigmoid(p[:, 2:])
+            d[k] = p
+        return d
+    last = None
+    for i in range(3):
+        last = ev.compute_losses(R.make_batch(B, H, W, tag="g8.train%d" % i), preds("train%d" % i), mode="train", return_batch_loss=True)
+    out["eval.last_batch"] = np.array([float(last[k]) for k in R.LOSS_KEYS], dtype=np.float64)
+    for i in range(2):
+        r = ev.compute_losses(R.make_batch(B, H, W, tag="g8.val%d" % i), preds("val%d" % i), mode="val")
+        assert r is None                                                               # evaluation.py:45-46
+    a = ev.get_averaged_losses("train", reset=False)
+    b = ev.get_averaged_losses("train", reset=True)
+    c = ev.get_averaged_losses("train", reset=True)
+    assert a == b and c == {}
+    out["eval.train_avg"] = np.array([a[k] for k in R.LOSS_KEYS], dtype=np.float64)
+    v = ev.get_averaged_losses("val", reset=True)
+    out["eval.val_avg"] = np.array([v[k] for k in R.LOSS_KEYS], dtype=np.float64)
+    return out
+
+
 def main():
     mods = ref_import.load_reference()
     assert mods is not None, "needs /root/reference"
@@ -238,7 +271,7 @@ def main():
     for name, fn in (("g1_blocks", lambda: g1_blocks(net)), ("g2_decoder", lambda: g2_decoder(net)),
                      ("g3_network", lambda: g3_network(net)), ("g4_loss", lambda: g4_loss(loss_mod)),
                      ("g5_train", lambda: g5_train(net, loss_mod)), ("g6_predict", lambda: g6_predict(net)),
-                     ("g7_metrics", g7_metrics)):
+                     ("g7_metrics", g7_metrics), ("g8_evaluator", g8_evaluator)):
         if only and name not in only:
             continue
         d = fn()

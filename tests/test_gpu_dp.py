@@ -56,6 +56,10 @@ def _worker(rank, world, port, q, overlap):
         mm = ModelManager()
         P, Bf = _state("dp" if rank == 0 else "dp.other")     # rank 1 starts from different weights: broadcast_state must fix that
         _load(mm.model, P, Bf)
+        mm.model.eval()
+        with torch.no_grad():                                   # a forward BEFORE the broadcast: the engine now holds packed / BN-folded copies
+            mm.model(_shard(rank)["image"])                     # of this rank's own weights, which broadcast_state has to invalidate
+        mm.model.train()
         broadcast_state(mm.model)
         ts = TrainStep(mm.model, mm.optimiser, distributed=True)
         assert ts.reducer is not None and ts.reducer.world == 2 and ts.reducer.overlap == bool(overlap)
@@ -126,3 +130,78 @@ def test_two_ranks_share_weights_and_match_summed_shard_gradients(overlap):
     err = np.abs(w0.astype(np.float64) - ref).max() / np.abs(ref).max()
     assert err < 1e-6, err
     assert res[0][3][-1] != res[1][3][-1]                                 # different shards => different per-rank losses
+
+
+def _nccl_worker(port, q):
+    try:
+        import torch.distributed as dist
+        os.environ["FP_DP_FORCE"] = "1"                           # issue the bucket collectives although world == 1
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        from footprints_amd.model_manager import ModelManager
+        from footprints_amd.training.train import TrainStep
+        P, Bf = _state("dp")
+        batch = _shard(0)
+        res = []
+        for mode in ("single", "after", "overlap"):
+            mm = ModelManager()
+            _load(mm.model, P, Bf)
+            ts = TrainStep(mm.model, mm.optimiser, distributed=(mode != "single"))
+            if ts.reducer is not None:
+                ts.reducer.overlap = (mode == "overlap")
+                assert ts.reducer.force and ts.reducer.world == 1 and len(ts.reducer.buckets) >= 7
+            losses = [float(ts(batch)[20]) for _ in range(3)]
+            torch.cuda.synchronize()
+            res.append((losses, torch.cat([p.detach().flatten() for p in mm.model.parameters()]).cpu().numpy()))
+        q.put(("ok", res))
+        dist.destroy_process_group()
+    except Exception as e:
+        import traceback
+        q.put(("error", traceback.format_exc(), repr(e)))
+
+
+def test_rccl_path_world_of_one_executes_and_is_exact():
+    """The RCCL code path (`init_process_group("nccl")`, GradReducer's bucket all-reduces on the comm stream, event gating, both
+    schedules) executed on the 1-GPU box with a world of one rank: a sum over one rank is the identity, so three steps must be
+    BIT-identical to the non-distributed TrainStep -- a wrong wait / a bucket reduced before its gradients landed would show."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_worker, args=(_free_port(), q))
+    p.start()
+    try:
+        r = q.get(timeout=600)
+    except Exception:
+        if p.is_alive():
+            p.terminate()
+        pytest.skip("the nccl worker did not report within 600 s")
+    p.join(timeout=120)
+    if r[0] == "error":
+        if "Address already in use" in r[1] or "Connection" in r[1]:
+            pytest.skip("rendezvous failed: " + r[2])
+        raise AssertionError("nccl worker failed:\n" + r[1])
+    (l0, w0), (l1, w1), (l2, w2) = r[1]
+    assert l0 == l1 == l2
+    assert np.array_equal(w0, w1) and np.array_equal(w0, w2)
+
+
+def test_engine_invalidate_after_data_write():
+    """`p.data.copy_()` does not move Parameter._version: without Engine.invalidate() the convolutions would keep the packed
+    copies of the OLD weights.  forward -> overwrite all weights -> invalidate -> forward == fresh model."""
+    from footprints_amd import FootprintNetwork
+    Pa, Ba = _state("dp")
+    Pb, Bb = _state("dp.other")
+    img = _shard(0)["image"]
+    m = _load(FootprintNetwork(pretrained=False), Pa, Ba).cuda().eval()
+    fresh = _load(FootprintNetwork(pretrained=False), Pb, Bb).cuda().eval()
+    with torch.no_grad():
+        m(img)
+        sd = m.state_dict()
+        for k, v in {**Pb, **Bb}.items():
+            sd[k].data.copy_(v)
+        m.engine().invalidate()
+        a, b = m(img), fresh(img)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k

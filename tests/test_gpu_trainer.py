@@ -1,0 +1,136 @@
+"""GPU: the trainer-loop pieces around the hot path -- Evaluator (training/evaluation.py:14-67), TrainManager's loop structure
+(training/train.py:145-215: averaged-loss line, log_freq validation pass in eval mode, per-epoch checkpoint + StepLR) and
+TrainStep.losses_dict -- against the G8 fixture (the reference's own Evaluator) and the CPU oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _g8_preds(tag, B=2, H=16, W=32):
+    from oracle import restatement as R
+    from tests.golden.digest import fill
+    d = {}
+    for k in R.SCALES:
+        p = fill("g8.%s.pred%s" % (tag, k), (B, 4, H, W), -3.0, 3.0)
+        p[:, 2:] = torch.sigmoid(p[:, 2:])
+        d[k] = p.cuda()
+    return d
+
+
+def test_g8_evaluator_matches_reference_evaluator():
+    from footprints_amd.training.evaluation import Evaluator
+    from oracle import restatement as R
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g8_evaluator.npz"))
+    ev = Evaluator((0.1, 100), 0.25)
+    last = None
+    for i in range(3):
+        batch = {k: v.cuda() for k, v in R.make_batch(2, 16, 32, tag="g8.train%d" % i).items()}
+        preds = _g8_preds("train%d" % i)
+        last = ev.compute_losses(batch, preds, mode="train", return_batch_loss=True)
+        assert len(preds) == 24                                                  # the loss manager mutates `predictions` (losses.py:90)
+    assert list(last.keys()) == R.LOSS_KEYS
+    for i in range(2):
+        batch = {k: v.cuda() for k, v in R.make_batch(2, 16, 32, tag="g8.val%d" % i).items()}
+        assert ev.compute_losses(batch, _g8_preds("val%d" % i), mode="val") is None   # evaluation.py:45-46
+    np.testing.assert_allclose([float(last[k]) for k in R.LOSS_KEYS], gold["eval.last_batch"], rtol=2e-6)
+    a = ev.get_averaged_losses("train", reset=False)
+    b = ev.get_averaged_losses("train", reset=True)
+    assert a == b and ev.get_averaged_losses("train", reset=True) == {}
+    np.testing.assert_allclose([a[k] for k in R.LOSS_KEYS], gold["eval.train_avg"], rtol=2e-6)
+    v = ev.get_averaged_losses("val", reset=True)
+    np.testing.assert_allclose([v[k] for k in R.LOSS_KEYS], gold["eval.val_avg"], rtol=2e-6)
+    assert len(ev.accumulated_val_losses) == 0
+
+
+def test_train_manager_loop_matches_oracle_trainer(tmp_path):
+    """two epochs x three steps with a validation pass: per-step losses, averaged train losses, validation averages (eval-mode
+    forward with the running statistics the training steps produced), checkpoint files and the StepLR schedule, against
+    the CPU oracle driven the way training/train.py drives the reference"""
+    from footprints_amd.training.train import TrainManager
+    from oracle import restatement as R
+    B, H, W = 2, 64, 96
+    P, Bf = R.make_state(tag="tm")
+    train_cpu = [R.make_batch(B, H, W, tag="tm.train%d" % i) for i in range(3)]
+    val_cpu = [R.make_batch(B, H, W, tag="tm.val%d" % i) for i in range(2)]
+    logs = []
+    tm = TrainManager(train_cpu, val_loader=val_cpu, epochs=2, learning_rate=1e-4, lr_step_size=1, log_freq=2, val_batches=3,
+                      save_folder=str(tmp_path), log=logs.append)
+    tm.model.load_state_dict({**P, **Bf})
+    tm.train()
+    torch.cuda.synchronize()
+    # ---- the oracle, same loop ------------------------------------------------------------------------------------
+    tr = R.OracleTrainer(P, Bf)
+    sched = torch.optim.lr_scheduler.StepLR(tr.opt, step_size=1)
+    ev = R.OracleEvaluator()
+    hist = {"train": [], "val": []}
+    step, vi = 0, 0
+    for epoch in range(2):
+        for batch in train_cpu:
+            out, losses = tr.step(batch)
+            for k, v in losses.items():
+                ev.acc["train"].setdefault(k, []).append(v.detach())
+            if step % 100 == 0 and step % 2 == 0:
+                hist["train"].append((step, ev.get_averaged_losses("train", reset=True)))
+                with torch.no_grad():
+                    for _ in range(3):
+                        vb = val_cpu[vi % 2]
+                        vi += 1
+                        ev.compute_losses(vb, R.footprint_network(vb["image"], tr.P, tr.B, False), "val")
+                hist["val"].append((step, ev.get_averaged_losses("val", reset=True)))
+            step += 1
+        sched.step()
+    assert tm.step == 6 and [s for s, _ in tm.history["train"]] == [s for s, _ in hist["train"]] == [0]
+    for kind in ("train", "val"):
+        for (s0, a), (s1, b) in zip(tm.history[kind], hist[kind]):
+            assert s0 == s1
+            for k in R.LOSS_KEYS:
+                assert abs(a[k] - b[k]) <= 1e-4 * max(abs(b[k]), 1e-3), (kind, s0, k, a[k], b[k])
+    assert len(logs) == 1 and logs[0].startswith("Epoch 0 -- Batch 0 -- Loss ")
+    assert abs(tm.optimiser.param_groups[0]["lr"] - tr.opt.param_groups[0]["lr"]) < 1e-12 and abs(tm.lr - 1e-5) < 1e-12
+    for e in range(2):
+        assert os.path.exists(tmp_path / ("weights_%d" % e) / "model.pth") and os.path.exists(tmp_path / ("weights_%d" % e) / "optimiser.pth")
+    # final losses of the last step: TrainStep.losses_dict against the oracle's last step
+    ld = tm.train_step.losses_dict()
+    assert list(ld.keys()) == R.LOSS_KEYS
+    for k in R.LOSS_KEYS:
+        assert abs(ld[k] - float(losses[k])) <= 1e-4 * max(abs(float(losses[k])), 1e-3), k
+
+
+def test_frozen_parameter_is_refused_and_mixed_grad_accumulation():
+    """(a) requires_grad=False parameters would be trained silently by the fused backward / Adam -> refused loudly;
+    (b) autograd semantics when only SOME parameters still hold their flat-buffer gradient (zero_grad over a subset)"""
+    from footprints_amd import FootprintNetwork
+    from footprints_amd.training.losses import LossManager
+    from oracle import restatement as R
+    P, Bf = R.make_state(tag="mix")
+    batch = {k: v.cuda() for k, v in R.make_batch(1, 64, 64, tag="mix").items()}
+    m = FootprintNetwork(pretrained=False)
+    m.load_state_dict({**P, **Bf})
+    m.cuda().train()
+    lm = LossManager((0.1, 100), 0.25, compute_viz=False)
+    lm(m(batch["image"]), batch)["loss"].backward()
+    g1 = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+    names = list(g1)
+    for n, p in m.named_parameters():                 # drop every other gradient, keep the rest (still aliased to the flat buffer)
+        if n in g1 and names.index(n) % 2 == 0:
+            p.grad = None
+    m.eval(); m.train()                               # no-op; BN statistics moved, gradients of the same batch change slightly
+    lm(m(batch["image"]), batch)["loss"].backward()
+    g2 = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+    m.zero_grad(set_to_none=True)
+    lm(m(batch["image"]), batch)["loss"].backward()
+    g3 = {n: p.grad for n, p in m.named_parameters() if p.grad is not None}
+    # the BN running statistics do not enter the train-mode forward, so the three backward passes see identical gradients g
+    for i, n in enumerate(names):
+        want = g3[n] if i % 2 == 0 else g3[n] * 2           # dropped: g ; kept: g1 + g = 2 g
+        assert torch.allclose(g2[n], want, rtol=1e-5, atol=1e-6 * float(want.abs().max())), n
+        assert torch.equal(g1[n], g3[n]), n
+    p0 = next(m.parameters())
+    p0.requires_grad_(False)
+    out = m(batch["image"])
+    with pytest.raises(RuntimeError, match="frozen parameters"):
+        lm(out, batch)["loss"].backward()

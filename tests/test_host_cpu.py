@@ -3,6 +3,7 @@ declares, the nn.Module tree reproduces the reference state_dict, CLI / preproce
 of any CPU compute path.  No kernel is launched here (no GPU in this container)."""
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -148,3 +149,31 @@ def test_no_packed_fp32_valu_in_device_code(tmp_path):
         assert not bad, "%s: packed fp32 VALU in device code: %s" % (p.name, bad[:3])
         mfma += asm.count("v_mfma_f32_32x32x16_bf16")
     assert mfma > 0            # the disassembly really covered the MFMA kernels
+
+
+def test_options_surface_matches_reference_flags():
+    """footprints_amd/options.py mirrors footprints/options.py:13-128: every reference flag with the same default (checked against
+    the reference's own parser when /root/reference is present, else against the committed table)"""
+    import importlib.util
+    from footprints_amd.options import Options
+    ours = vars(Options().parse([]))
+    table = {"mode": "train", "height": 192, "width": 640, "depth_range": [0.1, 100], "training_dataset": "kitti", "epochs": 10,
+             "log_freq": 250, "val_batches": 10, "batch_size": 12, "lr": 1e-4, "use_footprint_prior": False, "footprint_prior": 0.25,
+             "no_depth_mask": False, "moving_objects_method": "ours", "project_down_baseline": False, "num_workers": 8,
+             "config_path": "paths.yaml", "model_name": "model", "log_path": "./logs", "inference_data_type": "kitti",
+             "load_path": None, "inference_save_path": None, "save_test_visualisations": False}
+    ref_path = "/root/reference/footprints/options.py"
+    if os.path.exists(ref_path):
+        spec = importlib.util.spec_from_file_location("ref_options", ref_path)
+        mod = importlib.util.module_from_spec(spec)
+        sys.dont_write_bytecode = True
+        spec.loader.exec_module(mod)
+        argv, sys.argv = sys.argv, ["x"]
+        try:
+            ref = vars(mod.Options().parse())
+        finally:
+            sys.argv = argv
+        assert ref == table
+    for k, v in table.items():
+        assert ours[k] == v, k
+    assert set(ours) - set(table) == {"synthetic_steps", "device_augment"}

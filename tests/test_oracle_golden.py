@@ -199,3 +199,31 @@ def test_g7_metrics_oracle_reproduces_reference_scores():
             s = M.score_image(pred[i], gt_depth[i], None, "depth")
             np.testing.assert_array_equal(np.array([s[k] for k in DEPTH_KEYS], np.float64), g["%s.depth" % tag][i])
     assert np.isnan(g["float16.kitti.freespace"][4]).all() and np.isnan(g["float16.depth"][5]).all()      # the nan cases are in the fixture
+
+
+def _g8_preds(tag, B=2, H=16, W=32):
+    from tests.golden.digest import fill
+    d = {}
+    for k in R.SCALES:
+        p = fill("g8.%s.pred%s" % (tag, k), (B, 4, H, W), -3.0, 3.0)
+        p[:, 2:] = torch.sigmoid(p[:, 2:])
+        d[k] = p
+    return d
+
+
+def test_g8_evaluator_restatement_matches_reference_evaluator():
+    """training/evaluation.py:28-67 (fixture from the reference's own Evaluator): averaged train / val losses, reset semantics"""
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g8_evaluator.npz"))
+    ev = R.OracleEvaluator((0.1, 100), 0.25)
+    last = None
+    for i in range(3):
+        last = ev.compute_losses(R.make_batch(2, 16, 32, tag="g8.train%d" % i), _g8_preds("train%d" % i), "train", True)
+    for i in range(2):
+        assert ev.compute_losses(R.make_batch(2, 16, 32, tag="g8.val%d" % i), _g8_preds("val%d" % i), "val") is None
+    np.testing.assert_allclose([float(last[k]) for k in R.LOSS_KEYS], gold["eval.last_batch"], rtol=1e-6)
+    a = ev.get_averaged_losses("train", reset=False)
+    b = ev.get_averaged_losses("train", reset=True)
+    assert a == b and ev.get_averaged_losses("train") == {}
+    np.testing.assert_allclose([a[k] for k in R.LOSS_KEYS], gold["eval.train_avg"], rtol=1e-6)
+    v = ev.get_averaged_losses("val")
+    np.testing.assert_allclose([v[k] for k in R.LOSS_KEYS], gold["eval.val_avg"], rtol=1e-6)
