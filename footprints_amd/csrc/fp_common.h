@@ -17,6 +17,13 @@ int fp_check_launch(const char* what);
 
 static inline int64_t fp_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// A/B switches of the library (read once per call site through a function-local static)
+#include <stdlib.h>
+static inline bool fp_env_flag(const char* name) {
+  const char* v = getenv(name);
+  return v && atoi(v) != 0;
+}
+
 // ---- XCD-aware workgroup id remap (8 XCDs, private L2 each): consecutive logical tiles share halo rows
 // and weight slices, so give each XCD a contiguous range of logical ids. Bijective for any grid size.
 __device__ __forceinline__ int fp_xcd_remap(int bid, int nwg) {

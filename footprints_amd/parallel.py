@@ -14,10 +14,15 @@ import os
 import torch
 import torch.distributed as dist
 
-# RCCL's reduction kernels are ordinary VALU code (packed fp32 adds); on this part packed-fp32 VALU next to bf16 MFMAs was
-# observed to produce wrong sums (profiles/round1_notes.md), so by default the buckets are reduced AFTER the backward pass
-# (124 MB over xGMI: ~1 ms of a 23 ms step).  FP_DP_OVERLAP=1 restores the overlapped schedule.
-_OVERLAP = bool(int(os.environ.get("FP_DP_OVERLAP", "0")))
+# The bucket all-reduces overlap the remaining backward by default (north_star).  Round 1 kept them behind the backward pass
+# because RCCL's gfx950 code object contains packed-fp32 VALU instructions and a packed-fp32 kernel of this library
+# (head_wgrad, SLP-vectorised build) had been seen to return different sums next to the bf16-MFMA convolution.  Round 2 measured
+# (scripts/ubench/pk_hazard.hip, profiles/round2_notes.md): four standalone victims -- v_pk_fma_f32 accumulation, the
+# reduction-kernel pattern out = a + b with v_pk_add_f32, the compiler-packed op_sel forms of head_wgrad's own loop with its
+# shuffle tree -- are bit-stable next to a resident bf16-MFMA spinner (0 of 6 runs differ, each), so packed fp32 VALU beside
+# MFMA is not a hazard by itself; the head_wgrad effect reproduces only with that one kernel built with the SLP vectoriser (the
+# library stays built without it) and has nothing to do with collectives.  FP_DP_OVERLAP=0 reduces after the backward pass.
+_OVERLAP = bool(int(os.environ.get("FP_DP_OVERLAP", "1")))
 # FP_DP_FORCE=1: issue the bucket collectives even in a world of one rank (a 1-GPU box can then execute the RCCL code path:
 # communicator creation, bucket all-reduces on the comm stream, event gating -- tests/test_gpu_dp.py, `bench.py --force-dist`)
 _FORCE = bool(int(os.environ.get("FP_DP_FORCE", "0")))

@@ -85,6 +85,47 @@ __global__ void __launch_bounds__(256) vic_fma(const float4* __restrict__ x, con
   }
 }
 
+// victim D: the source pattern of head_wgrad_kernel's inner loop, left to the compiler (this file is built WITH the SLP vectoriser,
+// so adjacent scalar fp32 multiply-adds become v_pk_fma_f32 with op_sel broadcast forms -- exactly what the library's first build had)
+__global__ void __launch_bounds__(256) vic_slp(const float4* __restrict__ x, const float2* __restrict__ z, float* __restrict__ out, int n_per_thread) {
+  float acc[9][4][2];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[t][c][0] = acc[t][c][1] = 0.f;
+  const size_t base = (size_t)(blockIdx.x * 256 + threadIdx.x);
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (int i = 0; i + 9 <= n_per_thread; i += 9) {
+    const float2 zz = z[(base + i * stride) & 0xfffff];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const float4 v = x[base + (i + t) * stride];
+      acc[t][0][0] += v.x * zz.x; acc[t][0][1] += v.x * zz.y;
+      acc[t][1][0] += v.y * zz.x; acc[t][1][1] += v.y * zz.y;
+      acc[t][2][0] += v.z * zz.x; acc[t][2][1] += v.z * zz.y;
+      acc[t][3][0] += v.w * zz.x; acc[t][3][1] += v.w * zz.y;
+    }
+  }
+  // same wave reduction as head_wgrad (lanes q, q + 8, ...: fixed xor tree)
+  for (int o = 8; o < 64; o <<= 1) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        acc[t][c][0] += __shfl_xor(acc[t][c][0], o, 64);
+        acc[t][c][1] += __shfl_xor(acc[t][c][1], o, 64);
+      }
+  }
+  float* dst = out + base * 72;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      dst[(t * 4 + c) * 2 + 0] = acc[t][c][0];
+      dst[(t * 4 + c) * 2 + 1] = acc[t][c][1];
+    }
+}
+
 __global__ void __launch_bounds__(256) vic_pk_add(const float4* __restrict__ a, const float4* __restrict__ b, float4* __restrict__ out, size_t n4) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
     const float4 p = a[i], q = b[i];
@@ -107,7 +148,7 @@ int main(int argc, char** argv) {
   const size_t NX = (size_t)48 << 20;            // float4 elements of x (768 MB)
   float4 *x, *b4, *o4; float2* z; float *out, *aggout;
   CK(hipMalloc(&x, NX * 16)); CK(hipMalloc(&b4, NX * 16)); CK(hipMalloc(&o4, NX * 16));
-  CK(hipMalloc(&z, (1 << 20) * 8)); CK(hipMalloc(&out, (size_t)2048 * 256 * 16 * 4)); CK(hipMalloc(&aggout, 4096 * 256 * 4));
+  CK(hipMalloc(&z, (1 << 20) * 8)); CK(hipMalloc(&out, (size_t)2048 * 256 * 72 * 4)); CK(hipMalloc(&aggout, 4096 * 256 * 4));
   {
     std::vector<float> h(NX * 4);
     unsigned s = 12345u;
@@ -121,18 +162,20 @@ int main(int argc, char** argv) {
   CK(hipStreamCreateWithFlags(&sv, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking));
   const int VB = 2048, NPT = (int)(NX / ((size_t)VB * 256));
   const size_t n_fma_out = (size_t)VB * 256 * 16;
-  struct Vic { const char* name; int kind; } vics[3] = {{"pk_fma (v_pk_fma_f32 accumulate)", 0}, {"pk_add (v_pk_add_f32 elementwise, reduction-kernel style)", 1}, {"fma (scalar v_fma_f32 control)", 2}};
+  struct Vic { const char* name; int kind; } vics[4] = {{"pk_fma (v_pk_fma_f32 accumulate)", 0}, {"pk_add (v_pk_add_f32 elementwise, reduction-kernel style)", 1}, {"fma (scalar v_fma_f32 control)", 2},
+                                                       {"slp (head_wgrad's loop, compiler-packed + shfl tree)", 3}};
   const char* aggn[3] = {"none", "bf16 MFMA (v_mfma_f32_32x32x16_bf16)", "fp32 MFMA (v_mfma_f32_32x32x2_f32)"};
   auto launch_vic = [&](int kind) {
     if (kind == 0) hipLaunchKernelGGL(vic_fma<true>, dim3(VB), dim3(256), 0, sv, x, z, out, NPT);
     else if (kind == 2) hipLaunchKernelGGL(vic_fma<false>, dim3(VB), dim3(256), 0, sv, x, z, out, NPT);
+    else if (kind == 3) hipLaunchKernelGGL(vic_slp, dim3(VB), dim3(256), 0, sv, x, z, out, NPT);
     else hipLaunchKernelGGL(vic_pk_add, dim3(VB), dim3(256), 0, sv, x, b4, o4, NX);
   };
   int total_bad = 0;
   for (auto& v : vics) {
     launch_vic(v.kind);
     CK(hipStreamSynchronize(sv));
-    const size_t n = v.kind == 1 ? NX * 4 : n_fma_out;
+    const size_t n = v.kind == 1 ? NX * 4 : (v.kind == 3 ? (size_t)VB * 256 * 72 : n_fma_out);
     const float* dptr = v.kind == 1 ? (const float*)o4 : out;
     std::vector<float> ref = fetch(dptr, n);
     for (int ag = 0; ag < 3; ++ag) {

@@ -3,16 +3,31 @@
 The fp64-anchored rule: the CPU oracle run in float64 is the truth; the CPU oracle run in float32 (the arithmetic the
 reference itself uses, training/train.py:150-156 on torch CPU ops) shows how far a correct fp32 implementation sits from it.
 The HIP engine -- another fp32 implementation with a different summation order -- has to be as close to the truth as the
-reference's own arithmetic is:   err(GPU vs fp64) <= FACTOR * err(CPU-fp32 vs fp64)   per parameter tensor, with a floor far
-below every other tolerance of the suite for tensors where both errors are at round-off level.  No hand-picked constant
-per layer: ill-conditioned tensors (train-mode BatchNorm over few samples, ReLU masks next to 0) get exactly the slack the
-reference's own fp32 arithmetic needs on the same inputs."""
+reference's own arithmetic is:   err(GPU vs fp64) <= FACTOR * max(err_cpu32(tensor), median err_cpu32 of the tensor's stage)
+per parameter tensor (relative L2), with a floor far below every other tolerance of the suite for tensors where both errors are
+at round-off level.  No hand-picked constant per layer: ill-conditioned tensors (train-mode BatchNorm over few samples, ReLU
+masks next to 0) get exactly the slack the reference's own fp32 arithmetic needs on the same inputs.
+
+Why FACTOR = 4 and the stage median (measured on the MI355X box, profiles/round2_notes.md): over 196 tensors x 3 shapes the
+ratio err_gpu / err_cpu32 has median 0.90-1.15 -- the two fp32 implementations are equally far from the truth -- but a heavy
+tail: the encoder is piecewise linear (ReLU after train-mode BN), and ONE activation within fp32 round-off of 0 that the two
+implementations resolve differently moves a whole BatchNorm channel's statistics (ratios up to 3.3 on layer4 tensors at
+12x192x640; and a tensor on which the CPU happened to be lucky, 4e-6 against its neighbours' 1e-4..2e-3, reads as 25).  The stage
+median keeps one lucky CPU tensor from setting its own bound; the factor covers the flip tail.  A real defect shows as
+hundreds (the test that introduced the rule flagged a single |.|-kink sign flip in the depth loss at ratio 200-700).
+
+The loss has its own kink: log(|d(o) - depth| + 1) (losses.py:95-107) flips the sign of a pixel's gradient when the predicted
+depth crosses the target.  A pixel with |d - depth| within reach of fp32 output error is undetermined in ANY fp32
+implementation and, sitting at the steepest point of the loss, carries ~30x a typical pixel's gradient: one such pixel among
+327 680 moved every depth-decoder gradient by 1.5e-4 (1x512x640).  `tie_free_batch` removes those pixels from the valid masks
+(depth / ground_depth := 0 where the float64 prediction is within TIE of the target at any scale) for all three runs alike."""
 from collections import OrderedDict
 
 import torch
 
-FACTOR = 2.0
+FACTOR = 4.0
 FLOOR = 2e-5          # relative L2; both implementations at fp32 round-off
+TIE = 1e-2            # |predicted depth - target| (metres, relative to max(depth, 1)) below which the L1 kink is undetermined in fp32
 
 
 def rel_l2(t, ref64):
@@ -29,30 +44,65 @@ def chan_relerr(got, ref):
     return (d / s).tolist()
 
 
-def oracle_grads(P, B, cpu_batch, dtype):
-    """one train-mode fwd + loss + bwd of the CPU oracle in `dtype` -> (outputs, losses, {name: grad})"""
+def oracle_grads(P, B, cpu_batch, dtype, fix_batch=None):
+    """one train-mode fwd + loss + bwd of the CPU oracle in `dtype` -> (outputs, losses, {name: grad}, trainer, batch used).
+    fix_batch(batch, outputs) -> batch: applied between the forward and the loss (the outputs do not depend on the targets)"""
     from oracle import restatement as R
     Pd = OrderedDict((k, v.to(dtype)) for k, v in P.items())
     Bd = OrderedDict((k, v.to(dtype) if v.is_floating_point() else v.clone()) for k, v in B.items())
-    batch = OrderedDict((k, v.to(dtype)) for k, v in cpu_batch.items())
     tr = R.OracleTrainer(Pd, Bd)
-    out, losses = tr.forward_backward(batch)
+    out = R.footprint_network(cpu_batch["image"].to(dtype), tr.P, tr.B, True)
+    used = cpu_batch if fix_batch is None else fix_batch(cpu_batch, out)
+    losses, _ = R.loss_manager(out, OrderedDict((k, v.to(dtype)) for k, v in used.items()))
+    for p in tr.P.values():
+        p.grad = None
+    losses["loss"].backward()
     grads = OrderedDict((k, p.grad) for k, p in tr.P.items())
-    return {k: v.detach() for k, v in out.items()}, losses, grads, tr
+    return {k: v.detach() for k, v in out.items()}, losses, grads, tr, used
+
+
+def stage_of(name):
+    """encoder.layerK / mask_decoder.blockK / depth_decoder.outconvK ...: the granularity at which conditioning is homogeneous"""
+    p = name.split(".")
+    return ".".join(p[:2])
 
 
 def anchored_report(gpu, cpu32, ref64, factor=FACTOR, floor=FLOOR):
     """gpu / cpu32 / ref64: {name: tensor or None}.  Returns (failures, rows) with rows = (ratio, name, err_gpu, err_cpu)."""
-    rows, bad = [], []
+    errs = {}
     for n, r in ref64.items():
         if r is None:
             assert gpu.get(n) is None, "%s: the oracle has no gradient here, the engine produced one" % n
             continue
         assert gpu.get(n) is not None, "%s: missing gradient" % n
-        eg, ec = rel_l2(gpu[n], r), rel_l2(cpu32[n], r)
-        bound = max(factor * ec, floor)
+        errs[n] = (rel_l2(gpu[n], r), rel_l2(cpu32[n], r))
+    stages = {}
+    for n, (_, ec) in errs.items():
+        stages.setdefault(stage_of(n), []).append(ec)
+    med = {s: sorted(v)[len(v) // 2] for s, v in stages.items()}
+    rows, bad = [], []
+    for n, (eg, ec) in errs.items():
+        bound = max(factor * max(ec, med[stage_of(n)]), floor)
         rows.append((eg / max(ec, 1e-30), n, eg, ec))
         if not eg <= bound:
-            bad.append("%s gpu %.2e cpu32 %.2e bound %.2e" % (n, eg, ec, bound))
+            bad.append("%s gpu %.2e cpu32 %.2e stage median %.2e bound %.2e" % (n, eg, ec, med[stage_of(n)], bound))
     rows.sort(reverse=True)
     return bad, rows
+
+
+def tie_free_batch(cpu_batch, out64, depth_range=(0.1, 100.0), tie=TIE):
+    """copy of the batch with the |.|-kink pixels of the depth losses removed from the valid masks (see the module docstring);
+    out64: the float64 oracle's outputs (they do not depend on the targets).  Returns (batch, number of pixels removed)."""
+    batch = OrderedDict((k, v.clone()) for k, v in cpu_batch.items())
+    lo, hi = 1.0 / depth_range[1], 1.0 / depth_range[0]
+    removed = 0
+    for ch, key in ((2, "depth"), (3, "ground_depth")):
+        t = batch[key].double()
+        tiebrk = torch.zeros_like(t, dtype=torch.bool)
+        for o in out64.values():
+            d = 1.0 / (lo + (hi - lo) * o[:, ch].detach().double())
+            tiebrk |= ((d - t).abs() <= tie * d.clamp_min(1.0)) & (t > 0)
+        removed += int(tiebrk.sum())
+        batch[key][tiebrk] = 0.0
+    batch["all_ground"] = ((batch["ground_depth"] + batch["visible_ground"]) > 0).float()      # kitti_dataset.py:114-122
+    return batch, removed

@@ -77,7 +77,7 @@ def _worker(rank, world, port, q, overlap):
         q.put((rank, "error", traceback.format_exc(), repr(e)))
 
 
-@pytest.mark.parametrize("overlap", [False, True])     # buckets reduced after backward (default) / as soon as each stage is complete
+@pytest.mark.parametrize("overlap", [False, True])     # buckets reduced after backward (FP_DP_OVERLAP=0) / as soon as each stage is complete (default)
 def test_two_ranks_share_weights_and_match_summed_shard_gradients(overlap):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
