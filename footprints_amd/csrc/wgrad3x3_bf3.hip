@@ -12,6 +12,8 @@
 // fp32 kernel, wgrad3x3_tile.hip).  The kx = 1, 2 taps are the kx = 0 operand shifted by one / two bf16: a funnel shift
 // (v_alignbit) of the aligned 16-byte read plus the next dword.  Global loads of the next chunk fly under the MFMAs of the
 // current one (register prefetch, single LDS buffer, two barriers per chunk).  Sums across waves / splits: fixed order.
+#include <stdio.h>
+
 #include "fp_common.h"
 
 int fp_wgrad_reduce_launch(const float* part, float* dw, int S, int T, int Kc, int Nout, int stem, int accumulate, int kc_total,
@@ -31,6 +33,10 @@ struct W3Args {
   int N, H, W, C, Nout;
   int mode;           // 0 zero padding, 1 reflection, 2 reflection over the nearest-x2 upsampling of x ([N][H/2][W/2][C])
   int chunksY, chunksX, nchunks, chunksPerSplit, S, citiles, cotiles;
+  unsigned long long* stamps;   // debugging (FP_W3_STAMPS=file): per workgroup {start, loop start, loop end, end} shader clocks + HW id
+  int nofast;         // A/B switch: every chunk through the general (reflect / clamp / mask) staging path
+  int xcd;            // logical workgroup ids run contiguously inside an XCD: the citiles x cotiles workgroups of one pixel split read
+                      // the same X / dZ chunks and then share that XCD's L2 (consecutive hardware ids go to different XCDs)
 };
 
 constexpr int CH = 4, CW = 16, HR = CH + 2;
@@ -231,12 +237,15 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // two fp32 -> packed bf16 pairs of the three exact terms
 __device__ __forceinline__ void split_pair(const float x, const float y, unsigned& hi, unsigned& mid, unsigned& lo) {
-  const f32x2 v = {x, y};
-  const bf16x2 vh = __builtin_convertvector(v, bf16x2);
-  const f32x2 r1 = v - __builtin_convertvector(vh, f32x2);
-  const bf16x2 vm = __builtin_convertvector(r1, bf16x2);
-  const f32x2 r2 = r1 - __builtin_convertvector(vm, f32x2);
-  const bf16x2 vl = __builtin_convertvector(r2, bf16x2);
+  // scalar residuals on purpose: a 2-vector subtraction would become v_pk_add_f32, and the library keeps packed fp32 VALU out of its
+  // code objects (tests/test_host_cpu.py::test_no_packed_fp32_valu_in_device_code)
+  const bf16x2 vh = __builtin_convertvector(f32x2{x, y}, bf16x2);
+  const f32x2 fh = __builtin_convertvector(vh, f32x2);
+  const float rx = x - fh[0], ry = y - fh[1];
+  const bf16x2 vm = __builtin_convertvector(f32x2{rx, ry}, bf16x2);
+  const f32x2 fm = __builtin_convertvector(vm, f32x2);
+  const float sx = rx - fm[0], sy = ry - fm[1];
+  const bf16x2 vl = __builtin_convertvector(f32x2{sx, sy}, bf16x2);
   hi = __builtin_bit_cast(unsigned, vh);
   mid = __builtin_bit_cast(unsigned, vm);
   lo = __builtin_bit_cast(unsigned, vl);
@@ -245,7 +254,7 @@ __device__ __forceinline__ void split_pair(const float x, const float y, unsigne
 __global__ void __launch_bounds__(256, 2) wgrad3x3_bf3_v2_kernel(const W3Args a) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF2];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, idx = lane & 31, h = lane >> 5;
-  int b = blockIdx.x;
+  int b = a.xcd ? fp_xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
   const int cot = b % a.cotiles; b /= a.cotiles;
   const int cit = b % a.citiles; b /= a.citiles;
   const int s = b;
@@ -261,12 +270,34 @@ __global__ void __launch_bounds__(256, 2) wgrad3x3_bf3_v2_kernel(const W3Args a)
   unsigned xmask = 0, zmask = 0;
   const bool want_bias = a.bpart != nullptr && cit == 0;
   float bs[4] = {0.f, 0.f, 0.f, 0.f};
+  // Interior chunks (halo and the two padding columns inside the image: 80 % of the chunks of a 96 x 320 level) need no reflection,
+  // clamping or masks: the chunk origin is wave-uniform (scalar registers) and a thread's offsets from it never change, so the
+  // eight loads are base + constant.  The general path cost ~140 VALU instructions per chunk -- in a kernel whose waves spend
+  // their time ISSUING (PMC: 470 VALU + 54 MFMA instructions per chunk and wave, VALU pipe 58 % busy against 40 % of the MFMA pipe).
+  const int xgo = ((xhr - 1) * a.W + xcg * 4 - 1) * a.C + ci0 + q * 4;
+  const int zoffs = (zr * a.W + zcg * 4) * a.Nout + co0 + q * 4;
+  bool fast = false;
 
   auto issue = [&](int c) {
     const int cx = c % a.chunksX;
     const int r = c / a.chunksX;
     const int cy = r % a.chunksY, n = r / a.chunksY;
     const int y0 = cy * CH, x0 = cx * CW;
+    fast = !a.nofast && a.mode != 2 && y0 >= 1 && y0 + CH + 1 <= a.H && x0 >= 1 && x0 + CW + 3 <= a.W;
+    if (fast) {
+      const size_t org = (size_t)(n * a.H + y0) * a.W + x0;
+      if (xitem) {
+        const float* px = a.x + org * a.C + xgo;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xr[j] = *reinterpret_cast<const float4*>(px + j * a.C);
+      }
+      if (zitem) {
+        const float* pz = a.dz + org * a.Nout + zoffs;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) zv[j] = *reinterpret_cast<const float4*>(pz + j * a.Nout);
+      }
+      return;
+    }
     xmask = zmask = 0;
     {
       int sy = y0 + xhr - 1;
@@ -303,9 +334,11 @@ __global__ void __launch_bounds__(256, 2) wgrad3x3_bf3_v2_kernel(const W3Args a)
     unsigned char* const base = lds + buf * BUF2;
     if (xitem) {
       unsigned char* p = base + (xhr * 32 + q * 4) * LP2 + xcg * 16;
+      if (!fast) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (!(xmask & (1u << j))) xr[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < 4; ++j)
+          if (!(xmask & (1u << j))) xr[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
       *reinterpret_cast<float4*>(p) = make_float4(xr[0].x, xr[1].x, xr[2].x, xr[3].x);
       *reinterpret_cast<float4*>(p + LP2) = make_float4(xr[0].y, xr[1].y, xr[2].y, xr[3].y);
       *reinterpret_cast<float4*>(p + 2 * LP2) = make_float4(xr[0].z, xr[1].z, xr[2].z, xr[3].z);
@@ -313,9 +346,11 @@ __global__ void __launch_bounds__(256, 2) wgrad3x3_bf3_v2_kernel(const W3Args a)
     }
     if (zitem) {
       unsigned char* p = base + XB2 + (zr * 32 + q * 4) * LP2 + zcg * 16;
+      if (!fast) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (!(zmask & (1u << j))) zv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < 4; ++j)
+          if (!(zmask & (1u << j))) zv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
       if (want_bias) {
         bs[0] += (zv[0].x + zv[1].x) + (zv[2].x + zv[3].x); bs[1] += (zv[0].y + zv[1].y) + (zv[2].y + zv[3].y);
         bs[2] += (zv[0].z + zv[1].z) + (zv[2].z + zv[3].z); bs[3] += (zv[0].w + zv[1].w) + (zv[2].w + zv[3].w);
@@ -419,6 +454,255 @@ __global__ void __launch_bounds__(256, 2) wgrad3x3_bf3_v2_kernel(const W3Args a)
   }
 }
 
+// ---- third generation: [pixel][channel] bf16 planes in LDS, hardware transpose reads (ds_read_b64_tr_b16) ----------------------
+// PMC of the second kernel (64 -> 64 @ 96 x 320): per chunk and wave 54 MFMAs against ~470 VALU instructions; the waves spend 41 %
+// of their cycles issuing, the VALU pipe is 58 % busy, the MFMA pipe 40 %: the kernel is bound by the instructions that TRANSPOSE
+// (NHWC has channels contiguous, the contraction runs over pixels), shift (v_alignbit for the kx taps) and re-convert the operands.
+// gfx950's LDS can transpose on the way out: ds_read_b64_tr_b16 hands lane l the 4 ROWS x 1 column of a [4][16] bf16 block whose
+// 16 lanes each name one 8-byte quarter row (verified lane by lane on the box: scripts/ubench/bin/tr_probe).  So the planes stay in
+// the tensors' own order
+//     Xs[buf][plane][halo pixel 6 x 18][32 ci]   Zs[buf][plane][pixel 4 x 16][32 co]     (bf16, 64 bytes per pixel)
+// and   * staging is a straight copy: a thread converts one float4 (4 channels of one pixel) into its three exact bf16 terms and
+//         writes three 8-byte pieces; a wave's writes are 512 contiguous bytes (conflict-free), each element is converted ONCE;
+//       * an MFMA fragment (lane = channel, 8 consecutive pixels) is two transpose reads; the kx = 1, 2 taps are the same reads one /
+//         two pixels (64 / 128 bytes) further: no funnel shifts, no register copies; a half-wave's 32 lanes cover 256 contiguous
+//         bytes per read (all 64 banks once);
+//       * 33 KB per buffer: two buffers, two workgroups per CU, one barrier per chunk (as in the second kernel).
+// Per chunk and wave: 54 MFMAs + 60 LDS reads + ~110 VALU + 18 LDS writes instead of 54 + 11 + ~470 + 8.
+constexpr int HWD = CW + 2;                                     // halo width in pixels
+constexpr int PXB = 64;                                         // bytes per pixel per plane (32 channels bf16)
+constexpr int XP3 = HR * HWD * PXB, ZP3 = CH * CW * PXB;        // 6912, 4096 bytes per plane
+constexpr int XB3 = 3 * XP3, ZB3 = 3 * ZP3, BUF3 = XB3 + ZB3;   // 20736 + 12288 = 33024 bytes per buffer
+constexpr int XITEMS = HR * HWD * 8;                            // (pixel, channel quad) staging items of X: 864 (dZ: 4 x 16 x 8 = 512 = two per thread)
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint2 lds_tr16(const unsigned char* p) {
+  const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+  return __builtin_bit_cast(uint2, v);
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256, 2) wgrad3x3_bf3_v3_kernel(const W3Args a) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF3];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  int b = a.xcd ? fp_xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+  const int cot = b % a.cotiles; b /= a.cotiles;
+  const int cit = b % a.citiles; b /= a.citiles;
+  const int s = b;
+  const int ci0 = cit * 32, co0 = cot * 32;
+  // split s walks chunks s, s + S, s + 2 S, ...: image-border chunks (general staging path, +30 % per chunk) spread evenly over the
+  // workgroups -- with contiguous ranges the workgroups that own an image's top / bottom chunk rows ran 26 % longer than the median
+  // and set the kernel's duration -- and neighbouring workgroups of an XCD stage neighbouring chunks at the same time (L2 reuse)
+  const int c_begin = s, c_end = a.nchunks, c_step = a.S;
+  unsigned long long st0 = 0, st1 = 0, st2 = 0;
+  if (a.stamps) st0 = __builtin_readcyclecounter();
+
+  // staging items e = t + 256 k: pixel e / 8 (row-major over the halo / the chunk), channel quad e % 8
+  const int q = t & 7;
+  int xhy[4], xhx[4], xgo[4];
+  bool xit[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int e = t + 256 * k, p = e >> 3;
+    xit[k] = e < XITEMS;
+    xhy[k] = p / HWD;
+    xhx[k] = p - xhy[k] * HWD;
+    xgo[k] = ((xhy[k] - 1) * a.W + xhx[k] - 1) * a.C + ci0 + q * 4;      // offset from the chunk origin (interior chunks)
+  }
+  int zy[2], zx[2], zgo[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int p = (t + 256 * k) >> 3;
+    zy[k] = p / CW;
+    zx[k] = p - zy[k] * CW;
+    zgo[k] = (zy[k] * a.W + zx[k]) * a.Nout + co0 + q * 4;
+  }
+  float4 xr[4], zv[2];
+  const bool want_bias = a.bpart != nullptr && cit == 0;
+  float bs[4] = {0.f, 0.f, 0.f, 0.f};
+
+  auto issue = [&](int c) {
+    const int cx = c % a.chunksX;
+    const int r = c / a.chunksX;
+    const int cy = r % a.chunksY, n = r / a.chunksY;
+    const int y0 = cy * CH, x0 = cx * CW;
+    const bool fast = !a.nofast && MODE != 2 && y0 >= 1 && y0 + CH + 1 <= a.H && x0 >= 1 && x0 + CW + 1 <= a.W;
+    if (fast) {                                        // wave-uniform: no reflection, clamping or masks inside the image
+      const size_t org = (size_t)(n * a.H + y0) * a.W + x0;
+      const float* px = a.x + org * a.C;
+      const float* pz = a.dz + org * a.Nout;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (k < 3 || xit[k]) xr[k] = *reinterpret_cast<const float4*>(px + xgo[k]);
+#pragma unroll
+      for (int k = 0; k < 2; ++k) zv[k] = *reinterpret_cast<const float4*>(pz + zgo[k]);
+      return;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      int sy = y0 + xhy[k] - 1, sx = x0 + xhx[k] - 1;
+      bool ok = xit[k];
+      if (MODE == 0) ok = ok && sy >= 0 && sy < a.H && sx >= 0 && sx < a.W;
+      else { ok = ok && sy >= -1 && sy <= a.H && sx >= -1 && sx <= a.W; sy = fp_reflect(sy, a.H); sx = fp_reflect(sx, a.W); }
+      sy = min(max(sy, 0), a.H - 1);
+      sx = min(max(sx, 0), a.W - 1);
+      const size_t xpix = MODE == 2 ? (size_t)(n * (a.H >> 1) + (sy >> 1)) * (a.W >> 1) + (sx >> 1) : (size_t)(n * a.H + sy) * a.W + sx;
+      const float4 v = *reinterpret_cast<const float4*>(a.x + xpix * a.C + ci0 + q * 4);
+      xr[k] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int oy = y0 + zy[k], ox = x0 + zx[k];
+      const bool ok = oy < a.H && ox < a.W;
+      const float4 v = *reinterpret_cast<const float4*>(a.dz + ((size_t)(n * a.H + min(oy, a.H - 1)) * a.W + min(ox, a.W - 1)) * a.Nout + co0 + q * 4);
+      zv[k] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto stage = [&](int buf) {
+    unsigned char* const base = lds + buf * BUF3;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (k < 3 || xit[k]) split_store(base + (t + 256 * k) * 8, XP3, f32x4{xr[k].x, xr[k].y, xr[k].z, xr[k].w});
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      if (want_bias) { bs[0] += zv[k].x; bs[1] += zv[k].y; bs[2] += zv[k].z; bs[3] += zv[k].w; }
+      split_store(base + XB3 + (t + 256 * k) * 8, ZP3, f32x4{zv[k].x, zv[k].y, zv[k].z, zv[k].w});
+    }
+  };
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[tp][r] = 0.f;
+
+  if (c_begin < c_end) {
+    issue(c_begin);
+    stage(0);
+  }
+  __syncthreads();
+  if (a.stamps) st1 = __builtin_readcyclecounter();
+  // transpose-read addressing: lane -> (channel = lane % 32, pixel group = lane / 32); its 16-lane group reads a [4 px][16 ch] block,
+  // lane i of the group naming pixel i / 4, channels 4 (i % 4) .. + 3 of it
+  const int li = lane & 15;
+  const int lrow = 8 * (lane >> 5) + (li >> 2), lcol = 32 * ((lane >> 4) & 1) + 8 * (li & 3);
+  const int xrd = (wave * HWD + lrow) * PXB + lcol;
+  const int zrd = XB3 + (wave * CW + lrow) * PXB + lcol;
+  int par = 0;
+  for (int c = c_begin; c < c_end; c += c_step, par ^= 1) {
+    const unsigned char* const Bb = lds + par * BUF3;
+    if (c + c_step < c_end) issue(c + c_step);       // next chunk's global loads fly under this chunk's MFMAs
+    uint4 bz[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      const uint2 lo = lds_tr16(Bb + zrd + p * ZP3), hi = lds_tr16(Bb + zrd + p * ZP3 + 4 * PXB);
+      bz[p] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    }
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      uint4 af[3][3];                                // [kx][plane]
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          const unsigned char* src = Bb + xrd + (ky * HWD + kx) * PXB + p * XP3;
+          const uint2 lo = lds_tr16(src), hi = lds_tr16(src + 4 * PXB);
+          af[kx][p] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
+      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+      for (int qq = 0; qq < 6; ++qq) {
+        const bf16x8 bb = __builtin_bit_cast(bf16x8, bz[PB[qq]]);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+          acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[kx][PA[qq]]), bb, acc[ky * 3 + kx], 0, 0, 0);
+      }
+    }
+    if (c + c_step < c_end) stage(par ^ 1);           // the other buffer was last read in the previous chunk, before the barrier that ended it
+    __syncthreads();
+  }
+
+  if (a.stamps) st2 = __builtin_readcyclecounter();
+  // ---- sum the four waves' tiles through LDS (fixed order), one tap at a time -----------------------------------------------------
+  float* red = reinterpret_cast<float*>(lds);        // [4 waves][16 regs][64 lanes] = 16 KB
+  float* out = a.part + (size_t)s * 9 * a.C * a.Nout;
+  if (want_bias) {                                   // 32 staging threads per channel quad -> one partial per output channel
+#pragma unroll
+    for (int k = 0; k < 4; ++k) red[(t >> 3) * 32 + q * 4 + k] = bs[k];
+    __syncthreads();
+    if (t < 32) {
+      float v = 0.f;
+#pragma unroll
+      for (int g = 0; g < 32; ++g) v += red[g * 32 + t];
+      a.bpart[(size_t)s * a.Nout + co0 + t] = v;
+    }
+    __syncthreads();
+  }
+  const int idx = lane & 31;
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[tp][r];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int e = t + 256 * k;
+      const float v = ((red[e] + red[1024 + e]) + red[2048 + e]) + red[3072 + e];
+      const int r = e >> 6, ln = e & 63;
+      const int ci = ci0 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
+      out[((size_t)tp * a.C + ci) * a.Nout + co0 + (ln & 31)] = v;
+    }
+    __syncthreads();
+  }
+  (void)idx;
+  if (a.stamps && t == 0) {
+    unsigned hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    unsigned long long* o = a.stamps + (size_t)blockIdx.x * 6;
+    o[0] = st0; o[1] = st1; o[2] = st2; o[3] = __builtin_readcyclecounter(); o[4] = hwid; o[5] = xcc;
+  }
+}
+
+// dW_oihw[n][k_begin + k][tap] (+)= sum_s part[s][tap][k][n] and, in the SAME launch (tail blocks), db[n] (+)= sum_s bpart[s][n]: one
+// dependent launch instead of two behind every weight-gradient kernel (56 per training step).  Fixed combination order.
+__global__ void __launch_bounds__(256) wgrad_reduce_bias_kernel(const float* __restrict__ part, float* __restrict__ dw, int S, int Kc, int Nout,
+                                                                int accumulate, int kc_total, int k_begin, int main_blocks,
+                                                                const float* __restrict__ bpart, float* __restrict__ db) {
+  if ((int)blockIdx.x >= main_blocks) {
+    const int n = ((int)blockIdx.x - main_blocks) * 256 + threadIdx.x;
+    if (n >= Nout) return;
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    int s = 0;
+    for (; s + 3 < S; s += 4) {
+      v0 += bpart[(size_t)s * Nout + n]; v1 += bpart[(size_t)(s + 1) * Nout + n];
+      v2 += bpart[(size_t)(s + 2) * Nout + n]; v3 += bpart[(size_t)(s + 3) * Nout + n];
+    }
+    for (; s < S; ++s) v0 += bpart[(size_t)s * Nout + n];
+    const float v = (v0 + v1) + (v2 + v3);
+    db[n] = accumulate ? db[n] + v : v;
+    return;
+  }
+  const size_t total = (size_t)9 * Kc * Nout;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)main_blocks * 256) {
+    float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f, p4 = 0.f, p5 = 0.f, p6 = 0.f, p7 = 0.f;
+    int s = 0;
+    for (; s + 8 <= S; s += 8) {
+      const float* q = part + (size_t)s * total + e;
+      p0 += q[0]; p1 += q[total]; p2 += q[2 * total]; p3 += q[3 * total];
+      p4 += q[4 * total]; p5 += q[5 * total]; p6 += q[6 * total]; p7 += q[7 * total];
+    }
+    for (; s < S; ++s) p0 += part[(size_t)s * total + e];
+    const float sum = ((p0 + p1) + (p2 + p3)) + ((p4 + p5) + (p6 + p7));
+    const int n = (int)(e % Nout);
+    const size_t r = e / Nout;
+    const int kk = (int)(r % Kc), tap = (int)(r / Kc);
+    const size_t o = ((size_t)n * kc_total + k_begin + kk) * 9 + tap;
+    dw[o] = accumulate ? dw[o] + sum : sum;
+  }
+}
+
 // db[n] (+)= sum_s bpart[s][n], fixed order
 __global__ void __launch_bounds__(256) wgrad_bias_reduce_kernel(const float* __restrict__ bpart, int S, int Nout, float* __restrict__ db,
                                                                 int accumulate) {
@@ -486,16 +770,52 @@ extern "C" int fp_conv_wgrad_bf3(const fp_conv_desc* d, const float* x, const fl
   a.mode = d->gather == FP_GATHER_FWD_ZERO ? 0 : (d->gather == FP_GATHER_FWD_REFLECT_UP2 ? 2 : 1);
   a.chunksY = p.cy; a.chunksX = p.cx; a.nchunks = p.nchunks; a.chunksPerSplit = p.chunksPerSplit; a.S = p.S;
   a.citiles = p.citiles; a.cotiles = p.cotiles;
-  static const bool v1 = fp_env_flag("FP_WGRAD_BF3_V1");       // A/B switch: the first-generation kernel (split while staging)
-  if (v1) hipLaunchKernelGGL(wgrad3x3_bf3_kernel, dim3(p.S * p.citiles * p.cotiles), dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL(wgrad3x3_bf3_v2_kernel, dim3(p.S * p.citiles * p.cotiles), dim3(256), 0, stream, a);
+  static const bool no_xcd = fp_env_flag("FP_WGRAD_NO_XCD");
+  a.xcd = no_xcd ? 0 : 1;
+  static const bool no_fast = fp_env_flag("FP_WGRAD_NO_FAST");
+  a.nofast = no_fast ? 1 : 0;
+  a.stamps = nullptr;
+  static const char* stamp_file = getenv("FP_W3_STAMPS");
+  static unsigned long long* stamp_buf = nullptr;
+  const int nwg = p.S * p.citiles * p.cotiles;
+  if (stamp_file) {
+    if (!stamp_buf) (void)hipMalloc(&stamp_buf, (size_t)8192 * 6 * 8);
+    if (nwg <= 8192) a.stamps = stamp_buf;
+  }
+  static const int ver = getenv("FP_WGRAD_BF3_V") ? atoi(getenv("FP_WGRAD_BF3_V")) : 3;       // A/B switch: kernel generation
+  if (ver == 1) hipLaunchKernelGGL(wgrad3x3_bf3_kernel, dim3(nwg), dim3(256), 0, stream, a);
+  else if (ver == 2) hipLaunchKernelGGL(wgrad3x3_bf3_v2_kernel, dim3(nwg), dim3(256), 0, stream, a);
+  else if (a.mode == 0) hipLaunchKernelGGL(wgrad3x3_bf3_v3_kernel<0>, dim3(nwg), dim3(256), 0, stream, a);
+  else if (a.mode == 1) hipLaunchKernelGGL(wgrad3x3_bf3_v3_kernel<1>, dim3(nwg), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL(wgrad3x3_bf3_v3_kernel<2>, dim3(nwg), dim3(256), 0, stream, a);
   int rc = fp_check_launch("fp_conv_wgrad_bf3");
   if (rc) return rc;
-  if (db) {
-    hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3((d->Nout + 255) / 256), dim3(256), 0, stream, (const float*)a.bpart, p.S, d->Nout, db,
-                       accumulate);
-    rc = fp_check_launch("fp_conv_wgrad_bf3(bias)");
-    if (rc) return rc;
+  if (a.stamps) {                                   // debugging only: synchronous dump of the last launch's stamps
+    (void)hipStreamSynchronize(stream);
+    unsigned long long* h = (unsigned long long*)malloc((size_t)nwg * 6 * 8);
+    (void)hipMemcpy(h, stamp_buf, (size_t)nwg * 6 * 8, hipMemcpyDeviceToHost);
+    FILE* f = fopen(stamp_file, "w");
+    if (f) {
+      for (int i = 0; i < nwg; ++i) fprintf(f, "%d %llu %llu %llu %llu %llu %llu\n", i, h[i * 6], h[i * 6 + 1], h[i * 6 + 2], h[i * 6 + 3], h[i * 6 + 4], h[i * 6 + 5]);
+      fclose(f);
+    }
+    free(h);
   }
-  return fp_wgrad_reduce_launch((const float*)workspace, dw_oihw, p.S, 9, d->C0, d->Nout, 0, accumulate, kc_total, k_begin, stream);
+  static const bool split_reduce = fp_env_flag("FP_WGRAD_SPLIT_REDUCE");     // A/B switch: the two former reduce launches
+  if (split_reduce) {
+    if (db) {
+      hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3((d->Nout + 255) / 256), dim3(256), 0, stream, (const float*)a.bpart, p.S, d->Nout, db,
+                         accumulate);
+      rc = fp_check_launch("fp_conv_wgrad_bf3(bias)");
+      if (rc) return rc;
+    }
+    return fp_wgrad_reduce_launch((const float*)workspace, dw_oihw, p.S, 9, d->C0, d->Nout, 0, accumulate, kc_total, k_begin, stream);
+  }
+  const int64_t total = (int64_t)9 * d->C0 * d->Nout;
+  int main_blocks = (int)fp_ceil_div(total, 256);
+  if (main_blocks > 4096) main_blocks = 4096;
+  const int bias_blocks = db ? (d->Nout + 255) / 256 : 0;
+  hipLaunchKernelGGL(wgrad_reduce_bias_kernel, dim3(main_blocks + bias_blocks), dim3(256), 0, stream, (const float*)workspace, dw_oihw, p.S,
+                     d->C0, d->Nout, accumulate, kc_total, k_begin, main_blocks, (const float*)a.bpart, db);
+  return fp_check_launch("fp_conv_wgrad_bf3(reduce)");
 }

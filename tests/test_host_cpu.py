@@ -129,9 +129,12 @@ def test_bucket_ranges_cover_flat_buffer_in_backward_order():
 
 
 def test_no_packed_fp32_valu_in_device_code(tmp_path):
-    """Hardware hazard found on MI355X (profiles/round1_notes.md): a wave running v_pk_fma_f32 / v_pk_add_f32 next to another
-    wave's v_mfma_f32_32x32x16_bf16 silently gets wrong sums.  The library is built with -fno-slp-vectorize -fno-vectorize;
-    this disassembles every gfx950 code object of the built .so and fails on any packed-fp32 VALU instruction."""
+    """Tripwire.  Round 1 saw head_wgrad_kernel, built with clang's SLP vectoriser (v_pk_fma_f32 op_sel forms), return different
+    sums from run to run next to the bf16-MFMA convolution; round 2 showed that packed fp32 VALU beside MFMA is NOT a hazard by
+    itself (scripts/ubench/pk_hazard.hip: four standalone victims bit-stable) while the head_wgrad effect still reproduces with
+    the SLP build (profiles/round2_notes.md) -- cause open.  Until it is understood the library is built with
+    -fno-slp-vectorize -fno-vectorize and keeps packed fp32 VALU out of its code objects: this disassembles every gfx950 code
+    object of the built .so and fails on any of them, so a compiler flag change cannot bring them back unnoticed."""
     import shutil
     import subprocess
     from footprints_amd import _lib
