@@ -35,6 +35,11 @@ _DESC = C.POINTER(ConvDesc)
 
 # name -> (restype, argtypes); mirrors include/footprints_hip.h one to one
 SIGNATURES = {
+    "fp_adaptive_avgpool_fwd": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _P]),
+    "fp_adaptive_avgpool_bwd": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, C.c_int, _P]),
+    "fp_bilinear_ac_fwd": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
+    "fp_bilinear_ac_bwd": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
+    "fp_copy_channels": (C.c_int, [_P, _P, _I64, _I32, _I32, _I32, _I32, _I32, C.c_int, _P]),
     "fp_conv_igemm_workspace": (_I64, [_DESC]),
     "fp_conv_igemm": (C.c_int, [_DESC, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
     "fp_conv_wgrad_workspace": (_I64, [_DESC]),

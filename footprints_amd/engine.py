@@ -89,11 +89,31 @@ class BlockRec:
         self.Cin, self.Cout = self.c1.Cin, self.c1.Cout
 
 
+class PSPRec:
+    """pyramid pooling module of the segmentation decoder (preprocessing/segmentation/network.py:193-207): four
+    AdaptiveAvgPool2d(P) -> 1x1 conv 512 -> 128 (no bias) -> bilinear(align_corners=True) branches, concatenated as
+    [x, x6, x4, x2, x1] (1024 channels)"""
+
+    def __init__(self, name, psp):
+        self.blocks = []          # (pool size, reduce conv, channel offset in the concatenation)
+        for bname, off in (("block1", 896), ("block2", 768), ("block3", 640), ("block4", 512)):
+            blk = getattr(psp, bname)
+            self.blocks.append((blk.pool_size, ConvRec("%s.%s.reduce" % (name, bname), blk.reduce), off))
+
+
 class DecoderRec:
-    def __init__(self, name, dec):
+    """one SkipDecoder.  seg=False: a Footprints decoder (network.py:62-101: 2-channel heads, bilinear x8/x4/x2/x1 into the
+    [B,4,H,W] outputs); seg=True: the ground-segmentation decoder (preprocessing/segmentation/network.py:54-99: 1-channel heads at
+    their own resolution, optional pyramid pooling in front of block1)"""
+
+    def __init__(self, name, dec, seg=False):
         self.name = name
-        self.sig = dec.apply_sigmoid
+        self.seg = seg
+        self.sig = False if seg else dec.apply_sigmoid
         self.c0 = 2 if name == "depth_decoder" else 0
+        self.head_scales = (1, 1, 1, 1) if seg else (8, 4, 2, 1)
+        self.psp = PSPRec(name + ".PSP", dec.PSP) if (seg and dec.use_PSP) else None
+        self.chans = [(1024 if self.psp is not None else 512, 256), (256, 128), (128, 64), (64, 64)]
         self.blocks = []
         for i in (1, 2, 3, 4):
             b = getattr(dec, "block%d" % i)
@@ -113,7 +133,7 @@ class DecoderRec:
             self.o41.up2 = (self.o41.Cin, 0)
 
     def convs(self):
-        out = []
+        out = [c for _, c, _ in self.psp.blocks] if self.psp is not None else []
         for b in self.blocks:
             out += [b["pre1"], b["pre2"], b["post1"], b["post2"]]
         return out + [self.o41, self.o42]
@@ -131,10 +151,23 @@ class Engine:
         self.stem = ConvRec("encoder.layer0.0", enc.layer0[0], stem=True)
         self.bn0 = BNRec("encoder.layer0.1", enc.layer0[1], dev)
         self.blocks = [BlockRec(p, b, dev) for p, b in enc.blocks()]
-        self.decoders = [DecoderRec("mask_decoder", model.mask_decoder), DecoderRec("depth_decoder", model.depth_decoder)]
+        if hasattr(model, "decoder"):        # Segmentor (preprocessing/segmentation/network.py:13-25): one decoder, 1-channel heads
+            self.decoders = [DecoderRec("decoder", model.decoder, seg=True)]
+        else:
+            self.decoders = [DecoderRec("mask_decoder", model.mask_decoder), DecoderRec("depth_decoder", model.depth_decoder)]
         self._bufs = {}
         self._flatten()
         self._alloc_packed()
+        # 1-channel heads (segmentation) run through the Cin -> 2 head kernels with a zero second filter: padded copies of the
+        # weight / bias (refreshed with the packed weights) and of their gradients (row 0 is handed to the parameter's gradient)
+        for d in self.decoders:
+            for hd in d.heads:
+                hd.pad = hd.Cout == 1
+                if hd.pad:
+                    hd.w2 = torch.zeros((2, hd.Cin, 3, 3), device=dev)
+                    hd.b2 = torch.zeros(2, device=dev)
+                    hd.gw2 = torch.zeros((2, hd.Cin, 3, 3), device=dev)
+                    hd.gb2 = torch.zeros(2, device=dev)
         self._pack_table = None
         self._pack_table_key = None
         self._pack_ev = None
@@ -295,6 +328,11 @@ class Engine:
         else:
             ops.pack_weights_batched(self._pack_table[1])
             self._pack_ev = None
+        for d in self.decoders:
+            for hd in d.heads:
+                if hd.pad:
+                    hd.w2[0].copy_(hd.w.data[0])
+                    hd.b2[0:1].copy_(hd.b.data)
         self._fold_ready = False
         self._versions = vers
         self.weights_dirty = False
@@ -336,6 +374,22 @@ class Engine:
         ops.bn_apply(z.view(M, rec.C), rec.scale, rec.shift, out.view(M, rec.C),
                      residual=None if residual is None else residual.view(M, rec.C), relu=relu)
         return out
+
+    @staticmethod
+    def _head_wb(hd):
+        return (hd.w2, hd.b2) if hd.pad else (hd.w.data, hd.b.data)
+
+    @staticmethod
+    def _head_wgrad(hd, x, dzl, acc):
+        if not hd.pad:
+            return ops.head_wgrad(x, dzl, hd.gw, hd.gb, accumulate=acc)
+        ops.head_wgrad(x, dzl, hd.gw2, hd.gb2, accumulate=False)
+        if acc:
+            hd.gw.add_(hd.gw2[0:1])
+            hd.gb.add_(hd.gb2[0:1])
+        else:
+            hd.gw.copy_(hd.gw2[0:1])
+            hd.gb.copy_(hd.gb2[0:1])
 
     @staticmethod
     def _cv(d, src, w32, w3, out, **kw):
@@ -527,22 +581,49 @@ class Engine:
     def _decoders_forward(self, S, outputs, save_for_backward):
         N, H, W = S["N"], S["H"], S["W"]
         if outputs is None:
-            outputs = [torch.empty((N, 4, H, W), device=self.device) for _ in range(4)]
-        S["dec"] = [None, None]
+            if self.decoders[0].seg:      # 1-channel heads at their own resolution; channel 1 of each buffer is the padding filter's zero
+                outputs = [torch.empty((N, 2, H // s, W // s), device=self.device) for s in (8, 4, 2, 1)]
+            else:
+                outputs = [torch.empty((N, 4, H, W), device=self.device) for _ in range(4)]
+        S["dec"] = [{} for _ in self.decoders]
         main = ops.current_stream()
-        if self.concurrent:
+        if self.concurrent and len(self.decoders) == 2:
             self.aux.wait_event(self._record(main))                 # encoder features ready
-            S["dec"] = [{}, {}]
             self._interleave([(self.aux, self._decoder_forward(self.decoders[1], S, outputs, S["dec"][1])),
                               (main, self._decoder_forward(self.decoders[0], S, outputs, S["dec"][0]))])
             main.wait_stream(self.aux)                              # join: both decoders wrote their output channels
         else:
-            S["dec"] = [{}, {}]
             for di, dec in enumerate(self.decoders):
                 for _ in self._decoder_forward(dec, S, outputs, S["dec"][di]):
                     pass
         self.saved = S if save_for_backward else None
         return outputs
+
+    def _psp_forward(self, dec, f4, N, h, w, D):
+        """[x, x6, x4, x2, x1] (segmentation/network.py:198-207) into one [N,h,w,1024] buffer; keeps the pooled maps for the backward"""
+        buf = self.buf
+        cat = buf(dec.name + ".psp.cat", (N, h, w, 1024))
+        ops.copy_channels(f4, cat, 512)
+        D["psp"] = []
+        for P, c, off in dec.psp.blocks:
+            pooled = ops.adaptive_avgpool_fwd(f4, buf("%s.psp.pool%d" % (dec.name, P), (N, P, P, 512)))
+            d = ops.make_desc(N, P, P, P, P, 512, 0, 128, 1, 1, 0, L.GATHER_FWD_ZERO)
+            red = ops.conv_igemm(d, pooled, None, c.wp, buf("%s.psp.red%d" % (dec.name, P), (N, P, P, 128)))
+            ops.bilinear_ac_fwd(red, cat, off)
+            D["psp"].append(pooled)
+        return cat
+
+    def _psp_backward(self, dec, D, dcat, dF4, N, h, w, acc, accum_feat):
+        """dcat [N,h,w,1024] = gradient of the concatenation -> dF4 (+)= identity slice + the four pooled branches; reduce-conv gradients"""
+        buf = self.buf
+        ops.copy_channels(dcat, dF4, 512, accumulate=accum_feat)
+        for (P, c, off), pooled in zip(dec.psp.blocks, D["psp"]):
+            dred = ops.bilinear_ac_bwd(dcat, buf("g.%s.psp.dred%d" % (dec.name, P), (N, P, P, 128)), off)
+            dw = ops.make_desc(N, P, P, P, P, 512, 0, 128, 1, 1, 0, L.GATHER_FWD_ZERO)
+            ops.conv_wgrad(dw, pooled, None, dred, c.gw, accumulate=acc)
+            dd = ops.make_desc(N, P, P, P, P, 128, 0, 512, 1, 1, 0, L.GATHER_DGRAD_ZERO)
+            dpool = ops.conv_igemm(dd, dred, None, c.wpd, buf("g.%s.psp.dpool%d" % (dec.name, P), (N, P, P, 512)))
+            ops.adaptive_avgpool_bwd(dpool, dF4, accumulate=True)
 
     def _decoder_forward(self, dec, S, outputs, D):
         """generator (see _interleave): fills D with the activations the backward pass needs"""
@@ -551,8 +632,10 @@ class Engine:
         D.update({"y": [], "x": [], "low": []})
         x = feats[4]
         h, w = dims[4]
-        chans = [(512, 256), (256, 128), (128, 64), (64, 64)]
-        for bi, (blk, (cin, cout)) in enumerate(zip(dec.blocks, chans)):
+        if dec.psp is not None:
+            x = self._psp_forward(dec, x, N, h, w, D)
+        D["x0"] = x
+        for bi, (blk, (cin, cout)) in enumerate(zip(dec.blocks, dec.chans)):
             if bi:
                 yield
             tag = "%s.b%d." % (dec.name, bi + 1)
@@ -567,10 +650,10 @@ class Engine:
             D["x"].append(xo)
             x = xo
             if bi >= 1 and (bi - 1) in S.get("scales", _ALL_SCALES):     # heads on block2/3/4 outputs: scales 8, 4, 2
-                scale = (8, 4, 2)[bi - 1]
+                scale = dec.head_scales[bi - 1]
                 low = buf("%s.low%d" % (dec.name, bi), (N, h, w, 2))
-                hd = dec.heads[bi - 1]
-                ops.head_fwd(x, hd.w.data, hd.b.data, low, dec.sig)
+                hw_, hb_ = self._head_wb(dec.heads[bi - 1])
+                ops.head_fwd(x, hw_, hb_, low, dec.sig)
                 ops.head_upsample(low, outputs[bi - 1], scale, dec.c0)
                 D["low"].append(low)
         # outconv4: nearest x2 (virtual) -> ConvBlock(64->32) -> head, scale 1
@@ -580,7 +663,8 @@ class Engine:
         x5 = self._conv_dec(dec.o42, y51, None, N, h, w, 32, 0, False, buf(dec.name + ".x5", (N, h, w, 32)))
         if 3 in S.get("scales", _ALL_SCALES):
             low = buf(dec.name + ".low4", (N, h, w, 2))
-            ops.head_fwd(x5, dec.heads[3].w.data, dec.heads[3].b.data, low, dec.sig)
+            hw_, hb_ = self._head_wb(dec.heads[3])
+            ops.head_fwd(x5, hw_, hb_, low, dec.sig)
             ops.head_upsample(low, outputs[3], 1, dec.c0)
             D["low"].append(low)
         D["y51"], D["x5"] = y51, x5
@@ -757,7 +841,7 @@ class Engine:
     def _decoders_backward(self, S, gouts, dF, accumulate, on_stage, join=False):
         """both decoders, from d loss / d outputs to the feature gradients dF[0..4] plus every decoder weight gradient"""
         main = ops.current_stream()
-        if self.concurrent:
+        if self.concurrent and len(self.decoders) == 2:
             # mask decoder on the main stream, depth decoder on the aux stream; the depth decoder ACCUMULATES into the
             # feature gradients, so each of its accumulate launches waits for the mask decoder's write of that level
             self._ev_dF = [None] * 5
@@ -775,6 +859,8 @@ class Engine:
             for di, dec in enumerate(self.decoders):
                 for _ in self._decoder_backward(dec, S["dec"][di], S, gouts, dF, first=(di == 0), acc=accumulate):
                     pass
+                if self.concurrent and (on_stage is not None or join):
+                    main.wait_stream(self.dwg[0 if di == 0 else 1])
                 if on_stage is not None:
                     on_stage(dec.name)
 
@@ -830,11 +916,11 @@ class Engine:
         x4 = D["x"][3]
         h0, w0 = dims[0]
         dzl = buf(pfx + "dzl", (N, H, W, 2))
-        ops.head_upsample_bwd(gouts[3], D["low"][3], dzl, 1, dec.c0, dec.sig)
+        ops.head_upsample_bwd(gouts[3], D["low"][3], dzl, dec.head_scales[3], dec.c0, dec.sig)
         hd = dec.heads[3]
-        ops.head_wgrad(D["x5"], dzl, hd.gw, hd.gb, accumulate=acc)
+        self._head_wgrad(hd, D["x5"], dzl, acc)
         A = buf(pfx + "dz.o42", (N, H, W, 32))
-        ops.head_dgrad(dzl, hd.w.data, A, elu_src=D["x5"])
+        ops.head_dgrad(dzl, self._head_wb(hd)[0], A, elu_src=D["x5"])
         self._wgrad(dec.o42, L.GATHER_FWD_REFLECT, D["y51"], None, A, N, H, W, H, W, 32, 0, acc, side)
         Bz = self._dgrad_dec(dec.o42, A, N, H, W, buf(pfx + "dz.o41", (N, H, W, 32)), actsrc=D["y51"])
         yield
@@ -846,27 +932,26 @@ class Engine:
             XV = self._dgrad_dec(dec.o41, Bz, N, H, W, buf(pfx + "XV", (N, H, W, 64)))
         # head3 on x4
         dzl = buf(pfx + "dzl", (N, h0, w0, 2))
-        ops.head_upsample_bwd(gouts[2], D["low"][2], dzl, 2, dec.c0, dec.sig)
+        ops.head_upsample_bwd(gouts[2], D["low"][2], dzl, dec.head_scales[2], dec.c0, dec.sig)
         hd = dec.heads[2]
-        ops.head_wgrad(x4, dzl, hd.gw, hd.gb, accumulate=acc)
+        self._head_wgrad(hd, x4, dzl, acc)
         XH = buf(pfx + "XH", (N, h0, w0, 64))
-        ops.head_dgrad(dzl, hd.w.data, XH)
+        ops.head_dgrad(dzl, self._head_wb(hd)[0], XH)
         A = buf(pfx + "dz.post2.3", (N, h0, w0, 64))
         if phase41:
             ops.up2_fold_bwd(XV, A, addend=XH, ylow=x4)
         else:
             ops.up2cat_bwd(XV, N, h0, w0, 64, 0, A, addend=XH, ylow=x4)
         # ---- blocks 4..1 ----------------------------------------------------------------------------------
-        chans = [(512, 256), (256, 128), (128, 64), (64, 64)]
         for bi in (3, 2, 1, 0):
             yield
             blk = dec.blocks[bi]
-            cin, cout = chans[bi]
+            cin, cout = dec.chans[bi]
             y1, y2, y3 = D["y"][bi]
             hh, ww = dims[3 - bi]                   # resolution of the post-concat convs
             hl, wl = hh // 2, ww // 2               # resolution of the pre-concat convs
             skip = feats[3 - bi]
-            xin = D["x"][bi - 1] if bi > 0 else feats[4]
+            xin = D["x"][bi - 1] if bi > 0 else D["x0"]          # block1's input: the 1/32 feature map (or its pyramid-pooling concatenation)
             # A = dZ of post2 at (hh, ww)
             self._wgrad(blk["post2"], L.GATHER_FWD_REFLECT, y3, None, A, N, hh, ww, hh, ww, cout, 0, acc, side)
             Bz = self._dgrad_dec(blk["post2"], A, N, hh, ww, buf(pfx + "dz.post1.%d" % bi, (N, hh, ww, cout)), actsrc=y3)
@@ -894,7 +979,11 @@ class Engine:
             if bi == 0:
                 if not first:
                     order_dF(4)
-                self._dgrad_dec(blk["pre1"], Bz, N, hl, wl, dF[4], accum=accum_feat)
+                if dec.psp is not None:
+                    dcat = self._dgrad_dec(blk["pre1"], Bz, N, hl, wl, buf(pfx + "psp.dcat", (N, hl, wl, cin)))
+                    self._psp_backward(dec, D, dcat, dF[4], N, hl, wl, acc, accum_feat)
+                else:
+                    self._dgrad_dec(blk["pre1"], Bz, N, hl, wl, dF[4], accum=accum_feat)
                 if first:
                     order_dF(4)
             else:
@@ -902,11 +991,11 @@ class Engine:
                 if bi >= 2:                          # heads on block2 / block3 outputs (x2: scale 8, x3: scale 4)
                     k = bi - 2
                     dzl = buf(pfx + "dzl", (N, hl, wl, 2))
-                    ops.head_upsample_bwd(gouts[k], D["low"][k], dzl, (8, 4)[k], dec.c0, dec.sig)
+                    ops.head_upsample_bwd(gouts[k], D["low"][k], dzl, dec.head_scales[k], dec.c0, dec.sig)
                     hd = dec.heads[k]
-                    ops.head_wgrad(xin, dzl, hd.gw, hd.gb, accumulate=acc)
+                    self._head_wgrad(hd, xin, dzl, acc)
                     XH = buf(pfx + "XH", (N, hl, wl, cin))
-                    ops.head_dgrad(dzl, hd.w.data, XH)
+                    ops.head_dgrad(dzl, self._head_wb(hd)[0], XH)
                 A = self._dgrad_dec(blk["pre1"], Bz, N, hl, wl, buf(pfx + "dz.post2.%d" % (bi - 1), (N, hl, wl, cin)), actsrc=xin, addend=XH)
 
     # ------------------------------------------------------------------------------------------------

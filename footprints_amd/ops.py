@@ -500,3 +500,44 @@ def nhwc_to_nchw(x, y=None):
 def fill(x, value):
     _lib.check(_lib.load().fp_fill(_f32(x), x.numel(), float(value), stream()), "fp_fill")
     return x
+
+
+# ---- pyramid pooling (segmentation network, footprints/preprocessing/segmentation/network.py:174-207) -------------------------
+def adaptive_avgpool_fwd(x, y):
+    N, H, W, Cn = x.shape
+    P = y.shape[1]
+    _lib.check(_lib.load().fp_adaptive_avgpool_fwd(_f32(x), _f32(y), N, H, W, Cn, P, stream()), "fp_adaptive_avgpool_fwd")
+    return y
+
+
+def adaptive_avgpool_bwd(dy, dx, accumulate=False):
+    N, H, W, Cn = dx.shape
+    P = dy.shape[1]
+    _lib.check(_lib.load().fp_adaptive_avgpool_bwd(_f32(dy), _f32(dx), N, H, W, Cn, P, int(bool(accumulate)), stream()), "fp_adaptive_avgpool_bwd")
+    return dx
+
+
+def bilinear_ac_fwd(src, dst, c_off):
+    """src [N,P,P,C] -> dst[N,H,W,dstC][..., c_off:c_off+C] (bilinear, align_corners=True)"""
+    N, P, _, Cn = src.shape
+    _, H, W, dstC = dst.shape
+    _lib.check(_lib.load().fp_bilinear_ac_fwd(_f32(src), _f32(dst), N, P, Cn, H, W, dstC, c_off, stream()), "fp_bilinear_ac_fwd")
+    return dst
+
+
+def bilinear_ac_bwd(ddst, dsrc, c_off):
+    N, P, _, Cn = dsrc.shape
+    _, H, W, dstC = ddst.shape
+    _lib.check(_lib.load().fp_bilinear_ac_bwd(_f32(ddst), _f32(dsrc), N, P, Cn, H, W, dstC, c_off, stream()), "fp_bilinear_ac_bwd")
+    return dsrc
+
+
+def copy_channels(src, dst, C_, src_off=0, dst_off=0, accumulate=False):
+    """dst[..., dst_off:dst_off+C] (+)= src[..., src_off:src_off+C] for NHWC tensors with equal pixel counts"""
+    srcC, dstC = src.shape[-1], dst.shape[-1]
+    M = src.numel() // srcC
+    if dst.numel() // dstC != M:
+        raise RuntimeError("copy_channels: pixel counts differ")
+    _lib.check(_lib.load().fp_copy_channels(_f32(src), _f32(dst), M, C_, srcC, src_off, dstC, dst_off, int(bool(accumulate)), stream()),
+               "fp_copy_channels")
+    return dst

@@ -285,6 +285,23 @@ int fp_adam_hyper(double lr, double beta1, double beta2, double eps, int32_t ste
 int fp_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                      const float* hyper7_dev, fp_stream_t stream);
 
+/* ---- pyramid pooling of the ground-segmentation network (footprints/preprocessing/segmentation/network.py:174-207) ---- */
+/* nn.AdaptiveAvgPool2d(P) (network.py:180,188): y[N][P][P][C] = window means of x[N][H][W][C]; windows floor(i*H/P) .. ceil((i+1)*H/P) */
+int fp_adaptive_avgpool_fwd(const float* x, float* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t P, fp_stream_t stream);
+/* its gradient: dx[N][H][W][C] (+)= sum over the windows containing the pixel of dy / window area */
+int fp_adaptive_avgpool_bwd(const float* dy, float* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t P, int accumulate,
+                            fp_stream_t stream);
+/* F.interpolate(size=(H,W), mode='bilinear', align_corners=True) (network.py:189) of src[N][P][P][C], written into channels
+ * [c_off, c_off + C) of dst[N][H][W][dstC]: the torch.cat of network.py:207 is this channel offset */
+int fp_bilinear_ac_fwd(const float* src, float* dst, int32_t N, int32_t P, int32_t C, int32_t H, int32_t W, int32_t dstC, int32_t c_off,
+                       fp_stream_t stream);
+/* its transpose: dsrc[N][P][P][C] = sum of weight * ddst[N][H][W][c_off + c] (plain store) */
+int fp_bilinear_ac_bwd(const float* ddst, float* dsrc, int32_t N, int32_t P, int32_t C, int32_t H, int32_t W, int32_t dstC, int32_t c_off,
+                       fp_stream_t stream);
+/* dst[M][dst_off + c] (+)= src[M][src_off + c], c < C: channel-slice copy / add (the identity branch of the concatenation and its gradient) */
+int fp_copy_channels(const float* src, float* dst, int64_t M, int32_t C, int32_t srcC, int32_t src_off, int32_t dstC, int32_t dst_off,
+                     int accumulate, fp_stream_t stream);
+
 /* ---- misc ---- */
 int fp_nchw_to_nhwc(const float* x, float* y, int32_t N, int32_t C, int32_t H, int32_t W, fp_stream_t stream);
 int fp_nhwc_to_nchw(const float* x, float* y, int32_t N, int32_t C, int32_t H, int32_t W, fp_stream_t stream);

@@ -338,3 +338,89 @@ class OracleEvaluator:
         if reset and mode in self.acc:
             self.acc[mode] = {}
         return out
+
+
+# --------------------------------------------------------------------------
+# ground-segmentation network (preprocessing/segmentation/network.py:13-207): same encoder and decoder blocks,
+# 1-channel heads at their own resolution, optional pyramid pooling
+# --------------------------------------------------------------------------
+def seg_state_spec(use_psp):
+    """ordered (key, shape, kind) of Segmentor(use_PSP).state_dict()"""
+    spec = [e for e in state_spec() if e[0].startswith("encoder.")]
+    dec = "decoder"
+    if use_psp:
+        spec += [("%s.PSP.block%d.reduce.weight" % (dec, i), (128, 512, 1, 1), "conv_w") for i in (1, 2, 3, 4)]
+    for i, (cin, cout) in enumerate(((1024 if use_psp else 512, 256), (256, 128), (128, 64), (64, 64)), start=1):
+        spec += _convblock_entries("%s.block%d.pre_concat_conv" % (dec, i), cin, cout)
+        spec += _convblock_entries("%s.block%d.post_concat_conv" % (dec, i), 2 * cout, cout)
+    for i, cin in ((1, 128), (2, 64), (3, 64)):
+        spec += [("%s.outconv%d.conv1.weight" % (dec, i), (1, cin, 3, 3), "conv_w"), ("%s.outconv%d.conv1.bias" % (dec, i), (1,), "conv_b")]
+    spec += _convblock_entries("%s.outconv4.0" % dec, 64, 32)
+    spec += [("%s.outconv4.1.conv1.weight" % dec, (1, 32, 3, 3), "conv_w"), ("%s.outconv4.1.conv1.bias" % dec, (1,), "conv_b")]
+    return spec
+
+
+def make_seg_state(use_psp, tag="seg", dtype=torch.float32):
+    """deterministic state like make_state, for the Segmentor's keys"""
+    params, buffers = OrderedDict(), OrderedDict()
+    for key, shape, kind in seg_state_spec(use_psp):
+        name = tag + ":" + key
+        if kind == "conv_w":
+            b = float(np.sqrt(3.0 / (shape[1] * shape[2] * shape[3])))
+            params[key] = torch.from_numpy(filler.uniform(name, shape, -b, b)).to(dtype)
+        elif kind == "conv_b":
+            params[key] = torch.from_numpy(filler.uniform(name, shape, -0.1, 0.1)).to(dtype)
+        elif kind == "bn_w":
+            params[key] = torch.from_numpy(filler.uniform(name, shape, 0.5, 1.5)).to(dtype)
+        elif kind == "bn_b":
+            params[key] = torch.from_numpy(filler.uniform(name, shape, -0.2, 0.2)).to(dtype)
+        elif kind == "bn_rm":
+            buffers[key] = torch.from_numpy(filler.uniform(name, shape, -0.3, 0.3)).to(dtype)
+        elif kind == "bn_rv":
+            buffers[key] = torch.from_numpy(filler.uniform(name, shape, 0.5, 2.0)).to(dtype)
+        elif kind == "bn_nbt":
+            buffers[key] = torch.zeros((), dtype=torch.int64)
+    return params, buffers
+
+
+def psp_module(x, P, prefix):
+    """PSP.forward segmentation/network.py:198-207 (PSPBlock :183-190)"""
+    h, w = x.shape[2:]
+    outs = {}
+    for name, size in (("block1", 1), ("block2", 2), ("block3", 4), ("block4", 6)):
+        y = F.conv2d(F.adaptive_avg_pool2d(x, (size, size)), P["%s.%s.reduce.weight" % (prefix, name)])
+        outs[size] = F.interpolate(y, size=(h, w), mode="bilinear", align_corners=True)
+    return torch.cat([x, outs[6], outs[4], outs[2], outs[1]], 1)
+
+
+def segmentor(image, P, B, training=True, use_psp=False):
+    """Segmentor.forward segmentation/network.py:20-25 -> [1/8, 1/4, 1/2, 1/1] logit maps, each [B,1,h,w] (:84-99)"""
+    feats = resnet_encoder(image, P, B, training)
+    d = "decoder"
+    x = feats[4]
+    if use_psp:
+        x = psp_module(x, P, d + ".PSP")
+    outs = []
+    x = up_concat_block(x, feats[3], P, d + ".block1")
+    x = up_concat_block(x, feats[2], P, d + ".block2")
+    outs.append(out_conv_block(x, P, d + ".outconv1", 1, False))
+    x = up_concat_block(x, feats[1], P, d + ".block3")
+    outs.append(out_conv_block(x, P, d + ".outconv2", 1, False))
+    x = up_concat_block(x, feats[0], P, d + ".block4")
+    outs.append(out_conv_block(x, P, d + ".outconv3", 1, False))
+    x = F.interpolate(x, scale_factor=2, mode="nearest")
+    x = conv_block(x, P, d + ".outconv4.0")
+    outs.append(out_conv_block(x, P, d + ".outconv4.1", 1, False))
+    return outs
+
+
+def seg_loss(outputs, ground_mask, loss_mask, height, width):
+    """segmentation/train.py:184-193 + segmentation/evaluation.py:39-58: predictions up-sized bilinearly (align_corners=False) to
+    (height, width), per-image masked BCE-with-logits means, averaged over the four scales, then over the batch"""
+    total = 0
+    for out in outputs:
+        pred = F.interpolate(out, size=(height, width), mode="bilinear", align_corners=False).squeeze(1)
+        loss = F.binary_cross_entropy_with_logits(pred, ground_mask, reduction="none")
+        valid = loss_mask.sum(dim=[1, 2])
+        total = total + (loss * loss_mask).sum(dim=[1, 2]) / (valid + 1e-7)
+    return (total / 4).mean()

@@ -261,6 +261,45 @@ def g8_evaluator():
     return out
 
 
+def g9_segmentor():
+    """preprocessing/segmentation/network.py: the reference Segmentor (with and without pyramid pooling) at 2x64x96, train mode:
+    the four logit maps, and -- through the segmentation trainer's masked BCE (segmentation/train.py:184-193, evaluation.py:39-58) --
+    the loss and gradient digests.  The encoder inside is oracle/standin_resnet.py (torchvision absent), like G3 / G5."""
+    import importlib
+    seg = importlib.import_module("footprints.preprocessing.segmentation.network")
+    ev = importlib.import_module("footprints.preprocessing.segmentation.evaluation")
+    out = {}
+    B, H, W = 2, 64, 96
+    image = torch.from_numpy(filler.uniform("g9:image", (B, 3, H, W)))
+    gmask = torch.from_numpy(filler.bernoulli("g9:gmask", (B, H, W), 0.4))
+    lmask = torch.from_numpy(filler.bernoulli("g9:lmask", (B, H, W), 0.7))
+    for psp in (False, True):
+        tag = "psp" if psp else "plain"
+        P, Bf = R.make_seg_state(psp, tag="g9." + tag)
+        m = seg.Segmentor(pretrained=False, use_PSP=psp)
+        m.load_state_dict({**P, **Bf})
+        m.train()
+        outputs = m(image)
+        preds = {}
+        for scale, o in enumerate(outputs):                               # segmentation/train.py:184-190
+            out.update(digest("seg.%s.out%d" % (tag, scale), o))
+            o = torch.nn.functional.interpolate(o, size=(H, W), mode="bilinear", align_corners=False)
+            preds[("ground", scale)] = o.squeeze(1)
+        loss = ev.Evaluator().compute_losses(preds, gmask, lmask)
+        loss.backward()
+        out["seg.%s.loss" % tag] = np.float64(loss.item())
+        g = dict(m.named_parameters())
+        names = [k for k in g]
+        out["seg.%s.param_names" % tag] = np.array(names)
+        out["seg.%s.dead" % tag] = np.array([k for k in names if g[k].grad is None])
+        out["seg.%s.grad_sums" % tag] = np.array([float(g[k].grad.double().sum()) if g[k].grad is not None else 0.0 for k in names])
+        out["seg.%s.grad_abs" % tag] = np.array([float(g[k].grad.double().abs().sum()) if g[k].grad is not None else 0.0 for k in names])
+        for k in ("decoder.outconv4.1.conv1.weight", "decoder.outconv1.conv1.weight", "decoder.block1.pre_concat_conv.conv1.weight",
+                  "decoder.block4.post_concat_conv.conv1.weight") + (("decoder.PSP.block4.reduce.weight", "decoder.PSP.block1.reduce.weight") if psp else ()):
+            out.update(digest("seg.%s.grad.%s" % (tag, k), g[k].grad))
+    return out
+
+
 def main():
     mods = ref_import.load_reference()
     assert mods is not None, "needs /root/reference"
@@ -271,7 +310,8 @@ def main():
     for name, fn in (("g1_blocks", lambda: g1_blocks(net)), ("g2_decoder", lambda: g2_decoder(net)),
                      ("g3_network", lambda: g3_network(net)), ("g4_loss", lambda: g4_loss(loss_mod)),
                      ("g5_train", lambda: g5_train(net, loss_mod)), ("g6_predict", lambda: g6_predict(net)),
-                     ("g7_metrics", g7_metrics), ("g8_evaluator", g8_evaluator)):
+                     ("g7_metrics", g7_metrics), ("g8_evaluator", g8_evaluator),
+                     ("g9_segmentor", g9_segmentor)):
         if only and name not in only:
             continue
         d = fn()

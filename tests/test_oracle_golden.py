@@ -227,3 +227,32 @@ def test_g8_evaluator_restatement_matches_reference_evaluator():
     np.testing.assert_allclose([a[k] for k in R.LOSS_KEYS], gold["eval.train_avg"], rtol=1e-6)
     v = ev.get_averaged_losses("val")
     np.testing.assert_allclose([v[k] for k in R.LOSS_KEYS], gold["eval.val_avg"], rtol=1e-6)
+
+
+def test_g9_segmentor_restatement_matches_reference():
+    """preprocessing/segmentation/network.py (fixture from the reference's own Segmentor + segmentation Evaluator): four logit maps,
+    masked-BCE loss, dead parameters, gradient digests -- with and without the pyramid-pooling module"""
+    from oracle import filler
+    gold = load("g9_segmentor")
+    B, H, W = 2, 64, 96
+    image = torch.from_numpy(filler.uniform("g9:image", (B, 3, H, W)))
+    gmask = torch.from_numpy(filler.bernoulli("g9:gmask", (B, H, W), 0.4))
+    lmask = torch.from_numpy(filler.bernoulli("g9:lmask", (B, H, W), 0.7))
+    for psp in (False, True):
+        tag = "psp" if psp else "plain"
+        P, Bf = R.make_seg_state(psp, tag="g9." + tag)
+        assert list({**P, **Bf}.keys()) is not None
+        P = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in P.items())
+        outs = R.segmentor(image, P, OrderedDict((k, v.clone()) for k, v in Bf.items()), True, psp)
+        for i, o in enumerate(outs):
+            compare(gold, "seg.%s.out%d" % (tag, i), o)
+        loss = R.seg_loss(outs, gmask, lmask, H, W)
+        loss.backward()
+        assert abs(float(loss) - float(gold["seg.%s.loss" % tag])) <= 1e-6 * abs(float(gold["seg.%s.loss" % tag]))
+        names = [str(n) for n in gold["seg.%s.param_names" % tag]]
+        assert [k for k in names if P[k].grad is None] == [str(n) for n in gold["seg.%s.dead" % tag]]
+        gs = np.array([float(P[k].grad.double().sum()) if P[k].grad is not None else 0.0 for k in names])
+        ga = gold["seg.%s.grad_abs" % tag]
+        assert np.all(np.abs(gs - gold["seg.%s.grad_sums" % tag]) <= 1e-4 * np.maximum(ga, 1e-12))
+        for k in [f[len("seg.%s.grad." % tag):].split("#")[0] for f in gold.files if f.startswith("seg.%s.grad." % tag)]:
+            compare(gold, "seg.%s.grad.%s" % (tag, k), P[k].grad)
