@@ -22,7 +22,7 @@ cpu_batch = R.make_batch(Bn, Hn, Wn, tag="%s%d" % (tag, Hn))
 
 
 def oracle(dtype):
-    Pd = OrderedDict((k, v.to(dtype).requires_grad_(True)) for k, v in P.items())
+    Pd = OrderedDict((k, v.detach().clone().to(dtype).requires_grad_(True)) for k, v in P.items())
     Bd = OrderedDict((k, v.to(dtype) if v.is_floating_point() else v.clone()) for k, v in B.items())
     batch = OrderedDict((k, v.to(dtype)) for k, v in cpu_batch.items())
     out, feats = R.footprint_network(batch["image"], Pd, Bd, True, return_features=True)

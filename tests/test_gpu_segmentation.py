@@ -124,7 +124,7 @@ def test_segmentor_psp_train_step_fp64_anchored_at_kitti_resolution():
     P, Bf = R.make_seg_state(True, tag="segk")
     ref = {}
     for dt in (torch.float32, torch.float64):
-        Pd = OrderedDict((k, v.to(dt).requires_grad_(True)) for k, v in P.items())
+        Pd = OrderedDict((k, v.detach().clone().to(dt).requires_grad_(True)) for k, v in P.items())
         Bd = OrderedDict((k, v.to(dt) if v.is_floating_point() else v.clone()) for k, v in Bf.items())
         outs = R.segmentor(image.to(dt), Pd, Bd, True, True)
         loss = R.seg_loss(outs, gmask.to(dt), lmask.to(dt), H, W)
@@ -144,6 +144,7 @@ def test_segmentor_psp_train_step_fp64_anchored_at_kitti_resolution():
           "median %.2f" % float(np.median([r for r, *_ in rows])))
     assert not bad, bad[:10]
     # inference path (eval mode, folded BatchNorm, no_grad) == the oracle's eval forward
+    m = _seg_model(P, Bf, True)           # fresh running statistics (the training forward above moved the first model's)
     m.eval()
     with torch.no_grad():
         ev = m(image.cuda())
