@@ -35,6 +35,9 @@ _DESC = C.POINTER(ConvDesc)
 
 # name -> (restype, argtypes); mirrors include/footprints_hip.h one to one
 SIGNATURES = {
+    "fp_aug_params_bytes": (_I32, []),
+    "fp_assemble_images": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _P]),
+    "fp_assemble_labels": (C.c_int, [_P, _P, _P, _P, _P, _I32, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _D, _D, _D, _P]),
     "fp_adaptive_avgpool_fwd": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _P]),
     "fp_adaptive_avgpool_bwd": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, C.c_int, _P]),
     "fp_bilinear_ac_fwd": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P]),

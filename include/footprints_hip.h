@@ -285,6 +285,31 @@ int fp_adam_hyper(double lr, double beta1, double beta2, double eps, int32_t ste
 int fp_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                      const float* hyper7_dev, fp_stream_t stream);
 
+/* ---- device-side data path (footprints/datasets/footprint_dataset.py:55-65,73-85; kitti_dataset.py:66-112; matterport_dataset.py:69-97) ---- */
+/* one per sample; fp_aug_params_bytes() == sizeof(fp_aug_params) */
+typedef struct fp_aug_params {
+  int32_t flip;        /* horizontal flip of the image and every label map (footprint_dataset.py:73-75,84-85) */
+  int32_t n_ops;       /* 0 = no colour jitter, 4 = torchvision ColorJitter's four ops */
+  int32_t ops[4];      /* application order (random.shuffle in ColorJitter.get_params): 0 brightness, 1 contrast, 2 saturation, 3 hue */
+  float factor[4];     /* indexed by op id: ImageEnhance factors (float, as libImaging's Image.blend takes them) */
+  int32_t hue_shift;   /* np.uint8(hue_factor * 255) of torchvision's adjust_hue */
+  int32_t pad;
+} fp_aug_params;
+int32_t fp_aug_params_bytes(void);
+/* images_hwc uint8 [B][H][W][3] (as PIL delivers them after the resize, not flipped) -> out_nchw float [B][3][H][W] in [0,1]:
+ * flip, ColorJitter (bit-exact with Pillow 12's ImageEnhance / convert arithmetic), ToTensor.  luma_sums: B uint64 scratch
+ * (the contrast op needs the mean grey level of the image as it stands before that op: one integer reduction pass). */
+int fp_assemble_images(const uint8_t* images_hwc, const void* aug_params, uint64_t* luma_sums, float* out_nchw, int32_t B, int32_t H,
+                       int32_t W, fp_stream_t stream);
+/* label maps [B][H][W] (float32 or float64 as they leave the resize, not flipped) -> the six float32 maps of the batch schema.
+ * dataset 0 = KITTI (aux = resized pixel disparity before the -1.25; fxb = focal * baseline; moving may be NULL when !use_moving),
+ * 1 = Matterport (aux = raw 16-bit depth, depth_scaling = metres per unit).  Arithmetic in float64 like numpy in the reference. */
+int fp_assemble_labels(const void* visible_ground, const void* ground_depth, const void* depth_mask, const void* aux, const void* moving,
+                       int32_t is_double, const void* aug_params, float* o_visible_ground, float* o_depth, float* o_ground_depth,
+                       float* o_moving, float* o_depth_mask, float* o_all_ground, int32_t B, int32_t H, int32_t W, int32_t dataset,
+                       int32_t no_depth_mask, int32_t project_down_baseline, int32_t use_moving, double threshold, double fxb,
+                       double depth_scaling, fp_stream_t stream);
+
 /* ---- pyramid pooling of the ground-segmentation network (footprints/preprocessing/segmentation/network.py:174-207) ---- */
 /* nn.AdaptiveAvgPool2d(P) (network.py:180,188): y[N][P][P][C] = window means of x[N][H][W][C]; windows floor(i*H/P) .. ceil((i+1)*H/P) */
 int fp_adaptive_avgpool_fwd(const float* x, float* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t P, fp_stream_t stream);

@@ -300,6 +300,82 @@ def g9_segmentor():
     return out
 
 
+def g10_data_path():
+    """datasets/kitti_dataset.py:44-122 + datasets/footprint_dataset.py:55-105: the reference's own KITTIDataset.__getitem__ (is_train=True)
+    on synthetic files written at the target resolution (so every resize is the identity), Python RNG seeded.  Absent third-party
+    modules are stood in: cv2.resize (identity, asserted), skimage.measure.label (scipy.ndimage.label, 8-connectivity) and
+    torchvision.transforms.{ColorJitter,ToTensor} (oracle/data_path.py's restatement of torchvision 0.4.2 on top of the real Pillow)."""
+    import importlib
+    import random
+    import tempfile
+    import types
+    from PIL import Image
+    import scipy.ndimage
+    from oracle import data_path as D
+    from tests.golden.data_inputs import N_SAMPLES, SEED, H, W, sample_inputs
+    ref_import.load_reference()
+    cv2 = sys.modules["cv2"]
+    cv2.INTER_NEAREST, cv2.INTER_AREA = 0, 3
+
+    def resize(a, size, interpolation=None):
+        assert (a.shape[1], a.shape[0]) == tuple(size), "the fixture's files are written at the target resolution"
+        return np.ascontiguousarray(a)
+    cv2.resize = resize
+    sk = types.ModuleType("skimage"); skm = types.ModuleType("skimage.measure")
+    skm.label = lambda m: scipy.ndimage.label(m, structure=np.ones((3, 3)))[0]
+    sk.measure = skm
+    sys.modules["skimage"], sys.modules["skimage.measure"] = sk, skm
+    tvt = sys.modules["torchvision.transforms"]
+
+    class ColorJitter:
+        def __init__(self, brightness, contrast, saturation, hue):
+            assert (brightness, contrast, saturation, hue) == D.JITTER_RANGES
+        @staticmethod
+        def get_params(brightness, contrast, saturation, hue):
+            order, factors = D.jitter_params(random)
+            return lambda img: D.jitter_pil(img, order, factors)
+        def __call__(self, img):
+            return self.get_params(*D.JITTER_RANGES)(img)
+
+    class ToTensor:
+        def __call__(self, pic):
+            return torch.from_numpy(np.asarray(pic).copy()).permute(2, 0, 1).contiguous().float().div(255)
+    tvt.ColorJitter, tvt.ToTensor = ColorJitter, ToTensor
+    sys.modules["torchvision"].transforms = tvt
+    kd = importlib.import_module("footprints.datasets.kitti_dataset")
+    out = {"flags": np.zeros((N_SAMPLES, 2), np.int64)}
+    with tempfile.TemporaryDirectory() as tmp:
+        raw, tr = os.path.join(tmp, "raw"), os.path.join(tmp, "train")
+        names = []
+        for i in range(N_SAMPLES):
+            img, maps = sample_inputs(i)
+            seq, frame = "seq", "%010d" % i
+            os.makedirs(os.path.join(raw, seq, "image_02", "data"), exist_ok=True)
+            Image.fromarray(img, "RGB").save(os.path.join(raw, seq, "image_02", "data", frame + ".jpg"), format="PNG")   # lossless; PIL sniffs the content
+            for sub, key, leaf in (("ground_seg", "visible_ground", "data"), ("hidden_depths", "ground_depth", "data"), ("depth_masks", "depth_mask", "data"),
+                                   ("moving_objects", "moving_objects", "data"), ("stereo_matching_disps", "disparity", None)):
+                d = os.path.join(tr, sub, seq, "image_02", *( [leaf] if leaf else [] ))
+                os.makedirs(d, exist_ok=True)
+                np.save(os.path.join(d, frame + ".npy"), maps[key])
+            names.append("%s %d l" % (seq, i))
+        random.seed(SEED)
+        ds = kd.KITTIDataset(raw, tr, names, H, W, no_depth_mask=False, moving_objects_method="ours", project_down_baseline=False, is_train=True)
+        # the fixture's depth masks are isolated pixels: filter_depth_mask (footprint_dataset.py:95-105) must keep them all
+        for i in range(N_SAMPLES):
+            dm = sample_inputs(i)[1]["depth_mask"]
+            assert np.array_equal(ds.filter_depth_mask(dm), dm)
+        state = random.getstate()
+        probe = random.Random(); probe.setstate(state)
+        for i in range(N_SAMPLES):
+            out["flags"][i] = D.sample_augmentation(True, probe)
+            if out["flags"][i][1]:
+                D.jitter_params(probe)
+            item = ds[i]
+            for k, v in item.items():
+                out["%d.%s" % (i, k)] = v.numpy()
+    return out
+
+
 def main():
     mods = ref_import.load_reference()
     assert mods is not None, "needs /root/reference"
@@ -311,7 +387,7 @@ def main():
                      ("g3_network", lambda: g3_network(net)), ("g4_loss", lambda: g4_loss(loss_mod)),
                      ("g5_train", lambda: g5_train(net, loss_mod)), ("g6_predict", lambda: g6_predict(net)),
                      ("g7_metrics", g7_metrics), ("g8_evaluator", g8_evaluator),
-                     ("g9_segmentor", g9_segmentor)):
+                     ("g9_segmentor", g9_segmentor), ("g10_data_path", g10_data_path)):
         if only and name not in only:
             continue
         d = fn()
