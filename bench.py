@@ -326,6 +326,7 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="N = 1 only: run the data-parallel branch anyway (RCCL communicator, "
                     "bucketed all-reduces in a world of one rank) -- a dry run of the code path the N > 1 launches take")
     ap.add_argument("--dump-kernels", type=str, default=None, help="write the per-launch-shape timing tables (JSON) here")
+    ap.add_argument("--no-loader", action="store_true", help="skip the extra leg that feeds the step from the device-side data path")
     args = ap.parse_args()
     wl = WORKLOADS[args.workload]
     B, H, W = wl["B"], wl["H"], wl["W"]
@@ -382,8 +383,8 @@ def main():
     # kernel-exclusive pass (outside the timed region): same steps on ONE stream, HIP events around every convolution launch
     xtimer, xsteps = None, 3
     if rank == 0 and not args.no_kernel_events:
-        was = step.eng.concurrent
-        step.eng.concurrent = False
+        was, was_plan = step.eng.concurrent, step.use_plan
+        step.eng.concurrent, step.use_plan = False, False            # eager, one stream: the instrumented wrappers see every launch
         step(batch)
         xinst = Instrument(ops, CONV_OPS)
         xinst.install()
@@ -393,7 +394,7 @@ def main():
         torch.cuda.synchronize()
         xinst.remove()
         xtimer = xinst.timer
-        step.eng.concurrent = was
+        step.eng.concurrent, step.use_plan = was, was_plan
 
     # decoder backward alone: both decoders, from d loss / d outputs to d loss / d features plus all decoder
     # weight gradients, HIP events around repeated runs on one saved forward (all five streams, joined inside the bracket)
@@ -421,6 +422,51 @@ def main():
                            "time = HIP events around 10 repetitions after 2 warm-ups; the convolutions are MFMA-bound (72-755 flop/B), the "
                            "phase decomposition executes 4/9 of the upsample convs' FLOPs"}
 
+    # the same step fed by the device-side data path (outside the timed region, reported beside `value`):
+    # host samples (resized uint8 images + float64 label maps, as the file readers deliver them) -> pinned double-buffered H2D ->
+    # flip / ColorJitter / ToTensor / label algebra kernels on a copy stream -> TrainStep.  Decode + resize stay host-side.
+    loader_leg = None
+    if rank == 0 and not args.no_loader and args.workload == "kitti":
+        import random as _random
+        import numpy as np
+        from footprints_amd.datasets import DeviceBatchAssembler, DeviceLoader
+        nrng = np.random.default_rng(SEED)
+        pool = []
+        for _ in range(2 * B):
+            maps = {"visible_ground": nrng.random((H, W)), "ground_depth": nrng.random((H, W)) * 30 * (nrng.random((H, W)) < 0.5),
+                    "depth_mask": (nrng.random((H, W)) < 0.1).astype(np.float64), "disparity": nrng.random((H, W)) * 60,
+                    "moving_objects": (nrng.random((H, W)) < 0.05).astype(np.float64)}
+            pool.append((nrng.integers(0, 256, (H, W, 3), dtype=np.uint8), maps))
+        nb = max(6, min(args.steps, 12))
+        source = [[pool[(i * B + j) % len(pool)] for j in range(B)] for i in range(nb + 2)]
+        asm = DeviceBatchAssembler(B, H, W, dataset="kitti")
+        it = iter(DeviceLoader(source, asm, is_train=True, rng=_random.Random(SEED)))
+        for _ in range(2):
+            step(next(it))
+        torch.cuda.synchronize()
+        l0 = time.perf_counter()
+        n_l = 0
+        for bt in it:
+            step(bt)
+            n_l += 1
+        torch.cuda.synchronize()
+        l_ms = (time.perf_counter() - l0) / max(n_l, 1) * 1e3
+        # the assembly kernels alone (copy stream idle otherwise): one batch, HIP events on the assembler's stream
+        prm = [__import__("footprints_amd.datasets", fromlist=["draw_augmentation"]).draw_augmentation(True, _random.Random(i)) for i in range(B)]
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record(asm.stream)
+        sl = asm.submit(source[0], prm)
+        e1.record(asm.stream)
+        torch.cuda.synchronize()
+        asm.release(sl)
+        h2d_mb = (B * H * W * 3 + 5 * B * H * W * 8) / 1e6
+        loader_leg = {"ms_per_step": round(l_ms, 3), "img_per_s": round(B / l_ms * 1e3, 1), "steps": n_l,
+                      "h2d_plus_assembly_ms_per_batch": round(e0.elapsed_time(e1), 3), "h2d_mb_per_batch": round(h2d_mb, 1),
+                      "note": "same train step, batches produced by footprints_amd.datasets.DeviceLoader (pinned double-buffered H2D of uint8 images + "
+                              "float64 label maps, then fp_assemble_images / fp_assemble_labels on a copy stream under the previous step); the host side "
+                              "of this leg only memcpy's pre-decoded samples into pinned memory (decode / resize are dataset plumbing, out of scope)"}
+
     # forward-only latency (configs[1]): eval-mode, no_grad, same batch
     mm.model.eval()
     with torch.no_grad():
@@ -446,7 +492,7 @@ def main():
                "step_ms": {"median": round(step_ms[len(step_ms) // 2], 3), "p10": round(step_ms[len(step_ms) // 10], 3),
                            "p90": round(step_ms[min(len(step_ms) - 1, (len(step_ms) * 9) // 10)], 3),
                            "note": "GPU-side durations between per-step HIP events inside the timed region (rank 0)"},
-               "decoder_backward": dec_bwd}
+               "decoder_backward": dec_bwd, "device_data_path": loader_leg}
         gf_fwd, gf_step = network_conv_gflop(B, H, W)
         # whole-step figure: the reference graph's conv FLOPs (fwd + dgrad + wgrad) over the measured step time, i.e. including
         # every non-conv kernel, launch gap and the FLOPs the nearest-x2 phase decomposition does not execute

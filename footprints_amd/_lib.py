@@ -35,6 +35,13 @@ _DESC = C.POINTER(ConvDesc)
 
 # name -> (restype, argtypes); mirrors include/footprints_hip.h one to one
 SIGNATURES = {
+    "fp_plan_begin": (_P, []),
+    "fp_plan_mark": (_I32, [_P]),
+    "fp_plan_end": (_I32, [_P]),
+    "fp_plan_replay": (C.c_int, [_P, _I32, _I32]),
+    "fp_plan_destroy": (None, [_P]),
+    "fp_event_record": (_I64, [_P]),
+    "fp_event_wait": (C.c_int, [_P, _I64]),
     "fp_aug_params_bytes": (_I32, []),
     "fp_assemble_images": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _P]),
     "fp_assemble_labels": (C.c_int, [_P, _P, _P, _P, _P, _I32, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _D, _D, _D, _P]),

@@ -328,8 +328,8 @@ extern "C" int fp_bn_train_stats(const float* z, int64_t M, int32_t C, const flo
   FP_REQUIRE(bn_c_ok(C) && M > 0 && M < ((int64_t)1 << 31), "fp_bn_train_stats: unsupported C=%d", C);
   FP_REQUIRE(workspace_bytes >= fp_bn_workspace(M, C), "fp_bn_train_stats: workspace too small");
   const int nblk = bn_blocks(M, C);
-  hipLaunchKernelGGL(bn_stats_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, z, (int)M, C, (float*)workspace);
-  hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, nblk,
+  fp_launch(bn_stats_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, z, (int)M, C, (float*)workspace);
+  fp_launch(bn_stats_final_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, nblk,
                      C, gamma, beta, eps, momentum, running_mean, running_var, (long long*)num_batches_tracked, save_mean,
                      save_invstd, scale, shift);
   return fp_check_launch("fp_bn_train_stats");
@@ -338,7 +338,7 @@ extern "C" int fp_bn_train_stats(const float* z, int64_t M, int32_t C, const flo
 extern "C" int fp_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                                  float eps, int32_t C, float* scale, float* shift, fp_stream_t stream) {
   FP_REQUIRE(gamma && beta && running_mean && running_var && scale && shift, "fp_bn_eval_coeffs: null pointer");
-  hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma, beta, running_mean,
+  fp_launch(bn_eval_coeffs_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma, beta, running_mean,
                      running_var, eps, C, scale, shift);
   return fp_check_launch("fp_bn_eval_coeffs");
 }
@@ -347,7 +347,7 @@ extern "C" int fp_bn_apply(const float* z, const float* scale, const float* shif
                            int32_t C, int32_t relu, fp_stream_t stream) {
   FP_REQUIRE(z && scale && shift && y && C % 4 == 0, "fp_bn_apply: bad arguments");
   const size_t total4 = (size_t)M * (C / 4);
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, z, scale, shift, residual, y,
+  fp_launch(bn_apply_kernel, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, z, scale, shift, residual, y,
                      total4, C / 4, relu);
   return fp_check_launch("fp_bn_apply");
 }
@@ -361,12 +361,12 @@ extern "C" int fp_bn_bwd(const float* dy, const float* relu_out, const float* z,
   const int nblk = bn_blocks(M, C);
   float* part = (float*)workspace;
   float* coef = part + (size_t)nblk * C * 3;   // 16-byte aligned: nblk*C*3 floats with C%4==0
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, dy, relu_out, z, save_mean, save_invstd,
+  fp_launch(bn_bwd_reduce_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, dy, relu_out, z, save_mean, save_invstd,
                      (int)M, C, part);
-  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const float*)part, nblk, C,
+  fp_launch(bn_bwd_final_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const float*)part, nblk, C,
                      1.f / (float)M, coef, dgamma, dbeta, accumulate);
   const size_t total4 = (size_t)M * (C / 4);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, dy, relu_out, z, save_mean,
+  fp_launch(bn_bwd_apply_kernel, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, dy, relu_out, z, save_mean,
                      save_invstd, gamma, (const float*)coef, dz, g_out, total4, C / 4);
   return fp_check_launch("fp_bn_bwd");
 }
@@ -375,7 +375,7 @@ extern "C" int fp_maxpool_fwd(const float* x, float* y, uint8_t* argmax, int32_t
                               fp_stream_t stream) {
   FP_REQUIRE(x && y && argmax && C % 4 == 0, "fp_maxpool_fwd: bad arguments");
   const size_t total = (size_t)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
-  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, y, argmax, N, H, W, C);
+  fp_launch(maxpool_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, y, argmax, N, H, W, C);
   return fp_check_launch("fp_maxpool_fwd");
 }
 
@@ -383,7 +383,7 @@ extern "C" int fp_maxpool_bwd(const float* dy, const uint8_t* argmax, float* dx,
                               int accumulate, fp_stream_t stream) {
   FP_REQUIRE(dy && dx && argmax && C % 4 == 0, "fp_maxpool_bwd: bad arguments");
   const size_t total = (size_t)N * H * W * (C / 4);
-  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dy, argmax, dx, N, H, W, C,
+  fp_launch(maxpool_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dy, argmax, dx, N, H, W, C,
                      accumulate);
   return fp_check_launch("fp_maxpool_bwd");
 }

@@ -305,7 +305,7 @@ int launch_tile(TileArgs& a, hipStream_t stream) {
   a.tilesY = (int)fp_ceil_div(a.OH, TH);
   a.tilesN = (int)fp_ceil_div(a.Nout, BN);
   a.nwg = a.N * a.tilesY * a.tilesX * a.tilesN;
-  hipLaunchKernelGGL((conv3x3_tile_kernel<TH, TW, BN, WM, WN, FLIP, FOLD>), dim3(a.nwg), dim3(256), 0, stream, a);
+  fp_launch((conv3x3_tile_kernel<TH, TW, BN, WM, WN, FLIP, FOLD>), dim3(a.nwg), dim3(256), 0, stream, a);
   return fp_check_launch("fp_conv_igemm(tile)");
 }
 

@@ -389,7 +389,7 @@ __global__ void __launch_bounds__(256) conv3x3_tile_bf3_kernel(const Tile3Args a
 
 template <int TH, int TW, int BN, int WM, int WN, bool FLIP, bool FOLD>
 int launch3(Tile3Args& a, hipStream_t stream) {
-  hipLaunchKernelGGL((conv3x3_tile_bf3_kernel<TH, TW, BN, WM, WN, FLIP, FOLD>), dim3(a.nwg), dim3(256), 0, stream, a);
+  fp_launch((conv3x3_tile_bf3_kernel<TH, TW, BN, WM, WN, FLIP, FOLD>), dim3(a.nwg), dim3(256), 0, stream, a);
   return fp_check_launch("fp_conv3x3_bf3");
 }
 

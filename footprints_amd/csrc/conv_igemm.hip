@@ -348,11 +348,11 @@ int launch(IgemmArgs& a, hipStream_t stream, int64_t ws_floats) {
   a.stepsPerSplit = (int)fp_ceil_div(steps, sk);
   a.SK = (int)fp_ceil_div(steps, a.stepsPerSplit);
   a.nwg = tilesM * a.tilesN * a.SK;
-  hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, STEM>), dim3(a.nwg), dim3(256), 0, stream, a);
+  fp_launch((igemm_kernel<BM, BN, WM, WN, STEM>), dim3(a.nwg), dim3(256), 0, stream, a);
   if (a.SK > 1) {
     int64_t g = fp_ceil_div((int64_t)a.M * a.Nout, 256);
     if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)g), dim3(256), 0, stream, a);
+    fp_launch(splitk_reduce_kernel, dim3((int)g), dim3(256), 0, stream, a);
   }
   return fp_check_launch("fp_conv_igemm");
 }
@@ -370,7 +370,7 @@ int fp_splitk_reduce_launch(const float* part, int SK, int64_t M, int Nout, cons
   a.bias = bias; a.addend = addend; a.addend_mask = addend_mask; a.actsrc = actsrc; a.y = y; a.act = act; a.epi = epi;
   int64_t g = fp_ceil_div(M * Nout, 256);
   if (g > 4096) g = 4096;
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)g), dim3(256), 0, stream, a);
+  fp_launch(splitk_reduce_kernel, dim3((int)g), dim3(256), 0, stream, a);
   return fp_check_launch("splitk_reduce");
 }
 

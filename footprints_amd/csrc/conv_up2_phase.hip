@@ -538,11 +538,11 @@ extern "C" int fp_conv_up2_phase_fwd(const float* low, const float* wphase, cons
   if (Nout <= 32) {
     a.tilesN = (int)fp_ceil_div(Nout, 32);
     a.nwg = N * a.tilesY * a.tilesX * a.tilesN * 4;
-    hipLaunchKernelGGL((up2_phase_fwd_kernel<32, 4, 1>), dim3(a.nwg), dim3(256), 0, (hipStream_t)stream, a);
+    fp_launch((up2_phase_fwd_kernel<32, 4, 1>), dim3(a.nwg), dim3(256), 0, (hipStream_t)stream, a);
   } else {
     a.tilesN = (int)fp_ceil_div(Nout, 64);
     a.nwg = N * a.tilesY * a.tilesX * a.tilesN * 4;
-    hipLaunchKernelGGL((up2_phase_fwd_kernel<64, 2, 2>), dim3(a.nwg), dim3(256), 0, (hipStream_t)stream, a);
+    fp_launch((up2_phase_fwd_kernel<64, 2, 2>), dim3(a.nwg), dim3(256), 0, (hipStream_t)stream, a);
   }
   return fp_check_launch("fp_conv_up2_phase_fwd");
 }
@@ -560,11 +560,11 @@ extern "C" int fp_conv_up2_phase_fwd_bf3(const float* low, const void* wphase_bf
   if (Nout <= 32) {
     a.tilesN = (int)fp_ceil_div(Nout, 32);
     a.nwg = N * a.tilesY * a.tilesX * a.tilesN * 4;
-    hipLaunchKernelGGL((up2_phase_fwd_bf3_kernel<32, 4, 1>), dim3(a.nwg), dim3(256), 0, (hipStream_t)stream, a);
+    fp_launch((up2_phase_fwd_bf3_kernel<32, 4, 1>), dim3(a.nwg), dim3(256), 0, (hipStream_t)stream, a);
   } else {
     a.tilesN = (int)fp_ceil_div(Nout, 64);
     a.nwg = N * a.tilesY * a.tilesX * a.tilesN * 4;
-    hipLaunchKernelGGL((up2_phase_fwd_bf3_kernel<64, 2, 2>), dim3(a.nwg), dim3(256), 0, (hipStream_t)stream, a);
+    fp_launch((up2_phase_fwd_bf3_kernel<64, 2, 2>), dim3(a.nwg), dim3(256), 0, (hipStream_t)stream, a);
   }
   return fp_check_launch("fp_conv_up2_phase_fwd_bf3");
 }
@@ -581,11 +581,11 @@ extern "C" int fp_conv_up2_phase_dgrad_bf3(const float* dz, const void* wpacked_
   if (C0 <= 32) {
     a.tilesN = (int)fp_ceil_div(C0, 32);
     a.nwg = N * a.tilesY * a.tilesX * a.tilesN;
-    hipLaunchKernelGGL((up2_phase_dgrad_bf3_kernel<32, 4, 1>), dim3(a.nwg), dim3(256), 0, (hipStream_t)stream, a);
+    fp_launch((up2_phase_dgrad_bf3_kernel<32, 4, 1>), dim3(a.nwg), dim3(256), 0, (hipStream_t)stream, a);
   } else {
     a.tilesN = (int)fp_ceil_div(C0, 64);
     a.nwg = N * a.tilesY * a.tilesX * a.tilesN;
-    hipLaunchKernelGGL((up2_phase_dgrad_bf3_kernel<64, 2, 2>), dim3(a.nwg), dim3(256), 0, (hipStream_t)stream, a);
+    fp_launch((up2_phase_dgrad_bf3_kernel<64, 2, 2>), dim3(a.nwg), dim3(256), 0, (hipStream_t)stream, a);
   }
   return fp_check_launch("fp_conv_up2_phase_dgrad_bf3");
 }
@@ -593,7 +593,7 @@ extern "C" int fp_conv_up2_phase_dgrad_bf3(const float* dz, const void* wpacked_
 extern "C" int fp_up2_fold_bwd(const float* ext, int32_t N, int32_t h, int32_t w, int32_t C, const float* addend, const float* ylow_elu,
                                float* dlow, fp_stream_t stream) {
   FP_REQUIRE(ext && dlow && N > 0 && h > 0 && w > 0 && C > 0 && C % 4 == 0, "fp_up2_fold_bwd: bad arguments");
-  hipLaunchKernelGGL(up2_fold_bwd_kernel, dim3(grid_for((size_t)N * h * w * (C / 4))), dim3(256), 0, (hipStream_t)stream, ext, N, h, w, C,
+  fp_launch(up2_fold_bwd_kernel, dim3(grid_for((size_t)N * h * w * (C / 4))), dim3(256), 0, (hipStream_t)stream, ext, N, h, w, C,
                      addend, ylow_elu, dlow);
   return fp_check_launch("fp_up2_fold_bwd");
 }

@@ -270,7 +270,7 @@ int fp_wgrad_reduce_launch(const float* part, float* dw, int S, int T, int Kc, i
   const int64_t total = (int64_t)T * Kc * Nout;
   int rgrid = (int)fp_ceil_div(total, 256);
   if (rgrid > 4096) rgrid = 4096;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rgrid), dim3(256), 0, stream, part, dw, S, T, Kc, Nout, stem, accumulate,
+  fp_launch(wgrad_reduce_kernel, dim3(rgrid), dim3(256), 0, stream, part, dw, S, T, Kc, Nout, stem, accumulate,
                      kc_total, k_begin);
   return fp_check_launch("fp_conv_wgrad(reduce)");
 }
@@ -318,13 +318,13 @@ extern "C" int fp_conv_wgrad_slice(const fp_conv_desc* d, const float* src0, con
   a.kblocks = p.kblocks; a.nblocks = p.nblocks;
   const int grid = p.S * p.T * p.kblocks * p.nblocks;
   if (stem) {
-    hipLaunchKernelGGL((wgrad_kernel<64, 64, 2, 2, 1, true>), dim3(grid), dim3(256), 0, stream, a);
+    fp_launch((wgrad_kernel<64, 64, 2, 2, 1, true>), dim3(grid), dim3(256), 0, stream, a);
   } else if (p.BJ == 32) {
-    hipLaunchKernelGGL((wgrad_kernel<64, 32, 2, 1, 2, false>), dim3(grid), dim3(256), 0, stream, a);
+    fp_launch((wgrad_kernel<64, 32, 2, 1, 2, false>), dim3(grid), dim3(256), 0, stream, a);
   } else if (p.BI == 128) {
-    hipLaunchKernelGGL((wgrad_kernel<128, 64, 2, 2, 1, false>), dim3(grid), dim3(256), 0, stream, a);
+    fp_launch((wgrad_kernel<128, 64, 2, 2, 1, false>), dim3(grid), dim3(256), 0, stream, a);
   } else {
-    hipLaunchKernelGGL((wgrad_kernel<64, 64, 2, 2, 1, false>), dim3(grid), dim3(256), 0, stream, a);
+    fp_launch((wgrad_kernel<64, 64, 2, 2, 1, false>), dim3(grid), dim3(256), 0, stream, a);
   }
   int rc = fp_check_launch("fp_conv_wgrad");
   if (rc) return rc;

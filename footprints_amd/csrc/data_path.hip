@@ -203,13 +203,13 @@ extern "C" int fp_assemble_images(const uint8_t* images_hwc, const void* aug_par
   const int HW = H * W;
   int bx = (HW + 255) / 256;
   if (bx > 64) bx = 64;
-  hipLaunchKernelGGL(jitter_luma_sum_kernel, dim3(bx, B), dim3(256), 0, stream, images_hwc, (const AugParams*)aug_params, HW,
+  fp_launch(jitter_luma_sum_kernel, dim3(bx, B), dim3(256), 0, stream, images_hwc, (const AugParams*)aug_params, HW,
                      (unsigned long long*)luma_sums);
   int rc = fp_check_launch("fp_assemble_images(luma)");
   if (rc) return rc;
   int bx2 = (HW + 255) / 256;
   if (bx2 > 256) bx2 = 256;
-  hipLaunchKernelGGL(assemble_image_kernel, dim3(bx2, B), dim3(256), 0, stream, images_hwc, (const AugParams*)aug_params,
+  fp_launch(assemble_image_kernel, dim3(bx2, B), dim3(256), 0, stream, images_hwc, (const AugParams*)aug_params,
                      (const unsigned long long*)luma_sums, out_nchw, H, W);
   return fp_check_launch("fp_assemble_images");
 }
@@ -232,8 +232,8 @@ extern "C" int fp_assemble_labels(const void* visible_ground, const void* ground
   a.threshold = threshold; a.fxb = fxb; a.depth_scaling = depth_scaling;
   int bx = (H * W + 255) / 256;
   if (bx > 256) bx = 256;
-  if (is_double) hipLaunchKernelGGL(assemble_labels_kernel<double>, dim3(bx, B), dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL(assemble_labels_kernel<float>, dim3(bx, B), dim3(256), 0, stream, a);
+  if (is_double) fp_launch(assemble_labels_kernel<double>, dim3(bx, B), dim3(256), 0, stream, a);
+  else fp_launch(assemble_labels_kernel<float>, dim3(bx, B), dim3(256), 0, stream, a);
   return fp_check_launch("fp_assemble_labels");
 }
 

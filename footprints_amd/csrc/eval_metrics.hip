@@ -107,10 +107,10 @@ extern "C" int fp_eval_mask_counts(const void* pred, int32_t pred_is_half, const
                                    int32_t B, int64_t pixels, int64_t pred_stride, int64_t* counts, fp_stream_t stream) {
   FP_REQUIRE(pred && gt && counts && B > 0 && pixels > 0 && pred_stride >= pixels, "fp_eval_mask_counts: bad arguments");
   if (pred_is_half)
-    hipLaunchKernelGGL(eval_mask_kernel<true>, dim3(B), dim3(EVT), 0, (hipStream_t)stream, pred, gt, region, invert, (long long)pixels,
+    fp_launch(eval_mask_kernel<true>, dim3(B), dim3(EVT), 0, (hipStream_t)stream, pred, gt, region, invert, (long long)pixels,
                        (long long)pred_stride, (long long*)counts);
   else
-    hipLaunchKernelGGL(eval_mask_kernel<false>, dim3(B), dim3(EVT), 0, (hipStream_t)stream, pred, gt, region, invert, (long long)pixels,
+    fp_launch(eval_mask_kernel<false>, dim3(B), dim3(EVT), 0, (hipStream_t)stream, pred, gt, region, invert, (long long)pixels,
                        (long long)pred_stride, (long long*)counts);
   return fp_check_launch("fp_eval_mask_counts");
 }
@@ -123,10 +123,10 @@ extern "C" int fp_eval_depth_sums(const void* pred_disp, int32_t pred_is_half, c
   const double min_disp = 1.0 / max_depth, max_disp = 1.0 / min_depth;       // python floats in the reference
   const float md = (float)min_disp, dr = (float)(max_disp - min_disp);
   if (pred_is_half)
-    hipLaunchKernelGGL(eval_depth_kernel<true>, dim3(B), dim3(EVT), 0, (hipStream_t)stream, pred_disp, gt, (long long)pixels,
+    fp_launch(eval_depth_kernel<true>, dim3(B), dim3(EVT), 0, (hipStream_t)stream, pred_disp, gt, (long long)pixels,
                        (long long)pred_stride, md, dr, (float)clip_min, (float)clip_max, sums);
   else
-    hipLaunchKernelGGL(eval_depth_kernel<false>, dim3(B), dim3(EVT), 0, (hipStream_t)stream, pred_disp, gt, (long long)pixels,
+    fp_launch(eval_depth_kernel<false>, dim3(B), dim3(EVT), 0, (hipStream_t)stream, pred_disp, gt, (long long)pixels,
                        (long long)pred_stride, md, dr, (float)clip_min, (float)clip_max, sums);
   return fp_check_launch("fp_eval_depth_sums");
 }

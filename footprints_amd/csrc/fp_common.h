@@ -17,6 +17,31 @@ int fp_check_launch(const char* what);
 
 static inline int64_t fp_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// ---- every kernel launch of the library goes through fp_launch: it launches, and while a launch plan is recording (plan.cpp) it also
+// appends the launch -- kernel, geometry, stream and a private copy of the argument bytes -- to the plan
+#include <tuple>
+#include <utility>
+bool fp_plan_recording();
+void fp_plan_push_kernel(const void* func, dim3 grid, dim3 block, unsigned shmem, hipStream_t stream, void** args, const size_t* sizes, int nargs);
+
+template <typename... KArgs, size_t... I>
+inline void fp_launch_impl(void (*kernel)(KArgs...), dim3 grid, dim3 block, unsigned shmem, hipStream_t stream, std::tuple<KArgs...>& st,
+                           std::index_sequence<I...>) {
+  void* ptrs[sizeof...(KArgs) ? sizeof...(KArgs) : 1] = {(void*)&std::get<I>(st)...};
+  if (fp_plan_recording()) {
+    const size_t sizes[sizeof...(KArgs) ? sizeof...(KArgs) : 1] = {sizeof(KArgs)...};
+    fp_plan_push_kernel((const void*)kernel, grid, block, shmem, stream, ptrs, sizes, (int)sizeof...(KArgs));
+  }
+  (void)hipLaunchKernel((const void*)kernel, grid, block, ptrs, shmem, stream);
+}
+
+template <typename... KArgs, typename... Args>
+inline void fp_launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, unsigned shmem, hipStream_t stream, Args&&... args) {
+  static_assert(sizeof...(KArgs) == sizeof...(Args), "fp_launch: argument count differs from the kernel's parameter count");
+  std::tuple<KArgs...> st{static_cast<KArgs>(std::forward<Args>(args))...};       // the kernel's exact parameter types
+  fp_launch_impl(kernel, grid, block, shmem, stream, st, std::index_sequence_for<KArgs...>{});
+}
+
 // A/B switches of the library (read once per call site through a function-local static)
 #include <stdlib.h>
 static inline bool fp_env_flag(const char* name) {

@@ -481,7 +481,7 @@ extern "C" int fp_head_fwd(const float* x, const float* w_oihw, const float* bia
   FP_REQUIRE(x && w_oihw && bias && low, "fp_head_fwd: null pointer");
   FP_REQUIRE(head_cin_ok(Cin) && h >= 2 && w >= 2, "fp_head_fwd: Cin=%d must be a power of two in [4,128], dims >= 2", Cin);
   const HeadGrid g = head_grid(N, h, w, Cin, 16);
-  hipLaunchKernelGGL(head_fwd_kernel, dim3(g.colblocks, N * g.gpi), dim3(256), 0, (hipStream_t)stream, x, w_oihw, bias, low, h, w, Cin,
+  fp_launch(head_fwd_kernel, dim3(g.colblocks, N * g.gpi), dim3(256), 0, (hipStream_t)stream, x, w_oihw, bias, low, h, w, Cin,
                      g.rows, g.gpi, apply_sigmoid);
   return fp_check_launch("fp_head_fwd");
 }
@@ -492,7 +492,7 @@ extern "C" int fp_head_upsample(const float* low, float* out_nchw, int32_t N, in
   const int64_t total = (int64_t)N * h * scale * w * scale;
   int grid = (int)fp_ceil_div(total, 256);
   if (grid > 16384) grid = 16384;
-  hipLaunchKernelGGL(head_upsample_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, low, out_nchw, N, h, w, scale,
+  fp_launch(head_upsample_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, low, out_nchw, N, h, w, scale,
                      out_channels, c0);
   return fp_check_launch("fp_head_upsample");
 }
@@ -504,18 +504,18 @@ extern "C" int fp_head_upsample_bwd(const float* dout_nchw, const float* low, fl
   const int64_t total = (int64_t)N * h * w;
   const hipStream_t st = (hipStream_t)stream;
   if (scale == 2) {
-    hipLaunchKernelGGL(head_upsample_bwd_even_kernel<2>, dim3((int)fp_ceil_div(total, 256)), dim3(256), 0, st, dout_nchw, low, dzlow, N, h,
+    fp_launch(head_upsample_bwd_even_kernel<2>, dim3((int)fp_ceil_div(total, 256)), dim3(256), 0, st, dout_nchw, low, dzlow, N, h,
                        w, out_channels, c0, apply_sigmoid);
   } else if (scale == 4) {
-    hipLaunchKernelGGL(head_upsample_bwd_even_kernel<4>, dim3((int)fp_ceil_div(total * 4, 256)), dim3(256), 0, st, dout_nchw, low, dzlow,
+    fp_launch(head_upsample_bwd_even_kernel<4>, dim3((int)fp_ceil_div(total * 4, 256)), dim3(256), 0, st, dout_nchw, low, dzlow,
                        N, h, w, out_channels, c0, apply_sigmoid);
   } else if (scale == 8) {
-    hipLaunchKernelGGL(head_upsample_bwd_even_kernel<8>, dim3((int)fp_ceil_div(total * 4, 256)), dim3(256), 0, st, dout_nchw, low, dzlow,
+    fp_launch(head_upsample_bwd_even_kernel<8>, dim3((int)fp_ceil_div(total * 4, 256)), dim3(256), 0, st, dout_nchw, low, dzlow,
                        N, h, w, out_channels, c0, apply_sigmoid);
   } else {
     int grid = (int)fp_ceil_div(total, 256);
     if (grid > 16384) grid = 16384;
-    hipLaunchKernelGGL(head_upsample_bwd_kernel, dim3(grid), dim3(256), 0, st, dout_nchw, low, dzlow, N, h, w, scale, out_channels, c0,
+    fp_launch(head_upsample_bwd_kernel, dim3(grid), dim3(256), 0, st, dout_nchw, low, dzlow, N, h, w, scale, out_channels, c0,
                        apply_sigmoid);
   }
   return fp_check_launch("fp_head_upsample_bwd");
@@ -526,7 +526,7 @@ extern "C" int fp_head_dgrad(const float* dzlow, const float* w_oihw, const floa
   FP_REQUIRE(dzlow && w_oihw && dx, "fp_head_dgrad: null pointer");
   FP_REQUIRE(head_cin_ok(Cin) && h >= 2 && w >= 2, "fp_head_dgrad: unsupported Cin=%d", Cin);
   const HeadGrid g = head_grid(N, h, w, Cin, 16);
-  hipLaunchKernelGGL(head_dgrad_kernel, dim3(g.colblocks, N * g.gpi), dim3(256), 0, (hipStream_t)stream, dzlow, w_oihw, elu_src, dx, h, w,
+  fp_launch(head_dgrad_kernel, dim3(g.colblocks, N * g.gpi), dim3(256), 0, (hipStream_t)stream, dzlow, w_oihw, elu_src, dx, h, w,
                      Cin, g.rows, g.gpi);
   return fp_check_launch("fp_head_dgrad");
 }
@@ -541,11 +541,11 @@ extern "C" int fp_head_wgrad(const float* x, const float* dzlow, float* dw_oihw,
   FP_REQUIRE(head_cin_ok(Cin) && h >= 2 && w >= 2, "fp_head_wgrad: unsupported Cin=%d", Cin);
   FP_REQUIRE(workspace_bytes >= fp_head_wgrad_workspace(N, h, w, Cin), "fp_head_wgrad: workspace too small");
   const int nblk = head_wgrad_blocks((int64_t)N * h * w, Cin);
-  hipLaunchKernelGGL(head_wgrad_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, dzlow, (float*)workspace, N, h, w, Cin);
+  fp_launch(head_wgrad_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, dzlow, (float*)workspace, N, h, w, Cin);
   int rc = fp_check_launch("fp_head_wgrad");
   if (rc) return rc;
   const int per = 9 * Cin * 2 + 2;
-  hipLaunchKernelGGL(head_wgrad_reduce_kernel, dim3((int)fp_ceil_div(per, 4)), dim3(256), 0, (hipStream_t)stream,
+  fp_launch(head_wgrad_reduce_kernel, dim3((int)fp_ceil_div(per, 4)), dim3(256), 0, (hipStream_t)stream,
                      (const float*)workspace, dw_oihw, db, nblk, Cin, accumulate);
   return fp_check_launch("fp_head_wgrad(reduce)");
 }

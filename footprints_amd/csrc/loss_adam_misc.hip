@@ -282,8 +282,8 @@ extern "C" int fp_loss_fwd_bwd(const float* const preds[4], const float* visible
   a.B = B; a.HW = H * W;
   a.part = (float*)workspace;
   const int nblk = loss_blocks(npix);
-  hipLaunchKernelGGL(loss_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, a);
-  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const float*)workspace, nblk, 1.0 / (double)npix,
+  fp_launch(loss_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, a);
+  fp_launch(loss_final_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const float*)workspace, nblk, 1.0 / (double)npix,
                      losses_out);
   return fp_check_launch("fp_loss_fwd_bwd");
 }
@@ -297,7 +297,7 @@ extern "C" int fp_adam_step(float* param, const float* grad, float* exp_avg, flo
   const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
   const float step_size = (float)(lr / bc1);
   const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
-  hipLaunchKernelGGL(adam_kernel, dim3(ew_grid((size_t)n / 4 + 1, 4096)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
+  fp_launch(adam_kernel, dim3(ew_grid((size_t)n / 4 + 1, 4096)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
                      exp_avg_sq, (size_t)n, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), step_size, inv_bc2_sqrt, (float)eps,
                      (float)grad_scale);
   return fp_check_launch("fp_adam_step");
@@ -342,7 +342,7 @@ extern "C" int fp_adam_step_dev(float* param, const float* grad, float* exp_avg,
                                 fp_stream_t stream) {
   FP_REQUIRE(param && grad && exp_avg && exp_avg_sq && hyper7_dev && n > 0 && n % 4 == 0, "fp_adam_step_dev: bad arguments");
   FP_REQUIRE(((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) % 16 == 0, "fp_adam_step_dev: buffers must be 16-byte aligned");
-  hipLaunchKernelGGL(adam_dev_kernel, dim3(ew_grid((size_t)n / 4 + 1, 4096)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
+  fp_launch(adam_dev_kernel, dim3(ew_grid((size_t)n / 4 + 1, 4096)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
                      exp_avg_sq, (size_t)n, hyper7_dev);
   return fp_check_launch("fp_adam_step_dev");
 }
@@ -355,7 +355,7 @@ __global__ void __launch_bounds__(256) scale_rows_kernel(const float* __restrict
 
 extern "C" int fp_scale_rows(const float* w, const float* scale, float* out, int64_t rows, int64_t inner, fp_stream_t stream) {
   FP_REQUIRE(w && scale && out && rows > 0 && inner > 0 && inner < ((int64_t)1 << 31), "fp_scale_rows: bad arguments");
-  hipLaunchKernelGGL(scale_rows_kernel, dim3(ew_grid((size_t)rows * inner)), dim3(256), 0, (hipStream_t)stream, w, scale, out,
+  fp_launch(scale_rows_kernel, dim3(ew_grid((size_t)rows * inner)), dim3(256), 0, (hipStream_t)stream, w, scale, out,
                      (size_t)rows * inner, (int)inner);
   return fp_check_launch("fp_scale_rows");
 }
@@ -375,7 +375,7 @@ __global__ void __launch_bounds__(256) pack_pred_fp16_kernel(const float* __rest
 extern "C" int fp_pack_pred_fp16(const float* pred_nchw, void* out_half, int32_t B, int32_t H, int32_t W, fp_stream_t stream) {
   FP_REQUIRE(pred_nchw && out_half && B > 0 && H > 0 && W > 0, "fp_pack_pred_fp16: bad arguments");
   const size_t plane = (size_t)H * W, total = plane * 4 * B;
-  hipLaunchKernelGGL(pack_pred_fp16_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, pred_nchw, (__half*)out_half, plane,
+  fp_launch(pack_pred_fp16_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, pred_nchw, (__half*)out_half, plane,
                      total);
   return fp_check_launch("fp_pack_pred_fp16");
 }
@@ -391,8 +391,8 @@ extern "C" int fp_colsum(const float* x, int64_t M, int32_t C, float* out, int a
   FP_REQUIRE(C >= 4 && C % 4 == 0 && C <= 1024 && M > 0 && M < ((int64_t)1 << 31), "fp_colsum: unsupported C=%d", C);
   FP_REQUIRE(workspace_bytes >= fp_colsum_workspace(M, C), "fp_colsum: workspace too small");
   const int nblk = colsum_blocks(M, C);
-  hipLaunchKernelGGL(colsum_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, (int)M, C, (float*)workspace);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, nblk, C,
+  fp_launch(colsum_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, (int)M, C, (float*)workspace);
+  fp_launch(colsum_final_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, nblk, C,
                      out, accumulate);
   return fp_check_launch("fp_colsum");
 }
@@ -402,24 +402,24 @@ extern "C" int fp_up2cat_bwd(const float* dxv, int32_t N, int32_t h, int32_t w, 
   FP_REQUIRE(dxv && dlow && C0 > 0 && C0 % 4 == 0 && C1 % 4 == 0 && (C1 == 0 || dskip), "fp_up2cat_bwd: bad arguments");
   const size_t nlow = (size_t)N * h * w * (C0 / 4), nskip = (size_t)N * 4 * h * w * (C1 / 4);
   const size_t total = nlow > nskip ? nlow : nskip;
-  hipLaunchKernelGGL(up2cat_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dxv, N, h, w, C0, C1, addend,
+  fp_launch(up2cat_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dxv, N, h, w, C0, C1, addend,
                      ylow_elu, dlow, dskip, accumulate_skip);
   return fp_check_launch("fp_up2cat_bwd");
 }
 
 extern "C" int fp_nchw_to_nhwc(const float* x, float* y, int32_t N, int32_t C, int32_t H, int32_t W, fp_stream_t stream) {
   FP_REQUIRE(x && y, "fp_nchw_to_nhwc: null pointer");
-  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(ew_grid((size_t)N * C * H * W)), dim3(256), 0, (hipStream_t)stream, x, y, N, C, H, W);
+  fp_launch(nchw_to_nhwc_kernel, dim3(ew_grid((size_t)N * C * H * W)), dim3(256), 0, (hipStream_t)stream, x, y, N, C, H, W);
   return fp_check_launch("fp_nchw_to_nhwc");
 }
 extern "C" int fp_nhwc_to_nchw(const float* x, float* y, int32_t N, int32_t C, int32_t H, int32_t W, fp_stream_t stream) {
   FP_REQUIRE(x && y, "fp_nhwc_to_nchw: null pointer");
-  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(ew_grid((size_t)N * C * H * W)), dim3(256), 0, (hipStream_t)stream, x, y, N, C, H, W);
+  fp_launch(nhwc_to_nchw_kernel, dim3(ew_grid((size_t)N * C * H * W)), dim3(256), 0, (hipStream_t)stream, x, y, N, C, H, W);
   return fp_check_launch("fp_nhwc_to_nchw");
 }
 extern "C" int fp_fill(float* x, int64_t n, float value, fp_stream_t stream) {
   FP_REQUIRE(x && n >= 0, "fp_fill: bad arguments");
   if (n == 0) return FP_OK;
-  hipLaunchKernelGGL(fill_kernel, dim3(ew_grid((size_t)n)), dim3(256), 0, (hipStream_t)stream, x, (size_t)n, value);
+  fp_launch(fill_kernel, dim3(ew_grid((size_t)n)), dim3(256), 0, (hipStream_t)stream, x, (size_t)n, value);
   return fp_check_launch("fp_fill");
 }

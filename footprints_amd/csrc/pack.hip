@@ -155,7 +155,7 @@ int launch_one(int kind, const float* w, float* wp, int Cout, int Cin, int KH, i
   size_t g = (total + 255) / 256;
   if (g > 4096) g = 4096;
   if (g < 1) g = 1;
-  hipLaunchKernelGGL(pack_one_kernel, dim3((unsigned)g), dim3(256), 0, stream, j, total);
+  fp_launch(pack_one_kernel, dim3((unsigned)g), dim3(256), 0, stream, j, total);
   return fp_check_launch(what);
 }
 
@@ -231,6 +231,6 @@ extern "C" int32_t fp_pack_job_blocks(int32_t kind, int32_t Cout, int32_t KH, in
 
 extern "C" int fp_pack_weights_batched(const fp_pack_job* jobs_dev, const int32_t* blk2job_dev, int32_t nblocks, fp_stream_t stream) {
   FP_REQUIRE(jobs_dev && blk2job_dev && nblocks > 0, "fp_pack_weights_batched: bad arguments");
-  hipLaunchKernelGGL(pack_batched_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, jobs_dev, blk2job_dev);
+  fp_launch(pack_batched_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, jobs_dev, blk2job_dev);
   return fp_check_launch("fp_pack_weights_batched");
 }

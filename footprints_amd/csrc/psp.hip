@@ -158,14 +158,14 @@ int grid_for(int64_t total) {
 
 extern "C" int fp_adaptive_avgpool_fwd(const float* x, float* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t P, fp_stream_t stream_) {
   FP_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && P > 0 && C > 0 && C % 4 == 0, "fp_adaptive_avgpool_fwd: bad arguments (C must be a multiple of 4)");
-  hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(grid_for((int64_t)N * P * P * (C / 4))), dim3(256), 0, (hipStream_t)stream_, x, y, N, H, W, C, P);
+  fp_launch(avgpool_fwd_kernel, dim3(grid_for((int64_t)N * P * P * (C / 4))), dim3(256), 0, (hipStream_t)stream_, x, y, N, H, W, C, P);
   return fp_check_launch("fp_adaptive_avgpool_fwd");
 }
 
 extern "C" int fp_adaptive_avgpool_bwd(const float* dy, float* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t P, int accumulate,
                                        fp_stream_t stream_) {
   FP_REQUIRE(dy && dx && N > 0 && H > 0 && W > 0 && P > 0 && C > 0 && C % 4 == 0, "fp_adaptive_avgpool_bwd: bad arguments (C must be a multiple of 4)");
-  hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(grid_for((int64_t)N * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream_, dy, dx, N, H, W, C, P,
+  fp_launch(avgpool_bwd_kernel, dim3(grid_for((int64_t)N * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream_, dy, dx, N, H, W, C, P,
                      accumulate);
   return fp_check_launch("fp_adaptive_avgpool_bwd");
 }
@@ -174,7 +174,7 @@ extern "C" int fp_bilinear_ac_fwd(const float* src, float* dst, int32_t N, int32
                                   fp_stream_t stream_) {
   FP_REQUIRE(src && dst && N > 0 && P > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && dstC % 4 == 0 && c_off % 4 == 0 && c_off + C <= dstC,
              "fp_bilinear_ac_fwd: bad arguments");
-  hipLaunchKernelGGL(bilinear_ac_fwd_kernel, dim3(grid_for((int64_t)N * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream_, src, dst, N, P, C, H, W,
+  fp_launch(bilinear_ac_fwd_kernel, dim3(grid_for((int64_t)N * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream_, src, dst, N, P, C, H, W,
                      dstC, c_off);
   return fp_check_launch("fp_bilinear_ac_fwd");
 }
@@ -183,7 +183,7 @@ extern "C" int fp_bilinear_ac_bwd(const float* ddst, float* dsrc, int32_t N, int
                                   fp_stream_t stream_) {
   FP_REQUIRE(ddst && dsrc && N > 0 && P > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && dstC % 4 == 0 && c_off % 4 == 0 && c_off + C <= dstC,
              "fp_bilinear_ac_bwd: bad arguments");
-  hipLaunchKernelGGL(bilinear_ac_bwd_kernel, dim3(grid_for((int64_t)N * P * P * (C / 4))), dim3(256), 0, (hipStream_t)stream_, ddst, dsrc, N, P, C, H, W,
+  fp_launch(bilinear_ac_bwd_kernel, dim3(grid_for((int64_t)N * P * P * (C / 4))), dim3(256), 0, (hipStream_t)stream_, ddst, dsrc, N, P, C, H, W,
                      dstC, c_off);
   return fp_check_launch("fp_bilinear_ac_bwd");
 }
@@ -193,7 +193,7 @@ extern "C" int fp_copy_channels(const float* src, float* dst, int64_t M, int32_t
   FP_REQUIRE(src && dst && M > 0 && C > 0 && C % 4 == 0 && srcC % 4 == 0 && dstC % 4 == 0 && src_off % 4 == 0 && dst_off % 4 == 0 &&
                  src_off + C <= srcC && dst_off + C <= dstC,
              "fp_copy_channels: bad arguments");
-  hipLaunchKernelGGL(copy_channels_kernel, dim3(grid_for(M * (C / 4))), dim3(256), 0, (hipStream_t)stream_, src, dst, M, C, srcC, src_off, dstC, dst_off,
+  fp_launch(copy_channels_kernel, dim3(grid_for(M * (C / 4))), dim3(256), 0, (hipStream_t)stream_, src, dst, M, C, srcC, src_off, dstC, dst_off,
                      accumulate);
   return fp_check_launch("fp_copy_channels");
 }

@@ -100,6 +100,6 @@ int fp_stem_tile_dispatch(const fp_conv_desc* d, const float* img, const float* 
   a.img = img; a.w = wpacked; a.bias = (d->epi & FP_EPI_BIAS) ? bias : nullptr; a.y = y;
   a.N = d->N; a.IH = d->IH; a.IW = d->IW; a.OH = d->OH; a.OW = d->OW; a.act = d->act;
   a.tilesX = (int)fp_ceil_div(d->OW, TW); a.tilesY = (int)fp_ceil_div(d->OH, TH);
-  hipLaunchKernelGGL(stem_tile_kernel, dim3(d->N * a.tilesX * a.tilesY), dim3(256), 0, stream, a);
+  fp_launch(stem_tile_kernel, dim3(d->N * a.tilesX * a.tilesY), dim3(256), 0, stream, a);
   return fp_check_launch("fp_conv_igemm(stem)");
 }

@@ -783,11 +783,11 @@ extern "C" int fp_conv_wgrad_bf3(const fp_conv_desc* d, const float* x, const fl
     if (nwg <= 8192) a.stamps = stamp_buf;
   }
   static const int ver = getenv("FP_WGRAD_BF3_V") ? atoi(getenv("FP_WGRAD_BF3_V")) : 3;       // A/B switch: kernel generation
-  if (ver == 1) hipLaunchKernelGGL(wgrad3x3_bf3_kernel, dim3(nwg), dim3(256), 0, stream, a);
-  else if (ver == 2) hipLaunchKernelGGL(wgrad3x3_bf3_v2_kernel, dim3(nwg), dim3(256), 0, stream, a);
-  else if (a.mode == 0) hipLaunchKernelGGL(wgrad3x3_bf3_v3_kernel<0>, dim3(nwg), dim3(256), 0, stream, a);
-  else if (a.mode == 1) hipLaunchKernelGGL(wgrad3x3_bf3_v3_kernel<1>, dim3(nwg), dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL(wgrad3x3_bf3_v3_kernel<2>, dim3(nwg), dim3(256), 0, stream, a);
+  if (ver == 1) fp_launch(wgrad3x3_bf3_kernel, dim3(nwg), dim3(256), 0, stream, a);
+  else if (ver == 2) fp_launch(wgrad3x3_bf3_v2_kernel, dim3(nwg), dim3(256), 0, stream, a);
+  else if (a.mode == 0) fp_launch(wgrad3x3_bf3_v3_kernel<0>, dim3(nwg), dim3(256), 0, stream, a);
+  else if (a.mode == 1) fp_launch(wgrad3x3_bf3_v3_kernel<1>, dim3(nwg), dim3(256), 0, stream, a);
+  else fp_launch(wgrad3x3_bf3_v3_kernel<2>, dim3(nwg), dim3(256), 0, stream, a);
   int rc = fp_check_launch("fp_conv_wgrad_bf3");
   if (rc) return rc;
   if (a.stamps) {                                   // debugging only: synchronous dump of the last launch's stamps
@@ -804,7 +804,7 @@ extern "C" int fp_conv_wgrad_bf3(const fp_conv_desc* d, const float* x, const fl
   static const bool split_reduce = fp_env_flag("FP_WGRAD_SPLIT_REDUCE");     // A/B switch: the two former reduce launches
   if (split_reduce) {
     if (db) {
-      hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3((d->Nout + 255) / 256), dim3(256), 0, stream, (const float*)a.bpart, p.S, d->Nout, db,
+      fp_launch(wgrad_bias_reduce_kernel, dim3((d->Nout + 255) / 256), dim3(256), 0, stream, (const float*)a.bpart, p.S, d->Nout, db,
                          accumulate);
       rc = fp_check_launch("fp_conv_wgrad_bf3(bias)");
       if (rc) return rc;
@@ -815,7 +815,7 @@ extern "C" int fp_conv_wgrad_bf3(const fp_conv_desc* d, const float* x, const fl
   int main_blocks = (int)fp_ceil_div(total, 256);
   if (main_blocks > 4096) main_blocks = 4096;
   const int bias_blocks = db ? (d->Nout + 255) / 256 : 0;
-  hipLaunchKernelGGL(wgrad_reduce_bias_kernel, dim3(main_blocks + bias_blocks), dim3(256), 0, stream, (const float*)workspace, dw_oihw, p.S,
+  fp_launch(wgrad_reduce_bias_kernel, dim3(main_blocks + bias_blocks), dim3(256), 0, stream, (const float*)workspace, dw_oihw, p.S,
                      d->C0, d->Nout, accumulate, kc_total, k_begin, main_blocks, (const float*)a.bpart, db);
   return fp_check_launch("fp_conv_wgrad_bf3(reduce)");
 }

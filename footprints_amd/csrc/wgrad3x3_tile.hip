@@ -202,7 +202,7 @@ int fp_wgrad3x3_tile_dispatch(const fp_conv_desc* d, const float* src0, const fl
   a.mode = d->gather == FP_GATHER_FWD_ZERO ? 0 : (d->gather == FP_GATHER_FWD_REFLECT ? 1 : 2);
   a.chunksY = p.cy; a.chunksX = p.cx; a.nchunks = p.nchunks; a.chunksPerSplit = p.chunksPerSplit; a.S = p.S;
   a.citiles = p.citiles; a.cotiles = p.cotiles;
-  hipLaunchKernelGGL(wgrad3x3_tile_kernel, dim3(p.S * p.citiles * p.cotiles), dim3(256), 0, stream, a);
+  fp_launch(wgrad3x3_tile_kernel, dim3(p.S * p.citiles * p.cotiles), dim3(256), 0, stream, a);
   int rc = fp_check_launch("fp_conv_wgrad(tile)");
   if (rc) return rc;
   return fp_wgrad_reduce_launch((const float*)workspace, dw_oihw, p.S, 9, a.Kc, d->Nout, 0, accumulate, kc_total, k_begin, stream);

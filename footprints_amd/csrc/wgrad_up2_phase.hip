@@ -382,25 +382,25 @@ static int phase_wgrad_launch(bool bf3, const float* low, const float* dz, float
   a.N = N; a.h = h; a.w = w; a.C0 = C0; a.Nout = Nout;
   a.chunksY = p.cy; a.chunksX = p.cx; a.nchunks = p.nchunks; a.chunksPerSplit = p.chunksPerSplit; a.S = p.S;
   a.citiles = p.citiles; a.cotiles = p.cotiles;
-  if (bf3) hipLaunchKernelGGL(wgrad_up2_phase_bf3_kernel, dim3(p.S * p.citiles * p.cotiles), dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL(wgrad_up2_phase_kernel, dim3(p.S * p.citiles * p.cotiles), dim3(256), 0, stream, a);
+  if (bf3) fp_launch(wgrad_up2_phase_bf3_kernel, dim3(p.S * p.citiles * p.cotiles), dim3(256), 0, stream, a);
+  else fp_launch(wgrad_up2_phase_kernel, dim3(p.S * p.citiles * p.cotiles), dim3(256), 0, stream, a);
   int rc = fp_check_launch("fp_conv_up2_phase_wgrad");
   if (rc) return rc;
   if (db) {
-    hipLaunchKernelGGL(up2_wgrad_bias_reduce_kernel, dim3((Nout + 255) / 256), dim3(256), 0, stream, (const float*)a.bpart, p.S, Nout, db,
+    fp_launch(up2_wgrad_bias_reduce_kernel, dim3((Nout + 255) / 256), dim3(256), 0, stream, (const float*)a.bpart, p.S, Nout, db,
                        accumulate);
     rc = fp_check_launch("fp_conv_up2_phase_wgrad(bias)");
     if (rc) return rc;
   }
   const size_t tot16 = (size_t)16 * C0 * Nout;
   if (p.S > 1) {
-    hipLaunchKernelGGL(up2_wgrad_sum_kernel, dim3((unsigned)fp_ceil_div((int64_t)tot16, 64)), dim3(256), 0, stream, (float*)workspace, p.S, tot16);
+    fp_launch(up2_wgrad_sum_kernel, dim3((unsigned)fp_ceil_div((int64_t)tot16, 64)), dim3(256), 0, stream, (float*)workspace, p.S, tot16);
     rc = fp_check_launch("fp_conv_up2_phase_wgrad(sum)");
     if (rc) return rc;
   }
   int rgrid = (int)fp_ceil_div((int64_t)9 * C0 * Nout, 256);
   if (rgrid > 4096) rgrid = 4096;
-  hipLaunchKernelGGL(up2_wgrad_uncollapse_kernel, dim3(rgrid), dim3(256), 0, stream, (const float*)workspace, dw_oihw, C0, Nout, kc_total,
+  fp_launch(up2_wgrad_uncollapse_kernel, dim3(rgrid), dim3(256), 0, stream, (const float*)workspace, dw_oihw, C0, Nout, kc_total,
                      k_begin, accumulate);
   return fp_check_launch("fp_conv_up2_phase_wgrad(uncollapse)");
 }

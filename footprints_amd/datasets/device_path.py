@@ -181,3 +181,26 @@ class DeviceLoader:
             pending = nxt
         yield self.asm.collect(pending)
         self.asm.release(pending)
+
+
+class SyntheticSampleSource:
+    """`steps` batches of host samples with the shapes / dtypes the file readers deliver (stand-in for the KITTI reader, which is out
+    of scope): a small pool of random samples, cycled."""
+
+    def __init__(self, batch_size, height, width, steps, seed=10, pool=24):
+        rng = np.random.default_rng(seed)
+        self.B, self.steps = batch_size, steps
+        self.pool = []
+        for _ in range(pool):
+            maps = {"visible_ground": rng.random((height, width)), "ground_depth": rng.random((height, width)) * 30 * (rng.random((height, width)) < 0.5),
+                    "depth_mask": (rng.random((height, width)) < 0.1).astype(np.float64), "disparity": rng.random((height, width)) * 60,
+                    "moving_objects": (rng.random((height, width)) < 0.05).astype(np.float64)}
+            self.pool.append((rng.integers(0, 256, (height, width, 3), dtype=np.uint8), maps))
+        self.dataset = range(steps * batch_size)
+
+    def __len__(self):
+        return self.steps
+
+    def __iter__(self):
+        for i in range(self.steps):
+            yield [self.pool[(i * self.B + j) % len(self.pool)] for j in range(self.B)]

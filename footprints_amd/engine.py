@@ -321,7 +321,7 @@ class Engine:
         ops.pack_weights_batched(self._pack_table[0])
         cur = ops.current_stream()
         if self.concurrent and overlap:
-            self.wg.wait_event(self._record(cur))
+            ops.event_wait(self.wg, self._record(cur))
             with ops.on_stream(self.wg):
                 ops.pack_weights_batched(self._pack_table[1])
                 self._pack_ev = self._record(self.wg)
@@ -355,9 +355,8 @@ class Engine:
     # ------------------------------------------------------------------------------------------------
     @staticmethod
     def _record(stream):
-        ev = torch.cuda.Event()
-        ev.record(stream)
-        return ev
+        """event id on `stream` (library events, not framework events: a recording launch plan has to see every ordering edge)"""
+        return ops.event_record(stream)
 
     def _bn_coeffs(self, rec, z, training):
         bn = rec.bn
@@ -479,7 +478,7 @@ class Engine:
     def _wait_pack(self):
         """the side-stream part of the weight repack (everything after layer1) must have landed"""
         if self._pack_ev is not None:
-            ops.current_stream().wait_event(self._pack_ev)
+            ops.event_wait(ops.current_stream(), self._pack_ev)
             self._pack_ev = None
 
     def _conv_enc(self, c, x, N, H, W, out):
@@ -588,10 +587,10 @@ class Engine:
         S["dec"] = [{} for _ in self.decoders]
         main = ops.current_stream()
         if self.concurrent and len(self.decoders) == 2:
-            self.aux.wait_event(self._record(main))                 # encoder features ready
+            ops.event_wait(self.aux, self._record(main))                 # encoder features ready
             self._interleave([(self.aux, self._decoder_forward(self.decoders[1], S, outputs, S["dec"][1])),
                               (main, self._decoder_forward(self.decoders[0], S, outputs, S["dec"][0]))])
-            main.wait_stream(self.aux)                              # join: both decoders wrote their output channels
+            ops.stream_wait_stream(main, self.aux)                              # join: both decoders wrote their output channels
         else:
             for di, dec in enumerate(self.decoders):
                 for _ in self._decoder_forward(dec, S, outputs, S["dec"][di]):
@@ -686,7 +685,7 @@ class Engine:
                 ops.colsum(dz.view(-1, c.Cout), c.gb, accumulate=acc)
         if side is None:
             return launch()
-        side.wait_event(self._record(ops.current_stream()))
+        ops.event_wait(side, self._record(ops.current_stream()))
         with ops.on_stream(side):
             launch()
 
@@ -706,7 +705,7 @@ class Engine:
                     ops.conv_wgrad_bf3(d_sk, skip, dz, c.gw, C0, accumulate=acc)
             if side is None:
                 return launch_small()
-            side.wait_event(self._record(ops.current_stream()))
+            ops.event_wait(side, self._record(ops.current_stream()))
             with ops.on_stream(side):
                 return launch_small()
 
@@ -725,7 +724,7 @@ class Engine:
                 ops.colsum(dz.view(-1, c.Cout), c.gb, accumulate=acc)
         if side is None:
             return launch()
-        side.wait_event(self._record(ops.current_stream()))
+        ops.event_wait(side, self._record(ops.current_stream()))
         with ops.on_stream(side):
             launch()
 
@@ -820,7 +819,7 @@ class Engine:
                 self.debug_hook(i, dict(dout=dout, g=g, dz2=dz2, da1=da1, dz1=dz1, dnext=dnext, B=B))
             if first_of_layer and on_stage is not None:
                 if side is not None:
-                    main.wait_stream(side)        # this layer's weight gradients live on the side stream
+                    ops.stream_wait_stream(main, side)        # this layer's weight gradients live on the side stream
                 on_stage("encoder.layer%d" % (feat_of_block[min(k for k in feat_of_block if k >= i)]))
         # ---- stem ---------------------------------------------------------------------------------------
         h0, w0 = dims[0]
@@ -832,9 +831,9 @@ class Engine:
         d = ops.make_desc(N, h0, w0, S["H"], S["W"], 3, 0, 64, 7, 2, 3, L.GATHER_STEM)
         ops.conv_wgrad(d, S["image"], None, dz0, self.stem.gw, accumulate=accumulate)
         if side is not None:
-            main.wait_stream(side)                # join: every weight gradient is complete
-            main.wait_stream(self.dwg[0])
-            main.wait_stream(self.dwg[1])
+            ops.stream_wait_stream(main, side)                # join: every weight gradient is complete
+            ops.stream_wait_stream(main, self.dwg[0])
+            ops.stream_wait_stream(main, self.dwg[1])
         if on_stage is not None:
             on_stage("encoder.layer0")
 
@@ -845,13 +844,13 @@ class Engine:
             # mask decoder on the main stream, depth decoder on the aux stream; the depth decoder ACCUMULATES into the
             # feature gradients, so each of its accumulate launches waits for the mask decoder's write of that level
             self._ev_dF = [None] * 5
-            self.aux.wait_event(self._record(main))
+            ops.event_wait(self.aux, self._record(main))
             self._interleave([(main, self._decoder_backward(self.decoders[0], S["dec"][0], S, gouts, dF, first=True, acc=accumulate)),
                               (self.aux, self._decoder_backward(self.decoders[1], S["dec"][1], S, gouts, dF, first=False, acc=accumulate))])
-            main.wait_stream(self.aux)
+            ops.stream_wait_stream(main, self.aux)
             if on_stage is not None or join:         # data-parallel: the decoder stages are reduced now => join their weight gradients
-                main.wait_stream(self.dwg[0])
-                main.wait_stream(self.dwg[1])
+                ops.stream_wait_stream(main, self.dwg[0])
+                ops.stream_wait_stream(main, self.dwg[1])
             if on_stage is not None:
                 on_stage(self.decoders[0].name)
                 on_stage(self.decoders[1].name)
@@ -860,7 +859,7 @@ class Engine:
                 for _ in self._decoder_backward(dec, S["dec"][di], S, gouts, dF, first=(di == 0), acc=accumulate):
                     pass
                 if self.concurrent and (on_stage is not None or join):
-                    main.wait_stream(self.dwg[0 if di == 0 else 1])
+                    ops.stream_wait_stream(main, self.dwg[0 if di == 0 else 1])
                 if on_stage is not None:
                     on_stage(dec.name)
 
@@ -911,7 +910,7 @@ class Engine:
             if first:
                 self._ev_dF[k] = self._record(cur)
             elif self._ev_dF[k] is not None:
-                cur.wait_event(self._ev_dF[k])
+                ops.event_wait(cur, self._ev_dF[k])
         # ---- full-resolution tail: head4 <- o42 <- o41 <- up2(x4) ------------------------------------
         x4 = D["x"][3]
         h0, w0 = dims[0]

@@ -15,7 +15,14 @@ def main(argv=None):
         if opt.synthetic_steps <= 0:
             raise SystemExit("no dataset readers in this build: pass --synthetic_steps N, or construct TrainManager(options, "
                              "train_loader=..., val_loader=...) with your own loaders")
-        train = SyntheticLoader(opt.batch_size, opt.height, opt.width, opt.synthetic_steps)
+        if opt.device_augment and opt.training_dataset == "kitti":
+            # row N3: host samples as the file readers deliver them -> pinned double-buffered H2D -> flip / jitter / label kernels
+            from .datasets import DeviceBatchAssembler, DeviceLoader, SyntheticSampleSource
+            asm = DeviceBatchAssembler(opt.batch_size, opt.height, opt.width, dataset="kitti", no_depth_mask=opt.no_depth_mask,
+                                       project_down_baseline=opt.project_down_baseline, moving_objects_method=opt.moving_objects_method)
+            train = DeviceLoader(SyntheticSampleSource(opt.batch_size, opt.height, opt.width, opt.synthetic_steps), asm, is_train=True)
+        else:
+            train = SyntheticLoader(opt.batch_size, opt.height, opt.width, opt.synthetic_steps)
         val = SyntheticLoader(opt.batch_size, opt.height, opt.width, max(1, opt.val_batches), seed=11)
         TrainManager(opt, train_loader=train, val_loader=val).train()
     elif opt.mode == "inference":

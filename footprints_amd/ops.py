@@ -62,6 +62,24 @@ def current_stream():
     return _cur_stream[0] if _cur_stream is not None else torch.cuda.current_stream()
 
 
+def event_record(stream_obj=None):
+    """record a library event on `stream_obj` (default: the current launch stream) -> event id for event_wait"""
+    h = stream_obj.cuda_stream if stream_obj is not None else stream()
+    ev = _lib.load().fp_event_record(h)
+    if ev < 0:
+        raise RuntimeError("fp_event_record: %s" % _lib.load().fp_last_error_string().decode())
+    return ev
+
+
+def event_wait(stream_obj, ev):
+    _lib.check(_lib.load().fp_event_wait(stream_obj.cuda_stream, ev), "fp_event_wait")
+
+
+def stream_wait_stream(consumer, producer):
+    """everything queued on `producer` so far happens before whatever is queued on `consumer` from now on"""
+    event_wait(consumer, event_record(producer))
+
+
 _query_cache = {}
 
 

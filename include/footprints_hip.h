@@ -285,6 +285,21 @@ int fp_adam_hyper(double lr, double beta1, double beta2, double eps, int32_t ste
 int fp_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                      const float* hyper7_dev, fp_stream_t stream);
 
+/* ---- recorded launch plans: replay a whole training step (~740 launches on five streams) from C ------------------------------ */
+/* While a plan records (thread local) every kernel launch of this library and every fp_event_record / fp_event_wait is executed AND
+ * appended to the plan with a private copy of its arguments; fp_plan_replay re-issues nodes [begin, end) (end < 0: to the last node)
+ * with the same streams.  Valid as long as every pointer argument stays valid (static arena, workspaces and tables).
+ * fp_plan_mark returns the current node count (stage boundaries for a replay in pieces, e.g. around gradient all-reduces). */
+void* fp_plan_begin(void);
+int32_t fp_plan_mark(void* plan);
+int32_t fp_plan_end(void* plan);
+int fp_plan_replay(void* plan, int32_t begin, int32_t end);
+void fp_plan_destroy(void* plan);
+/* stream-to-stream ordering used by the engine (instead of framework events, so that a recording sees it): record returns an event
+ * id >= 0 (valid for fp_event_wait until ~4000 further records, or -- inside a recording -- until the recording ends) */
+int64_t fp_event_record(fp_stream_t stream);
+int fp_event_wait(fp_stream_t stream, int64_t event_id);
+
 /* ---- device-side data path (footprints/datasets/footprint_dataset.py:55-65,73-85; kitti_dataset.py:66-112; matterport_dataset.py:69-97) ---- */
 /* one per sample; fp_aug_params_bytes() == sizeof(fp_aug_params) */
 typedef struct fp_aug_params {

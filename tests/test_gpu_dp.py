@@ -152,7 +152,8 @@ def _nccl_worker(port, q):
             if ts.reducer is not None:
                 ts.reducer.overlap = (mode == "overlap")
                 assert ts.reducer.force and ts.reducer.world == 1 and len(ts.reducer.buckets) >= 7
-            losses = [float(ts(batch)[20]) for _ in range(3)]
+            losses = [float(ts(batch)[20]) for _ in range(6)]        # 2 eager + 1 recorded + 3 replayed in pieces around the bucket all-reduces
+            assert len(ts._plans) == 1
             torch.cuda.synchronize()
             res.append((losses, torch.cat([p.detach().flatten() for p in mm.model.parameters()]).cpu().numpy()))
         q.put(("ok", res))
@@ -165,7 +166,8 @@ def _nccl_worker(port, q):
 def test_rccl_path_world_of_one_executes_and_is_exact():
     """The RCCL code path (`init_process_group("nccl")`, GradReducer's bucket all-reduces on the comm stream, event gating, both
     schedules) executed on the 1-GPU box with a world of one rank: a sum over one rank is the identity, so three steps must be
-    BIT-identical to the non-distributed TrainStep -- a wrong wait / a bucket reduced before its gradients landed would show."""
+    BIT-identical to the non-distributed TrainStep -- a wrong wait / a bucket reduced before its gradients landed would show.  Steps 4-6
+    replay the recorded launch plan in pieces (one per stage mark) with the collectives issued between the pieces."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

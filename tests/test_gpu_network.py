@@ -371,6 +371,38 @@ def test_trainstep_graph_replay_is_bit_identical_to_eager():
         assert torch.equal(a, b)
 
 
+def test_trainstep_launch_plan_replay_is_bit_identical_to_eager():
+    """recorded launch plan (csrc/plan.cpp; TrainStep(plan=True), the default): 2 eager steps, 1 recording step, then replays from C --
+    same losses and weights as issuing every step from Python, also when the batch alternates between two sets of input buffers
+    (the double-buffered loader: one plan per set) and when an eval forward runs between replays"""
+    from footprints_amd.model_manager import ModelManager
+    from footprints_amd.training.train import TrainStep, synthetic_batch
+    from oracle import restatement as R
+    P, Bf = R.make_state(tag="plan")
+    b0, b1 = synthetic_batch(2, 96, 128, "cuda", seed=3), synthetic_batch(2, 96, 128, "cuda", seed=4)
+    res = []
+    for plan in (False, True):
+        mm = ModelManager()
+        _load_state(mm.model, P, Bf)
+        ts = TrainStep(mm.model, mm.optimiser, plan=plan)
+        losses = []
+        for i in range(9):
+            losses.append(ts(b0 if i % 2 == 0 else b1).clone())
+            if i == 6:
+                mm.model.eval()
+                with torch.no_grad():
+                    ev = mm.model(b0["image"])["1/1"].clone()
+                mm.model.train()
+        res.append((losses, [v.clone() for v in mm.model.state_dict().values()], ev))
+        if plan:
+            assert len(ts._plans) == 2 and all(n > 500 for *_, n in ts._plans.values())
+    for a, b in zip(res[0][0], res[1][0]):
+        assert torch.equal(a, b)
+    for a, b in zip(res[0][1], res[1][1]):
+        assert torch.equal(a, b)
+    assert torch.equal(res[0][2], res[1][2])
+
+
 def test_eval_forward_with_folded_batchnorm_matches_unfolded():
     """inference fast path: encoder BN folded into the conv weights == conv -> BN launches, after training steps
     have moved the running statistics, and again after they move once more (the fold is rebuilt)"""
