@@ -381,8 +381,9 @@ def main():
     final_loss = float(step.losses[20])
 
     # kernel-exclusive pass (outside the timed region): same steps on ONE stream, HIP events around every convolution launch
+    # (every rank runs it when data-parallel: the steps contain the bucket all-reduces; rank 0 reports)
     xtimer, xsteps = None, 3
-    if rank == 0 and not args.no_kernel_events:
+    if not args.no_kernel_events:
         was, was_plan = step.eng.concurrent, step.use_plan
         step.eng.concurrent, step.use_plan = False, False            # eager, one stream: the instrumented wrappers see every launch
         step(batch)
@@ -426,7 +427,7 @@ def main():
     # host samples (resized uint8 images + float64 label maps, as the file readers deliver them) -> pinned double-buffered H2D ->
     # flip / ColorJitter / ToTensor / label algebra kernels on a copy stream -> TrainStep.  Decode + resize stay host-side.
     loader_leg = None
-    if rank == 0 and not args.no_loader and args.workload == "kitti":
+    if rank == 0 and not distributed and not args.no_loader and args.workload == "kitti":
         import random as _random
         import numpy as np
         from footprints_amd.datasets import DeviceBatchAssembler, DeviceLoader
