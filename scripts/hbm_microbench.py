@@ -1,9 +1,11 @@
 """HBM-bound kernels of the 192x640 decoder tail (heads, loss, Adam, max-pool) timed alone: algorithmic bytes / launch duration
 against the 8 TB/s HBM3E peak.  FP_LIB=<other .so> runs the same table on another build (A/B inside one gpurun call)."""
+import os
 import sys
 
 import torch
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from footprints_amd import ops
 from footprints_amd.training.train import synthetic_batch
 

@@ -23,3 +23,18 @@ def sample_inputs(i):
     }
     maps["disparity"][0, :5] = 1.25                                # disp - 1.25 == 0: the `disp - (disp == 0)` branch of utils.py:31
     return img, maps
+
+
+def sample_inputs_matterport(i):
+    """Matterport flavour: 'depth_raw' = the 16-bit depth png's values; ground depth with exact 0.1 entries (missing pixels,
+    matterport_dataset.py:73) and values beyond the 10 m cut (:76)"""
+    img, _ = sample_inputs(i)
+    gd = (filler.uniform("g11:%d:gd" % i, (H, W), 0.0, 14.0) * filler.bernoulli("g11:%d:gdv" % i, (H, W), 0.6)).astype(np.float64)
+    gd[1, :7] = 0.1
+    maps = {
+        "visible_ground": filler.uniform("g11:%d:vg" % i, (H, W)).astype(np.float64),
+        "ground_depth": gd,
+        "depth_mask": filler.bernoulli("g11:%d:dm" % i, (H, W), 0.02).astype(np.float64),
+        "depth_raw": np.floor(filler.uniform("g11:%d:depth" % i, (H, W), 0.0, 40000.0)).astype(np.float64),
+    }
+    return img, maps

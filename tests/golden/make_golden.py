@@ -300,19 +300,12 @@ def g9_segmentor():
     return out
 
 
-def g10_data_path():
-    """datasets/kitti_dataset.py:44-122 + datasets/footprint_dataset.py:55-105: the reference's own KITTIDataset.__getitem__ (is_train=True)
-    on synthetic files written at the target resolution (so every resize is the identity), Python RNG seeded.  Absent third-party
-    modules are stood in: cv2.resize (identity, asserted), skimage.measure.label (scipy.ndimage.label, 8-connectivity) and
-    torchvision.transforms.{ColorJitter,ToTensor} (oracle/data_path.py's restatement of torchvision 0.4.2 on top of the real Pillow)."""
-    import importlib
+def _data_standins():
+    """stand-ins for the third-party modules the reference's dataset code imports and this image lacks (see g10_data_path)"""
     import random
-    import tempfile
     import types
-    from PIL import Image
     import scipy.ndimage
     from oracle import data_path as D
-    from tests.golden.data_inputs import N_SAMPLES, SEED, H, W, sample_inputs
     ref_import.load_reference()
     cv2 = sys.modules["cv2"]
     cv2.INTER_NEAREST, cv2.INTER_AREA = 0, 3
@@ -342,6 +335,22 @@ def g10_data_path():
             return torch.from_numpy(np.asarray(pic).copy()).permute(2, 0, 1).contiguous().float().div(255)
     tvt.ColorJitter, tvt.ToTensor = ColorJitter, ToTensor
     sys.modules["torchvision"].transforms = tvt
+
+
+def g10_data_path():
+    """datasets/kitti_dataset.py:44-122 + datasets/footprint_dataset.py:55-105: the reference's own KITTIDataset.__getitem__ (is_train=True)
+    on synthetic files written at the target resolution (so every resize is the identity), Python RNG seeded.  Absent third-party
+    modules are stood in: cv2.resize (identity, asserted), skimage.measure.label (scipy.ndimage.label, 8-connectivity) and
+    torchvision.transforms.{ColorJitter,ToTensor} (oracle/data_path.py's restatement of torchvision 0.4.2 on top of the real Pillow)."""
+    import importlib
+    import random
+    import tempfile
+    import types
+    from PIL import Image
+    import scipy.ndimage
+    from oracle import data_path as D
+    from tests.golden.data_inputs import N_SAMPLES, SEED, H, W, sample_inputs
+    _data_standins()
     kd = importlib.import_module("footprints.datasets.kitti_dataset")
     out = {"flags": np.zeros((N_SAMPLES, 2), np.int64)}
     with tempfile.TemporaryDirectory() as tmp:
@@ -376,6 +385,49 @@ def g10_data_path():
     return out
 
 
+def g11_data_path_matterport():
+    """datasets/matterport_dataset.py:33-110: the reference's MatterportDataset.__getitem__ (is_train=True) on synthetic files at the
+    target resolution (RGB png, 16-bit depth png, npy label maps), same stand-ins and RNG discipline as G10"""
+    import importlib
+    import random
+    import tempfile
+    from PIL import Image
+    from oracle import data_path as D
+    from tests.golden.data_inputs import N_SAMPLES, SEED, H, W, sample_inputs_matterport
+    _data_standins()
+    md = importlib.import_module("footprints.datasets.matterport_dataset")
+    out = {"flags": np.zeros((N_SAMPLES, 2), np.int64)}
+    with tempfile.TemporaryDirectory() as tmp:
+        raw, tr = os.path.join(tmp, "raw"), os.path.join(tmp, "train")
+        names = []
+        for i in range(N_SAMPLES):
+            img, maps = sample_inputs_matterport(i)
+            scan, pos, hh, dd = "scan", "p%02d" % i, "1", "2"
+            os.makedirs(os.path.join(raw, scan, scan, "matterport_color_images"), exist_ok=True)
+            os.makedirs(os.path.join(raw, scan, scan, "matterport_depth_images"), exist_ok=True)
+            Image.fromarray(img, "RGB").save(os.path.join(raw, scan, scan, "matterport_color_images", "%s_i%s_%s.jpg" % (pos, hh, dd)), format="PNG")
+            Image.fromarray(maps["depth_raw"].astype(np.uint16)).save(os.path.join(raw, scan, scan, "matterport_depth_images", "%s_d%s_%s.png" % (pos, hh, dd)))
+            for sub, key in (("ground_seg", "visible_ground"), ("hidden_depth", "ground_depth"), ("depth_masks", "depth_mask")):
+                d = os.path.join(tr, sub, scan, "data")
+                os.makedirs(d, exist_ok=True)
+                np.save(os.path.join(d, "%s_%s_%s.npy" % (pos, hh, dd)), maps[key])
+            names.append("%s %s %s %s" % (scan, pos, hh, dd))
+        random.seed(SEED)
+        ds = md.MatterportDataset(raw, tr, names, H, W, no_depth_mask=False, is_train=True)
+        for i in range(N_SAMPLES):
+            dm = sample_inputs_matterport(i)[1]["depth_mask"]
+            assert np.array_equal(ds.filter_depth_mask(dm), dm)
+        probe = random.Random(); probe.setstate(random.getstate())
+        for i in range(N_SAMPLES):
+            out["flags"][i] = D.sample_augmentation(True, probe)
+            if out["flags"][i][1]:
+                D.jitter_params(probe)
+            item = ds[i]
+            for k, v in item.items():
+                out["%d.%s" % (i, k)] = v.numpy()
+    return out
+
+
 def main():
     mods = ref_import.load_reference()
     assert mods is not None, "needs /root/reference"
@@ -387,7 +439,8 @@ def main():
                      ("g3_network", lambda: g3_network(net)), ("g4_loss", lambda: g4_loss(loss_mod)),
                      ("g5_train", lambda: g5_train(net, loss_mod)), ("g6_predict", lambda: g6_predict(net)),
                      ("g7_metrics", g7_metrics), ("g8_evaluator", g8_evaluator),
-                     ("g9_segmentor", g9_segmentor), ("g10_data_path", g10_data_path)):
+                     ("g9_segmentor", g9_segmentor), ("g10_data_path", g10_data_path),
+                     ("g11_data_path_matterport", g11_data_path_matterport)):
         if only and name not in only:
             continue
         d = fn()

@@ -45,6 +45,23 @@ def test_g10_device_path_equals_reference_dataset_bit_for_bit():
             assert np.array_equal(ref, got), (i, k, float(np.abs(ref - got).max()))
 
 
+def test_g11_device_path_equals_reference_matterport_dataset_bit_for_bit():
+    from footprints_amd.datasets import DeviceBatchAssembler, draw_augmentation
+    from oracle import data_path as D
+    from tests.golden.data_inputs import N_SAMPLES, SEED, H, W, sample_inputs_matterport
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g11_data_path_matterport.npz"))
+    rng = random.Random(SEED)
+    D.jitter_params(rng)
+    samples = [sample_inputs_matterport(i) for i in range(N_SAMPLES)]
+    params = [draw_augmentation(True, rng) for _ in range(N_SAMPLES)]
+    asm = DeviceBatchAssembler(N_SAMPLES, H, W, dataset="matterport", map_dtype=np.float64)
+    batch = asm.collect(asm.submit(samples, params))
+    torch.cuda.synchronize()
+    for i in range(N_SAMPLES):
+        for k, v in batch.items():
+            assert np.array_equal(g["%d.%s" % (i, k)], v[i].cpu().numpy()), (i, k)
+
+
 @pytest.mark.parametrize("B,H,W", [(3, 37, 53), (12, 192, 640)])
 def test_device_path_equals_oracle_every_op_order(B, H, W):
     import itertools
