@@ -17,7 +17,7 @@ y = torch.empty(N, H, W, Co, device="cuda")
 b = torch.zeros(Co, device="cuda")
 dg = mode == "dgrad"
 wp3 = ops.pack_conv_weight_bf3(w if not dg else w.permute(1, 0, 2, 3).contiguous(), torch.empty(ops.packed_weight_elems_bf3(Co, C, 3, False), device="cuda"), False)
-d = ops.make_desc(N, H, W, H, W, C, 0, Co, 3, 1, 1, L.GATHER_DGRAD_REFLECT if dg else L.GATHER_FWD_REFLECT, act=0 if dg else L.ACT_ELU)
+d = ops.make_desc(N, H, W, H, W, C, 0, Co, 3, 1, 1, L.GATHER_DGRAD_REFLECT if dg else L.GATHER_FWD_REFLECT, act=0 if (dg or mode == "fwdnoact") else L.ACT_ELU)
 run = (lambda: ops.conv3x3_bf3(d, x, wp3, y, actsrc=x if C == Co else None)) if dg else (lambda: ops.conv3x3_bf3(d, x, wp3, y, bias=b))
 if dg and C == Co:
     d.epi = L.EPI_ACTGRAD_ELU
