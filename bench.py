@@ -343,6 +343,8 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         if args.force_dist:
             os.environ["FP_DP_FORCE"] = "1"                        # read when footprints_amd.parallel is imported (below)
+        if os.environ.get("NCCL_DEBUG", "").upper() in ("", "VERSION"):
+            os.environ["NCCL_DEBUG"] = "WARN"                      # RCCL's version banner goes to stdout, where the ONE JSON line belongs
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from footprints_amd import ops
@@ -522,9 +524,16 @@ def main():
                 json.dump({"groups": xtimer.groups(xsteps), "shapes": xtimer.table()}, fh, indent=1)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
     if distributed:
+        dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        try:                                                       # C-side stdio of the libraries first: the JSON line is the last line on stdout
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
