@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libfootprints_hip.so")
 # enum fp_gather
 GATHER_FWD_ZERO, GATHER_FWD_REFLECT, GATHER_FWD_REFLECT_UP2, GATHER_DGRAD_ZERO, GATHER_DGRAD_REFLECT, GATHER_STEM = range(6)
 ACT_NONE, ACT_ELU, ACT_RELU = range(3)
-EPI_BIAS, EPI_ADDEND, EPI_ADDEND_MASK, EPI_ACTGRAD_ELU, EPI_ACTGRAD_RELU, EPI_ACCUM = 1, 2, 4, 8, 16, 32
+EPI_BIAS, EPI_ADDEND, EPI_ADDEND_MASK, EPI_ACTGRAD_ELU, EPI_ACTGRAD_RELU, EPI_ACCUM, EPI_BF16X2 = 1, 2, 4, 8, 16, 32, 64
 
 
 class ConvDesc(C.Structure):

@@ -72,14 +72,16 @@ __device__ __forceinline__ void fp_tile_pixel(int pt, int& py, int& px) {
   if (TW == 16) px = (px - 2 * (py & 1)) & 15;
 }
 
-template <int TH, int TW, int BN, int WM, int WN, bool FLIP, bool FOLD>
+// NP = number of bf16 terms per operand: 3 = the exact split (six products); 2 = h + m only (three products: ah*bh + ah*bm + am*bh,
+// operands rounded to 16 significant bits, ~2^-17 relative) -- an opt-in INFERENCE mode (FP_EPI_BF16X2), never used for training
+template <int TH, int TW, int BN, int WM, int WN, bool FLIP, bool FOLD, int NP = 3>
 __global__ void __launch_bounds__(256) conv3x3_tile_bf3_kernel(const Tile3Args a) {
   constexpr int BM128 = 128;
   constexpr int TM = BM128 / WM / 32, TN = BN / WN / 32;
   constexpr int HW2 = TW + 2, HP = (TH + 2) * HW2;
   constexpr int NS = (HP * 4 + 255) / 256;
   constexpr int PLANE = HP * PIXB;                   // bytes per plane
-  constexpr int BUF = 3 * PLANE;                     // bytes per halo buffer
+  constexpr int BUF = NP * PLANE;                    // bytes per halo buffer
   constexpr int NPIX = TH * TW;                      // valid rows of the 128-row M tile (8x16 = 128; 6x20 = 120, rows 120..127 idle)
   static_assert(WM * WN == 4 && NPIX <= BM128 && BM128 == 128, "tile shape");
   __shared__ __attribute__((aligned(16))) unsigned char lds[(2 * BUF + 1023) / 1024 * 1024];   // whole LDS allocation granules
@@ -157,19 +159,19 @@ __global__ void __launch_bounds__(256) conv3x3_tile_bf3_kernel(const Tile3Args a
       unsigned char* p = lds + buf * BUF + lds_off[k];
       *reinterpret_cast<uint2*>(p) = __builtin_bit_cast(uint2, vh);
       *reinterpret_cast<uint2*>(p + PLANE) = __builtin_bit_cast(uint2, vm);
-      *reinterpret_cast<uint2*>(p + 2 * PLANE) = __builtin_bit_cast(uint2, vl);
+      if (NP == 3) *reinterpret_cast<uint2*>(p + 2 * PLANE) = __builtin_bit_cast(uint2, vl);
     }
   };
 
   // ---- weight slices: [tap][chunk][plane][n][16] bf16; lane (n = idx, k-group = h) reads 16 bytes per plane -----------------
-  uint4 bq[3][TN][3];
-  auto load_b = [&](int tap, int cc, uint4 (&bf)[TN][3]) {
+  uint4 bq[3][TN][NP];
+  auto load_b = [&](int tap, int cc, uint4 (&bf)[TN][NP]) {
     const unsigned short* ws = a.w + (size_t)(tap * a.KC16 + cc) * 3 * a.Nout * 16 + h * 8;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int n = min(n0 + (wn * TN + j) * 32 + idx, a.Nout - 1);
 #pragma unroll
-      for (int p = 0; p < 3; ++p) bf[j][p] = *reinterpret_cast<const uint4*>(ws + ((size_t)p * a.Nout + n) * 16);
+      for (int p = 0; p < NP; ++p) bf[j][p] = *reinterpret_cast<const uint4*>(ws + ((size_t)p * a.Nout + n) * 16);
     }
   };
 
@@ -206,10 +208,11 @@ __global__ void __launch_bounds__(256) conv3x3_tile_bf3_kernel(const Tile3Args a
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // six products, smallest first; consecutive MFMAs alternate accumulators (i, j)
-  auto mma6 = [&](const uint4 (&af)[TM][3], const uint4 (&bf)[TN][3]) {
-    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+  constexpr int NPROD = NP == 3 ? 6 : 3;
+  auto mma6 = [&](const uint4 (&af)[TM][NP], const uint4 (&bf)[TN][NP]) {
+    constexpr int PA[6] = {NP == 3 ? 2 : 1, 0, NP == 3 ? 1 : 0, 1, 0, 0}, PB[6] = {0, NP == 3 ? 2 : 1, NP == 3 ? 1 : 0, 0, 1, 0};
 #pragma unroll
-    for (int q = 0; q < 6; ++q)
+    for (int q = 0; q < NPROD; ++q)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -231,12 +234,12 @@ __global__ void __launch_bounds__(256) conv3x3_tile_bf3_kernel(const Tile3Args a
     const int ccn = min(cc + 1, c_end - 1);
     // A fragments are read one tap ahead (two register sets): with 32-cycle MFMAs an LDS read issued right before its
     // consumer costs ~150 cycles per 384-cycle tap
-    uint4 af[2][TM][3];
-    auto load_a = [&](int tap, uint4 (&dst)[TM][3]) {
+    uint4 af[2][TM][NP];
+    auto load_a = [&](int tap, uint4 (&dst)[TM][NP]) {
       const int ky = tap / 3, kx = tap % 3;
       const int toff = ((FLIP ? 2 - ky : ky) * HW2 + (FLIP ? 2 - kx : kx)) * PIXB;
 #pragma unroll
-      for (int p = 0; p < 3; ++p)
+      for (int p = 0; p < NP; ++p)
 #pragma unroll
         for (int i = 0; i < TM; ++i) dst[i][p] = *reinterpret_cast<const uint4*>(Hb + p * PLANE + abase[i] + toff);
     };
@@ -254,8 +257,8 @@ __global__ void __launch_bounds__(256) conv3x3_tile_bf3_kernel(const Tile3Args a
         else load_b(tap - 7, ccn, bq[(tap + 2) % 3]);
         mma6(af[tap & 1], bq[tap % 3]);
         // issue order: one LDS / global read between consecutive MFMAs (this tap's MFMAs only depend on older reads)
-        if (tap < 8) fp_sched_interleave<TM * 3, TN * 3, 6 * TM * TN>();
-        else fp_sched_interleave<0, TN * 3, 6 * TM * TN>();
+        if (tap < 8) fp_sched_interleave<TM * NP, TN * NP, NPROD * TM * TN>();
+        else fp_sched_interleave<0, TN * NP, NPROD * TM * TN>();
         if (WF) {
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
@@ -265,14 +268,14 @@ __global__ void __launch_bounds__(256) conv3x3_tile_bf3_kernel(const Tile3Args a
             const bool need_c = ft.csel == 0 || (ft.csel == 1 ? has_c1 : has_cW);
             if (!(need_r && need_c)) continue;                             // uniform per workgroup
             const int toff = (ft.ao * HW2 + ft.bo) * PIXB;
-            uint4 ax[TM][3];
+            uint4 ax[TM][NP];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
               const unsigned mr = ft.rsel == 0 ? ~0u : (ft.rsel == 1 ? m_r1[i] : m_rH[i]);
               const unsigned mc = ft.csel == 0 ? ~0u : (ft.csel == 1 ? m_c1[i] : m_cW[i]);
               const unsigned mk = mr & mc;
 #pragma unroll
-              for (int p = 0; p < 3; ++p) {
+              for (int p = 0; p < NP; ++p) {
                 uint4 v = *reinterpret_cast<const uint4*>(Hb + p * PLANE + abase[i] + toff);
                 v.x &= mk; v.y &= mk; v.z &= mk; v.w &= mk;
                 ax[i][p] = v;
@@ -387,9 +390,9 @@ __global__ void __launch_bounds__(256) conv3x3_tile_bf3_kernel(const Tile3Args a
     }
 }
 
-template <int TH, int TW, int BN, int WM, int WN, bool FLIP, bool FOLD>
+template <int TH, int TW, int BN, int WM, int WN, bool FLIP, bool FOLD, int NP = 3>
 int launch3(Tile3Args& a, hipStream_t stream) {
-  fp_launch((conv3x3_tile_bf3_kernel<TH, TW, BN, WM, WN, FLIP, FOLD>), dim3(a.nwg), dim3(256), 0, stream, a);
+  fp_launch((conv3x3_tile_bf3_kernel<TH, TW, BN, WM, WN, FLIP, FOLD, NP>), dim3(a.nwg), dim3(256), 0, stream, a);
   return fp_check_launch("fp_conv3x3_bf3");
 }
 
@@ -481,9 +484,16 @@ extern "C" int fp_conv3x3_bf3(const fp_conv_desc* d, const float* src, const flo
                       : (flip ? launch3<TH_, TW_, 32, 4, 1, true, false>(a, stream) : launch3<TH_, TW_, 32, 4, 1, false, false>(a, stream))) \
               : (fold ? launch3<TH_, TW_, 64, 2, 2, true, true>(a, stream)                                                    \
                       : (flip ? launch3<TH_, TW_, 64, 2, 2, true, false>(a, stream) : launch3<TH_, TW_, 64, 2, 2, false, false>(a, stream))))
-  rc = p.th == 8 ? FP_L3(8, 16) : FP_L3(6, 20);
+  if ((d->epi & FP_EPI_BF16X2) && !flip) {          // opt-in inference mode: two bf16 terms per operand, three products (forward only)
+    a.epi &= ~FP_EPI_BF16X2;
+    if (p.th == 8) rc = p.bn == 32 ? launch3<8, 16, 32, 4, 1, false, false, 2>(a, stream) : launch3<8, 16, 64, 2, 2, false, false, 2>(a, stream);
+    else rc = p.bn == 32 ? launch3<6, 20, 32, 4, 1, false, false, 2>(a, stream) : launch3<6, 20, 64, 2, 2, false, false, 2>(a, stream);
+  } else {
+    a.epi &= ~FP_EPI_BF16X2;
+    rc = p.th == 8 ? FP_L3(8, 16) : FP_L3(6, 20);
+  }
 #undef FP_L3
   if (rc || p.SK <= 1) return rc;
-  return fp_splitk_reduce_launch(a.part, p.SK, (int64_t)d->N * d->OH * d->OW, d->Nout, bias, addend, addend_mask, actsrc, y, d->act, d->epi,
+  return fp_splitk_reduce_launch(a.part, p.SK, (int64_t)d->N * d->OH * d->OW, d->Nout, bias, addend, addend_mask, actsrc, y, d->act, d->epi & ~FP_EPI_BF16X2,
                                  stream);
 }

@@ -172,6 +172,10 @@ class Engine:
         self._pack_table_key = None
         self._pack_ev = None
         self.fold_eval = _FOLD
+        # opt-in inference precision: "bf16x2" runs the 3x3 stride-1 tile convolutions of an eval / no-grad forward with two bf16 terms per
+        # operand (three MFMA products instead of six).  NOT exact (measured output error in profiles/round2_notes.md); never used when
+        # a backward pass may follow.  model.inference_precision = "bf16x2" sets it through FootprintNetwork.forward.
+        self.inference_bf16x2 = False
         self._fold_ready = False        # folded (conv * BN scale, BN shift) copies of the encoder are current
         self._fold_buf = None
         self._fold_vers = None
@@ -514,7 +518,11 @@ class Engine:
         if scales is not None and save_for_backward:
             raise ValueError("a subset of output scales is an inference-only option")
         with ops.on_stream(torch.cuda.current_stream()):      # caches the raw stream handle for the launch wrappers
-            return self._forward(image, training, save_for_backward, outputs, scales)
+            ops._bf16x2 = bool(self.inference_bf16x2 and not training and not save_for_backward)
+            try:
+                return self._forward(image, training, save_for_backward, outputs, scales)
+            finally:
+                ops._bf16x2 = False
 
     def _forward(self, image, training, save_for_backward, outputs, scales=None):
         if image.dim() != 4 or image.shape[1] != 3:

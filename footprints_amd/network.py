@@ -151,6 +151,7 @@ class FootprintNetwork(nn.Module):
             # inference_scales (optional attribute, e.g. ("1/1",)): evaluate only those heads and return only those keys --
             # predict_simple and the reference's test-set inference consume '1/1' alone (predict_simple.py:68)
             keys = ("1/8", "1/4", "1/2", "1/1")
+            eng.inference_bf16x2 = getattr(self, "inference_precision", "exact") == "bf16x2"     # opt-in, see Engine.__init__
             want = getattr(self, "inference_scales", None)
             idx = None if want is None else sorted(keys.index(k) for k in want)
             outs = eng.forward(input_image, training=self.training, save_for_backward=False, scales=idx)

@@ -132,11 +132,16 @@ def conv3x3_bf3_supported(desc):
     return bool(_cached_query("fp_conv3x3_bf3_supported", desc))
 
 
+_bf16x2 = False      # opt-in inference mode of the bf16 tile kernel (Engine.forward sets it around an eval forward): two bf16 terms per operand
+
+
 def conv3x3_bf3(desc, src, wpacked_bf3, y, bias=None, addend=None, addend_mask=None, actsrc=None, src1=None):
     """3x3 stride-1 conv / data-gradient with exactly split bf16x3 operands (same semantics as conv_igemm; src1 = the skip tensor
     of the GATHER_FWD_REFLECT_UP2 concat)"""
     epi = desc.epi | (_lib.EPI_BIAS if bias is not None else 0) | (_lib.EPI_ADDEND if addend is not None else 0) | \
         (_lib.EPI_ADDEND_MASK if addend_mask is not None else 0)
+    if _bf16x2 and desc.gather in (_lib.GATHER_FWD_ZERO, _lib.GATHER_FWD_REFLECT, _lib.GATHER_FWD_REFLECT_UP2):
+        epi |= _lib.EPI_BF16X2
     lib = _lib.load()
     d = ConvDesc.from_buffer_copy(desc)
     d.epi = epi

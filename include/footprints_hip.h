@@ -52,6 +52,8 @@ enum fp_act { FP_ACT_NONE = 0, FP_ACT_ELU = 1, FP_ACT_RELU = 2 };
 #define FP_EPI_ACTGRAD_ELU 8u  /* v *= (s > 0 ? 1 : s + 1), s = actsrc = saved ELU OUTPUT (nn.ELU(inplace=True), network.py:118) */
 #define FP_EPI_ACTGRAD_RELU 16u /* v *= (actsrc > 0) */
 #define FP_EPI_ACCUM 32u       /* y += v (second decoder / second consumer accumulating into the same gradient) */
+#define FP_EPI_BF16X2 64u      /* fp_conv3x3_bf3 forward only, opt-in INFERENCE mode: operands rounded to two bf16 terms (16 significant
+                                  bits), three MFMA products instead of six; not exact -- never set by the training path */
 
 typedef struct fp_conv_desc {
   int32_t N;          /* batch */

@@ -11,7 +11,7 @@ db = sys.argv[1]
 which = int(sys.argv[2]) if len(sys.argv) > 2 else -2
 cur = sqlite3.connect(db).cursor()
 rows = list(cur.execute("select name, start, end, stream_id from kernels order by start"))
-adam = [i for i, r in enumerate(rows) if "adam_kernel" in r[0]]
+adam = [i for i, r in enumerate(rows) if "adam_kernel" in r[0] or "adam_dev_kernel" in r[0]]
 if len(adam) < 3:
     sys.exit("need >= 3 adam_kernel launches")
 a0, a1 = adam[which - 1], adam[which]
