@@ -220,239 +220,8 @@ __global__ void __launch_bounds__(256) wgrad3x3_bf3_kernel(const W3Args a) {
   }
 }
 
-// ---- second generation: fp32 transposed in LDS, exact split at READ time, double-buffered, ONE barrier per chunk -----------
-// The first kernel splits while staging (three bf16 planes, 46 KB per workgroup: no room for a second buffer beside a second
-// resident workgroup) and needs two barriers per 64-pixel chunk; its staging writes (ds_write_b64 at a 192-byte lane stride) are
-// 4-way bank-conflicted and every operand row is re-read as three planes.  Here the staging is a pure transpose
-//     Xs[buf][halo row 6][ci 32][20 px fp32]   Zs[buf][row 4][co 32][16 px fp32 (+4 pad)]       (80-byte lines = 5 x 16-byte slots:
-// lane (channel c, pixel half h) -> slot 5c + 2h, a bijection mod 16 for any 16 distinct c: conflict-free ds_read_b128 AND, with
-// the staging map (channel quad q, pixel group cg) -> slot 5k + 4q + cg, conflict-free ds_write_b128), 25 KB per buffer, so two
-// buffers fit twice per CU; a chunk is: issue the next chunk's global loads -> read this chunk's rows (2 x b128 + b64 per row),
-// split each fp32 into its three bf16 terms in registers (same round-to-nearest chain as split_store: bit-identical planes, so
-// bit-identical sums) -> 54 MFMAs -> write the next chunk into the other buffer -> one barrier.
-constexpr int LP2 = 80;
-constexpr int XB2 = HR * 32 * LP2, ZB2 = CH * 32 * LP2, BUF2 = XB2 + ZB2;      // 15360 + 10240 = 25600 bytes per buffer
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-// two fp32 -> packed bf16 pairs of the three exact terms
-__device__ __forceinline__ void split_pair(const float x, const float y, unsigned& hi, unsigned& mid, unsigned& lo) {
-  // scalar residuals on purpose: a 2-vector subtraction would become v_pk_add_f32, and the library keeps packed fp32 VALU out of its
-  // code objects (tests/test_host_cpu.py::test_no_packed_fp32_valu_in_device_code)
-  const bf16x2 vh = __builtin_convertvector(f32x2{x, y}, bf16x2);
-  const f32x2 fh = __builtin_convertvector(vh, f32x2);
-  const float rx = x - fh[0], ry = y - fh[1];
-  const bf16x2 vm = __builtin_convertvector(f32x2{rx, ry}, bf16x2);
-  const f32x2 fm = __builtin_convertvector(vm, f32x2);
-  const float sx = rx - fm[0], sy = ry - fm[1];
-  const bf16x2 vl = __builtin_convertvector(f32x2{sx, sy}, bf16x2);
-  hi = __builtin_bit_cast(unsigned, vh);
-  mid = __builtin_bit_cast(unsigned, vm);
-  lo = __builtin_bit_cast(unsigned, vl);
-}
-
-__global__ void __launch_bounds__(256, 2) wgrad3x3_bf3_v2_kernel(const W3Args a) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF2];
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, idx = lane & 31, h = lane >> 5;
-  int b = a.xcd ? fp_xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
-  const int cot = b % a.cotiles; b /= a.cotiles;
-  const int cit = b % a.citiles; b /= a.citiles;
-  const int s = b;
-  const int ci0 = cit * 32, co0 = cot * 32;
-  const int c_begin = s * a.chunksPerSplit;
-  const int c_end = min(a.nchunks, c_begin + a.chunksPerSplit);
-
-  const int q = t & 7;
-  const int xcg = (t >> 3) % 5, xhr = t / 40;
-  const int zcg = (t >> 3) & 3, zr = t >> 5;
-  const bool xitem = t < 240, zitem = t < 128;
-  float4 xr[4], zv[4];
-  unsigned xmask = 0, zmask = 0;
-  const bool want_bias = a.bpart != nullptr && cit == 0;
-  float bs[4] = {0.f, 0.f, 0.f, 0.f};
-  // Interior chunks (halo and the two padding columns inside the image: 80 % of the chunks of a 96 x 320 level) need no reflection,
-  // clamping or masks: the chunk origin is wave-uniform (scalar registers) and a thread's offsets from it never change, so the
-  // eight loads are base + constant.  The general path cost ~140 VALU instructions per chunk -- in a kernel whose waves spend
-  // their time ISSUING (PMC: 470 VALU + 54 MFMA instructions per chunk and wave, VALU pipe 58 % busy against 40 % of the MFMA pipe).
-  const int xgo = ((xhr - 1) * a.W + xcg * 4 - 1) * a.C + ci0 + q * 4;
-  const int zoffs = (zr * a.W + zcg * 4) * a.Nout + co0 + q * 4;
-  bool fast = false;
-
-  auto issue = [&](int c) {
-    const int cx = c % a.chunksX;
-    const int r = c / a.chunksX;
-    const int cy = r % a.chunksY, n = r / a.chunksY;
-    const int y0 = cy * CH, x0 = cx * CW;
-    fast = !a.nofast && a.mode != 2 && y0 >= 1 && y0 + CH + 1 <= a.H && x0 >= 1 && x0 + CW + 3 <= a.W;
-    if (fast) {
-      const size_t org = (size_t)(n * a.H + y0) * a.W + x0;
-      if (xitem) {
-        const float* px = a.x + org * a.C + xgo;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) xr[j] = *reinterpret_cast<const float4*>(px + j * a.C);
-      }
-      if (zitem) {
-        const float* pz = a.dz + org * a.Nout + zoffs;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) zv[j] = *reinterpret_cast<const float4*>(pz + j * a.Nout);
-      }
-      return;
-    }
-    xmask = zmask = 0;
-    {
-      int sy = y0 + xhr - 1;
-      bool rowok = xitem;
-      if (a.mode == 0) rowok = rowok && sy >= 0 && sy < a.H;
-      else { rowok = rowok && sy >= -1 && sy <= a.H; sy = fp_reflect(sy, a.H); }
-      sy = min(max(sy, 0), a.H - 1);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int hx = xcg * 4 + j;
-        int sx = x0 + hx - 1;
-        bool ok = rowok && hx < CW + 2;
-        if (a.mode == 0) ok = ok && sx >= 0 && sx < a.W;
-        else { ok = ok && sx >= -1 && sx <= a.W; sx = fp_reflect(sx, a.W); }
-        sx = min(max(sx, 0), a.W - 1);
-        const size_t xpix = a.mode == 2 ? (size_t)(n * (a.H >> 1) + (sy >> 1)) * (a.W >> 1) + (sx >> 1) : (size_t)(n * a.H + sy) * a.W + sx;
-        xr[j] = *reinterpret_cast<const float4*>(a.x + xpix * a.C + ci0 + q * 4);
-        xmask |= ok ? (1u << j) : 0u;
-      }
-    }
-    {
-      const int oy = min(y0 + zr, a.H - 1);
-      const bool rowok = zitem && y0 + zr < a.H;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int ox = x0 + zcg * 4 + j;
-        const bool ok = rowok && ox < a.W;
-        zv[j] = *reinterpret_cast<const float4*>(a.dz + ((size_t)(n * a.H + oy) * a.W + min(ox, a.W - 1)) * a.Nout + co0 + q * 4);
-        zmask |= ok ? (1u << j) : 0u;
-      }
-    }
-  };
-  auto stage = [&](int buf) {
-    unsigned char* const base = lds + buf * BUF2;
-    if (xitem) {
-      unsigned char* p = base + (xhr * 32 + q * 4) * LP2 + xcg * 16;
-      if (!fast) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (!(xmask & (1u << j))) xr[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-      *reinterpret_cast<float4*>(p) = make_float4(xr[0].x, xr[1].x, xr[2].x, xr[3].x);
-      *reinterpret_cast<float4*>(p + LP2) = make_float4(xr[0].y, xr[1].y, xr[2].y, xr[3].y);
-      *reinterpret_cast<float4*>(p + 2 * LP2) = make_float4(xr[0].z, xr[1].z, xr[2].z, xr[3].z);
-      *reinterpret_cast<float4*>(p + 3 * LP2) = make_float4(xr[0].w, xr[1].w, xr[2].w, xr[3].w);
-    }
-    if (zitem) {
-      unsigned char* p = base + XB2 + (zr * 32 + q * 4) * LP2 + zcg * 16;
-      if (!fast) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (!(zmask & (1u << j))) zv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-      if (want_bias) {
-        bs[0] += (zv[0].x + zv[1].x) + (zv[2].x + zv[3].x); bs[1] += (zv[0].y + zv[1].y) + (zv[2].y + zv[3].y);
-        bs[2] += (zv[0].z + zv[1].z) + (zv[2].z + zv[3].z); bs[3] += (zv[0].w + zv[1].w) + (zv[2].w + zv[3].w);
-      }
-      *reinterpret_cast<float4*>(p) = make_float4(zv[0].x, zv[1].x, zv[2].x, zv[3].x);
-      *reinterpret_cast<float4*>(p + LP2) = make_float4(zv[0].y, zv[1].y, zv[2].y, zv[3].y);
-      *reinterpret_cast<float4*>(p + 2 * LP2) = make_float4(zv[0].z, zv[1].z, zv[2].z, zv[3].z);
-      *reinterpret_cast<float4*>(p + 3 * LP2) = make_float4(zv[0].w, zv[1].w, zv[2].w, zv[3].w);
-    }
-  };
-
-  f32x16 acc[9];
-#pragma unroll
-  for (int tp = 0; tp < 9; ++tp)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[tp][r] = 0.f;
-
-  if (c_begin < c_end) {
-    issue(c_begin);
-    stage(0);
-  }
-  __syncthreads();
-  const int zoff = XB2 + (wave * 32 + idx) * LP2 + h * 32;
-  const int xoff = (wave * 32 + idx) * LP2 + h * 32;
-  for (int c = c_begin; c < c_end; ++c) {
-    const unsigned char* const Bb = lds + ((c - c_begin) & 1) * BUF2;
-    if (c + 1 < c_end) issue(c + 1);                 // next chunk's global loads fly under this chunk's conversions and MFMAs
-    // B fragments: dZ row `wave`, lane (co = idx, pixel group h): 8 fp32 -> three planes of 8 bf16
-    uint4 bz[3];
-    {
-      const float4 z0 = *reinterpret_cast<const float4*>(Bb + zoff), z1 = *reinterpret_cast<const float4*>(Bb + zoff + 16);
-      split_pair(z0.x, z0.y, bz[0].x, bz[1].x, bz[2].x);
-      split_pair(z0.z, z0.w, bz[0].y, bz[1].y, bz[2].y);
-      split_pair(z1.x, z1.y, bz[0].z, bz[1].z, bz[2].z);
-      split_pair(z1.z, z1.w, bz[0].w, bz[1].w, bz[2].w);
-    }
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      const unsigned char* row = Bb + xoff + ky * 32 * LP2;
-      const float4 x0 = *reinterpret_cast<const float4*>(row), x1 = *reinterpret_cast<const float4*>(row + 16);
-      const float2 x2 = *reinterpret_cast<const float2*>(row + 32);                   // columns 8h+8, 8h+9
-      unsigned P[3][5];
-      split_pair(x0.x, x0.y, P[0][0], P[1][0], P[2][0]);
-      split_pair(x0.z, x0.w, P[0][1], P[1][1], P[2][1]);
-      split_pair(x1.x, x1.y, P[0][2], P[1][2], P[2][2]);
-      split_pair(x1.z, x1.w, P[0][3], P[1][3], P[2][3]);
-      split_pair(x2.x, x2.y, P[0][4], P[1][4], P[2][4]);
-      uint4 a0[3], a1[3], a2[3];
-#pragma unroll
-      for (int p = 0; p < 3; ++p) {
-        a0[p] = make_uint4(P[p][0], P[p][1], P[p][2], P[p][3]);
-        a1[p] = make_uint4(__builtin_amdgcn_alignbit(P[p][1], P[p][0], 16), __builtin_amdgcn_alignbit(P[p][2], P[p][1], 16),
-                           __builtin_amdgcn_alignbit(P[p][3], P[p][2], 16), __builtin_amdgcn_alignbit(P[p][4], P[p][3], 16));
-        a2[p] = make_uint4(P[p][1], P[p][2], P[p][3], P[p][4]);
-      }
-      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-      for (int qq = 0; qq < 6; ++qq) {
-        const bf16x8 bb = __builtin_bit_cast(bf16x8, bz[PB[qq]]);
-        acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a0[PA[qq]]), bb, acc[ky * 3 + 0], 0, 0, 0);
-        acc[ky * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a1[PA[qq]]), bb, acc[ky * 3 + 1], 0, 0, 0);
-        acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a2[PA[qq]]), bb, acc[ky * 3 + 2], 0, 0, 0);
-      }
-    }
-    // the other buffer was last read during chunk c - 1, and every wave has passed the barrier that ended that chunk
-    if (c + 1 < c_end) stage((c + 1 - c_begin) & 1);
-    __syncthreads();                                  // next chunk visible; this chunk's buffer free for chunk c + 2
-  }
-
-  // ---- sum the four waves' tiles through LDS (fixed order), one tap at a time: same order as the first kernel ---------------------
-  float* red = reinterpret_cast<float*>(lds);        // [4 waves][16 regs][64 lanes] = 16 KB
-  float* out = a.part + (size_t)s * 9 * a.C * a.Nout;
-  if (want_bias) {
-    if (zitem) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) red[(t >> 3) * 32 + q * 4 + k] = bs[k];
-    }
-    __syncthreads();
-    if (t < 32) {
-      float v = 0.f;
-#pragma unroll
-      for (int g = 0; g < 16; ++g) v += red[g * 32 + t];
-      a.bpart[(size_t)s * a.Nout + co0 + t] = v;
-    }
-    __syncthreads();
-  }
-#pragma unroll
-  for (int tp = 0; tp < 9; ++tp) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[tp][r];
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int e = t + 256 * k;
-      const float v = ((red[e] + red[1024 + e]) + red[2048 + e]) + red[3072 + e];
-      const int r = e >> 6, ln = e & 63;
-      const int ci = ci0 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
-      out[((size_t)tp * a.C + ci) * a.Nout + co0 + (ln & 31)] = v;
-    }
-    __syncthreads();
-  }
-}
+// (A second generation -- fp32 transposed in LDS, exact split at read time, double-buffered, one barrier per chunk -- measured the same
+// as the first in the training step and is gone from the tree: commit df15caf still has it, profiles/round2_notes.md its counters.)
 
 // ---- third generation: [pixel][channel] bf16 planes in LDS, hardware transpose reads (ds_read_b64_tr_b16) ----------------------
 // PMC of the second kernel (64 -> 64 @ 96 x 320): per chunk and wave 54 MFMAs against ~470 VALU instructions; the waves spend 41 %
@@ -782,9 +551,8 @@ extern "C" int fp_conv_wgrad_bf3(const fp_conv_desc* d, const float* x, const fl
     if (!stamp_buf) (void)hipMalloc(&stamp_buf, (size_t)8192 * 6 * 8);
     if (nwg <= 8192) a.stamps = stamp_buf;
   }
-  static const int ver = getenv("FP_WGRAD_BF3_V") ? atoi(getenv("FP_WGRAD_BF3_V")) : 3;       // A/B switch: kernel generation
+  static const int ver = getenv("FP_WGRAD_BF3_V") ? atoi(getenv("FP_WGRAD_BF3_V")) : 3;       // A/B switch: 1 = first generation, else third
   if (ver == 1) fp_launch(wgrad3x3_bf3_kernel, dim3(nwg), dim3(256), 0, stream, a);
-  else if (ver == 2) fp_launch(wgrad3x3_bf3_v2_kernel, dim3(nwg), dim3(256), 0, stream, a);
   else if (a.mode == 0) fp_launch(wgrad3x3_bf3_v3_kernel<0>, dim3(nwg), dim3(256), 0, stream, a);
   else if (a.mode == 1) fp_launch(wgrad3x3_bf3_v3_kernel<1>, dim3(nwg), dim3(256), 0, stream, a);
   else fp_launch(wgrad3x3_bf3_v3_kernel<2>, dim3(nwg), dim3(256), 0, stream, a);
