@@ -50,7 +50,9 @@ def draw_augmentation(is_train=True, rng=random):
 
 
 class DeviceBatchAssembler:
-    """Pinned staging buffers (one set per slot, `slots` >= 2 for double buffering), a copy stream, and the two assembly kernels.
+    """Pinned staging buffers (one set per slot), a copy stream, and the two assembly kernels.  Three slots by default: while the
+    network works on batch i (slot a) and batch i + 1 sits assembled in slot b, the host can already fill slot c with batch i + 2 --
+    with two slots the refill of a slot has to wait for the step that last read it, and the GPU idles for the host's memcpy.
 
         asm = DeviceBatchAssembler(12, 192, 640, dataset="kitti")
         slot = asm.submit(samples, params)        # host memcpy into pinned memory + async H2D + kernels on the copy stream
@@ -60,7 +62,7 @@ class DeviceBatchAssembler:
     mask already through filter_depth_mask).  map_dtype float64 reproduces the reference's numpy arithmetic bit for bit; float32
     halves the H2D bytes (inputs rounded once before the same float64 algebra)."""
 
-    def __init__(self, batch_size, height, width, dataset="kitti", map_dtype=np.float64, slots=2, no_depth_mask=False,
+    def __init__(self, batch_size, height, width, dataset="kitti", map_dtype=np.float64, slots=3, no_depth_mask=False,
                  project_down_baseline=False, moving_objects_method="ours", footprint_threshold=0.75, baseline=0.54,
                  depth_scaling=0.25e-3, device="cuda"):
         if dataset not in MAP_KEYS:
