@@ -392,7 +392,8 @@ __global__ void __launch_bounds__(256) conv3x3_tile_bf3_kernel(const Tile3Args a
 
 template <int TH, int TW, int BN, int WM, int WN, bool FLIP, bool FOLD, int NP = 3>
 int launch3(Tile3Args& a, hipStream_t stream) {
-  fp_launch((conv3x3_tile_bf3_kernel<TH, TW, BN, WM, WN, FLIP, FOLD, NP>), dim3(a.nwg), dim3(256), 0, stream, a);
+  static const unsigned extra_lds = getenv("FP_TILE_EXTRA_LDS") ? (unsigned)atoi(getenv("FP_TILE_EXTRA_LDS")) : 0u;   // occupancy experiments
+  fp_launch((conv3x3_tile_bf3_kernel<TH, TW, BN, WM, WN, FLIP, FOLD, NP>), dim3(a.nwg), dim3(256), extra_lds, stream, a);
   return fp_check_launch("fp_conv3x3_bf3");
 }
 
