@@ -295,9 +295,9 @@ def test_cpu_input_is_refused():
 # ----------------------------------------------------------------------------------------------------------
 # BASELINE.json full sizes: size-independent properties
 # ----------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("B,H,W", [(12, 192, 640), (4, 512, 640)])
+@pytest.mark.parametrize("B,H,W", [(12, 192, 640), (4, 512, 640), (2, 256, 448)])
 def test_full_size_properties(B, H, W):
-    """KITTI bs=12 192x640 and Matterport bs=4 512x640: (1) bit-reproducible step, (2) eval forward of a batch ==
+    """KITTI bs=12 192x640, Matterport bs=4 512x640 and predict_simple's `handheld` resolution 256x448 (8x14 pyramid top): (1) bit-reproducible step, (2) eval forward of a batch ==
     per-image forwards (images are independent in eval mode; equal to fp32 round-off, not bitwise: small grids are
     split along K, so the summation grouping depends on the batch size), (3) image 0 against the CPU oracle (eval)."""
     from footprints_amd.model_manager import ModelManager
