@@ -19,6 +19,10 @@
 int fp_splitk_reduce_launch(const float* part, int SK, int64_t M, int Nout, const float* bias, const float* addend, const float* addend_mask,
                             const float* actsrc, float* y, int act, unsigned epi, hipStream_t stream);
 
+#ifndef FP_BF2_PRODUCTS
+#define FP_BF2_PRODUCTS 3
+#endif
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -208,9 +212,11 @@ __global__ void __launch_bounds__(256) conv3x3_tile_bf3_kernel(const Tile3Args a
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // six products, smallest first; consecutive MFMAs alternate accumulators (i, j)
-  constexpr int NPROD = NP == 3 ? 6 : 3;
+  constexpr int NPROD = NP == 3 ? 6 : (FP_BF2_PRODUCTS);
   auto mma6 = [&](const uint4 (&af)[TM][NP], const uint4 (&bf)[TN][NP]) {
-    constexpr int PA[6] = {NP == 3 ? 2 : 1, 0, NP == 3 ? 1 : 0, 1, 0, 0}, PB[6] = {0, NP == 3 ? 2 : 1, NP == 3 ? 1 : 0, 0, 1, 0};
+    // NP == 2 with four products (timing proxy of an fp16-pair split: hh + hm + mh + mm): order mm, mh, hm, hh
+    constexpr int PA[6] = {NP == 3 ? 2 : 1, NP == 3 ? 0 : (NPROD == 4 ? 1 : 0), NP == 3 ? 1 : 0, NP == 3 ? 1 : 0, 0, 0};
+    constexpr int PB[6] = {NP == 3 ? 0 : (NPROD == 4 ? 1 : 0), NP == 3 ? 2 : (NPROD == 4 ? 0 : 1), NP == 3 ? 1 : (NPROD == 4 ? 1 : 0), 0, 1, 0};
 #pragma unroll
     for (int q = 0; q < NPROD; ++q)
 #pragma unroll
