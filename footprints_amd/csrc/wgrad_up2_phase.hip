@@ -144,13 +144,15 @@ __global__ void __launch_bounds__(256, 3) wgrad_up2_phase_bf3_kernel(const PWArg
   unsigned char* const Xs = lds;
   unsigned char* const Zs = lds + 3 * PXPLANE;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, idx = lane & 31, h = lane >> 5;
-  int b = blockIdx.x;
+  // XCD-contiguous logical ids: the ci x co tile workgroups of one pixel split stage the same X / dZ chunks and then share that XCD's
+  // L2 (consecutive hardware ids go to different XCDs; PMC showed 3x the fused-minimum HBM bytes per launch); split s walks chunks
+  // s, s + S, ... so that neighbouring workgroups of an XCD work on neighbouring chunks at the same time
+  int b = fp_xcd_remap(blockIdx.x, gridDim.x);
   const int cot = b % a.cotiles; b /= a.cotiles;
   const int cit = b % a.citiles; b /= a.citiles;
   const int s = b;
   const int ci0 = cit * 32, co0 = cot * 32;
-  const int c_begin = s * a.chunksPerSplit;
-  const int c_end = min(a.nchunks, c_begin + a.chunksPerSplit);
+  const int c_begin = s, c_end = a.nchunks, c_step = a.S;
   const int H2 = 2 * a.h, W2 = 2 * a.w;
   const int dy = wave >> 1, dx = wave & 1;
   const unsigned dxm = 0u - (unsigned)dx;
@@ -224,8 +226,8 @@ __global__ void __launch_bounds__(256, 3) wgrad_up2_phase_bf3_kernel(const PWArg
     stage();
   }
   __syncthreads();
-  for (int c = c_begin; c < c_end; ++c) {
-    if (c + 1 < c_end) issue(c + 1);                 // next chunk's global loads fly under this chunk's MFMAs
+  for (int c = c_begin; c < c_end; c += c_step) {
+    if (c + c_step < c_end) issue(c + c_step);       // next chunk's global loads fly under this chunk's MFMAs
 #pragma unroll
     for (int r = 0; r < CHL; ++r) {
       uint4 bz[3];
@@ -256,7 +258,7 @@ __global__ void __launch_bounds__(256, 3) wgrad_up2_phase_bf3_kernel(const PWArg
       }
     }
     __syncthreads();                                  // every wave has read this chunk
-    if (c + 1 < c_end) stage();
+    if (c + c_step < c_end) stage();
     __syncthreads();                                  // next chunk visible
   }
   float* out = a.part + ((size_t)s * 16 + wave * 4) * a.C0 * a.Nout;

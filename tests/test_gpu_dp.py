@@ -15,7 +15,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-STEPS, B, H, W = 2, 2, 64, 96
+STEPS, B, H, W = 5, 2, 64, 96      # 2 eager + 1 recorded + 2 replayed steps: the launch plan in pieces around the bucket all-reduces
 
 
 def _free_port():

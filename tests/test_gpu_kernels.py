@@ -790,7 +790,8 @@ def test_conv3x3_bf3_up2_concat_gather(N, h, w, C0, C1, Cout):
 
 @pytest.mark.parametrize("mode,N,H,W,C0,Cout", [
     ("zero", 12, 48, 160, 64, 64), ("reflect", 4, 96, 320, 64, 32), ("reflect", 2, 192, 640, 32, 32), ("reflect", 12, 24, 80, 128, 128),
-    ("zero", 6, 12, 40, 256, 256), ("reflect", 3, 10, 46, 32, 96), ("zero", 12, 8, 32, 64, 32), ("reflect", 5, 7, 32, 32, 32)])
+    ("zero", 6, 12, 40, 256, 256), ("reflect", 3, 10, 46, 32, 96), ("zero", 12, 8, 32, 64, 32), ("reflect", 5, 7, 32, 32, 32),
+    ("zero", 12, 6, 20, 512, 256), ("reflect", 12, 6, 20, 256, 256), ("zero", 4, 6, 20, 64, 32), ("reflect", 2, 16, 20, 32, 64)])
 def test_wgrad3x3_bf3_kernel(mode, N, H, W, C0, Cout):
     """weight gradient with exactly split bf16x3 operands (wgrad3x3_bf3.hip), float64 reference, slice destination + accumulate"""
     ops, L = _ops()
