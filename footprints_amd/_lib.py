@@ -27,7 +27,7 @@ PACK_FWD, PACK_DGRAD, PACK_STEM, PACK_UP2_FWD, PACK_UP2_DGRAD, PACK_FWD_BF3, PAC
 class PackJob(C.Structure):
     """fp_pack_job (include/footprints_hip.h): one entry of the device-resident table of fp_pack_weights_batched"""
     _fields_ = [("w", C.c_void_p), ("wp", C.c_void_p)] + [(n, C.c_int32) for n in (
-        "Cout", "Cin", "KH", "KW", "kind", "c_begin", "c_count", "block_begin", "block_count")]
+        "Cout", "Cin", "KH", "KW", "kind", "c_begin", "c_count", "block_begin", "block_count")] + [("amax", C.c_void_p)]
 
 
 _P, _I32, _I64, _F, _D = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double
@@ -80,6 +80,13 @@ SIGNATURES = {
     "fp_conv3x3_bf3_workspace": (_I64, [_DESC]),
     "fp_conv3x3_bf3": (C.c_int, [_DESC, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
     "fp_packed_weight_elems_bf3": (_I64, [_I32, _I32, _I32, _I32, _I32]),
+    "fp_zero_u32": (C.c_int, [_P, _I64, _P]),
+    "fp_amax_f32": (C.c_int, [_P, _I64, _P, _P]),
+    "fp_weight_amax": (C.c_int, [_P, _I64, _P, _P]),
+    "fp_packed_weight_elems_hp": (_I64, [_I32, _I32, _I32, _I32, _I32]),
+    "fp_pack_conv_weight_hp": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _P, _I32, _P]),
+    "fp_pack_weights_amax": (C.c_int, [_P, _P, _I32, _P]),
+    "fp_conv3x3_hp": (C.c_int, [_DESC, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P]),
     "fp_pack_conv_weight_bf3": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _P]),
     "fp_adam_hyper": (C.c_int, [_D, _D, _D, _D, _I32, _D, _P]),
     "fp_adam_step_dev": (C.c_int, [_P, _P, _P, _P, _I64, _P, _P]),

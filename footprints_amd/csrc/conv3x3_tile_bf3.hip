@@ -28,6 +28,8 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 struct Tile3Args {
   const float* src_lo;       // FWD_REFLECT_UP2: the half-resolution tensor whose nearest x2 upsampling forms input channels [0, Clo)
@@ -47,6 +49,14 @@ struct Tile3Args {
   int SK, chunksPerSplit;   // split-K over 16-channel chunks for small grids: raw partials [SK][N*OH*OW][Nout] -> fp_splitk_reduce_launch
   int wmajor;               // workgroup ids enumerate pixel tiles fastest, (channel tile, split) slowest
   float* part;
+  // fp16-pair mode (HP): amax slots of the source tensor(s) and of the weights; optional slot receiving max |y| of this launch
+  const unsigned* amax_a;
+  const unsigned* amax_a1;
+  const unsigned* amax_w;
+  unsigned* amax_out;
+#ifdef FP_TILE_STAMPS
+  unsigned long long* stamps;   // diagnostics build only (scripts/build_variant.sh ... -DFP_TILE_STAMPS): 16 clocks per workgroup
+#endif
 };
 
 struct FoldTap { int wtap, ao, bo, rsel, csel; };
@@ -78,13 +88,17 @@ __device__ __forceinline__ void fp_tile_pixel(int pt, int& py, int& px) {
 
 // NP = number of bf16 terms per operand: 3 = the exact split (six products); 2 = h + m only (three products: ah*bh + ah*bm + am*bh,
 // operands rounded to 16 significant bits, ~2^-17 relative) -- an opt-in INFERENCE mode (FP_EPI_BF16X2), never used for training
-template <int TH, int TW, int BN, int WM, int WN, bool FLIP, bool FOLD, int NP = 3>
+// HP = the fp16-pair format of fp_common.h (NP = 2 planes, four products hh + hm + mh + mm on v_mfma_f32_32x32x16_f16): operands carry
+// 22 significant bits after a per-tensor power-of-two scaling; two thirds of the MFMA work and of the LDS / weight traffic of the exact split.
+template <int TH, int TW, int BN, int WM, int WN, bool FLIP, bool FOLD, int NP = 3, bool HP = false>
 __global__ void __launch_bounds__(256) conv3x3_tile_bf3_kernel(const Tile3Args a) {
+  static_assert(!HP || NP == 2, "the fp16-pair format has two planes");
+  constexpr int WPL = HP ? 2 : 3;                    // planes per weight slice in the packed buffer
   constexpr int BM128 = 128;
   constexpr int TM = BM128 / WM / 32, TN = BN / WN / 32;
-  constexpr int HW2 = TW + 2, HP = (TH + 2) * HW2;
-  constexpr int NS = (HP * 4 + 255) / 256;
-  constexpr int PLANE = HP * PIXB;                   // bytes per plane
+  constexpr int HW2 = TW + 2, HPX = (TH + 2) * HW2;
+  constexpr int NS = (HPX * 4 + 255) / 256;
+  constexpr int PLANE = HPX * PIXB;                   // bytes per plane
   constexpr int BUF = NP * PLANE;                    // bytes per halo buffer
   constexpr int NPIX = TH * TW;                      // valid rows of the 128-row M tile (8x16 = 128; 6x20 = 120, rows 120..127 idle)
   static_assert(WM * WN == 4 && NPIX <= BM128 && BM128 == 128, "tile shape");
@@ -113,13 +127,20 @@ __global__ void __launch_bounds__(256) conv3x3_tile_bf3_kernel(const Tile3Args a
   }
   const int y0 = tile_y * TH, x0 = tile_x * TW, n0 = tile_n * BN;
 
+  int ka = 0, kunscale = 0;                          // HP: source scale exponent, and -(ka + kw) for the epilogue (wave-uniform)
+  if (HP) {
+    unsigned ab = fp_amax_bits(a.amax_a);
+    if (a.amax_a1) ab = max(ab, fp_amax_bits(a.amax_a1));
+    ka = fp_hp_exponent(ab, FP_HP_TARGET_ACT);
+    kunscale = -(ka + fp_hp_exponent(fp_amax_bits(a.amax_w), FP_HP_TARGET_W));
+  }
   // ---- halo staging slots (unconditional loads; invalid slots read the nearest in-image pixel and are stored as zero) ----------
   int pix[NS], pixlo[NS], lds_off[NS];
   bool hvalid[NS];
 #pragma unroll
   for (int k = 0; k < NS; ++k) {
-    const int lin = t + 256 * k, hp = min(lin >> 2, HP - 1);
-    lds_off[k] = (lin >> 2) < HP ? hp * PIXB + (lin & 3) * 8 : -1;
+    const int lin = t + 256 * k, hp = min(lin >> 2, HPX - 1);
+    lds_off[k] = (lin >> 2) < HPX ? hp * PIXB + (lin & 3) * 8 : -1;
     const int hy = hp / HW2, hx = hp - hy * HW2;
     int sy = y0 + hy - 1, sx = x0 + hx - 1;
     if (a.mode == 0) {
@@ -155,12 +176,21 @@ __global__ void __launch_bounds__(256) conv3x3_tile_bf3_kernel(const Tile3Args a
       if (lds_off[k] < 0) continue;
       f32x4 v = {hreg[k].x, hreg[k].y, hreg[k].z, hreg[k].w};
       if (!hvalid[k] || hzero) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      unsigned char* p = lds + buf * BUF + lds_off[k];
+      if (HP) {
+        v = f32x4{ldexpf(v.x, ka), ldexpf(v.y, ka), ldexpf(v.z, ka), ldexpf(v.w, ka)};
+        const f16x4 vh = __builtin_convertvector(v, f16x4);
+        const f32x4 r1 = v - __builtin_convertvector(vh, f32x4);
+        const f16x4 vm = __builtin_convertvector(r1, f16x4);
+        *reinterpret_cast<uint2*>(p) = __builtin_bit_cast(uint2, vh);
+        *reinterpret_cast<uint2*>(p + PLANE) = __builtin_bit_cast(uint2, vm);
+        continue;
+      }
       const bf16x4 vh = __builtin_convertvector(v, bf16x4);
       const f32x4 r1 = v - __builtin_convertvector(vh, f32x4);
       const bf16x4 vm = __builtin_convertvector(r1, bf16x4);
       const f32x4 r2 = r1 - __builtin_convertvector(vm, f32x4);
       const bf16x4 vl = __builtin_convertvector(r2, bf16x4);
-      unsigned char* p = lds + buf * BUF + lds_off[k];
       *reinterpret_cast<uint2*>(p) = __builtin_bit_cast(uint2, vh);
       *reinterpret_cast<uint2*>(p + PLANE) = __builtin_bit_cast(uint2, vm);
       if (NP == 3) *reinterpret_cast<uint2*>(p + 2 * PLANE) = __builtin_bit_cast(uint2, vl);
@@ -169,8 +199,15 @@ __global__ void __launch_bounds__(256) conv3x3_tile_bf3_kernel(const Tile3Args a
 
   // ---- weight slices: [tap][chunk][plane][n][16] bf16; lane (n = idx, k-group = h) reads 16 bytes per plane -----------------
   uint4 bq[3][TN][NP];
-  auto load_b = [&](int tap, int cc, uint4 (&bf)[TN][NP]) {
-    const unsigned short* ws = a.w + (size_t)(tap * a.KC16 + cc) * 3 * a.Nout * 16 + h * 8;
+  auto load_b = [&](int tap, int cc, uint4 (&bf)[TN][NP], bool prologue = false) {
+#if defined(FP_TILE_ABL) && FP_TILE_ABL == 3        // ablation: weight fragments loaded once
+    if (!prologue) return;
+#endif
+#if defined(FP_TILE_ABL) && FP_TILE_ABL == 1        // ablation: every weight fragment from one L1-resident slice
+    const unsigned short* ws = a.w + (size_t)((tap & 1) * a.KC16) * WPL * a.Nout * 16 + h * 8;
+#else
+    const unsigned short* ws = a.w + (size_t)(tap * a.KC16 + cc) * WPL * a.Nout * 16 + h * 8;
+#endif
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int n = min(n0 + (wn * TN + j) * 32 + idx, a.Nout - 1);
@@ -212,29 +249,57 @@ __global__ void __launch_bounds__(256) conv3x3_tile_bf3_kernel(const Tile3Args a
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // six products, smallest first; consecutive MFMAs alternate accumulators (i, j)
-  constexpr int NPROD = NP == 3 ? 6 : (FP_BF2_PRODUCTS);
+  constexpr int NPROD = NP == 3 ? 6 : (HP ? 4 : (FP_BF2_PRODUCTS));
   auto mma6 = [&](const uint4 (&af)[TM][NP], const uint4 (&bf)[TN][NP]) {
     // NP == 2 with four products (timing proxy of an fp16-pair split: hh + hm + mh + mm): order mm, mh, hm, hh
     constexpr int PA[6] = {NP == 3 ? 2 : 1, NP == 3 ? 0 : (NPROD == 4 ? 1 : 0), NP == 3 ? 1 : 0, NP == 3 ? 1 : 0, 0, 0};
     constexpr int PB[6] = {NP == 3 ? 0 : (NPROD == 4 ? 1 : 0), NP == 3 ? 2 : (NPROD == 4 ? 0 : 1), NP == 3 ? 1 : (NPROD == 4 ? 1 : 0), 0, 1, 0};
+#if defined(FP_TILE_ABL) && FP_TILE_ABL == 2        // ablation: operands consumed, no MFMA
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int p = 0; p < NP; ++p) asm volatile("" ::"v"(af[i][p].x), "v"(af[i][p].y), "v"(af[i][p].z), "v"(af[i][p].w));
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int p = 0; p < NP; ++p) asm volatile("" ::"v"(bf[j][p].x), "v"(bf[j][p].y), "v"(bf[j][p].z), "v"(bf[j][p].w));
+    return;
+#endif
 #pragma unroll
     for (int q = 0; q < NPROD; ++q)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[i][PA[q]]), __builtin_bit_cast(bf16x8, bf[j][PB[q]]),
-                                                              acc[i][j], 0, 0, 0);
+          if (HP)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i][PA[q]]), __builtin_bit_cast(f16x8, bf[j][PB[q]]),
+                                                               acc[i][j], 0, 0, 0);
+          else
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[i][PA[q]]), __builtin_bit_cast(bf16x8, bf[j][PB[q]]),
+                                                                acc[i][j], 0, 0, 0);
   };
 
   const int c_begin = split * a.chunksPerSplit, c_end = min(a.KC16, c_begin + a.chunksPerSplit);
+#ifdef FP_TILE_STAMPS
+  unsigned long long st[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) st[k] = 0;
+  st[0] = __builtin_readcyclecounter();
+  st[12] = __builtin_amdgcn_s_memrealtime();       // 100 MHz constant clock: calibrates the shader clock under this kernel's load
+#endif
   load_halo(c_begin);
-  load_b(0, c_begin, bq[0]);                 // issued before the halo is consumed: one exposed load latency in the prologue, not two
-  load_b(1, c_begin, bq[1]);
+  load_b(0, c_begin, bq[0], true);           // issued before the halo is consumed: one exposed load latency in the prologue, not two
+  load_b(1, c_begin, bq[1], true);
+#if defined(FP_TILE_ABL) && FP_TILE_ABL == 3
+  load_b(2, c_begin, bq[2], true);
+#endif
   store_halo(0);
   load_halo(min(c_begin + 1, c_end - 1));
   __syncthreads();
 
+#ifdef FP_TILE_STAMPS
+  st[1] = __builtin_readcyclecounter();
+#endif
   for (int cc = c_begin; cc < c_end; ++cc) {
     const unsigned char* Hb = lds + ((cc - c_begin) & 1) * BUF;
     const int ccn = min(cc + 1, c_end - 1);
@@ -292,11 +357,21 @@ __global__ void __launch_bounds__(256) conv3x3_tile_bf3_kernel(const Tile3Args a
         }
       }
     }
+#ifdef FP_TILE_STAMPS
+    { const unsigned long long now = __builtin_readcyclecounter();       // after the taps of chunk k (k < 6), before the next halo store
+#pragma unroll
+      for (int k = 0; k < 6; ++k) if (cc - c_begin == k) st[2 + k] = now; }
+#endif
     if (cc + 1 < c_end) {
       store_halo((cc + 1 - c_begin) & 1);
       load_halo(min(cc + 2, c_end - 1));
       __syncthreads();
     }
+#ifdef FP_TILE_STAMPS
+    { const unsigned long long now = __builtin_readcyclecounter();       // after the barrier that publishes chunk k + 1
+#pragma unroll
+      for (int k = 0; k < 6; ++k) if (cc - c_begin == k) st[8 + k] = now; }
+#endif
   }
 
   // ---- epilogue.  The flag tests are hoisted and every optional operand (addend, its mask, the activation source, the old
@@ -307,6 +382,7 @@ __global__ void __launch_bounds__(256) conv3x3_tile_bf3_kernel(const Tile3Args a
   const int act = a.SK > 1 ? 0 : a.act;
   float* const dst = a.SK > 1 ? a.part + (size_t)split * a.N * a.OH * a.OW * a.Nout : a.y;
   const bool interior = NPIX == 128 && y0 + TH <= a.OH && x0 + TW <= a.OW;
+  float ymax = 0.f;                                  // HP: largest stored magnitude of this lane (the consumer's scale)
   auto rows8 = [&](auto full_tag, int i, int j, int n, float bias, int half) {
     constexpr bool FULL = decltype(full_tag)::value;
     int off[8];
@@ -346,7 +422,7 @@ __global__ void __launch_bounds__(256) conv3x3_tile_bf3_kernel(const Tile3Args a
     // every option for every element)
     float v[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = acc[i][j][half * 8 + k] + bias;
+    for (int k = 0; k < 8; ++k) v[k] = (HP ? ldexpf(acc[i][j][half * 8 + k], kunscale) : acc[i][j][half * 8 + k]) + bias;
     if (epi & FP_EPI_ADDEND) {
       if (epi & FP_EPI_ADDEND_MASK) {
 #pragma unroll
@@ -375,9 +451,15 @@ __global__ void __launch_bounds__(256) conv3x3_tile_bf3_kernel(const Tile3Args a
 #pragma unroll
       for (int k = 0; k < 8; ++k) v[k] += yo[k];
     }
+#if defined(FP_TILE_ABL) && FP_TILE_ABL == 4        // ablation: epilogue arithmetic without the stores (a.mode is never negative)
+    if (a.mode >= 0) return;
+#endif
 #pragma unroll
     for (int k = 0; k < 8; ++k)
-      if (FULL || ok[k]) dst[off[k]] = v[k];
+      if (FULL || ok[k]) {
+        dst[off[k]] = v[k];
+        if (HP) ymax = fmaxf(ymax, fabsf(v[k]));
+      }
   };
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -394,12 +476,55 @@ __global__ void __launch_bounds__(256) conv3x3_tile_bf3_kernel(const Tile3Args a
         rows8(std::false_type{}, i, j, n, bias, 1);
       }
     }
+  if (HP && a.amax_out && a.SK <= 1) {
+    ymax = fp_wave_max(ymax);
+    if (lane == 0) fp_amax_publish(a.amax_out, blockIdx.x * 4 + wave, ymax);
+  }
+#ifdef FP_TILE_STAMPS
+  if (a.stamps && lane == 0) {
+    st[14] = __builtin_readcyclecounter();
+    st[13] = __builtin_amdgcn_s_memrealtime();
+    unsigned hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    st[15] = hwid;
+    unsigned long long* o = a.stamps + ((size_t)blockIdx.x * 4 + wave) * 16;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) o[k] = st[k];
+  }
+#endif
 }
 
-template <int TH, int TW, int BN, int WM, int WN, bool FLIP, bool FOLD, int NP = 3>
+template <int TH, int TW, int BN, int WM, int WN, bool FLIP, bool FOLD, int NP = 3, bool HP = false>
 int launch3(Tile3Args& a, hipStream_t stream) {
   static const unsigned extra_lds = getenv("FP_TILE_EXTRA_LDS") ? (unsigned)atoi(getenv("FP_TILE_EXTRA_LDS")) : 0u;   // occupancy experiments
-  fp_launch((conv3x3_tile_bf3_kernel<TH, TW, BN, WM, WN, FLIP, FOLD, NP>), dim3(a.nwg), dim3(256), extra_lds, stream, a);
+#ifdef FP_TILE_STAMPS
+  static unsigned long long* stamp_buf = nullptr;
+  const char* stamp_file = getenv("FP_TILE_STAMPS_FILE");
+  if (!stamp_buf) (void)hipMalloc(&stamp_buf, (size_t)16384 * 4 * 16 * 8);
+  a.stamps = stamp_file && a.nwg <= 16384 ? stamp_buf : nullptr;
+#endif
+  fp_launch((conv3x3_tile_bf3_kernel<TH, TW, BN, WM, WN, FLIP, FOLD, NP, HP>), dim3(a.nwg), dim3(256), extra_lds, stream, a);
+#ifdef FP_TILE_STAMPS
+  static int launch_no = 0;
+  static const int dump_at = getenv("FP_TILE_STAMPS_AT") ? atoi(getenv("FP_TILE_STAMPS_AT")) : -1;     // dump only that launch (steady state)
+  ++launch_no;
+  if (a.stamps && (dump_at < 0 || launch_no == dump_at)) {      // synchronous dump of this launch: one line per wave
+    (void)hipStreamSynchronize(stream);
+    const size_t n = (size_t)a.nwg * 4 * 16;
+    unsigned long long* hbuf = (unsigned long long*)malloc(n * 8);
+    (void)hipMemcpy(hbuf, stamp_buf, n * 8, hipMemcpyDeviceToHost);
+    FILE* f = fopen(stamp_file, "w");
+    if (f) {
+      for (size_t i = 0; i < (size_t)a.nwg * 4; ++i) {
+        fprintf(f, "%zu", i);
+        for (int k = 0; k < 16; ++k) fprintf(f, " %llu", hbuf[i * 16 + k]);
+        fprintf(f, "\n");
+      }
+      fclose(f);
+    }
+    free(hbuf);
+  }
+#endif
   return fp_check_launch("fp_conv3x3_bf3");
 }
 
@@ -456,51 +581,83 @@ extern "C" int64_t fp_conv3x3_bf3_workspace(const fp_conv_desc* d) {
   return (int64_t)p.SK * d->N * d->OH * d->OW * d->Nout * (int64_t)sizeof(float);
 }
 
-extern "C" int fp_conv3x3_bf3(const fp_conv_desc* d, const float* src, const float* src1, const void* wpacked_bf3, const float* bias,
-                              const float* addend, const float* addend_mask, const float* actsrc, float* y, void* workspace,
-                              int64_t workspace_bytes, fp_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  FP_REQUIRE(d && src && wpacked_bf3 && y, "fp_conv3x3_bf3: null pointer");
+namespace {
+struct HpSlots { const unsigned* a; const unsigned* a1; const unsigned* w; unsigned* out; };
+
+int run_tile3(const char* who, const fp_conv_desc* d, const float* src, const float* src1, const void* wpacked, const float* bias,
+              const float* addend, const float* addend_mask, const float* actsrc, float* y, void* workspace, int64_t workspace_bytes,
+              const HpSlots* hp, hipStream_t stream) {
+  FP_REQUIRE(d && src && wpacked && y, "fp_conv3x3_bf3 / fp_conv3x3_hp: null pointer");
   const Plan3 p = plan3(d);
-  FP_REQUIRE(p.ok, "fp_conv3x3_bf3: shape not supported (see fp_conv3x3_bf3_supported)");
-  FP_REQUIRE(!(d->epi & FP_EPI_BIAS) || bias, "fp_conv3x3_bf3: bias missing");
-  FP_REQUIRE(!(d->epi & FP_EPI_ADDEND) || addend, "fp_conv3x3_bf3: addend missing");
-  FP_REQUIRE(!(d->epi & FP_EPI_ADDEND_MASK) || addend_mask, "fp_conv3x3_bf3: addend_mask missing");
-  FP_REQUIRE(!(d->epi & (FP_EPI_ACTGRAD_ELU | FP_EPI_ACTGRAD_RELU)) || actsrc, "fp_conv3x3_bf3: actsrc missing");
-  FP_REQUIRE(p.SK <= 1 || (workspace && workspace_bytes >= fp_conv3x3_bf3_workspace(d)), "fp_conv3x3_bf3: workspace too small");
-  FP_REQUIRE((int64_t)d->N * d->OH * d->OW * d->Nout < ((int64_t)1 << 31), "fp_conv3x3_bf3: output larger than 2^31 elements");
+  FP_REQUIRE(p.ok, "fp_conv3x3_bf3 / fp_conv3x3_hp: shape not supported (see fp_conv3x3_bf3_supported)");
+  FP_REQUIRE(!(d->epi & FP_EPI_BIAS) || bias, "fp_conv3x3_bf3 / fp_conv3x3_hp: bias missing");
+  FP_REQUIRE(!(d->epi & FP_EPI_ADDEND) || addend, "fp_conv3x3_bf3 / fp_conv3x3_hp: addend missing");
+  FP_REQUIRE(!(d->epi & FP_EPI_ADDEND_MASK) || addend_mask, "fp_conv3x3_bf3 / fp_conv3x3_hp: addend_mask missing");
+  FP_REQUIRE(!(d->epi & (FP_EPI_ACTGRAD_ELU | FP_EPI_ACTGRAD_RELU)) || actsrc, "fp_conv3x3_bf3 / fp_conv3x3_hp: actsrc missing");
+  FP_REQUIRE(p.SK <= 1 || (workspace && workspace_bytes >= fp_conv3x3_bf3_workspace(d)), "fp_conv3x3_bf3 / fp_conv3x3_hp: workspace too small");
+  FP_REQUIRE((int64_t)d->N * d->OH * d->OW * d->Nout < ((int64_t)1 << 31), "fp_conv3x3_bf3 / fp_conv3x3_hp: output larger than 2^31 elements");
   Tile3Args a;
   const bool up2 = d->gather == FP_GATHER_FWD_REFLECT_UP2;
-  FP_REQUIRE(!up2 || d->C1 == 0 || src1, "fp_conv3x3_bf3: the concat gather needs the skip tensor (src1)");
+  FP_REQUIRE(!up2 || d->C1 == 0 || src1, "fp_conv3x3_bf3 / fp_conv3x3_hp: the concat gather needs the skip tensor (src1)");
   a.src_lo = up2 ? src : nullptr; a.Clo = up2 ? d->C0 : 0;
-  a.src = up2 ? (d->C1 ? src1 : src) : src; a.w = (const unsigned short*)wpacked_bf3; a.bias = bias; a.addend = addend; a.addend_mask = addend_mask; a.actsrc = actsrc;
+  a.src = up2 ? (d->C1 ? src1 : src) : src; a.w = (const unsigned short*)wpacked; a.bias = bias; a.addend = addend; a.addend_mask = addend_mask; a.actsrc = actsrc;
   a.y = y;
   a.N = d->N; a.OH = d->OH; a.OW = d->OW; a.IH = d->IH; a.IW = d->IW; a.C = d->C0 + d->C1; a.Nout = d->Nout;
   a.KC16 = (d->C0 + d->C1 + 15) / 16;
   const bool flip = d->gather == FP_GATHER_DGRAD_ZERO || d->gather == FP_GATHER_DGRAD_REFLECT;
   const bool fold = d->gather == FP_GATHER_DGRAD_REFLECT;
   a.mode = (d->gather == FP_GATHER_FWD_REFLECT || up2) ? 1 : 0;
-  a.act = d->act; a.epi = d->epi;
+  a.act = d->act; a.epi = d->epi & ~FP_EPI_BF16X2;
   a.tilesX = p.tilesX; a.tilesY = p.tilesY; a.tilesN = p.tilesN; a.SK = p.SK; a.chunksPerSplit = p.chunksPerSplit;
   a.part = (float*)workspace;
-  a.wmajor = (int64_t)9 * (d->C0 + d->C1) * d->Nout * 6 > ((int64_t)4 << 20);
+  a.amax_a = hp ? hp->a : nullptr; a.amax_a1 = hp && up2 && d->C1 ? hp->a1 : nullptr; a.amax_w = hp ? hp->w : nullptr;
+  a.amax_out = hp ? hp->out : nullptr;
+  const int planes = hp ? 4 : 6;                    // bytes of packed weight per element
+  a.wmajor = (int64_t)9 * (d->C0 + d->C1) * d->Nout * planes > ((int64_t)4 << 20);
   a.nwg = d->N * p.tilesY * p.tilesX * p.tilesN * p.SK;
   int rc;
-#define FP_L3(TH_, TW_)                                                                                                       \
-  (p.bn == 32 ? (fold ? launch3<TH_, TW_, 32, 4, 1, true, true>(a, stream)                                                    \
-                      : (flip ? launch3<TH_, TW_, 32, 4, 1, true, false>(a, stream) : launch3<TH_, TW_, 32, 4, 1, false, false>(a, stream))) \
-              : (fold ? launch3<TH_, TW_, 64, 2, 2, true, true>(a, stream)                                                    \
-                      : (flip ? launch3<TH_, TW_, 64, 2, 2, true, false>(a, stream) : launch3<TH_, TW_, 64, 2, 2, false, false>(a, stream))))
-  if ((d->epi & FP_EPI_BF16X2) && !flip) {          // opt-in inference mode: two bf16 terms per operand, three products (forward only)
-    a.epi &= ~FP_EPI_BF16X2;
+#define FP_L3X(TH_, TW_, NP_, HP_)                                                                                            \
+  (p.bn == 32 ? (fold ? launch3<TH_, TW_, 32, 4, 1, true, true, NP_, HP_>(a, stream)                                          \
+                      : (flip ? launch3<TH_, TW_, 32, 4, 1, true, false, NP_, HP_>(a, stream)                                 \
+                              : launch3<TH_, TW_, 32, 4, 1, false, false, NP_, HP_>(a, stream)))                              \
+              : (fold ? launch3<TH_, TW_, 64, 2, 2, true, true, NP_, HP_>(a, stream)                                          \
+                      : (flip ? launch3<TH_, TW_, 64, 2, 2, true, false, NP_, HP_>(a, stream)                                 \
+                              : launch3<TH_, TW_, 64, 2, 2, false, false, NP_, HP_>(a, stream))))
+  if (hp) {
+    rc = p.th == 8 ? FP_L3X(8, 16, 2, true) : FP_L3X(6, 20, 2, true);
+  } else if ((d->epi & FP_EPI_BF16X2) && !flip) {   // opt-in inference mode: two bf16 terms per operand, three products (forward only)
     if (p.th == 8) rc = p.bn == 32 ? launch3<8, 16, 32, 4, 1, false, false, 2>(a, stream) : launch3<8, 16, 64, 2, 2, false, false, 2>(a, stream);
     else rc = p.bn == 32 ? launch3<6, 20, 32, 4, 1, false, false, 2>(a, stream) : launch3<6, 20, 64, 2, 2, false, false, 2>(a, stream);
   } else {
-    a.epi &= ~FP_EPI_BF16X2;
-    rc = p.th == 8 ? FP_L3(8, 16) : FP_L3(6, 20);
+    rc = p.th == 8 ? FP_L3X(8, 16, 3, false) : FP_L3X(6, 20, 3, false);
   }
-#undef FP_L3
+#undef FP_L3X
+  (void)who;
   if (rc || p.SK <= 1) return rc;
-  return fp_splitk_reduce_launch(a.part, p.SK, (int64_t)d->N * d->OH * d->OW, d->Nout, bias, addend, addend_mask, actsrc, y, d->act, d->epi & ~FP_EPI_BF16X2,
-                                 stream);
+  rc = fp_splitk_reduce_launch(a.part, p.SK, (int64_t)d->N * d->OH * d->OW, d->Nout, bias, addend, addend_mask, actsrc, y, d->act,
+                               d->epi & ~FP_EPI_BF16X2, stream);
+  if (rc || !hp || !hp->out) return rc;
+  return fp_amax_f32(y, (int64_t)d->N * d->OH * d->OW * d->Nout, hp->out, (fp_stream_t)stream);     // split-K launches publish their amax here
+}
+}  // namespace
+
+extern "C" int fp_conv3x3_bf3(const fp_conv_desc* d, const float* src, const float* src1, const void* wpacked_bf3, const float* bias,
+                              const float* addend, const float* addend_mask, const float* actsrc, float* y, void* workspace,
+                              int64_t workspace_bytes, fp_stream_t stream_) {
+  return run_tile3("fp_conv3x3_bf3", d, src, src1, wpacked_bf3, bias, addend, addend_mask, actsrc, y, workspace, workspace_bytes, nullptr,
+                   (hipStream_t)stream_);
+}
+
+// Same operation with fp16-pair operands (fp_common.h): weights from fp_pack_conv_weight_hp / FP_PACK_{FWD,DGRAD}_HP jobs with the
+// slot `amax_w` they were scaled by; `amax_src` (and `amax_src1` for the skip tensor of the concat gather) hold max |x| of the
+// source tensor(s) -- fp_amax_f32 or a producer's `amax_out`; `amax_out` (optional, zeroed by the caller) receives max |y|.
+extern "C" int fp_conv3x3_hp(const fp_conv_desc* d, const float* src, const float* src1, const void* wpacked_hp, const float* bias,
+                             const float* addend, const float* addend_mask, const float* actsrc, float* y, void* workspace,
+                             int64_t workspace_bytes, const uint32_t* amax_src, const uint32_t* amax_src1, const uint32_t* amax_w,
+                             uint32_t* amax_out, fp_stream_t stream_) {
+  FP_REQUIRE(amax_src && amax_w, "fp_conv3x3_hp: amax slots missing");
+  FP_REQUIRE(!(d && d->gather == FP_GATHER_FWD_REFLECT_UP2 && d->C1) || amax_src1, "fp_conv3x3_hp: the skip tensor's amax slot is missing");
+  const HpSlots hp = {amax_src, amax_src1, amax_w, amax_out};
+  return run_tile3("fp_conv3x3_hp", d, src, src1, wpacked_hp, bias, addend, addend_mask, actsrc, y, workspace, workspace_bytes, &hp,
+                   (hipStream_t)stream_);
 }

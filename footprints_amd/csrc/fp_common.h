@@ -156,6 +156,40 @@ __device__ __forceinline__ float fp_elu(float v) {
   return v > -0.25f ? p : __expf(v) - 1.f;
 }
 
+// ---- fp16-pair ("hp") operands ----------------------------------------------------------------------------
+// x * 2^k = h + m with h = fp16(x * 2^k), m = fp16(x * 2^k - h): 11 + 11 significant bits (relative error <= 2^-22, ~2^-23.5 rms);
+// the four products hh, hm, mh, mm are exact in the fp32 accumulator of v_mfma_f32_32x32x16_f16.  k is a per-tensor power of two
+// taken from the tensor's largest magnitude (an "amax slot": FP_AMAX_SLOTS uint32 holding float bit patterns of |x|, combined
+// with max; producers publish into slot[id % FP_AMAX_SLOTS] with atomicMax, so same-address traffic stays low), which maps that
+// magnitude to [2^target, 2^(target+1)): no overflow (fp16 max 65504), and anything above 2^-24 / 2^k is still represented, i.e.
+// the absolute error floor is 2^-37 of the tensor's largest element.  Scaling by powers of two is exact and undone in the epilogue.
+static_assert(FP_AMAX_SLOTS == 16, "amax slot width (include/footprints_hip.h)");
+constexpr int FP_HP_TARGET_ACT = 12;    // activations / gradients: amax -> [2^12, 2^13)
+constexpr int FP_HP_TARGET_W = 11;      // weights: amax -> [2^11, 2^12) (the nearest-x2 phase kernels add up to four of them)
+__device__ __forceinline__ unsigned fp_amax_bits(const unsigned* __restrict__ slot) {
+  unsigned m = 0;
+#pragma unroll
+  for (int i = 0; i < FP_AMAX_SLOTS; ++i) m = max(m, slot[i]);
+  return m;
+}
+// exponent k with amax * 2^k in [2^target, 2^(target+1)); 0 for an all-zero tensor; inf / nan propagate through the data itself
+__device__ __forceinline__ int fp_hp_exponent(unsigned amax_bits, int target) {
+  return amax_bits ? target - ((int)(amax_bits >> 23) - 127) : 0;
+}
+// publish a magnitude into an amax slot.  Same-address atomics serialise at ~2 ns each (11 520 waves: +64 us on a 100 us kernel), so
+// the slot is read first (agent scope: from L2, a stale value only costs a redundant atomic) and only record-setting values
+// issue the atomic: ~ln(n) per sub-slot.
+__device__ __forceinline__ void fp_amax_publish(unsigned* slot, unsigned id, float m) {
+  unsigned* s = slot + id % FP_AMAX_SLOTS;
+  const unsigned bits = __float_as_uint(m);
+  if (bits > __hip_atomic_load(s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(s, bits);
+}
+__device__ __forceinline__ float fp_wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
 // ---- wave / block reductions (wave = 64) ---------------------------------------------------------------
 __device__ __forceinline__ float fp_wave_sum(float v) {
 #pragma unroll

@@ -423,3 +423,40 @@ extern "C" int fp_fill(float* x, int64_t n, float value, fp_stream_t stream) {
   fp_launch(fill_kernel, dim3(ew_grid((size_t)n)), dim3(256), 0, (hipStream_t)stream, x, (size_t)n, value);
   return fp_check_launch("fp_fill");
 }
+
+// ---- amax slots of the fp16-pair operand format (fp_common.h) -----------------------------------------------------------
+namespace {
+__global__ void __launch_bounds__(256) amax_kernel(const float* __restrict__ x, size_t n, unsigned* __restrict__ slot) {
+  const size_t n4 = n >> 2;
+  float m = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(x[(n4 << 2) + threadIdx.x]));
+  m = fp_wave_max(m);
+  __shared__ float wm[4];
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+    fp_amax_publish(slot, blockIdx.x, m);
+  }
+}
+__global__ void __launch_bounds__(256) zero_u32_kernel(unsigned* __restrict__ p, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = 0u;
+}
+}  // namespace
+
+extern "C" int fp_zero_u32(uint32_t* p, int64_t n, fp_stream_t stream) {
+  FP_REQUIRE(p && n > 0, "fp_zero_u32: bad arguments");
+  fp_launch(zero_u32_kernel, dim3(ew_grid((size_t)n, 64)), dim3(256), 0, (hipStream_t)stream, p, (size_t)n);
+  return fp_check_launch("fp_zero_u32");
+}
+
+extern "C" int fp_amax_f32(const float* x, int64_t n, uint32_t* slot, fp_stream_t stream) {
+  FP_REQUIRE(x && slot && n > 0, "fp_amax_f32: bad arguments");
+  FP_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, "fp_amax_f32: x must be 16-byte aligned");
+  fp_launch(amax_kernel, dim3(ew_grid((size_t)n / 16 + 1, 1024)), dim3(256), 0, (hipStream_t)stream, x, (size_t)n, slot);
+  return fp_check_launch("fp_amax_f32");
+}

@@ -16,6 +16,7 @@ __device__ __forceinline__ float pack_elem(const fp_pack_job& j, size_t e) {
   const int kr = (int)(e & 15);
   size_t r = e >> 4;
   switch (j.kind) {
+    case FP_PACK_FWD_HP:
     case FP_PACK_FWD_BF3:
     case FP_PACK_FWD: {
       const int T = j.KH * j.KW, KC16 = (j.c_count + 15) / 16;
@@ -24,6 +25,7 @@ __device__ __forceinline__ float pack_elem(const fp_pack_job& j, size_t e) {
       const int k = kc * 16 + kr;
       return k < j.c_count ? w[((size_t)n * j.Cin + j.c_begin + k) * T + tap] : 0.f;
     }
+    case FP_PACK_DGRAD_HP:
     case FP_PACK_DGRAD_BF3:
     case FP_PACK_DGRAD: {
       const int T = j.KH * j.KW, KC16 = (j.Cout + 15) / 16;
@@ -39,6 +41,7 @@ __device__ __forceinline__ float pack_elem(const fp_pack_job& j, size_t e) {
       const int ky = kk / 21, rem = kk - ky * 21, kx = rem / 3, ci = rem - kx * 3;
       return w[((n * 3 + ci) * 7 + ky) * 7 + kx];
     }
+    case FP_PACK_UP2_FWD_HP:
     case FP_PACK_UP2_FWD_BF3:
     case FP_PACK_UP2_FWD: {
       const int KC16 = (j.c_count + 15) / 16;
@@ -73,6 +76,7 @@ __device__ __forceinline__ float pack_elem(const fp_pack_job& j, size_t e) {
         for (int kx = kx_lo; kx <= kx_hi; ++kx) v += wk[ky * 3 + kx];
       return v;
     }
+    case FP_PACK_UP2_DGRAD_HP:
     case FP_PACK_UP2_DGRAD_BF3: {   // [phase 4][tap 4][KC16 over Cout][c][16 n]: K4[(py+1)%2 + 2a][(px+1)%2 + 2b][n][c]
       const int KC16 = (j.Cout + 15) / 16;
       const int c = (int)(r % j.c_count); r /= j.c_count;
@@ -96,13 +100,17 @@ __device__ __forceinline__ float pack_elem(const fp_pack_job& j, size_t e) {
 __host__ __device__ inline int64_t pack_elems(int kind, int Cout, int KH, int KW, int c_count) {
   const int64_t T = (int64_t)KH * KW;
   switch (kind) {
+    case FP_PACK_FWD_HP:
     case FP_PACK_FWD_BF3:
     case FP_PACK_FWD: return T * ((c_count + 15) / 16) * Cout * 16;
+    case FP_PACK_DGRAD_HP:
     case FP_PACK_DGRAD_BF3:
     case FP_PACK_DGRAD: return T * ((Cout + 15) / 16) * c_count * 16;
     case FP_PACK_STEM: return 10 * 64 * 16;
+    case FP_PACK_UP2_FWD_HP:
     case FP_PACK_UP2_FWD_BF3:
     case FP_PACK_UP2_FWD: return (int64_t)16 * ((c_count + 15) / 16) * Cout * 16;
+    case FP_PACK_UP2_DGRAD_HP:
     case FP_PACK_UP2_DGRAD_BF3:
     case FP_PACK_UP2_DGRAD: return (int64_t)16 * ((Cout + 15) / 16) * c_count * 16;
     default: return 0;
@@ -116,7 +124,21 @@ __device__ __forceinline__ unsigned short bf16_rne(float x) {
   u += 0x7FFFu + ((u >> 16) & 1u);
   return (unsigned short)(u >> 16);
 }
-__device__ __forceinline__ void pack_store(const fp_pack_job& j, size_t e, float v) {
+__device__ __forceinline__ bool pack_is_hp(int kind) {
+  return kind == FP_PACK_FWD_HP || kind == FP_PACK_DGRAD_HP || kind == FP_PACK_UP2_FWD_HP || kind == FP_PACK_UP2_DGRAD_HP;
+}
+// *_HP layouts: v * 2^kw (kw from the weight tensor's amax slot, FP_HP_TARGET_W) as an fp16 pair, planes [tap][chunk][2][ncols][16]
+__device__ __forceinline__ void pack_store(const fp_pack_job& j, size_t e, float v, int kw) {
+  if (pack_is_hp(j.kind)) {
+    const size_t ncols = (j.kind == FP_PACK_DGRAD_HP || j.kind == FP_PACK_UP2_DGRAD_HP) ? j.c_count : j.Cout;
+    const size_t k = e & 15, n = (e >> 4) % ncols, blk = (e >> 4) / ncols;
+    _Float16* o = reinterpret_cast<_Float16*>(j.wp) + (blk * 2 * ncols + n) * 16 + k;
+    const float vs = ldexpf(v, kw);
+    const _Float16 h = (_Float16)vs;
+    o[0] = h;
+    o[ncols * 16] = (_Float16)(vs - (float)h);
+    return;
+  }
   if (j.kind != FP_PACK_FWD_BF3 && j.kind != FP_PACK_DGRAD_BF3 && j.kind != FP_PACK_UP2_FWD_BF3 && j.kind != FP_PACK_UP2_DGRAD_BF3) {
     j.wp[e] = v;
     return;
@@ -134,7 +156,8 @@ __device__ __forceinline__ void pack_store(const fp_pack_job& j, size_t e, float
 }
 
 __global__ void __launch_bounds__(256) pack_one_kernel(const fp_pack_job j, size_t total) {
-  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) pack_store(j, e, pack_elem(j, e));
+  const int kw = pack_is_hp(j.kind) ? fp_hp_exponent(fp_amax_bits(j.amax), FP_HP_TARGET_W) : 0;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) pack_store(j, e, pack_elem(j, e), kw);
 }
 
 // block b serves job blk2job[b]; a job's blocks are contiguous starting at jobs[job].block_begin
@@ -143,12 +166,35 @@ __global__ void __launch_bounds__(256) pack_batched_kernel(const fp_pack_job* __
   const fp_pack_job j = jobs[ji];
   const size_t total = (size_t)pack_elems(j.kind, j.Cout, j.KH, j.KW, j.c_count);
   const size_t stride = (size_t)j.block_count * 256;
-  for (size_t e = (size_t)(blockIdx.x - j.block_begin) * 256 + threadIdx.x; e < total; e += stride) pack_store(j, e, pack_elem(j, e));
+  const int kw = pack_is_hp(j.kind) ? fp_hp_exponent(fp_amax_bits(j.amax), FP_HP_TARGET_W) : 0;
+  for (size_t e = (size_t)(blockIdx.x - j.block_begin) * 256 + threadIdx.x; e < total; e += stride) pack_store(j, e, pack_elem(j, e), kw);
+}
+
+// amax of every fp16-pair job's raw weight tensor into the job's slot (jobs of one tensor share a slot; slots zeroed by the caller)
+__global__ void __launch_bounds__(256) pack_amax_kernel(const fp_pack_job* __restrict__ jobs, const int32_t* __restrict__ blk2job) {
+  const int ji = blk2job[blockIdx.x];
+  const fp_pack_job j = jobs[ji];
+  if (!pack_is_hp(j.kind)) return;                    // uniform per block
+  const size_t total = (size_t)j.Cout * j.Cin * j.KH * j.KW, stride = (size_t)j.block_count * 256;
+  float m = 0.f;
+  for (size_t e = (size_t)(blockIdx.x - j.block_begin) * 256 + threadIdx.x; e < total; e += stride) m = fmaxf(m, fabsf(j.w[e]));
+  m = fp_wave_max(m);
+  if ((threadIdx.x & 63) == 0) fp_amax_publish(j.amax, blockIdx.x * 4 + (threadIdx.x >> 6), m);
+}
+__global__ void __launch_bounds__(256) pack_amax_one_kernel(const float* __restrict__ w, size_t total, unsigned* __restrict__ slot) {
+  float m = 0.f;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) m = fmaxf(m, fabsf(w[e]));
+  m = fp_wave_max(m);
+  if ((threadIdx.x & 63) == 0) fp_amax_publish(slot, blockIdx.x * 4 + (threadIdx.x >> 6), m);
+}
+__global__ void __launch_bounds__(64) pack_zero_slot_kernel(unsigned* __restrict__ slot) {
+  if (threadIdx.x < FP_AMAX_SLOTS) slot[threadIdx.x] = 0u;
 }
 
 int launch_one(int kind, const float* w, float* wp, int Cout, int Cin, int KH, int KW, int c_begin, int c_count, hipStream_t stream,
-               const char* what) {
+               const char* what, uint32_t* amax = nullptr) {
   fp_pack_job j;
+  j.amax = amax;
   j.w = w; j.wp = wp; j.Cout = Cout; j.Cin = Cin; j.KH = KH; j.KW = KW; j.kind = kind; j.c_begin = c_begin; j.c_count = c_count;
   j.block_begin = 0; j.block_count = 0;
   const size_t total = (size_t)pack_elems(kind, Cout, KH, KW, c_count);
@@ -175,6 +221,35 @@ extern "C" int fp_pack_conv_weight_bf3(const float* w_oihw, void* wp, int32_t Co
   return launch_one(for_dgrad ? FP_PACK_DGRAD_BF3 : FP_PACK_FWD_BF3, w_oihw, (float*)wp, Cout, Cin, KH, KW, 0, Cin, (hipStream_t)stream,
                     "fp_pack_conv_weight_bf3");
 }
+// ---- fp16-pair layouts (two fp16 per weight = one float of storage) --------------------------------------------------------
+extern "C" int64_t fp_packed_weight_elems_hp(int32_t Cout, int32_t Cin, int32_t KH, int32_t KW, int32_t for_dgrad) {
+  return pack_elems(for_dgrad ? FP_PACK_DGRAD_HP : FP_PACK_FWD_HP, Cout, KH, KW, Cin);
+}
+// fills the weight tensor's amax slot (zero + reduce) unless `amax_ready`, then packs
+extern "C" int fp_weight_amax(const float* w, int64_t n, uint32_t* amax_slot, fp_stream_t stream) {
+  FP_REQUIRE(w && amax_slot && n > 0, "fp_weight_amax: bad arguments");
+  fp_launch(pack_zero_slot_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, amax_slot);
+  size_t g = ((size_t)n + 2047) / 2048;
+  if (g > 1024) g = 1024;
+  fp_launch(pack_amax_one_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, w, (size_t)n, amax_slot);
+  return fp_check_launch("fp_weight_amax");
+}
+extern "C" int fp_pack_conv_weight_hp(const float* w_oihw, void* wp, int32_t Cout, int32_t Cin, int32_t KH, int32_t KW, int32_t for_dgrad,
+                                      uint32_t* amax_slot, int32_t amax_ready, fp_stream_t stream) {
+  FP_REQUIRE(w_oihw && wp && amax_slot, "fp_pack_conv_weight_hp: null pointer");
+  if (!amax_ready) {
+    const int rc = fp_weight_amax(w_oihw, (int64_t)Cout * Cin * KH * KW, amax_slot, stream);
+    if (rc) return rc;
+  }
+  return launch_one(for_dgrad ? FP_PACK_DGRAD_HP : FP_PACK_FWD_HP, w_oihw, (float*)wp, Cout, Cin, KH, KW, 0, Cin, (hipStream_t)stream,
+                    "fp_pack_conv_weight_hp", amax_slot);
+}
+extern "C" int fp_pack_weights_amax(const fp_pack_job* jobs_dev, const int32_t* blk2job_dev, int32_t nblocks, fp_stream_t stream) {
+  FP_REQUIRE(jobs_dev && blk2job_dev && nblocks > 0, "fp_pack_weights_amax: bad arguments");
+  fp_launch(pack_amax_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, jobs_dev, blk2job_dev);
+  return fp_check_launch("fp_pack_weights_amax");
+}
+
 extern "C" int64_t fp_up2_packed_weight_elems(int32_t Ncols, int32_t K) { return pack_elems(FP_PACK_UP2_FWD, Ncols, 3, 3, K); }
 extern "C" int fp_pack_up2_weight_dgrad_bf3(const float* w_oihw, void* wp, int32_t Cout, int32_t Cin, int32_t c_begin, int32_t c_count,
                                             fp_stream_t stream) {

@@ -155,6 +155,64 @@ def conv3x3_bf3(desc, src, wpacked_bf3, y, bias=None, addend=None, addend_mask=N
     return y
 
 
+# ---- fp16-pair operands (include/footprints_hip.h "hp"): amax slots are int32 tensors of AMAX_SLOTS elements ---------------------
+AMAX_SLOTS = 16
+
+
+def _u32(t, what="slot"):
+    if t is None:
+        return 0
+    if t.dtype != torch.int32 or not t.is_cuda or t.numel() < AMAX_SLOTS:
+        raise RuntimeError("footprints_amd: %s must be a CUDA int32 tensor of >= %d elements" % (what, AMAX_SLOTS))
+    return t.data_ptr()
+
+
+def zero_u32(t):
+    _lib.check(_lib.load().fp_zero_u32(t.data_ptr(), t.numel(), stream()), "fp_zero_u32")
+    return t
+
+
+def amax_f32(x, slot):
+    """slot (zeroed by the caller) <- max |x| (bit pattern, spread over AMAX_SLOTS sub-slots)"""
+    _lib.check(_lib.load().fp_amax_f32(_f32(x, "x"), x.numel(), _u32(slot), stream()), "fp_amax_f32")
+    return slot
+
+
+def amax_value(slot):
+    """host-side read of a slot (tests / debugging): the float it encodes"""
+    return float(slot[:AMAX_SLOTS].max().view(torch.int32).cpu().view(torch.float32))
+
+
+def packed_weight_elems_hp(Cout, Cin, K, for_dgrad=False):
+    return int(_lib.load().fp_packed_weight_elems_hp(Cout, Cin, K, K, int(for_dgrad)))
+
+
+def pack_conv_weight_hp(w, wp, slot, for_dgrad=False, amax_ready=False):
+    Cout, Cin, KH, KW = w.shape
+    _lib.check(_lib.load().fp_pack_conv_weight_hp(_f32(w), _f32(wp), Cout, Cin, KH, KW, int(for_dgrad), _u32(slot), int(amax_ready), stream()),
+               "fp_pack_conv_weight_hp")
+    return wp
+
+
+def conv3x3_hp(desc, src, wpacked_hp, y, amax_src, amax_w, amax_out=None, bias=None, addend=None, addend_mask=None, actsrc=None, src1=None,
+               amax_src1=None):
+    """conv3x3_bf3 with fp16-pair operands; amax_* are slots (see amax_f32); amax_out (zeroed by the caller) receives max |y|"""
+    epi = desc.epi | (_lib.EPI_BIAS if bias is not None else 0) | (_lib.EPI_ADDEND if addend is not None else 0) | \
+        (_lib.EPI_ADDEND_MASK if addend_mask is not None else 0)
+    lib = _lib.load()
+    d = ConvDesc.from_buffer_copy(desc)
+    d.epi = epi
+    need = _cached_query("fp_conv3x3_bf3_workspace", d)
+    ws_ptr, ws_n = 0, 0
+    if need > 0:
+        ws = workspace(need, y.device, "igemm")
+        ws_ptr, ws_n = ws.data_ptr(), ws.numel()
+    _lib.check(lib.fp_conv3x3_hp(C.byref(d), _f32(src, "src"), _f32(src1, "src1"), _f32(wpacked_hp, "wpacked"), _f32(bias), _f32(addend),
+                                 _f32(addend_mask), _f32(actsrc), _f32(y, "y"), ws_ptr, ws_n, _u32(amax_src, "amax_src"),
+                                 _u32(amax_src1, "amax_src1"), _u32(amax_w, "amax_w"), _u32(amax_out, "amax_out"), stream()), "fp_conv3x3_hp")
+    return y
+
+
 def packed_weight_elems_bf3(Cout, Cin, K, for_dgrad=False):
     return int(_lib.load().fp_packed_weight_elems_bf3(Cout, Cin, K, K, int(for_dgrad)))
 

@@ -94,7 +94,8 @@ int fp_conv_wgrad(const fp_conv_desc* d, const float* src0, const float* src1, c
 /* One repacking job of fp_pack_weights_batched: every convolution's packed copies are refreshed by ONE launch after the
  * optimizer step (the table lives in device memory and is built once: parameter and packed buffers never move). */
 enum { FP_PACK_FWD = 0, FP_PACK_DGRAD = 1, FP_PACK_STEM = 2, FP_PACK_UP2_FWD = 3, FP_PACK_UP2_DGRAD = 4,
-       FP_PACK_FWD_BF3 = 5, FP_PACK_DGRAD_BF3 = 6, FP_PACK_UP2_FWD_BF3 = 7, FP_PACK_UP2_DGRAD_BF3 = 8 /* bf16x3 split planes, see fp_conv3x3_bf3 */ };
+       FP_PACK_FWD_BF3 = 5, FP_PACK_DGRAD_BF3 = 6, FP_PACK_UP2_FWD_BF3 = 7, FP_PACK_UP2_DGRAD_BF3 = 8, /* bf16x3 split planes, see fp_conv3x3_bf3 */
+       FP_PACK_FWD_HP = 9, FP_PACK_DGRAD_HP = 10, FP_PACK_UP2_FWD_HP = 11, FP_PACK_UP2_DGRAD_HP = 12 /* scaled fp16 pairs, see fp_conv3x3_hp */ };
 typedef struct fp_pack_job {
   const float* w;  /* [Cout][Cin][KH][KW] */
   float* wp;       /* packed destination */
@@ -102,6 +103,7 @@ typedef struct fp_pack_job {
   int32_t kind;             /* FP_PACK_* */
   int32_t c_begin, c_count; /* input-channel slice (whole tensor: 0, Cin) */
   int32_t block_begin, block_count; /* this job's contiguous range of workgroups in the batched launch */
+  uint32_t* amax;           /* *_HP kinds: the weight tensor's amax slot (FP_AMAX_SLOTS uint32, shared by all jobs of the tensor) */
 } fp_pack_job;
 int32_t fp_pack_job_blocks(int32_t kind, int32_t Cout, int32_t KH, int32_t KW, int32_t c_count);
 int fp_pack_weights_batched(const fp_pack_job* jobs_dev, const int32_t* blk2job_dev, int32_t nblocks, fp_stream_t stream);
@@ -131,6 +133,27 @@ int fp_conv3x3_bf3(const fp_conv_desc* d, const float* src, const float* src1, c
 int64_t fp_packed_weight_elems_bf3(int32_t Cout, int32_t Cin, int32_t KH, int32_t KW, int32_t for_dgrad);
 int fp_pack_conv_weight_bf3(const float* w_oihw, void* wp, int32_t Cout, int32_t Cin, int32_t KH, int32_t KW,
                             int32_t for_dgrad, fp_stream_t stream);
+
+/* ---- fp16-pair operands ("hp"): x * 2^k = h + m, h = fp16(x * 2^k), m = fp16(x * 2^k - h) -- 22 significant bits after a per-tensor
+ * power-of-two scaling taken from the tensor's largest magnitude; four fp16 products (hh + hm + mh + mm, exact in the fp32
+ * accumulator of v_mfma_f32_32x32x16_f16) instead of the six of the exact split and two operand planes instead of three.
+ * An "amax slot" is FP_AMAX_SLOTS = 16 uint32 holding float bit patterns of |x| (combined with max): zero it (fp_zero_u32), then
+ * either reduce a tensor into it (fp_amax_f32) or let the kernel that produces the tensor publish into it (`amax_out`). */
+#define FP_AMAX_SLOTS 16
+int fp_zero_u32(uint32_t* p, int64_t n, fp_stream_t stream);
+int fp_amax_f32(const float* x, int64_t n, uint32_t* slot, fp_stream_t stream);          /* x 16-byte aligned; slot zeroed by the caller */
+int fp_weight_amax(const float* w, int64_t n, uint32_t* amax_slot, fp_stream_t stream);  /* zero + reduce */
+int64_t fp_packed_weight_elems_hp(int32_t Cout, int32_t Cin, int32_t KH, int32_t KW, int32_t for_dgrad);   /* floats of storage */
+int fp_pack_conv_weight_hp(const float* w_oihw, void* wp, int32_t Cout, int32_t Cin, int32_t KH, int32_t KW, int32_t for_dgrad,
+                           uint32_t* amax_slot, int32_t amax_ready, fp_stream_t stream);
+int fp_pack_weights_amax(const fp_pack_job* jobs_dev, const int32_t* blk2job_dev, int32_t nblocks, fp_stream_t stream);
+/* fp_conv3x3_bf3 with fp16-pair operands: same shapes, gathers and epilogue flags; weights from fp_pack_conv_weight_hp /
+ * FP_PACK_{FWD,DGRAD}_HP jobs together with the slot they were scaled by (`amax_w`); `amax_src` (and `amax_src1` for the skip tensor
+ * of FP_GATHER_FWD_REFLECT_UP2) = max |x| of the source tensor(s); `amax_out` (optional, zeroed by the caller) receives max |y|. */
+int fp_conv3x3_hp(const fp_conv_desc* d, const float* src, const float* src1, const void* wpacked_hp, const float* bias,
+                  const float* addend, const float* addend_mask, const float* actsrc, float* y, void* workspace,
+                  int64_t workspace_bytes, const uint32_t* amax_src, const uint32_t* amax_src1, const uint32_t* amax_w,
+                  uint32_t* amax_out, fp_stream_t stream);
 
 /* Weight gradient with the same exactly split operands (wgrad3x3_bf3.hip): 3x3 / stride 1 / pad 1, FWD_ZERO, FWD_REFLECT or
  * FWD_REFLECT_UP2 gather (then x is the half-resolution tensor [N][OH/2][OW/2][C0]: the upsampled half of a concat conv), C1 = 0, C0 and Nout multiples of 32; fp_conv_wgrad_bf3_workspace returns -1 for anything else (use fp_conv_wgrad).
