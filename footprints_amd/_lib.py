@@ -22,6 +22,7 @@ class ConvDesc(C.Structure):
 
 
 PACK_FWD, PACK_DGRAD, PACK_STEM, PACK_UP2_FWD, PACK_UP2_DGRAD, PACK_FWD_BF3, PACK_DGRAD_BF3, PACK_UP2_FWD_BF3, PACK_UP2_DGRAD_BF3 = range(9)
+PACK_FWD_HP, PACK_DGRAD_HP, PACK_UP2_FWD_HP, PACK_UP2_DGRAD_HP = range(9, 13)
 
 
 class PackJob(C.Structure):
@@ -80,6 +81,12 @@ SIGNATURES = {
     "fp_conv3x3_bf3_workspace": (_I64, [_DESC]),
     "fp_conv3x3_bf3": (C.c_int, [_DESC, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
     "fp_packed_weight_elems_bf3": (_I64, [_I32, _I32, _I32, _I32, _I32]),
+    "fp_amax_slot_elems": (_I32, []),
+    "fp_amax_out_next": (C.c_int, [_P]),
+    "fp_conv_wgrad_hp": (C.c_int, [_DESC, _P, _P, _P, _P, _I32, _I32, C.c_int, _P, _I64, _P, _P, _P]),
+    "fp_conv_up2_phase_wgrad_hp": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, C.c_int, _P, _I64, _P, _P, _P]),
+    "fp_conv_up2_phase_fwd_hp": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P]),
+    "fp_conv_up2_phase_dgrad_hp": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P]),
     "fp_zero_u32": (C.c_int, [_P, _I64, _P]),
     "fp_amax_f32": (C.c_int, [_P, _I64, _P, _P]),
     "fp_weight_amax": (C.c_int, [_P, _I64, _P, _P]),

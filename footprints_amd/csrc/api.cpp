@@ -24,3 +24,15 @@ int fp_check_launch(const char* what) {
 
 extern "C" int fp_version(void) { return 1; }
 extern "C" const char* fp_last_error_string(void) { return g_err; }
+
+// amax sink (include/footprints_hip.h, fp_amax_out_next): consumed -- and cleared -- by the next launch of this thread that can publish
+static thread_local uint32_t* g_amax_next = nullptr;
+extern "C" int fp_amax_out_next(uint32_t* slot) {
+  g_amax_next = slot;
+  return FP_OK;
+}
+unsigned* fp_take_amax_out() {
+  unsigned* s = g_amax_next;
+  g_amax_next = nullptr;
+  return s;
+}

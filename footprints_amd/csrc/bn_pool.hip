@@ -119,7 +119,8 @@ __global__ void __launch_bounds__(256) bn_eval_coeffs_kernel(const float* gamma,
 
 __global__ void __launch_bounds__(256) bn_apply_kernel(const float* __restrict__ z, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, const float* __restrict__ res,
-                                                       float* __restrict__ y, size_t total4, int C4, int relu) {
+                                                       float* __restrict__ y, size_t total4, int C4, int relu, unsigned* amax_out) {
+  float ymax = 0.f;
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total4; e += (size_t)gridDim.x * 256) {
     const int cq = (int)(e % C4);
     const float4 v = reinterpret_cast<const float4*>(z)[e];
@@ -132,7 +133,9 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const float* __restrict__
     }
     if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
     reinterpret_cast<float4*>(y)[e] = o;
+    ymax = fp_amax4(ymax, o);
   }
+  if (amax_out) fp_amax_publish_block(amax_out, ymax);
 }
 
 // partial[block][c][2] = (sum g, sum g*xhat), g = dy * (relu_out > 0)
@@ -206,7 +209,8 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ z, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                            const float* __restrict__ coef, float* __restrict__ dz,
-                                                           float* __restrict__ gout, size_t total4, int C4) {
+                                                           float* __restrict__ gout, size_t total4, int C4, unsigned* amax_out) {
+  float ymax = 0.f;
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total4; e += (size_t)gridDim.x * 256) {
     const int cq = (int)(e % C4);
     float4 g = reinterpret_cast<const float4*>(dy)[e];
@@ -227,14 +231,17 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restri
     o.z = ga.z * is.z * (g.z - c23.x - (v.z - mu.z) * is.z * c23.y);
     o.w = ga.w * is.w * (g.w - c23.z - (v.w - mu.w) * is.w * c23.w);
     reinterpret_cast<float4*>(dz)[e] = o;
+    ymax = fp_amax4(ymax, o);
   }
+  if (amax_out) fp_amax_publish_block(amax_out, ymax);
 }
 
 // ---- max-pool 3x3 stride 2 pad 1; argmax = first maximum in (ky,kx) scan order (ATen max_pool2d tie rule) ----
 __global__ void __launch_bounds__(256) maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                          uint8_t* __restrict__ am, int N, int H, int W, int C) {
+                                                          uint8_t* __restrict__ am, int N, int H, int W, int C, unsigned* amax_out) {
   const int OH = (H + 1) / 2, OW = (W + 1) / 2, C4 = C >> 2;
   const size_t total = (size_t)N * OH * OW * C4;
+  float ymax = 0.f;
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
     const int cq = (int)(e % C4);
     size_t r = e / C4;
@@ -263,7 +270,9 @@ __global__ void __launch_bounds__(256) maxpool_fwd_kernel(const float* __restric
     }
     reinterpret_cast<float4*>(y)[e] = make_float4(best[0], best[1], best[2], best[3]);
     reinterpret_cast<uchar4*>(am)[e] = make_uchar4((unsigned char)bi[0], (unsigned char)bi[1], (unsigned char)bi[2], (unsigned char)bi[3]);
+    ymax = fp_amax4(ymax, make_float4(best[0], best[1], best[2], best[3]));
   }
+  if (amax_out) fp_amax_publish_block(amax_out, ymax);
 }
 
 __global__ void __launch_bounds__(256) maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ am,
@@ -309,9 +318,9 @@ __global__ void __launch_bounds__(256) maxpool_bwd_kernel(const float* __restric
 }
 
 bool bn_c_ok(int C) { return C >= 4 && C % 4 == 0 && 256 % (C / 4) == 0 && C / 4 <= 256; }
-int ew_grid(size_t total) {
+int ew_grid(size_t total, size_t cap = 8192) {
   size_t g = (total + 255) / 256;
-  return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
+  return (int)(g > cap ? cap : (g < 1 ? 1 : g));
 }
 
 }  // namespace
@@ -347,8 +356,9 @@ extern "C" int fp_bn_apply(const float* z, const float* scale, const float* shif
                            int32_t C, int32_t relu, fp_stream_t stream) {
   FP_REQUIRE(z && scale && shift && y && C % 4 == 0, "fp_bn_apply: bad arguments");
   const size_t total4 = (size_t)M * (C / 4);
-  fp_launch(bn_apply_kernel, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, z, scale, shift, residual, y,
-                     total4, C / 4, relu);
+  unsigned* amax_out = fp_take_amax_out();
+  fp_launch(bn_apply_kernel, dim3(ew_grid(total4, 8192)), dim3(256), 0, (hipStream_t)stream, z, scale, shift,
+            residual, y, total4, C / 4, relu, amax_out);
   return fp_check_launch("fp_bn_apply");
 }
 
@@ -366,8 +376,9 @@ extern "C" int fp_bn_bwd(const float* dy, const float* relu_out, const float* z,
   fp_launch(bn_bwd_final_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const float*)part, nblk, C,
                      1.f / (float)M, coef, dgamma, dbeta, accumulate);
   const size_t total4 = (size_t)M * (C / 4);
-  fp_launch(bn_bwd_apply_kernel, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, dy, relu_out, z, save_mean,
-                     save_invstd, gamma, (const float*)coef, dz, g_out, total4, C / 4);
+  unsigned* amax_out = fp_take_amax_out();
+  fp_launch(bn_bwd_apply_kernel, dim3(ew_grid(total4, 8192)), dim3(256), 0, (hipStream_t)stream, dy, relu_out, z,
+            save_mean, save_invstd, gamma, (const float*)coef, dz, g_out, total4, C / 4, amax_out);
   return fp_check_launch("fp_bn_bwd");
 }
 
@@ -375,7 +386,9 @@ extern "C" int fp_maxpool_fwd(const float* x, float* y, uint8_t* argmax, int32_t
                               fp_stream_t stream) {
   FP_REQUIRE(x && y && argmax && C % 4 == 0, "fp_maxpool_fwd: bad arguments");
   const size_t total = (size_t)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
-  fp_launch(maxpool_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, y, argmax, N, H, W, C);
+  unsigned* amax_out = fp_take_amax_out();
+  fp_launch(maxpool_fwd_kernel, dim3(ew_grid(total, 8192)), dim3(256), 0, (hipStream_t)stream, x, y, argmax, N, H, W,
+            C, amax_out);
   return fp_check_launch("fp_maxpool_fwd");
 }
 

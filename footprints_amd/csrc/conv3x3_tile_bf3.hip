@@ -17,7 +17,7 @@
 #include "fp_common.h"
 
 int fp_splitk_reduce_launch(const float* part, int SK, int64_t M, int Nout, const float* bias, const float* addend, const float* addend_mask,
-                            const float* actsrc, float* y, int act, unsigned epi, hipStream_t stream);
+                            const float* actsrc, float* y, int act, unsigned epi, hipStream_t stream, unsigned* amax_out = nullptr);
 
 #ifndef FP_BF2_PRODUCTS
 #define FP_BF2_PRODUCTS 3
@@ -476,9 +476,13 @@ __global__ void __launch_bounds__(256) conv3x3_tile_bf3_kernel(const Tile3Args a
         rows8(std::false_type{}, i, j, n, bias, 1);
       }
     }
-  if (HP && a.amax_out && a.SK <= 1) {
+  if (HP && a.amax_out && a.SK <= 1) {               // one publication per workgroup (the halo buffers are free by now)
     ymax = fp_wave_max(ymax);
-    if (lane == 0) fp_amax_publish(a.amax_out, blockIdx.x * 4 + wave, ymax);
+    float* wmax = reinterpret_cast<float*>(lds);
+    __syncthreads();
+    if (lane == 0) wmax[wave] = ymax;
+    __syncthreads();
+    if (t == 0) fp_amax_publish(a.amax_out, blockIdx.x, fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3])));
   }
 #ifdef FP_TILE_STAMPS
   if (a.stamps && lane == 0) {
@@ -634,10 +638,8 @@ int run_tile3(const char* who, const fp_conv_desc* d, const float* src, const fl
 #undef FP_L3X
   (void)who;
   if (rc || p.SK <= 1) return rc;
-  rc = fp_splitk_reduce_launch(a.part, p.SK, (int64_t)d->N * d->OH * d->OW, d->Nout, bias, addend, addend_mask, actsrc, y, d->act,
-                               d->epi & ~FP_EPI_BF16X2, stream);
-  if (rc || !hp || !hp->out) return rc;
-  return fp_amax_f32(y, (int64_t)d->N * d->OH * d->OW * d->Nout, hp->out, (fp_stream_t)stream);     // split-K launches publish their amax here
+  return fp_splitk_reduce_launch(a.part, p.SK, (int64_t)d->N * d->OH * d->OW, d->Nout, bias, addend, addend_mask, actsrc, y, d->act,
+                                 d->epi & ~FP_EPI_BF16X2, stream, hp ? hp->out : nullptr);      // split-K launches publish max |y| here
 }
 }  // namespace
 

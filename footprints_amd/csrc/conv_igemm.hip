@@ -47,6 +47,7 @@ struct IgemmArgs {
   // heaviest first, each class padded to whole tiles: Mc real rows, McP padded), so a workgroup's rows share one class and it
   // walks only that class's taps: 2.25 taps per pixel on average instead of 9 with three quarters of them all-zero.
   int pm, Mc, McP;
+  unsigned* amax_out;     // split-K reduce only: amax slot receiving max |y| (fp16-pair consumers), or null
 };
 
 // row of the parity-major enumeration -> class (cpy, cpx), validity, (n, oy, ox)
@@ -313,6 +314,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmArgs a) {
 // y = epilogue(sum_s part[s]) -- fixed summation order
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(const IgemmArgs a) {
   const size_t total = (size_t)a.M * a.Nout;
+  float ymax = 0.f;
   for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (size_t)gridDim.x * 256) {
     float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;              // four loads in flight, fixed combination order
     int s = 0;
@@ -321,8 +323,11 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const IgemmArgs a) {
       p0 += q[0]; p1 += q[total]; p2 += q[2 * total]; p3 += q[3 * total];
     }
     for (; s < a.SK; ++s) p0 += a.part[(size_t)s * total + o];
-    a.y[o] = igemm_epilogue(a, o, (int)(o % a.Nout), (p0 + p1) + (p2 + p3));
+    const float v = igemm_epilogue(a, o, (int)(o % a.Nout), (p0 + p1) + (p2 + p3));
+    a.y[o] = v;
+    ymax = fmaxf(ymax, fabsf(v));
   }
+  if (a.amax_out) fp_amax_publish_block(a.amax_out, ymax);
 }
 
 // split-K factor for a grid of `tiles` workgroups over `steps` K-steps: fill ~3 workgroups per CU, >= 8 steps each
@@ -364,8 +369,9 @@ constexpr int64_t MAX_SK = 24;
 
 // y = epilogue(sum over `SK` raw partial copies [SK][M][Nout]) in a fixed order -- shared with conv3x3_tile_bf3.hip
 int fp_splitk_reduce_launch(const float* part, int SK, int64_t M, int Nout, const float* bias, const float* addend, const float* addend_mask,
-                            const float* actsrc, float* y, int act, unsigned epi, hipStream_t stream) {
+                            const float* actsrc, float* y, int act, unsigned epi, hipStream_t stream, unsigned* amax_out) {
   IgemmArgs a = {};
+  a.amax_out = amax_out;
   a.part = const_cast<float*>(part); a.SK = SK; a.M = (int)M; a.Nout = Nout;
   a.bias = bias; a.addend = addend; a.addend_mask = addend_mask; a.actsrc = actsrc; a.y = y; a.act = act; a.epi = epi;
   int64_t g = fp_ceil_div(M * Nout, 256);
@@ -421,6 +427,7 @@ extern "C" int fp_conv_igemm(const fp_conv_desc* d, const float* src0, const flo
     }
   }
   IgemmArgs a;
+  a.amax_out = nullptr;
   a.src0 = src0; a.src1 = src1; a.w = wpacked; a.bias = bias; a.addend = addend; a.addend_mask = addend_mask;
   a.actsrc = actsrc; a.y = y;
   a.g = FpGeom{d->N, d->OH, d->OW, d->IH, d->IW, d->C0, d->C1, d->KH, d->KW, d->stride, d->pad, d->gather};

@@ -30,6 +30,9 @@ struct PhaseArgs {
   float* y;             // [N][2h][2w][Nout]
   int N, h, w_, C0, Nout, KC16, act, tilesX, tilesY, tilesN, nwg;
   unsigned epi;
+  const unsigned* amax_a;   // fp16-pair variant: amax slots of `low` and of the weights; optional slot receiving max |y|
+  const unsigned* amax_w;
+  unsigned* amax_out;
 };
 
 template <int BN, int WM, int WN>
@@ -169,14 +172,56 @@ __global__ void __launch_bounds__(256) up2_phase_fwd_kernel(const PhaseArgs a) {
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
 constexpr int PIXB = 48, PLANE3 = HP * PIXB, BUF3 = 3 * PLANE3;
+// NP = 3: the exact bf16 split (six products); NP = 2: scaled fp16 pairs (fp_common.h; four products on v_mfma_f32_32x32x16_f16)
+template <int NP>
+__device__ __forceinline__ void phase_store_split(unsigned char* p, f32x4_t v, int ka) {
+  if (NP == 2) {
+    v = f32x4_t{ldexpf(v.x, ka), ldexpf(v.y, ka), ldexpf(v.z, ka), ldexpf(v.w, ka)};
+    const f16x4_t vh = __builtin_convertvector(v, f16x4_t);
+    const f32x4_t r1 = v - __builtin_convertvector(vh, f32x4_t);
+    const f16x4_t vm = __builtin_convertvector(r1, f16x4_t);
+    *reinterpret_cast<uint2*>(p) = __builtin_bit_cast(uint2, vh);
+    *reinterpret_cast<uint2*>(p + PLANE3) = __builtin_bit_cast(uint2, vm);
+  } else {
+    const bf16x4_t vh = __builtin_convertvector(v, bf16x4_t);
+    const f32x4_t r1 = v - __builtin_convertvector(vh, f32x4_t);
+    const bf16x4_t vm = __builtin_convertvector(r1, bf16x4_t);
+    const f32x4_t r2 = r1 - __builtin_convertvector(vm, f32x4_t);
+    const bf16x4_t vl = __builtin_convertvector(r2, bf16x4_t);
+    *reinterpret_cast<uint2*>(p) = __builtin_bit_cast(uint2, vh);
+    *reinterpret_cast<uint2*>(p + PLANE3) = __builtin_bit_cast(uint2, vm);
+    *reinterpret_cast<uint2*>(p + 2 * PLANE3) = __builtin_bit_cast(uint2, vl);
+  }
+}
+template <int NP, int TM, int TN>
+__device__ __forceinline__ void phase_mma(f32x16 (&acc)[TM][TN], const uint4 (&af)[TM][NP], const uint4 (&bf)[TN][NP]) {
+  constexpr int NPROD = NP == 3 ? 6 : 4;
+  constexpr int PA[6] = {NP == 3 ? 2 : 1, NP == 3 ? 0 : 1, NP == 3 ? 1 : 0, NP == 3 ? 1 : 0, 0, 0};
+  constexpr int PB[6] = {NP == 3 ? 0 : 1, NP == 3 ? 2 : 0, 1, 0, 1, 0};            // smallest products first
+#pragma unroll
+  for (int q = 0; q < NPROD; ++q)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        if (NP == 2)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, af[i][PA[q]]), __builtin_bit_cast(f16x8_t, bf[j][PB[q]]),
+                                                             acc[i][j], 0, 0, 0);
+        else
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[i][PA[q]]), __builtin_bit_cast(bf16x8_t, bf[j][PB[q]]),
+                                                              acc[i][j], 0, 0, 0);
+}
 
-template <int BN, int WM, int WN>
+template <int BN, int WM, int WN, int NP = 3>
 __global__ void __launch_bounds__(256) up2_phase_fwd_bf3_kernel(const PhaseArgs a) {
+  constexpr int BUFN = NP * PLANE3;
   constexpr int BM = TH * TW;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int NS = (HP * 4 + 255) / 256;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF3];
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUFN];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, idx = lane & 31, h = lane >> 5;
   const int wm = wave / WN, wn = wave % WN;
   int wg = fp_xcd_remap(blockIdx.x, a.nwg);
@@ -188,6 +233,11 @@ __global__ void __launch_bounds__(256) up2_phase_fwd_bf3_kernel(const PhaseArgs 
   const int dy = phase >> 1, dx = phase & 1;
   const int y0 = tile_y * TH, x0 = tile_x * TW, n0 = tile_n * BN;
   const unsigned short* wq = reinterpret_cast<const unsigned short*>(a.w);
+  int ka = 0, kunscale = 0;
+  if (NP == 2) {
+    ka = fp_hp_exponent(fp_amax_bits(a.amax_a), FP_HP_TARGET_ACT);
+    kunscale = -(ka + fp_hp_exponent(fp_amax_bits(a.amax_w), FP_HP_TARGET_W));
+  }
 
   int pix[NS], lds_off[NS];
 #pragma unroll
@@ -213,25 +263,17 @@ __global__ void __launch_bounds__(256) up2_phase_fwd_bf3_kernel(const PhaseArgs 
       if (lds_off[k] < 0) continue;
       f32x4_t v = {hreg[k].x, hreg[k].y, hreg[k].z, hreg[k].w};
       if (hzero) v = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      const bf16x4_t vh = __builtin_convertvector(v, bf16x4_t);
-      const f32x4_t r1 = v - __builtin_convertvector(vh, f32x4_t);
-      const bf16x4_t vm = __builtin_convertvector(r1, bf16x4_t);
-      const f32x4_t r2 = r1 - __builtin_convertvector(vm, f32x4_t);
-      const bf16x4_t vl = __builtin_convertvector(r2, bf16x4_t);
-      unsigned char* p = lds + buf * BUF3 + lds_off[k];
-      *reinterpret_cast<uint2*>(p) = __builtin_bit_cast(uint2, vh);
-      *reinterpret_cast<uint2*>(p + PLANE3) = __builtin_bit_cast(uint2, vm);
-      *reinterpret_cast<uint2*>(p + 2 * PLANE3) = __builtin_bit_cast(uint2, vl);
+      phase_store_split<NP>(lds + buf * BUFN + lds_off[k], v, ka);
     }
   };
-  uint4 bq[4][TN][3];
-  auto load_b = [&](int tap, int cc, uint4 (&bf)[TN][3]) {
-    const unsigned short* ws = wq + (size_t)((phase * 4 + tap) * a.KC16 + cc) * 3 * a.Nout * 16 + h * 8;
+  uint4 bq[4][TN][NP];
+  auto load_b = [&](int tap, int cc, uint4 (&bf)[TN][NP]) {
+    const unsigned short* ws = wq + (size_t)((phase * 4 + tap) * a.KC16 + cc) * NP * a.Nout * 16 + h * 8;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int n = min(n0 + (wn * TN + j) * 32 + idx, a.Nout - 1);
 #pragma unroll
-      for (int p = 0; p < 3; ++p) bf[j][p] = *reinterpret_cast<const uint4*>(ws + ((size_t)p * a.Nout + n) * 16);
+      for (int p = 0; p < NP; ++p) bf[j][p] = *reinterpret_cast<const uint4*>(ws + ((size_t)p * a.Nout + n) * 16);
     }
   };
   int abase[TM];
@@ -255,13 +297,13 @@ __global__ void __launch_bounds__(256) up2_phase_fwd_bf3_kernel(const PhaseArgs 
   load_halo(min(1, a.KC16 - 1));
   __syncthreads();
   for (int cc = 0; cc < a.KC16; ++cc) {
-    const unsigned char* Hb = lds + (cc & 1) * BUF3;
+    const unsigned char* Hb = lds + (cc & 1) * BUFN;
     const int ccn = min(cc + 1, a.KC16 - 1);
-    uint4 af[2][TM][3];                                     // A fragments one tap ahead (see conv3x3_tile_bf3.hip)
-    auto load_a = [&](int tap, uint4 (&dst)[TM][3]) {
+    uint4 af[2][TM][NP];                                     // A fragments one tap ahead (see conv3x3_tile_bf3.hip)
+    auto load_a = [&](int tap, uint4 (&dst)[TM][NP]) {
       const int toff = ((tap >> 1) * HW2 + (tap & 1)) * PIXB;
 #pragma unroll
-      for (int p = 0; p < 3; ++p)
+      for (int p = 0; p < NP; ++p)
 #pragma unroll
         for (int i = 0; i < TM; ++i) dst[i][p] = *reinterpret_cast<const uint4*>(Hb + p * PLANE3 + abase[i] + toff);
     };
@@ -272,17 +314,9 @@ __global__ void __launch_bounds__(256) up2_phase_fwd_bf3_kernel(const PhaseArgs 
       if (tap < 3) load_a(tap + 1, af[(tap + 1) & 1]);
       if (tap < 2) load_b(tap + 2, cc, bq[tap + 2]);
       else load_b(tap - 2, ccn, bq[tap - 2]);
-      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-      for (int q = 0; q < 6; ++q)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[tap & 1][i][PA[q]]),
-                                                                __builtin_bit_cast(bf16x8_t, bq[tap][j][PB[q]]), acc[i][j], 0, 0, 0);
-      if (tap < 3) fp_sched_interleave<TM * 3, TN * 3, 6 * TM * TN>();      // one read between consecutive MFMAs (fp_common.h)
-      else fp_sched_interleave<0, TN * 3, 6 * TM * TN>();
+      phase_mma<NP, TM, TN>(acc, af[tap & 1], bq[tap]);
+      if (tap < 3) fp_sched_interleave<TM * NP, TN * NP, (NP == 3 ? 6 : 4) * TM * TN>();      // one read between consecutive MFMAs (fp_common.h)
+      else fp_sched_interleave<0, TN * NP, (NP == 3 ? 6 : 4) * TM * TN>();
     }
     if (cc + 1 < a.KC16) {
       store_halo((cc + 1) & 1);
@@ -291,6 +325,7 @@ __global__ void __launch_bounds__(256) up2_phase_fwd_bf3_kernel(const PhaseArgs 
     }
   }
   const int OH = 2 * a.h, OW = 2 * a.w_;
+  float ymax = 0.f;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -315,12 +350,16 @@ __global__ void __launch_bounds__(256) up2_phase_fwd_bf3_kernel(const PhaseArgs 
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float v = acc[i][j][r] + bias;
+        float v = (NP == 2 ? ldexpf(acc[i][j][r], kunscale) : acc[i][j][r]) + bias;
         if (a.epi & FP_EPI_ADDEND) v += ad[r];
         if (a.act == FP_ACT_ELU) v = fp_elu(v);
-        if (ok[r]) a.y[off[r]] = v;
+        if (ok[r]) {
+          a.y[off[r]] = v;
+          ymax = fmaxf(ymax, fabsf(v));
+        }
       }
     }
+  if (a.amax_out) fp_amax_publish_block(a.amax_out, ymax);
 }
 
 // ---- data gradient of the upsampled half, bf16x3: the 4x4 stride-2 convolution over dZ (see the comment further down), phase by
@@ -333,14 +372,17 @@ struct PhaseDgradArgs {
   const unsigned short* w;   // bf16 [phase 4][tap 4][KC16 over Cout][3][C0][16]
   float* ext;           // [N][h+2][w+2][C0]
   int N, h, w_, Cout, C0, KC16, tilesX, tilesY, tilesN, nwg;
+  const unsigned* amax_a;   // fp16-pair variant: amax slots of dz and of the weights
+  const unsigned* amax_w;
 };
 
-template <int BN, int WM, int WN>
+template <int BN, int WM, int WN, int NP = 3>
 __global__ void __launch_bounds__(256) up2_phase_dgrad_bf3_kernel(const PhaseDgradArgs a) {
+  constexpr int BUFN = NP * PLANE3;
   constexpr int BM = TH * TW;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int NS = (HP * 4 + 255) / 256;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF3];
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUFN];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, idx = lane & 31, h = lane >> 5;
   const int wm = wave / WN, wn = wave % WN;
   int wg = fp_xcd_remap(blockIdx.x, a.nwg);
@@ -351,6 +393,11 @@ __global__ void __launch_bounds__(256) up2_phase_dgrad_bf3_kernel(const PhaseDgr
   const int y0 = tile_y * TH, x0 = tile_x * TW, n0 = tile_n * BN;
   const int H2 = 2 * a.h, W2 = 2 * a.w_, EH = a.h + 2, EW = a.w_ + 2;
   const int nsteps = 4 * a.KC16;
+  int ka = 0, kunscale = 0;
+  if (NP == 2) {
+    ka = fp_hp_exponent(fp_amax_bits(a.amax_a), FP_HP_TARGET_ACT);
+    kunscale = -(ka + fp_hp_exponent(fp_amax_bits(a.amax_w), FP_HP_TARGET_W));
+  }
 
   int pix[NS], lds_off[NS];
   bool hvalid[NS];
@@ -380,26 +427,18 @@ __global__ void __launch_bounds__(256) up2_phase_dgrad_bf3_kernel(const PhaseDgr
       if (lds_off[k] < 0) continue;
       f32x4_t v = {hreg[k].x, hreg[k].y, hreg[k].z, hreg[k].w};
       if (hzero || !hvalid[k]) v = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      const bf16x4_t vh = __builtin_convertvector(v, bf16x4_t);
-      const f32x4_t r1 = v - __builtin_convertvector(vh, f32x4_t);
-      const bf16x4_t vm = __builtin_convertvector(r1, bf16x4_t);
-      const f32x4_t r2 = r1 - __builtin_convertvector(vm, f32x4_t);
-      const bf16x4_t vl = __builtin_convertvector(r2, bf16x4_t);
-      unsigned char* p = lds + buf * BUF3 + lds_off[k];
-      *reinterpret_cast<uint2*>(p) = __builtin_bit_cast(uint2, vh);
-      *reinterpret_cast<uint2*>(p + PLANE3) = __builtin_bit_cast(uint2, vm);
-      *reinterpret_cast<uint2*>(p + 2 * PLANE3) = __builtin_bit_cast(uint2, vl);
+      phase_store_split<NP>(lds + buf * BUFN + lds_off[k], v, ka);
     }
   };
-  uint4 bq[4][TN][3];
-  auto load_b = [&](int tap, int step, uint4 (&bf)[TN][3]) {
+  uint4 bq[4][TN][NP];
+  auto load_b = [&](int tap, int step, uint4 (&bf)[TN][NP]) {
     const int ph = step / a.KC16, cc = step - ph * a.KC16;
-    const unsigned short* ws = a.w + (size_t)((ph * 4 + tap) * a.KC16 + cc) * 3 * a.C0 * 16 + h * 8;
+    const unsigned short* ws = a.w + (size_t)((ph * 4 + tap) * a.KC16 + cc) * NP * a.C0 * 16 + h * 8;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int n = min(n0 + (wn * TN + j) * 32 + idx, a.C0 - 1);
 #pragma unroll
-      for (int p = 0; p < 3; ++p) bf[j][p] = *reinterpret_cast<const uint4*>(ws + ((size_t)p * a.C0 + n) * 16);
+      for (int p = 0; p < NP; ++p) bf[j][p] = *reinterpret_cast<const uint4*>(ws + ((size_t)p * a.C0 + n) * 16);
     }
   };
   int abase[TM];
@@ -423,15 +462,15 @@ __global__ void __launch_bounds__(256) up2_phase_dgrad_bf3_kernel(const PhaseDgr
   load_halo(min(1, nsteps - 1));
   __syncthreads();
   for (int step = 0; step < nsteps; ++step) {
-    const unsigned char* Hb = lds + (step & 1) * BUF3;
+    const unsigned char* Hb = lds + (step & 1) * BUFN;
     const int stepn = min(step + 1, nsteps - 1);
     const int ph = step / a.KC16;
     const int poff = ((1 - (ph >> 1)) * HW2 + (1 - (ph & 1))) * PIXB;     // tap (a, b) reads halo offset (a + 1 - py, b + 1 - px)
-    uint4 af[2][TM][3];
-    auto load_a = [&](int tap, uint4 (&dst)[TM][3]) {
+    uint4 af[2][TM][NP];
+    auto load_a = [&](int tap, uint4 (&dst)[TM][NP]) {
       const int toff = poff + ((tap >> 1) * HW2 + (tap & 1)) * PIXB;
 #pragma unroll
-      for (int p = 0; p < 3; ++p)
+      for (int p = 0; p < NP; ++p)
 #pragma unroll
         for (int i = 0; i < TM; ++i) dst[i][p] = *reinterpret_cast<const uint4*>(Hb + p * PLANE3 + abase[i] + toff);
     };
@@ -442,17 +481,9 @@ __global__ void __launch_bounds__(256) up2_phase_dgrad_bf3_kernel(const PhaseDgr
       if (tap < 3) load_a(tap + 1, af[(tap + 1) & 1]);
       if (tap < 2) load_b(tap + 2, step, bq[tap + 2]);
       else load_b(tap - 2, stepn, bq[tap - 2]);
-      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-      for (int q = 0; q < 6; ++q)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[tap & 1][i][PA[q]]),
-                                                                __builtin_bit_cast(bf16x8_t, bq[tap][j][PB[q]]), acc[i][j], 0, 0, 0);
-      if (tap < 3) fp_sched_interleave<TM * 3, TN * 3, 6 * TM * TN>();      // one read between consecutive MFMAs (fp_common.h)
-      else fp_sched_interleave<0, TN * 3, 6 * TM * TN>();
+      phase_mma<NP, TM, TN>(acc, af[tap & 1], bq[tap]);
+      if (tap < 3) fp_sched_interleave<TM * NP, TN * NP, (NP == 3 ? 6 : 4) * TM * TN>();      // one read between consecutive MFMAs (fp_common.h)
+      else fp_sched_interleave<0, TN * NP, (NP == 3 ? 6 : 4) * TM * TN>();
     }
     if (step + 1 < nsteps) {
       store_halo((step + 1) & 1);
@@ -470,7 +501,7 @@ __global__ void __launch_bounds__(256) up2_phase_dgrad_bf3_kernel(const PhaseDgr
       for (int r = 0; r < 16; ++r) {
         const int pt = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         const int ey = y0 + pt / TW, ex = x0 + pt % TW;
-        if (ey < EH && ex < EW) a.ext[((size_t)(n_img * EH + ey) * EW + ex) * a.C0 + n] = acc[i][j][r];
+        if (ey < EH && ex < EW) a.ext[((size_t)(n_img * EH + ey) * EW + ex) * a.C0 + n] = NP == 2 ? ldexpf(acc[i][j][r], kunscale) : acc[i][j][r];
       }
     }
 }
@@ -484,9 +515,10 @@ __global__ void __launch_bounds__(256) up2_phase_dgrad_bf3_kernel(const PhaseDgr
 // (packing: pack.hip, FP_PACK_UP2_DGRAD)
 __global__ void __launch_bounds__(256) up2_fold_bwd_kernel(const float* __restrict__ ext, int N, int h, int w, int C,
                                                            const float* __restrict__ addend, const float* __restrict__ ylow,
-                                                           float* __restrict__ dlow) {
+                                                           float* __restrict__ dlow, unsigned* amax_out) {
   const int Q = C >> 2, we = w + 2;
   const size_t total = (size_t)N * h * w * Q;
+  float ymax = 0.f;
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
     const int q = (int)(e % Q);
     size_t r = e / Q;
@@ -517,7 +549,9 @@ __global__ void __launch_bounds__(256) up2_fold_bwd_kernel(const float* __restri
       g.z *= (s.z > 0.f ? 1.f : s.z + 1.f); g.w *= (s.w > 0.f ? 1.f : s.w + 1.f);
     }
     *reinterpret_cast<float4*>(dlow + o) = g;
+    ymax = fp_amax4(ymax, g);
   }
+  if (amax_out) fp_amax_publish_block(amax_out, ymax);
 }
 
 int grid_for(size_t total) {
@@ -531,6 +565,7 @@ extern "C" int fp_conv_up2_phase_fwd(const float* low, const float* wphase, cons
                                      int32_t N, int32_t h, int32_t w, int32_t C0, int32_t Nout, int32_t act, fp_stream_t stream) {
   FP_REQUIRE(low && wphase && y && N > 0 && h >= 1 && w >= 1 && C0 > 0 && C0 % 4 == 0 && Nout > 0, "fp_conv_up2_phase_fwd: bad arguments");
   PhaseArgs a;
+  a.amax_a = a.amax_w = nullptr; a.amax_out = nullptr;
   a.low = low; a.w = wphase; a.bias = bias; a.addend = addend; a.y = y;
   a.N = N; a.h = h; a.w_ = w; a.C0 = C0; a.Nout = Nout; a.KC16 = (C0 + 15) / 16; a.act = act;
   a.epi = (bias ? FP_EPI_BIAS : 0u) | (addend ? FP_EPI_ADDEND : 0u);
@@ -547,12 +582,15 @@ extern "C" int fp_conv_up2_phase_fwd(const float* low, const float* wphase, cons
   return fp_check_launch("fp_conv_up2_phase_fwd");
 }
 
-extern "C" int fp_conv_up2_phase_fwd_bf3(const float* low, const void* wphase_bf3, const float* bias, const float* addend, float* y,
-                                         int32_t N, int32_t h, int32_t w, int32_t C0, int32_t Nout, int32_t act, fp_stream_t stream) {
+static int phase_fwd_split(const float* low, const void* wphase_bf3, const float* bias, const float* addend, float* y, int32_t N, int32_t h,
+                           int32_t w, int32_t C0, int32_t Nout, int32_t act, const uint32_t* amax_low, const uint32_t* amax_w,
+                           uint32_t* amax_out, fp_stream_t stream) {
   FP_REQUIRE(low && wphase_bf3 && y && N > 0 && h >= 1 && w >= 1 && C0 > 0 && C0 % 4 == 0 && Nout > 0,
-             "fp_conv_up2_phase_fwd_bf3: bad arguments");
-  FP_REQUIRE((int64_t)N * 4 * h * w * Nout < ((int64_t)1 << 31), "fp_conv_up2_phase_fwd_bf3: output larger than 2^31 elements");
+             "fp_conv_up2_phase_fwd_bf3 / _hp: bad arguments");
+  FP_REQUIRE((int64_t)N * 4 * h * w * Nout < ((int64_t)1 << 31), "fp_conv_up2_phase_fwd_bf3 / _hp: output larger than 2^31 elements");
   PhaseArgs a;
+  a.amax_a = amax_low; a.amax_w = amax_w; a.amax_out = amax_out;
+  const bool hp = amax_low != nullptr;
   a.low = low; a.w = (const float*)wphase_bf3; a.bias = bias; a.addend = addend; a.y = y;
   a.N = N; a.h = h; a.w_ = w; a.C0 = C0; a.Nout = Nout; a.KC16 = (C0 + 15) / 16; a.act = act;
   a.epi = (bias ? FP_EPI_BIAS : 0u) | (addend ? FP_EPI_ADDEND : 0u);
@@ -560,40 +598,67 @@ extern "C" int fp_conv_up2_phase_fwd_bf3(const float* low, const void* wphase_bf
   if (Nout <= 32) {
     a.tilesN = (int)fp_ceil_div(Nout, 32);
     a.nwg = N * a.tilesY * a.tilesX * a.tilesN * 4;
-    fp_launch((up2_phase_fwd_bf3_kernel<32, 4, 1>), dim3(a.nwg), dim3(256), 0, (hipStream_t)stream, a);
+    if (hp) fp_launch((up2_phase_fwd_bf3_kernel<32, 4, 1, 2>), dim3(a.nwg), dim3(256), 0, (hipStream_t)stream, a);
+    else fp_launch((up2_phase_fwd_bf3_kernel<32, 4, 1, 3>), dim3(a.nwg), dim3(256), 0, (hipStream_t)stream, a);
   } else {
     a.tilesN = (int)fp_ceil_div(Nout, 64);
     a.nwg = N * a.tilesY * a.tilesX * a.tilesN * 4;
-    fp_launch((up2_phase_fwd_bf3_kernel<64, 2, 2>), dim3(a.nwg), dim3(256), 0, (hipStream_t)stream, a);
+    if (hp) fp_launch((up2_phase_fwd_bf3_kernel<64, 2, 2, 2>), dim3(a.nwg), dim3(256), 0, (hipStream_t)stream, a);
+    else fp_launch((up2_phase_fwd_bf3_kernel<64, 2, 2, 3>), dim3(a.nwg), dim3(256), 0, (hipStream_t)stream, a);
   }
-  return fp_check_launch("fp_conv_up2_phase_fwd_bf3");
+  return fp_check_launch("fp_conv_up2_phase_fwd_bf3 / _hp");
+}
+extern "C" int fp_conv_up2_phase_fwd_bf3(const float* low, const void* wphase_bf3, const float* bias, const float* addend, float* y,
+                                         int32_t N, int32_t h, int32_t w, int32_t C0, int32_t Nout, int32_t act, fp_stream_t stream) {
+  return phase_fwd_split(low, wphase_bf3, bias, addend, y, N, h, w, C0, Nout, act, nullptr, nullptr, fp_take_amax_out(), stream);
+}
+// fp16-pair operands (fp_conv3x3_hp): weights from FP_PACK_UP2_FWD_HP jobs / fp_pack_up2_weight_hp with the slot they were scaled by
+extern "C" int fp_conv_up2_phase_fwd_hp(const float* low, const void* wphase_hp, const float* bias, const float* addend, float* y, int32_t N,
+                                        int32_t h, int32_t w, int32_t C0, int32_t Nout, int32_t act, const uint32_t* amax_low,
+                                        const uint32_t* amax_w, uint32_t* amax_out, fp_stream_t stream) {
+  FP_REQUIRE(amax_low && amax_w, "fp_conv_up2_phase_fwd_hp: amax slots missing");
+  return phase_fwd_split(low, wphase_hp, bias, addend, y, N, h, w, C0, Nout, act, amax_low, amax_w, amax_out, stream);
 }
 
-extern "C" int fp_conv_up2_phase_dgrad_bf3(const float* dz, const void* wpacked_bf3, float* ext, int32_t N, int32_t h, int32_t w,
-                                           int32_t Cout, int32_t C0, fp_stream_t stream) {
+static int phase_dgrad_split(const float* dz, const void* wpacked_bf3, float* ext, int32_t N, int32_t h, int32_t w, int32_t Cout, int32_t C0,
+                             const uint32_t* amax_dz, const uint32_t* amax_w, fp_stream_t stream) {
   FP_REQUIRE(dz && wpacked_bf3 && ext && N > 0 && h >= 1 && w >= 1 && Cout > 0 && Cout % 4 == 0 && C0 > 0,
-             "fp_conv_up2_phase_dgrad_bf3: bad arguments");
-  FP_REQUIRE((int64_t)N * 4 * h * w * Cout < ((int64_t)1 << 31), "fp_conv_up2_phase_dgrad_bf3: dZ larger than 2^31 elements");
+             "fp_conv_up2_phase_dgrad_bf3 / _hp: bad arguments");
+  FP_REQUIRE((int64_t)N * 4 * h * w * Cout < ((int64_t)1 << 31), "fp_conv_up2_phase_dgrad_bf3 / _hp: dZ larger than 2^31 elements");
   PhaseDgradArgs a;
+  a.amax_a = amax_dz; a.amax_w = amax_w;
+  const bool hp = amax_dz != nullptr;
   a.dz = dz; a.w = (const unsigned short*)wpacked_bf3; a.ext = ext;
   a.N = N; a.h = h; a.w_ = w; a.Cout = Cout; a.C0 = C0; a.KC16 = (Cout + 15) / 16;
   a.tilesX = (int)fp_ceil_div(w + 2, TW); a.tilesY = (int)fp_ceil_div(h + 2, TH);
   if (C0 <= 32) {
     a.tilesN = (int)fp_ceil_div(C0, 32);
     a.nwg = N * a.tilesY * a.tilesX * a.tilesN;
-    fp_launch((up2_phase_dgrad_bf3_kernel<32, 4, 1>), dim3(a.nwg), dim3(256), 0, (hipStream_t)stream, a);
+    if (hp) fp_launch((up2_phase_dgrad_bf3_kernel<32, 4, 1, 2>), dim3(a.nwg), dim3(256), 0, (hipStream_t)stream, a);
+    else fp_launch((up2_phase_dgrad_bf3_kernel<32, 4, 1, 3>), dim3(a.nwg), dim3(256), 0, (hipStream_t)stream, a);
   } else {
     a.tilesN = (int)fp_ceil_div(C0, 64);
     a.nwg = N * a.tilesY * a.tilesX * a.tilesN;
-    fp_launch((up2_phase_dgrad_bf3_kernel<64, 2, 2>), dim3(a.nwg), dim3(256), 0, (hipStream_t)stream, a);
+    if (hp) fp_launch((up2_phase_dgrad_bf3_kernel<64, 2, 2, 2>), dim3(a.nwg), dim3(256), 0, (hipStream_t)stream, a);
+    else fp_launch((up2_phase_dgrad_bf3_kernel<64, 2, 2, 3>), dim3(a.nwg), dim3(256), 0, (hipStream_t)stream, a);
   }
-  return fp_check_launch("fp_conv_up2_phase_dgrad_bf3");
+  return fp_check_launch("fp_conv_up2_phase_dgrad_bf3 / _hp");
+}
+extern "C" int fp_conv_up2_phase_dgrad_bf3(const float* dz, const void* wpacked_bf3, float* ext, int32_t N, int32_t h, int32_t w,
+                                           int32_t Cout, int32_t C0, fp_stream_t stream) {
+  return phase_dgrad_split(dz, wpacked_bf3, ext, N, h, w, Cout, C0, nullptr, nullptr, stream);
+}
+extern "C" int fp_conv_up2_phase_dgrad_hp(const float* dz, const void* wpacked_hp, float* ext, int32_t N, int32_t h, int32_t w, int32_t Cout,
+                                          int32_t C0, const uint32_t* amax_dz, const uint32_t* amax_w, fp_stream_t stream) {
+  FP_REQUIRE(amax_dz && amax_w, "fp_conv_up2_phase_dgrad_hp: amax slots missing");
+  return phase_dgrad_split(dz, wpacked_hp, ext, N, h, w, Cout, C0, amax_dz, amax_w, stream);
 }
 
 extern "C" int fp_up2_fold_bwd(const float* ext, int32_t N, int32_t h, int32_t w, int32_t C, const float* addend, const float* ylow_elu,
                                float* dlow, fp_stream_t stream) {
   FP_REQUIRE(ext && dlow && N > 0 && h > 0 && w > 0 && C > 0 && C % 4 == 0, "fp_up2_fold_bwd: bad arguments");
-  fp_launch(up2_fold_bwd_kernel, dim3(grid_for((size_t)N * h * w * (C / 4))), dim3(256), 0, (hipStream_t)stream, ext, N, h, w, C,
-                     addend, ylow_elu, dlow);
+  unsigned* amax_out = fp_take_amax_out();
+  int g = grid_for((size_t)N * h * w * (C / 4));
+  fp_launch(up2_fold_bwd_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, ext, N, h, w, C, addend, ylow_elu, dlow, amax_out);
   return fp_check_launch("fp_up2_fold_bwd");
 }

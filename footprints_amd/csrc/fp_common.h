@@ -160,7 +160,7 @@ __device__ __forceinline__ float fp_elu(float v) {
 // x * 2^k = h + m with h = fp16(x * 2^k), m = fp16(x * 2^k - h): 11 + 11 significant bits (relative error <= 2^-22, ~2^-23.5 rms);
 // the four products hh, hm, mh, mm are exact in the fp32 accumulator of v_mfma_f32_32x32x16_f16.  k is a per-tensor power of two
 // taken from the tensor's largest magnitude (an "amax slot": FP_AMAX_SLOTS uint32 holding float bit patterns of |x|, combined
-// with max; producers publish into slot[id % FP_AMAX_SLOTS] with atomicMax, so same-address traffic stays low), which maps that
+// with max; a producer on XCD k publishes into the sub-slots of XCD k, see fp_amax_publish), which maps that
 // magnitude to [2^target, 2^(target+1)): no overflow (fp16 max 65504), and anything above 2^-24 / 2^k is still represented, i.e.
 // the absolute error floor is 2^-37 of the tensor's largest element.  Scaling by powers of two is exact and undone in the epilogue.
 static_assert(FP_AMAX_SLOTS == 16, "amax slot width (include/footprints_hip.h)");
@@ -169,20 +169,44 @@ constexpr int FP_HP_TARGET_W = 11;      // weights: amax -> [2^11, 2^12) (the ne
 __device__ __forceinline__ unsigned fp_amax_bits(const unsigned* __restrict__ slot) {
   unsigned m = 0;
 #pragma unroll
-  for (int i = 0; i < FP_AMAX_SLOTS; ++i) m = max(m, slot[i]);
+  for (int i = 0; i < FP_AMAX_SLOTS; ++i) m = max(m, slot[i * FP_AMAX_STRIDE]);
   return m;
 }
 // exponent k with amax * 2^k in [2^target, 2^(target+1)); 0 for an all-zero tensor; inf / nan propagate through the data itself
 __device__ __forceinline__ int fp_hp_exponent(unsigned amax_bits, int target) {
   return amax_bits ? target - ((int)(amax_bits >> 23) - 127) : 0;
 }
-// publish a magnitude into an amax slot.  Same-address atomics serialise at ~2 ns each (11 520 waves: +64 us on a 100 us kernel), so
-// the slot is read first (agent scope: from L2, a stale value only costs a redundant atomic) and only record-setting values
-// issue the atomic: ~ln(n) per sub-slot.
+// publish a magnitude into an amax slot.  Agent-scope atomics execute at the memory side and same-address ones serialise at ~90 ns
+// each (measured: 11 520 publishing waves = +64 us; 1 024 workgroups of an element-wise kernel finishing together = +20 us), so a
+// publication is a WORKGROUP-scope atomic -- executed in the issuing XCD's L2 -- on a sub-slot that only this XCD touches (index from
+// the XCC id, one 128-byte line per sub-slot: no line is ever dirty in two L2s).  The L2 writes the line back at the end of the kernel
+// like any other store, and the consumer -- a later kernel -- combines the sub-slots with max.
+__device__ __forceinline__ unsigned fp_xcc_id() {
+  unsigned x;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+  return x & 7u;
+}
 __device__ __forceinline__ void fp_amax_publish(unsigned* slot, unsigned id, float m) {
-  unsigned* s = slot + id % FP_AMAX_SLOTS;
+  unsigned* s = slot + ((fp_xcc_id() * 2 + (id & 1u)) % FP_AMAX_SLOTS) * FP_AMAX_STRIDE;
   const unsigned bits = __float_as_uint(m);
-  if (bits > __hip_atomic_load(s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(s, bits);
+  if (bits) __hip_atomic_fetch_max(s, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+unsigned* fp_take_amax_out();     // api.cpp: the slot registered by fp_amax_out_next for this thread's next publishing launch (then cleared)
+__device__ __forceinline__ float fp_wave_max(float v);
+// one candidate per workgroup: every thread of the block calls this once (wave maxima through 64 bytes of shared scratch)
+__device__ __forceinline__ void fp_amax_publish_block(unsigned* slot, float m) {
+  __shared__ float fp_amax_scratch[16];
+  m = fp_wave_max(m);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) fp_amax_scratch[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (unsigned i = 1; i < (blockDim.x + 63) / 64; ++i) m = fmaxf(m, fp_amax_scratch[i]);
+    fp_amax_publish(slot, blockIdx.x, m);
+  }
+}
+__device__ __forceinline__ float fp_amax4(float m, const float4& v) {
+  return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
 }
 __device__ __forceinline__ float fp_wave_max(float v) {
 #pragma unroll

@@ -298,7 +298,8 @@ struct HeadDzWindow {
 
 __global__ void __launch_bounds__(256) head_dgrad_kernel(const float* __restrict__ dz, const float* __restrict__ w,
                                                          const float* __restrict__ elu_src, float* __restrict__ dx, int H, int W,
-                                                         int Cin, int rows, int gpi) {
+                                                         int Cin, int rows, int gpi, unsigned* amax_out) {
+  float ymax = 0.f;
   __shared__ __attribute__((aligned(16))) float Ws0[9 * MAXC];
   __shared__ __attribute__((aligned(16))) float Ws1[9 * MAXC];
   load_head_weights(w, Cin, Ws0, Ws1);
@@ -338,7 +339,10 @@ __global__ void __launch_bounds__(256) head_dgrad_kernel(const float* __restrict
       acc.x *= (s.x > 0.f ? 1.f : s.x + 1.f); acc.y *= (s.y > 0.f ? 1.f : s.y + 1.f);
       acc.z *= (s.z > 0.f ? 1.f : s.z + 1.f); acc.w *= (s.w > 0.f ? 1.f : s.w + 1.f);
     }
-    if (l.live) *reinterpret_cast<float4*>(dx + pix0 + (size_t)py * rowstride) = acc;
+    if (l.live) {
+      *reinterpret_cast<float4*>(dx + pix0 + (size_t)py * rowstride) = acc;
+      ymax = fp_amax4(ymax, acc);
+    }
   };
   float2 r0[3], r1[3], r2[3], r3[3];
   float4 e0 = make_float4(0.f, 0.f, 0.f, 0.f), e1 = e0;
@@ -355,6 +359,7 @@ __global__ void __launch_bounds__(256) head_dgrad_kernel(const float* __restrict
     if (py + 3 >= l.rend) break;
     body(py + 3, r3, r0, r1, r2, e1, e0);
   }
+  if (amax_out) fp_amax_publish_block(amax_out, ymax);
 }
 
 // Weight gradient, gather form with a grid-stride pixel loop (measured faster than row-walk variants with a register window, in
@@ -527,7 +532,7 @@ extern "C" int fp_head_dgrad(const float* dzlow, const float* w_oihw, const floa
   FP_REQUIRE(head_cin_ok(Cin) && h >= 2 && w >= 2, "fp_head_dgrad: unsupported Cin=%d", Cin);
   const HeadGrid g = head_grid(N, h, w, Cin, 16);
   fp_launch(head_dgrad_kernel, dim3(g.colblocks, N * g.gpi), dim3(256), 0, (hipStream_t)stream, dzlow, w_oihw, elu_src, dx, h, w,
-                     Cin, g.rows, g.gpi);
+                     Cin, g.rows, g.gpi, fp_take_amax_out());
   return fp_check_launch("fp_head_dgrad");
 }
 

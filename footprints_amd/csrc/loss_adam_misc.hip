@@ -448,6 +448,8 @@ __global__ void __launch_bounds__(256) zero_u32_kernel(unsigned* __restrict__ p,
 }
 }  // namespace
 
+extern "C" int32_t fp_amax_slot_elems(void) { return FP_AMAX_ELEMS; }
+
 extern "C" int fp_zero_u32(uint32_t* p, int64_t n, fp_stream_t stream) {
   FP_REQUIRE(p && n > 0, "fp_zero_u32: bad arguments");
   fp_launch(zero_u32_kernel, dim3(ew_grid((size_t)n, 64)), dim3(256), 0, (hipStream_t)stream, p, (size_t)n);

@@ -177,9 +177,14 @@ __global__ void __launch_bounds__(256) pack_amax_kernel(const fp_pack_job* __res
   if (!pack_is_hp(j.kind)) return;                    // uniform per block
   const size_t total = (size_t)j.Cout * j.Cin * j.KH * j.KW, stride = (size_t)j.block_count * 256;
   float m = 0.f;
-  for (size_t e = (size_t)(blockIdx.x - j.block_begin) * 256 + threadIdx.x; e < total; e += stride) m = fmaxf(m, fabsf(j.w[e]));
-  m = fp_wave_max(m);
-  if ((threadIdx.x & 63) == 0) fp_amax_publish(j.amax, blockIdx.x * 4 + (threadIdx.x >> 6), m);
+  if ((reinterpret_cast<uintptr_t>(j.w) & 15) == 0) {
+    const size_t t4 = total >> 2;
+    for (size_t e = (size_t)(blockIdx.x - j.block_begin) * 256 + threadIdx.x; e < t4; e += stride) m = fp_amax4(m, reinterpret_cast<const float4*>(j.w)[e]);
+    if (blockIdx.x == j.block_begin && threadIdx.x < (total & 3)) m = fmaxf(m, fabsf(j.w[(t4 << 2) + threadIdx.x]));
+  } else {
+    for (size_t e = (size_t)(blockIdx.x - j.block_begin) * 256 + threadIdx.x; e < total; e += stride) m = fmaxf(m, fabsf(j.w[e]));
+  }
+  fp_amax_publish_block(j.amax, m);
 }
 __global__ void __launch_bounds__(256) pack_amax_one_kernel(const float* __restrict__ w, size_t total, unsigned* __restrict__ slot) {
   float m = 0.f;
@@ -188,7 +193,7 @@ __global__ void __launch_bounds__(256) pack_amax_one_kernel(const float* __restr
   if ((threadIdx.x & 63) == 0) fp_amax_publish(slot, blockIdx.x * 4 + (threadIdx.x >> 6), m);
 }
 __global__ void __launch_bounds__(64) pack_zero_slot_kernel(unsigned* __restrict__ slot) {
-  if (threadIdx.x < FP_AMAX_SLOTS) slot[threadIdx.x] = 0u;
+  if (threadIdx.x < FP_AMAX_SLOTS) slot[threadIdx.x * FP_AMAX_STRIDE] = 0u;
 }
 
 int launch_one(int kind, const float* w, float* wp, int Cout, int Cin, int KH, int KW, int c_begin, int c_count, hipStream_t stream,

@@ -35,6 +35,8 @@ struct W3Args {
   int chunksY, chunksX, nchunks, chunksPerSplit, S, citiles, cotiles;
   unsigned long long* stamps;   // debugging (FP_W3_STAMPS=file): per workgroup {start, loop start, loop end, end} shader clocks + HW id
   int nofast;         // A/B switch: every chunk through the general (reflect / clamp / mask) staging path
+  const unsigned* amax_x;    // fp16-pair variant: amax slots of x and dz (null = exact bf16 split)
+  const unsigned* amax_dz;
   int xcd;            // logical workgroup ids run contiguously inside an XCD: the citiles x cotiles workgroups of one pixel split read
                       // the same X / dZ chunks and then share that XCD's L2 (consecutive hardware ids go to different XCDs)
 };
@@ -244,15 +246,38 @@ constexpr int XP3 = HR * HWD * PXB, ZP3 = CH * CW * PXB;        // 6912, 4096 by
 constexpr int XB3 = 3 * XP3, ZB3 = 3 * ZP3, BUF3 = XB3 + ZB3;   // 20736 + 12288 = 33024 bytes per buffer
 constexpr int XITEMS = HR * HWD * 8;                            // (pixel, channel quad) staging items of X: 864 (dZ: 4 x 16 x 8 = 512 = two per thread)
 
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+template <int NP>
+__device__ __forceinline__ void split_store_np(unsigned char* p, int plane_stride, f32x4 v, int kscale) {
+  if (NP == 3) {
+    split_store(p, plane_stride, v);
+    return;
+  }
+  v = f32x4{ldexpf(v.x, kscale), ldexpf(v.y, kscale), ldexpf(v.z, kscale), ldexpf(v.w, kscale)};
+  const f16x4 vh = __builtin_convertvector(v, f16x4);
+  const f32x4 r1 = v - __builtin_convertvector(vh, f32x4);
+  const f16x4 vm = __builtin_convertvector(r1, f16x4);
+  *reinterpret_cast<uint2*>(p) = __builtin_bit_cast(uint2, vh);
+  *reinterpret_cast<uint2*>(p + plane_stride) = __builtin_bit_cast(uint2, vm);
+}
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint2 lds_tr16(const unsigned char* p) {
   const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
   return __builtin_bit_cast(uint2, v);
 }
 
-template <int MODE>
+// NP = 3: exact bf16 split (six products); NP = 2: scaled fp16 pairs (fp_common.h: four products on v_mfma_f32_32x32x16_f16; X and dZ
+// each scaled by their own amax slot, the partial sums are unscaled -- exactly -- before they leave the workgroup)
+template <int MODE, int NP = 3>
 __global__ void __launch_bounds__(256, 2) wgrad3x3_bf3_v3_kernel(const W3Args a) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF3];
+  constexpr int XBN = NP * XP3, BUFN = NP * (XP3 + ZP3);
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUFN];
+  int kx_ = 0, kz_ = 0;
+  if (NP == 2) {
+    kx_ = fp_hp_exponent(fp_amax_bits(a.amax_x), FP_HP_TARGET_ACT);
+    kz_ = fp_hp_exponent(fp_amax_bits(a.amax_dz), FP_HP_TARGET_ACT);
+  }
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   int b = a.xcd ? fp_xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
   const int cot = b % a.cotiles; b /= a.cotiles;
@@ -328,14 +353,14 @@ __global__ void __launch_bounds__(256, 2) wgrad3x3_bf3_v3_kernel(const W3Args a)
     }
   };
   auto stage = [&](int buf) {
-    unsigned char* const base = lds + buf * BUF3;
+    unsigned char* const base = lds + buf * BUFN;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-      if (k < 3 || xit[k]) split_store(base + (t + 256 * k) * 8, XP3, f32x4{xr[k].x, xr[k].y, xr[k].z, xr[k].w});
+      if (k < 3 || xit[k]) split_store_np<NP>(base + (t + 256 * k) * 8, XP3, f32x4{xr[k].x, xr[k].y, xr[k].z, xr[k].w}, kx_);
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       if (want_bias) { bs[0] += zv[k].x; bs[1] += zv[k].y; bs[2] += zv[k].z; bs[3] += zv[k].w; }
-      split_store(base + XB3 + (t + 256 * k) * 8, ZP3, f32x4{zv[k].x, zv[k].y, zv[k].z, zv[k].w});
+      split_store_np<NP>(base + XBN + (t + 256 * k) * 8, ZP3, f32x4{zv[k].x, zv[k].y, zv[k].z, zv[k].w}, kz_);
     }
   };
 
@@ -356,35 +381,41 @@ __global__ void __launch_bounds__(256, 2) wgrad3x3_bf3_v3_kernel(const W3Args a)
   const int li = lane & 15;
   const int lrow = 8 * (lane >> 5) + (li >> 2), lcol = 32 * ((lane >> 4) & 1) + 8 * (li & 3);
   const int xrd = (wave * HWD + lrow) * PXB + lcol;
-  const int zrd = XB3 + (wave * CW + lrow) * PXB + lcol;
+  const int zrd = XBN + (wave * CW + lrow) * PXB + lcol;
   int par = 0;
   for (int c = c_begin; c < c_end; c += c_step, par ^= 1) {
-    const unsigned char* const Bb = lds + par * BUF3;
+    const unsigned char* const Bb = lds + par * BUFN;
     if (c + c_step < c_end) issue(c + c_step);       // next chunk's global loads fly under this chunk's MFMAs
-    uint4 bz[3];
+    uint4 bz[NP];
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
+    for (int p = 0; p < NP; ++p) {
       const uint2 lo = lds_tr16(Bb + zrd + p * ZP3), hi = lds_tr16(Bb + zrd + p * ZP3 + 4 * PXB);
       bz[p] = make_uint4(lo.x, lo.y, hi.x, hi.y);
     }
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
-      uint4 af[3][3];                                // [kx][plane]
+      uint4 af[3][NP];                               // [kx][plane]
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < NP; ++p) {
           const unsigned char* src = Bb + xrd + (ky * HWD + kx) * PXB + p * XP3;
           const uint2 lo = lds_tr16(src), hi = lds_tr16(src + 4 * PXB);
           af[kx][p] = make_uint4(lo.x, lo.y, hi.x, hi.y);
         }
-      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+      constexpr int NPROD = NP == 3 ? 6 : 4;         // smallest products first
+      constexpr int PA[6] = {NP == 3 ? 2 : 1, NP == 3 ? 0 : 1, NP == 3 ? 1 : 0, NP == 3 ? 1 : 0, 0, 0};
+      constexpr int PB[6] = {NP == 3 ? 0 : 1, NP == 3 ? 2 : 0, 1, 0, 1, 0};
 #pragma unroll
-      for (int qq = 0; qq < 6; ++qq) {
-        const bf16x8 bb = __builtin_bit_cast(bf16x8, bz[PB[qq]]);
+      for (int qq = 0; qq < NPROD; ++qq) {
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx)
-          acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[kx][PA[qq]]), bb, acc[ky * 3 + kx], 0, 0, 0);
+          if (NP == 2)
+            acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[kx][PA[qq]]), __builtin_bit_cast(f16x8, bz[PB[qq]]),
+                                                                      acc[ky * 3 + kx], 0, 0, 0);
+          else
+            acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[kx][PA[qq]]), __builtin_bit_cast(bf16x8, bz[PB[qq]]),
+                                                                       acc[ky * 3 + kx], 0, 0, 0);
       }
     }
     if (c + c_step < c_end) stage(par ^ 1);           // the other buffer was last read in the previous chunk, before the barrier that ended it
@@ -416,7 +447,8 @@ __global__ void __launch_bounds__(256, 2) wgrad3x3_bf3_v3_kernel(const W3Args a)
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int e = t + 256 * k;
-      const float v = ((red[e] + red[1024 + e]) + red[2048 + e]) + red[3072 + e];
+      float v = ((red[e] + red[1024 + e]) + red[2048 + e]) + red[3072 + e];
+      if (NP == 2) v = ldexpf(v, -(kx_ + kz_));
       const int r = e >> 6, ln = e & 63;
       const int ci = ci0 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
       out[((size_t)tp * a.C + ci) * a.Nout + co0 + (ln & 31)] = v;
@@ -527,8 +559,23 @@ extern "C" int64_t fp_conv_wgrad_bf3_workspace(const fp_conv_desc* d) {
   return ((int64_t)p.S * 9 * d->C0 * d->Nout + (int64_t)p.S * d->Nout) * (int64_t)sizeof(float);
 }
 
+static int wgrad_split(const fp_conv_desc* d, const float* x, const float* dz, float* dw_oihw, float* db, int32_t kc_total, int32_t k_begin,
+                       int accumulate, void* workspace, int64_t workspace_bytes, const uint32_t* amax_x, const uint32_t* amax_dz,
+                       fp_stream_t stream_);
 extern "C" int fp_conv_wgrad_bf3(const fp_conv_desc* d, const float* x, const float* dz, float* dw_oihw, float* db, int32_t kc_total,
                                  int32_t k_begin, int accumulate, void* workspace, int64_t workspace_bytes, fp_stream_t stream_) {
+  return wgrad_split(d, x, dz, dw_oihw, db, kc_total, k_begin, accumulate, workspace, workspace_bytes, nullptr, nullptr, stream_);
+}
+// fp16-pair operands (fp_conv3x3_hp): `amax_x` / `amax_dz` = amax slots of the two tensors; same shapes, workspace and results layout
+extern "C" int fp_conv_wgrad_hp(const fp_conv_desc* d, const float* x, const float* dz, float* dw_oihw, float* db, int32_t kc_total,
+                                int32_t k_begin, int accumulate, void* workspace, int64_t workspace_bytes, const uint32_t* amax_x,
+                                const uint32_t* amax_dz, fp_stream_t stream_) {
+  FP_REQUIRE(amax_x && amax_dz, "fp_conv_wgrad_hp: amax slots missing");
+  return wgrad_split(d, x, dz, dw_oihw, db, kc_total, k_begin, accumulate, workspace, workspace_bytes, amax_x, amax_dz, stream_);
+}
+static int wgrad_split(const fp_conv_desc* d, const float* x, const float* dz, float* dw_oihw, float* db, int32_t kc_total, int32_t k_begin,
+                       int accumulate, void* workspace, int64_t workspace_bytes, const uint32_t* amax_x, const uint32_t* amax_dz,
+                       fp_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   FP_REQUIRE(d && x && dz && dw_oihw && workspace, "fp_conv_wgrad_bf3: null pointer");
   FP_REQUIRE(eligible(d), "fp_conv_wgrad_bf3: shape not supported (see fp_conv_wgrad_bf3_workspace)");
@@ -536,6 +583,8 @@ extern "C" int fp_conv_wgrad_bf3(const fp_conv_desc* d, const float* x, const fl
   const WPlan p = plan(d);
   FP_REQUIRE(workspace_bytes >= fp_conv_wgrad_bf3_workspace(d), "fp_conv_wgrad_bf3: workspace too small");
   W3Args a;
+  a.amax_x = amax_x; a.amax_dz = amax_dz;
+  const bool hp = amax_x != nullptr;
   a.x = x; a.dz = dz; a.part = (float*)workspace;
   a.bpart = db ? (float*)workspace + (size_t)p.S * 9 * d->C0 * d->Nout : nullptr;
   a.N = d->N; a.H = d->OH; a.W = d->OW; a.C = d->C0; a.Nout = d->Nout;
@@ -555,10 +604,14 @@ extern "C" int fp_conv_wgrad_bf3(const fp_conv_desc* d, const float* x, const fl
     if (nwg <= 8192) a.stamps = stamp_buf;
   }
   static const int ver = getenv("FP_WGRAD_BF3_V") ? atoi(getenv("FP_WGRAD_BF3_V")) : 3;       // A/B switch: 1 = first generation, else third
-  if (ver == 1) fp_launch(wgrad3x3_bf3_kernel, dim3(nwg), dim3(256), 0, stream, a);
-  else if (a.mode == 0) fp_launch(wgrad3x3_bf3_v3_kernel<0>, dim3(nwg), dim3(256), 0, stream, a);
-  else if (a.mode == 1) fp_launch(wgrad3x3_bf3_v3_kernel<1>, dim3(nwg), dim3(256), 0, stream, a);
-  else fp_launch(wgrad3x3_bf3_v3_kernel<2>, dim3(nwg), dim3(256), 0, stream, a);
+  if (hp) {
+    if (a.mode == 0) fp_launch((wgrad3x3_bf3_v3_kernel<0, 2>), dim3(nwg), dim3(256), 0, stream, a);
+    else if (a.mode == 1) fp_launch((wgrad3x3_bf3_v3_kernel<1, 2>), dim3(nwg), dim3(256), 0, stream, a);
+    else fp_launch((wgrad3x3_bf3_v3_kernel<2, 2>), dim3(nwg), dim3(256), 0, stream, a);
+  } else if (ver == 1) fp_launch(wgrad3x3_bf3_kernel, dim3(nwg), dim3(256), 0, stream, a);
+  else if (a.mode == 0) fp_launch((wgrad3x3_bf3_v3_kernel<0, 3>), dim3(nwg), dim3(256), 0, stream, a);
+  else if (a.mode == 1) fp_launch((wgrad3x3_bf3_v3_kernel<1, 3>), dim3(nwg), dim3(256), 0, stream, a);
+  else fp_launch((wgrad3x3_bf3_v3_kernel<2, 3>), dim3(nwg), dim3(256), 0, stream, a);
   int rc = fp_check_launch("fp_conv_wgrad_bf3");
   if (rc) return rc;
   if (a.stamps) {                                   // debugging only: synchronous dump of the last launch's stamps

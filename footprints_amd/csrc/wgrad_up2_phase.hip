@@ -23,6 +23,8 @@ struct PWArgs {
   float* bpart;       // [S][Nout] column sums of dZ (bias gradient) or null -- bf16x3 kernel only, written by the ci-tile-0 workgroups
   int N, h, w, C0, Nout;
   int chunksY, chunksX, nchunks, chunksPerSplit, S, citiles, cotiles;
+  const unsigned* amax_low;   // fp16-pair variant: amax slots of low and dz
+  const unsigned* amax_dz;
 };
 
 constexpr int CHL = 2, CW = 16;
@@ -128,7 +130,20 @@ typedef float pf32x4 __attribute__((ext_vector_type(4)));
 constexpr int PXROW = 48, PZROW = 32;
 constexpr int PXPLANE = XR * 32 * PXROW, PZPLANE = 4 * CHL * 32 * PZROW;      // 6144, 8192 bytes
 
-__device__ __forceinline__ void psplit_store(unsigned char* p, int plane_stride, const pf32x4 v) {
+typedef _Float16 pf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 pf16x4 __attribute__((ext_vector_type(4)));
+// NP = 3: exact bf16 split; NP = 2: fp16 pair of v * 2^kscale (fp_common.h)
+template <int NP>
+__device__ __forceinline__ void psplit_store(unsigned char* p, int plane_stride, pf32x4 v, int kscale) {
+  if (NP == 2) {
+    v = pf32x4{ldexpf(v.x, kscale), ldexpf(v.y, kscale), ldexpf(v.z, kscale), ldexpf(v.w, kscale)};
+    const pf16x4 vh = __builtin_convertvector(v, pf16x4);
+    const pf32x4 r1 = v - __builtin_convertvector(vh, pf32x4);
+    const pf16x4 vm = __builtin_convertvector(r1, pf16x4);
+    *reinterpret_cast<uint2*>(p) = __builtin_bit_cast(uint2, vh);
+    *reinterpret_cast<uint2*>(p + plane_stride) = __builtin_bit_cast(uint2, vm);
+    return;
+  }
   const pbf16x4 vh = __builtin_convertvector(v, pbf16x4);
   const pf32x4 r1 = v - __builtin_convertvector(vh, pf32x4);
   const pbf16x4 vm = __builtin_convertvector(r1, pbf16x4);
@@ -139,10 +154,16 @@ __device__ __forceinline__ void psplit_store(unsigned char* p, int plane_stride,
   *reinterpret_cast<uint2*>(p + 2 * plane_stride) = __builtin_bit_cast(uint2, vl);
 }
 
+template <int NP>
 __global__ void __launch_bounds__(256, 3) wgrad_up2_phase_bf3_kernel(const PWArgs a) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[3 * (PXPLANE + PZPLANE)];
+  __shared__ __attribute__((aligned(16))) unsigned char lds[NP * (PXPLANE + PZPLANE)];
   unsigned char* const Xs = lds;
-  unsigned char* const Zs = lds + 3 * PXPLANE;
+  unsigned char* const Zs = lds + NP * PXPLANE;
+  int kx_ = 0, kz_ = 0;
+  if (NP == 2) {
+    kx_ = fp_hp_exponent(fp_amax_bits(a.amax_low), FP_HP_TARGET_ACT);
+    kz_ = fp_hp_exponent(fp_amax_bits(a.amax_dz), FP_HP_TARGET_ACT);
+  }
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, idx = lane & 31, h = lane >> 5;
   // XCD-contiguous logical ids: the ci x co tile workgroups of one pixel split stage the same X / dZ chunks and then share that XCD's
   // L2 (consecutive hardware ids go to different XCDs; PMC showed 3x the fused-minimum HBM bytes per launch); split s walks chunks
@@ -194,10 +215,10 @@ __global__ void __launch_bounds__(256, 3) wgrad_up2_phase_bf3_kernel(const PWArg
   auto stage = [&]() {
     if (xitem) {
       unsigned char* p = Xs + (xhr * 32 + q * 4) * PXROW + xcg * 8;
-      psplit_store(p, PXPLANE, pf32x4{xr[0].x, xr[1].x, xr[2].x, xr[3].x});
-      psplit_store(p + PXROW, PXPLANE, pf32x4{xr[0].y, xr[1].y, xr[2].y, xr[3].y});
-      psplit_store(p + 2 * PXROW, PXPLANE, pf32x4{xr[0].z, xr[1].z, xr[2].z, xr[3].z});
-      psplit_store(p + 3 * PXROW, PXPLANE, pf32x4{xr[0].w, xr[1].w, xr[2].w, xr[3].w});
+      psplit_store<NP>(p, PXPLANE, pf32x4{xr[0].x, xr[1].x, xr[2].x, xr[3].x}, kx_);
+      psplit_store<NP>(p + PXROW, PXPLANE, pf32x4{xr[0].y, xr[1].y, xr[2].y, xr[3].y}, kx_);
+      psplit_store<NP>(p + 2 * PXROW, PXPLANE, pf32x4{xr[0].z, xr[1].z, xr[2].z, xr[3].z}, kx_);
+      psplit_store<NP>(p + 3 * PXROW, PXPLANE, pf32x4{xr[0].w, xr[1].w, xr[2].w, xr[3].w}, kx_);
     }
     {
       unsigned char* p = Zs + ((wave * CHL + zr) * 32 + q * 4) * PZROW + zcg * 8;
@@ -208,10 +229,10 @@ __global__ void __launch_bounds__(256, 3) wgrad_up2_phase_bf3_kernel(const PWArg
         bs[0] += (zv[0].x + zv[1].x) + (zv[2].x + zv[3].x); bs[1] += (zv[0].y + zv[1].y) + (zv[2].y + zv[3].y);
         bs[2] += (zv[0].z + zv[1].z) + (zv[2].z + zv[3].z); bs[3] += (zv[0].w + zv[1].w) + (zv[2].w + zv[3].w);
       }
-      psplit_store(p, PZPLANE, pf32x4{zv[0].x, zv[1].x, zv[2].x, zv[3].x});
-      psplit_store(p + PZROW, PZPLANE, pf32x4{zv[0].y, zv[1].y, zv[2].y, zv[3].y});
-      psplit_store(p + 2 * PZROW, PZPLANE, pf32x4{zv[0].z, zv[1].z, zv[2].z, zv[3].z});
-      psplit_store(p + 3 * PZROW, PZPLANE, pf32x4{zv[0].w, zv[1].w, zv[2].w, zv[3].w});
+      psplit_store<NP>(p, PZPLANE, pf32x4{zv[0].x, zv[1].x, zv[2].x, zv[3].x}, kz_);
+      psplit_store<NP>(p + PZROW, PZPLANE, pf32x4{zv[0].y, zv[1].y, zv[2].y, zv[3].y}, kz_);
+      psplit_store<NP>(p + 2 * PZROW, PZPLANE, pf32x4{zv[0].z, zv[1].z, zv[2].z, zv[3].z}, kz_);
+      psplit_store<NP>(p + 3 * PZROW, PZPLANE, pf32x4{zv[0].w, zv[1].w, zv[2].w, zv[3].w}, kz_);
     }
   };
 
@@ -230,14 +251,14 @@ __global__ void __launch_bounds__(256, 3) wgrad_up2_phase_bf3_kernel(const PWArg
     if (c + c_step < c_end) issue(c + c_step);       // next chunk's global loads fly under this chunk's MFMAs
 #pragma unroll
     for (int r = 0; r < CHL; ++r) {
-      uint4 bz[3];
+      uint4 bz[NP];
 #pragma unroll
-      for (int p = 0; p < 3; ++p) bz[p] = *reinterpret_cast<const uint4*>(Zs + p * PZPLANE + ((wave * CHL + r) * 32 + idx) * PZROW + h * 16);
+      for (int p = 0; p < NP; ++p) bz[p] = *reinterpret_cast<const uint4*>(Zs + p * PZPLANE + ((wave * CHL + r) * 32 + idx) * PZROW + h * 16);
 #pragma unroll
       for (int ta = 0; ta < 2; ++ta) {
-        uint4 a0[3], a1[3];             // taps b = 0, 1: halo columns shifted by dx, dx + 1
+        uint4 a0[NP], a1[NP];           // taps b = 0, 1: halo columns shifted by dx, dx + 1
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < NP; ++p) {
           const unsigned char* row = Xs + p * PXPLANE + ((r + dy + ta) * 32 + idx) * PXROW + h * 16;
           const uint4 d = *reinterpret_cast<const uint4*>(row);                  // columns 8h .. 8h+7
           const unsigned e = *reinterpret_cast<const unsigned*>(row + 16);       // columns 8h+8, 8h+9
@@ -248,12 +269,20 @@ __global__ void __launch_bounds__(256, 3) wgrad_up2_phase_bf3_kernel(const PWArg
           a0[p] = make_uint4((s1.x & dxm) | (d.x & ~dxm), (s1.y & dxm) | (d.y & ~dxm), (s1.z & dxm) | (d.z & ~dxm), (s1.w & dxm) | (d.w & ~dxm));
           a1[p] = make_uint4((s2.x & dxm) | (s1.x & ~dxm), (s2.y & dxm) | (s1.y & ~dxm), (s2.z & dxm) | (s1.z & ~dxm), (s2.w & dxm) | (s1.w & ~dxm));
         }
-        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+        constexpr int NPROD = NP == 3 ? 6 : 4;       // smallest products first
+        constexpr int PA[6] = {NP == 3 ? 2 : 1, NP == 3 ? 0 : 1, NP == 3 ? 1 : 0, NP == 3 ? 1 : 0, 0, 0};
+        constexpr int PB[6] = {NP == 3 ? 0 : 1, NP == 3 ? 2 : 0, 1, 0, 1, 0};
 #pragma unroll
-        for (int qq = 0; qq < 6; ++qq) {
-          const pbf16x8 bb = __builtin_bit_cast(pbf16x8, bz[PB[qq]]);
-          acc[ta * 2 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(pbf16x8, a0[PA[qq]]), bb, acc[ta * 2 + 0], 0, 0, 0);
-          acc[ta * 2 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(pbf16x8, a1[PA[qq]]), bb, acc[ta * 2 + 1], 0, 0, 0);
+        for (int qq = 0; qq < NPROD; ++qq) {
+          if (NP == 2) {
+            const pf16x8 bb = __builtin_bit_cast(pf16x8, bz[PB[qq]]);
+            acc[ta * 2 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(pf16x8, a0[PA[qq]]), bb, acc[ta * 2 + 0], 0, 0, 0);
+            acc[ta * 2 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(pf16x8, a1[PA[qq]]), bb, acc[ta * 2 + 1], 0, 0, 0);
+          } else {
+            const pbf16x8 bb = __builtin_bit_cast(pbf16x8, bz[PB[qq]]);
+            acc[ta * 2 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(pbf16x8, a0[PA[qq]]), bb, acc[ta * 2 + 0], 0, 0, 0);
+            acc[ta * 2 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(pbf16x8, a1[PA[qq]]), bb, acc[ta * 2 + 1], 0, 0, 0);
+          }
         }
       }
     }
@@ -267,7 +296,7 @@ __global__ void __launch_bounds__(256, 3) wgrad_up2_phase_bf3_kernel(const PWArg
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int ci = ci0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      out[((size_t)tp * a.C0 + ci) * a.Nout + co0 + idx] = acc[tp][r];
+      out[((size_t)tp * a.C0 + ci) * a.Nout + co0 + idx] = NP == 2 ? ldexpf(acc[tp][r], -(kx_ + kz_)) : acc[tp][r];
     }
   if (want_bias) {                                   // 32 staging threads per channel quad -> one partial per output channel
     float* red = reinterpret_cast<float*>(lds);      // the main loop ended with a barrier: the planes are dead
@@ -371,7 +400,8 @@ extern "C" int64_t fp_conv_up2_phase_wgrad_workspace(int32_t N, int32_t h, int32
 
 static int phase_wgrad_launch(bool bf3, const float* low, const float* dz, float* dw_oihw, float* db, int32_t N, int32_t h, int32_t w, int32_t C0,
                               int32_t Nout, int32_t kc_total, int32_t k_begin, int accumulate, void* workspace,
-                              int64_t workspace_bytes, fp_stream_t stream_) {
+                              int64_t workspace_bytes, fp_stream_t stream_, const uint32_t* amax_low = nullptr,
+                              const uint32_t* amax_dz = nullptr) {
   hipStream_t stream = (hipStream_t)stream_;
   FP_REQUIRE(low && dz && dw_oihw && workspace, "fp_conv_up2_phase_wgrad: null pointer");
   FP_REQUIRE(eligible(N, h, w, C0, Nout), "fp_conv_up2_phase_wgrad: shape not supported (see fp_conv_up2_phase_wgrad_workspace)");
@@ -379,12 +409,14 @@ static int phase_wgrad_launch(bool bf3, const float* low, const float* dz, float
   const PPlan p = plan(N, h, w, C0, Nout);
   FP_REQUIRE(workspace_bytes >= fp_conv_up2_phase_wgrad_workspace(N, h, w, C0, Nout), "fp_conv_up2_phase_wgrad: workspace too small");
   PWArgs a;
+  a.amax_low = amax_low; a.amax_dz = amax_dz;
   a.low = low; a.dz = dz; a.part = (float*)workspace;
   a.bpart = db ? (float*)workspace + (size_t)p.S * 16 * C0 * Nout : nullptr;
   a.N = N; a.h = h; a.w = w; a.C0 = C0; a.Nout = Nout;
   a.chunksY = p.cy; a.chunksX = p.cx; a.nchunks = p.nchunks; a.chunksPerSplit = p.chunksPerSplit; a.S = p.S;
   a.citiles = p.citiles; a.cotiles = p.cotiles;
-  if (bf3) fp_launch(wgrad_up2_phase_bf3_kernel, dim3(p.S * p.citiles * p.cotiles), dim3(256), 0, stream, a);
+  if (bf3 && amax_low) fp_launch(wgrad_up2_phase_bf3_kernel<2>, dim3(p.S * p.citiles * p.cotiles), dim3(256), 0, stream, a);
+  else if (bf3) fp_launch(wgrad_up2_phase_bf3_kernel<3>, dim3(p.S * p.citiles * p.cotiles), dim3(256), 0, stream, a);
   else fp_launch(wgrad_up2_phase_kernel, dim3(p.S * p.citiles * p.cotiles), dim3(256), 0, stream, a);
   int rc = fp_check_launch("fp_conv_up2_phase_wgrad");
   if (rc) return rc;
@@ -419,4 +451,13 @@ extern "C" int fp_conv_up2_phase_wgrad_bf3(const float* low, const float* dz, fl
                                            int32_t C0, int32_t Nout, int32_t kc_total, int32_t k_begin, int accumulate, void* workspace,
                                            int64_t workspace_bytes, fp_stream_t stream) {
   return phase_wgrad_launch(true, low, dz, dw_oihw, db, N, h, w, C0, Nout, kc_total, k_begin, accumulate, workspace, workspace_bytes, stream);
+}
+
+// fp16-pair operands (fp_conv3x3_hp): `amax_low` / `amax_dz` = amax slots of the two tensors
+extern "C" int fp_conv_up2_phase_wgrad_hp(const float* low, const float* dz, float* dw_oihw, float* db, int32_t N, int32_t h, int32_t w,
+                                          int32_t C0, int32_t Nout, int32_t kc_total, int32_t k_begin, int accumulate, void* workspace,
+                                          int64_t workspace_bytes, const uint32_t* amax_low, const uint32_t* amax_dz, fp_stream_t stream) {
+  FP_REQUIRE(amax_low && amax_dz, "fp_conv_up2_phase_wgrad_hp: amax slots missing");
+  return phase_wgrad_launch(true, low, dz, dw_oihw, db, N, h, w, C0, Nout, kc_total, k_begin, accumulate, workspace, workspace_bytes, stream,
+                            amax_low, amax_dz);
 }

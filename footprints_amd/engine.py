@@ -32,6 +32,9 @@ _FOLD = not bool(int(os.environ.get("FP_NO_FOLD", "0")))
 _BF3 = not bool(int(os.environ.get("FP_NO_BF3", "0")))
 _WBF3 = _BF3 and not bool(int(os.environ.get("FP_NO_WBF3", "0")))      # ... and for the weight-gradient kernel
 _PWBF3 = not bool(int(os.environ.get("FP_NO_PHASE_WBF3", "0")))           # ... and for the phase weight-gradient kernel (A/B switch)
+# fp16-pair operands (two fp16 terms after a per-tensor power-of-two scaling, four MFMA products, 22 significant bits) for the same
+# kernels, with the scaling taken from amax slots that producers publish / a reduction fills (csrc/fp_common.h); FP_HP=0 keeps bf16x3
+_HP = _BF3 and bool(int(os.environ.get("FP_HP", "1")))
 # nearest-x2 phase decomposition of the upsample convs (conv_up2_phase.hip); FP_NO_PHASE=1 keeps the fused-gather path.
 _PHASE = not bool(int(os.environ.get("FP_NO_PHASE", "0")))
 
@@ -57,6 +60,10 @@ class ConvRec:
         # bf16x3-split copies (3x3 stride-1 convs): forward, dgrad, and the skip-slice pair of the upsample convs
         self.bf3 = _BF3 and self.K == 3 and self.stride == 1 and not stem and not head
         self.wp3 = self.wpd3 = self.wsk3 = self.wds3 = self.wph3 = self.wdu3 = None
+        # fp16-pair copies of the same four tile packings, and the slot holding max |w| they were scaled by
+        self.hp = self.bf3 and _HP
+        self.hp_f = self.hp_d = self.hp_sk = self.hp_ds = self.hp_ph = self.hp_du = None      # + phase forward / phase data-gradient
+        self.wslot = None
         self.gw = None    # gradient views (flat grad buffer)
         self.gb = None
 
@@ -139,6 +146,62 @@ class DecoderRec:
         return out + [self.o41, self.o42]
 
 
+class AmaxBook:
+    """amax slots of the fp16-pair kernels (include/footprints_hip.h): which slot holds max |x| of which activation / gradient tensor.
+
+    Slots are addressed by a TAG (arena buffer name + role), so a recorded launch plan replays the same addresses every step; the
+    whole pool is zeroed at the start of a forward.  An association tensor -> slot is made when a kernel publishes the amax of its
+    output or when `get` reduces the tensor on the stream that is about to consume it; it is dropped when the arena hands the
+    buffer out again (Engine.buf: every producer obtains its output there).  A slot filled on one stream is only reused by a
+    consumer on the same stream -- or on any stream once `globalize` declared the streams joined (end of the forward pass)."""
+
+    def __init__(self, device, nslots=1024):
+        self.pool = torch.zeros(nslots * ops.amax_elems(), dtype=torch.int32, device=device)
+        self.nslots = nslots
+        self.by_tag = {}
+        self.assoc = {}        # data_ptr -> (slot, raw stream handle or None = any stream)
+        self.name_of = {}      # data_ptr -> arena name (Engine.buf)
+
+    def slot(self, tag):
+        i = self.by_tag.get(tag)
+        if i is None:
+            i = self.by_tag[tag] = len(self.by_tag)
+            if i >= self.nslots:
+                raise RuntimeError("footprints_amd: amax slot pool exhausted")
+        return self.pool[i * ops.amax_elems():(i + 1) * ops.amax_elems()]
+
+    def begin(self):
+        ops.zero_u32(self.pool)
+        self.assoc.clear()
+
+    def globalize(self):
+        for k, (sl, _) in list(self.assoc.items()):
+            self.assoc[k] = (sl, None)
+
+    def drop(self, t):
+        self.assoc.pop(t.data_ptr(), None)
+
+    def out_slot(self, t):
+        """slot a producer of `t` publishes into (associate with `published` after the launch)"""
+        return self.slot("out:" + self.name_of.get(t.data_ptr(), "ptr%x" % t.data_ptr()))
+
+    def published(self, t, sl, any_stream=False):
+        self.assoc[t.data_ptr()] = (sl, None if any_stream else ops.stream())
+
+    def get(self, t, any_stream=False):
+        """slot holding max |t|, valid for a consumer launched on the current stream from now on"""
+        e = self.assoc.get(t.data_ptr())
+        cur = ops.stream()
+        if e is not None and (e[1] is None or e[1] == cur):
+            if any_stream and e[1] is not None:
+                self.assoc[t.data_ptr()] = (e[0], None)
+            return e[0]
+        sl = self.slot("in:%s@%x" % (self.name_of.get(t.data_ptr(), "ptr%x" % t.data_ptr()), cur))
+        ops.amax_f32(t, sl)
+        self.assoc[t.data_ptr()] = (sl, None if any_stream else cur)
+        return sl
+
+
 class Engine:
     def __init__(self, model):
         self.model = model
@@ -156,6 +219,7 @@ class Engine:
         else:
             self.decoders = [DecoderRec("mask_decoder", model.mask_decoder), DecoderRec("depth_decoder", model.depth_decoder)]
         self._bufs = {}
+        self.amax = AmaxBook(dev)
         self._flatten()
         self._alloc_packed()
         # 1-channel heads (segmentation) run through the Cin -> 2 head kernels with a zero second filter: padded copies of the
@@ -272,6 +336,16 @@ class Engine:
                            ops.up2_packed_weight_elems(C0, c.Cout) * 3 // 2]
             else:
                 ex += [0, 0, 0, 0, 0, 0]
+            if c.hp:      # fp16-pair copies of the tile packings (same roles as wp3 / wpd3 / wsk3 / wds3)
+                if c.up2 is None:
+                    ex += [ops.packed_weight_elems_hp(c.Cout, c.Cin, 3, False), ops.packed_weight_elems_hp(c.Cout, c.Cin, 3, True), 0, 0, 0, 0]
+                else:
+                    C0, C1 = c.up2
+                    ex += [ops.packed_weight_elems_hp(c.Cout, c.Cin, 3, False) if C1 else 0, 0,
+                           ops.packed_weight_elems_hp(c.Cout, C1, 3, False) if C1 else 0, ops.packed_weight_elems_hp(c.Cout, C1, 3, True) if C1 else 0,
+                           ops.up2_packed_weight_elems(c.Cout, C0), ops.up2_packed_weight_elems(C0, c.Cout)]      # two fp16 = one float per weight
+            else:
+                ex += [0, 0, 0, 0, 0, 0]
             plan.append((c, total, nf, nd, ex))
             total += nf + nd + sum(ex)
         self.packed = torch.empty(total, device=self.device)
@@ -283,29 +357,46 @@ class Engine:
             for n in ex:
                 views.append(self.packed[o:o + n] if n else None)
                 o += n
-            c.wph, c.wsk, c.wdu, c.wds, c.wp3, c.wpd3, c.wsk3, c.wds3, c.wph3, c.wdu3 = views
+            c.wph, c.wsk, c.wdu, c.wds, c.wp3, c.wpd3, c.wsk3, c.wds3, c.wph3, c.wdu3, c.hp_f, c.hp_d, c.hp_sk, c.hp_ds, c.hp_ph, c.hp_du = views
+        convs = self.all_convs()
+        self.wamax = torch.zeros(len(convs) * ops.amax_elems(), dtype=torch.int32, device=self.device)
+        for i, c in enumerate(convs):
+            c.wslot = self.wamax[i * ops.amax_elems():(i + 1) * ops.amax_elems()]
 
     def refresh_packed(self, force=False, overlap=False):
         """repack every convolution's weights if they changed.  overlap=True (Engine.forward only): all but the stem / layer1
         tables are packed on a side stream and the caller waits for self._pack_ev (self._wait_pack) before layer2."""
         vers = tuple(c.w._version for c in self.all_convs())
-        if not (force or self.weights_dirty or vers != self._versions):
+        key = (self.flat_param.data_ptr(), bool(self.inference_bf16x2))
+        if not (force or self.weights_dirty or vers != self._versions or key != self._pack_table_key):
             return
-        if self._pack_table is None or self._pack_table_key != self.flat_param.data_ptr():
+        if self._pack_table is None or self._pack_table_key != key:
             def jobs_of(convs):
                 jobs = []
                 for c in convs:
                     jobs.append((L.PACK_STEM if c.stem else L.PACK_FWD, c.w.data, c.wp, 0, c.Cin))
                     if c.wpd is not None:
                         jobs.append((L.PACK_DGRAD, c.w.data, c.wpd, 0, c.Cin))
-                    if c.wp3 is not None:
+                    if c.hp:                 # fp16-pair tile packings, scaled by the weight tensor's amax slot
+                        if c.hp_f is not None:
+                            jobs.append((L.PACK_FWD_HP, c.w.data, c.hp_f, 0, c.Cin, c.wslot))
+                        if c.hp_d is not None:
+                            jobs.append((L.PACK_DGRAD_HP, c.w.data, c.hp_d, 0, c.Cin, c.wslot))
+                        if c.hp_sk is not None:
+                            jobs.append((L.PACK_FWD_HP, c.w.data, c.hp_sk, c.up2[0], c.up2[1], c.wslot))
+                            jobs.append((L.PACK_DGRAD_HP, c.w.data, c.hp_ds, c.up2[0], c.up2[1], c.wslot))
+                        if c.hp_ph is not None:
+                            jobs.append((L.PACK_UP2_FWD_HP, c.w.data, c.hp_ph, 0, c.up2[0], c.wslot))
+                            jobs.append((L.PACK_UP2_DGRAD_HP, c.w.data, c.hp_du, 0, c.up2[0], c.wslot))
+                    keep3 = (not c.hp) or self.inference_bf16x2       # the bf16 tile packings: only where a kernel still reads them
+                    if c.wp3 is not None and keep3:
                         jobs.append((L.PACK_FWD_BF3, c.w.data, c.wp3, 0, c.Cin))
-                    if c.wpd3 is not None:
+                    if c.wpd3 is not None and keep3:
                         jobs.append((L.PACK_DGRAD_BF3, c.w.data, c.wpd3, 0, c.Cin))
-                    if c.wsk3 is not None:
+                    if c.wsk3 is not None and keep3:
                         jobs.append((L.PACK_FWD_BF3, c.w.data, c.wsk3, c.up2[0], c.up2[1]))
                         jobs.append((L.PACK_DGRAD_BF3, c.w.data, c.wds3, c.up2[0], c.up2[1]))
-                    if c.wph3 is not None:
+                    if c.wph3 is not None and not c.hp:
                         jobs.append((L.PACK_UP2_FWD_BF3, c.w.data, c.wph3, 0, c.up2[0]))
                         jobs.append((L.PACK_UP2_DGRAD_BF3, c.w.data, c.wdu3, 0, c.up2[0]))
                     if c.up2 is not None:
@@ -321,15 +412,22 @@ class Engine:
             first = [self.stem] + [c for blk in self.blocks if blk.Cout == 64 and blk.stride == 1 for c in (blk.c1, blk.c2)]
             rest = [c for c in self.all_convs() if not any(c is f for f in first)]
             self._pack_table = (ops.build_pack_table(jobs_of(first), self.device), ops.build_pack_table(jobs_of(rest), self.device))
-            self._pack_table_key = self.flat_param.data_ptr()      # parameters live in self.flat_param: pointers are stable
+            self._pack_table_key = key      # parameters live in self.flat_param: pointers are stable
+        if _HP:
+            ops.zero_u32(self.wamax)
+            ops.pack_weights_amax(self._pack_table[0])
         ops.pack_weights_batched(self._pack_table[0])
         cur = ops.current_stream()
         if self.concurrent and overlap:
             ops.event_wait(self.wg, self._record(cur))
             with ops.on_stream(self.wg):
+                if _HP:
+                    ops.pack_weights_amax(self._pack_table[1])
                 ops.pack_weights_batched(self._pack_table[1])
                 self._pack_ev = self._record(self.wg)
         else:
+            if _HP:
+                ops.pack_weights_amax(self._pack_table[1])
             ops.pack_weights_batched(self._pack_table[1])
             self._pack_ev = None
         for d in self.decoders:
@@ -352,6 +450,8 @@ class Engine:
         if t is None or t.numel() < n or t.dtype != dtype:
             t = torch.empty(max(n, 1), dtype=dtype, device=self.device)
             self._bufs[name] = t
+            self.amax.name_of[t.data_ptr()] = name
+        self.amax.assoc.pop(t.data_ptr(), None)       # the buffer is about to be rewritten: its amax slot no longer describes it
         return t[:n].view(shape)
 
     # ------------------------------------------------------------------------------------------------
@@ -374,8 +474,11 @@ class Engine:
 
     def _bn_apply(self, rec, z, out, residual=None, relu=True):
         M = z.numel() // rec.C
+        so = self.amax.out_slot(out) if _HP else None        # the next convolution's operand scale comes out of this pass
         ops.bn_apply(z.view(M, rec.C), rec.scale, rec.shift, out.view(M, rec.C),
-                     residual=None if residual is None else residual.view(M, rec.C), relu=relu)
+                     residual=None if residual is None else residual.view(M, rec.C), relu=relu, amax_out=so)
+        if so is not None:
+            self.amax.published(out, so)
         return out
 
     @staticmethod
@@ -394,12 +497,32 @@ class Engine:
             hd.gw.copy_(hd.gw2[0:1])
             hd.gb.copy_(hd.gb2[0:1])
 
-    @staticmethod
-    def _cv(d, src, w32, w3, out, **kw):
-        """one 3x3 / 1x1 convolution or data-gradient launch: the bf16x3-split tile kernel where it applies, else fp_conv_igemm"""
-        if w3 is not None and ops.conv3x3_bf3_supported(d):
+    def _cv(self, d, src, w32, w3, out, hp=None, **kw):
+        """one 3x3 / 1x1 convolution or data-gradient launch: the split-operand tile kernel where it applies (hp = (fp16-pair packing,
+        weight amax slot): four fp16 products; else w3: six bf16 products), else fp_conv_igemm"""
+        if (w3 is not None or hp is not None) and ops.conv3x3_bf3_supported(d):
+            if hp is not None and hp[0] is not None and not ops._bf16x2:
+                return self._cv_hp(d, src, hp[0], hp[1], out, **kw)
             return ops.conv3x3_bf3(d, src, w3, out, **kw)
         return ops.conv_igemm(d, src, None, w32, out, **kw)
+
+    def _sink_slot(self, t):
+        """amax slot the producer of `t` publishes into (None with the bf16 operand format); follow the launch with _sink_done(t)"""
+        return self.amax.out_slot(t) if _HP else None
+
+    def _sink_done(self, t):
+        if _HP:
+            self.amax.published(t, self.amax.out_slot(t))
+
+    def _cv_hp(self, d, src, wh, wslot, out, src1=None, **kw):
+        book = self.amax
+        sa = book.get(src)
+        sa1 = book.get(src1) if (src1 is not None and d.C1) else None
+        so = None if (d.epi & L.EPI_ACCUM) else book.out_slot(out)        # an accumulated tensor is never a tile-conv operand
+        ops.conv3x3_hp(d, src, wh, out, sa, wslot, amax_out=so, src1=src1, amax_src1=sa1, **kw)
+        if so is not None:
+            book.published(out, so)
+        return out
 
     # ------------------------------------------------------------------------------------------------
     # inference fast path: eval-mode BatchNorm folded into the encoder convs
@@ -420,6 +543,7 @@ class Engine:
             total = 0
             for c, _ in pairs:
                 n3 = ops.packed_weight_elems_bf3(c.Cout, c.Cin, 3, False) if c.bf3 else 0
+                n3 += ops.packed_weight_elems_hp(c.Cout, c.Cin, 3, False) if c.hp else 0
                 total += c.w.numel() + ops.packed_weight_elems(c.Cout, c.Cin, c.K, False, c.stem) + n3 + c.Cout
             self._fold_buf = torch.empty(total, device=self.device)
             o = 0
@@ -433,6 +557,10 @@ class Engine:
                 n = ops.packed_weight_elems_bf3(c.Cout, c.Cin, 3, False) if c.bf3 else 0
                 c.fwp3 = self._fold_buf[o:o + n] if n else None
                 o += n
+                n = ops.packed_weight_elems_hp(c.Cout, c.Cin, 3, False) if c.hp else 0
+                c.fhp = self._fold_buf[o:o + n] if n else None
+                o += n
+                c.fslot = torch.zeros(ops.amax_elems(), dtype=torch.int32, device=self.device) if n else None
                 rec.fshift = self._fold_buf[o:o + c.Cout]
                 o += c.Cout
         for c, rec in pairs:
@@ -440,8 +568,10 @@ class Engine:
             ops.bn_eval_coeffs(bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, rec.scale, rec.fshift, bn.eps)
             ops.scale_rows(c.w.data, rec.scale, c.fw)
             ops.pack_conv_weight(c.fw, c.fwp, c.stem)
-            if c.fwp3 is not None:
+            if c.fwp3 is not None and (c.fhp is None or self.inference_bf16x2):
                 ops.pack_conv_weight_bf3(c.fw, c.fwp3, False)
+            if c.fhp is not None:
+                ops.pack_conv_weight_hp(c.fw, c.fhp, c.fslot, False)
         self._fold_ready = True
 
     def _encoder_eval_folded(self, image, N, H, W, S):
@@ -456,7 +586,10 @@ class Engine:
                        bias=self.bn0.fshift)
         hp, wp_ = (h + 1) // 2, (w + 1) // 2
         pool = buf("pool", (N, hp, wp_, 64))
-        ops.maxpool_fwd(f0, pool, buf("pool.argmax", (N, hp, wp_, 64), torch.uint8))
+        so = self.amax.out_slot(pool) if _HP else None
+        ops.maxpool_fwd(f0, pool, buf("pool.argmax", (N, hp, wp_, 64), torch.uint8), amax_out=so)
+        if so is not None:
+            self.amax.published(pool, so)
         feats, dims = [f0], [(h, w)]
         x, h, w = pool, hp, wp_
         self._wait_pack()          # the decoders' packed weights (the folded encoder copies are packed by _build_fold)
@@ -464,14 +597,16 @@ class Engine:
             s = blk.stride
             oh, ow = (h - 1) // s + 1, (w - 1) // s + 1
             d1 = ops.make_desc(N, oh, ow, h, w, blk.c1.Cin, 0, blk.Cout, 3, s, 1, L.GATHER_FWD_ZERO, act=L.ACT_RELU)
-            a1 = self._cv(d1, x, blk.c1.fwp, blk.c1.fwp3, buf("b%d.a1" % i, (N, oh, ow, blk.Cout)), bias=blk.bn1.fshift)
+            a1 = self._cv(d1, x, blk.c1.fwp, blk.c1.fwp3, buf("b%d.a1" % i, (N, oh, ow, blk.Cout)), hp=(blk.c1.fhp, blk.c1.fslot),
+                          bias=blk.bn1.fshift)
             if blk.ds is not None:
                 dd = ops.make_desc(N, oh, ow, h, w, blk.ds.Cin, 0, blk.Cout, 1, s, 0, L.GATHER_FWD_ZERO)
                 idt = self._cv(dd, x, blk.ds.fwp, None, buf("b%d.idt" % i, (N, oh, ow, blk.Cout)), bias=blk.bnd.fshift)
             else:
                 idt = x
             d2 = ops.make_desc(N, oh, ow, oh, ow, blk.Cout, 0, blk.Cout, 3, 1, 1, L.GATHER_FWD_ZERO, act=L.ACT_RELU)
-            out = self._cv(d2, a1, blk.c2.fwp, blk.c2.fwp3, buf("b%d.out" % i, (N, oh, ow, blk.Cout)), bias=blk.bn2.fshift, addend=idt)
+            out = self._cv(d2, a1, blk.c2.fwp, blk.c2.fwp3, buf("b%d.out" % i, (N, oh, ow, blk.Cout)), hp=(blk.c2.fhp, blk.c2.fslot),
+                           bias=blk.bn2.fshift, addend=idt)
             x, h, w = out, oh, ow
             if (i + 1 == len(self.blocks)) or (self.blocks[i + 1].stride == 2):
                 feats.append(out)
@@ -488,7 +623,7 @@ class Engine:
     def _conv_enc(self, c, x, N, H, W, out):
         OH, OW = (H + 2 * c.pad - c.K) // c.stride + 1, (W + 2 * c.pad - c.K) // c.stride + 1
         d = ops.make_desc(N, OH, OW, H, W, c.Cin, 0, c.Cout, c.K, c.stride, c.pad, L.GATHER_FWD_ZERO)
-        return self._cv(d, x, c.wp, c.wp3, out)
+        return self._cv(d, x, c.wp, c.wp3, out, hp=(c.hp_f, c.wslot))
 
     @staticmethod
     def _phase_ok(h, w):
@@ -499,14 +634,22 @@ class Engine:
         if up2 and c.up2 is not None and self._phase_ok(H // 2, W // 2):
             if C1:      # skip half at full resolution (raw partial sums), then the four phases of the upsampled half on top
                 d = ops.make_desc(N, H, W, H, W, C1, 0, c.Cout, 3, 1, 1, L.GATHER_FWD_REFLECT)
-                self._cv(d, x1, c.wsk, c.wsk3, out)
+                self._cv(d, x1, c.wsk, c.wsk3, out, hp=(c.hp_sk, c.wslot))
+            if c.hp_ph is not None:
+                so = self.amax.out_slot(out)
+                ops.conv_up2_phase_fwd_hp(x0, c.hp_ph, c.b.data, out, self.amax.get(x0), c.wslot, amax_out=so, act=L.ACT_ELU,
+                                          addend=out if C1 else None)
+                self.amax.published(out, so)
+                return out
             phase_fwd = ops.conv_up2_phase_fwd_bf3 if c.wph3 is not None else ops.conv_up2_phase_fwd
             return phase_fwd(x0, c.wph3 if c.wph3 is not None else c.wph, c.b.data, out, act=L.ACT_ELU, addend=out if C1 else None)
         gather = L.GATHER_FWD_REFLECT_UP2 if up2 else L.GATHER_FWD_REFLECT
         d = ops.make_desc(N, H, W, H, W, C0, C1, c.Cout, 3, 1, 1, gather, act=L.ACT_ELU)
         if x1 is None and not up2:
-            return self._cv(d, x0, c.wp, c.wp3, out, bias=c.b.data)
-        if up2 and c.wp3 is not None and ops.conv3x3_bf3_supported(d):      # concat gather inside the bf16x3 tile kernel
+            return self._cv(d, x0, c.wp, c.wp3, out, hp=(c.hp_f, c.wslot), bias=c.b.data)
+        if up2 and c.wp3 is not None and ops.conv3x3_bf3_supported(d):      # concat gather inside the split-operand tile kernel
+            if c.hp_f is not None and not ops._bf16x2:
+                return self._cv_hp(d, x0, c.hp_f, c.wslot, out, src1=x1, bias=c.b.data)
             return ops.conv3x3_bf3(d, x0, c.wp3, out, bias=c.b.data, src1=x1)
         return ops.conv_igemm(d, x0, x1, c.wp, out, bias=c.b.data)
 
@@ -534,6 +677,8 @@ class Engine:
             self._flatten()
             self.weights_dirty = True
         self.refresh_packed(overlap=True)
+        if _HP:
+            self.amax.begin()
         image = image.contiguous().float()
         S = {"N": N, "H": H, "W": W, "image": image, "training": training,
              "scales": set(range(4)) if scales is None else set(scales)}
@@ -553,7 +698,10 @@ class Engine:
         hp, wp_ = (h + 1) // 2, (w + 1) // 2
         pool = buf("pool", (N, hp, wp_, 64))
         am = buf("pool.argmax", (N, hp, wp_, 64), torch.uint8)
-        ops.maxpool_fwd(f0, pool, am)
+        so = self.amax.out_slot(pool) if _HP else None
+        ops.maxpool_fwd(f0, pool, am, amax_out=so)
+        if so is not None:
+            self.amax.published(pool, so)
         feats = [f0]
         dims = [(h, w)]
         x, h, w = pool, hp, wp_
@@ -594,6 +742,9 @@ class Engine:
                 outputs = [torch.empty((N, 4, H, W), device=self.device) for _ in range(4)]
         S["dec"] = [{} for _ in self.decoders]
         main = ops.current_stream()
+        if _HP:
+            for f in S["feats"]:                     # both decoders read the features: one reduction each, before the streams fork
+                self.amax.get(f, any_stream=True)
         if self.concurrent and len(self.decoders) == 2:
             ops.event_wait(self.aux, self._record(main))                 # encoder features ready
             self._interleave([(self.aux, self._decoder_forward(self.decoders[1], S, outputs, S["dec"][1])),
@@ -683,10 +834,13 @@ class Engine:
         """Weight (+bias) gradient of one conv.  side = a stream: launch there, ordered after everything already
         queued on the current stream (dz is ready) -- the caller guarantees dz / src stay untouched until the join."""
         d = ops.make_desc(N, OH, OW, IH, IW, C0, C1, c.Cout, c.K, c.stride, c.pad, gather)
+        split = _WBF3 and src1 is None and ops.conv_wgrad_bf3_supported(d)
+        # fp16-pair operands: both amax slots are settled on THIS stream (the producers', or a reduction here) before the side stream forks
+        am = (self.amax.get(src0), self.amax.get(dz)) if (split and _HP) else None
 
         def launch():
-            if _WBF3 and src1 is None and ops.conv_wgrad_bf3_supported(d):
-                ops.conv_wgrad_bf3(d, src0, dz, c.gw, 0, accumulate=acc, db=c.gb)       # bias gradient from the same pass over dz
+            if split:
+                ops.conv_wgrad_bf3(d, src0, dz, c.gw, 0, accumulate=acc, db=c.gb, amax=am)       # bias gradient from the same pass over dz
                 return
             ops.conv_wgrad(d, src0, src1, dz, c.gw, accumulate=acc)
             if c.gb is not None:
@@ -706,25 +860,37 @@ class Engine:
             d_sk = ops.make_desc(N, H, W, H, W, C1, 0, c.Cout, 3, 1, 1, L.GATHER_FWD_REFLECT) if C1 else None
             if not (_WBF3 and ops.conv_wgrad_bf3_supported(d_lo) and (d_sk is None or ops.conv_wgrad_bf3_supported(d_sk))):
                 return self._wgrad(c, L.GATHER_FWD_REFLECT_UP2, low, skip, dz, N, H, W, H, W, C0, C1, acc, side)
+            s_dz = self.amax.get(dz) if _HP else None
+            am_lo = (self.amax.get(low), s_dz) if _HP else None
+            am_sk = (self.amax.get(skip), s_dz) if (_HP and d_sk is not None) else None
 
-            def launch_small():      # small images (12x40): both halves through the bf16x3 kernel, the upsampling folded into its gather
-                ops.conv_wgrad_bf3(d_lo, low, dz, c.gw, 0, accumulate=acc, db=c.gb)
+            def launch_small():      # small images (12x40): both halves through the split-operand kernel, the upsampling folded into its gather
+                ops.conv_wgrad_bf3(d_lo, low, dz, c.gw, 0, accumulate=acc, db=c.gb, amax=am_lo)
                 if d_sk is not None:
-                    ops.conv_wgrad_bf3(d_sk, skip, dz, c.gw, C0, accumulate=acc)
+                    ops.conv_wgrad_bf3(d_sk, skip, dz, c.gw, C0, accumulate=acc, amax=am_sk)
             if side is None:
                 return launch_small()
             ops.event_wait(side, self._record(ops.current_stream()))
             with ops.on_stream(side):
                 return launch_small()
 
+        pbf3 = _WBF3 and _PWBF3
+        d_skip = ops.make_desc(N, H, W, H, W, C1, 0, c.Cout, 3, 1, 1, L.GATHER_FWD_REFLECT) if C1 else None
+        skip_split = d_skip is not None and _WBF3 and ops.conv_wgrad_bf3_supported(d_skip)
+        s_dz = self.amax.get(dz) if (_HP and (pbf3 or skip_split)) else None
+        s_low = self.amax.get(low) if (_HP and pbf3) else None
+        am_sk = (self.amax.get(skip), s_dz) if (_HP and skip_split) else None
+
         def launch():
-            pbf3 = _WBF3 and _PWBF3
-            ops.conv_up2_phase_wgrad(low, dz, c.gw, 0, accumulate=acc, bf3=pbf3, db=c.gb if pbf3 else None)   # + bias gradient
+            if s_low is not None:
+                ops.conv_up2_phase_wgrad_hp(low, dz, c.gw, s_low, s_dz, 0, accumulate=acc, db=c.gb)               # + bias gradient
+            else:
+                ops.conv_up2_phase_wgrad(low, dz, c.gw, 0, accumulate=acc, bf3=pbf3, db=c.gb if pbf3 else None)   # + bias gradient
             bias_done = pbf3 or c.gb is None
             if C1:
-                d = ops.make_desc(N, H, W, H, W, C1, 0, c.Cout, 3, 1, 1, L.GATHER_FWD_REFLECT)
-                if _WBF3 and ops.conv_wgrad_bf3_supported(d):
-                    ops.conv_wgrad_bf3(d, skip, dz, c.gw, C0, accumulate=acc, db=None if bias_done else c.gb)
+                d = d_skip
+                if skip_split:
+                    ops.conv_wgrad_bf3(d, skip, dz, c.gw, C0, accumulate=acc, db=None if bias_done else c.gb, amax=am_sk)
                     bias_done = True
                 else:
                     ops.conv_wgrad_slice(d, skip, None, dz, c.gw, C0, accumulate=acc)
@@ -739,12 +905,14 @@ class Engine:
     def _dgrad_dec(self, c, dz, N, H, W, out, actsrc=None, addend=None, accum=False):
         epi = (L.EPI_ACTGRAD_ELU if actsrc is not None else 0) | (L.EPI_ACCUM if accum else 0)
         d = ops.make_desc(N, H, W, H, W, c.Cout, 0, c.Cin, 3, 1, 1, L.GATHER_DGRAD_REFLECT, epi=epi)
-        return self._cv(d, dz, c.wpd, c.wpd3, out, actsrc=actsrc, addend=addend)
+        return self._cv(d, dz, c.wpd, c.wpd3, out, hp=(c.hp_d, c.wslot), actsrc=actsrc, addend=addend)
 
     def _dgrad_up2_ext(self, c, dz, N, hl, wl, C0, pfx):
         """gradient wrt the low-res input of an upsample conv on the (hl+2) x (wl+2) extended grid (ops.up2_fold_bwd folds it)"""
         ext = self.buf(pfx + "XV", (N, hl + 2, wl + 2, C0))
-        if c.wdu3 is not None and self._phase_ok(hl + 2, wl + 2):      # bf16x3 phase kernel (8x16 tiles of the extended grid)
+        if c.wdu3 is not None and self._phase_ok(hl + 2, wl + 2):      # split-operand phase kernel (8x16 tiles of the extended grid)
+            if c.hp_du is not None:
+                return ops.conv_up2_phase_dgrad_hp(dz, c.hp_du, ext, self.amax.get(dz), c.wslot)
             return ops.conv_up2_phase_dgrad_bf3(dz, c.wdu3, ext)
         d = ops.make_desc(N, hl + 2, wl + 2, 2 * hl, 2 * wl, c.Cout, 0, C0, 4, 2, 3, L.GATHER_FWD_ZERO)
         return ops.conv_igemm(d, dz, None, c.wdu, ext)
@@ -770,6 +938,7 @@ class Engine:
         N = S["N"]
         feats, dims = S["feats"], S["dims"]
         buf = self.buf
+        self.amax.globalize()            # every stream of the forward pass was joined: its slots are valid for any backward stream
         gouts = [g.contiguous() for g in grad_outputs]
         dF = [buf("dF%d" % i, tuple(f.shape)) for i, f in enumerate(feats)]
         main = ops.current_stream()
@@ -793,13 +962,16 @@ class Engine:
             dz2 = buf("g.dz2.%d" % i, (N, h, w, C))      # per-block: read later by the side-stream wgrad
             g = buf("g.g", (N, h, w, C))
             ops.bn_bwd(dout.view(M, C), B["out"].view(M, C), B["z2"].view(M, C), blk.bn2.mean, blk.bn2.invstd, blk.bn2.bn.weight.data,
-                       dz2.view(M, C), blk.bn2.gg, blk.bn2.gb, g_out=g.view(M, C), accumulate=accumulate)
+                       dz2.view(M, C), blk.bn2.gg, blk.bn2.gb, g_out=g.view(M, C), accumulate=accumulate, amax_out=self._sink_slot(dz2))
+            self._sink_done(dz2)
             self._wgrad(blk.c2, L.GATHER_FWD_ZERO, B["a1"], None, dz2, N, h, w, h, w, C, 0, accumulate, side)
             da1 = buf("g.da1", (N, h, w, C))
-            self._cv(ops.make_desc(N, h, w, h, w, C, 0, C, 3, 1, 1, L.GATHER_DGRAD_ZERO), dz2, blk.c2.wpd, blk.c2.wpd3, da1)
+            self._cv(ops.make_desc(N, h, w, h, w, C, 0, C, 3, 1, 1, L.GATHER_DGRAD_ZERO), dz2, blk.c2.wpd, blk.c2.wpd3, da1,
+                     hp=(blk.c2.hp_d, blk.c2.wslot))
             dz1 = buf("g.dz1.%d" % i, (N, h, w, C))
             ops.bn_bwd(da1.view(M, C), B["a1"].view(M, C), B["z1"].view(M, C), blk.bn1.mean, blk.bn1.invstd, blk.bn1.bn.weight.data,
-                       dz1.view(M, C), blk.bn1.gg, blk.bn1.gb, accumulate=accumulate)
+                       dz1.view(M, C), blk.bn1.gg, blk.bn1.gb, accumulate=accumulate, amax_out=self._sink_slot(dz1))
+            self._sink_done(dz1)
             self._wgrad(blk.c1, L.GATHER_FWD_ZERO, B["x"], None, dz1, N, h, w, hin, win, Cin, 0, accumulate, side)
             first_of_layer = (i == 0) or blk.stride == 2
             dgd = ops.make_desc(N, hin, win, h, w, C, 0, Cin, 3, blk.stride, 1, L.GATHER_DGRAD_ZERO)
@@ -810,18 +982,18 @@ class Engine:
                 self._wgrad(blk.ds, L.GATHER_FWD_ZERO, B["x"], None, dzd, N, h, w, hin, win, Cin, 0, accumulate, side)
                 tgt = dF[feat_of_block[i - 1]]          # block input is the previous layer's feature (already holds decoder grads)
                 dgd.epi = L.EPI_ACCUM
-                self._cv(dgd, dz1, blk.c1.wpd, blk.c1.wpd3, tgt)
+                self._cv(dgd, dz1, blk.c1.wpd, blk.c1.wpd3, tgt, hp=(blk.c1.hp_d, blk.c1.wslot))
                 d1 = ops.make_desc(N, hin, win, h, w, C, 0, Cin, 1, blk.stride, 0, L.GATHER_DGRAD_ZERO, epi=L.EPI_ACCUM)
                 ops.conv_igemm(d1, dzd, None, blk.ds.wpd, tgt)
                 dnext = None
             elif first_of_layer:                        # layer1 block 0: input is the max-pool output
                 dpool = buf("g.dpool", (N, hin, win, Cin))
-                self._cv(dgd, dz1, blk.c1.wpd, blk.c1.wpd3, dpool, addend=g)
+                self._cv(dgd, dz1, blk.c1.wpd, blk.c1.wpd3, dpool, hp=(blk.c1.hp_d, blk.c1.wslot), addend=g)
                 ops.maxpool_bwd(dpool, self._bufs["pool.argmax"][:dpool.numel()].view(dpool.shape), dF[0], accumulate=True)
                 dnext = None
             else:
                 dx = buf("g.dx%d" % (i & 1), (N, hin, win, Cin))
-                self._cv(dgd, dz1, blk.c1.wpd, blk.c1.wpd3, dx, addend=g)
+                self._cv(dgd, dz1, blk.c1.wpd, blk.c1.wpd3, dx, hp=(blk.c1.hp_d, blk.c1.wslot), addend=g)
                 dnext = dx
             if self.debug_hook is not None:
                 self.debug_hook(i, dict(dout=dout, g=g, dz2=dz2, da1=da1, dz1=dz1, dnext=dnext, B=B))
@@ -879,6 +1051,7 @@ class Engine:
             S = self.saved
             if S is None or not S["training"]:
                 raise RuntimeError("decoders_backward needs a saved training-mode forward")
+            self.amax.globalize()
             gouts = [g.contiguous() for g in grad_outputs]
             dF = [self.buf("dF%d" % i, tuple(f.shape)) for i, f in enumerate(S["feats"])]
             self._decoders_backward(S, gouts, dF, False, None, join=True)
@@ -927,7 +1100,8 @@ class Engine:
         hd = dec.heads[3]
         self._head_wgrad(hd, D["x5"], dzl, acc)
         A = buf(pfx + "dz.o42", (N, H, W, 32))
-        ops.head_dgrad(dzl, self._head_wb(hd)[0], A, elu_src=D["x5"])
+        ops.head_dgrad(dzl, self._head_wb(hd)[0], A, elu_src=D["x5"], amax_out=self._sink_slot(A))
+        self._sink_done(A)
         self._wgrad(dec.o42, L.GATHER_FWD_REFLECT, D["y51"], None, A, N, H, W, H, W, 32, 0, acc, side)
         Bz = self._dgrad_dec(dec.o42, A, N, H, W, buf(pfx + "dz.o41", (N, H, W, 32)), actsrc=D["y51"])
         yield
@@ -946,7 +1120,8 @@ class Engine:
         ops.head_dgrad(dzl, self._head_wb(hd)[0], XH)
         A = buf(pfx + "dz.post2.3", (N, h0, w0, 64))
         if phase41:
-            ops.up2_fold_bwd(XV, A, addend=XH, ylow=x4)
+            ops.up2_fold_bwd(XV, A, addend=XH, ylow=x4, amax_out=self._sink_slot(A))
+            self._sink_done(A)
         else:
             ops.up2cat_bwd(XV, N, h0, w0, 64, 0, A, addend=XH, ylow=x4)
         # ---- blocks 4..1 ----------------------------------------------------------------------------------
@@ -966,12 +1141,13 @@ class Engine:
             A = buf(pfx + "dz.pre2.%d" % bi, (N, hl, wl, cout))
             if blk["post1"].up2 is not None:
                 # d(low) = 4x4 stride-2 conv over dZ + border fold (* ELU'); d(skip) straight into the feature gradient
-                ops.up2_fold_bwd(self._dgrad_up2_ext(blk["post1"], Bz, N, hl, wl, cout, pfx), A, ylow=y2)
+                ops.up2_fold_bwd(self._dgrad_up2_ext(blk["post1"], Bz, N, hl, wl, cout, pfx), A, ylow=y2, amax_out=self._sink_slot(A))
+                self._sink_done(A)
                 if not first:
                     order_dF(3 - bi)
                 ds = ops.make_desc(N, hh, ww, hh, ww, cout, 0, cout, 3, 1, 1, L.GATHER_DGRAD_REFLECT,
                                    epi=L.EPI_ACCUM if accum_feat else 0)
-                self._cv(ds, Bz, blk["post1"].wds, blk["post1"].wds3, dF[3 - bi])
+                self._cv(ds, Bz, blk["post1"].wds, blk["post1"].wds3, dF[3 - bi], hp=(blk["post1"].hp_ds, blk["post1"].wslot))
             else:
                 XV = self._dgrad_dec(blk["post1"], Bz, N, hh, ww, buf(pfx + "XV", (N, hh, ww, 2 * cout)))
                 if not first:

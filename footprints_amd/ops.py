@@ -155,16 +155,30 @@ def conv3x3_bf3(desc, src, wpacked_bf3, y, bias=None, addend=None, addend_mask=N
     return y
 
 
-# ---- fp16-pair operands (include/footprints_hip.h "hp"): amax slots are int32 tensors of AMAX_SLOTS elements ---------------------
-AMAX_SLOTS = 16
+# ---- fp16-pair operands (include/footprints_hip.h "hp"): amax slots are int32 tensors of amax_elems() elements ---------------------
+_amax_elems = None
+
+
+def amax_elems():
+    """int32 elements of storage per amax slot (FP_AMAX_ELEMS of the loaded library)"""
+    global _amax_elems
+    if _amax_elems is None:
+        _amax_elems = int(_lib.load().fp_amax_slot_elems())
+    return _amax_elems
 
 
 def _u32(t, what="slot"):
     if t is None:
         return 0
-    if t.dtype != torch.int32 or not t.is_cuda or t.numel() < AMAX_SLOTS:
-        raise RuntimeError("footprints_amd: %s must be a CUDA int32 tensor of >= %d elements" % (what, AMAX_SLOTS))
+    if t.dtype != torch.int32 or not t.is_cuda or t.numel() < amax_elems():
+        raise RuntimeError("footprints_amd: %s must be a CUDA int32 tensor of >= %d elements" % (what, amax_elems()))
     return t.data_ptr()
+
+
+def _sink(amax_out):
+    """register `amax_out` with the library: the NEXT launch of this thread publishes max |its output| there (then the sink is cleared)"""
+    if amax_out is not None:
+        _lib.load().fp_amax_out_next(_u32(amax_out, "amax_out"))
 
 
 def zero_u32(t):
@@ -173,14 +187,14 @@ def zero_u32(t):
 
 
 def amax_f32(x, slot):
-    """slot (zeroed by the caller) <- max |x| (bit pattern, spread over AMAX_SLOTS sub-slots)"""
+    """slot (zeroed by the caller) <- max |x| (bit pattern, spread over the sub-slots)"""
     _lib.check(_lib.load().fp_amax_f32(_f32(x, "x"), x.numel(), _u32(slot), stream()), "fp_amax_f32")
     return slot
 
 
 def amax_value(slot):
     """host-side read of a slot (tests / debugging): the float it encodes"""
-    return float(slot[:AMAX_SLOTS].max().view(torch.int32).cpu().view(torch.float32))
+    return float(slot[:amax_elems()].max().view(torch.int32).cpu().view(torch.float32))
 
 
 def packed_weight_elems_hp(Cout, Cin, K, for_dgrad=False):
@@ -236,14 +250,17 @@ def conv_wgrad_bf3_supported(desc):
     return _cached_query("fp_conv_wgrad_bf3_workspace", desc) >= 0
 
 
-def conv_wgrad_bf3(desc, x, dz, dw, k_begin=0, accumulate=False, db=None):
-    """3x3 stride-1 weight gradient with exactly split bf16x3 operands, into dw[:, k_begin:k_begin + C0]; db (optional) receives
-    the bias gradient (column sums of dz) from the same pass"""
+def conv_wgrad_bf3(desc, x, dz, dw, k_begin=0, accumulate=False, db=None, amax=None):
+    """3x3 stride-1 weight gradient with split operands, into dw[:, k_begin:k_begin + C0]; db (optional) receives the bias gradient
+    (column sums of dz) from the same pass.  amax = (slot of x, slot of dz): scaled fp16 pairs (four products); None: the exact
+    bf16x3 split (six)"""
     lib = _lib.load()
     need = _cached_query("fp_conv_wgrad_bf3_workspace", desc)
     if need < 0:
         raise RuntimeError("fp_conv_wgrad_bf3: shape not supported")
     ws = workspace(need, dz.device)
+    if amax is not None:
+        return conv_wgrad_hp(desc, x, dz, dw, amax[0], amax[1], k_begin, accumulate, db, ws)
     _lib.check(lib.fp_conv_wgrad_bf3(C.byref(desc), _f32(x), _f32(dz), _f32(dw), _f32(db), dw.shape[1], k_begin, int(bool(accumulate)),
                                      ws.data_ptr(), ws.numel(), stream()), "fp_conv_wgrad_bf3")
     return dw
@@ -260,6 +277,29 @@ def conv_wgrad_slice(desc, src0, src1, dz, dw, k_begin, accumulate=False):
 
 def up2_phase_wgrad_supported(N, h, w, C0, Nout):
     return _lib.load().fp_conv_up2_phase_wgrad_workspace(N, h, w, C0, Nout) >= 0
+
+
+def conv_wgrad_hp(desc, x, dz, dw, amax_x, amax_dz, k_begin=0, accumulate=False, db=None, ws=None):
+    lib = _lib.load()
+    if ws is None:
+        ws = workspace(_cached_query("fp_conv_wgrad_bf3_workspace", desc), dz.device)
+    _lib.check(lib.fp_conv_wgrad_hp(C.byref(desc), _f32(x), _f32(dz), _f32(dw), _f32(db), dw.shape[1], k_begin, int(bool(accumulate)),
+                                    ws.data_ptr(), ws.numel(), _u32(amax_x, "amax_x"), _u32(amax_dz, "amax_dz"), stream()), "fp_conv_wgrad_hp")
+    return dw
+
+
+def conv_up2_phase_wgrad_hp(low, dz, dw, amax_low, amax_dz, k_begin=0, accumulate=False, db=None):
+    lib = _lib.load()
+    N, h, w, C0 = low.shape
+    Nout = dz.shape[3]
+    need = lib.fp_conv_up2_phase_wgrad_workspace(N, h, w, C0, Nout)
+    if need < 0:
+        raise RuntimeError("fp_conv_up2_phase_wgrad_hp: shape not supported")
+    ws = workspace(need, dz.device)
+    _lib.check(lib.fp_conv_up2_phase_wgrad_hp(_f32(low), _f32(dz), _f32(dw), _f32(db), N, h, w, C0, Nout, dw.shape[1], k_begin,
+                                              int(bool(accumulate)), ws.data_ptr(), ws.numel(), _u32(amax_low, "amax_low"),
+                                              _u32(amax_dz, "amax_dz"), stream()), "fp_conv_up2_phase_wgrad_hp")
+    return dw
 
 
 def conv_up2_phase_wgrad(low, dz, dw, k_begin=0, accumulate=False, bf3=False, db=None):
@@ -319,8 +359,24 @@ def pack_up2_weight_bf3(w, wp, c_begin, c_count):
     return wp
 
 
-def conv_up2_phase_fwd_bf3(low, wphase_bf3, bias, y, act=0, addend=None):
+def conv_up2_phase_fwd_hp(low, wphase_hp, bias, y, amax_low, amax_w, amax_out=None, act=0, addend=None):
     N, h, w, C0 = low.shape
+    _lib.check(_lib.load().fp_conv_up2_phase_fwd_hp(_f32(low), _f32(wphase_hp), _f32(bias), _f32(addend), _f32(y), N, h, w, C0, y.shape[3],
+                                                    int(act), _u32(amax_low, "amax_low"), _u32(amax_w, "amax_w"), _u32(amax_out, "amax_out"),
+                                                    stream()), "fp_conv_up2_phase_fwd_hp")
+    return y
+
+
+def conv_up2_phase_dgrad_hp(dz, wpacked_hp, ext, amax_dz, amax_w):
+    N, H2, W2, Cout = dz.shape
+    _lib.check(_lib.load().fp_conv_up2_phase_dgrad_hp(_f32(dz), _f32(wpacked_hp), _f32(ext), N, H2 // 2, W2 // 2, Cout, ext.shape[3],
+                                                      _u32(amax_dz, "amax_dz"), _u32(amax_w, "amax_w"), stream()), "fp_conv_up2_phase_dgrad_hp")
+    return ext
+
+
+def conv_up2_phase_fwd_bf3(low, wphase_bf3, bias, y, act=0, addend=None, amax_out=None):
+    N, h, w, C0 = low.shape
+    _sink(amax_out)
     _lib.check(_lib.load().fp_conv_up2_phase_fwd_bf3(_f32(low), _f32(wphase_bf3), _f32(bias), _f32(addend), _f32(y), N, h, w, C0, y.shape[3],
                                                      int(act), stream()), "fp_conv_up2_phase_fwd_bf3")
     return y
@@ -361,8 +417,9 @@ def pack_conv_weight_dgrad_slice(w, wp, c_begin, c_count):
     return wp
 
 
-def up2_fold_bwd(ext, dlow, addend=None, ylow=None):
+def up2_fold_bwd(ext, dlow, addend=None, ylow=None, amax_out=None):
     N, h, w, Cn = dlow.shape
+    _sink(amax_out)
     _lib.check(_lib.load().fp_up2_fold_bwd(_f32(ext), N, h, w, Cn, _f32(addend), _f32(ylow), _f32(dlow), stream()), "fp_up2_fold_bwd")
     return dlow
 
@@ -373,17 +430,25 @@ def build_pack_table(jobs, device):
     lib = _lib.load()
     arr = (_lib.PackJob * len(jobs))()
     blk2job = []
-    for i, (kind, w, wp, c_begin, c_count) in enumerate(jobs):
+    for i, job in enumerate(jobs):
+        kind, w, wp, c_begin, c_count = job[:5]
         Cout, Cin, KH, KW = w.shape
         nb = lib.fp_pack_job_blocks(kind, Cout, KH, KW, c_count)
         j = arr[i]
         j.w, j.wp = _f32(w), _f32(wp)
         j.Cout, j.Cin, j.KH, j.KW, j.kind, j.c_begin, j.c_count = Cout, Cin, KH, KW, kind, c_begin, c_count
         j.block_begin, j.block_count = len(blk2job), nb
+        j.amax = job[5].data_ptr() if len(job) > 5 else None        # fp16-pair kinds: the weight tensor's amax slot
         blk2job += [i] * nb
     raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
     b2j = torch.tensor(blk2job, dtype=torch.int32, device=device)
     return raw, b2j, len(blk2job)
+
+
+def pack_weights_amax(table):
+    """max |w| of every fp16-pair job's weight tensor into its slot (zeroed by the caller); before pack_weights_batched"""
+    raw, b2j, nblocks = table
+    _lib.check(_lib.load().fp_pack_weights_amax(raw.data_ptr(), b2j.data_ptr(), nblocks, stream()), "fp_pack_weights_amax")
 
 
 def pack_weights_batched(table):
@@ -424,8 +489,9 @@ def head_upsample_bwd(dout_nchw, low, dzlow, scale, c0, sigmoid):
     return dzlow
 
 
-def head_dgrad(dzlow, w, dx, elu_src=None):
+def head_dgrad(dzlow, w, dx, elu_src=None, amax_out=None):
     N, h, wd, Cin = dx.shape
+    _sink(amax_out)
     _lib.check(_lib.load().fp_head_dgrad(_f32(dzlow), _f32(w), _f32(elu_src), _f32(dx), N, h, wd, Cin, stream()), "fp_head_dgrad")
     return dx
 
@@ -460,25 +526,29 @@ def scale_rows(w, scale, out):
     return out
 
 
-def bn_apply(z2d, scale, shift, y2d, residual=None, relu=True):
+def bn_apply(z2d, scale, shift, y2d, residual=None, relu=True, amax_out=None):
     M, Cn = z2d.shape
+    _sink(amax_out)
     _lib.check(_lib.load().fp_bn_apply(_f32(z2d), _f32(scale), _f32(shift), _f32(residual), _f32(y2d), M, Cn, int(bool(relu)), stream()),
                "fp_bn_apply")
     return y2d
 
 
-def bn_bwd(dy2d, relu_out, z2d, save_mean, save_invstd, gamma, dz2d, dgamma, dbeta, g_out=None, accumulate=False):
+def bn_bwd(dy2d, relu_out, z2d, save_mean, save_invstd, gamma, dz2d, dgamma, dbeta, g_out=None, accumulate=False, amax_out=None):
+    """amax_out: slot receiving max |dz| (the apply stage publishes it)"""
     lib = _lib.load()
     M, Cn = z2d.shape
     ws = workspace(lib.fp_bn_workspace(M, Cn), z2d.device)
+    _sink(amax_out)
     _lib.check(lib.fp_bn_bwd(_f32(dy2d), _f32(relu_out), _f32(z2d), _f32(save_mean), _f32(save_invstd), _f32(gamma), _f32(dz2d),
                              _f32(g_out), _f32(dgamma), _f32(dbeta), int(bool(accumulate)), M, Cn, ws.data_ptr(), ws.numel(), stream()),
                "fp_bn_bwd")
     return dz2d
 
 
-def maxpool_fwd(x, y, argmax):
+def maxpool_fwd(x, y, argmax, amax_out=None):
     N, H, W, Cn = x.shape
+    _sink(amax_out)
     _lib.check(_lib.load().fp_maxpool_fwd(_f32(x), _f32(y), _chk(argmax), N, H, W, Cn, stream()), "fp_maxpool_fwd")
     return y
 

@@ -103,7 +103,7 @@ typedef struct fp_pack_job {
   int32_t kind;             /* FP_PACK_* */
   int32_t c_begin, c_count; /* input-channel slice (whole tensor: 0, Cin) */
   int32_t block_begin, block_count; /* this job's contiguous range of workgroups in the batched launch */
-  uint32_t* amax;           /* *_HP kinds: the weight tensor's amax slot (FP_AMAX_SLOTS uint32, shared by all jobs of the tensor) */
+  uint32_t* amax;           /* *_HP kinds: the weight tensor's amax slot (FP_AMAX_ELEMS uint32, shared by all jobs of the tensor) */
 } fp_pack_job;
 int32_t fp_pack_job_blocks(int32_t kind, int32_t Cout, int32_t KH, int32_t KW, int32_t c_count);
 int fp_pack_weights_batched(const fp_pack_job* jobs_dev, const int32_t* blk2job_dev, int32_t nblocks, fp_stream_t stream);
@@ -137,9 +137,18 @@ int fp_pack_conv_weight_bf3(const float* w_oihw, void* wp, int32_t Cout, int32_t
 /* ---- fp16-pair operands ("hp"): x * 2^k = h + m, h = fp16(x * 2^k), m = fp16(x * 2^k - h) -- 22 significant bits after a per-tensor
  * power-of-two scaling taken from the tensor's largest magnitude; four fp16 products (hh + hm + mh + mm, exact in the fp32
  * accumulator of v_mfma_f32_32x32x16_f16) instead of the six of the exact split and two operand planes instead of three.
- * An "amax slot" is FP_AMAX_SLOTS = 16 uint32 holding float bit patterns of |x| (combined with max): zero it (fp_zero_u32), then
+ * An "amax slot" is FP_AMAX_SLOTS = 16 uint32 (FP_AMAX_STRIDE apart) holding float bit patterns of |x| (combined with max): zero it (fp_zero_u32), then
  * either reduce a tensor into it (fp_amax_f32) or let the kernel that produces the tensor publish into it (`amax_out`). */
-#define FP_AMAX_SLOTS 16
+#define FP_AMAX_SLOTS 16                 /* sub-slots per amax slot */
+#ifndef FP_AMAX_STRIDE
+#define FP_AMAX_STRIDE 32                /* uint32 elements between consecutive sub-slots: one 128-byte line each */
+#endif
+#define FP_AMAX_ELEMS (FP_AMAX_SLOTS * FP_AMAX_STRIDE)     /* uint32 elements of storage per slot */
+int32_t fp_amax_slot_elems(void);        /* = FP_AMAX_ELEMS of the loaded build */
+/* amax sink: the NEXT launch issued by this thread through fp_bn_apply, fp_bn_bwd (its dz), fp_maxpool_fwd, fp_up2_fold_bwd, fp_head_dgrad or
+ * fp_conv_up2_phase_fwd_bf3 also publishes max |output| into `slot` (zeroed by the caller); the registration is consumed by that
+ * call.  Keeps the signatures of the element-wise producers unchanged. */
+int fp_amax_out_next(uint32_t* slot);
 int fp_zero_u32(uint32_t* p, int64_t n, fp_stream_t stream);
 int fp_amax_f32(const float* x, int64_t n, uint32_t* slot, fp_stream_t stream);          /* x 16-byte aligned; slot zeroed by the caller */
 int fp_weight_amax(const float* w, int64_t n, uint32_t* amax_slot, fp_stream_t stream);  /* zero + reduce */
@@ -154,6 +163,21 @@ int fp_conv3x3_hp(const fp_conv_desc* d, const float* src, const float* src1, co
                   const float* addend, const float* addend_mask, const float* actsrc, float* y, void* workspace,
                   int64_t workspace_bytes, const uint32_t* amax_src, const uint32_t* amax_src1, const uint32_t* amax_w,
                   uint32_t* amax_out, fp_stream_t stream);
+
+/* nearest-x2 phase kernels (conv_up2_phase.hip) with fp16-pair operands: weights from FP_PACK_UP2_FWD_HP / FP_PACK_UP2_DGRAD_HP jobs */
+int fp_conv_up2_phase_fwd_hp(const float* low, const void* wphase_hp, const float* bias, const float* addend, float* y, int32_t N,
+                             int32_t h, int32_t w, int32_t C0, int32_t Nout, int32_t act, const uint32_t* amax_low,
+                             const uint32_t* amax_w, uint32_t* amax_out, fp_stream_t stream);
+int fp_conv_up2_phase_dgrad_hp(const float* dz, const void* wpacked_hp, float* ext, int32_t N, int32_t h, int32_t w, int32_t Cout,
+                               int32_t C0, const uint32_t* amax_dz, const uint32_t* amax_w, fp_stream_t stream);
+
+/* weight gradients with fp16-pair operands: fp_conv_wgrad_bf3 / fp_conv_up2_phase_wgrad_bf3 with the amax slots of their two tensors */
+int fp_conv_wgrad_hp(const fp_conv_desc* d, const float* x, const float* dz, float* dw_oihw, float* db, int32_t kc_total,
+                     int32_t k_begin, int accumulate, void* workspace, int64_t workspace_bytes, const uint32_t* amax_x,
+                     const uint32_t* amax_dz, fp_stream_t stream);
+int fp_conv_up2_phase_wgrad_hp(const float* low, const float* dz, float* dw_oihw, float* db, int32_t N, int32_t h, int32_t w,
+                               int32_t C0, int32_t Nout, int32_t kc_total, int32_t k_begin, int accumulate, void* workspace,
+                               int64_t workspace_bytes, const uint32_t* amax_low, const uint32_t* amax_dz, fp_stream_t stream);
 
 /* Weight gradient with the same exactly split operands (wgrad3x3_bf3.hip): 3x3 / stride 1 / pad 1, FWD_ZERO, FWD_REFLECT or
  * FWD_REFLECT_UP2 gather (then x is the half-resolution tensor [N][OH/2][OW/2][C0]: the upsampled half of a concat conv), C1 = 0, C0 and Nout multiples of 32; fp_conv_wgrad_bf3_workspace returns -1 for anything else (use fp_conv_wgrad).

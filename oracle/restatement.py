@@ -393,9 +393,10 @@ def psp_module(x, P, prefix):
     return torch.cat([x, outs[6], outs[4], outs[2], outs[1]], 1)
 
 
-def segmentor(image, P, B, training=True, use_psp=False):
-    """Segmentor.forward segmentation/network.py:20-25 -> [1/8, 1/4, 1/2, 1/1] logit maps, each [B,1,h,w] (:84-99)"""
-    feats = resnet_encoder(image, P, B, training)
+def segmentor(image, P, B, training=True, use_psp=False, record=None):
+    """Segmentor.forward segmentation/network.py:20-25 -> [1/8, 1/4, 1/2, 1/1] logit maps, each [B,1,h,w] (:84-99);
+    record: see resnet_encoder"""
+    feats = resnet_encoder(image, P, B, training, record)
     d = "decoder"
     x = feats[4]
     if use_psp:

@@ -18,15 +18,17 @@ sw = float(sys.argv[9]) if len(sys.argv) > 9 else 0.1
 torch.manual_seed(1)
 x = (torch.randn(N, H, W, C, device="cuda") * sx)
 x = x * (torch.rand_like(x) > 0.3)            # post-ReLU-like sparsity
+if os.environ.get("HP_HEAVY"):                # heavy-tailed magnitudes: |x| spans 2^-p .. 1 (p uniform in [0, HP_HEAVY])
+    x = x * torch.exp2(-torch.rand_like(x) * float(os.environ["HP_HEAVY"]))
 w = torch.randn(Co, C, 3, 3, device="cuda") * sw
 b = torch.randn(Co, device="cuda") * 0.1
 dg = mode == "dgrad"
 wt = w if not dg else w.permute(1, 0, 2, 3).contiguous()
 wp3 = ops.pack_conv_weight_bf3(wt, torch.empty(ops.packed_weight_elems_bf3(Co, C, 3, False), device="cuda"), False)
-slot_w = torch.zeros(16, dtype=torch.int32, device="cuda")
+slot_w = torch.zeros(ops.amax_elems(), dtype=torch.int32, device="cuda")
 wph = ops.pack_conv_weight_hp(wt, torch.empty(ops.packed_weight_elems_hp(Co, C, 3, False), device="cuda"), slot_w, False)
-slot_x = ops.amax_f32(x, torch.zeros(16, dtype=torch.int32, device="cuda"))
-slot_y = torch.zeros(16, dtype=torch.int32, device="cuda")
+slot_x = ops.amax_f32(x, torch.zeros(ops.amax_elems(), dtype=torch.int32, device="cuda"))
+slot_y = torch.zeros(ops.amax_elems(), dtype=torch.int32, device="cuda")
 d = ops.make_desc(N, H, W, H, W, C, 0, Co, 3, 1, 1, L.GATHER_DGRAD_REFLECT if dg else L.GATHER_FWD_REFLECT, act=0)
 y3 = torch.empty(N, H, W, Co, device="cuda")
 yh = torch.empty(N, H, W, Co, device="cuda")
@@ -72,6 +74,15 @@ t3 = timeit(lambda: ops.conv3x3_bf3(d, x, wp3, y3, **kw))
 th = timeit(lambda: ops.conv3x3_hp(d, x, wph, yh, slot_x, slot_w, amax_out=slot_y, **kw))
 th0 = timeit(lambda: ops.conv3x3_hp(d, x, wph, yh, slot_x, slot_w, **kw))
 ta = timeit(lambda: ops.amax_f32(x, slot_x))
+
+
+def cold():
+    ops.zero_u32(slot_y)
+    ops.conv3x3_hp(d, x, wph, yh, slot_x, slot_w, amax_out=slot_y, **kw)
+
+
+tz = timeit(lambda: ops.zero_u32(slot_y))
+tc = timeit(cold) - tz
 fl = 2.0 * N * H * W * C * Co * 9
-print("%s %d->%d @%dx%dx%d: bf16x3 %.1f us (%.1f TF/s)  fp16-pair %.1f us (%.1f TF/s; without amax_out %.1f us)  standalone amax(x) %.1f us" % (
-    mode, C, Co, H, W, N, t3, fl / t3 / 1e6, th, fl / th / 1e6, th0, ta))
+print("%s %d->%d @%dx%dx%d: bf16x3 %.1f us (%.1f TF/s)  fp16-pair %.1f us (%.1f TF/s; without amax_out %.1f us; slot zeroed before every launch %.1f us)  standalone amax(x) %.1f us" % (
+    mode, C, Co, H, W, N, t3, fl / t3 / 1e6, th, fl / th / 1e6, th0, tc, ta))
