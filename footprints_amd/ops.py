@@ -197,6 +197,16 @@ def amax_value(slot):
     return float(slot[:amax_elems()].max().view(torch.int32).cpu().view(torch.float32))
 
 
+def weight_amax(w, slot):
+    """slot <- max |w| (zeroes the slot first): the scale of every fp16-pair packing of this weight tensor"""
+    _lib.check(_lib.load().fp_weight_amax(_f32(w), w.numel(), _u32(slot), stream()), "fp_weight_amax")
+    return slot
+
+
+def new_slot(device="cuda"):
+    return torch.zeros(amax_elems(), dtype=torch.int32, device=device)
+
+
 def packed_weight_elems_hp(Cout, Cin, K, for_dgrad=False):
     return int(_lib.load().fp_packed_weight_elems_hp(Cout, Cin, K, K, int(for_dgrad)))
 

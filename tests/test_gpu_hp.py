@@ -1,0 +1,284 @@
+"""GPU: the fp16-pair ("hp") operand format (include/footprints_hip.h): amax slots and their publication by producers, HP weight
+packing, and every hp kernel against a float64 reference with the bounds of the exact bf16x3 kernels it replaces (the operands
+carry 22 significant bits after a per-tensor power-of-two scaling; products and accumulation are as exact as the bf16 split's)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.test_gpu_kernels import _ops, _up2_ref, check, nchw, nhwc, relerr, rnd
+
+pytestmark = pytest.mark.gpu
+
+
+def slot_of(t):
+    ops, _ = _ops()
+    return ops.amax_f32(t, ops.new_slot())
+
+
+def pack_hp(w, dgrad=False):
+    ops, _ = _ops()
+    Cout, Cin = w.shape[:2]
+    s = ops.new_slot()
+    wp = ops.pack_conv_weight_hp(w.contiguous().cuda(), torch.empty(ops.packed_weight_elems_hp(Cout, Cin, 3, dgrad), device="cuda"), s, dgrad)
+    assert ops.amax_value(s) == float(w.abs().max())
+    return wp, s
+
+
+def pack_job_hp(kind, w, elems, c_begin, c_count):
+    """the batched path (what the engine uses): amax pass + pack pass over a one-job table"""
+    ops, _ = _ops()
+    wd = w.contiguous().cuda()
+    wp, s = torch.empty(elems, device="cuda"), ops.new_slot()
+    table = ops.build_pack_table([(kind, wd, wp, c_begin, c_count, s)], "cuda")
+    ops.pack_weights_amax(table)
+    ops.pack_weights_batched(table)
+    assert ops.amax_value(s) == float(w.abs().max())
+    return wp, s
+
+
+def test_amax_reduction_and_zeroing():
+    ops, _ = _ops()
+    for n, scale in ((1, 1.0), (3, 1e-30), (1000, 1e30), (12 * 96 * 320 * 64, 7.0), (1 << 20, 1e-3)):
+        x = (torch.rand(n + 4, device="cuda")[:n] - 0.5) * scale
+        s = slot_of(x)
+        assert ops.amax_value(s) == float(x.abs().max()), (n, scale)
+        ops.zero_u32(s)
+        assert int(s.abs().sum()) == 0
+    z = torch.zeros(4096, device="cuda")
+    assert ops.amax_value(slot_of(z)) == 0.0
+    x = torch.rand(4096, device="cuda")
+    x[77] = float("inf")
+    assert ops.amax_value(slot_of(x)) == float("inf")
+
+
+def test_producers_publish_their_exact_amax():
+    """fp_amax_out_next: bn_apply, bn_bwd (dz), maxpool_fwd, up2_fold_bwd, head_dgrad and the split-K reduce publish max |output| from
+    XCD-local atomics; repeated launches must never lose an update"""
+    ops, L = _ops()
+    torch.manual_seed(5)
+    for rep in range(6):
+        M, C = 12 * 48 * 160, 64
+        z, res = torch.randn(M, C, device="cuda") * (10.0 ** (rep - 3)), torch.randn(M, C, device="cuda")
+        sc, sh = torch.rand(C, device="cuda") + 0.5, torch.randn(C, device="cuda")
+        y, s = torch.empty_like(z), ops.new_slot()
+        ops.bn_apply(z, sc, sh, y, residual=res, relu=True, amax_out=s)
+        assert ops.amax_value(s) == float(y.abs().max())
+        x4 = z.view(12, 48, 160, C)
+        pool, am, s = torch.empty((12, 24, 80, C), device="cuda"), torch.empty((12, 24, 80, C), dtype=torch.uint8, device="cuda"), ops.new_slot()
+        ops.maxpool_fwd(x4, pool, am, amax_out=s)
+        assert ops.amax_value(s) == float(pool.abs().max())
+        ext, s = torch.randn(2, 26, 82, 64, device="cuda"), ops.new_slot()
+        dlow = ops.up2_fold_bwd(ext, torch.empty((2, 24, 80, 64), device="cuda"), amax_out=s)
+        assert ops.amax_value(s) == float(dlow.abs().max())
+        dzl, hw = torch.randn(2, 48, 160, 2, device="cuda"), torch.randn(2, 64, 3, 3, device="cuda")
+        dx, s = torch.empty((2, 48, 160, 64), device="cuda"), ops.new_slot()
+        ops.head_dgrad(dzl, hw, dx, amax_out=s)
+        assert ops.amax_value(s) == float(dx.abs().max())
+        # bn_bwd: the apply stage publishes max |dz|
+        dy, out = torch.randn(M, C, device="cuda"), torch.relu(torch.randn(M, C, device="cuda"))
+        mean, invstd, gamma = torch.randn(C, device="cuda"), torch.rand(C, device="cuda") + 0.5, torch.rand(C, device="cuda") + 0.5
+        dz, s = torch.empty(M, C, device="cuda"), ops.new_slot()
+        ops.bn_bwd(dy, out, z, mean, invstd, gamma, dz, torch.empty(C, device="cuda"), torch.empty(C, device="cuda"), amax_out=s)
+        assert ops.amax_value(s) == float(dz.abs().max())
+    # a sink is consumed by exactly one launch
+    s = ops.new_slot()
+    ops.bn_apply(z, sc, sh, y, amax_out=s)
+    before = ops.amax_value(s)
+    ops.bn_apply(z * 100.0, sc, sh, y)
+    assert ops.amax_value(s) == before
+
+
+@pytest.mark.parametrize("mode,N,H,W,C0,Cout", [
+    ("zero", 12, 48, 160, 64, 64), ("reflect", 4, 96, 320, 64, 64), ("reflect", 2, 192, 640, 32, 32), ("reflect", 12, 24, 80, 128, 128),
+    ("zero", 6, 40, 176, 32, 96), ("zero", 20, 24, 80, 24, 40), ("dgrad", 12, 48, 160, 64, 64), ("dgrad", 12, 24, 80, 128, 128),
+    ("dgrad_reflect", 12, 48, 160, 64, 64), ("dgrad_reflect", 2, 192, 640, 32, 32), ("dgrad_reflect", 6, 40, 144, 64, 128),
+    ("zero", 12, 12, 40, 256, 256), ("zero", 12, 6, 20, 512, 512), ("reflect", 12, 12, 40, 256, 128),
+    ("dgrad", 12, 6, 20, 512, 512), ("dgrad_reflect", 12, 6, 20, 256, 512), ("zero", 8, 18, 60, 48, 80)])
+@pytest.mark.parametrize("scale", [1.0, 1e-7])
+def test_conv3x3_hp_kernel(mode, N, H, W, C0, Cout, scale):
+    """same cases and bound as test_conv3x3_bf3_kernel; scale 1e-7 = gradient-sized operands (the per-tensor scaling must carry them);
+    the published amax of the output is exact, also on the split-K path"""
+    ops, L = _ops()
+    tol = 2e-6
+    so = ops.new_slot()
+    if mode == "dgrad_reflect":
+        pre = rnd((N, C0, H, W), 92, -2.0, 2.0).requires_grad_(True)
+        w = rnd((Cout, C0, 3, 3), 93, -0.1, 0.1)
+        x = F.elu(pre)
+        yr = F.conv2d(F.pad(x.double(), (1, 1, 1, 1), mode="reflect"), w.double())
+        g, extra = rnd(tuple(yr.shape), 94) * scale, rnd(tuple(x.shape), 95) * scale
+        ((yr * g.double()).sum() + (x.double() * extra.double()).sum()).backward()
+        dz = torch.empty((N, H, W, C0), device="cuda")
+        d = ops.make_desc(N, H, W, H, W, Cout, 0, C0, 3, 1, 1, L.GATHER_DGRAD_REFLECT, epi=L.EPI_ACTGRAD_ELU)
+        wp, sw = pack_hp(w, dgrad=True)
+        gz = nhwc(g)
+        ops.conv3x3_hp(d, gz, wp, dz, slot_of(gz), sw, amax_out=so, actsrc=nhwc(x.detach()), addend=nhwc(extra))
+        check(nchw(dz), pre.grad, "hp dgrad_reflect (fold) + epilogue", tol)
+        assert ops.amax_value(so) == float(dz.abs().max())
+        return
+    if mode == "dgrad":
+        x = rnd((N, C0, H, W), 80).double().requires_grad_(True)
+        w = rnd((Cout, C0, 3, 3), 81, -0.1, 0.1)
+        yr = F.conv2d(x, w.double(), None, 1, 1)
+        g = rnd(tuple(yr.shape), 82) * scale
+        add, msk, act = rnd(tuple(x.shape), 83) * scale, rnd(tuple(x.shape), 84), rnd(tuple(x.shape), 85)
+        yr.backward(g.double())
+        ref = (x.grad + add * (msk > 0).float()) * (act > 0).float()
+        dx = torch.empty((N, H, W, C0), device="cuda")
+        d = ops.make_desc(N, H, W, H, W, Cout, 0, C0, 3, 1, 1, L.GATHER_DGRAD_ZERO, epi=L.EPI_ACTGRAD_RELU)
+        wp, sw = pack_hp(w, dgrad=True)
+        gz = nhwc(g)
+        ops.conv3x3_hp(d, gz, wp, dx, slot_of(gz), sw, amax_out=so, addend=nhwc(add), addend_mask=nhwc(msk), actsrc=nhwc(act))
+        check(nchw(dx), ref, "hp dgrad_zero + epilogue", tol)
+        assert ops.amax_value(so) == float(dx.abs().max())
+        return
+    w, b = rnd((Cout, C0, 3, 3), 86, -0.1, 0.1), rnd((Cout,), 87) * scale
+    x = rnd((N, C0, H, W), 90) * scale
+    if mode == "reflect":
+        ref = F.elu(F.conv2d(F.pad(x.double(), (1, 1, 1, 1), mode="reflect"), w.double(), b.double()))
+        gather = L.GATHER_FWD_REFLECT
+    else:
+        ref = F.elu(F.conv2d(x.double(), w.double(), b.double(), 1, 1))
+        gather = L.GATHER_FWD_ZERO
+    y = torch.empty((N, H, W, Cout), device="cuda")
+    d = ops.make_desc(N, H, W, H, W, C0, 0, Cout, 3, 1, 1, gather, act=L.ACT_ELU)
+    wp, sw = pack_hp(w)
+    xs = nhwc(x)
+    ops.conv3x3_hp(d, xs, wp, y, slot_of(xs), sw, amax_out=so, bias=b.cuda())
+    check(nchw(y), ref, "hp forward " + mode, tol)
+    assert ops.amax_value(so) == float(y.abs().max())
+
+
+def test_conv3x3_hp_dynamic_range_and_specials():
+    """heavy-tailed operands (|x| over 24 binades), an all-zero source, and inf / nan propagation like fp32's"""
+    ops, L = _ops()
+    N, H, W, C0, Cout = 4, 48, 160, 64, 64
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn((N, C0, H, W), generator=g) * torch.exp2(-torch.rand((N, C0, H, W), generator=g) * 24.0)
+    w = torch.randn((Cout, C0, 3, 3), generator=g) * 0.05 * torch.exp2(-torch.rand((Cout, C0, 3, 3), generator=g) * 12.0)
+    ref = F.conv2d(x.double(), w.double(), None, 1, 1)
+    d = ops.make_desc(N, H, W, H, W, C0, 0, Cout, 3, 1, 1, L.GATHER_FWD_ZERO)
+    wp, sw = pack_hp(w)
+    xs, y = nhwc(x), torch.empty((N, H, W, Cout), device="cuda")
+    ops.conv3x3_hp(d, xs, wp, y, slot_of(xs), sw)
+    e_hp = ((nchw(y).double() - ref).norm() / ref.norm()).item()
+    e_32 = ((F.conv2d(x, w, None, 1, 1).double() - ref).norm() / ref.norm()).item()
+    assert e_hp <= 2.0 * e_32 + 1e-7, (e_hp, e_32)          # as good as an fp32 convolution on the CPU
+    z = torch.zeros_like(xs)
+    ops.conv3x3_hp(d, z, wp, y, slot_of(z), sw)
+    assert float(y.abs().max()) == 0.0
+    xs2 = xs.clone()
+    xs2[1, 7, 9, 3] = float("inf")
+    ops.conv3x3_hp(d, xs2, wp, y, slot_of(xs2), sw)
+    assert not bool(torch.isfinite(y[1, 6:9, 8:11]).all()) and bool(torch.isfinite(y[0]).all())
+
+
+@pytest.mark.parametrize("N,h,w,C0,C1,Cout", [(12, 6, 20, 256, 256, 256), (8, 24, 32, 32, 16, 32), (16, 16, 32, 32, 0, 64), (12, 4, 24, 64, 64, 96)])
+def test_conv3x3_hp_up2_concat_gather(N, h, w, C0, C1, Cout):
+    """cat[nearest_x2(low), skip] inside the tile kernel: the two sources share one scale (the larger amax); sources of very different size"""
+    ops, L = _ops()
+    wt, b = rnd((Cout, C0 + C1, 3, 3), 340, -0.1, 0.1), rnd((Cout,), 341)
+    lo = rnd((N, C0, h, w), 342) * 1e-3
+    skip = rnd((N, C1, 2 * h, 2 * w), 343) * 30.0 if C1 else None
+    ref = F.elu(_up2_ref(lo.double(), skip.double() if C1 else None, wt.double(), b.double()))
+    d = ops.make_desc(N, 2 * h, 2 * w, 2 * h, 2 * w, C0, C1, Cout, 3, 1, 1, L.GATHER_FWD_REFLECT_UP2, act=L.ACT_ELU)
+    y = torch.empty((N, 2 * h, 2 * w, Cout), device="cuda")
+    wp, sw = pack_hp(wt)
+    los, sks = nhwc(lo), nhwc(skip) if C1 else None
+    ops.conv3x3_hp(d, los, wp, y, slot_of(los), sw, bias=b.cuda(), src1=sks, amax_src1=slot_of(sks) if C1 else None)
+    check(nchw(y), ref, "hp up2 concat", 2e-6)
+
+
+@pytest.mark.parametrize("mode,N,H,W,C0,Cout", [
+    ("zero", 12, 48, 160, 64, 64), ("reflect", 4, 96, 320, 64, 32), ("reflect", 2, 192, 640, 32, 32), ("reflect", 12, 24, 80, 128, 128),
+    ("zero", 6, 12, 40, 256, 256), ("reflect", 3, 10, 46, 32, 96), ("zero", 12, 6, 20, 512, 256), ("reflect", 2, 16, 20, 32, 64)])
+@pytest.mark.parametrize("gscale", [1.0, 1e-8])
+def test_wgrad3x3_hp_kernel(mode, N, H, W, C0, Cout, gscale):
+    ops, L = _ops()
+    w = rnd((Cout, C0, 3, 3), 96, -0.1, 0.1).double().requires_grad_(True)
+    x = rnd((N, C0, H, W), 99) * 20.0
+    if mode == "reflect":
+        y = F.conv2d(F.pad(x.double(), (1, 1, 1, 1), mode="reflect"), w)
+        gather = L.GATHER_FWD_REFLECT
+    else:
+        y = F.conv2d(x.double(), w, None, 1, 1)
+        gather = L.GATHER_FWD_ZERO
+    g = rnd(tuple(y.shape), 101) * gscale
+    y.backward(g.double())
+    d = ops.make_desc(N, H, W, H, W, C0, 0, Cout, 3, 1, 1, gather)
+    assert ops.conv_wgrad_bf3_supported(d)
+    pad = 32
+    dw = torch.full((Cout, C0 + 2 * pad, 3, 3), 7.0, device="cuda")
+    db = torch.full((Cout,), 3.0, device="cuda")
+    xs, gz = nhwc(x), nhwc(g)
+    am = (slot_of(xs), slot_of(gz))
+    ops.conv_wgrad_bf3(d, xs, gz, dw, pad, db=db, amax=am)
+    check(dw[:, pad:pad + C0], w.grad, "wgrad hp " + mode, 3e-6)
+    assert bool((dw[:, :pad] == 7.0).all()) and bool((dw[:, pad + C0:] == 7.0).all())
+    bref = g.double().sum((0, 2, 3))
+    check(db, bref, "wgrad hp bias " + mode, 2e-6)
+    ops.conv_wgrad_bf3(d, xs, gz, dw, pad, accumulate=True, db=db, amax=am)
+    check(dw[:, pad:pad + C0], 2 * w.grad, "wgrad hp accumulate " + mode, 3e-6)
+
+
+@pytest.mark.parametrize("N,h,w,C0,Cout", [(12, 6, 20, 256, 256), (4, 8, 24, 32, 64), (6, 6, 16, 64, 32)])
+def test_wgrad3x3_hp_up2_gather(N, h, w, C0, Cout):
+    ops, L = _ops()
+    wt = rnd((Cout, C0, 3, 3), 350, -0.1, 0.1).double().requires_grad_(True)
+    lo = rnd((N, C0, h, w), 351)
+    y = _up2_ref(lo.double(), None, wt, None)
+    g = rnd(tuple(y.shape), 352) * 1e-5
+    y.backward(g.double())
+    d = ops.make_desc(N, 2 * h, 2 * w, 2 * h, 2 * w, C0, 0, Cout, 3, 1, 1, L.GATHER_FWD_REFLECT_UP2)
+    dw, db = torch.empty((Cout, C0, 3, 3), device="cuda"), torch.empty((Cout,), device="cuda")
+    los, gz = nhwc(lo), nhwc(g)
+    ops.conv_wgrad_bf3(d, los, gz, dw, 0, db=db, amax=(slot_of(los), slot_of(gz)))
+    check(dw, wt.grad, "wgrad hp up2 gather", 3e-6)
+    check(db, g.double().sum((0, 2, 3)), "wgrad hp up2 gather bias", 2e-6)
+
+
+@pytest.mark.parametrize("N,h,w,C0,Cout", [(2, 24, 80, 64, 64), (2, 96, 320, 64, 32), (1, 5, 7, 32, 16), (2, 1, 1, 16, 16), (2, 9, 17, 20, 72)])
+def test_up2_phase_fwd_hp(N, h, w, C0, Cout):
+    ops, L = _ops()
+    wt, b = rnd((Cout, C0, 3, 3), 304, -0.1, 0.1), rnd((Cout,), 305)
+    lo, prev = rnd((N, C0, h, w), 306) * 50.0, rnd((N, Cout, 2 * h, 2 * w), 307)
+    ref = F.elu(_up2_ref(lo.double(), None, wt.double(), b.double()) + prev.double())
+    wph, sw = pack_job_hp(L.PACK_UP2_FWD_HP, wt, ops.up2_packed_weight_elems(Cout, C0), 0, C0)
+    y, los, so = nhwc(prev), nhwc(lo), ops.new_slot()
+    ops.conv_up2_phase_fwd_hp(los, wph, b.cuda(), y, slot_of(los), sw, amax_out=so, act=L.ACT_ELU, addend=y)
+    check(nchw(y), ref, "up2 phase fwd hp", 3e-6)
+    assert ops.amax_value(so) == float(y.abs().max())
+
+
+@pytest.mark.parametrize("N,h,w,C0,Cout", [(2, 24, 80, 64, 64), (1, 96, 320, 64, 32), (2, 6, 20, 256, 256), (2, 1, 1, 16, 16), (1, 3, 2, 24, 48),
+                                           (3, 9, 17, 20, 72)])
+def test_up2_phase_dgrad_hp(N, h, w, C0, Cout):
+    ops, L = _ops()
+    wt = rnd((Cout, C0, 3, 3), 340, -0.1, 0.1)
+    lo = rnd((N, C0, h, w), 341).double().requires_grad_(True)
+    yr = _up2_ref(lo, None, wt.double(), None)
+    g = rnd(tuple(yr.shape), 342) * 1e-6
+    yr.backward(g.double())
+    gz = nhwc(g)
+    wp, sw = pack_job_hp(L.PACK_UP2_DGRAD_HP, wt, ops.up2_packed_weight_elems(C0, Cout), 0, C0)
+    ext = ops.conv_up2_phase_dgrad_hp(gz, wp, torch.full((N, h + 2, w + 2, C0), float("nan"), device="cuda"), slot_of(gz), sw)
+    dlow = ops.up2_fold_bwd(ext, torch.empty((N, h, w, C0), device="cuda"))
+    check(nchw(dlow), lo.grad, "up2 phase dgrad hp", 3e-6)
+
+
+@pytest.mark.parametrize("N,h,w,C0,Cout,acc", [(2, 24, 80, 64, 64, False), (2, 12, 48, 32, 32, True), (1, 48, 160, 64, 32, False),
+                                               (16, 2, 16, 32, 32, False), (1, 96, 320, 64, 32, True), (3, 6, 27, 64, 64, False)])
+def test_up2_phase_wgrad_hp(N, h, w, C0, Cout, acc):
+    ops, L = _ops()
+    wt = rnd((Cout, C0, 3, 3), 320, -0.1, 0.1).requires_grad_(True)
+    lo = rnd((N, C0, h, w), 321)
+    yr = _up2_ref(lo, None, wt, None)
+    g = rnd(tuple(yr.shape), 323)
+    yr.backward(g)
+    init = rnd((Cout, C0, 3, 3), 324) if acc else torch.full((Cout, C0, 3, 3), float("nan"))
+    binit = rnd((Cout,), 325) if acc else torch.full((Cout,), float("nan"))
+    dw, db = init.clone().cuda(), binit.clone().cuda()
+    los, gz = nhwc(lo), nhwc(g)
+    ops.conv_up2_phase_wgrad_hp(los, gz, dw, slot_of(los), slot_of(gz), 0, accumulate=acc, db=db)
+    check(db.cpu(), g.sum((0, 2, 3)) + (binit if acc else 0), "up2 phase wgrad hp bias", 1e-5)
+    check(dw.cpu(), wt.grad + (init if acc else 0), "up2 phase wgrad hp")
