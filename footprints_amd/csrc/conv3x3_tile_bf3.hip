@@ -19,6 +19,9 @@
 int fp_splitk_reduce_launch(const float* part, int SK, int64_t M, int Nout, const float* bias, const float* addend, const float* addend_mask,
                             const float* actsrc, float* y, int act, unsigned epi, hipStream_t stream, unsigned* amax_out = nullptr);
 
+#ifndef FP_TILE_HP_WAVES
+#define FP_TILE_HP_WAVES 1      // minimum waves per SIMD requested from the register allocator (A/B: 4 = 128 VGPRs for the fp16-pair variants)
+#endif
 #ifndef FP_BF2_PRODUCTS
 #define FP_BF2_PRODUCTS 3
 #endif
@@ -91,7 +94,7 @@ __device__ __forceinline__ void fp_tile_pixel(int pt, int& py, int& px) {
 // HP = the fp16-pair format of fp_common.h (NP = 2 planes, four products hh + hm + mh + mm on v_mfma_f32_32x32x16_f16): operands carry
 // 22 significant bits after a per-tensor power-of-two scaling; two thirds of the MFMA work and of the LDS / weight traffic of the exact split.
 template <int TH, int TW, int BN, int WM, int WN, bool FLIP, bool FOLD, int NP = 3, bool HP = false>
-__global__ void __launch_bounds__(256) conv3x3_tile_bf3_kernel(const Tile3Args a) {
+__global__ void __launch_bounds__(256, HP ? FP_TILE_HP_WAVES : 1) conv3x3_tile_bf3_kernel(const Tile3Args a) {
   static_assert(!HP || NP == 2, "the fp16-pair format has two planes");
   constexpr int WPL = HP ? 2 : 3;                    // planes per weight slice in the packed buffer
   constexpr int BM128 = 128;

@@ -39,6 +39,13 @@ def collect(d, counter):
                         if frag in name:
                             key = entry
                             break
+                    # fp16-pair instantiations of the same kernel templates (NP = 2 / HP = true) are their own entry points
+                    hp = ((key == "conv3x3_bf3" and ", 2, true>" in name) or
+                          (key == "conv_wgrad_bf3" and ", 2>(" in name) or (key == "conv_up2_phase_wgrad_bf3" and "<2>(" in name) or
+                          (key in ("conv_up2_phase_fwd_bf3", "conv_up2_phase_dgrad_bf3") and ", 2>(" in name))
+                    if hp:
+                        key = {"conv3x3_bf3": "conv3x3_hp", "conv_wgrad_bf3": "conv_wgrad_hp", "conv_up2_phase_wgrad_bf3": "conv_up2_phase_wgrad_hp",
+                               "conv_up2_phase_fwd_bf3": "conv_up2_phase_fwd_hp", "conv_up2_phase_dgrad_bf3": "conv_up2_phase_dgrad_hp"}[key]
                 if key is None:
                     continue
                 a = per.setdefault(key, [0, 0.0])
