@@ -385,7 +385,9 @@ __global__ void __launch_bounds__(256, 2) wgrad3x3_bf3_v3_kernel(const W3Args a)
   int par = 0;
   for (int c = c_begin; c < c_end; c += c_step, par ^= 1) {
     const unsigned char* const Bb = lds + par * BUFN;
+#if !defined(FP_W3_ABL) || FP_W3_ABL != 1               // ablation 1: operands loaded once
     if (c + c_step < c_end) issue(c + c_step);       // next chunk's global loads fly under this chunk's MFMAs
+#endif
     uint4 bz[NP];
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
@@ -403,6 +405,13 @@ __global__ void __launch_bounds__(256, 2) wgrad3x3_bf3_v3_kernel(const W3Args a)
           const uint2 lo = lds_tr16(src), hi = lds_tr16(src + 4 * PXB);
           af[kx][p] = make_uint4(lo.x, lo.y, hi.x, hi.y);
         }
+#if defined(FP_W3_ABL) && FP_W3_ABL == 2                 // ablation 2: operands consumed, no MFMA
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int p = 0; p < NP; ++p) asm volatile("" ::"v"(af[kx][p].x), "v"(af[kx][p].y), "v"(af[kx][p].z), "v"(af[kx][p].w), "v"(bz[p].x), "v"(bz[p].y));
+      continue;
+#endif
       constexpr int NPROD = NP == 3 ? 6 : 4;         // smallest products first
       constexpr int PA[6] = {NP == 3 ? 2 : 1, NP == 3 ? 0 : 1, NP == 3 ? 1 : 0, NP == 3 ? 1 : 0, 0, 0};
       constexpr int PB[6] = {NP == 3 ? 0 : 1, NP == 3 ? 2 : 0, 1, 0, 1, 0};

@@ -155,7 +155,7 @@ class AmaxBook:
     buffer out again (Engine.buf: every producer obtains its output there).  A slot filled on one stream is only reused by a
     consumer on the same stream -- or on any stream once `globalize` declared the streams joined (end of the forward pass)."""
 
-    def __init__(self, device, nslots=1024):
+    def __init__(self, device, nslots=2048):
         self.pool = torch.zeros(nslots * ops.amax_elems(), dtype=torch.int32, device=device)
         self.nslots = nslots
         self.by_tag = {}

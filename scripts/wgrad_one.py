@@ -15,15 +15,20 @@ dz = torch.rand(N, H, W, Co, device="cuda") - 0.5
 dw = torch.empty(Co, C, 3, 3, device="cuda")
 db = torch.empty(Co, device="cuda")
 d = ops.make_desc(N, H, W, H, W, C, 0, Co, 3, 1, 1, L.GATHER_FWD_REFLECT)
+am = None
+if os.environ.get("WG_HP", "1") != "0":            # fp16-pair operands (the engine's default); WG_HP=0: exact bf16x3 split
+    am = (ops.amax_f32(x, ops.new_slot()), ops.amax_f32(dz, ops.new_slot()))
 for _ in range(3):
-    ops.conv_wgrad_bf3(d, x, dz, dw, 0, db=db)
+    ops.conv_wgrad_bf3(d, x, dz, dw, 0, db=db, amax=am)
 torch.cuda.synchronize()
 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 s.record()
 for _ in range(reps):
-    ops.conv_wgrad_bf3(d, x, dz, dw, 0, db=db)
+    ops.conv_wgrad_bf3(d, x, dz, dw, 0, db=db, amax=am)
 e.record()
 torch.cuda.synchronize()
 us = s.elapsed_time(e) / reps * 1e3
 fl = 2.0 * N * H * W * C * Co * 9
-print("wgrad_bf3 %d->%d @%dx%dx%d: %.1f us  %.1f TF/s fp32-equivalent  (%.3f of the bf16x6 roof)" % (C, Co, H, W, N, us, fl / us / 1e6, fl / us / 1e6 / (2500 / 6)))
+nprod = 6 if am is None else 4
+print("wgrad %s %d->%d @%dx%dx%d: %.1f us  %.1f TF/s fp32-equivalent  (%.3f of the %d-product roof)" % (
+    "bf16x3" if am is None else "fp16-pair", C, Co, H, W, N, us, fl / us / 1e6, fl / us / 1e6 / (2500 / nprod), nprod))
