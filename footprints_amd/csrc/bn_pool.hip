@@ -354,9 +354,9 @@ extern "C" int fp_bn_eval_coeffs(const float* gamma, const float* beta, const fl
 
 extern "C" int fp_bn_apply(const float* z, const float* scale, const float* shift, const float* residual, float* y, int64_t M,
                            int32_t C, int32_t relu, fp_stream_t stream) {
+  unsigned* amax_out = fp_take_amax_out();     // consumed first: an argument error below must not leave the sink armed
   FP_REQUIRE(z && scale && shift && y && C % 4 == 0, "fp_bn_apply: bad arguments");
   const size_t total4 = (size_t)M * (C / 4);
-  unsigned* amax_out = fp_take_amax_out();
   fp_launch(bn_apply_kernel, dim3(ew_grid(total4, 8192)), dim3(256), 0, (hipStream_t)stream, z, scale, shift,
             residual, y, total4, C / 4, relu, amax_out);
   return fp_check_launch("fp_bn_apply");
@@ -365,6 +365,7 @@ extern "C" int fp_bn_apply(const float* z, const float* scale, const float* shif
 extern "C" int fp_bn_bwd(const float* dy, const float* relu_out, const float* z, const float* save_mean, const float* save_invstd,
                          const float* gamma, float* dz, float* g_out, float* dgamma, float* dbeta, int accumulate, int64_t M,
                          int32_t C, void* workspace, int64_t workspace_bytes, fp_stream_t stream) {
+  unsigned* amax_out = fp_take_amax_out();     // consumed first: an argument error below must not leave the sink armed
   FP_REQUIRE(dy && z && save_mean && save_invstd && gamma && dz && workspace, "fp_bn_bwd: null pointer");
   FP_REQUIRE(bn_c_ok(C) && M > 0 && M < ((int64_t)1 << 31), "fp_bn_bwd: unsupported C=%d", C);
   FP_REQUIRE(workspace_bytes >= fp_bn_workspace(M, C), "fp_bn_bwd: workspace too small");
@@ -376,7 +377,6 @@ extern "C" int fp_bn_bwd(const float* dy, const float* relu_out, const float* z,
   fp_launch(bn_bwd_final_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const float*)part, nblk, C,
                      1.f / (float)M, coef, dgamma, dbeta, accumulate);
   const size_t total4 = (size_t)M * (C / 4);
-  unsigned* amax_out = fp_take_amax_out();
   fp_launch(bn_bwd_apply_kernel, dim3(ew_grid(total4, 8192)), dim3(256), 0, (hipStream_t)stream, dy, relu_out, z,
             save_mean, save_invstd, gamma, (const float*)coef, dz, g_out, total4, C / 4, amax_out);
   return fp_check_launch("fp_bn_bwd");
@@ -384,9 +384,9 @@ extern "C" int fp_bn_bwd(const float* dy, const float* relu_out, const float* z,
 
 extern "C" int fp_maxpool_fwd(const float* x, float* y, uint8_t* argmax, int32_t N, int32_t H, int32_t W, int32_t C,
                               fp_stream_t stream) {
+  unsigned* amax_out = fp_take_amax_out();     // consumed first: an argument error below must not leave the sink armed
   FP_REQUIRE(x && y && argmax && C % 4 == 0, "fp_maxpool_fwd: bad arguments");
   const size_t total = (size_t)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
-  unsigned* amax_out = fp_take_amax_out();
   fp_launch(maxpool_fwd_kernel, dim3(ew_grid(total, 8192)), dim3(256), 0, (hipStream_t)stream, x, y, argmax, N, H, W,
             C, amax_out);
   return fp_check_launch("fp_maxpool_fwd");

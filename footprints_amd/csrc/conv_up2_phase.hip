@@ -656,8 +656,8 @@ extern "C" int fp_conv_up2_phase_dgrad_hp(const float* dz, const void* wpacked_h
 
 extern "C" int fp_up2_fold_bwd(const float* ext, int32_t N, int32_t h, int32_t w, int32_t C, const float* addend, const float* ylow_elu,
                                float* dlow, fp_stream_t stream) {
+  unsigned* amax_out = fp_take_amax_out();     // consumed first: an argument error below must not leave the sink armed
   FP_REQUIRE(ext && dlow && N > 0 && h > 0 && w > 0 && C > 0 && C % 4 == 0, "fp_up2_fold_bwd: bad arguments");
-  unsigned* amax_out = fp_take_amax_out();
   int g = grid_for((size_t)N * h * w * (C / 4));
   fp_launch(up2_fold_bwd_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, ext, N, h, w, C, addend, ylow_elu, dlow, amax_out);
   return fp_check_launch("fp_up2_fold_bwd");

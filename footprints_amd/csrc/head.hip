@@ -528,11 +528,12 @@ extern "C" int fp_head_upsample_bwd(const float* dout_nchw, const float* low, fl
 
 extern "C" int fp_head_dgrad(const float* dzlow, const float* w_oihw, const float* elu_src, float* dx, int32_t N, int32_t h,
                              int32_t w, int32_t Cin, fp_stream_t stream) {
+  unsigned* amax_out = fp_take_amax_out();     // consumed first: an argument error below must not leave the sink armed
   FP_REQUIRE(dzlow && w_oihw && dx, "fp_head_dgrad: null pointer");
   FP_REQUIRE(head_cin_ok(Cin) && h >= 2 && w >= 2, "fp_head_dgrad: unsupported Cin=%d", Cin);
   const HeadGrid g = head_grid(N, h, w, Cin, 16);
   fp_launch(head_dgrad_kernel, dim3(g.colblocks, N * g.gpi), dim3(256), 0, (hipStream_t)stream, dzlow, w_oihw, elu_src, dx, h, w,
-                     Cin, g.rows, g.gpi, fp_take_amax_out());
+                     Cin, g.rows, g.gpi, amax_out);
   return fp_check_launch("fp_head_dgrad");
 }
 

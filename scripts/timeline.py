@@ -58,6 +58,26 @@ for n, s, e, st in step:
     streams[st] += (e - s) / 1e3
 print("per-stream busy: " + ", ".join("%s: %.0f us" % kv for kv in sorted(streams.items())))
 
+# which kernels run ALONE (concurrency 1): the serial part of the schedule
+ev2 = []
+for i, (n, s, e, st) in enumerate(step):
+    ev2 += [(max(s, t0), 1, i), (min(e, t1), -1, i)]
+ev2.sort()
+alone = defaultdict(float)
+active, last = set(), t0
+for t, d, i in ev2:
+    if len(active) == 1 and t > last:
+        (j,) = tuple(active)
+        alone[step[j][0].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:60]] += (t - last) / 1e3
+    if d > 0:
+        active.add(i)
+    else:
+        active.discard(i)
+    last = t
+print("time with exactly one kernel running, by kernel: total %.0f us" % sum(alone.values()))
+for n, d in sorted(alone.items(), key=lambda kv: -kv[1])[:22]:
+    print("  %-62s %8.0f us" % (n, d))
+
 if len(sys.argv) > 3 and sys.argv[3] == "buckets":
     nb = int(wall // 1000) + 1
     print("\nper-ms buckets: [busy1 busy2+] top kernels")
