@@ -120,7 +120,8 @@ class KernelTimer:
             products = float(info.get("products", 6 if info["bf16x3"] else 1))
             peak = BF16_PEAK_TFLOPS if products > 1 else MFMA_F32_PEAK_TFLOPS
             ach = products * ex / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-            label = {6.0: "bf16 x6 products (exact 3-way split)", 4.0: "fp16 x4 products (scaled fp16 pairs, 22 significant bits)", 1.0: "fp32"}[products]
+            label = {6.0: "bf16 x6 products (exact 3-way split)", 4.0: "fp16 x4 products (scaled fp16 pairs, 22 significant bits)",
+                     3.0: "fp16 x3 products (scaled fp16 pairs, 22 significant bits: hh + hm + mh)", 1.0: "fp32"}[products]
             rows.append({"kernel": info["kernel"], "entry_point": g, "mfma": label,
                          "launches_per_step": round(n / steps, 1), "exclusive_ms_per_step": round(ms / steps, 3),
                          "avg_launch_us": round(ms / n * 1e3, 2), "executed_mfma_gflop_per_launch": round(products * ex / n / 1e9, 3),
@@ -209,16 +210,17 @@ def phase_key(tag):
 
 # entry point (footprints_amd.ops name) -> how its launches are counted.  `exec` = multiply-adds x2 the kernel really executes
 # (the phase kernels run 4/9 of the dense conv), `dense` = the reference graph's conv, `bytes` = fused-minimum HBM bytes.
+HP_PRODUCTS = 3      # csrc/fp_common.h: FP_HP_PRODUCTS of the default build
 HP_ON = os.environ.get("FP_HP", "1") != "0" and os.environ.get("FP_NO_BF3", "0") == "0"      # mirrors footprints_amd.engine._HP
 GROUPS = {
     "conv3x3_bf3": dict(kernel="conv3x3_tile_bf3_kernel (+ splitk_reduce_kernel on small grids)", bf16x3=True),
     "conv3x3_hp": dict(kernel="conv3x3_tile_bf3_kernel<..., HP> (fp16-pair operands; + splitk_reduce_kernel / amax_kernel on small grids)", bf16x3=False,
-                       products=4),
-    "conv_up2_phase_fwd_hp": dict(kernel="up2_phase_fwd_bf3_kernel<..., 2> (fp16-pair operands)", bf16x3=False, products=4),
-    "conv_up2_phase_dgrad_hp": dict(kernel="up2_phase_dgrad_bf3_kernel<..., 2> (fp16-pair operands)", bf16x3=False, products=4),
-    "conv_wgrad_hp": dict(kernel="wgrad3x3_bf3_v3_kernel<MODE, 2> (fp16-pair operands; + wgrad_reduce_bias_kernel)", bf16x3=False, products=4),
+                       products=HP_PRODUCTS),
+    "conv_up2_phase_fwd_hp": dict(kernel="up2_phase_fwd_bf3_kernel<..., 2> (fp16-pair operands)", bf16x3=False, products=HP_PRODUCTS),
+    "conv_up2_phase_dgrad_hp": dict(kernel="up2_phase_dgrad_bf3_kernel<..., 2> (fp16-pair operands)", bf16x3=False, products=HP_PRODUCTS),
+    "conv_wgrad_hp": dict(kernel="wgrad3x3_bf3_v3_kernel<MODE, 2> (fp16-pair operands; + wgrad_reduce_bias_kernel)", bf16x3=False, products=HP_PRODUCTS),
     "conv_up2_phase_wgrad_hp": dict(kernel="wgrad_up2_phase_bf3_kernel<2> (fp16-pair operands; + its sum / un-collapse / bias reduce launches)",
-                                    bf16x3=False, products=4),
+                                    bf16x3=False, products=HP_PRODUCTS),
     "conv_igemm": dict(kernel="igemm_kernel / stem_tile_kernel (stride 2, 1x1, 7x7 stem, 4x4/2 phase dgrad of small levels)", bf16x3=False),
     "conv_up2_phase_fwd_bf3": dict(kernel="up2_phase_fwd_bf3_kernel", bf16x3=True),
     "conv_up2_phase_fwd": dict(kernel="up2_phase_fwd_kernel", bf16x3=False),
@@ -516,8 +518,9 @@ def main():
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "arithmetic": ("fp32 tensors and accumulation; 3x3 stride-1 convs (fwd, dgrad, wgrad) multiply operands split into scaled fp16 "
-                              "pairs (x * 2^k = h + m, per-tensor k from the tensor's largest magnitude, 22 significant bits, four fp16 MFMA "
-                              "products, fp32 accumulate: measured error vs float64 equal to the exact bf16x3 split's and to fp32 MIOpen's); "
+                              "pairs (x * 2^k = h + m, per-tensor k from the tensor's largest magnitude, 22 significant bits, three fp16 MFMA "
+                              "products hh + hm + mh, fp32 accumulate: measured error vs float64 equal to the exact bf16x3 split's and to fp32 "
+                              "MIOpen's); "
                               "remaining convs native fp32 MFMA" if HP_ON else
                               "fp32 tensors and accumulation; 3x3 stride-1 convs (fwd, dgrad, wgrad) multiply exactly split operands "
                               "(x = h + m + l in bf16, 6 of 9 bf16 MFMA products: error <= fp32 MFMA); remaining convs native fp32 MFMA"),
@@ -551,7 +554,7 @@ def main():
                                "fp32_equiv_tflops": dom["fp32_equiv_tflops"], "algorithmic_mb_per_launch": dom["algorithmic_mb_per_launch"],
                                "how": "dominant = largest exclusive time per step among the convolution entry points; HIP events on the launch "
                                       "stream around every launch of %d extra steps with concurrency off (one stream), outside the timed region; "
-                                      "achieved = executed MFMA FLOPs (4 fp16 products per multiply-add for scaled fp16 pairs, 6 bf16 products "
+                                      "achieved = executed MFMA FLOPs (3 fp16 products per multiply-add for scaled fp16 pairs, 6 bf16 products "
                                       "for the exact bf16 split) / duration" % xsteps,
                                "conv_exclusive_ms_per_step": round(sum(g["exclusive_ms_per_step"] for g in groups), 3),
                                "groups": groups}

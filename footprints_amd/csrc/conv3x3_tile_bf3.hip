@@ -91,7 +91,7 @@ __device__ __forceinline__ void fp_tile_pixel(int pt, int& py, int& px) {
 
 // NP = number of bf16 terms per operand: 3 = the exact split (six products); 2 = h + m only (three products: ah*bh + ah*bm + am*bh,
 // operands rounded to 16 significant bits, ~2^-17 relative) -- an opt-in INFERENCE mode (FP_EPI_BF16X2), never used for training
-// HP = the fp16-pair format of fp_common.h (NP = 2 planes, four products hh + hm + mh + mm on v_mfma_f32_32x32x16_f16): operands carry
+// HP = the fp16-pair format of fp_common.h (NP = 2 planes, FP_HP_PRODUCTS = three products hh + hm + mh on v_mfma_f32_32x32x16_f16): operands carry
 // 22 significant bits after a per-tensor power-of-two scaling; two thirds of the MFMA work and of the LDS / weight traffic of the exact split.
 template <int TH, int TW, int BN, int WM, int WN, bool FLIP, bool FOLD, int NP = 3, bool HP = false>
 __global__ void __launch_bounds__(256, HP ? FP_TILE_HP_WAVES : 1) conv3x3_tile_bf3_kernel(const Tile3Args a) {
@@ -252,9 +252,9 @@ __global__ void __launch_bounds__(256, HP ? FP_TILE_HP_WAVES : 1) conv3x3_tile_b
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // six products, smallest first; consecutive MFMAs alternate accumulators (i, j)
-  constexpr int NPROD = NP == 3 ? 6 : (HP ? 4 : (FP_BF2_PRODUCTS));
+  constexpr int NPROD = NP == 3 ? 6 : (HP ? FP_HP_PRODUCTS : (FP_BF2_PRODUCTS));
   auto mma6 = [&](const uint4 (&af)[TM][NP], const uint4 (&bf)[TN][NP]) {
-    // NP == 2 with four products (timing proxy of an fp16-pair split: hh + hm + mh + mm): order mm, mh, hm, hh
+    // NP == 2: four products in the order mm, mh, hm, hh; three: mh, hm, hh
     constexpr int PA[6] = {NP == 3 ? 2 : 1, NP == 3 ? 0 : (NPROD == 4 ? 1 : 0), NP == 3 ? 1 : 0, NP == 3 ? 1 : 0, 0, 0};
     constexpr int PB[6] = {NP == 3 ? 0 : (NPROD == 4 ? 1 : 0), NP == 3 ? 2 : (NPROD == 4 ? 0 : 1), NP == 3 ? 1 : (NPROD == 4 ? 1 : 0), 0, 1, 0};
 #if defined(FP_TILE_ABL) && FP_TILE_ABL == 2        // ablation: operands consumed, no MFMA

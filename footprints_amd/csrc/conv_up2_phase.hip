@@ -175,7 +175,7 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
 constexpr int PIXB = 48, PLANE3 = HP * PIXB, BUF3 = 3 * PLANE3;
-// NP = 3: the exact bf16 split (six products); NP = 2: scaled fp16 pairs (fp_common.h; four products on v_mfma_f32_32x32x16_f16)
+// NP = 3: the exact bf16 split (six products); NP = 2: scaled fp16 pairs (fp_common.h; FP_HP_PRODUCTS products on v_mfma_f32_32x32x16_f16)
 template <int NP>
 __device__ __forceinline__ void phase_store_split(unsigned char* p, f32x4_t v, int ka) {
   if (NP == 2) {
@@ -198,11 +198,11 @@ __device__ __forceinline__ void phase_store_split(unsigned char* p, f32x4_t v, i
 }
 template <int NP, int TM, int TN>
 __device__ __forceinline__ void phase_mma(f32x16 (&acc)[TM][TN], const uint4 (&af)[TM][NP], const uint4 (&bf)[TN][NP]) {
-  constexpr int NPROD = NP == 3 ? 6 : 4;
+  constexpr int NPROD = NP == 3 ? 6 : 4, Q0 = NP == 3 ? 0 : 4 - FP_HP_PRODUCTS;     // fp16 pairs: optionally without the mm product
   constexpr int PA[6] = {NP == 3 ? 2 : 1, NP == 3 ? 0 : 1, NP == 3 ? 1 : 0, NP == 3 ? 1 : 0, 0, 0};
   constexpr int PB[6] = {NP == 3 ? 0 : 1, NP == 3 ? 2 : 0, 1, 0, 1, 0};            // smallest products first
 #pragma unroll
-  for (int q = 0; q < NPROD; ++q)
+  for (int q = Q0; q < NPROD; ++q)
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -315,8 +315,8 @@ __global__ void __launch_bounds__(256) up2_phase_fwd_bf3_kernel(const PhaseArgs 
       if (tap < 2) load_b(tap + 2, cc, bq[tap + 2]);
       else load_b(tap - 2, ccn, bq[tap - 2]);
       phase_mma<NP, TM, TN>(acc, af[tap & 1], bq[tap]);
-      if (tap < 3) fp_sched_interleave<TM * NP, TN * NP, (NP == 3 ? 6 : 4) * TM * TN>();      // one read between consecutive MFMAs (fp_common.h)
-      else fp_sched_interleave<0, TN * NP, (NP == 3 ? 6 : 4) * TM * TN>();
+      if (tap < 3) fp_sched_interleave<TM * NP, TN * NP, (NP == 3 ? 6 : FP_HP_PRODUCTS) * TM * TN>();      // one read between consecutive MFMAs (fp_common.h)
+      else fp_sched_interleave<0, TN * NP, (NP == 3 ? 6 : FP_HP_PRODUCTS) * TM * TN>();
     }
     if (cc + 1 < a.KC16) {
       store_halo((cc + 1) & 1);
@@ -482,8 +482,8 @@ __global__ void __launch_bounds__(256) up2_phase_dgrad_bf3_kernel(const PhaseDgr
       if (tap < 2) load_b(tap + 2, step, bq[tap + 2]);
       else load_b(tap - 2, stepn, bq[tap - 2]);
       phase_mma<NP, TM, TN>(acc, af[tap & 1], bq[tap]);
-      if (tap < 3) fp_sched_interleave<TM * NP, TN * NP, (NP == 3 ? 6 : 4) * TM * TN>();      // one read between consecutive MFMAs (fp_common.h)
-      else fp_sched_interleave<0, TN * NP, (NP == 3 ? 6 : 4) * TM * TN>();
+      if (tap < 3) fp_sched_interleave<TM * NP, TN * NP, (NP == 3 ? 6 : FP_HP_PRODUCTS) * TM * TN>();      // one read between consecutive MFMAs (fp_common.h)
+      else fp_sched_interleave<0, TN * NP, (NP == 3 ? 6 : FP_HP_PRODUCTS) * TM * TN>();
     }
     if (step + 1 < nsteps) {
       store_halo((step + 1) & 1);

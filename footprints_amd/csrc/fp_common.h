@@ -158,12 +158,18 @@ __device__ __forceinline__ float fp_elu(float v) {
 
 // ---- fp16-pair ("hp") operands ----------------------------------------------------------------------------
 // x * 2^k = h + m with h = fp16(x * 2^k), m = fp16(x * 2^k - h): 11 + 11 significant bits (relative error <= 2^-22, ~2^-23.5 rms);
-// the four products hh, hm, mh, mm are exact in the fp32 accumulator of v_mfma_f32_32x32x16_f16.  k is a per-tensor power of two
+// every fp16 x fp16 product is exact in the fp32 accumulator of v_mfma_f32_32x32x16_f16 (FP_HP_PRODUCTS below says which are formed).  k is a per-tensor power of two
 // taken from the tensor's largest magnitude (an "amax slot": FP_AMAX_SLOTS uint32 holding float bit patterns of |x|, combined
 // with max; a producer on XCD k publishes into the sub-slots of XCD k, see fp_amax_publish), which maps that
 // magnitude to [2^target, 2^(target+1)): no overflow (fp16 max 65504), and anything above 2^-24 / 2^k is still represented, i.e.
 // the absolute error floor is 2^-37 of the tensor's largest element.  Scaling by powers of two is exact and undone in the epilogue.
 static_assert(FP_AMAX_SLOTS == 16, "amax slot width (include/footprints_hip.h)");
+// products per multiply-add: hh + hm + mh; the fourth, mm, is <= 2^-22 of a product (~2^-24 rms, random sign): measured relative L2
+// error against float64 2.733e-7 with three products, 2.722e-7 with four, 2.6e-7 for an fp32 convolution -- and a quarter of the MFMA
+// work.  -DFP_HP_PRODUCTS=4 builds the four-product form for A/B runs.
+#ifndef FP_HP_PRODUCTS
+#define FP_HP_PRODUCTS 3
+#endif
 constexpr int FP_HP_TARGET_ACT = 12;    // activations / gradients: amax -> [2^12, 2^13)
 constexpr int FP_HP_TARGET_W = 11;      // weights: amax -> [2^11, 2^12) (the nearest-x2 phase kernels add up to four of them)
 __device__ __forceinline__ unsigned fp_amax_bits(const unsigned* __restrict__ slot) {

@@ -267,7 +267,7 @@ __device__ __forceinline__ uint2 lds_tr16(const unsigned char* p) {
   return __builtin_bit_cast(uint2, v);
 }
 
-// NP = 3: exact bf16 split (six products); NP = 2: scaled fp16 pairs (fp_common.h: four products on v_mfma_f32_32x32x16_f16; X and dZ
+// NP = 3: exact bf16 split (six products); NP = 2: scaled fp16 pairs (fp_common.h: FP_HP_PRODUCTS products on v_mfma_f32_32x32x16_f16; X and dZ
 // each scaled by their own amax slot, the partial sums are unscaled -- exactly -- before they leave the workgroup)
 template <int MODE, int NP = 3>
 __global__ void __launch_bounds__(256, 2) wgrad3x3_bf3_v3_kernel(const W3Args a) {
@@ -416,7 +416,7 @@ __global__ void __launch_bounds__(256, 2) wgrad3x3_bf3_v3_kernel(const W3Args a)
       constexpr int PA[6] = {NP == 3 ? 2 : 1, NP == 3 ? 0 : 1, NP == 3 ? 1 : 0, NP == 3 ? 1 : 0, 0, 0};
       constexpr int PB[6] = {NP == 3 ? 0 : 1, NP == 3 ? 2 : 0, 1, 0, 1, 0};
 #pragma unroll
-      for (int qq = 0; qq < NPROD; ++qq) {
+      for (int qq = (NP == 2 ? 4 - FP_HP_PRODUCTS : 0); qq < NPROD; ++qq) {
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx)
           if (NP == 2)

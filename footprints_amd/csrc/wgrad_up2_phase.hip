@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(256, 3) wgrad_up2_phase_bf3_kernel(const PWArg
         constexpr int PA[6] = {NP == 3 ? 2 : 1, NP == 3 ? 0 : 1, NP == 3 ? 1 : 0, NP == 3 ? 1 : 0, 0, 0};
         constexpr int PB[6] = {NP == 3 ? 0 : 1, NP == 3 ? 2 : 0, 1, 0, 1, 0};
 #pragma unroll
-        for (int qq = 0; qq < NPROD; ++qq) {
+        for (int qq = (NP == 2 ? 4 - FP_HP_PRODUCTS : 0); qq < NPROD; ++qq) {
           if (NP == 2) {
             const pf16x8 bb = __builtin_bit_cast(pf16x8, bz[PB[qq]]);
             acc[ta * 2 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(pf16x8, a0[PA[qq]]), bb, acc[ta * 2 + 0], 0, 0, 0);

@@ -499,7 +499,7 @@ class Engine:
 
     def _cv(self, d, src, w32, w3, out, hp=None, **kw):
         """one 3x3 / 1x1 convolution or data-gradient launch: the split-operand tile kernel where it applies (hp = (fp16-pair packing,
-        weight amax slot): four fp16 products; else w3: six bf16 products), else fp_conv_igemm"""
+        weight amax slot): three fp16 products; else w3: six bf16 products), else fp_conv_igemm"""
         if (w3 is not None or hp is not None) and ops.conv3x3_bf3_supported(d):
             if hp is not None and hp[0] is not None and not ops._bf16x2:
                 return self._cv_hp(d, src, hp[0], hp[1], out, **kw)

@@ -262,7 +262,7 @@ def conv_wgrad_bf3_supported(desc):
 
 def conv_wgrad_bf3(desc, x, dz, dw, k_begin=0, accumulate=False, db=None, amax=None):
     """3x3 stride-1 weight gradient with split operands, into dw[:, k_begin:k_begin + C0]; db (optional) receives the bias gradient
-    (column sums of dz) from the same pass.  amax = (slot of x, slot of dz): scaled fp16 pairs (four products); None: the exact
+    (column sums of dz) from the same pass.  amax = (slot of x, slot of dz): scaled fp16 pairs (three products); None: the exact
     bf16x3 split (six)"""
     lib = _lib.load()
     need = _cached_query("fp_conv_wgrad_bf3_workspace", desc)

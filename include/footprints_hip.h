@@ -135,7 +135,7 @@ int fp_pack_conv_weight_bf3(const float* w_oihw, void* wp, int32_t Cout, int32_t
                             int32_t for_dgrad, fp_stream_t stream);
 
 /* ---- fp16-pair operands ("hp"): x * 2^k = h + m, h = fp16(x * 2^k), m = fp16(x * 2^k - h) -- 22 significant bits after a per-tensor
- * power-of-two scaling taken from the tensor's largest magnitude; four fp16 products (hh + hm + mh + mm, exact in the fp32
+ * power-of-two scaling taken from the tensor's largest magnitude; three fp16 products (hh + hm + mh; mm is <= 2^-22 of a product and left out; each exact in the fp32
  * accumulator of v_mfma_f32_32x32x16_f16) instead of the six of the exact split and two operand planes instead of three.
  * An "amax slot" is FP_AMAX_SLOTS = 16 uint32 (FP_AMAX_STRIDE apart) holding float bit patterns of |x| (combined with max): zero it (fp_zero_u32), then
  * either reduce a tensor into it (fp_amax_f32) or let the kernel that produces the tensor publish into it (`amax_out`). */

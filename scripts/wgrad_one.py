@@ -29,6 +29,6 @@ e.record()
 torch.cuda.synchronize()
 us = s.elapsed_time(e) / reps * 1e3
 fl = 2.0 * N * H * W * C * Co * 9
-nprod = 6 if am is None else 4
+nprod = 6 if am is None else 3
 print("wgrad %s %d->%d @%dx%dx%d: %.1f us  %.1f TF/s fp32-equivalent  (%.3f of the %d-product roof)" % (
     "bf16x3" if am is None else "fp16-pair", C, Co, H, W, N, us, fl / us / 1e6, fl / us / 1e6 / (2500 / nprod), nprod))
