@@ -19,8 +19,12 @@
 int fp_splitk_reduce_launch(const float* part, int SK, int64_t M, int Nout, const float* bias, const float* addend, const float* addend_mask,
                             const float* actsrc, float* y, int act, unsigned epi, hipStream_t stream, unsigned* amax_out = nullptr);
 
+// waves per SIMD requested from the register allocator for the fp16-pair variants: 4 = 128 VGPRs (34 KB of LDS per workgroup allow four
+// workgroups per CU; the reflection-fold variants spill 3-4 registers).  Training step 15.16 / 15.24 vs 15.30 / 15.40 ms with 1 (= 160
+// VGPRs, three waves), the kernel alone measures the same: a few more waves to cover prologues and epilogues now that a third of the MFMA
+// work per wave is left.
 #ifndef FP_TILE_HP_WAVES
-#define FP_TILE_HP_WAVES 1      // minimum waves per SIMD requested from the register allocator (A/B: 4 = 128 VGPRs for the fp16-pair variants)
+#define FP_TILE_HP_WAVES 4
 #endif
 #ifndef FP_BF2_PRODUCTS
 #define FP_BF2_PRODUCTS 3
