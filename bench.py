@@ -556,6 +556,10 @@ def main():
                                       "stream around every launch of %d extra steps with concurrency off (one stream), outside the timed region; "
                                       "achieved = executed MFMA FLOPs (3 fp16 products per multiply-add for scaled fp16 pairs, 6 bf16 products "
                                       "for the exact bf16 split) / duration" % xsteps,
+                               "reading": "frac prices EXECUTED MFMA FLOPs against the nominal dense peak, so it falls whenever products are removed "
+                                          "from the split (exact bf16x3: 6 per multiply-add, frac 0.33 at 136 fp32-equivalent TFLOP/s; scaled fp16 pairs: "
+                                          "3, frac 0.20 at 163): compare fp32_equiv_tflops across operand formats; the chip sustains ~1.7 of its 2.4 GHz "
+                                          "under these kernels (profiles/round2_notes.md), i.e. 0.7 of the nominal peak is attainable",
                                "conv_exclusive_ms_per_step": round(sum(g["exclusive_ms_per_step"] for g in groups), 3),
                                "groups": groups}
         if args.dump_kernels and xtimer is not None:
