@@ -35,6 +35,9 @@ _PWBF3 = not bool(int(os.environ.get("FP_NO_PHASE_WBF3", "0")))           # ... 
 # fp16-pair operands (two fp16 terms after a per-tensor power-of-two scaling, four MFMA products, 22 significant bits) for the same
 # kernels, with the scaling taken from amax slots that producers publish / a reduction fills (csrc/fp_common.h); FP_HP=0 keeps bf16x3
 _HP = _BF3 and bool(int(os.environ.get("FP_HP", "1")))
+# the 1x1 downsample branch of a BasicBlock (conv -> BN, and its gradients) on the aux stream beside the block's main branch: the encoder
+# is the serial spine of the step (one kernel on the GPU at a time), the aux stream idles until the decoders start.  FP_DS_AUX=0: in line
+_DS_AUX = bool(int(os.environ.get("FP_DS_AUX", "1")))
 # nearest-x2 phase decomposition of the upsample convs (conv_up2_phase.hip); FP_NO_PHASE=1 keeps the fused-gather path.
 _PHASE = not bool(int(os.environ.get("FP_NO_PHASE", "0")))
 
@@ -597,13 +600,22 @@ class Engine:
             s = blk.stride
             oh, ow = (h - 1) // s + 1, (w - 1) // s + 1
             d1 = ops.make_desc(N, oh, ow, h, w, blk.c1.Cin, 0, blk.Cout, 3, s, 1, L.GATHER_FWD_ZERO, act=L.ACT_RELU)
-            a1 = self._cv(d1, x, blk.c1.fwp, blk.c1.fwp3, buf("b%d.a1" % i, (N, oh, ow, blk.Cout)), hp=(blk.c1.fhp, blk.c1.fslot),
-                          bias=blk.bn1.fshift)
+            ev_idt = None
             if blk.ds is not None:
                 dd = ops.make_desc(N, oh, ow, h, w, blk.ds.Cin, 0, blk.Cout, 1, s, 0, L.GATHER_FWD_ZERO)
-                idt = self._cv(dd, x, blk.ds.fwp, None, buf("b%d.idt" % i, (N, oh, ow, blk.Cout)), bias=blk.bnd.fshift)
+                if self.concurrent and _DS_AUX:           # 1x1 shortcut beside conv1 on the (still idle) aux stream
+                    ops.event_wait(self.aux, self._record(ops.current_stream()))
+                    with ops.on_stream(self.aux):
+                        idt = self._cv(dd, x, blk.ds.fwp, None, buf("b%d.idt" % i, (N, oh, ow, blk.Cout)), bias=blk.bnd.fshift)
+                        ev_idt = self._record(self.aux)
+                else:
+                    idt = self._cv(dd, x, blk.ds.fwp, None, buf("b%d.idt" % i, (N, oh, ow, blk.Cout)), bias=blk.bnd.fshift)
             else:
                 idt = x
+            a1 = self._cv(d1, x, blk.c1.fwp, blk.c1.fwp3, buf("b%d.a1" % i, (N, oh, ow, blk.Cout)), hp=(blk.c1.fhp, blk.c1.fslot),
+                          bias=blk.bn1.fshift)
+            if ev_idt is not None:
+                ops.event_wait(ops.current_stream(), ev_idt)
             d2 = ops.make_desc(N, oh, ow, oh, ow, blk.Cout, 0, blk.Cout, 3, 1, 1, L.GATHER_FWD_ZERO, act=L.ACT_RELU)
             out = self._cv(d2, a1, blk.c2.fwp, blk.c2.fwp3, buf("b%d.out" % i, (N, oh, ow, blk.Cout)), hp=(blk.c2.fhp, blk.c2.fslot),
                            bias=blk.bn2.fshift, addend=idt)
@@ -711,18 +723,26 @@ class Engine:
             if s == 2:
                 self._wait_pack()
             oh, ow = (h - 1) // s + 1, (w - 1) // s + 1
+            zd, idt, ev_idt = None, x, None
+
+            def shortcut():
+                zd_ = self._conv_enc(blk.ds, x, N, h, w, buf("b%d.zd" % i, (N, oh, ow, blk.Cout)))
+                self._bn_coeffs(blk.bnd, zd_, training)
+                return zd_, self._bn_apply(blk.bnd, zd_, buf("b%d.idt" % i, (N, oh, ow, blk.Cout)), relu=False)
+            if blk.ds is not None and self.concurrent and _DS_AUX:       # downsample branch beside conv1 / conv2 (joined before the residual add)
+                ops.event_wait(self.aux, self._record(ops.current_stream()))
+                with ops.on_stream(self.aux):
+                    zd, idt = shortcut()
+                    ev_idt = self._record(self.aux)
             z1 = self._conv_enc(blk.c1, x, N, h, w, buf("b%d.z1" % i, (N, oh, ow, blk.Cout)))
             self._bn_coeffs(blk.bn1, z1, training)
             a1 = self._bn_apply(blk.bn1, z1, buf("b%d.a1" % i, (N, oh, ow, blk.Cout)))
             z2 = self._conv_enc(blk.c2, a1, N, oh, ow, buf("b%d.z2" % i, (N, oh, ow, blk.Cout)))
             self._bn_coeffs(blk.bn2, z2, training)
-            zd = None
-            if blk.ds is not None:
-                zd = self._conv_enc(blk.ds, x, N, h, w, buf("b%d.zd" % i, (N, oh, ow, blk.Cout)))
-                self._bn_coeffs(blk.bnd, zd, training)
-                idt = self._bn_apply(blk.bnd, zd, buf("b%d.idt" % i, (N, oh, ow, blk.Cout)), relu=False)
-            else:
-                idt = x
+            if blk.ds is not None and ev_idt is None:
+                zd, idt = shortcut()
+            if ev_idt is not None:
+                ops.event_wait(ops.current_stream(), ev_idt)
             out = self._bn_apply(blk.bn2, z2, buf("b%d.out" % i, (N, oh, ow, blk.Cout)), residual=idt)
             S["blocks"].append(dict(x=x, z1=z1, a1=a1, z2=z2, zd=zd, out=out, hin=h, win=w, h=oh, w=ow))
             x, h, w = out, oh, ow
@@ -964,6 +984,20 @@ class Engine:
             ops.bn_bwd(dout.view(M, C), B["out"].view(M, C), B["z2"].view(M, C), blk.bn2.mean, blk.bn2.invstd, blk.bn2.bn.weight.data,
                        dz2.view(M, C), blk.bn2.gg, blk.bn2.gb, g_out=g.view(M, C), accumulate=accumulate, amax_out=self._sink_slot(dz2))
             self._sink_done(dz2)
+            ev_ds = None
+            if blk.ds is not None and self.concurrent and _DS_AUX:
+                # downsample branch on the aux stream: BN backward, weight gradient, and its data gradient FIRST into the previous layer's
+                # feature gradient; the main branch's conv1 data gradient accumulates on top after the join (fixed order)
+                tgt = dF[feat_of_block[i - 1]]
+                ops.event_wait(self.aux, self._record(ops.current_stream()))
+                with ops.on_stream(self.aux):
+                    dzd = buf("g.dzd.%d" % i, (N, h, w, C))
+                    ops.bn_bwd(g.view(M, C), None, B["zd"].view(M, C), blk.bnd.mean, blk.bnd.invstd, blk.bnd.bn.weight.data,
+                               dzd.view(M, C), blk.bnd.gg, blk.bnd.gb, accumulate=accumulate)
+                    self._wgrad(blk.ds, L.GATHER_FWD_ZERO, B["x"], None, dzd, N, h, w, hin, win, Cin, 0, accumulate, side)
+                    d1 = ops.make_desc(N, hin, win, h, w, C, 0, Cin, 1, blk.stride, 0, L.GATHER_DGRAD_ZERO, epi=L.EPI_ACCUM)
+                    ops.conv_igemm(d1, dzd, None, blk.ds.wpd, tgt)
+                    ev_ds = self._record(self.aux)
             self._wgrad(blk.c2, L.GATHER_FWD_ZERO, B["a1"], None, dz2, N, h, w, h, w, C, 0, accumulate, side)
             da1 = buf("g.da1", (N, h, w, C))
             self._cv(ops.make_desc(N, h, w, h, w, C, 0, C, 3, 1, 1, L.GATHER_DGRAD_ZERO), dz2, blk.c2.wpd, blk.c2.wpd3, da1,
@@ -975,7 +1009,12 @@ class Engine:
             self._wgrad(blk.c1, L.GATHER_FWD_ZERO, B["x"], None, dz1, N, h, w, hin, win, Cin, 0, accumulate, side)
             first_of_layer = (i == 0) or blk.stride == 2
             dgd = ops.make_desc(N, hin, win, h, w, C, 0, Cin, 3, blk.stride, 1, L.GATHER_DGRAD_ZERO)
-            if blk.ds is not None:
+            if blk.ds is not None and ev_ds is not None:
+                ops.event_wait(ops.current_stream(), ev_ds)
+                dgd.epi = L.EPI_ACCUM
+                self._cv(dgd, dz1, blk.c1.wpd, blk.c1.wpd3, dF[feat_of_block[i - 1]], hp=(blk.c1.hp_d, blk.c1.wslot))
+                dnext = None
+            elif blk.ds is not None:
                 dzd = buf("g.dzd.%d" % i, (N, h, w, C))
                 ops.bn_bwd(g.view(M, C), None, B["zd"].view(M, C), blk.bnd.mean, blk.bnd.invstd, blk.bnd.bn.weight.data,
                            dzd.view(M, C), blk.bnd.gg, blk.bnd.gb, accumulate=accumulate)
