@@ -562,15 +562,27 @@ Plan3 plan3(const fp_conv_desc* d) {
   else if (waste_ok(6, 20, 128)) { p.th = 6; p.tw = 20; }
   else return p;
   p.bn = d->Nout <= 32 ? 32 : 64;
+  static const int exp_bn32 = getenv("FP_TILE_BN32_BELOW") ? atoi(getenv("FP_TILE_BN32_BELOW")) : 0;     // experiment knobs
+  static const int exp_maxsk = getenv("FP_TILE_MAX_SK") ? atoi(getenv("FP_TILE_MAX_SK")) : 16;
+  {
+    const int64_t t64 = (int64_t)d->N * fp_ceil_div(d->OW, p.tw) * fp_ceil_div(d->OH, p.th) * fp_ceil_div(d->Nout, 64);
+    if (exp_bn32 && t64 < exp_bn32) p.bn = 32;      // more, narrower workgroups instead of split-K partials
+  }
   p.tilesX = (int)fp_ceil_div(d->OW, p.tw); p.tilesY = (int)fp_ceil_div(d->OH, p.th); p.tilesN = (int)fp_ceil_div(d->Nout, p.bn);
   const int64_t tiles = (int64_t)d->N * p.tilesY * p.tilesX * p.tilesN;
   const int KC16 = (d->C0 + d->C1 + 15) / 16;
   // small grids: split the channel chunks up to one full round of resident workgroups, >= 2 chunks per split, <= 16 partial copies
+  // grids of >= 160 tiles run unsplit even though they fill < 1 workgroup per CU: with split-K every workgroup of the single round ends in
+  // the same burst of partial stores (23.6 MB for 256 -> 256 @ 12 x 40: ~8 us, not overlapped with anything) and a reduce launch follows;
+  // 256 -> 256 @ 12 x 40: 45.6 -> 36.7 us, 128 -> 128 @ 24 x 80: 44.8 -> 31.7 us, training step 15.07 -> 14.71 ms (FP_TILE_SK1_FROM=384: old rule)
+  static const int sk1_from = getenv("FP_TILE_SK1_FROM") ? atoi(getenv("FP_TILE_SK1_FROM")) : 160;
   int64_t sk = 1;
-  if (tiles < 384) {
-    sk = 768 / tiles;                               // three workgroups per CU are resident: at most one full round of 768
+  if (tiles < sk1_from) {
+    static const int sk_target = getenv("FP_TILE_SK_TARGET") ? atoi(getenv("FP_TILE_SK_TARGET")) : 768;
+    sk = sk_target / tiles;                         // three workgroups per CU are resident: at most one full round of 768
     if (sk > KC16 / 2) sk = KC16 / 2;
     if (sk > 16) sk = 16;
+    if (sk > exp_maxsk) sk = exp_maxsk;
     if (sk < 1) sk = 1;
   }
   p.chunksPerSplit = (int)fp_ceil_div(KC16, sk);

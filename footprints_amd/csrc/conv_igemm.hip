@@ -332,7 +332,8 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const IgemmArgs a) {
 
 // split-K factor for a grid of `tiles` workgroups over `steps` K-steps: fill ~3 workgroups per CU, >= 8 steps each
 int pick_splitk(int64_t tiles, int steps, int64_t MN, int64_t ws_floats) {
-  if (tiles >= 384 || ws_floats <= 0) return 1;
+  static const int sk1_from = getenv("FP_IGEMM_SK1_FROM") ? atoi(getenv("FP_IGEMM_SK1_FROM")) : 160;     // as in conv3x3_tile_bf3.hip (plan3)
+  if (tiles >= sk1_from || ws_floats <= 0) return 1;
   int64_t sk = fp_ceil_div(768, tiles);
   if (sk > steps / 8) sk = steps / 8;
   if (sk * MN > ws_floats) sk = ws_floats / MN;

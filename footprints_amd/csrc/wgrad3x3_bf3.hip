@@ -550,7 +550,11 @@ WPlan plan(const fp_conv_desc* d) {
   p.nchunks = d->N * p.cy * p.cx;
   p.citiles = d->C0 / 32; p.cotiles = d->Nout / 32;
   const int64_t base = (int64_t)p.citiles * p.cotiles;
-  int64_t S = fp_ceil_div(512, base);      // two workgroups per CU are resident (240 registers): one full round
+  static const int target = getenv("FP_WGRAD_TARGET_WGS") ? atoi(getenv("FP_WGRAD_TARGET_WGS")) : 256;
+  // pixel splits for ~one workgroup per CU: measured in the training step 14.73 (512 workgroups: one full round of the two resident per CU),
+  // 14.39 (384), 14.27 / 13.93 (256), 14.02 (192), 14.30 (128) ms -- fewer splits write and re-read fewer partial tensors, and the
+  // weight gradients run on side streams beside the data-gradient chain, which gets the other half of the CUs
+  int64_t S = fp_ceil_div(target, base);
   if (S > p.nchunks / 4) S = p.nchunks / 4;
   if (S < 1) S = 1;
   if (S > 512) S = 512;

@@ -380,7 +380,8 @@ PPlan plan(int N, int h, int w, int C0, int Nout) {
   p.nchunks = N * p.cy * p.cx;
   p.citiles = C0 / 32; p.cotiles = Nout / 32;
   const int64_t base = (int64_t)p.citiles * p.cotiles;
-  int64_t S = fp_ceil_div(768, base);      // three workgroups per CU are resident (43-51 KB of LDS): one full round
+  static const int target = getenv("FP_PWGRAD_TARGET_WGS") ? atoi(getenv("FP_PWGRAD_TARGET_WGS")) : 768;
+  int64_t S = fp_ceil_div(target, base);   // three workgroups per CU are resident (43-51 KB of LDS): one full round
   if (S > p.nchunks / 4) S = p.nchunks / 4;
   if (S < 1) S = 1;
   if (S > 512) S = 512;
