@@ -785,7 +785,9 @@ def test_conv3x3_bf3_up2_concat_gather(N, h, w, C0, C1, Cout):
     assert ops.conv3x3_bf3_supported(d)
     y = torch.empty((N, 2 * h, 2 * w, Cout), device="cuda")
     ops.conv3x3_bf3(d, nhwc(lo), pack_bf3(wt), y, bias=b.cuda(), src1=nhwc(skip) if C1 else None)
-    check(nchw(y), ref, "bf3 up2 concat", 2e-6)
+    # 3e-6: the 12x40 case accumulates K = 9 * 512 = 4608 products in ONE fp32 chain since grids of >= 160 tiles run without split-K
+    # (measured 2.3e-6 of max|y|; four partial chains of 1152 gave 1.6e-6) -- the rounding of the fp32 accumulator, not of the operands
+    check(nchw(y), ref, "bf3 up2 concat", 3e-6)
 
 
 @pytest.mark.parametrize("mode,N,H,W,C0,Cout", [
