@@ -249,7 +249,8 @@ Plan make_plan(const fp_conv_desc* d) {
   const int64_t M = (int64_t)d->N * d->OH * d->OW;
   const int64_t chunks = fp_ceil_div(M, PK);
   const int64_t base = (int64_t)p.T * p.kblocks * p.nblocks;
-  int64_t S = fp_ceil_div(1024, base);
+  static const int target = getenv("FP_WGRAD32_TARGET_WGS") ? atoi(getenv("FP_WGRAD32_TARGET_WGS")) : 1024;
+  int64_t S = fp_ceil_div(target, base);
   if (S > chunks / 4) S = chunks / 4;  // at least 4 chunks per split
   if (S < 1) S = 1;
   if (S > 256) S = 256;
