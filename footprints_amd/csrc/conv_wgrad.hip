@@ -16,6 +16,8 @@
 
 #include "fp_common.h"
 
+int fp_stem_wgrad_tile_dispatch(const fp_conv_desc* d, const float* img, const float* dz, float* part, int splits, hipStream_t stream);
+
 int64_t fp_wgrad3x3_tile_workspace(const fp_conv_desc* d);
 int fp_wgrad3x3_tile_dispatch(const fp_conv_desc* d, const float* src0, const float* src1, const float* dz, float* dw_oihw,
                               int accumulate, int kc_total, int k_begin, void* workspace, int64_t workspace_bytes, hipStream_t stream);
@@ -254,6 +256,12 @@ Plan make_plan(const fp_conv_desc* d) {
   if (S > chunks / 4) S = chunks / 4;  // at least 4 chunks per split
   if (S < 1) S = 1;
   if (S > 256) S = 256;
+  if (stem) {      // stem_tile.hip's weight-gradient kernel: one partial tensor per workgroup, three workgroups per CU (42 KB of LDS each)
+    static const int stem_wgs = getenv("FP_STEM_WGRAD_WGS") ? atoi(getenv("FP_STEM_WGRAD_WGS")) : 768;
+    S = stem_wgs;
+    if (S > chunks / 4) S = chunks / 4;
+    if (S < 1) S = 1;
+  }
   p.chunksPerSplit = (int)fp_ceil_div(chunks, S);
   p.S = (int)fp_ceil_div(chunks, p.chunksPerSplit);
   return p;
@@ -318,6 +326,13 @@ extern "C" int fp_conv_wgrad_slice(const fp_conv_desc* d, const float* src0, con
   a.Nout = d->Nout; a.M = d->N * d->OH * d->OW; a.Kc = p.Kc; a.T = p.T; a.S = p.S; a.chunksPerSplit = p.chunksPerSplit;
   a.kblocks = p.kblocks; a.nblocks = p.nblocks;
   const int grid = p.S * p.T * p.kblocks * p.nblocks;
+  if (stem) {      // patch-in-LDS kernel (stem_tile.hip): p.S partial tensors, one per workgroup
+    const int rc = fp_stem_wgrad_tile_dispatch(d, src0, dz, (float*)workspace, p.S, stream);
+    if (rc != -1000) {
+      if (rc) return rc;
+      return fp_wgrad_reduce_launch((const float*)workspace, dw_oihw, p.S, p.T, p.Kc, d->Nout, 1, accumulate, kc_total, k_begin, stream);
+    }
+  }
   if (stem) {
     fp_launch((wgrad_kernel<64, 64, 2, 2, 1, true>), dim3(grid), dim3(256), 0, stream, a);
   } else if (p.BJ == 32) {

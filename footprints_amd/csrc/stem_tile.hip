@@ -90,7 +90,106 @@ __global__ void __launch_bounds__(256) stem_tile_kernel(const StemArgs a) {
     }
 }
 
+// ---- weight gradient of the stem, same patch-in-LDS scheme -------------------------------------------------------------------------
+// dW[k][co] = sum over output pixels of patch(k; pixel) * dZ[pixel][co], k = (ky*7 + kx)*3 + ci: the contraction runs over pixels, so an MFMA
+// K-step is two output pixels; A = one patch word per lane (row = k, the pixel from the step), B = one dZ word per lane (column = co) from the
+// staged [128 pixels][64] tile.  The 5 x 2 accumulator tiles (147 -> 160 rows x 64 columns) are spread over the four waves (3, 3, 2, 2); a
+// workgroup walks pixel tiles tile = id, id + grid, ... and writes ONE partial [147][64] at the end (wgrad_reduce_kernel sums them in a fixed
+// order).  The flattened kernel it replaces gathered every A element with per-element index math: 264 us for the KITTI stem, alone on the GPU
+// at the very end of the backward pass.
+struct StemWArgs {
+  const float* img;    // [N][3][IH][IW]
+  const float* dz;     // [N][OH][OW][64]
+  float* part;         // [gridDim.x][147][64]
+  int N, IH, IW, OH, OW, tilesX, tilesY, ntiles;
+};
+
+__global__ void __launch_bounds__(256) stem_wgrad_tile_kernel(const StemWArgs a) {
+  __shared__ float P[3 * PH * PWS];
+  __shared__ __attribute__((aligned(16))) float Z[TH * TW * 64];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, idx = lane & 31, h = lane >> 5;
+  int koff[3], ctile[3], krow0[3];
+  bool kval[3], tvalid[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int id = wave + 4 * j;                       // accumulator tile id: k tile = id % 5, co tile = id / 5 (ids 10, 11 do not exist)
+    tvalid[j] = id < 10;
+    const int kt = id % 5;
+    ctile[j] = tvalid[j] ? id / 5 : 0;
+    krow0[j] = kt * 32;
+    const int k = kt * 32 + idx, kc = min(k, 146);
+    const int ky = kc / 21, rem = kc - ky * 21, kx = rem / 3, ci = rem - kx * 3;
+    koff[j] = (ci * PH + ky) * PWS + (kx & 1) * (PWS / 2) + (kx >> 1);
+    kval[j] = tvalid[j] && k < 147;
+  }
+  f32x16 acc[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    int b = tile;
+    const int tx = b % a.tilesX; b /= a.tilesX;
+    const int ty = b % a.tilesY;
+    const int n = b / a.tilesY;
+    const int y0 = ty * TH, x0 = tx * TW;
+    __syncthreads();                                   // the previous tile has been read by every wave
+    for (int e = t; e < 3 * PH * PW; e += 256) {
+      const int ci = e / (PH * PW), r = e - ci * (PH * PW);
+      const int py = r / PW, px = r - py * PW;
+      const int iy = 2 * y0 + py - 3, ix = 2 * x0 + px - 3;
+      float v = 0.f;
+      if (iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW) v = (a.img[((size_t)(n * 3 + ci) * a.IH + iy) * a.IW + ix] - 0.45f) / 0.225f;
+      P[(ci * PH + py) * PWS + (px & 1) * (PWS / 2) + (px >> 1)] = v;
+    }
+    for (int e = t; e < TH * TW * 16; e += 256) {
+      const int pt = e >> 4, q = e & 15;
+      const int oy = y0 + pt / TW, ox = x0 + pt % TW;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (oy < a.OH && ox < a.OW) v = *reinterpret_cast<const float4*>(a.dz + ((size_t)(n * a.OH + oy) * a.OW + ox) * 64 + q * 4);
+      *reinterpret_cast<float4*>(Z + pt * 64 + q * 4) = v;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int s = 0; s < TH * TW / 2; ++s) {
+      const int p = 2 * s + h;
+      const int pb = (2 * (p / TW)) * PWS + (p % TW);
+      const float b0 = Z[p * 64 + idx], b1 = Z[p * 64 + 32 + idx];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        if (!tvalid[j]) continue;                       // wave-uniform
+        const float av = kval[j] ? P[pb + koff[j]] : 0.f;
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, ctile[j] ? b1 : b0, acc[j], 0, 0, 0);
+      }
+    }
+  }
+  float* out = a.part + (size_t)blockIdx.x * 147 * 64;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    if (!tvalid[j]) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int k = krow0[j] + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (k < 147) out[(size_t)k * 64 + ctile[j] * 32 + idx] = acc[j][r];
+    }
+  }
+}
+
 }  // namespace
+
+// stem weight gradient into `splits` partial tensors [splits][147][64] (then fp_wgrad_reduce_launch); -1000 = not handled
+int fp_stem_wgrad_tile_dispatch(const fp_conv_desc* d, const float* img, const float* dz, float* part, int splits, hipStream_t stream) {
+  static const bool off = getenv("FP_NO_STEM_WTILE") && atoi(getenv("FP_NO_STEM_WTILE"));
+  if (off || d->Nout != 64 || d->IH != 2 * d->OH || d->IW != 2 * d->OW || splits < 1) return -1000;
+  StemWArgs a;
+  a.img = img; a.dz = dz; a.part = part;
+  a.N = d->N; a.IH = d->IH; a.IW = d->IW; a.OH = d->OH; a.OW = d->OW;
+  a.tilesX = (int)fp_ceil_div(d->OW, TW); a.tilesY = (int)fp_ceil_div(d->OH, TH);
+  a.ntiles = d->N * a.tilesX * a.tilesY;
+  fp_launch(stem_wgrad_tile_kernel, dim3(splits), dim3(256), 0, stream, a);
+  return fp_check_launch("fp_conv_wgrad(stem)");
+}
 
 // -1000 = not handled (caller falls back to the flattened kernel)
 int fp_stem_tile_dispatch(const fp_conv_desc* d, const float* img, const float* wpacked, const float* bias, float* y, hipStream_t stream) {

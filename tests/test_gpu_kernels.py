@@ -569,9 +569,10 @@ def test_wgrad3x3_tile_kernel(mode, N, H, W, C0, C1, Cout):
     check(dw, 2 * w.grad, "wgrad tile accumulate " + mode)
 
 
-def test_stem_wgrad():
+@pytest.mark.parametrize("N,H,W", [(2, 64, 96), (2, 192, 640), (3, 72, 104), (1, 16, 32)])
+def test_stem_wgrad(N, H, W):
+    """7x7 / 2 stem weight gradient (stem_tile.hip: patch-in-LDS kernel; partial tiles at the right / bottom edge; accumulate)"""
     ops, L = _ops()
-    N, H, W = 2, 64, 96
     img = rnd((N, 3, H, W), 33, 0.0, 1.0)
     w = rnd((64, 3, 7, 7), 34, -0.1, 0.1).requires_grad_(True)
     y = F.conv2d((img - 0.45) / 0.225, w, None, 2, 3)
@@ -581,6 +582,8 @@ def test_stem_wgrad():
     dw = torch.empty((64, 3, 7, 7), device="cuda")
     ops.conv_wgrad(d, img.cuda(), None, nhwc(g), dw)
     check(dw, w.grad, "stem wgrad")
+    ops.conv_wgrad(d, img.cuda(), None, nhwc(g), dw, accumulate=True)
+    check(dw, 2 * w.grad, "stem wgrad accumulate")
 
 
 # ----------------------------------------------------------------------------------------------------------
