@@ -503,8 +503,9 @@ class Engine:
     def _cv(self, d, src, w32, w3, out, hp=None, **kw):
         """one 3x3 / 1x1 convolution or data-gradient launch: the split-operand tile kernel where it applies (hp = (fp16-pair packing,
         weight amax slot): three fp16 products; else w3: six bf16 products), else fp_conv_igemm"""
-        if (w3 is not None or hp is not None) and ops.conv3x3_bf3_supported(d):
-            if hp is not None and hp[0] is not None and not ops._bf16x2:
+        use_hp = hp is not None and hp[0] is not None and not ops._bf16x2
+        if (w3 is not None or use_hp) and ops.conv3x3_bf3_supported(d):
+            if use_hp:
                 return self._cv_hp(d, src, hp[0], hp[1], out, **kw)
             return ops.conv3x3_bf3(d, src, w3, out, **kw)
         return ops.conv_igemm(d, src, None, w32, out, **kw)

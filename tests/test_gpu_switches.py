@@ -1,0 +1,64 @@
+"""GPU: the A/B switches documented in DESIGN.md select working code paths.  Each case runs three training steps of a small batch in a
+fresh process (the switches are read at import / first use) and must reproduce the default build's losses: bit-identically where only the
+schedule changes, within 1e-4 where the arithmetic of the convolutions changes (fp16 pairs vs the exact bf16 split vs fp32 MFMA)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PROG = """
+import json, torch
+from footprints_amd.model_manager import ModelManager
+from footprints_amd.training.train import SEED, TrainStep, synthetic_batch
+torch.manual_seed(SEED)
+mm = ModelManager(use_cuda=True)
+ts = TrainStep(mm.model, mm.optimiser)
+batch = synthetic_batch(2, 128, 192, "cuda")
+out = []
+for _ in range(4):
+    ts(batch)
+    out.append([float(v) for v in ts.losses.cpu()])
+print("LOSSES " + json.dumps(out))
+"""
+
+
+def run(env_extra):
+    env = dict(os.environ)
+    for k in ("FP_HP", "FP_NO_BF3", "FP_SERIAL", "FP_NO_PHASE", "FP_DS_AUX", "FP_PLAN", "FP_NO_WBF3"):
+        env.pop(k, None)
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, "-c", PROG], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("LOSSES ")][-1]
+    return json.loads(line[len("LOSSES "):])
+
+
+@pytest.fixture(scope="module")
+def baseline():
+    return run({})
+
+
+@pytest.mark.parametrize("env,exact", [
+    ({"FP_SERIAL": "1"}, False),           # one stream instead of five (the downsample branch then runs in line: another accumulation order)
+    ({"FP_SERIAL": "1", "FP_DS_AUX": "0"}, False),
+    ({"FP_PLAN": "0"}, True),              # launches issued from Python instead of the recorded plan (step 4 is a replay by default)
+    ({"FP_DS_AUX": "0"}, False),           # downsample branch in line: its data gradient accumulates after conv1's instead of before
+    ({"FP_HP": "0", "FP_NO_PHASE": "1"}, False),
+    ({"FP_HP": "0"}, False),               # exact bf16x3 split instead of scaled fp16 pairs
+    ({"FP_NO_BF3": "1"}, False),           # fp32-MFMA kernels everywhere
+    ({"FP_NO_PHASE": "1"}, False),         # fused nearest-x2 gather instead of the phase decomposition
+])
+def test_switch_reproduces_the_default_losses(baseline, env, exact):
+    got = run(env)
+    assert len(got) == len(baseline) == 4
+    for step, (a, b) in enumerate(zip(got, baseline)):
+        for x, y in zip(a, b):
+            if exact:
+                assert x == y, (env, step, x, y)
+            else:
+                assert abs(x - y) <= 1e-4 * max(abs(y), 1e-3), (env, step, x, y)
