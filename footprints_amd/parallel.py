@@ -81,15 +81,18 @@ class GradReducer:
     def grad_scale(self):
         return 1.0 / self.world
 
-    def stage_ready(self, stage):
-        """Called by the backward schedule when every gradient of `stage` has been written."""
+    def stage_ready(self, stage, streams=None):
+        """Called by the backward schedule when every gradient of `stage` has been launched.  streams: every stream that may still be
+        writing them (Engine.stage_streams(): the weight gradients run on side streams that the main stream does not wait for); the
+        collective is ordered after all of them.  None: the current stream only."""
         if (self.world == 1 and not self.force) or stage in self._done_stage:
             return
         self._done_stage.add(stage)
         if self.cuda:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream())
-            self.stream.wait_event(ev)
+            for st in (streams or [torch.cuda.current_stream()]):
+                ev = torch.cuda.Event()
+                ev.record(st)
+                self.stream.wait_event(ev)
             with torch.cuda.stream(self.stream):
                 for s, lo, hi in self.buckets:
                     if s == stage:
@@ -104,7 +107,7 @@ class GradReducer:
         if self.world > 1 or self.force:
             for s in ("mask_decoder", "depth_decoder", "encoder.layer4", "encoder.layer3", "encoder.layer2", "encoder.layer1",
                       "encoder.layer0"):
-                self.stage_ready(s)          # anything the schedule did not report explicitly
+                self.stage_ready(s)          # anything the schedule did not report explicitly (the backward pass has joined its streams by now)
             for w in self._pending:
                 w.wait()
             if self.cuda:

@@ -113,7 +113,7 @@ class TrainStep:
             if self.reducer is not None:
                 for mark, stage in marks:
                     _lib.check(lib.fp_plan_replay(plan, pos, mark), "fp_plan_replay")
-                    self.reducer.stage_ready(stage)
+                    self.reducer.stage_ready(stage, self.eng.stage_streams())
                     pos = mark
                 _lib.check(lib.fp_plan_replay(plan, pos, adam_at), "fp_plan_replay")
                 self.reducer.finish()
@@ -173,7 +173,7 @@ class TrainStep:
             def on_stage(stage):                          # recording: remember where the stage's gradients are complete
                 if on_mark is not None:
                     on_mark(stage)
-                self.reducer.stage_ready(stage)
+                self.reducer.stage_ready(stage, eng.stage_streams())
         eng.backward(self.dpreds, accumulate=False, on_stage=on_stage)
         if before_adam is not None:
             before_adam()
