@@ -174,7 +174,7 @@ typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
-constexpr int PIXB = 48, PLANE3 = HP * PIXB, BUF3 = 3 * PLANE3;
+constexpr int PIXB = 48, PLANE3 = HP * PIXB;      // bytes per halo pixel and per operand plane (a buffer holds NP planes)
 // NP = 3: the exact bf16 split (six products); NP = 2: scaled fp16 pairs (fp_common.h; FP_HP_PRODUCTS products on v_mfma_f32_32x32x16_f16)
 template <int NP>
 __device__ __forceinline__ void phase_store_split(unsigned char* p, f32x4_t v, int ka) {

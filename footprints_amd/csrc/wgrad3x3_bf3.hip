@@ -243,7 +243,7 @@ __global__ void __launch_bounds__(256) wgrad3x3_bf3_kernel(const W3Args a) {
 constexpr int HWD = CW + 2;                                     // halo width in pixels
 constexpr int PXB = 64;                                         // bytes per pixel per plane (32 channels bf16)
 constexpr int XP3 = HR * HWD * PXB, ZP3 = CH * CW * PXB;        // 6912, 4096 bytes per plane
-constexpr int XB3 = 3 * XP3, ZB3 = 3 * ZP3, BUF3 = XB3 + ZB3;   // 20736 + 12288 = 33024 bytes per buffer
+// a buffer holds NP planes of each: 3 x (6912 + 4096) = 33024 bytes (bf16 split), 2 x = 22016 bytes (fp16 pairs)
 constexpr int XITEMS = HR * HWD * 8;                            // (pixel, channel quad) staging items of X: 864 (dZ: 4 x 16 x 8 = 512 = two per thread)
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
