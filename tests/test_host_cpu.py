@@ -58,6 +58,35 @@ def test_workspace_queries_and_argument_validation_without_gpu():
     assert rc == -1 and b"multiples of 4" in lib.fp_last_error_string()
 
 
+def test_hp_host_side_contract_without_gpu():
+    """fp16-pair operand format: header constants = binding, pack-job struct layout, storage sizes, argument validation (no launches)"""
+    import ctypes as C
+    from footprints_amd import _lib, ops
+    lib = _lib.load()
+    hdr = open(os.path.join(ROOT, "include", "footprints_hip.h")).read()
+    slots = int(re.search(r"#define FP_AMAX_SLOTS (\d+)", hdr).group(1))
+    stride = int(re.search(r"#define FP_AMAX_STRIDE (\d+)", hdr).group(1))
+    assert ops.amax_elems() == lib.fp_amax_slot_elems() == slots * stride and stride * 4 == 128      # one 128-byte line per sub-slot
+    # fp_pack_job: the amax pointer was appended behind the nine int32 fields (8-byte aligned)
+    assert _lib.PackJob.amax.offset == 56 and C.sizeof(_lib.PackJob) == 64
+    kinds = re.search(r"FP_PACK_FWD_HP = (\d+), FP_PACK_DGRAD_HP = (\d+), FP_PACK_UP2_FWD_HP = (\d+), FP_PACK_UP2_DGRAD_HP = (\d+)", hdr).groups()
+    assert tuple(int(k) for k in kinds) == (_lib.PACK_FWD_HP, _lib.PACK_DGRAD_HP, _lib.PACK_UP2_FWD_HP, _lib.PACK_UP2_DGRAD_HP)
+    # two fp16 per weight = one float of storage per padded weight; the exact bf16 split needs 1.5
+    assert lib.fp_packed_weight_elems_hp(64, 64, 3, 3, 0) == 9 * 4 * 64 * 16
+    assert lib.fp_packed_weight_elems_bf3(64, 64, 3, 3, 0) == 9 * 4 * 64 * 16 * 3 // 2
+    assert lib.fp_packed_weight_elems_hp(8, 20, 3, 3, 1) == 9 * 1 * 20 * 16          # data-gradient layout: chunks over Cout, columns = Cin
+    d = ops.make_desc(12, 48, 160, 48, 160, 64, 0, 64, 3, 1, 1, _lib.GATHER_FWD_REFLECT)
+    assert lib.fp_conv3x3_bf3_supported(C.byref(d)) == 1 and lib.fp_conv3x3_bf3_workspace(C.byref(d)) == 0
+    small = ops.make_desc(12, 6, 20, 6, 20, 512, 0, 512, 3, 1, 1, _lib.GATHER_FWD_ZERO)      # 96 tiles: split over the channel chunks
+    assert lib.fp_conv3x3_bf3_workspace(C.byref(small)) > 0
+    mid = ops.make_desc(12, 12, 40, 12, 40, 256, 0, 256, 3, 1, 1, _lib.GATHER_FWD_ZERO)      # 180 tiles: unsplit since round 2
+    assert lib.fp_conv3x3_bf3_workspace(C.byref(mid)) == 0
+    rc = lib.fp_conv3x3_hp(C.byref(d), 1, 0, 1, 0, 0, 0, 0, 1, None, 0, None, None, None, None, None)      # amax slots missing
+    assert rc == -1 and b"amax slots missing" in lib.fp_last_error_string()
+    rc = lib.fp_conv_wgrad_hp(C.byref(d), 1, 1, 1, 0, 64, 0, 0, 1, 1 << 30, None, None, None)
+    assert rc == -1 and b"amax slots missing" in lib.fp_last_error_string()
+
+
 def test_module_tree_reproduces_reference_state_dict():
     from footprints_amd import FootprintNetwork
     from footprints_amd.network import is_dead_param
