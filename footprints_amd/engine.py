@@ -3,14 +3,17 @@
 Design (MI355X-first, not an autograd graph):
   * activations NHWC fp32, resident in a named arena that is allocated once and reused every step (static
     addresses => the whole step is capturable in a hipGraph: TrainStep(graph=True));
-  * 3x3 stride-1 convolutions (forward, data- and weight-gradient) multiply exactly split operands (three bf16 terms per
-    fp32 value, six bf16 MFMA products, fp32 accumulation: conv3x3_tile_bf3.hip); the rest uses the fp32 MFMA kernels;
+  * 3x3 stride-1 convolutions (forward, data- and weight-gradient) multiply split operands: scaled fp16 pairs (22 significant bits
+    after a per-tensor power-of-two scaling, three fp16 MFMA products, fp32 accumulation; the scale comes from amax slots that the
+    producing kernels publish, AmaxBook below) or, with FP_HP=0, the exact three-term bf16 split (six products) -- one kernel
+    template for both (conv3x3_tile_bf3.hip); the rest uses the fp32 MFMA kernels;
   * nearest-x2 upsample, skip concat, reflection / zero padding, ELU / ReLU, residual adds and their
     gradients never exist as tensors -- they are loader / epilogue modes of the implicit-GEMM kernels;
   * all live parameters are views of ONE flat fp32 buffer (same for gradients) in forward order, so Adam is
     one kernel launch and the data-parallel all-reduce works on contiguous buckets;
   * backward is a hand-written schedule (decoders, then encoder, reverse order); gradients of tensors with
-    several consumers are accumulated in a fixed order by epilogue flags (deterministic, no atomics).
+    several consumers are accumulated in a fixed order by epilogue flags (deterministic; the only atomics are the integer-max
+    publications of the amax slots, which are order-independent).
 
 Reference call stack being replaced: FootprintNetwork.forward (network.py:21-30) and autograd's backward of
 it (training/train.py:155).
@@ -32,7 +35,7 @@ _FOLD = not bool(int(os.environ.get("FP_NO_FOLD", "0")))
 _BF3 = not bool(int(os.environ.get("FP_NO_BF3", "0")))
 _WBF3 = _BF3 and not bool(int(os.environ.get("FP_NO_WBF3", "0")))      # ... and for the weight-gradient kernel
 _PWBF3 = not bool(int(os.environ.get("FP_NO_PHASE_WBF3", "0")))           # ... and for the phase weight-gradient kernel (A/B switch)
-# fp16-pair operands (two fp16 terms after a per-tensor power-of-two scaling, four MFMA products, 22 significant bits) for the same
+# fp16-pair operands (two fp16 terms after a per-tensor power-of-two scaling, three MFMA products, 22 significant bits) for the same
 # kernels, with the scaling taken from amax slots that producers publish / a reduction fills (csrc/fp_common.h); FP_HP=0 keeps bf16x3
 _HP = _BF3 and bool(int(os.environ.get("FP_HP", "1")))
 # the 1x1 downsample branch of a BasicBlock (conv -> BN, and its gradients) on the aux stream beside the block's main branch: the encoder
