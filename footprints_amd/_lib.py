@@ -36,6 +36,17 @@ _DESC = C.POINTER(ConvDesc)
 
 # name -> (restype, argtypes); mirrors include/footprints_hip.h one to one
 SIGNATURES = {
+    "fp_comm_unique_id_bytes": (_I32, []),
+    "fp_comm_unique_id": (C.c_int, [_P, _I32]),
+    "fp_comm_init": (C.c_int, [_P, _I32, _I32, C.POINTER(C.c_void_p)]),
+    "fp_comm_version": (_I32, []),
+    "fp_comm_allreduce_async": (C.c_int, [_P, _P, _I64, _P]),
+    "fp_comm_broadcast": (C.c_int, [_P, _P, _I64, _I32, _P]),
+    "fp_comm_wait": (C.c_int, [_P, _P, _P]),
+    "fp_comm_destroy": (C.c_int, [_P]),
+    "fp_ktime_begin": (C.c_int, []),
+    "fp_ktime_end": (_I32, []),
+    "fp_ktime_row": (C.c_int, [_I32, C.c_char_p, _I32, C.POINTER(_I64), C.POINTER(_D)]),
     "fp_plan_begin": (_P, []),
     "fp_plan_mark": (_I32, [_P]),
     "fp_plan_end": (_I32, [_P]),

@@ -23,16 +23,23 @@ static inline int64_t fp_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b
 #include <utility>
 bool fp_plan_recording();
 void fp_plan_push_kernel(const void* func, dim3 grid, dim3 block, unsigned shmem, hipStream_t stream, void** args, const size_t* sizes, int nargs);
+void fp_plan_mark_failed();
+hipError_t fp_launch_timed(const void* func, dim3 grid, dim3 block, void** args, unsigned shmem, hipStream_t stream);   // plan.cpp: + fp_ktime_* events when on
 
 template <typename... KArgs, size_t... I>
 inline void fp_launch_impl(void (*kernel)(KArgs...), dim3 grid, dim3 block, unsigned shmem, hipStream_t stream, std::tuple<KArgs...>& st,
                            std::index_sequence<I...>) {
   void* ptrs[sizeof...(KArgs) ? sizeof...(KArgs) : 1] = {(void*)&std::get<I>(st)...};
+  // launch first: only a launch the runtime accepted becomes a plan node (the entry point's fp_check_launch reports the error itself)
+  const hipError_t e = fp_launch_timed((const void*)kernel, grid, block, ptrs, shmem, stream);
   if (fp_plan_recording()) {
+    if (e != hipSuccess) {
+      fp_plan_mark_failed();
+      return;
+    }
     const size_t sizes[sizeof...(KArgs) ? sizeof...(KArgs) : 1] = {sizeof(KArgs)...};
     fp_plan_push_kernel((const void*)kernel, grid, block, shmem, stream, ptrs, sizes, (int)sizeof...(KArgs));
   }
-  (void)hipLaunchKernel((const void*)kernel, grid, block, ptrs, shmem, stream);
 }
 
 template <typename... KArgs, typename... Args>

@@ -9,17 +9,25 @@
 // concurrency and the results are exactly those of the recorded eager step (a graph replay measured slower on ROCm 7.2).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
+#include <cxxabi.h>
+
+#include <atomic>
+#include <map>
+#include <string>
 #include <vector>
 
 #include "footprints_hip.h"
 
 int fp_set_error(int code, const char* fmt, ...);
+hipError_t fp_launch_timed(const void* func, dim3 grid, dim3 block, void** args, unsigned shmem, hipStream_t stream);
+int fp_comm_allreduce_raw(void* comm, float* buf, int64_t count, hipStream_t stream);     // comm.cpp
 
 namespace {
 
-enum NodeKind { NODE_KERNEL = 0, NODE_RECORD = 1, NODE_WAIT = 2 };
+enum NodeKind { NODE_KERNEL = 0, NODE_RECORD = 1, NODE_WAIT = 2, NODE_ALLREDUCE = 3 };
 
 struct Node {
   int kind;
@@ -29,9 +37,15 @@ struct Node {
   hipStream_t stream;
   uint32_t arg_first, nargs;   // into Plan::arg_off
   int event;                   // plan-local event index (record / wait)
+  void* comm;                  // NODE_ALLREDUCE: communicator, buffer (in place), element count
+  float* buf;
+  int64_t count;
 };
 
+constexpr uint32_t MAX_KERNEL_ARGS = 64;     // fp_plan_replay's argv; the library's widest kernel takes 31 parameters
+
 struct Plan {
+  bool failed = false;                  // a launch failed / was rejected while recording: fp_plan_end reports it
   std::vector<Node> nodes;
   std::vector<unsigned char> bytes;     // argument storage (16-byte aligned slots)
   std::vector<uint32_t> arg_off;        // byte offset of every argument
@@ -44,15 +58,101 @@ thread_local Plan* g_rec = nullptr;
 constexpr int RING = 4096;
 hipEvent_t g_ring[RING];
 bool g_ring_made[RING];
-int g_ring_next = 0;
+std::atomic<int> g_ring_next{0};      // fp_event_record may be called from several host threads (loader thread + trainer)
+std::atomic<bool> g_ring_lock{false}; // guards the lazy creation of a ring slot's event
 
 }  // namespace
 
 bool fp_plan_recording() { return g_rec != nullptr; }
 
-// called by fp_launch for every kernel launch of the library while a plan records
+// ---- per-kernel timing (fp_ktime_*): HIP events on the launch stream around every kernel launch of the library --------------------
+// bench.py's roofline leg: the duration of every launch, measured live with events recorded on the stream the kernel is launched
+// on, aggregated per kernel symbol -- the same quantity `rocprofv3 --kernel-trace --stats` reports per kernel.
+namespace {
+struct TimedLaunch { const void* func; hipEvent_t a, b; };
+bool g_kt_on = false;
+std::vector<TimedLaunch> g_kt;
+std::vector<hipEvent_t> g_kt_pool;
+struct KRow { std::string name; int64_t launches; double ms; };
+std::vector<KRow> g_kt_rows;
+hipEvent_t kt_event() {
+  if (!g_kt_pool.empty()) { hipEvent_t e = g_kt_pool.back(); g_kt_pool.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+}  // namespace
+
+hipError_t fp_launch_timed(const void* func, dim3 grid, dim3 block, void** args, unsigned shmem, hipStream_t stream) {
+  if (!g_kt_on) return hipLaunchKernel(func, grid, block, args, shmem, stream);
+  TimedLaunch t{func, kt_event(), kt_event()};
+  (void)hipEventRecord(t.a, stream);
+  const hipError_t e = hipLaunchKernel(func, grid, block, args, shmem, stream);
+  (void)hipEventRecord(t.b, stream);
+  g_kt.push_back(t);
+  return e;
+}
+
+extern "C" int fp_ktime_begin(void) {
+  for (auto& t : g_kt) { g_kt_pool.push_back(t.a); g_kt_pool.push_back(t.b); }
+  g_kt.clear();
+  g_kt_rows.clear();
+  g_kt_on = true;
+  return FP_OK;
+}
+
+// stops collecting, waits for the device, and aggregates per kernel symbol; returns the number of distinct kernels (rows of fp_ktime_row)
+extern "C" int32_t fp_ktime_end(void) {
+  g_kt_on = false;
+  const hipError_t se = hipDeviceSynchronize();
+  if (se != hipSuccess) return fp_set_error((int)se, "fp_ktime_end: %s", hipGetErrorString(se));
+  std::map<const void*, size_t> index;
+  g_kt_rows.clear();
+  for (auto& t : g_kt) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, t.a, t.b) != hipSuccess) ms = 0.f;
+    auto it = index.find(t.func);
+    if (it == index.end()) {
+      const char* mangled = hipKernelNameRefByPtr(t.func, nullptr);
+      std::string name = mangled ? mangled : "?";
+      int st = 0;
+      char* dm = mangled ? abi::__cxa_demangle(mangled, nullptr, nullptr, &st) : nullptr;
+      if (dm && st == 0) name = dm;
+      free(dm);
+      it = index.emplace(t.func, g_kt_rows.size()).first;
+      g_kt_rows.push_back(KRow{name, 0, 0.0});
+    }
+    g_kt_rows[it->second].launches += 1;
+    g_kt_rows[it->second].ms += ms;
+    g_kt_pool.push_back(t.a);
+    g_kt_pool.push_back(t.b);
+  }
+  g_kt.clear();
+  return (int32_t)g_kt_rows.size();
+}
+
+extern "C" int fp_ktime_row(int32_t i, char* name, int32_t name_cap, int64_t* launches, double* total_ms) {
+  if (i < 0 || i >= (int32_t)g_kt_rows.size() || !name || name_cap < 2 || !launches || !total_ms) return fp_set_error(FP_EINVAL, "fp_ktime_row: bad row / buffer");
+  const KRow& r = g_kt_rows[i];
+  strncpy(name, r.name.c_str(), (size_t)name_cap - 1);
+  name[name_cap - 1] = 0;
+  *launches = r.launches;
+  *total_ms = r.ms;
+  return FP_OK;
+}
+
+// called by fp_launch for every SUCCESSFUL kernel launch of the library while a plan records (a failed launch marks the plan instead)
+void fp_plan_mark_failed() {
+  if (g_rec) g_rec->failed = true;
+}
+
 void fp_plan_push_kernel(const void* func, dim3 grid, dim3 block, unsigned shmem, hipStream_t stream, void** args, const size_t* sizes, int nargs) {
   Plan* p = g_rec;
+  if (nargs < 0 || (uint32_t)nargs > MAX_KERNEL_ARGS) {
+    p->failed = true;
+    fp_set_error(FP_EINVAL, "fp_plan: a kernel with %d parameters cannot be recorded (limit %u)", nargs, MAX_KERNEL_ARGS);
+    return;
+  }
   Node n;
   n.kind = NODE_KERNEL; n.func = func; n.grid = grid; n.block = block; n.shmem = shmem; n.stream = stream;
   n.arg_first = (uint32_t)p->arg_off.size(); n.nargs = (uint32_t)nargs; n.event = -1;
@@ -63,6 +163,14 @@ void fp_plan_push_kernel(const void* func, dim3 grid, dim3 block, unsigned shmem
     p->arg_off.push_back((uint32_t)off);
   }
   p->nodes.push_back(n);
+}
+
+// called by fp_comm_allreduce_async (comm.cpp) after it issued the collective while a plan records
+void fp_plan_push_allreduce(void* comm, float* buf, int64_t count, hipStream_t stream) {
+  Node n;
+  n.kind = NODE_ALLREDUCE; n.func = nullptr; n.shmem = 0; n.stream = stream; n.arg_first = n.nargs = 0; n.event = -1;
+  n.comm = comm; n.buf = buf; n.count = count;
+  g_rec->nodes.push_back(n);
 }
 
 extern "C" void* fp_plan_begin(void) {
@@ -76,6 +184,7 @@ extern "C" int32_t fp_plan_mark(void* plan) { return plan ? (int32_t)((Plan*)pla
 extern "C" int32_t fp_plan_end(void* plan) {
   if (!plan || g_rec != (Plan*)plan) return fp_set_error(FP_EINVAL, "fp_plan_end: this plan is not recording on this thread");
   g_rec = nullptr;
+  if (((Plan*)plan)->failed) return fp_set_error(FP_EINVAL, "fp_plan_end: a launch failed or was rejected while this plan recorded");
   return (int32_t)((Plan*)plan)->nodes.size();
 }
 
@@ -92,13 +201,17 @@ extern "C" int fp_plan_replay(void* plan, int32_t begin, int32_t end) {
   if (!p || g_rec == p) return fp_set_error(FP_EINVAL, "fp_plan_replay: null plan or plan still recording");
   if (end < 0 || end > (int32_t)p->nodes.size()) end = (int32_t)p->nodes.size();
   if (begin < 0 || begin > end) return fp_set_error(FP_EINVAL, "fp_plan_replay: bad node range");
-  void* argv[64];
+  void* argv[MAX_KERNEL_ARGS];
   for (int32_t i = begin; i < end; ++i) {
     const Node& n = p->nodes[i];
     hipError_t e;
     if (n.kind == NODE_KERNEL) {
       for (uint32_t k = 0; k < n.nargs; ++k) argv[k] = p->bytes.data() + p->arg_off[n.arg_first + k];
-      e = hipLaunchKernel(n.func, n.grid, n.block, argv, n.shmem, n.stream);
+      e = fp_launch_timed(n.func, n.grid, n.block, argv, n.shmem, n.stream);
+    } else if (n.kind == NODE_ALLREDUCE) {
+      const int r = fp_comm_allreduce_raw(n.comm, n.buf, n.count, n.stream);
+      if (r != FP_OK) return r;
+      e = hipSuccess;
     } else if (n.kind == NODE_RECORD) {
       e = hipEventRecord(p->events[n.event], n.stream);
     } else {
@@ -125,13 +238,15 @@ extern "C" int64_t fp_event_record(fp_stream_t stream_) {
     g_rec->nodes.push_back(n);
     id |= (int64_t)1 << 40;                           // tag: plan-local id
   } else {
-    const int slot = g_ring_next;
-    g_ring_next = (g_ring_next + 1) % RING;
+    const int slot = (int)((unsigned)g_ring_next.fetch_add(1, std::memory_order_relaxed) % RING);
+    while (g_ring_lock.exchange(true, std::memory_order_acquire)) {}
+    hipError_t ce = hipSuccess;
     if (!g_ring_made[slot]) {
-      hipError_t e = hipEventCreateWithFlags(&g_ring[slot], hipEventDisableTiming);
-      if (e != hipSuccess) return fp_set_error(-(int)e - 1000, "fp_event_record: %s", hipGetErrorString(e));
-      g_ring_made[slot] = true;
+      ce = hipEventCreateWithFlags(&g_ring[slot], hipEventDisableTiming);
+      if (ce == hipSuccess) g_ring_made[slot] = true;
     }
+    g_ring_lock.store(false, std::memory_order_release);
+    if (ce != hipSuccess) return fp_set_error(-(int)ce - 1000, "fp_event_record: %s", hipGetErrorString(ce));
     ev = g_ring[slot];
     id = slot;
   }

@@ -167,6 +167,12 @@ class AmaxBook:
         self.by_tag = {}
         self.assoc = {}        # data_ptr -> (slot, raw stream handle or None = any stream)
         self.name_of = {}      # data_ptr -> arena name (Engine.buf)
+        # an arena buffer that is handed out several times per step (g.g, g.da1, ...dzl, ...) gets a FRESH slot per hand-out (tag =
+        # name + use count): a slot is only ever max-combined, so sharing one between uses would scale a later tensor by an
+        # earlier, larger one's amax and give up mantissa bits of the 22-bit operand format.  The counts restart with every
+        # forward (begin) and, for a backward pass repeated on one saved forward, at the point the forward left them (globalize).
+        self.uses = {}
+        self._uses_fwd = None
 
     def slot(self, tag):
         i = self.by_tag.get(tag)
@@ -179,17 +185,30 @@ class AmaxBook:
     def begin(self):
         ops.zero_u32(self.pool)
         self.assoc.clear()
+        self.uses = {}
+        self._uses_fwd = None
+
+    def handed_out(self, name):
+        self.uses[name] = self.uses.get(name, 0) + 1
+
+    def _tag(self, t):
+        name = self.name_of.get(t.data_ptr(), "ptr%x" % t.data_ptr())
+        return "%s#%d" % (name, self.uses.get(name, 0))
 
     def globalize(self):
         for k, (sl, _) in list(self.assoc.items()):
             self.assoc[k] = (sl, None)
+        if self._uses_fwd is None:
+            self._uses_fwd = dict(self.uses)
+        else:                                  # a backward pass repeated on the same saved forward: the same slots again
+            self.uses = dict(self._uses_fwd)
 
     def drop(self, t):
         self.assoc.pop(t.data_ptr(), None)
 
     def out_slot(self, t):
         """slot a producer of `t` publishes into (associate with `published` after the launch)"""
-        return self.slot("out:" + self.name_of.get(t.data_ptr(), "ptr%x" % t.data_ptr()))
+        return self.slot("out:" + self._tag(t))
 
     def published(self, t, sl, any_stream=False):
         self.assoc[t.data_ptr()] = (sl, None if any_stream else ops.stream())
@@ -202,7 +221,7 @@ class AmaxBook:
             if any_stream and e[1] is not None:
                 self.assoc[t.data_ptr()] = (e[0], None)
             return e[0]
-        sl = self.slot("in:%s@%x" % (self.name_of.get(t.data_ptr(), "ptr%x" % t.data_ptr()), cur))
+        sl = self.slot("in:%s@%x" % (self._tag(t), cur))
         ops.amax_f32(t, sl)
         self.assoc[t.data_ptr()] = (sl, None if any_stream else cur)
         return sl
@@ -272,6 +291,7 @@ class Engine:
             total += (p.numel() + 3) // 4 * 4
         self.flat_param = torch.zeros(total, device=self.device)
         self.flat_grad = torch.zeros(total, device=self.device)
+        ops.bump_alloc_generation()
         self.offsets = offs
         self.grad_views = []
         with torch.no_grad():
@@ -419,6 +439,7 @@ class Engine:
             rest = [c for c in self.all_convs() if not any(c is f for f in first)]
             self._pack_table = (ops.build_pack_table(jobs_of(first), self.device), ops.build_pack_table(jobs_of(rest), self.device))
             self._pack_table_key = key      # parameters live in self.flat_param: pointers are stable
+            ops.bump_alloc_generation()     # the previous tables (device-resident job lists) are gone
         if _HP:
             ops.zero_u32(self.wamax)
             ops.pack_weights_amax(self._pack_table[0])
@@ -457,7 +478,9 @@ class Engine:
             t = torch.empty(max(n, 1), dtype=dtype, device=self.device)
             self._bufs[name] = t
             self.amax.name_of[t.data_ptr()] = name
+            ops.bump_alloc_generation()               # recorded launch plans hold the old address
         self.amax.assoc.pop(t.data_ptr(), None)       # the buffer is about to be rewritten: its amax slot no longer describes it
+        self.amax.handed_out(name)                    # ... and its next producer publishes into a fresh slot
         return t[:n].view(shape)
 
     # ------------------------------------------------------------------------------------------------
@@ -503,13 +526,13 @@ class Engine:
             hd.gw.copy_(hd.gw2[0:1])
             hd.gb.copy_(hd.gb2[0:1])
 
-    def _cv(self, d, src, w32, w3, out, hp=None, **kw):
+    def _cv(self, d, src, w32, w3, out, hp=None, publish=True, **kw):
         """one 3x3 / 1x1 convolution or data-gradient launch: the split-operand tile kernel where it applies (hp = (fp16-pair packing,
         weight amax slot): three fp16 products; else w3: six bf16 products), else fp_conv_igemm"""
         use_hp = hp is not None and hp[0] is not None and not ops._bf16x2
         if (w3 is not None or use_hp) and ops.conv3x3_bf3_supported(d):
             if use_hp:
-                return self._cv_hp(d, src, hp[0], hp[1], out, **kw)
+                return self._cv_hp(d, src, hp[0], hp[1], out, publish=publish, **kw)
             return ops.conv3x3_bf3(d, src, w3, out, **kw)
         return ops.conv_igemm(d, src, None, w32, out, **kw)
 
@@ -521,11 +544,11 @@ class Engine:
         if _HP:
             self.amax.published(t, self.amax.out_slot(t))
 
-    def _cv_hp(self, d, src, wh, wslot, out, src1=None, **kw):
+    def _cv_hp(self, d, src, wh, wslot, out, src1=None, publish=True, **kw):
         book = self.amax
         sa = book.get(src)
         sa1 = book.get(src1) if (src1 is not None and d.C1) else None
-        so = None if (d.epi & L.EPI_ACCUM) else book.out_slot(out)        # an accumulated tensor is never a tile-conv operand
+        so = None if ((d.epi & L.EPI_ACCUM) or not publish) else book.out_slot(out)        # an accumulated tensor is never a tile-conv operand
         ops.conv3x3_hp(d, src, wh, out, sa, wslot, amax_out=so, src1=src1, amax_src1=sa1, **kw)
         if so is not None:
             book.published(out, so)
@@ -650,7 +673,7 @@ class Engine:
         if up2 and c.up2 is not None and self._phase_ok(H // 2, W // 2):
             if C1:      # skip half at full resolution (raw partial sums), then the four phases of the upsampled half on top
                 d = ops.make_desc(N, H, W, H, W, C1, 0, c.Cout, 3, 1, 1, L.GATHER_FWD_REFLECT)
-                self._cv(d, x1, c.wsk, c.wsk3, out, hp=(c.hp_sk, c.wslot))
+                self._cv(d, x1, c.wsk, c.wsk3, out, hp=(c.hp_sk, c.wslot), publish=False)   # raw partial sums: not the tensor's amax
             if c.hp_ph is not None:
                 so = self.amax.out_slot(out)
                 ops.conv_up2_phase_fwd_hp(x0, c.hp_ph, c.b.data, out, self.amax.get(x0), c.wslot, amax_out=so, act=L.ACT_ELU,

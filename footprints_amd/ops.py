@@ -14,6 +14,18 @@ from . import _lib
 from ._lib import ConvDesc
 
 _workspaces = {}
+# allocation generation: bumped whenever a buffer that kernels address by raw pointer is (re)allocated -- the activation arena
+# (Engine.buf), a workspace below, the flat parameter / gradient buffers, the pack tables.  A recorded launch plan freezes raw
+# pointers; TrainStep compares the generation it recorded at with the current one and drops its plans on a mismatch.
+_alloc_gen = [0]
+
+
+def alloc_generation():
+    return _alloc_gen[0]
+
+
+def bump_alloc_generation():
+    _alloc_gen[0] += 1
 _NO_SPLITK = bool(int(__import__("os").environ.get("FP_NO_SPLITK", "0")))   # debugging aid: never split small grids along K
 
 
@@ -100,6 +112,7 @@ def workspace(nbytes, device, tag="main"):
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         _workspaces[key] = ws
+        bump_alloc_generation()
     return ws
 
 

@@ -11,7 +11,6 @@ The reference quirk of thresholding the *logit* at 0.5 for the visualisation mas
 kept.  `--no_cuda` is accepted for CLI compatibility but raises: this package has no CPU compute path.
 """
 import argparse
-import glob
 import os
 
 import numpy as np
@@ -92,30 +91,36 @@ class InferenceManager:
         vis = rgb * (1 - m) + cmap * m
         return (vis * 255).astype(np.uint8)
 
-    def predict_for_folder(self, folder_path):
-        for path in glob.glob(os.path.join(folder_path, "*")):
-            if os.path.splitext(path)[1].lower() in IMAGE_EXTENSIONS:
-                self.predict_for_single_image(path)
+    def _image_files(self, folder):
+        """image files directly inside `folder` (same extension filter as predict_simple.py:21-25), in sorted order"""
+        return [os.path.join(folder, name) for name in sorted(os.listdir(folder))
+                if os.path.splitext(name)[1].lower() in IMAGE_EXTENSIONS]
 
     def predict(self, image_path):
-        if os.path.isfile(image_path):
-            self.predict_for_single_image(image_path)
-        elif os.path.isdir(image_path):
-            self.predict_for_folder(image_path)
+        """--image may name one file or a folder of images (predict_simple.py:94-110); returns the number of images written"""
+        if os.path.isdir(image_path):
+            targets = self._image_files(image_path)
+        elif os.path.isfile(image_path):
+            targets = [image_path]
         else:
-            raise Exception("Can not find args.image: {}".format(image_path))
+            raise FileNotFoundError("--image: no such file or folder: %r" % (image_path,))
+        for path in targets:
+            self.predict_for_single_image(path)
+        return len(targets)
 
 
 def parse_args(argv=None):
-    parser = argparse.ArgumentParser(description="Simple prediction from a footprints model.")
-    parser.add_argument("--image", type=str, help="path to a test image or folder of images", required=True)
-    parser.add_argument("--model", type=str, help="name of a pretrained model to use", choices=["kitti", "matterport", "handheld"])
-    parser.add_argument("--no_cuda", help="if set, disables CUDA", action="store_true")
-    parser.add_argument("--no_save_vis", help="if set, disables visualisation saveing", action="store_true")
-    parser.add_argument("--save_dir", type=str, help="where to save npy and visualisations to", default="predictions")
-    parser.add_argument("--weights", type=str, default=None,
-                        help="folder holding model.pth (default: %s/<model>; this build cannot download)" % MODEL_DIR)
-    return parser.parse_args(argv)
+    """the reference's flag names and defaults (predict_simple.py:113-131) -- they are the CLI contract -- plus --weights"""
+    ap = argparse.ArgumentParser(prog="footprints_amd.predict_simple",
+                                 description="Footprints prediction for one image or a folder of images on the HIP engine.")
+    ap.add_argument("--image", required=True, type=str, help="image file, or a folder whose image files are all predicted")
+    ap.add_argument("--model", type=str, choices=sorted(MODEL_HEIGHT_WIDTH), help="which released model: fixes the input resolution")
+    ap.add_argument("--no_cuda", action="store_true", help="accepted for compatibility; raises (no CPU compute path here)")
+    ap.add_argument("--no_save_vis", action="store_true", help="write only the .npy predictions, no .jpg overlays")
+    ap.add_argument("--save_dir", type=str, default="predictions", help="output root (outputs/ and visualisations/ below it)")
+    ap.add_argument("--weights", type=str, default=None,
+                    help="folder holding model.pth (default: %s/<model>; this build cannot download)" % MODEL_DIR)
+    return ap.parse_args(argv)
 
 
 def main(argv=None):

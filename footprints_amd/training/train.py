@@ -42,6 +42,7 @@ class TrainStep:
         self.use_plan = (_PLAN if plan is None else bool(plan)) and not self.use_graph
         self._plans = {}            # (input pointers, shapes) -> (plan handle, stage marks, node index where Adam starts, node count)
         self._plan_shape = None
+        self._plan_gen = None       # ops.alloc_generation() the plans were recorded at
         self._graph = None
         self._eager_steps = 0
         self._static = None
@@ -96,6 +97,16 @@ class TrainStep:
         if shape != self._plan_shape:                     # new batch shape: the arena / outputs are re-allocated -> every plan is stale
             self._drop_plans()
             self._plan_shape, self._eager_steps = shape, 0
+        if self._plans and self._plan_gen != ops.alloc_generation():
+            # something a plan addresses by raw pointer was re-allocated since it was recorded (a validation forward on a larger
+            # batch grew the arena or a workspace, the parameters were re-flattened, a pack table was rebuilt): replaying would
+            # read and write freed memory.  Start over: two eager steps, then record again.
+            self._drop_plans()
+            self._eager_steps = 0
+        # a plan bakes the pointers the kernels read: only inputs the engine consumes in place qualify (a non-contiguous or
+        # non-fp32 tensor is converted into a temporary whose address dies with the step) -- those batches stay eager
+        if not all(batch[k].is_contiguous() and batch[k].dtype == torch.float32 for k in ("image",) + TARGET_KEYS):
+            return self._eager(batch, None)
         if self._eager_steps < 2:                         # warm-up: arena, workspaces, packing tables reach their final addresses
             self._eager_steps += 1
             return self._eager(batch, None)
@@ -104,7 +115,14 @@ class TrainStep:
         if rec is None:
             if len(self._plans) >= 8:                     # inputs that never repeat (no static / double-buffered batches): stay eager
                 return self._eager(batch, None)
-            rec = self._plans[key] = self._record_plan(batch, lib, _lib)
+            gen0 = ops.alloc_generation()
+            rec = self._record_plan(batch, lib, _lib)
+            if ops.alloc_generation() != gen0:            # the recording step itself still allocated: its plan holds dead addresses
+                _lib.load().fp_plan_destroy(rec[0])
+                self._drop_plans()
+                return self.losses
+            self._plans[key] = rec
+            self._plan_gen = gen0
             return self.losses
         plan, marks, adam_at, n = rec
         self._hyper.copy_(self.optimiser.next_hyper(), non_blocking=True)

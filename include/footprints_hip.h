@@ -396,6 +396,31 @@ int fp_nchw_to_nhwc(const float* x, float* y, int32_t N, int32_t C, int32_t H, i
 int fp_nhwc_to_nchw(const float* x, float* y, int32_t N, int32_t C, int32_t H, int32_t W, fp_stream_t stream);
 int fp_fill(float* x, int64_t n, float value, fp_stream_t stream);
 
+/* ---- data-parallel gradient exchange: RCCL over xGMI (the reference is single-GPU, README.md:128,136) -- */
+/* One process per GPU.  Rank 0 obtains a unique id (fp_comm_unique_id_bytes() bytes, ncclUniqueId) and hands it to every rank by
+ * any host transport; every rank then calls fp_comm_init on its own device (collective: returns when all `world` ranks called it).
+ * fp_comm_allreduce_async sums `count` floats in place across the ranks, asynchronously on `stream` -- the caller orders that
+ * stream behind the kernels that write the buffer (fp_event_record / fp_event_wait) -- and, while a launch plan records, is also
+ * appended to the plan (fp_plan_replay re-issues it).  fp_comm_wait makes `consumer` wait for everything queued on `comm_stream`
+ * so far.  RCCL is resolved at run time (dlopen); a box without librccl.so gets FP_EINVAL from these calls and nothing else of
+ * the library is affected.  Errors: -100 - ncclResult_t. */
+int32_t fp_comm_unique_id_bytes(void);
+int fp_comm_unique_id(void* id_out, int32_t cap);
+int fp_comm_init(const void* id_bytes, int32_t rank, int32_t world, void** comm_out);
+int32_t fp_comm_version(void); /* ncclGetVersion, or -1 */
+int fp_comm_allreduce_async(void* comm, float* buf, int64_t count, fp_stream_t stream);
+int fp_comm_broadcast(void* comm, float* buf, int64_t count, int32_t root, fp_stream_t stream);
+int fp_comm_wait(void* comm, fp_stream_t comm_stream, fp_stream_t consumer);
+int fp_comm_destroy(void* comm);
+
+/* ---- per-kernel timing: HIP events on the launch stream around every kernel launch of the library (bench.py roofline leg) ------ */
+/* fp_ktime_begin starts collecting (eager launches and plan replays alike); fp_ktime_end stops, synchronises the device and
+ * returns the number of distinct kernel symbols seen; fp_ktime_row(i) gives a symbol's demangled name, launch count and summed
+ * event-to-event milliseconds -- the per-kernel quantity of `rocprofv3 --kernel-trace --stats`.  Single host thread. */
+int fp_ktime_begin(void);
+int32_t fp_ktime_end(void);
+int fp_ktime_row(int32_t i, char* name, int32_t name_cap, int64_t* launches, double* total_ms);
+
 int fp_version(void);
 const char* fp_last_error_string(void);
 
