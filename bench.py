@@ -1,8 +1,15 @@
 """bench.py -- headline benchmark of BASELINE.json: training images/sec at 192x640 bs=12 on 1..8 MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W                                (N > 1: spawns its N ranks itself, see below)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W                                   (N > 1, one rank per GPU, RCCL)
+
+Started plainly with --gpus N > 1 (no WORLD_SIZE in the environment) it re-executes itself through torch.distributed.run with
+N ranks on 127.0.0.1 and a free port, passes the ranks' output through and exits with their status: rank 0 still prints the ONE
+JSON line.  The ranks rendezvous over a "cpu:gloo,cuda:nccl" group (host plumbing: unique-id exchange, barriers, the max over
+ranks of the timed region); the gradient buckets travel over RCCL through this library's own fp_comm_* entry points
+(footprints_amd/parallel.py).  On a box with fewer GPUs than ranks the ranks share the GPUs and exchange over gloo (RCCL refuses two
+ranks per device): a functional dry run of the launch path, flagged "shared_gpu" in the line, never a performance number.
 
 A "step" = one full training step of the hot path on one per-GPU batch of 12 synthetic 192x640 images:
 forward + fused loss + backward + (bucketed gradient all-reduce when N > 1) + fused Adam, all inputs resident
@@ -27,12 +34,17 @@ Extra objects in the line:
                 weight gradients) timed with HIP events, as achieved_hbm = algorithmic GB / t against 8 TB/s and achieved_mfma =
                 GFLOP / t against the fp32 MFMA peak and the bf16x6 roof (the convolutions are MFMA-bound: F/B 72-755 vs a ridge of ~20).
   step_ms       median / p10 / p90 of the GPU-side step durations inside the timed region.
-  cpu_baseline  the CPU oracle (a restatement of the reference's PyTorch CPU path, kind "port") timed on this box's host cores on
-                ONE full train step of the same workload at the same batch size (rank 0, N = 1 only).
+  cpu_baseline  the CPU oracle (a restatement of the reference's PyTorch CPU path, kind "port") timed on this box's host cores:
+                1 warm-up + 3 timed full train steps of the same workload at the same batch size, plus the eval-mode forward in
+                ms per image (rank 0, N = 1 only).
+  exact_split   the same training step with FP_HP=0 (exactly split bf16x3 operands: >= 24 significant bits in every product
+                sum), timed in a child process outside the timed region: the strictly-fp32-or-better number beside `value`.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -230,6 +242,15 @@ GROUPS = {
     "conv_up2_phase_wgrad": dict(kernel="wgrad_up2_phase_kernel", bf16x3=False),
     "conv_wgrad": dict(kernel="wgrad_kernel / wgrad3x3_tile_kernel (fp32 MFMA: stem, stride 2, 1x1, shapes the bf16x3 kernel rejects)", bf16x3=False),
 }
+# main kernel symbol(s) of each entry point (the name before the template arguments, as fp_ktime_row / rocprofv3 print it)
+GROUP_SYMBOL = {
+    "conv3x3_hp": ("conv3x3_tile_bf3_kernel",), "conv3x3_bf3": ("conv3x3_tile_bf3_kernel",),
+    "conv_wgrad_hp": ("wgrad3x3_bf3_v3_kernel", "wgrad3x3_bf3_kernel"), "conv_wgrad_bf3": ("wgrad3x3_bf3_v3_kernel", "wgrad3x3_bf3_kernel"),
+    "conv_up2_phase_fwd_hp": ("up2_phase_fwd_bf3_kernel",), "conv_up2_phase_fwd_bf3": ("up2_phase_fwd_bf3_kernel",),
+    "conv_up2_phase_dgrad_hp": ("up2_phase_dgrad_bf3_kernel",), "conv_up2_phase_dgrad_bf3": ("up2_phase_dgrad_bf3_kernel",),
+    "conv_up2_phase_wgrad_hp": ("wgrad_up2_phase_bf3_kernel",), "conv_up2_phase_wgrad_bf3": ("wgrad_up2_phase_bf3_kernel",),
+    "conv_igemm": ("igemm_kernel", "stem_tile_kernel"), "conv_wgrad": ("wgrad_kernel", "wgrad3x3_tile_kernel", "stem_wgrad_tile_kernel"),
+}
 CONV_OPS = {
     "conv_igemm": dict(group="conv_igemm", dense=conv_flops, exec=conv_flops, bytes=conv_bytes),
     "conv3x3_bf3": dict(group="conv3x3_bf3", dense=conv_flops, exec=conv_flops, bytes=conv_bytes),
@@ -305,31 +326,89 @@ def _pick_threads():
 
 
 def cpu_baseline():
-    """ONE full train step (fwd + loss + bwd + Adam) of the CPU oracle on the SAME workload and batch size as the GPU line
-    (SURVEY.md section 8d / BASELINE.md section 4), after a batch-1 warm-up step; plus the shipped trainer's own setting
-    (one thread, training/train.py:12-14) on one batch-1 step."""
+    """BASELINE.md section 4 / SURVEY.md section 8d: 1 warm-up + 3 timed full train steps (fwd + loss + bwd + Adam, the span of
+    training/train.py:149-159) of the CPU oracle on the SAME workload and batch size as the GPU line, then the eval-mode forward in
+    ms per image; plus the shipped trainer's own setting (one thread, training/train.py:12-14) on one batch-1 step."""
     from oracle import restatement as R
     cores, eff = _pick_threads()
     torch.set_num_threads(cores)
     P, Bf = R.make_state(tag="bench")
     tr = R.OracleTrainer(P, Bf)
-    tr.step(R.make_batch(1, H, W, tag="bench.warm"))
     batch = R.make_batch(B, H, W, tag="bench.cpu")
-    t0 = time.time()
-    tr.step(batch)
-    dt = time.time() - t0
+    tr.step(batch)                                   # warm-up at the timed shape (oneDNN primitive caches, allocator)
+    times = []
+    for _ in range(3):
+        t0 = time.time()
+        tr.step(batch)
+        times.append(time.time() - t0)
+    dt = sum(times) / len(times)
+    with torch.no_grad():
+        R.footprint_network(batch["image"], tr.P, tr.B, training=False)
+        f0 = time.time()
+        R.footprint_network(batch["image"], tr.P, tr.B, training=False)
+        fwd_ms_img = (time.time() - f0) / B * 1e3
     torch.set_num_threads(1)
     t1 = time.time()
     tr.step(R.make_batch(1, H, W, tag="bench.warm"))
     dt1 = time.time() - t1
     torch.set_num_threads(cores)
     return {"value": round(B / dt, 4), "unit": "img/s", "cores": cores, "kind": "port",
+            "eval_fwd_ms_per_img": round(fwd_ms_img, 2),
             "single_thread": {"value": round(1.0 / dt1, 4), "unit": "img/s", "cores": 1,
                               "sample": "1 full train step at batch 1 with torch.set_num_threads(1), the reference trainer's own setting"},
-            "sample": "1 timed full train step (fwd+loss+bwd+Adam) of the CPU oracle at %dx%d, batch %d (the GPU line's workload and batch "
-                      "size), torch.set_num_threads(%d) = fastest of {8,16,32,64,%d} on this host (%d effective cores), after 1 batch-1 "
-                      "warm-up step" % (H, W, B, cores, eff, eff),
-            "s_per_step": round(dt, 3), "host_cores": eff}
+            "sample": "mean of 3 timed full train steps (fwd+loss+bwd+Adam) of the CPU oracle at %dx%d, batch %d (the GPU line's workload and "
+                      "batch size) after 1 warm-up step at the same shape, then 1 timed eval-mode forward of the same batch; "
+                      "torch.set_num_threads(%d) = fastest of {8,16,32,64,%d} on this host (%d effective cores)" % (H, W, B, cores, eff, eff),
+            "s_per_step": round(dt, 3), "s_per_step_each": [round(t, 3) for t in times], "host_cores": eff}
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` started plainly: run the N ranks through torch.distributed.run on this node and pass their output
+    through (rank 0 prints the ONE JSON line); the exit status is theirs."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def exact_split_leg(workload, steps=10, warmup=4):
+    """child process with FP_HP=0 (the operand format is fixed when footprints_amd.engine is imported): `steps` training steps of
+    the same workload with exactly split bf16x3 operands -> img/s, or None"""
+    env = dict(os.environ)
+    env["FP_HP"] = "0"
+    try:
+        p = subprocess.run([sys.executable, os.path.abspath(__file__), "--leg", "train-only", "--workload", workload, "--steps", str(steps),
+                            "--warmup", str(warmup)], env=env, capture_output=True, text=True, timeout=600)
+        line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        return json.loads(line[-1]) if line else {"error": (p.stderr or "")[-300:]}
+    except Exception as e:      # the headline must not die with a side leg
+        return {"error": repr(e)}
+
+
+def kernel_table(lib, steps):
+    """rows of the fp_ktime_* collection: per kernel symbol launches / step, total ms / step, average microseconds"""
+    import ctypes
+    n = lib.fp_ktime_end()
+    rows = []
+    name = ctypes.create_string_buffer(2048)
+    cnt, ms = ctypes.c_int64(), ctypes.c_double()
+    for i in range(max(n, 0)):
+        if lib.fp_ktime_row(i, name, 2048, ctypes.byref(cnt), ctypes.byref(ms)) == 0:
+            pretty = name.value.decode().replace("(anonymous namespace)::", "")
+            pretty = pretty[5:] if pretty.startswith("void ") else pretty
+            rows.append({"kernel": pretty, "launches_per_step": round(cnt.value / steps, 2), "ms_per_step": round(ms.value / steps, 4),
+                         "avg_us": round(ms.value / max(cnt.value, 1) * 1e3, 2)})
+    return sorted(rows, key=lambda r: -r["ms_per_step"])
 
 
 def main():
@@ -346,42 +425,67 @@ def main():
                     "bucketed all-reduces in a world of one rank) -- a dry run of the code path the N > 1 launches take")
     ap.add_argument("--dump-kernels", type=str, default=None, help="write the per-launch-shape timing tables (JSON) here")
     ap.add_argument("--no-loader", action="store_true", help="skip the extra leg that feeds the step from the device-side data path")
+    ap.add_argument("--no-exact-split", action="store_true", help="skip the FP_HP=0 (exactly split bf16x3 operands) leg")
+    ap.add_argument("--leg", choices=["train-only"], default=None, help="internal: time the training step only and print a small "
+                    "JSON object (what the exact-split leg runs in its child process)")
+    ap.add_argument("--dry-run-dist", action="store_true", help="N > 1: spawn / rendezvous / one collective / ONE JSON line, no GPU "
+                    "work (what the CPU test of the launch path runs)")
     args = ap.parse_args()
     wl = WORKLOADS[args.workload]
     B, H, W = wl["B"], wl["H"], wl["W"]
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:          # started plainly: become the launcher of N ranks
+        raise SystemExit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
-    torch.cuda.set_device(local_rank)
+        raise SystemExit("bench.py --gpus %d: WORLD_SIZE is %d (torch.distributed.run --nproc-per-node must equal --gpus)" % (args.gpus, world))
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    shared_gpu = world > 1 and have < world                       # a dry run of the launch path on a smaller box (or none)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    if os.environ.get("NCCL_DEBUG", "").upper() in ("", "VERSION"):
+        os.environ["NCCL_DEBUG"] = "WARN"                          # RCCL's version banner goes to stdout, where the ONE JSON line belongs
+    if world > 1:
+        # host-side group: rendezvous, unique-id exchange, barriers, max over ranks.  "cuda:nccl" is only instantiated if the
+        # library's own RCCL transport (fp_comm_*) is unavailable and the reducer falls back to framework collectives.
+        dist.init_process_group("gloo" if shared_gpu else "cpu:gloo,cuda:nccl", rank=rank, world_size=world)
+    if args.dry_run_dist:
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t)
+            dist.barrier()
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_sum": float(t.item()), "gpus_visible": have, "shared_gpu": shared_gpu,
+                              "backend": str(dist.get_backend()) if world > 1 else None}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    if have == 0:
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path (use --dry-run-dist to exercise the launch path alone)")
+    torch.cuda.set_device(local_rank % have)
     distributed = world > 1 or args.force_dist
-    if distributed:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        if args.force_dist:
-            os.environ["FP_DP_FORCE"] = "1"                        # read when footprints_amd.parallel is imported (below)
-        if os.environ.get("NCCL_DEBUG", "").upper() in ("", "VERSION"):
-            os.environ["NCCL_DEBUG"] = "WARN"                      # RCCL's version banner goes to stdout, where the ONE JSON line belongs
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    if args.force_dist:
+        os.environ["FP_DP_FORCE"] = "1"                            # read when footprints_amd.parallel is imported (below)
 
-    from footprints_amd import ops
+    from footprints_amd import _lib, ops
     from footprints_amd.model_manager import ModelManager
-    from footprints_amd.parallel import broadcast_state
+    from footprints_amd.parallel import broadcast_state, destroy_communicators
     from footprints_amd.training.train import SEED, TrainStep, synthetic_batch
 
     torch.manual_seed(SEED)
     mm = ModelManager(use_cuda=True, learning_rate=1e-4)          # random-init weights (no checkpoints offline)
-    if distributed:
+    if world > 1:
         broadcast_state(mm.model)
     step = TrainStep(mm.model, mm.optimiser, distributed=distributed)
     batch = synthetic_batch(B, H, W, "cuda", seed=SEED + rank)     # per-rank shard, resident in HBM
 
     def barrier():
-        if distributed:
-            dist.barrier()
         torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step(batch)
@@ -395,15 +499,21 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
-    t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+    t = torch.tensor([dt], dtype=torch.float64)
     if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)                   # host tensor: the gloo side of the group
     dt = float(t.item())
     final_loss = float(step.losses[20])
+    if args.leg == "train-only":
+        if rank == 0:
+            print(json.dumps({"img_per_s": round(world * B * args.steps / dt, 2), "ms_per_step": round(dt / args.steps * 1e3, 3),
+                              "steps": args.steps, "warmup": args.warmup, "final_loss": round(final_loss, 5),
+                              "FP_HP": os.environ.get("FP_HP", "1")}), flush=True)
+        return
 
     # kernel-exclusive pass (outside the timed region): same steps on ONE stream, HIP events around every convolution launch
     # (every rank runs it when data-parallel: the steps contain the bucket all-reduces; rank 0 reports)
-    xtimer, xsteps = None, 3
+    xtimer, xsteps, ktable, ktable_conc = None, 3, None, None
     if not args.no_kernel_events:
         was, was_plan = step.eng.concurrent, step.use_plan
         step.eng.concurrent, step.use_plan = False, False            # eager, one stream: the instrumented wrappers see every launch
@@ -411,12 +521,22 @@ def main():
         xinst = Instrument(ops, CONV_OPS)
         xinst.install()
         torch.cuda.synchronize()
+        lib = _lib.load()
+        lib.fp_ktime_begin()                                         # HIP events on the launch stream around EVERY kernel launch
         for _ in range(xsteps):
             step(batch)
-        torch.cuda.synchronize()
+        ktable = kernel_table(lib, xsteps)                           # synchronises; per kernel symbol, like rocprofv3 --kernel-trace --stats
         xinst.remove()
         xtimer = xinst.timer
         step.eng.concurrent, step.use_plan = was, was_plan
+        # the default schedule (five streams, recorded plan) through the same events: what each kernel takes when it shares the chip
+        for _ in range(3):
+            step(batch)
+        torch.cuda.synchronize()
+        lib.fp_ktime_begin()
+        for _ in range(xsteps):
+            step(batch)
+        ktable_conc = kernel_table(lib, xsteps)
 
     # decoder backward alone: both decoders, from d loss / d outputs to d loss / d features plus all decoder
     # weight gradients, HIP events around repeated runs on one saved forward (all five streams, joined inside the bracket)
@@ -516,7 +636,9 @@ def main():
         ms_per_step = dt / args.steps * 1e3
         out = {"metric": "training images/sec at %dx%d bs=%d" % (H, W, B), "value": round(world * B * args.steps / dt, 2), "unit": "img/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": ("f32 tensors; fp16x2-split operands (22-bit), fp32 accumulate" if HP_ON else
+                         "f32 tensors; bf16x3-split operands (exact 24-bit), fp32 accumulate"), "data": "synthetic",
                "arithmetic": ("fp32 tensors and accumulation; 3x3 stride-1 convs (fwd, dgrad, wgrad) multiply operands split into scaled fp16 "
                               "pairs (x * 2^k = h + m, per-tensor k from the tensor's largest magnitude, 22 significant bits, three fp16 MFMA "
                               "products hh + hm + mh, fp32 accumulate: measured error vs float64 equal to the exact bf16x3 split's and to fp32 "
@@ -543,31 +665,72 @@ def main():
                                    "fwd_algorithmic_gflop": round(gf_fwd, 1), "fwd_tflops": round(gf_fwd / (fwd_ms_img * B), 2)}
         if xtimer is not None:
             groups = xtimer.groups(xsteps)
+            # kernel-only durations (fp_ktime_*: events around the kernel launch itself, per kernel symbol) next to each entry
+            # point's bracket, which also contains its helper launches (split-K / partial-sum reduces, amax reductions)
+            for g in groups:
+                sym = GROUP_SYMBOL.get(g["entry_point"])
+                rows = [r for r in (ktable or []) if sym and r["kernel"].split("<")[0].split("(")[0] in sym]
+                if rows:
+                    k_ms = sum(r["ms_per_step"] for r in rows)
+                    k_n = sum(r["launches_per_step"] for r in rows)
+                    g["kernel_symbol"] = "/".join(sym)
+                    g["kernel_only_ms_per_step"] = round(k_ms, 3)
+                    g["kernel_launches_per_step"] = round(k_n, 1)
+                    g["avg_kernel_us"] = round(k_ms / max(k_n, 1e-9) * 1e3, 2)
+                    ex_gflop_step = g["executed_mfma_gflop_per_launch"] * g["launches_per_step"]
+                    g["achieved_kernel_only"] = round(ex_gflop_step / k_ms, 1) if k_ms > 0 else 0.0      # GFLOP / ms = TFLOP/s
+                    g["frac_kernel_only"] = round(g["achieved_kernel_only"] / g["peak"], 4)
             dom = groups[0]
             tr = load_traffic(args.workload, dom["entry_point"])
-            out["roofline"] = {"bound": "mfma", "achieved": dom["achieved"], "peak": dom["peak"], "unit": "TFLOP/s", "frac": dom["frac"],
+            ach = dom.get("achieved_kernel_only", dom["achieved"])
+            out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": dom["peak"], "unit": "TFLOP/s", "frac": round(ach / dom["peak"], 4),
                                "traffic": tr,
                                "kernel": dom["kernel"], "entry_point": "fp_" + dom["entry_point"], "mfma": dom["mfma"],
                                "launches_per_step": dom["launches_per_step"], "avg_launch_us": dom["avg_launch_us"],
+                               "avg_kernel_us": dom.get("avg_kernel_us"), "kernel_launches_per_step": dom.get("kernel_launches_per_step"),
+                               "kernel_only_ms_per_step": dom.get("kernel_only_ms_per_step"),
+                               "entry_point_bracket": {"achieved": dom["achieved"], "frac": dom["frac"],
+                                                       "note": "the same FLOPs over the entry point's event bracket, which also contains its helper "
+                                                               "launches (split-K reduce, amax reduction)"},
                                "exclusive_ms_per_step": dom["exclusive_ms_per_step"],
                                "executed_mfma_gflop_per_launch": dom["executed_mfma_gflop_per_launch"],
                                "fp32_equiv_tflops": dom["fp32_equiv_tflops"], "algorithmic_mb_per_launch": dom["algorithmic_mb_per_launch"],
-                               "how": "dominant = largest exclusive time per step among the convolution entry points; HIP events on the launch "
-                                      "stream around every launch of %d extra steps with concurrency off (one stream), outside the timed region; "
-                                      "achieved = executed MFMA FLOPs (3 fp16 products per multiply-add for scaled fp16 pairs, 6 bf16 products "
-                                      "for the exact bf16 split) / duration" % xsteps,
+                               "how": "dominant = largest exclusive time per step among the convolution entry points; %d extra steps with "
+                                      "concurrency off (one stream) outside the timed region; achieved = executed MFMA FLOPs of the entry point's "
+                                      "launches (3 fp16 products per multiply-add for scaled fp16 pairs, 6 bf16 products for the exact bf16 "
+                                      "split) / summed duration of its main kernel's launches, each measured with HIP events recorded on the "
+                                      "launch stream right around the kernel launch (fp_ktime_*: the per-kernel figure of rocprofv3 "
+                                      "--kernel-trace --stats, see `kernels`)" % xsteps,
                                "reading": "frac prices EXECUTED MFMA FLOPs against the nominal dense peak, so it falls whenever products are removed "
                                           "from the split (exact bf16x3: 6 per multiply-add, frac 0.33 at 136 fp32-equivalent TFLOP/s; scaled fp16 pairs: "
                                           "3, frac 0.20 at 163): compare fp32_equiv_tflops across operand formats; the chip sustains ~1.7 of its 2.4 GHz "
                                           "under these kernels (profiles/round2_notes.md), i.e. 0.7 of the nominal peak is attainable",
                                "conv_exclusive_ms_per_step": round(sum(g["exclusive_ms_per_step"] for g in groups), 3),
                                "groups": groups}
+            out["kernels"] = {"serial": (ktable or [])[:24], "concurrent": (ktable_conc or [])[:24],
+                              "note": "per kernel symbol, from HIP events around every kernel launch of %d steps (fp_ktime_*): `serial` = one stream, "
+                                      "eager launches (exclusive durations); `concurrent` = the default five-stream schedule replayed from the "
+                                      "recorded plan (a launch shares the chip with its neighbours)" % xsteps}
         if args.dump_kernels and xtimer is not None:
             with open(args.dump_kernels, "w") as fh:
                 json.dump({"groups": xtimer.groups(xsteps), "shapes": xtimer.table()}, fh, indent=1)
+        if shared_gpu:
+            out["shared_gpu"] = {"gpus_visible": have, "note": "fewer GPUs than ranks: the ranks share them and exchange gradients over gloo -- a "
+                                                               "functional dry run of the launch path, NOT a performance number"}
+        if step.reducer is not None:
+            out["config"]["gradient_exchange"] = {"transport": step.reducer.transport, "buckets": len(step.reducer.buckets),
+                                                  "overlap_with_backward": bool(step.reducer.overlap),
+                                                  "in_launch_plan": bool(step.reducer.plan_recordable and step.use_plan)}
+        if world == 1 and not args.force_dist and not args.no_exact_split:
+            del step, mm                                               # free this process's arena before the child builds its own
+            torch.cuda.empty_cache()
+            out["exact_split"] = {"what": "the same training step with FP_HP=0: 3x3 stride-1 convs multiply EXACTLY split operands (x = h + m + l in "
+                                          "bf16, six MFMA products: every operand keeps its 24 significant bits), timed in a child process",
+                                  "result": exact_split_leg(args.workload)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-    if distributed:
+    destroy_communicators()
+    if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

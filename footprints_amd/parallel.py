@@ -61,10 +61,108 @@ def bucket_ranges(names, offsets, total, max_elems=8 << 20):
     return out
 
 
+# Transport of the bucket collectives on GPUs: "rccl" = this library's own fp_comm_* entry points (csrc/comm.cpp: ncclAllReduce on
+# a stream the engine names, recordable into a launch plan, no framework watchdog / side streams), "torch" = torch.distributed
+# collectives on the group (gloo in the CPU tests and when two test ranks share one GPU; "nccl" as the fallback when fp_comm_init
+# fails on some rank).  FP_DP_TRANSPORT=torch|rccl overrides the choice.
+_TRANSPORT = os.environ.get("FP_DP_TRANSPORT", "")
+# which stream carries the all-reduces: "own" = a dedicated stream; "dwg0" / "dwg1" / "aux" / "wg" = that engine stream (ROCm maps a
+# process's streams onto a handful of hardware queues -- every extra stream that is busy during the backward pass can end up sharing
+# a queue with one of the five the schedule already uses, and streams that share a queue serialise)
+_COMM_STREAM = os.environ.get("FP_DP_COMM_STREAM", "own")
+
+
+class Communicator:
+    """RCCL communicator behind the C ABI (fp_comm_*): one per process, on the current device.  The 128-byte unique id travels from
+    rank 0 over the torch.distributed group (any backend; object broadcast) -- host plumbing only."""
+
+    def __init__(self, group=None):
+        from . import _lib
+        import ctypes as C
+        self._lib, self._C = _lib, C
+        lib = _lib.load()
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        nbytes = lib.fp_comm_unique_id_bytes()
+        ident = [None]
+        if self.rank == 0:
+            raw = C.create_string_buffer(nbytes)
+            _lib.check(lib.fp_comm_unique_id(raw, nbytes), "fp_comm_unique_id")
+            ident = [raw.raw]
+        if self.world > 1:
+            dist.broadcast_object_list(ident, src=0, group=group)
+        handle = C.c_void_p()
+        _lib.check(lib.fp_comm_init(ident[0], self.rank, self.world, C.byref(handle)), "fp_comm_init")
+        self.handle = handle
+
+    def allreduce(self, t, stream):
+        """in-place sum over the ranks, asynchronous on `stream` (a torch stream)"""
+        self._lib.check(self._lib.load().fp_comm_allreduce_async(self.handle, t.data_ptr(), t.numel(), stream.cuda_stream),
+                        "fp_comm_allreduce_async")
+
+    def broadcast(self, t, root, stream):
+        self._lib.check(self._lib.load().fp_comm_broadcast(self.handle, t.data_ptr(), t.numel(), root, stream.cuda_stream),
+                        "fp_comm_broadcast")
+
+    def destroy(self):
+        if self.handle:
+            self._lib.load().fp_comm_destroy(self.handle)
+            self.handle = None
+
+
+_COMMS = {}
+
+
+def get_communicator(group=None, create=True):
+    """the process's fp_comm communicator for `group`, created on first use by ALL ranks together; None when it cannot be used: every
+    rank reports whether its fp_comm_init succeeded and the transport is only chosen if all did (else everyone falls back to
+    torch.distributed collectives on the group)."""
+    key = id(group)
+    if key in _COMMS or not create:
+        return _COMMS.get(key)
+    comm, ok = None, 1
+    try:
+        comm = Communicator(group)
+    except Exception as e:        # librccl missing, bootstrap failure, ...: agree on the fallback below, loudly
+        ok = 0
+        print("footprints_amd.parallel: fp_comm unavailable on rank %s (%s); falling back to torch.distributed collectives"
+              % (dist.get_rank(group) if dist.is_initialized() else 0, e), flush=True)
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        flag = torch.tensor([ok], dtype=torch.int32)
+        if "gloo" not in str(dist.get_backend(group)):
+            flag = flag.cuda()
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        ok = int(flag.item())
+    if not ok and comm is not None:
+        comm.destroy()
+        comm = None
+    _COMMS[key] = comm
+    return comm
+
+
+def destroy_communicators():
+    for c in _COMMS.values():
+        if c is not None:
+            c.destroy()
+    _COMMS.clear()
+
+
+def _pick_transport(flat_grad, group, force):
+    if not flat_grad.is_cuda:
+        return "torch"
+    if _TRANSPORT in ("torch", "rccl"):
+        return _TRANSPORT
+    if not dist.is_initialized():
+        return "rccl" if force else "torch"
+    backend = str(dist.get_backend(group))
+    # a pure-gloo group over CUDA tensors = several test ranks sharing one GPU (RCCL refuses two ranks per device)
+    return "rccl" if "nccl" in backend else "torch"
+
+
 class GradReducer:
     """Bucketed, stream-overlapped all-reduce of a flat gradient buffer."""
 
-    def __init__(self, flat_grad, names, offsets, group=None, max_elems=8 << 20, overlap=None, force=None):
+    def __init__(self, flat_grad, names, offsets, group=None, max_elems=8 << 20, overlap=None, force=None, comm_stream=None):
         self.flat = flat_grad
         self.force = _FORCE if force is None else bool(force)
         # overlap: issue each bucket as soon as its stage is complete (default on CPU/gloo; on GPUs see _OVERLAP above)
@@ -73,7 +171,14 @@ class GradReducer:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.buckets = bucket_ranges(names, offsets, flat_grad.numel(), max_elems)
         self.cuda = flat_grad.is_cuda
-        self.stream = torch.cuda.Stream() if self.cuda else None
+        self.active = self.world > 1 or self.force
+        self.transport = _pick_transport(flat_grad, group, self.force) if self.active else "torch"
+        self.comm = None
+        if self.transport == "rccl":
+            self.comm = get_communicator(group)
+            if self.comm is None:
+                self.transport = "torch"
+        self.stream = (comm_stream if comm_stream is not None else torch.cuda.Stream()) if self.cuda else None
         self._pending = []
         self._done_stage = set()
 
@@ -81,37 +186,54 @@ class GradReducer:
     def grad_scale(self):
         return 1.0 / self.world
 
+    @property
+    def plan_recordable(self):
+        """the collectives go through the library (fp_comm_allreduce_async) and become nodes of a recording launch plan"""
+        return self.transport == "rccl"
+
     def stage_ready(self, stage, streams=None):
         """Called by the backward schedule when every gradient of `stage` has been launched.  streams: every stream that may still be
         writing them (Engine.stage_streams(): the weight gradients run on side streams that the main stream does not wait for); the
         collective is ordered after all of them.  None: the current stream only."""
-        if (self.world == 1 and not self.force) or stage in self._done_stage:
+        if not self.active or stage in self._done_stage:
             return
         self._done_stage.add(stage)
-        if self.cuda:
-            for st in (streams or [torch.cuda.current_stream()]):
-                ev = torch.cuda.Event()
-                ev.record(st)
-                self.stream.wait_event(ev)
-            with torch.cuda.stream(self.stream):
-                for s, lo, hi in self.buckets:
-                    if s == stage:
-                        self._pending.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-        else:
-            for s, lo, hi in self.buckets:
-                if s == stage:
-                    dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
+        mine = [(lo, hi) for s, lo, hi in self.buckets if s == stage]
+        if not self.cuda:
+            for lo, hi in mine:
+                dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
+            return
+        from . import ops
+        if self.transport == "rccl":
+            for st in (streams or [ops.current_stream()]):
+                if st.cuda_stream != self.stream.cuda_stream:
+                    ops.event_wait(self.stream, ops.event_record(st))       # library events: a recording plan sees the edge
+            for lo, hi in mine:
+                self.comm.allreduce(self.flat[lo:hi], self.stream)
+            return
+        for st in (streams or [torch.cuda.current_stream()]):
+            ev = torch.cuda.Event()
+            ev.record(st)
+            self.stream.wait_event(ev)
+        with torch.cuda.stream(self.stream):
+            for lo, hi in mine:
+                self._pending.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
         """Make the compute stream wait for every outstanding bucket (call before the optimiser step)."""
-        if self.world > 1 or self.force:
+        if self.active:
             for s in ("mask_decoder", "depth_decoder", "encoder.layer4", "encoder.layer3", "encoder.layer2", "encoder.layer1",
                       "encoder.layer0"):
                 self.stage_ready(s)          # anything the schedule did not report explicitly (the backward pass has joined its streams by now)
             for w in self._pending:
                 w.wait()
             if self.cuda:
-                torch.cuda.current_stream().wait_stream(self.stream)
+                if self.transport == "rccl":
+                    from . import ops
+                    if ops.current_stream().cuda_stream != self.stream.cuda_stream:
+                        ops.stream_wait_stream(ops.current_stream(), self.stream)
+                else:
+                    torch.cuda.current_stream().wait_stream(self.stream)
         self._pending = []
         self._done_stage = set()
 
@@ -124,11 +246,27 @@ def broadcast_state(model, src=0, group=None):
         return
     eng = getattr(model, "_engine", None)
     done = set()
+    first = next(model.parameters())
+    comm = get_communicator(group) if (first.is_cuda and _pick_transport(first.data, group, False) == "rccl") else None
+
+    def bcast(t):
+        if comm is None:
+            dist.broadcast(t, src=src, group=group)
+        elif t.dtype == torch.float32 and t.is_contiguous() and t.numel():
+            comm.broadcast(t, src, torch.cuda.current_stream())
+        elif "gloo" in str(dist.get_backend(group)):
+            c = t.cpu()            # the few integer buffers (num_batches_tracked): through the host, so that the group's own CUDA
+            dist.broadcast(c, src=src, group=group)      # backend (its communicator, watchdog and streams) is never instantiated
+            t.copy_(c)
+        else:
+            dist.broadcast(t, src=src, group=group)
     if eng is not None and eng.params_alias_flat():
-        dist.broadcast(eng.flat_param, src=src, group=group)
+        bcast(eng.flat_param)
         done = {id(p) for p in eng.live_params}
     for t in list(model.parameters()) + list(model.buffers()):
         if id(t) not in done:
-            dist.broadcast(t.data, src=src, group=group)
+            bcast(t.data)
+    if first.is_cuda:
+        torch.cuda.current_stream().synchronize()
     if eng is not None:
         eng.invalidate()

@@ -54,7 +54,10 @@ class TrainStep:
         self.dpreds = None
         self.reducer = None
         if distributed:
-            self.reducer = GradReducer(self.eng.flat_grad, self.eng.live_names, self.eng.offsets)
+            from ..parallel import _COMM_STREAM
+            eng = self.eng
+            comm_stream = {"aux": eng.aux, "wg": eng.wg, "dwg0": eng.dwg[0], "dwg1": eng.dwg[1]}.get(_COMM_STREAM)
+            self.reducer = GradReducer(eng.flat_grad, eng.live_names, eng.offsets, comm_stream=comm_stream)
             optimiser.grad_scale = self.reducer.grad_scale
 
     def __call__(self, batch):
@@ -128,7 +131,7 @@ class TrainStep:
         self._hyper.copy_(self.optimiser.next_hyper(), non_blocking=True)
         with ops.on_stream(torch.cuda.current_stream()):
             pos = 0
-            if self.reducer is not None:
+            if self.reducer is not None and not self.reducer.plan_recordable:      # framework collectives: replay in pieces around them
                 for mark, stage in marks:
                     _lib.check(lib.fp_plan_replay(plan, pos, mark), "fp_plan_replay")
                     self.reducer.stage_ready(stage, self.eng.stage_streams())

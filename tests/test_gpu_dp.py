@@ -132,14 +132,16 @@ def test_two_ranks_share_weights_and_match_summed_shard_gradients(overlap):
     assert res[0][3][-1] != res[1][3][-1]                                 # different shards => different per-rank losses
 
 
-def _nccl_worker(port, q):
+def _nccl_worker(port, q, transport):
     try:
         import torch.distributed as dist
         os.environ["FP_DP_FORCE"] = "1"                           # issue the bucket collectives although world == 1
+        os.environ["FP_DP_TRANSPORT"] = transport
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
         torch.cuda.set_device(0)
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        if transport == "torch":                                  # framework collectives need the framework's group; fp_comm_* does not
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
         from footprints_amd.model_manager import ModelManager
         from footprints_amd.training.train import TrainStep
         P, Bf = _state("dp")
@@ -152,26 +154,33 @@ def _nccl_worker(port, q):
             if ts.reducer is not None:
                 ts.reducer.overlap = (mode == "overlap")
                 assert ts.reducer.force and ts.reducer.world == 1 and len(ts.reducer.buckets) >= 7
-            losses = [float(ts(batch)[20]) for _ in range(6)]        # 2 eager + 1 recorded + 3 replayed in pieces around the bucket all-reduces
+                assert ts.reducer.transport == transport and ts.reducer.plan_recordable == (transport == "rccl")
+            losses = [float(ts(batch)[20]) for _ in range(6)]        # 2 eager + 1 recorded + 3 replayed (torch: in pieces around the bucket all-reduces;
+                                                                     # rccl: in one piece, the all-reduces are nodes of the plan)
             assert len(ts._plans) == 1
             torch.cuda.synchronize()
             res.append((losses, torch.cat([p.detach().flatten() for p in mm.model.parameters()]).cpu().numpy()))
         q.put(("ok", res))
-        dist.destroy_process_group()
+        from footprints_amd.parallel import destroy_communicators
+        destroy_communicators()
+        if dist.is_initialized():
+            dist.destroy_process_group()
     except Exception as e:
         import traceback
         q.put(("error", traceback.format_exc(), repr(e)))
 
 
-def test_rccl_path_world_of_one_executes_and_is_exact():
-    """The RCCL code path (`init_process_group("nccl")`, GradReducer's bucket all-reduces on the comm stream, event gating, both
-    schedules) executed on the 1-GPU box with a world of one rank: a sum over one rank is the identity, so three steps must be
-    BIT-identical to the non-distributed TrainStep -- a wrong wait / a bucket reduced before its gradients landed would show.  Steps 4-6
-    replay the recorded launch plan in pieces (one per stage mark) with the collectives issued between the pieces."""
+@pytest.mark.parametrize("transport", ["rccl", "torch"])
+def test_rccl_path_world_of_one_executes_and_is_exact(transport):
+    """The RCCL code path executed on the 1-GPU box with a world of one rank, through both transports of GradReducer: "rccl" = the
+    library's own fp_comm_* entry points (ncclCommInitRank / ncclAllReduce through csrc/comm.cpp, the all-reduces recorded into the
+    launch plan), "torch" = torch.distributed collectives on an "nccl" group (the fallback).  Bucket all-reduces on the comm stream,
+    event gating, both schedules: a sum over one rank is the identity, so the steps must be BIT-identical to the non-distributed
+    TrainStep -- a wrong wait / a bucket reduced before its gradients landed would show.  Steps 4-6 replay the recorded launch plan."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    p = ctx.Process(target=_nccl_worker, args=(_free_port(), q))
+    p = ctx.Process(target=_nccl_worker, args=(_free_port(), q, transport))
     p.start()
     try:
         r = q.get(timeout=600)
