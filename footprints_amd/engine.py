@@ -44,6 +44,9 @@ _DS_AUX = bool(int(os.environ.get("FP_DS_AUX", "1")))
 # nearest-x2 phase decomposition of the upsample convs (conv_up2_phase.hip); FP_NO_PHASE=1 keeps the fused-gather path.
 _PHASE = not bool(int(os.environ.get("FP_NO_PHASE", "0")))
 
+# role -> side-stream pool index: aux, encoder weight gradients, mask decoder's / depth decoder's weight gradients (see Engine.__init__)
+_STREAM_LAYOUT = "0,1,2,2"
+
 SCALE_KEYS = ("1/8", "1/4", "1/2", "1/1")
 _ALL_SCALES = frozenset(range(4))
 
@@ -273,9 +276,28 @@ class Engine:
         self.saved = None
         self.debug_hook = None      # tests/debugging: called after every encoder block of the backward schedule
         self.concurrent = _CONCURRENT
-        self.aux = torch.cuda.Stream(device=self.device)    # second decoder
-        self.wg = torch.cuda.Stream(device=self.device)     # encoder weight gradients
-        self.dwg = [torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device)]   # decoder weight gradients
+        # Side streams.  The HIP runtime maps a process's streams onto at most FOUR hardware queues per priority (GPU_MAX_HW_QUEUES;
+        # five or six measured 23 ms per step instead of 13.9); a fifth stream silently shares the queue of an earlier one, every
+        # packet carries the barrier bit, so two streams on one hardware queue execute strictly in order -- and which pair shares
+        # used to be decided by the order in which the streams first ran a kernel (with four roles + the main stream the two
+        # decoders' weight-gradient streams ended up on one queue; once an RCCL communicator had created its own streams first, other
+        # pairs did: that was round 2's unexplained 2.7 ms "data-parallel tax", profiles/round3_notes.md).  So the engine owns the
+        # decision: the four roles are mapped onto THREE side streams (main + 3 = the four queues), and every stream runs one tiny
+        # kernel right here, so its hardware queue is created and owned before any other library of the process creates streams.
+        # FP_STREAM_LAYOUT = "aux,wg,dwg0,dwg1" as indices into the side-stream pool.
+        lay = [int(v) for v in os.environ.get("FP_STREAM_LAYOUT", _STREAM_LAYOUT).split(",")]
+        if len(lay) != 4 or min(lay) < 0:
+            raise ValueError("FP_STREAM_LAYOUT: four pool indices expected (aux, wg, dwg0, dwg1)")
+        pool = [torch.cuda.Stream(device=self.device) for _ in range(max(lay) + 1)]
+        self.side_streams = pool
+        self.aux = pool[lay[0]]     # second decoder, downsample branch of the stride-2 blocks
+        self.wg = pool[lay[1]]      # encoder weight gradients, side part of the weight repack
+        self.dwg = [pool[lay[2]], pool[lay[3]]]   # decoder weight gradients
+        tiny = torch.zeros(64, device=self.device)
+        for st in pool:
+            with ops.on_stream(st):
+                ops.fill(tiny, 0.0)
+        torch.cuda.synchronize(self.device)
         self._ev_dF = [None] * 5
 
     # ------------------------------------------------------------------------------------------------

@@ -69,7 +69,7 @@ _TRANSPORT = os.environ.get("FP_DP_TRANSPORT", "")
 # which stream carries the all-reduces: "own" = a dedicated stream; "dwg0" / "dwg1" / "aux" / "wg" = that engine stream (ROCm maps a
 # process's streams onto a handful of hardware queues -- every extra stream that is busy during the backward pass can end up sharing
 # a queue with one of the five the schedule already uses, and streams that share a queue serialise)
-_COMM_STREAM = os.environ.get("FP_DP_COMM_STREAM", "own")
+_COMM_STREAM = os.environ.get("FP_DP_COMM_STREAM", "dwg0")
 
 
 class Communicator:
@@ -244,9 +244,10 @@ def broadcast_state(model, src=0, group=None):
     weight copies are stale -- `.data` writes do not move `Parameter._version` (Engine.invalidate)."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
-    eng = getattr(model, "_engine", None)
-    done = set()
     first = next(model.parameters())
+    # the engine first: its streams must own their hardware queues before a communicator creates streams of its own (Engine.__init__)
+    eng = model.engine() if (first.is_cuda and hasattr(model, "engine")) else getattr(model, "_engine", None)
+    done = set()
     comm = get_communicator(group) if (first.is_cuda and _pick_transport(first.data, group, False) == "rccl") else None
 
     def bcast(t):

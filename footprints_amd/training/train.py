@@ -56,7 +56,9 @@ class TrainStep:
         if distributed:
             from ..parallel import _COMM_STREAM
             eng = self.eng
-            comm_stream = {"aux": eng.aux, "wg": eng.wg, "dwg0": eng.dwg[0], "dwg1": eng.dwg[1]}.get(_COMM_STREAM)
+            # the bucket all-reduces run on one of the engine's own streams (default: the mask decoder's weight-gradient stream, idle
+            # once the decoders are done) -- a stream of their own would be a fifth one and share a hardware queue with a busy one
+            comm_stream = {"aux": eng.aux, "wg": eng.wg, "dwg0": eng.dwg[0], "dwg1": eng.dwg[1], "own": None}[_COMM_STREAM]
             self.reducer = GradReducer(eng.flat_grad, eng.live_names, eng.offsets, comm_stream=comm_stream)
             optimiser.grad_scale = self.reducer.grad_scale
 
