@@ -532,6 +532,22 @@ class Engine:
             self.amax.published(out, so)
         return out
 
+    def _bn(self, rec, z, out, training, residual=None, relu=True):
+        """BatchNorm of one encoder conv output: train mode = batch statistics + normalisation (one fused launch; FP_BN_FUSED=0: three)"""
+        if not (training and ops._BN_FUSED):
+            self._bn_coeffs(rec, z, training)
+            return self._bn_apply(rec, z, out, residual=residual, relu=relu)
+        bn = rec.bn
+        M = z.numel() // rec.C
+        so = self.amax.out_slot(out) if _HP else None
+        ops.bn_train_fused(z.view(M, rec.C), out.view(M, rec.C), bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var,
+                           bn.num_batches_tracked, rec.mean, rec.invstd, rec.scale, rec.shift,
+                           residual=None if residual is None else residual.view(M, rec.C), relu=relu, eps=bn.eps,
+                           momentum=bn.momentum if bn.momentum is not None else 0.1, amax_out=so)
+        if so is not None:
+            self.amax.published(out, so)
+        return out
+
     @staticmethod
     def _head_wb(hd):
         return (hd.w2, hd.b2) if hd.pad else (hd.w.data, hd.b.data)
@@ -754,8 +770,7 @@ class Engine:
         h, w = H // 2, W // 2
         z0 = buf("z0", (N, h, w, 64))
         ops.conv_igemm(ops.make_desc(N, h, w, H, W, 3, 0, 64, 7, 2, 3, L.GATHER_STEM), image, None, self.stem.wp, z0)
-        self._bn_coeffs(self.bn0, z0, training)
-        f0 = self._bn_apply(self.bn0, z0, buf("f0", (N, h, w, 64)))
+        f0 = self._bn(self.bn0, z0, buf("f0", (N, h, w, 64)), training)
         hp, wp_ = (h + 1) // 2, (w + 1) // 2
         pool = buf("pool", (N, hp, wp_, 64))
         am = buf("pool.argmax", (N, hp, wp_, 64), torch.uint8)
@@ -776,23 +791,20 @@ class Engine:
 
             def shortcut():
                 zd_ = self._conv_enc(blk.ds, x, N, h, w, buf("b%d.zd" % i, (N, oh, ow, blk.Cout)))
-                self._bn_coeffs(blk.bnd, zd_, training)
-                return zd_, self._bn_apply(blk.bnd, zd_, buf("b%d.idt" % i, (N, oh, ow, blk.Cout)), relu=False)
+                return zd_, self._bn(blk.bnd, zd_, buf("b%d.idt" % i, (N, oh, ow, blk.Cout)), training, relu=False)
             if blk.ds is not None and self.concurrent and _DS_AUX:       # downsample branch beside conv1 / conv2 (joined before the residual add)
                 ops.event_wait(self.aux, self._record(ops.current_stream()))
                 with ops.on_stream(self.aux):
                     zd, idt = shortcut()
                     ev_idt = self._record(self.aux)
             z1 = self._conv_enc(blk.c1, x, N, h, w, buf("b%d.z1" % i, (N, oh, ow, blk.Cout)))
-            self._bn_coeffs(blk.bn1, z1, training)
-            a1 = self._bn_apply(blk.bn1, z1, buf("b%d.a1" % i, (N, oh, ow, blk.Cout)))
+            a1 = self._bn(blk.bn1, z1, buf("b%d.a1" % i, (N, oh, ow, blk.Cout)), training)
             z2 = self._conv_enc(blk.c2, a1, N, oh, ow, buf("b%d.z2" % i, (N, oh, ow, blk.Cout)))
-            self._bn_coeffs(blk.bn2, z2, training)
             if blk.ds is not None and ev_idt is None:
                 zd, idt = shortcut()
             if ev_idt is not None:
                 ops.event_wait(ops.current_stream(), ev_idt)
-            out = self._bn_apply(blk.bn2, z2, buf("b%d.out" % i, (N, oh, ow, blk.Cout)), residual=idt)
+            out = self._bn(blk.bn2, z2, buf("b%d.out" % i, (N, oh, ow, blk.Cout)), training, residual=idt)
             S["blocks"].append(dict(x=x, z1=z1, a1=a1, z2=z2, zd=zd, out=out, hin=h, win=w, h=oh, w=ow))
             x, h, w = out, oh, ow
             last_of_layer = (i + 1 == len(self.blocks)) or (self.blocks[i + 1].stride == 2)

@@ -286,6 +286,18 @@ int fp_bn_eval_coeffs(const float* gamma, const float* beta, const float* runnin
  * conv's bias), so inference runs conv + bias + ReLU (+ residual) in one launch -- SURVEY.md section 8(f) N1. */
 int fp_scale_rows(const float* w, const float* scale, float* out, int64_t rows, int64_t inner, fp_stream_t stream);
 /* y = [relu](z*scale + shift [+ residual]) */
+/* Fused train-mode BatchNorm: statistics, their combination and the normalisation (fp_bn_train_stats + fp_bn_apply; fp_bn_bwd's three
+ * stages) in ONE launch with an in-kernel grid dependency -- every workgroup is resident, the last one to arrive combines the partials
+ * in a fixed order (results independent of arrival order).  `sync`: fp_grid_sync_words() uint32 owned by ONE stream, zeroed once by
+ * the caller; the kernels re-arm it.  Same outputs and amax sink as the unfused entry points. */
+int32_t fp_grid_sync_words(void);
+int fp_bn_train_fused(const float* z, const float* residual, float* y, int64_t M, int32_t C, const float* gamma, const float* beta,
+                      float eps, float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                      float* save_mean, float* save_invstd, float* scale, float* shift, int32_t relu, void* workspace,
+                      int64_t workspace_bytes, uint32_t* sync, fp_stream_t stream);
+int fp_bn_bwd_fused(const float* dy, const float* relu_out, const float* z, const float* save_mean, const float* save_invstd,
+                    const float* gamma, float* dz, float* g_out, float* dgamma, float* dbeta, int accumulate, int64_t M, int32_t C,
+                    void* workspace, int64_t workspace_bytes, uint32_t* sync, fp_stream_t stream);
 int fp_bn_apply(const float* z, const float* scale, const float* shift, const float* residual, float* y, int64_t M,
                 int32_t C, int32_t relu, fp_stream_t stream);
 /* backward: g = dy * (relu_out > 0 if relu_out) ; dgamma (+)= sum g*xhat ; dbeta (+)= sum g ;

@@ -1,0 +1,124 @@
+"""GPU: the fused train-mode BatchNorm kernels (fp_bn_train_fused / fp_bn_bwd_fused: statistics -> in-kernel grid dependency ->
+normalisation in one launch, csrc/bn_pool.hip) against a float64 torch reference of native_batch_norm (+ residual + ReLU) and its
+backward -- the ops behind torchvision's BatchNorm2d in footprints/network.py:38-44 -- at every (M, C) the encoder produces for the
+benchmark workloads, plus ragged sizes; against the three-launch entry points; and for what the grid dependency could break:
+bit-identical results over many repetitions, back-to-back launches that reuse one sync block, and two streams running fused
+kernels concurrently on their own sync blocks."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from footprints_amd import ops
+    return ops
+
+
+def _case(M, C, seed, with_res):
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s: torch.rand(*s, generator=g)
+    z = (r(M, C) * 2 - 1) * (0.25 + 4 * r(1, C)) + (r(1, C) * 6 - 3)          # per-channel scale and offset: cancellation-prone means
+    gamma, beta = r(C) + 0.5, r(C) * 2 - 1
+    rm, rv = r(C) * 2 - 1, r(C) * 1.5 + 0.5
+    res = (r(M, C) * 2 - 1) if with_res else None
+    dy = r(M, C) * 2 - 1
+    return z, gamma, beta, rm, rv, res, dy
+
+
+def _reference(z, gamma, beta, rm, rv, res, dy, relu):
+    z64 = z.double().requires_grad_(True)
+    g64, b64 = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    rm64, rv64 = rm.double().clone(), rv.double().clone()
+    y = F.batch_norm(z64.t()[None], rm64, rv64, g64, b64, True, 0.1, 1e-5)[0].t()        # [M, C] -> [1, C, M]
+    if res is not None:
+        y = y + res.double()
+    if relu:
+        y = F.relu(y)
+    y.backward(dy.double())
+    return y.detach(), z64.grad, g64.grad, b64.grad, rm64, rv64
+
+
+def _run_fused(ops, z, gamma, beta, rm, rv, res, dy, relu):
+    M, C = z.shape
+    d = lambda t: None if t is None else t.detach().clone().cuda().contiguous()
+    zs, rmd, rvd = d(z), d(rm), d(rv)
+    nbt = torch.zeros((), dtype=torch.int64, device="cuda")
+    mean, invstd, scale, shift = (torch.empty(C, device="cuda") for _ in range(4))
+    y = torch.empty_like(zs)
+    ops.bn_train_fused(zs, y, d(gamma), d(beta), rmd, rvd, nbt, mean, invstd, scale, shift, residual=d(res), relu=relu)
+    dz, gout = torch.empty_like(zs), torch.empty_like(zs)
+    dgam, dbet = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    assert ops._BN_FUSED
+    ops.bn_bwd(d(dy), y if relu else None, zs, mean, invstd, d(gamma), dz, dgam, dbet, g_out=gout)
+    return dict(y=y, dz=dz, dgamma=dgam, dbeta=dbet, rm=rmd, rv=rvd, nbt=nbt, mean=mean, invstd=invstd, scale=scale, shift=shift, gout=gout)
+
+
+def _rel(got, ref):
+    ref = ref.double()
+    return ((got.double().cpu() - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
+
+
+# (M, C): stem 12x96x320 / layer1 12x48x160 x 64, layer2 12x24x80 x 128, layer3 12x12x40 x 256, layer4 12x6x20 x 512 (KITTI bs=12);
+# Matterport bs=4 layer1 / layer4; small and ragged row counts (fewer rows than one workgroup pass, M not a multiple of anything)
+SHAPES = [(12 * 96 * 320, 64), (12 * 48 * 160, 64), (12 * 24 * 80, 128), (12 * 12 * 40, 256), (12 * 6 * 20, 512), (4 * 128 * 160, 64),
+          (4 * 16 * 20, 512), (7, 64), (1, 16), (1000, 128), (333, 512), (4097, 16), (65, 1024)]
+
+
+@pytest.mark.parametrize("M,C", SHAPES)
+@pytest.mark.parametrize("relu,with_res", [(True, True), (True, False), (False, False)])
+def test_fused_bn_against_float64(M, C, relu, with_res):
+    if M == 1:
+        pytest.skip("batch statistics over one sample: torch refuses it")
+    ops = _ops()
+    case = _case(M, C, 100 + C + M % 97, with_res)
+    y, dz, dgam, dbet, rm64, rv64 = _reference(*case, relu)
+    out = _run_fused(ops, *case, relu)
+    assert _rel(out["y"], y) <= 2e-6, ("y", _rel(out["y"], y))
+    assert _rel(out["rm"], rm64) <= 1e-6 and _rel(out["rv"], rv64) <= 2e-6
+    assert int(out["nbt"]) == 1
+    assert _rel(out["dz"], dz) <= 1e-5, ("dz", _rel(out["dz"], dz))
+    assert _rel(out["dgamma"], dgam) <= 1e-5 and _rel(out["dbeta"], dbet) <= 1e-5
+    mask = (y > 0).float() if relu else torch.ones_like(y)
+    assert _rel(out["gout"], case[6].double() * mask) <= 1e-7
+
+
+@pytest.mark.parametrize("M,C", [(12 * 48 * 160, 64), (12 * 6 * 20, 512), (333, 512)])
+def test_fused_bn_equals_three_launch_form_closely_and_is_bit_reproducible(M, C):
+    """same arithmetic family as fp_bn_train_stats + fp_bn_apply (Welford partials in a different, still fixed, grouping): 1e-6; and 25
+    repetitions -- each re-using the same sync block back to back, arrival orders differing from run to run -- are bit-identical"""
+    ops = _ops()
+    case = _case(M, C, 7, True)
+    first = _run_fused(ops, *case, True)
+    torch.cuda.synchronize()
+    for _ in range(25):
+        again = _run_fused(ops, *case, True)
+        for k in ("y", "dz", "dgamma", "dbeta", "rm", "rv", "mean", "invstd", "scale", "shift"):
+            assert torch.equal(first[k], again[k]), k
+    z, gamma, beta, rm, rv, res, dy = case
+    d = lambda t: t.detach().clone().cuda().contiguous()
+    mean, invstd, scale, shift = (torch.empty(C, device="cuda") for _ in range(4))
+    rmd, rvd, nbt = d(rm), d(rv), torch.zeros((), dtype=torch.int64, device="cuda")
+    ops.bn_train_stats(d(z), d(gamma), d(beta), rmd, rvd, nbt, mean, invstd, scale, shift)
+    y3 = torch.empty(M, C, device="cuda")
+    ops.bn_apply(d(z), scale, shift, y3, residual=d(res), relu=True)
+    assert _rel(first["y"], y3.cpu()) <= 1e-6 and _rel(first["mean"], mean.cpu()) <= 1e-6 and _rel(first["rv"], rvd.cpu()) <= 1e-6
+
+
+def test_fused_bn_on_two_streams_concurrently():
+    """the encoder's downsample branch runs its BatchNorm on the aux stream beside the main branch's: two fused kernels in flight, each
+    on its own stream's sync block (ops.grid_sync_block), 40 rounds; every result equals the single-stream one bit for bit"""
+    ops = _ops()
+    a, b = _case(12 * 24 * 80, 128, 11, True), _case(12 * 24 * 80, 128, 12, False)
+    ref_a, ref_b = _run_fused(ops, *a, True), _run_fused(ops, *b, False)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(40):
+        with ops.on_stream(s1):
+            ra = _run_fused(ops, *a, True)
+        with ops.on_stream(s2):
+            rb = _run_fused(ops, *b, False)
+        torch.cuda.synchronize()
+        for k in ("y", "dz", "dgamma", "rm", "rv"):
+            assert torch.equal(ra[k], ref_a[k]) and torch.equal(rb[k], ref_b[k]), k
