@@ -252,12 +252,14 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restri
 struct BnGeom {
   int M, C, rows_per_wg;
 };
+constexpr int BN_UNROLL = 4;
 
 int bn_fused_grid(int64_t M, int C, int* rows_per_wg) {
   const int R = 256 / (C / 4);
-  static const int kb = getenv("FP_BN_FUSED_KB") ? atoi(getenv("FP_BN_FUSED_KB")) : 48;       // bytes of z per workgroup (KB), lower bound
+  static const int kb = getenv("FP_BN_FUSED_KB") ? atoi(getenv("FP_BN_FUSED_KB")) : 32;       // bytes of z per workgroup (KB), lower bound
+  static const int maxwg = getenv("FP_BN_FUSED_MAXWG") ? atoi(getenv("FP_BN_FUSED_MAXWG")) : 512;   // all of them must be resident at once
   int64_t rows = ((int64_t)kb * 1024) / ((int64_t)C * 4);
-  if (rows * 256 < M) rows = fp_ceil_div(M, 256);                                            // at most 256 workgroups
+  if (rows * maxwg < M) rows = fp_ceil_div(M, maxwg);
   rows = fp_ceil_div(rows, R) * R;
   if (rows < R) rows = R;
   *rows_per_wg = (int)rows;
@@ -279,11 +281,20 @@ __global__ void __launch_bounds__(256) bn_fused_fwd_kernel(const float* __restri
   // ---- phase 1: Welford over this workgroup's rows ------------------------------------------------------------------------
   Wf w[4] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
   float cnt = 0.f;
-  for (int m = m0 + rr; m < m1; m += R) {
-    const float4 v = *reinterpret_cast<const float4*>(z + (size_t)m * C + cq * 4);
-    cnt += 1.f;
-    const float rn = 1.f / cnt;
-    wf_add(w[0], v.x, cnt, rn); wf_add(w[1], v.y, cnt, rn); wf_add(w[2], v.z, cnt, rn); wf_add(w[3], v.w, cnt, rn);
+  for (int m = m0 + rr; m < m1; m += BN_UNROLL * R) {       // BN_UNROLL independent loads in flight per thread
+    float4 v[BN_UNROLL];
+#pragma unroll
+    for (int u = 0; u < BN_UNROLL; ++u) {
+      const int mm = min(m + u * R, m1 - 1);
+      v[u] = *reinterpret_cast<const float4*>(z + (size_t)mm * C + cq * 4);
+    }
+#pragma unroll
+    for (int u = 0; u < BN_UNROLL; ++u) {
+      if (m + u * R >= m1) break;
+      cnt += 1.f;
+      const float rn = 1.f / cnt;
+      wf_add(w[0], v[u].x, cnt, rn); wf_add(w[1], v[u].y, cnt, rn); wf_add(w[2], v[u].z, cnt, rn); wf_add(w[3], v[u].w, cnt, rn);
+    }
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -348,17 +359,24 @@ __global__ void __launch_bounds__(256) bn_fused_fwd_kernel(const float* __restri
   sh.x = fp_gs_load(shift + cq * 4 + 0); sh.y = fp_gs_load(shift + cq * 4 + 1); sh.z = fp_gs_load(shift + cq * 4 + 2); sh.w = fp_gs_load(shift + cq * 4 + 3);
   fp_gs_leave(sync, b, G);
   float ymax = 0.f;
-  for (int m = m0 + rr; m < m1; m += R) {
-    const size_t e = (size_t)m * C + cq * 4;
-    const float4 v = *reinterpret_cast<const float4*>(z + e);
-    float4 o = make_float4(v.x * sc.x + sh.x, v.y * sc.y + sh.y, v.z * sc.z + sh.z, v.w * sc.w + sh.w);
-    if (res) {
-      const float4 r = *reinterpret_cast<const float4*>(res + e);
-      o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+  for (int m = m0 + rr; m < m1; m += BN_UNROLL * R) {
+    float4 v[BN_UNROLL], rq[BN_UNROLL];
+#pragma unroll
+    for (int u = 0; u < BN_UNROLL; ++u) {
+      const size_t e = (size_t)min(m + u * R, m1 - 1) * C + cq * 4;
+      v[u] = *reinterpret_cast<const float4*>(z + e);
+      rq[u] = res ? *reinterpret_cast<const float4*>(res + e) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-    *reinterpret_cast<float4*>(y + e) = o;
-    ymax = fp_amax4(ymax, o);
+#pragma unroll
+    for (int u = 0; u < BN_UNROLL; ++u) {
+      if (m + u * R >= m1) break;
+      const size_t e = (size_t)(m + u * R) * C + cq * 4;
+      float4 o = make_float4(v[u].x * sc.x + sh.x, v[u].y * sc.y + sh.y, v[u].z * sc.z + sh.z, v[u].w * sc.w + sh.w);
+      o.x += rq[u].x; o.y += rq[u].y; o.z += rq[u].z; o.w += rq[u].w;
+      if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+      *reinterpret_cast<float4*>(y + e) = o;
+      ymax = fp_amax4(ymax, o);
+    }
   }
   if (amax_out) fp_amax_publish_block(amax_out, ymax);
 }
@@ -376,18 +394,26 @@ __global__ void __launch_bounds__(256) bn_fused_bwd_kernel(const float* __restri
   const float4 mu = reinterpret_cast<const float4*>(mean)[cq];
   const float4 is = reinterpret_cast<const float4*>(invstd)[cq];
   float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
-  for (int m = m0 + rr; m < m1; m += R) {
-    const size_t o = (size_t)m * C + cq * 4;
-    float4 gq = *reinterpret_cast<const float4*>(dy + o);
-    if (ro) {
-      const float4 r = *reinterpret_cast<const float4*>(ro + o);
-      gq.x = r.x > 0.f ? gq.x : 0.f; gq.y = r.y > 0.f ? gq.y : 0.f; gq.z = r.z > 0.f ? gq.z : 0.f; gq.w = r.w > 0.f ? gq.w : 0.f;
+  for (int m = m0 + rr; m < m1; m += BN_UNROLL * R) {
+    float4 gv[BN_UNROLL], rv[BN_UNROLL], zv[BN_UNROLL];
+#pragma unroll
+    for (int u = 0; u < BN_UNROLL; ++u) {
+      const size_t o = (size_t)min(m + u * R, m1 - 1) * C + cq * 4;
+      gv[u] = *reinterpret_cast<const float4*>(dy + o);
+      rv[u] = ro ? *reinterpret_cast<const float4*>(ro + o) : make_float4(1.f, 1.f, 1.f, 1.f);
+      zv[u] = *reinterpret_cast<const float4*>(z + o);
     }
-    const float4 v = *reinterpret_cast<const float4*>(z + o);
-    s1[0] += gq.x; s2[0] += gq.x * ((v.x - mu.x) * is.x);
-    s1[1] += gq.y; s2[1] += gq.y * ((v.y - mu.y) * is.y);
-    s1[2] += gq.z; s2[2] += gq.z * ((v.z - mu.z) * is.z);
-    s1[3] += gq.w; s2[3] += gq.w * ((v.w - mu.w) * is.w);
+#pragma unroll
+    for (int u = 0; u < BN_UNROLL; ++u) {
+      if (m + u * R >= m1) break;
+      float4 gq = gv[u];
+      const float4 r = rv[u], v = zv[u];
+      gq.x = r.x > 0.f ? gq.x : 0.f; gq.y = r.y > 0.f ? gq.y : 0.f; gq.z = r.z > 0.f ? gq.z : 0.f; gq.w = r.w > 0.f ? gq.w : 0.f;
+      s1[0] += gq.x; s2[0] += gq.x * ((v.x - mu.x) * is.x);
+      s1[1] += gq.y; s2[1] += gq.y * ((v.y - mu.y) * is.y);
+      s1[2] += gq.z; s2[2] += gq.z * ((v.z - mu.z) * is.z);
+      s1[3] += gq.w; s2[3] += gq.w * ((v.w - mu.w) * is.w);
+    }
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -444,22 +470,31 @@ __global__ void __launch_bounds__(256) bn_fused_bwd_kernel(const float* __restri
   fp_gs_leave(sync, b, G);
   const float4 ga = reinterpret_cast<const float4*>(gamma)[cq];
   float ymax = 0.f;
-  for (int m = m0 + rr; m < m1; m += R) {
-    const size_t e = (size_t)m * C + cq * 4;
-    float4 gq = *reinterpret_cast<const float4*>(dy + e);
-    if (ro) {
-      const float4 r = *reinterpret_cast<const float4*>(ro + e);
-      gq.x = r.x > 0.f ? gq.x : 0.f; gq.y = r.y > 0.f ? gq.y : 0.f; gq.z = r.z > 0.f ? gq.z : 0.f; gq.w = r.w > 0.f ? gq.w : 0.f;
+  for (int m = m0 + rr; m < m1; m += BN_UNROLL * R) {
+    float4 gv[BN_UNROLL], rv[BN_UNROLL], zv[BN_UNROLL];
+#pragma unroll
+    for (int u = 0; u < BN_UNROLL; ++u) {
+      const size_t e = (size_t)min(m + u * R, m1 - 1) * C + cq * 4;
+      gv[u] = *reinterpret_cast<const float4*>(dy + e);
+      rv[u] = ro ? *reinterpret_cast<const float4*>(ro + e) : make_float4(1.f, 1.f, 1.f, 1.f);
+      zv[u] = *reinterpret_cast<const float4*>(z + e);
     }
-    if (gout) *reinterpret_cast<float4*>(gout + e) = gq;
-    const float4 v = *reinterpret_cast<const float4*>(z + e);
-    float4 o;
-    o.x = ga.x * is.x * (gq.x - c1[0] - (v.x - mu.x) * is.x * c2[0]);
-    o.y = ga.y * is.y * (gq.y - c1[1] - (v.y - mu.y) * is.y * c2[1]);
-    o.z = ga.z * is.z * (gq.z - c1[2] - (v.z - mu.z) * is.z * c2[2]);
-    o.w = ga.w * is.w * (gq.w - c1[3] - (v.w - mu.w) * is.w * c2[3]);
-    *reinterpret_cast<float4*>(dz + e) = o;
-    ymax = fp_amax4(ymax, o);
+#pragma unroll
+    for (int u = 0; u < BN_UNROLL; ++u) {
+      if (m + u * R >= m1) break;
+      const size_t e = (size_t)(m + u * R) * C + cq * 4;
+      float4 gq = gv[u];
+      const float4 r = rv[u], v = zv[u];
+      gq.x = r.x > 0.f ? gq.x : 0.f; gq.y = r.y > 0.f ? gq.y : 0.f; gq.z = r.z > 0.f ? gq.z : 0.f; gq.w = r.w > 0.f ? gq.w : 0.f;
+      if (gout) *reinterpret_cast<float4*>(gout + e) = gq;
+      float4 o;
+      o.x = ga.x * is.x * (gq.x - c1[0] - (v.x - mu.x) * is.x * c2[0]);
+      o.y = ga.y * is.y * (gq.y - c1[1] - (v.y - mu.y) * is.y * c2[1]);
+      o.z = ga.z * is.z * (gq.z - c1[2] - (v.z - mu.z) * is.z * c2[2]);
+      o.w = ga.w * is.w * (gq.w - c1[3] - (v.w - mu.w) * is.w * c2[3]);
+      *reinterpret_cast<float4*>(dz + e) = o;
+      ymax = fp_amax4(ymax, o);
+    }
   }
   if (amax_out) fp_amax_publish_block(amax_out, ymax);
 }

@@ -533,7 +533,7 @@ class Engine:
         return out
 
     def _bn(self, rec, z, out, training, residual=None, relu=True):
-        """BatchNorm of one encoder conv output: train mode = batch statistics + normalisation (one fused launch; FP_BN_FUSED=0: three)"""
+        """BatchNorm of one encoder conv output: train mode = batch statistics + normalisation (statistics, their combination, normalisation: three launches; FP_BN_FUSED=1: one fused launch)"""
         if not (training and ops._BN_FUSED):
             self._bn_coeffs(rec, z, training)
             return self._bn_apply(rec, z, out, residual=residual, relu=relu)
@@ -800,11 +800,15 @@ class Engine:
             z1 = self._conv_enc(blk.c1, x, N, h, w, buf("b%d.z1" % i, (N, oh, ow, blk.Cout)))
             a1 = self._bn(blk.bn1, z1, buf("b%d.a1" % i, (N, oh, ow, blk.Cout)), training)
             z2 = self._conv_enc(blk.c2, a1, N, oh, ow, buf("b%d.z2" % i, (N, oh, ow, blk.Cout)))
+            fused2 = training and ops._BN_FUSED
+            if not fused2:
+                self._bn_coeffs(blk.bn2, z2, training)          # the statistics do not need the shortcut branch: before the join
             if blk.ds is not None and ev_idt is None:
                 zd, idt = shortcut()
             if ev_idt is not None:
                 ops.event_wait(ops.current_stream(), ev_idt)
-            out = self._bn(blk.bn2, z2, buf("b%d.out" % i, (N, oh, ow, blk.Cout)), training, residual=idt)
+            ob = buf("b%d.out" % i, (N, oh, ow, blk.Cout))
+            out = self._bn(blk.bn2, z2, ob, training, residual=idt) if fused2 else self._bn_apply(blk.bn2, z2, ob, residual=idt)
             S["blocks"].append(dict(x=x, z1=z1, a1=a1, z2=z2, zd=zd, out=out, hin=h, win=w, h=oh, w=ow))
             x, h, w = out, oh, ow
             last_of_layer = (i + 1 == len(self.blocks)) or (self.blocks[i + 1].stride == 2)

@@ -538,9 +538,11 @@ def bn_train_stats(z2d, gamma, beta, running_mean, running_var, nbt, save_mean, 
                                      ws.numel(), stream()), "fp_bn_train_stats")
 
 
-# fused train-mode BatchNorm (one launch per layer and direction, in-kernel grid dependency: csrc/bn_pool.hip); FP_BN_FUSED=0 keeps the
-# three-launch form
-_BN_FUSED = bool(int(os.environ.get("FP_BN_FUSED", "1")))
+# fused train-mode BatchNorm (one launch per layer and direction, in-kernel grid dependency: csrc/bn_pool.hip).  OPT-IN (FP_BN_FUSED=1):
+# correct and bit-reproducible (tests/test_gpu_bn_fused.py) but measured SLOWER in the training step (16.7 vs 13.9 ms, round 3): the
+# per-XCD L2s are not coherent, so everything workgroups exchange goes through memory at 1-2 us per dependent hop, and the last
+# arriver's combine of G x C partials is a serial chain of such hops -- a dependent launch (~10 us) is cheaper (profiles/round3_notes.md)
+_BN_FUSED = bool(int(os.environ.get("FP_BN_FUSED", "0")))
 _sync_blocks = {}
 
 

@@ -50,8 +50,11 @@ def _run_fused(ops, z, gamma, beta, rm, rv, res, dy, relu):
     ops.bn_train_fused(zs, y, d(gamma), d(beta), rmd, rvd, nbt, mean, invstd, scale, shift, residual=d(res), relu=relu)
     dz, gout = torch.empty_like(zs), torch.empty_like(zs)
     dgam, dbet = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
-    assert ops._BN_FUSED
-    ops.bn_bwd(d(dy), y if relu else None, zs, mean, invstd, d(gamma), dz, dgam, dbet, g_out=gout)
+    was, ops._BN_FUSED = ops._BN_FUSED, True          # ops.bn_bwd routes to fp_bn_bwd_fused (opt-in in the product: FP_BN_FUSED=1)
+    try:
+        ops.bn_bwd(d(dy), y if relu else None, zs, mean, invstd, d(gamma), dz, dgam, dbet, g_out=gout)
+    finally:
+        ops._BN_FUSED = was
     return dict(y=y, dz=dz, dgamma=dgam, dbeta=dbet, rm=rmd, rv=rvd, nbt=nbt, mean=mean, invstd=invstd, scale=scale, shift=shift, gout=gout)
 
 
