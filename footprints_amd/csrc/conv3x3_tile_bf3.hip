@@ -390,6 +390,7 @@ __global__ void __launch_bounds__(256, HP ? FP_TILE_HP_WAVES : 1) conv3x3_tile_b
   float* const dst = a.SK > 1 ? a.part + (size_t)split * a.N * a.OH * a.OW * a.Nout : a.y;
   const bool interior = NPIX == 128 && y0 + TH <= a.OH && x0 + TW <= a.OW;
   float ymax = 0.f;                                  // HP: largest stored magnitude of this lane (the consumer's scale)
+  const float unscale = HP ? ldexpf(1.f, kunscale) : 1.f;      // wave-uniform power of two: one fused multiply-add per element un-scales and adds the bias
   auto rows8 = [&](auto full_tag, int i, int j, int n, float bias, int half) {
     constexpr bool FULL = decltype(full_tag)::value;
     int off[8];
@@ -429,7 +430,7 @@ __global__ void __launch_bounds__(256, HP ? FP_TILE_HP_WAVES : 1) conv3x3_tile_b
     // every option for every element)
     float v[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = (HP ? ldexpf(acc[i][j][half * 8 + k], kunscale) : acc[i][j][half * 8 + k]) + bias;
+    for (int k = 0; k < 8; ++k) v[k] = HP ? fmaf(acc[i][j][half * 8 + k], unscale, bias) : acc[i][j][half * 8 + k] + bias;   // * 2^kunscale is exact
     if (epi & FP_EPI_ADDEND) {
       if (epi & FP_EPI_ADDEND_MASK) {
 #pragma unroll

@@ -157,10 +157,18 @@ __device__ __forceinline__ float fp_stem_load(const FpGeom& g, const float* __re
 // expm1f (ocml) is ~40 instructions and made the epilogue 10-20 % of the bf16x3 conv kernels.  For -0.25 < v <= 0 a degree-7
 // Taylor polynomial (relative error < 2e-9); below that e^v - 1 has no cancellation and the hardware exponential is accurate to
 // ~1e-7 absolute (argument rounding + 1 ulp), i.e. < 5e-7 of the result.  Same value is stored and later used for ELU'.
+// Round 3 A/B: the five-instruction form e = exp2(v * log2 e) - 1 (absolute error ~1e-7 near zero; -DFP_ELU_EXP) leaves the training
+// step where it was (13.73 / 13.78 vs 13.77 / 13.77 ms): the epilogue's ELU is not what the tile kernel waits for in the step, so the
+// accurate form stays.
 __device__ __forceinline__ float fp_elu(float v) {
+#ifdef FP_ELU_EXP
+  const float e = __builtin_amdgcn_exp2f(v * 1.44269504088896341f) - 1.f;
+  return v > 0.f ? v : e;
+#else
   if (v > 0.f) return v;
   const float p = v * (1.f + v * (0.5f + v * (1.f / 6.f + v * (1.f / 24.f + v * (1.f / 120.f + v * (1.f / 720.f + v * (1.f / 5040.f)))))));
   return v > -0.25f ? p : __expf(v) - 1.f;
+#endif
 }
 
 // ---- fp16-pair ("hp") operands ----------------------------------------------------------------------------
