@@ -185,7 +185,10 @@ static_assert(FP_AMAX_SLOTS == 16, "amax slot width (include/footprints_hip.h)")
 #ifndef FP_HP_PRODUCTS
 #define FP_HP_PRODUCTS 3
 #endif
-constexpr int FP_HP_TARGET_ACT = 12;    // activations / gradients: amax -> [2^12, 2^13)
+#ifndef FP_HP_TARGET_ACT_V
+#define FP_HP_TARGET_ACT_V 12
+#endif
+constexpr int FP_HP_TARGET_ACT = FP_HP_TARGET_ACT_V;    // activations / gradients: amax -> [2^12, 2^13)
 constexpr int FP_HP_TARGET_W = 11;      // weights: amax -> [2^11, 2^12) (the nearest-x2 phase kernels add up to four of them)
 __device__ __forceinline__ unsigned fp_amax_bits(const unsigned* __restrict__ slot) {
   unsigned m = 0;

@@ -38,6 +38,10 @@ _PWBF3 = not bool(int(os.environ.get("FP_NO_PHASE_WBF3", "0")))           # ... 
 # fp16-pair operands (two fp16 terms after a per-tensor power-of-two scaling, three MFMA products, 22 significant bits) for the same
 # kernels, with the scaling taken from amax slots that producers publish / a reduction fills (csrc/fp_common.h); FP_HP=0 keeps bf16x3
 _HP = _BF3 and bool(int(os.environ.get("FP_HP", "1")))
+# per kernel family (A/B and precision studies, profiles/round3_notes.md): FP_HP_WGRAD=0 keeps the weight-gradient kernels on the exact
+# bf16 split while forward / data-gradient use fp16 pairs; FP_HP_TILE=0 the other way round
+_HP_WGRAD = _HP and bool(int(os.environ.get("FP_HP_WGRAD", "1")))
+_HP_TILE = _HP and bool(int(os.environ.get("FP_HP_TILE", "1")))
 # the 1x1 downsample branch of a BasicBlock (conv -> BN, and its gradients) on the aux stream beside the block's main branch: the encoder
 # is the serial spine of the step (one kernel on the GPU at a time), the aux stream idles until the decoders start.  FP_DS_AUX=0: in line
 _DS_AUX = bool(int(os.environ.get("FP_DS_AUX", "1")))
@@ -436,7 +440,7 @@ class Engine:
                         if c.hp_ph is not None:
                             jobs.append((L.PACK_UP2_FWD_HP, c.w.data, c.hp_ph, 0, c.up2[0], c.wslot))
                             jobs.append((L.PACK_UP2_DGRAD_HP, c.w.data, c.hp_du, 0, c.up2[0], c.wslot))
-                    keep3 = (not c.hp) or self.inference_bf16x2       # the bf16 tile packings: only where a kernel still reads them
+                    keep3 = (not c.hp) or self.inference_bf16x2 or not _HP_TILE       # the bf16 tile packings: only where a kernel still reads them
                     if c.wp3 is not None and keep3:
                         jobs.append((L.PACK_FWD_BF3, c.w.data, c.wp3, 0, c.Cin))
                     if c.wpd3 is not None and keep3:
@@ -444,7 +448,7 @@ class Engine:
                     if c.wsk3 is not None and keep3:
                         jobs.append((L.PACK_FWD_BF3, c.w.data, c.wsk3, c.up2[0], c.up2[1]))
                         jobs.append((L.PACK_DGRAD_BF3, c.w.data, c.wds3, c.up2[0], c.up2[1]))
-                    if c.wph3 is not None and not c.hp:
+                    if c.wph3 is not None and (not c.hp or not _HP_TILE):
                         jobs.append((L.PACK_UP2_FWD_BF3, c.w.data, c.wph3, 0, c.up2[0]))
                         jobs.append((L.PACK_UP2_DGRAD_BF3, c.w.data, c.wdu3, 0, c.up2[0]))
                     if c.up2 is not None:
@@ -567,7 +571,7 @@ class Engine:
     def _cv(self, d, src, w32, w3, out, hp=None, publish=True, **kw):
         """one 3x3 / 1x1 convolution or data-gradient launch: the split-operand tile kernel where it applies (hp = (fp16-pair packing,
         weight amax slot): three fp16 products; else w3: six bf16 products), else fp_conv_igemm"""
-        use_hp = hp is not None and hp[0] is not None and not ops._bf16x2
+        use_hp = _HP_TILE and hp is not None and hp[0] is not None and not ops._bf16x2
         if (w3 is not None or use_hp) and ops.conv3x3_bf3_supported(d):
             if use_hp:
                 return self._cv_hp(d, src, hp[0], hp[1], out, publish=publish, **kw)
@@ -712,7 +716,7 @@ class Engine:
             if C1:      # skip half at full resolution (raw partial sums), then the four phases of the upsampled half on top
                 d = ops.make_desc(N, H, W, H, W, C1, 0, c.Cout, 3, 1, 1, L.GATHER_FWD_REFLECT)
                 self._cv(d, x1, c.wsk, c.wsk3, out, hp=(c.hp_sk, c.wslot), publish=False)   # raw partial sums: not the tensor's amax
-            if c.hp_ph is not None:
+            if c.hp_ph is not None and _HP_TILE:
                 so = self.amax.out_slot(out)
                 ops.conv_up2_phase_fwd_hp(x0, c.hp_ph, c.b.data, out, self.amax.get(x0), c.wslot, amax_out=so, act=L.ACT_ELU,
                                           addend=out if C1 else None)
@@ -725,7 +729,7 @@ class Engine:
         if x1 is None and not up2:
             return self._cv(d, x0, c.wp, c.wp3, out, hp=(c.hp_f, c.wslot), bias=c.b.data)
         if up2 and c.wp3 is not None and ops.conv3x3_bf3_supported(d):      # concat gather inside the split-operand tile kernel
-            if c.hp_f is not None and not ops._bf16x2:
+            if c.hp_f is not None and not ops._bf16x2 and _HP_TILE:
                 return self._cv_hp(d, x0, c.hp_f, c.wslot, out, src1=x1, bias=c.b.data)
             return ops.conv3x3_bf3(d, x0, c.wp3, out, bias=c.b.data, src1=x1)
         return ops.conv_igemm(d, x0, x1, c.wp, out, bias=c.b.data)
@@ -921,7 +925,7 @@ class Engine:
         d = ops.make_desc(N, OH, OW, IH, IW, C0, C1, c.Cout, c.K, c.stride, c.pad, gather)
         split = _WBF3 and src1 is None and ops.conv_wgrad_bf3_supported(d)
         # fp16-pair operands: both amax slots are settled on THIS stream (the producers', or a reduction here) before the side stream forks
-        am = (self.amax.get(src0), self.amax.get(dz)) if (split and _HP) else None
+        am = (self.amax.get(src0), self.amax.get(dz)) if (split and _HP_WGRAD) else None
 
         def launch():
             if split:
@@ -945,9 +949,9 @@ class Engine:
             d_sk = ops.make_desc(N, H, W, H, W, C1, 0, c.Cout, 3, 1, 1, L.GATHER_FWD_REFLECT) if C1 else None
             if not (_WBF3 and ops.conv_wgrad_bf3_supported(d_lo) and (d_sk is None or ops.conv_wgrad_bf3_supported(d_sk))):
                 return self._wgrad(c, L.GATHER_FWD_REFLECT_UP2, low, skip, dz, N, H, W, H, W, C0, C1, acc, side)
-            s_dz = self.amax.get(dz) if _HP else None
-            am_lo = (self.amax.get(low), s_dz) if _HP else None
-            am_sk = (self.amax.get(skip), s_dz) if (_HP and d_sk is not None) else None
+            s_dz = self.amax.get(dz) if _HP_WGRAD else None
+            am_lo = (self.amax.get(low), s_dz) if _HP_WGRAD else None
+            am_sk = (self.amax.get(skip), s_dz) if (_HP_WGRAD and d_sk is not None) else None
 
             def launch_small():      # small images (12x40): both halves through the split-operand kernel, the upsampling folded into its gather
                 ops.conv_wgrad_bf3(d_lo, low, dz, c.gw, 0, accumulate=acc, db=c.gb, amax=am_lo)
@@ -962,9 +966,9 @@ class Engine:
         pbf3 = _WBF3 and _PWBF3
         d_skip = ops.make_desc(N, H, W, H, W, C1, 0, c.Cout, 3, 1, 1, L.GATHER_FWD_REFLECT) if C1 else None
         skip_split = d_skip is not None and _WBF3 and ops.conv_wgrad_bf3_supported(d_skip)
-        s_dz = self.amax.get(dz) if (_HP and (pbf3 or skip_split)) else None
-        s_low = self.amax.get(low) if (_HP and pbf3) else None
-        am_sk = (self.amax.get(skip), s_dz) if (_HP and skip_split) else None
+        s_dz = self.amax.get(dz) if (_HP_WGRAD and (pbf3 or skip_split)) else None
+        s_low = self.amax.get(low) if (_HP_WGRAD and pbf3) else None
+        am_sk = (self.amax.get(skip), s_dz) if (_HP_WGRAD and skip_split) else None
 
         def launch():
             if s_low is not None:
@@ -996,7 +1000,7 @@ class Engine:
         """gradient wrt the low-res input of an upsample conv on the (hl+2) x (wl+2) extended grid (ops.up2_fold_bwd folds it)"""
         ext = self.buf(pfx + "XV", (N, hl + 2, wl + 2, C0))
         if c.wdu3 is not None and self._phase_ok(hl + 2, wl + 2):      # split-operand phase kernel (8x16 tiles of the extended grid)
-            if c.hp_du is not None:
+            if c.hp_du is not None and _HP_TILE:
                 return ops.conv_up2_phase_dgrad_hp(dz, c.hp_du, ext, self.amax.get(dz), c.wslot)
             return ops.conv_up2_phase_dgrad_bf3(dz, c.wdu3, ext)
         d = ops.make_desc(N, hl + 2, wl + 2, 2 * hl, 2 * wl, c.Cout, 0, C0, 4, 2, 3, L.GATHER_FWD_ZERO)

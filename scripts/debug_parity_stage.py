@@ -19,6 +19,10 @@ Bn, Hn, Wn = (int(v) for v in sys.argv[1:4])
 tag = sys.argv[4] if len(sys.argv) > 4 else "anch"
 P, B = R.make_state(tag=tag)
 cpu_batch = R.make_batch(Bn, Hn, Wn, tag="%s%d" % (tag, Hn))
+if tag == "natural":          # the low-pass / saturated images and 2^16-range BatchNorm parameters of tests/test_gpu_parity_fullsize.py
+    from tests.test_gpu_parity_fullsize import _natural_batch, _wide_range_state
+    P, B = _wide_range_state()
+    cpu_batch = _natural_batch(Bn, Hn, Wn)
 
 
 def oracle(dtype):

@@ -20,7 +20,12 @@ The loss has its own kink: log(|d(o) - depth| + 1) (losses.py:95-107) flips the 
 depth crosses the target.  A pixel with |d - depth| within reach of fp32 output error is undetermined in ANY fp32
 implementation and, sitting at the steepest point of the loss, carries ~30x a typical pixel's gradient: one such pixel among
 327 680 moved every depth-decoder gradient by 1.5e-4 (1x512x640).  `tie_free_batch` removes those pixels from the valid masks
-(depth / ground_depth := 0 where the float64 prediction is within TIE of the target at any scale) for all three runs alike."""
+(depth / ground_depth := 0 where the float64 prediction is within TIE of the target at any scale) for all three runs alike.
+Round 3: the band is also as wide as the depth moves under an OUTPUT perturbation of the parity tolerance itself (TIE_SIGMA = 1e-4 on
+the sigmoid: (hi - lo) d^2 * 1e-4 metres).  With saturated predictions (sigmoid ~ 0, d ~ 100 m: the natural-statistics case) a
+relative band of 1 % is 1 m while two conforming implementations may differ by 10 m there; the fp16-pair path lost that lottery on
+one pixel (gradient ratios up to 54 in layer3/4) while the exact split and the fp32 CPU path happened to win it, with all three
+within 5e-5 of the float64 outputs (profiles/round3_notes.md)."""
 from collections import OrderedDict
 
 import torch
@@ -28,6 +33,9 @@ import torch
 FACTOR = 4.0
 FLOOR = 2e-5          # relative L2; both implementations at fp32 round-off
 TIE = 1e-2            # |predicted depth - target| (metres, relative to max(depth, 1)) below which the L1 kink is undetermined in fp32
+TIE_SIGMA = 1e-4      # ... and the output tolerance of the parity contract itself (north_star: depth / mask tensors within 1e-4): a sigmoid
+                      # output may move by this much between two conforming implementations, which moves the predicted depth
+                      # d = 1 / (lo + (hi - lo) sigma) by (hi - lo) d^2 * 1e-4 -- 10 m at d = 100 m: far pixels sit on the kink for any target
 
 
 def rel_l2(t, ref64):
@@ -44,13 +52,19 @@ def chan_relerr(got, ref):
     return (d / s).tolist()
 
 
-def oracle_grads(P, B, cpu_batch, dtype, fix_batch=None):
+def oracle_grads(P, B, cpu_batch, dtype, fix_batch=None, perturb=0.0, seed=0):
     """one train-mode fwd + loss + bwd of the CPU oracle in `dtype` -> (outputs, losses, {name: grad}, trainer, batch used).
-    fix_batch(batch, outputs) -> batch: applied between the forward and the loss (the outputs do not depend on the targets)"""
+    fix_batch(batch, outputs) -> batch: applied between the forward and the loss (the outputs do not depend on the targets).
+    perturb > 0: the image is multiplied by (1 + perturb * u), u uniform in [-1, 1) (seeded) -- "another conforming fp32
+    implementation": a perturbation at round-off level draws a different set of ReLU-kink decisions (see fp32_spread)"""
     from oracle import restatement as R
     Pd = OrderedDict((k, v.to(dtype)) for k, v in P.items())
     Bd = OrderedDict((k, v.to(dtype) if v.is_floating_point() else v.clone()) for k, v in B.items())
     tr = R.OracleTrainer(Pd, Bd)
+    if perturb > 0.0:
+        g = torch.Generator().manual_seed(1234 + seed)
+        cpu_batch = OrderedDict(cpu_batch)
+        cpu_batch["image"] = cpu_batch["image"] * (1.0 + perturb * (torch.rand(cpu_batch["image"].shape, generator=g) * 2 - 1))
     out = R.footprint_network(cpu_batch["image"].to(dtype), tr.P, tr.B, True)
     used = cpu_batch if fix_batch is None else fix_batch(cpu_batch, out)
     losses, _ = R.loss_manager(out, OrderedDict((k, v.to(dtype)) for k, v in used.items()))
@@ -67,15 +81,20 @@ def stage_of(name):
     return ".".join(p[:2])
 
 
-def anchored_report(gpu, cpu32, ref64, factor=FACTOR, floor=FLOOR):
-    """gpu / cpu32 / ref64: {name: tensor or None}.  Returns (failures, rows) with rows = (ratio, name, err_gpu, err_cpu)."""
+def anchored_report(gpu, cpu32, ref64, factor=FACTOR, floor=FLOOR, spread=()):
+    """gpu / cpu32 / ref64: {name: tensor or None}.  Returns (failures, rows) with rows = (ratio, name, err_gpu, err_cpu).
+    spread: further fp32 CPU runs on inputs perturbed at round-off level (oracle_grads(perturb=...)): a tensor's fp32 error is then
+    the LARGEST over all fp32 runs -- where the network is chaotic (extreme BatchNorm scales over a few hundred samples: one ReLU
+    decision within round-off of zero moves a whole channel's statistics) one fp32 run is a single draw of a heavy-tailed lottery,
+    and the bound has to come from how far conforming fp32 implementations scatter, not from one of them."""
     errs = {}
     for n, r in ref64.items():
         if r is None:
             assert gpu.get(n) is None, "%s: the oracle has no gradient here, the engine produced one" % n
             continue
         assert gpu.get(n) is not None, "%s: missing gradient" % n
-        errs[n] = (rel_l2(gpu[n], r), rel_l2(cpu32[n], r))
+        ec = max([rel_l2(cpu32[n], r)] + [rel_l2(sp[n], r) for sp in spread])
+        errs[n] = (rel_l2(gpu[n], r), ec)
     stages = {}
     for n, (_, ec) in errs.items():
         stages.setdefault(stage_of(n), []).append(ec)
@@ -90,7 +109,7 @@ def anchored_report(gpu, cpu32, ref64, factor=FACTOR, floor=FLOOR):
     return bad, rows
 
 
-def tie_free_batch(cpu_batch, out64, depth_range=(0.1, 100.0), tie=TIE):
+def tie_free_batch(cpu_batch, out64, depth_range=(0.1, 100.0), tie=TIE, tie_sigma=TIE_SIGMA):
     """copy of the batch with the |.|-kink pixels of the depth losses removed from the valid masks (see the module docstring);
     out64: the float64 oracle's outputs (they do not depend on the targets).  Returns (batch, number of pixels removed)."""
     batch = OrderedDict((k, v.clone()) for k, v in cpu_batch.items())
@@ -101,7 +120,8 @@ def tie_free_batch(cpu_batch, out64, depth_range=(0.1, 100.0), tie=TIE):
         tiebrk = torch.zeros_like(t, dtype=torch.bool)
         for o in out64.values():
             d = 1.0 / (lo + (hi - lo) * o[:, ch].detach().double())
-            tiebrk |= ((d - t).abs() <= tie * d.clamp_min(1.0)) & (t > 0)
+            band = torch.maximum(tie * d.clamp_min(1.0), (hi - lo) * d * d * tie_sigma)
+            tiebrk |= ((d - t).abs() <= band) & (t > 0)
         removed += int(tiebrk.sum())
         batch[key][tiebrk] = 0.0
     batch["all_ground"] = ((batch["ground_depth"] + batch["visible_ground"]) > 0).float()      # kitti_dataset.py:114-122

@@ -34,13 +34,13 @@ def _reference(z, gamma, beta, rm, rv, res, dy, relu):
     y = F.batch_norm(z64.t()[None], rm64, rv64, g64, b64, True, 0.1, 1e-5)[0].t()        # [M, C] -> [1, C, M]
     if res is not None:
         y = y + res.double()
+    pre = y.detach()
     if relu:
         y = F.relu(y)
     y.backward(dy.double())
     # elements whose pre-activation is within fp32 round-off of the ReLU kink: their mask bit -- and with it one whole dz element --
     # is undetermined in any fp32 implementation (~1e-6 of 23.6 M elements at the largest shape); excluded from the dz comparison
-    pre = y.detach() if not relu else None
-    tie = (y.detach().abs() < 2e-5) if relu else torch.zeros_like(y, dtype=torch.bool)
+    tie = (pre.abs() < 2e-5) if relu else torch.zeros_like(pre, dtype=torch.bool)
     return y.detach(), z64.grad, g64.grad, b64.grad, rm64, rv64, tie
 
 
@@ -89,8 +89,9 @@ def test_fused_bn_against_float64(M, C, relu, with_res):
     e_dz = ((out["dz"].double().cpu() - dz).abs() * ok).max().item() / dz.abs().max().item()
     assert e_dz <= 1e-5, ("dz", e_dz, int(tie.sum()))
     assert int(tie.sum()) <= max(4, 2e-4 * tie.numel())
-    # a flipped tie element moves its channel's sums by one dy: bounded by (ties per channel) / (sum's magnitude)
-    assert _rel(out["dgamma"], dgam) <= 1e-4 and _rel(out["dbeta"], dbet) <= 1e-4
+    # a flipped tie element moves its channel's sums by one dy (* xhat for dgamma): |dy| <= 1, |xhat| <= ~4
+    slack = lambda ref: 1e-5 + 4.0 * int(tie.sum()) / ref.abs().max().item()
+    assert _rel(out["dgamma"], dgam) <= slack(dgam) and _rel(out["dbeta"], dbet) <= slack(dbet)
     mask = (y > 0).float() if relu else torch.ones_like(y)
     e_g = ((out["gout"].double().cpu() - case[6].double() * mask).abs() * ok).max().item()
     assert e_g <= 1e-7
