@@ -48,6 +48,10 @@ struct IgemmArgs {
   // walks only that class's taps: 2.25 taps per pixel on average instead of 9 with three quarters of them all-zero.
   int pm, Mc, McP;
   unsigned* amax_out;     // split-K reduce only: amax slot receiving max |y| (fp16-pair consumers), or null
+  // igemm_hp_kernel (fp16-pair operands): packed weights [tap][chunk][2 planes][Nout][16] fp16 and the two operand amax slots
+  const unsigned short* w_hp;
+  const unsigned* amax_a;
+  const unsigned* amax_w;
 };
 
 // row of the parity-major enumeration -> class (cpy, cpx), validity, (n, oy, ox)
@@ -80,6 +84,96 @@ __device__ __forceinline__ float igemm_epilogue(const IgemmArgs& a, size_t o, in
   if (a.act == FP_ACT_RELU) v = fmaxf(v, 0.f);
   if (a.epi & FP_EPI_ACCUM) v += a.y[o];
   return v;
+}
+
+// ---- shared epilogue of the flattened kernels.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+// unscale: power of two the accumulators are multiplied by before the bias (1 for fp32 operands: fmaf(acc, 1, bias) == acc + bias)
+template <int TM, int TN>
+__device__ __forceinline__ void igemm_store_tile(const IgemmArgs& a, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int idx, int h, int split,
+                                                 float unscale) {
+  const FpGeom& g = a.g;
+  // flag tests hoisted, optional operands of eight rows loaded before any arithmetic (element-at-a-time code serialises the
+  // load latencies; see conv3x3_tile_bf3.hip)
+  const unsigned epi = a.SK > 1 ? 0u : a.epi;
+  const int act = a.SK > 1 ? 0 : a.act;
+  float* const dst = a.SK > 1 ? a.part + (size_t)split * a.M * a.Nout : a.y;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + (wn * TN + j) * 32 + idx;
+      if (n >= a.Nout) continue;
+      const float bias = (epi & FP_EPI_BIAS) ? a.bias[n] : 0.f;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        size_t off[8];
+        bool ok[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int r = half * 8 + k;
+          const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (a.pm) {
+            int en, ey, ex;
+            ok[k] = pm_decode(a, m, en, ey, ex);
+            off[k] = ((size_t)(en * g.OH + ey) * g.OW + ex) * a.Nout + n;
+            continue;
+          }
+          ok[k] = m < a.M;
+          off[k] = (size_t)min(m, a.M - 1) * a.Nout + n;
+        }
+        float ad[8], mk[8], sv[8], yo[8];
+        if (epi & FP_EPI_ADDEND) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) ad[k] = a.addend[off[k]];
+        }
+        if (epi & FP_EPI_ADDEND_MASK) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) mk[k] = a.addend_mask[off[k]];
+        }
+        if (epi & (FP_EPI_ACTGRAD_ELU | FP_EPI_ACTGRAD_RELU)) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) sv[k] = a.actsrc[off[k]];
+        }
+        if (epi & FP_EPI_ACCUM) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) yo[k] = a.y[off[k]];
+        }
+        float v[8];                                   // one wave-uniform branch per flag around an 8-element body
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = fmaf(acc[i][j][half * 8 + k], unscale, bias);
+        if (epi & FP_EPI_ADDEND) {
+          if (epi & FP_EPI_ADDEND_MASK) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] += mk[k] > 0.f ? ad[k] : 0.f;
+          } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] += ad[k];
+          }
+        }
+        if (epi & FP_EPI_ACTGRAD_ELU) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] *= (sv[k] > 0.f ? 1.f : sv[k] + 1.f);
+        }
+        if (epi & FP_EPI_ACTGRAD_RELU) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] = sv[k] > 0.f ? v[k] : 0.f;
+        }
+        if (act == FP_ACT_ELU) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] = fp_elu(v[k]);
+        } else if (act == FP_ACT_RELU) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+        }
+        if (epi & FP_EPI_ACCUM) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] += yo[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (ok[k]) dst[off[k]] = v[k];
+      }
+    }
 }
 
 constexpr int LD = 20;
@@ -226,89 +320,180 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmArgs a) {
     __syncthreads();
   }
 
-  // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
-  // flag tests hoisted, optional operands of eight rows loaded before any arithmetic (element-at-a-time code serialises the
-  // load latencies; see conv3x3_tile_bf3.hip)
-  const unsigned epi = a.SK > 1 ? 0u : a.epi;
-  const int act = a.SK > 1 ? 0 : a.act;
-  float* const dst = a.SK > 1 ? a.part + (size_t)split * a.M * a.Nout : a.y;
+  igemm_store_tile<TM, TN>(a, acc, m0, n0, wm, wn, idx, h, split, 1.f);
+}
+
+// ---- fp16-pair variant (round 3): the same flattened implicit GEMM for the convolutions the halo-tile kernel does not take -- 3x3 stride 2,
+// 1x1 (any stride), and their data gradients (zero-padding gathers, parity-major rows included) -- with the operand format of
+// conv3x3_tile_bf3.hip: x * 2^ka = h + m in fp16 (per-tensor exponent from the source's amax slot), weights from the FP_PACK_{FWD,DGRAD}_HP
+// planes, three v_mfma_f32_32x32x16_f16 products per 16-channel K-step instead of sixteen v_mfma_f32_32x32x2_f32: 192 MFMA cycles per step
+// and wave instead of 1024.  A operand: gathered fp32 -> two fp16 planes in LDS ([plane][row][16 + 8 pad]: 48-byte rows, a lane's
+// 16-byte fragment read is conflict-free); B operand: straight from the packed planes (L1 / L2 resident, 1 KB contiguous per wave and
+// plane), one K-step ahead in registers.  Two K-steps (32 channels) per barrier.
+typedef _Float16 ig_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 ig_f16x4 __attribute__((ext_vector_type(4)));
+typedef float ig_f32x4 __attribute__((ext_vector_type(4)));
+constexpr int HPROW = 48;      // bytes per row and plane
+
+template <int BM, int BN, int WM, int WN>
+__global__ void __launch_bounds__(256) igemm_hp_kernel(const IgemmArgs a) {
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int AV = BM / 64;
+  constexpr int PLANE = BM * HPROW, STEPB = 2 * PLANE;     // one K-step = two planes
+  static_assert(WM * WN == 4, "4 waves");
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * STEPB];      // [buffer 2][K-step 2][plane 2][BM][48]
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int idx = lane & 31, h = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+  const int wg = fp_xcd_remap(blockIdx.x, a.nwg);
+  const int split = wg % a.SK, tile = wg / a.SK;
+  const int tile_n = tile % a.tilesN, tile_m = tile / a.tilesN;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const FpGeom& g = a.g;
+  const int ka = fp_hp_exponent(fp_amax_bits(a.amax_a), FP_HP_TARGET_ACT);
+  const int kunscale = -(ka + fp_hp_exponent(fp_amax_bits(a.amax_w), FP_HP_TARGET_W));
+
+  const int q = t & 3;
+  int pn[AV], py[AV], px[AV];
+  bool pvalid[AV];
+#pragma unroll
+  for (int i = 0; i < AV; ++i) {
+    const int m = m0 + (t >> 2) + 64 * i;
+    if (a.pm) {
+      pvalid[i] = pm_decode(a, m, pn[i], py[i], px[i]);
+      continue;
+    }
+    pvalid[i] = m < a.M;
+    const int mm = pvalid[i] ? m : 0;
+    const int ox = mm % g.OW, r = mm / g.OW;
+    px[i] = ox;
+    py[i] = r % g.OH;
+    pn[i] = r / g.OH;
+  }
+  const int pm_cls = a.pm ? m0 / a.McP : 0;
+  const int pm_odd_y = (1 - (pm_cls >> 1) + g.pad) & 1, pm_odd_x = (1 - (pm_cls & 1) + g.pad) & 1;
+  const int pm_ny = pm_odd_y ? 1 : 2, pm_nx = pm_odd_x ? 1 : 2;
+  auto pm_tap = [&](int lt) {
+    const int ly = lt / pm_nx, lx = lt - ly * pm_nx;
+    return (pm_odd_y ? 1 : 2 * ly) * 3 + (pm_odd_x ? 1 : 2 * lx);
+  };
+  int pix[AV][4], pix1[AV];
+  auto set_tap = [&](int tap) {
+    const int ky = tap / g.KW, kx = tap - ky * g.KW;
+#pragma unroll
+    for (int i = 0; i < AV; ++i) {
+      fp_gather_tap(g, pn[i], py[i], px[i], ky, kx, pix[i], pix1[i]);
+      if (!pvalid[i]) { pix[i][0] = pix[i][1] = pix[i][2] = pix[i][3] = -1; pix1[i] = -1; }
+    }
+  };
+
+  // a "pair" = two consecutive K-steps (tap, chunk), staged and consumed together: one barrier per 32 channels
+  float4 areg[2][AV];
+  uint4 breg[2][TN][2];
+  int ltap, lcc, tap;
+  auto advance = [&]() {
+    if (++lcc == a.KC16) { lcc = 0; ++ltap; tap = a.pm ? pm_tap(ltap) : ltap; set_tap(tap); }
+  };
+  auto load_half = [&](int u, bool valid) {              // gathers for the current (tap, lcc) into register set u (zeros past the split's end)
+#pragma unroll
+    for (int i = 0; i < AV; ++i)
+      areg[u][i] = valid ? fp_gather_load4(g, a.src0, nullptr, pix[i], pix1[i], lcc * 16 + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const unsigned short* ws = a.w_hp + (size_t)(tap * a.KC16 + lcc) * 2 * a.Nout * 16 + h * 8;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = min(n0 + (wn * TN + j) * 32 + idx, a.Nout - 1);
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+        breg[u][j][p] = valid ? *reinterpret_cast<const uint4*>(ws + ((size_t)p * a.Nout + n) * 16) : make_uint4(0u, 0u, 0u, 0u);
+    }
+  };
+  auto store_half = [&](int buf, int u) {                // fp32 -> scaled fp16 pair, 8 bytes per plane and slot
+#pragma unroll
+    for (int i = 0; i < AV; ++i) {
+      ig_f32x4 v = {areg[u][i].x, areg[u][i].y, areg[u][i].z, areg[u][i].w};
+      v = ig_f32x4{ldexpf(v.x, ka), ldexpf(v.y, ka), ldexpf(v.z, ka), ldexpf(v.w, ka)};
+      const ig_f16x4 vh = __builtin_convertvector(v, ig_f16x4);
+      const ig_f32x4 r1 = v - __builtin_convertvector(vh, ig_f32x4);
+      const ig_f16x4 vm = __builtin_convertvector(r1, ig_f16x4);
+      unsigned char* p = lds + (buf * 2 + u) * STEPB + ((t >> 2) + 64 * i) * HPROW + q * 8;
+      *reinterpret_cast<uint2*>(p) = __builtin_bit_cast(uint2, vh);
+      *reinterpret_cast<uint2*>(p + PLANE) = __builtin_bit_cast(uint2, vm);
+    }
+  };
+
+  f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = n0 + (wn * TN + j) * 32 + idx;
-      if (n >= a.Nout) continue;
-      const float bias = (epi & FP_EPI_BIAS) ? a.bias[n] : 0.f;
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        size_t off[8];
-        bool ok[8];
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int total_steps = (a.pm ? pm_ny * pm_nx : a.T) * a.KC16;
+  const int s_begin = split * a.stepsPerSplit;
+  const int steps = a.pm ? total_steps : min(a.stepsPerSplit, total_steps - s_begin);
+  const int pairs = (steps + 1) >> 1;
+  ltap = s_begin / a.KC16;
+  lcc = s_begin - ltap * a.KC16;
+  tap = a.pm ? pm_tap(ltap) : ltap;
+  set_tap(tap);
+  // the loads of a pair: step 2p (always valid) and step 2p + 1 (zeros when the split has an odd number of steps)
+  auto load_pair = [&](int pr) {
+    load_half(0, true);
+    const bool v1 = 2 * pr + 1 < steps;
+    if (v1) advance();
+    load_half(1, v1);
+    if (2 * pr + 2 < steps) advance();
+  };
+  uint4 bcur[2][TN][2];
+  load_pair(0);
+  store_half(0, 0);
+  store_half(0, 1);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const int r = half * 8 + k;
-          const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          if (a.pm) {
-            int en, ey, ex;
-            ok[k] = pm_decode(a, m, en, ey, ex);
-            off[k] = ((size_t)(en * g.OH + ey) * g.OW + ex) * a.Nout + n;
-            continue;
-          }
-          ok[k] = m < a.M;
-          off[k] = (size_t)min(m, a.M - 1) * a.Nout + n;
-        }
-        float ad[8], mk[8], sv[8], yo[8];
-        if (epi & FP_EPI_ADDEND) {
+  for (int u = 0; u < 2; ++u)
 #pragma unroll
-          for (int k = 0; k < 8; ++k) ad[k] = a.addend[off[k]];
-        }
-        if (epi & FP_EPI_ADDEND_MASK) {
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
-          for (int k = 0; k < 8; ++k) mk[k] = a.addend_mask[off[k]];
-        }
-        if (epi & (FP_EPI_ACTGRAD_ELU | FP_EPI_ACTGRAD_RELU)) {
+      for (int p = 0; p < 2; ++p) bcur[u][j][p] = breg[u][j][p];
+  __syncthreads();
+
+  for (int pr = 0; pr < pairs; ++pr) {
+    const bool more = pr + 1 < pairs;
+    if (more) load_pair(pr + 1);                       // global loads of the next pair stay in flight under this pair's MFMAs
 #pragma unroll
-          for (int k = 0; k < 8; ++k) sv[k] = a.actsrc[off[k]];
-        }
-        if (epi & FP_EPI_ACCUM) {
+    for (int u = 0; u < 2; ++u) {
+      const unsigned char* Ab = lds + ((pr & 1) * 2 + u) * STEPB + ((wm * TM) * 32 + idx) * HPROW + h * 16;
+      uint4 af[TM][2];
 #pragma unroll
-          for (int k = 0; k < 8; ++k) yo[k] = a.y[off[k]];
-        }
-        float v[8];                                   // one wave-uniform branch per flag around an 8-element body
+      for (int p = 0; p < 2; ++p)
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = acc[i][j][half * 8 + k] + bias;
-        if (epi & FP_EPI_ADDEND) {
-          if (epi & FP_EPI_ADDEND_MASK) {
+        for (int i = 0; i < TM; ++i) af[i][p] = *reinterpret_cast<const uint4*>(Ab + p * PLANE + i * 32 * HPROW);
+      // products mh, hm, hh (smallest first), as in conv3x3_tile_bf3.hip
+      constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] += mk[k] > 0.f ? ad[k] : 0.f;
-          } else {
+      for (int qd = 0; qd < 3; ++qd)
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] += ad[k];
-          }
-        }
-        if (epi & FP_EPI_ACTGRAD_ELU) {
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int k = 0; k < 8; ++k) v[k] *= (sv[k] > 0.f ? 1.f : sv[k] + 1.f);
-        }
-        if (epi & FP_EPI_ACTGRAD_RELU) {
-#pragma unroll
-          for (int k = 0; k < 8; ++k) v[k] = sv[k] > 0.f ? v[k] : 0.f;
-        }
-        if (act == FP_ACT_ELU) {
-#pragma unroll
-          for (int k = 0; k < 8; ++k) v[k] = fp_elu(v[k]);
-        } else if (act == FP_ACT_RELU) {
-#pragma unroll
-          for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
-        }
-        if (epi & FP_EPI_ACCUM) {
-#pragma unroll
-          for (int k = 0; k < 8; ++k) v[k] += yo[k];
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-          if (ok[k]) dst[off[k]] = v[k];
-      }
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(ig_f16x8, af[i][PA[qd]]), __builtin_bit_cast(ig_f16x8, bcur[u][j][PB[qd]]),
+                                                               acc[i][j], 0, 0, 0);
     }
+    if (more) {
+      store_half((pr + 1) & 1, 0);
+      store_half((pr + 1) & 1, 1);
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int p = 0; p < 2; ++p) bcur[u][j][p] = breg[u][j][p];
+    }
+    __syncthreads();
+  }
+  igemm_store_tile<TM, TN>(a, acc, m0, n0, wm, wn, idx, h, split, ldexpf(1.f, kunscale));
 }
 
 // y = epilogue(sum_s part[s]) -- fixed summation order
@@ -361,6 +546,30 @@ int launch(IgemmArgs& a, hipStream_t stream, int64_t ws_floats) {
     fp_launch(splitk_reduce_kernel, dim3((int)g), dim3(256), 0, stream, a);
   }
   return fp_check_launch("fp_conv_igemm");
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_hp(IgemmArgs& a, hipStream_t stream, int64_t ws_floats) {
+  int tilesM = (int)fp_ceil_div(a.M, BM);
+  if (a.pm) {
+    a.McP = (int)fp_ceil_div(a.Mc, BM) * BM;
+    tilesM = 4 * (a.McP / BM);
+    ws_floats = 0;
+  }
+  a.tilesN = (int)fp_ceil_div(a.Nout, BN);
+  const int steps = a.T * a.KC16;
+  const int sk = pick_splitk((int64_t)tilesM * a.tilesN, steps, (int64_t)a.M * a.Nout, ws_floats);
+  a.stepsPerSplit = (int)fp_ceil_div(steps, sk);
+  a.stepsPerSplit += a.stepsPerSplit & 1;            // whole pairs of K-steps per split
+  a.SK = (int)fp_ceil_div(steps, a.stepsPerSplit);
+  a.nwg = tilesM * a.tilesN * a.SK;
+  fp_launch((igemm_hp_kernel<BM, BN, WM, WN>), dim3(a.nwg), dim3(256), 0, stream, a);
+  if (a.SK > 1) {
+    int64_t g = fp_ceil_div((int64_t)a.M * a.Nout, 256);
+    if (g > 4096) g = 4096;
+    fp_launch(splitk_reduce_kernel, dim3((int)g), dim3(256), 0, stream, a);
+  }
+  return fp_check_launch("fp_conv_igemm_hp");
 }
 
 // worst-case split-K workspace: the launcher never uses more than 24 partial copies of the output
@@ -457,4 +666,51 @@ extern "C" int fp_conv_igemm(const fp_conv_desc* d, const float* src0, const flo
   if (d->Nout % 128 == 0 && t128 * (d->Nout / 128) >= 256) return launch<128, 128, 2, 2, false>(a, stream, ws);
   if (M >= 256) return launch<128, 64, 2, 2, false>(a, stream, ws);   // small grids are filled by split-K
   return launch<64, 64, 2, 2, false>(a, stream, ws);
+}
+
+// ---- fp16-pair operands for the flattened kernel (round 3): 3x3 stride-2 / 1x1 convolutions and their data gradients ------------------
+// Same operation and epilogue flags as fp_conv_igemm for zero-padding gathers of ONE source tensor (FP_GATHER_FWD_ZERO / FP_GATHER_DGRAD_ZERO,
+// C1 = 0, C0 a multiple of 4); weights from FP_PACK_FWD_HP / FP_PACK_DGRAD_HP jobs (any kernel size) with the slot `amax_w` they were scaled
+// by; `amax_src` holds max |src|.  Replaces aten::convolution / convolution_backward(data) of torchvision's stride-2 BasicBlock convs and
+// 1x1 downsample convs (footprints/network.py:38-44) on the fp16 matrix path instead of the fp32 one.
+extern "C" int fp_conv_igemm_hp_supported(const fp_conv_desc* d) {
+  if (!d || d->C1 != 0 || d->C0 <= 0 || d->C0 % 4 || d->Nout <= 0) return 0;
+  if (d->gather != FP_GATHER_FWD_ZERO && d->gather != FP_GATHER_DGRAD_ZERO) return 0;
+  return 1;
+}
+
+extern "C" int fp_conv_igemm_hp(const fp_conv_desc* d, const float* src, const void* wpacked_hp, const float* bias, const float* addend,
+                                const float* addend_mask, const float* actsrc, float* y, void* workspace, int64_t workspace_bytes,
+                                const uint32_t* amax_src, const uint32_t* amax_w, fp_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  FP_REQUIRE(d && src && wpacked_hp && y && amax_src && amax_w, "fp_conv_igemm_hp: null pointer");
+  FP_REQUIRE(fp_conv_igemm_hp_supported(d), "fp_conv_igemm_hp: shape / gather not supported (see fp_conv_igemm_hp_supported)");
+  FP_REQUIRE(!(d->epi & FP_EPI_BIAS) || bias, "fp_conv_igemm_hp: bias flag without pointer");
+  FP_REQUIRE(!(d->epi & FP_EPI_ADDEND) || addend, "fp_conv_igemm_hp: addend flag without pointer");
+  FP_REQUIRE(!(d->epi & FP_EPI_ADDEND_MASK) || addend_mask, "fp_conv_igemm_hp: addend_mask flag without pointer");
+  FP_REQUIRE(!(d->epi & (FP_EPI_ACTGRAD_ELU | FP_EPI_ACTGRAD_RELU)) || actsrc, "fp_conv_igemm_hp: actgrad flag without pointer");
+  const int64_t M64 = (int64_t)d->N * d->OH * d->OW;
+  FP_REQUIRE(M64 > 0 && M64 < (int64_t)1 << 31 && M64 * d->Nout < (int64_t)1 << 40, "fp_conv_igemm_hp: problem too large / empty");
+  IgemmArgs a = {};
+  a.src0 = src; a.w_hp = (const unsigned short*)wpacked_hp; a.bias = bias; a.addend = addend; a.addend_mask = addend_mask; a.actsrc = actsrc; a.y = y;
+  a.amax_a = amax_src; a.amax_w = amax_w; a.amax_out = nullptr;
+  a.g = FpGeom{d->N, d->OH, d->OW, d->IH, d->IW, d->C0, 0, d->KH, d->KW, d->stride, d->pad, d->gather};
+  a.Nout = d->Nout; a.act = d->act; a.epi = d->epi;
+  a.M = (int)M64;
+  a.T = d->KH * d->KW;
+  a.KC16 = (d->C0 + 15) / 16;
+  a.part = (float*)workspace;
+  a.SK = 1;
+  static const bool no_pm = getenv("FP_NO_PM") && atoi(getenv("FP_NO_PM"));
+  a.pm = !no_pm && d->gather == FP_GATHER_DGRAD_ZERO && d->stride == 2 && d->KH == 3 && d->KW == 3 && d->OH % 2 == 0 && d->OW % 2 == 0 &&
+         d->IH * 2 == d->OH && d->IW * 2 == d->OW;
+  a.Mc = a.pm ? d->N * (d->OH / 2) * (d->OW / 2) : 0;
+  a.McP = a.Mc;
+  int64_t ws = workspace ? workspace_bytes / (int64_t)sizeof(float) : 0;
+  if (ws > MAX_SK * M64 * d->Nout) ws = MAX_SK * M64 * d->Nout;
+  if (d->Nout <= 32) return launch_hp<128, 32, 4, 1>(a, stream, ws);
+  const int64_t t128 = fp_ceil_div(M64, 128);
+  if (d->Nout % 128 == 0 && t128 * (d->Nout / 128) >= 256) return launch_hp<128, 128, 2, 2>(a, stream, ws);
+  if (M64 >= 256) return launch_hp<128, 64, 2, 2>(a, stream, ws);
+  return launch_hp<64, 64, 2, 2>(a, stream, ws);
 }

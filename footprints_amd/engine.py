@@ -42,6 +42,8 @@ _HP = _BF3 and bool(int(os.environ.get("FP_HP", "1")))
 # bf16 split while forward / data-gradient use fp16 pairs; FP_HP_TILE=0 the other way round
 _HP_WGRAD = _HP and bool(int(os.environ.get("FP_HP_WGRAD", "1")))
 _HP_TILE = _HP and bool(int(os.environ.get("FP_HP_TILE", "1")))
+# fp16 pairs also for the stride-2 3x3 / 1x1 convolutions and their data gradients (fp_conv_igemm_hp, round 3); FP_HP_IGEMM=0: fp32 MFMA
+_HP_IGEMM = _HP and bool(int(os.environ.get("FP_HP_IGEMM", "1")))
 # the 1x1 downsample branch of a BasicBlock (conv -> BN, and its gradients) on the aux stream beside the block's main branch: the encoder
 # is the serial spine of the step (one kernel on the GPU at a time), the aux stream idles until the decoders start.  FP_DS_AUX=0: in line
 _DS_AUX = bool(int(os.environ.get("FP_DS_AUX", "1")))
@@ -75,6 +77,8 @@ class ConvRec:
         self.wp3 = self.wpd3 = self.wsk3 = self.wds3 = self.wph3 = self.wdu3 = None
         # fp16-pair copies of the same four tile packings, and the slot holding max |w| they were scaled by
         self.hp = self.bf3 and _HP
+        # ... and of the flattened-kernel packings for the convolutions the tile kernel does not take (3x3 stride 2, 1x1): fp_conv_igemm_hp
+        self.hp_ig = _HP_IGEMM and not self.bf3 and not stem and not head and self.K in (1, 3)
         self.hp_f = self.hp_d = self.hp_sk = self.hp_ds = self.hp_ph = self.hp_du = None      # + phase forward / phase data-gradient
         self.wslot = None
         self.gw = None    # gradient views (flat grad buffer)
@@ -388,9 +392,9 @@ class Engine:
                            ops.up2_packed_weight_elems(C0, c.Cout) * 3 // 2]
             else:
                 ex += [0, 0, 0, 0, 0, 0]
-            if c.hp:      # fp16-pair copies of the tile packings (same roles as wp3 / wpd3 / wsk3 / wds3)
+            if c.hp or c.hp_ig:      # fp16-pair copies of the tile packings (same roles as wp3 / wpd3 / wsk3 / wds3)
                 if c.up2 is None:
-                    ex += [ops.packed_weight_elems_hp(c.Cout, c.Cin, 3, False), ops.packed_weight_elems_hp(c.Cout, c.Cin, 3, True), 0, 0, 0, 0]
+                    ex += [ops.packed_weight_elems_hp(c.Cout, c.Cin, c.K, False), ops.packed_weight_elems_hp(c.Cout, c.Cin, c.K, True), 0, 0, 0, 0]
                 else:
                     C0, C1 = c.up2
                     ex += [ops.packed_weight_elems_hp(c.Cout, c.Cin, 3, False) if C1 else 0, 0,
@@ -429,7 +433,7 @@ class Engine:
                     jobs.append((L.PACK_STEM if c.stem else L.PACK_FWD, c.w.data, c.wp, 0, c.Cin))
                     if c.wpd is not None:
                         jobs.append((L.PACK_DGRAD, c.w.data, c.wpd, 0, c.Cin))
-                    if c.hp:                 # fp16-pair tile packings, scaled by the weight tensor's amax slot
+                    if c.hp or c.hp_ig:      # fp16-pair packings, scaled by the weight tensor's amax slot
                         if c.hp_f is not None:
                             jobs.append((L.PACK_FWD_HP, c.w.data, c.hp_f, 0, c.Cin, c.wslot))
                         if c.hp_d is not None:
@@ -576,6 +580,8 @@ class Engine:
             if use_hp:
                 return self._cv_hp(d, src, hp[0], hp[1], out, publish=publish, **kw)
             return ops.conv3x3_bf3(d, src, w3, out, **kw)
+        if _HP_IGEMM and hp is not None and hp[0] is not None and not ops._bf16x2 and ops.conv_igemm_hp_supported(d):
+            return ops.conv_igemm_hp(d, src, hp[0], out, self.amax.get(src), hp[1], **kw)
         return ops.conv_igemm(d, src, None, w32, out, **kw)
 
     def _sink_slot(self, t):
@@ -615,7 +621,7 @@ class Engine:
             total = 0
             for c, _ in pairs:
                 n3 = ops.packed_weight_elems_bf3(c.Cout, c.Cin, 3, False) if c.bf3 else 0
-                n3 += ops.packed_weight_elems_hp(c.Cout, c.Cin, 3, False) if c.hp else 0
+                n3 += ops.packed_weight_elems_hp(c.Cout, c.Cin, c.K, False) if (c.hp or c.hp_ig) else 0
                 total += c.w.numel() + ops.packed_weight_elems(c.Cout, c.Cin, c.K, False, c.stem) + n3 + c.Cout
             self._fold_buf = torch.empty(total, device=self.device)
             o = 0
@@ -629,7 +635,7 @@ class Engine:
                 n = ops.packed_weight_elems_bf3(c.Cout, c.Cin, 3, False) if c.bf3 else 0
                 c.fwp3 = self._fold_buf[o:o + n] if n else None
                 o += n
-                n = ops.packed_weight_elems_hp(c.Cout, c.Cin, 3, False) if c.hp else 0
+                n = ops.packed_weight_elems_hp(c.Cout, c.Cin, c.K, False) if (c.hp or c.hp_ig) else 0
                 c.fhp = self._fold_buf[o:o + n] if n else None
                 o += n
                 c.fslot = torch.zeros(ops.amax_elems(), dtype=torch.int32, device=self.device) if n else None
@@ -673,12 +679,16 @@ class Engine:
             if blk.ds is not None:
                 dd = ops.make_desc(N, oh, ow, h, w, blk.ds.Cin, 0, blk.Cout, 1, s, 0, L.GATHER_FWD_ZERO)
                 if self.concurrent and _DS_AUX:           # 1x1 shortcut beside conv1 on the (still idle) aux stream
+                    if _HP_IGEMM:
+                        self.amax.get(x, any_stream=True)
                     ops.event_wait(self.aux, self._record(ops.current_stream()))
                     with ops.on_stream(self.aux):
-                        idt = self._cv(dd, x, blk.ds.fwp, None, buf("b%d.idt" % i, (N, oh, ow, blk.Cout)), bias=blk.bnd.fshift)
+                        idt = self._cv(dd, x, blk.ds.fwp, None, buf("b%d.idt" % i, (N, oh, ow, blk.Cout)), hp=(blk.ds.fhp, blk.ds.fslot),
+                                       bias=blk.bnd.fshift)
                         ev_idt = self._record(self.aux)
                 else:
-                    idt = self._cv(dd, x, blk.ds.fwp, None, buf("b%d.idt" % i, (N, oh, ow, blk.Cout)), bias=blk.bnd.fshift)
+                    idt = self._cv(dd, x, blk.ds.fwp, None, buf("b%d.idt" % i, (N, oh, ow, blk.Cout)), hp=(blk.ds.fhp, blk.ds.fslot),
+                                   bias=blk.bnd.fshift)
             else:
                 idt = x
             a1 = self._cv(d1, x, blk.c1.fwp, blk.c1.fwp3, buf("b%d.a1" % i, (N, oh, ow, blk.Cout)), hp=(blk.c1.fhp, blk.c1.fslot),
@@ -797,6 +807,8 @@ class Engine:
                 zd_ = self._conv_enc(blk.ds, x, N, h, w, buf("b%d.zd" % i, (N, oh, ow, blk.Cout)))
                 return zd_, self._bn(blk.bnd, zd_, buf("b%d.idt" % i, (N, oh, ow, blk.Cout)), training, relu=False)
             if blk.ds is not None and self.concurrent and _DS_AUX:       # downsample branch beside conv1 / conv2 (joined before the residual add)
+                if _HP_IGEMM:
+                    self.amax.get(x, any_stream=True)                    # published on this stream; the aux stream is ordered behind it below
                 ops.event_wait(self.aux, self._record(ops.current_stream()))
                 with ops.on_stream(self.aux):
                     zd, idt = shortcut()
@@ -1070,10 +1082,13 @@ class Engine:
                 with ops.on_stream(self.aux):
                     dzd = buf("g.dzd.%d" % i, (N, h, w, C))
                     ops.bn_bwd(g.view(M, C), None, B["zd"].view(M, C), blk.bnd.mean, blk.bnd.invstd, blk.bnd.bn.weight.data,
-                               dzd.view(M, C), blk.bnd.gg, blk.bnd.gb, accumulate=accumulate)
+                               dzd.view(M, C), blk.bnd.gg, blk.bnd.gb, accumulate=accumulate,
+                               amax_out=self._sink_slot(dzd) if blk.ds.hp_ig else None)
+                    if blk.ds.hp_ig:
+                        self._sink_done(dzd)
                     self._wgrad(blk.ds, L.GATHER_FWD_ZERO, B["x"], None, dzd, N, h, w, hin, win, Cin, 0, accumulate, side)
                     d1 = ops.make_desc(N, hin, win, h, w, C, 0, Cin, 1, blk.stride, 0, L.GATHER_DGRAD_ZERO, epi=L.EPI_ACCUM)
-                    ops.conv_igemm(d1, dzd, None, blk.ds.wpd, tgt)
+                    self._cv(d1, dzd, blk.ds.wpd, None, tgt, hp=(blk.ds.hp_d, blk.ds.wslot))
                     ev_ds = self._record(self.aux)
             self._wgrad(blk.c2, L.GATHER_FWD_ZERO, B["a1"], None, dz2, N, h, w, h, w, C, 0, accumulate, side)
             da1 = buf("g.da1", (N, h, w, C))
@@ -1094,13 +1109,16 @@ class Engine:
             elif blk.ds is not None:
                 dzd = buf("g.dzd.%d" % i, (N, h, w, C))
                 ops.bn_bwd(g.view(M, C), None, B["zd"].view(M, C), blk.bnd.mean, blk.bnd.invstd, blk.bnd.bn.weight.data,
-                           dzd.view(M, C), blk.bnd.gg, blk.bnd.gb, accumulate=accumulate)
+                           dzd.view(M, C), blk.bnd.gg, blk.bnd.gb, accumulate=accumulate,
+                           amax_out=self._sink_slot(dzd) if blk.ds.hp_ig else None)
+                if blk.ds.hp_ig:
+                    self._sink_done(dzd)
                 self._wgrad(blk.ds, L.GATHER_FWD_ZERO, B["x"], None, dzd, N, h, w, hin, win, Cin, 0, accumulate, side)
                 tgt = dF[feat_of_block[i - 1]]          # block input is the previous layer's feature (already holds decoder grads)
                 dgd.epi = L.EPI_ACCUM
                 self._cv(dgd, dz1, blk.c1.wpd, blk.c1.wpd3, tgt, hp=(blk.c1.hp_d, blk.c1.wslot))
                 d1 = ops.make_desc(N, hin, win, h, w, C, 0, Cin, 1, blk.stride, 0, L.GATHER_DGRAD_ZERO, epi=L.EPI_ACCUM)
-                ops.conv_igemm(d1, dzd, None, blk.ds.wpd, tgt)
+                self._cv(d1, dzd, blk.ds.wpd, None, tgt, hp=(blk.ds.hp_d, blk.ds.wslot))
                 dnext = None
             elif first_of_layer:                        # layer1 block 0: input is the max-pool output
                 dpool = buf("g.dpool", (N, hin, win, Cin))

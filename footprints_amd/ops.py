@@ -141,6 +141,32 @@ def conv_igemm(desc, src0, src1, wpacked, y, bias=None, addend=None, addend_mask
     return y
 
 
+def conv_igemm_hp_supported(desc):
+    return bool(_cached_query("fp_conv_igemm_hp_supported", desc))
+
+
+def conv_igemm_hp(desc, src, wpacked_hp, y, amax_src, amax_w, bias=None, addend=None, addend_mask=None, actsrc=None):
+    """flattened implicit GEMM with fp16-pair operands (3x3 stride 2, 1x1, their data gradients): weights from FP_PACK_{FWD,DGRAD}_HP"""
+    lib = _lib.load()
+    epi = desc.epi
+    if bias is not None:
+        epi |= _lib.EPI_BIAS
+    if addend is not None:
+        epi |= _lib.EPI_ADDEND
+    if addend_mask is not None:
+        epi |= _lib.EPI_ADDEND_MASK
+    d = ConvDesc.from_buffer_copy(desc)
+    d.epi = epi
+    need = 0 if _NO_SPLITK else _cached_query("fp_conv_igemm_workspace", d)
+    ws_ptr, ws_n = 0, 0
+    if need > 0:
+        ws = workspace(need, y.device, "igemm")
+        ws_ptr, ws_n = ws.data_ptr(), ws.numel()
+    _lib.check(lib.fp_conv_igemm_hp(C.byref(d), _f32(src, "src"), _chk(wpacked_hp, "wpacked_hp"), _f32(bias), _f32(addend), _f32(addend_mask),
+                                    _f32(actsrc), _f32(y, "y"), ws_ptr, ws_n, _u32(amax_src), _u32(amax_w), stream()), "fp_conv_igemm_hp")
+    return y
+
+
 def conv3x3_bf3_supported(desc):
     return bool(_cached_query("fp_conv3x3_bf3_supported", desc))
 

@@ -286,6 +286,16 @@ int fp_bn_eval_coeffs(const float* gamma, const float* beta, const float* runnin
  * conv's bias), so inference runs conv + bias + ReLU (+ residual) in one launch -- SURVEY.md section 8(f) N1. */
 int fp_scale_rows(const float* w, const float* scale, float* out, int64_t rows, int64_t inner, fp_stream_t stream);
 /* y = [relu](z*scale + shift [+ residual]) */
+/* fp16-pair operands for the flattened implicit GEMM (round 3): the 3x3 stride-2 and 1x1 convolutions of torchvision's BasicBlocks
+ * (footprints/network.py:38-44) and their data gradients -- everything fp_conv3x3_hp does not take -- on the fp16 matrix path instead of
+ * the fp32 one.  Same operation / epilogue flags / split-K workspace as fp_conv_igemm for zero-padding gathers of one source tensor
+ * (FP_GATHER_FWD_ZERO, FP_GATHER_DGRAD_ZERO; C1 = 0); weights from FP_PACK_FWD_HP / FP_PACK_DGRAD_HP jobs (any kernel size) with the
+ * slot `amax_w` they were scaled by; `amax_src` holds max |src| (fp_amax_f32 or a producer's publication). */
+int fp_conv_igemm_hp_supported(const fp_conv_desc* d);
+int fp_conv_igemm_hp(const fp_conv_desc* d, const float* src, const void* wpacked_hp, const float* bias, const float* addend,
+                     const float* addend_mask, const float* actsrc, float* y, void* workspace, int64_t workspace_bytes,
+                     const uint32_t* amax_src, const uint32_t* amax_w, fp_stream_t stream);
+
 /* Fused train-mode BatchNorm: statistics, their combination and the normalisation (fp_bn_train_stats + fp_bn_apply; fp_bn_bwd's three
  * stages) in ONE launch with an in-kernel grid dependency -- every workgroup is resident, the last one to arrive combines the partials
  * in a fixed order (results independent of arrival order).  `sync`: fp_grid_sync_words() uint32 owned by ONE stream, zeroed once by

@@ -282,3 +282,54 @@ def test_up2_phase_wgrad_hp(N, h, w, C0, Cout, acc):
     ops.conv_up2_phase_wgrad_hp(los, gz, dw, slot_of(los), slot_of(gz), 0, accumulate=acc, db=db)
     check(db.cpu(), g.sum((0, 2, 3)) + (binit if acc else 0), "up2 phase wgrad hp bias", 1e-5)
     check(dw.cpu(), wt.grad + (init if acc else 0), "up2 phase wgrad hp")
+
+
+# ---- fp_conv_igemm_hp (round 3): the flattened kernel with fp16-pair operands -- 3x3 stride 2, 1x1 (stride 1 / 2), their data gradients ----
+@pytest.mark.parametrize("N,H,W,Cin,Cout,K,stride", [
+    (12, 48, 160, 64, 128, 3, 2), (12, 24, 80, 128, 256, 3, 2), (12, 12, 40, 256, 512, 3, 2),      # layer2/3/4 block 0 conv1 (KITTI bs=12)
+    (12, 48, 160, 64, 128, 1, 2), (12, 12, 40, 256, 512, 1, 2), (4, 128, 160, 64, 128, 1, 2),      # 1x1 downsample convs (+ Matterport layer2)
+    (2, 9, 13, 16, 24, 3, 2), (3, 7, 5, 4, 8, 1, 1), (1, 6, 20, 512, 128, 1, 1), (2, 10, 14, 36, 40, 3, 2)])     # ragged, odd sizes, C % 16 != 0
+@pytest.mark.parametrize("mode", ["fwd", "dgrad"])
+def test_igemm_hp_against_float64(N, H, W, Cin, Cout, K, stride, mode):
+    """against a float64 convolution / its data gradient of the same fp32 operands: relative L2 <= 1e-6 (measured ~3e-7, like the tile
+    kernel's), split-K and parity-major plans included; the accumulate epilogue (the form the backward pass uses) on top"""
+    import torch.nn.functional as F
+    from footprints_amd import _lib as L
+    from footprints_amd import ops
+    g = torch.Generator().manual_seed(K * 1000 + Cin + H)
+    x = ((torch.rand(N, Cin, H, W, generator=g) * 2 - 1) * (torch.rand(N, Cin, H, W, generator=g) > 0.3)).cuda()
+    w = ((torch.rand(Cout, Cin, K, K, generator=g) * 2 - 1) * 0.1).cuda()
+    pad = K // 2
+    OH, OW = (H + 2 * pad - K) // stride + 1, (W + 2 * pad - K) // stride + 1
+    slot_w = torch.zeros(ops.amax_elems(), dtype=torch.int32, device="cuda")
+    if mode == "fwd":
+        wp = ops.pack_conv_weight_hp(w, torch.empty(ops.packed_weight_elems_hp(Cout, Cin, K, False), device="cuda"), slot_w, False)
+        src = x.permute(0, 2, 3, 1).contiguous()
+        d = ops.make_desc(N, OH, OW, H, W, Cin, 0, Cout, K, stride, pad, L.GATHER_FWD_ZERO)
+        y = torch.empty(N, OH, OW, Cout, device="cuda")
+        ref = F.conv2d(x.double(), w.double(), stride=stride, padding=pad).permute(0, 2, 3, 1)
+    else:
+        wp = ops.pack_conv_weight_hp(w, torch.empty(ops.packed_weight_elems_hp(Cout, Cin, K, True), device="cuda"), slot_w, True)
+        dz = ((torch.rand(N, Cout, OH, OW, generator=g) * 2 - 1) * 1e-6).cuda()              # gradients are small numbers: the scale has to find them
+        src = dz.permute(0, 2, 3, 1).contiguous()
+        d = ops.make_desc(N, H, W, OH, OW, Cout, 0, Cin, K, stride, pad, L.GATHER_DGRAD_ZERO)
+        y = torch.empty(N, H, W, Cin, device="cuda")
+        xin = torch.zeros(N, Cin, H, W, dtype=torch.float64, device="cuda", requires_grad=True)
+        F.conv2d(xin, w.double(), stride=stride, padding=pad).backward(dz.double())
+        ref = xin.grad.permute(0, 2, 3, 1)
+    assert ops.conv_igemm_hp_supported(d)
+    slot_s = ops.amax_f32(src, torch.zeros(ops.amax_elems(), dtype=torch.int32, device="cuda"))
+    ops.conv_igemm_hp(d, src, wp, y, slot_s, slot_w)
+    err = ((y.double() - ref).norm() / ref.norm()).item()
+    assert err <= 1e-6, err
+    # the accumulating form, on top of an existing tensor
+    base = torch.rand(y.shape, generator=g).cuda() * ref.abs().max().float()
+    y2 = base.clone()
+    d.epi = L.EPI_ACCUM
+    ops.conv_igemm_hp(d, src, wp, y2, slot_s, slot_w)
+    err2 = ((y2.double() - (ref + base.double())).norm() / (ref + base.double()).norm()).item()
+    assert err2 <= 1e-6, err2
+    # bit-reproducible
+    y3 = base.clone()
+    ops.conv_igemm_hp(d, src, wp, y3, slot_s, slot_w)
+    assert torch.equal(y2, y3)
