@@ -233,7 +233,9 @@ GROUPS = {
     "conv_wgrad_hp": dict(kernel="wgrad3x3_bf3_v3_kernel<MODE, 2> (fp16-pair operands; + wgrad_reduce_bias_kernel)", bf16x3=False, products=HP_PRODUCTS),
     "conv_up2_phase_wgrad_hp": dict(kernel="wgrad_up2_phase_bf3_kernel<2> (fp16-pair operands; + its sum / un-collapse / bias reduce launches)",
                                     bf16x3=False, products=HP_PRODUCTS),
-    "conv_igemm": dict(kernel="igemm_kernel / stem_tile_kernel (stride 2, 1x1, 7x7 stem, 4x4/2 phase dgrad of small levels)", bf16x3=False),
+    "conv_igemm": dict(kernel="igemm_kernel / stem_tile_kernel (7x7 stem, 4x4/2 phase dgrad of small levels; stride 2 / 1x1 with FP_HP_IGEMM=0)", bf16x3=False),
+    "conv_igemm_hp": dict(kernel="igemm_hp_kernel (fp16-pair operands: 3x3 stride 2, 1x1, their data gradients; + splitk_reduce_kernel on small grids)",
+                          bf16x3=False, products=HP_PRODUCTS),
     "conv_up2_phase_fwd_bf3": dict(kernel="up2_phase_fwd_bf3_kernel", bf16x3=True),
     "conv_up2_phase_fwd": dict(kernel="up2_phase_fwd_kernel", bf16x3=False),
     "conv_up2_phase_dgrad_bf3": dict(kernel="up2_phase_dgrad_bf3_kernel", bf16x3=True),
@@ -249,10 +251,11 @@ GROUP_SYMBOL = {
     "conv_up2_phase_fwd_hp": ("up2_phase_fwd_bf3_kernel",), "conv_up2_phase_fwd_bf3": ("up2_phase_fwd_bf3_kernel",),
     "conv_up2_phase_dgrad_hp": ("up2_phase_dgrad_bf3_kernel",), "conv_up2_phase_dgrad_bf3": ("up2_phase_dgrad_bf3_kernel",),
     "conv_up2_phase_wgrad_hp": ("wgrad_up2_phase_bf3_kernel",), "conv_up2_phase_wgrad_bf3": ("wgrad_up2_phase_bf3_kernel",),
-    "conv_igemm": ("igemm_kernel", "stem_tile_kernel"), "conv_wgrad": ("wgrad_kernel", "wgrad3x3_tile_kernel", "stem_wgrad_tile_kernel"),
+    "conv_igemm": ("igemm_kernel", "stem_tile_kernel"), "conv_igemm_hp": ("igemm_hp_kernel",), "conv_wgrad": ("wgrad_kernel", "wgrad3x3_tile_kernel", "stem_wgrad_tile_kernel"),
 }
 CONV_OPS = {
     "conv_igemm": dict(group="conv_igemm", dense=conv_flops, exec=conv_flops, bytes=conv_bytes),
+    "conv_igemm_hp": dict(group="conv_igemm_hp", dense=conv_flops, exec=conv_flops, bytes=conv_bytes),
     "conv3x3_bf3": dict(group="conv3x3_bf3", dense=conv_flops, exec=conv_flops, bytes=conv_bytes),
     "conv3x3_hp": dict(group="conv3x3_hp", dense=conv_flops, exec=conv_flops, bytes=conv_bytes),
     "conv_up2_phase_fwd": dict(group="conv_up2_phase_fwd", dense=phase_fwd_dense, exec=_frac(phase_fwd_dense, 4.0 / 9.0), bytes=phase_fwd_bytes,
@@ -295,7 +298,9 @@ class Instrument:
 
 def load_traffic(workload, entry_point):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (scripts/pmc_hbm.sh -> profiles/), or None"""
-    path = os.path.join(ROOT, "profiles", "round2_pmc_hbm_%s.json" % workload)
+    path = os.path.join(ROOT, "profiles", "round3_pmc_hbm_%s.json" % workload)
+    if not os.path.exists(path):
+        path = os.path.join(ROOT, "profiles", "round2_pmc_hbm_%s.json" % workload)
     try:
         with open(path) as fh:
             t = json.load(fh).get(entry_point)

@@ -12,7 +12,7 @@ rows = list(cur.execute("select name, total_calls, total_duration, average, perc
 total = sum(r[2] for r in rows)
 with open(out, "w") as fh:
     fh.write("# rocprofv3 --kernel-trace --stats summary (durations in microseconds, from the rocpd `top_kernels` view)\n")
-    fh.write("# command: %s\n# total kernel time: %.3f ms over %d kernels\n" % (cmd, total / 1e6, len(rows)))
+    fh.write("# command: %s\n# total kernel time: %.3f ms over %d kernel symbols (all profiled steps together)\n" % (cmd, total / 1e3, len(rows)))
     fh.write("%-100s %8s %14s %12s %7s\n" % ("kernel", "calls", "total_us", "avg_us", "pct"))
     for name, calls, tot, avg, pct in rows:
         name = name.replace("(anonymous namespace)::", "").replace("void ", "")
