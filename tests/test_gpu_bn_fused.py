@@ -116,7 +116,7 @@ def test_fused_bn_equals_three_launch_form_closely_and_is_bit_reproducible(M, C)
     ops.bn_train_stats(d(z), d(gamma), d(beta), rmd, rvd, nbt, mean, invstd, scale, shift)
     y3 = torch.empty(M, C, device="cuda")
     ops.bn_apply(d(z), scale, shift, y3, residual=d(res), relu=True)
-    assert _rel(first["y"], y3.cpu()) <= 1e-6 and _rel(first["mean"], mean.cpu()) <= 1e-6 and _rel(first["rv"], rvd.cpu()) <= 1e-6
+    assert _rel(first["y"], y3.cpu()) <= 3e-6 and _rel(first["mean"], mean.cpu()) <= 1e-6 and _rel(first["rv"], rvd.cpu()) <= 2e-6
 
 
 def test_fused_bn_on_two_streams_concurrently():
