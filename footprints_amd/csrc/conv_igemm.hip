@@ -327,26 +327,23 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmArgs a) {
 // 1x1 (any stride), and their data gradients (zero-padding gathers, parity-major rows included) -- with the operand format of
 // conv3x3_tile_bf3.hip: x * 2^ka = h + m in fp16 (per-tensor exponent from the source's amax slot), weights from the FP_PACK_{FWD,DGRAD}_HP
 // planes, three v_mfma_f32_32x32x16_f16 products per 16-channel K-step instead of sixteen v_mfma_f32_32x32x2_f32: 192 MFMA cycles per step
-// and wave instead of 1024.  A operand: gathered fp32 -> two fp16 planes in LDS ([plane][row][16 + 8 pad]: 48-byte rows, a lane's
-// 16-byte fragment read is conflict-free); B operand: straight from the packed planes (L1 / L2 resident, 1 KB contiguous per wave and
-// plane), one K-step ahead in registers.  Two K-steps (32 channels) per barrier.
+// and 32 x 32 tile instead of 1024.
+// No LDS and no barriers: the A operand of v_mfma_f32_32x32x16_f16 is "lane = row, 8 consecutive k", i.e. 8 consecutive CHANNELS of the
+// lane's own source pixel -- 32 contiguous bytes of the NHWC tensor -- so every lane gathers its own fragment (two float4), splits it in
+// registers, and nothing is shared between waves but the cache; the B fragments come straight from the packed planes (1 KB contiguous per
+// wave and plane, L1 / L2 resident).  A wave owns 32 rows x 32 TN columns and runs its K loop on its own, loads two K-steps ahead in three
+// rotating register sets: waves drift apart and hide each other's latencies.  (The first version of this kernel staged A through LDS
+// like igemm_kernel, one barrier per two K-steps with the next pair's loads behind it: 50 us per launch against 65 for the fp32 kernel
+// -- every pair exposed a full memory latency; profiles/round3_notes.md.)
 typedef _Float16 ig_f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 ig_f16x4 __attribute__((ext_vector_type(4)));
-typedef float ig_f32x4 __attribute__((ext_vector_type(4)));
-constexpr int HPROW = 48;      // bytes per row and plane
+typedef float ig_f32x8 __attribute__((ext_vector_type(8)));
 
-template <int BM, int BN, int WM, int WN>
+template <int TN>
 __global__ void __launch_bounds__(256) igemm_hp_kernel(const IgemmArgs a) {
-  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-  constexpr int AV = BM / 64;
-  constexpr int PLANE = BM * HPROW, STEPB = 2 * PLANE;     // one K-step = two planes
-  static_assert(WM * WN == 4, "4 waves");
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * STEPB];      // [buffer 2][K-step 2][plane 2][BM][48]
-
+  constexpr int BM = 128, BN = 32 * TN;
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
   const int idx = lane & 31, h = lane >> 5;
-  const int wm = wave / WN, wn = wave % WN;
   const int wg = fp_xcd_remap(blockIdx.x, a.nwg);
   const int split = wg % a.SK, tile = wg / a.SK;
   const int tile_n = tile % a.tilesN, tile_m = tile / a.tilesN;
@@ -355,22 +352,21 @@ __global__ void __launch_bounds__(256) igemm_hp_kernel(const IgemmArgs a) {
   const int ka = fp_hp_exponent(fp_amax_bits(a.amax_a), FP_HP_TARGET_ACT);
   const int kunscale = -(ka + fp_hp_exponent(fp_amax_bits(a.amax_w), FP_HP_TARGET_W));
 
-  const int q = t & 3;
-  int pn[AV], py[AV], px[AV];
-  bool pvalid[AV];
-#pragma unroll
-  for (int i = 0; i < AV; ++i) {
-    const int m = m0 + (t >> 2) + 64 * i;
+  // this lane's row of the GEMM = one output pixel (forward) / one input-gradient pixel (data gradient)
+  int pn, py, px;
+  bool pvalid;
+  {
+    const int m = m0 + wave * 32 + idx;
     if (a.pm) {
-      pvalid[i] = pm_decode(a, m, pn[i], py[i], px[i]);
-      continue;
+      pvalid = pm_decode(a, m, pn, py, px);
+    } else {
+      pvalid = m < a.M;
+      const int mm = pvalid ? m : 0;
+      px = mm % g.OW;
+      const int r = mm / g.OW;
+      py = r % g.OH;
+      pn = r / g.OH;
     }
-    pvalid[i] = m < a.M;
-    const int mm = pvalid[i] ? m : 0;
-    const int ox = mm % g.OW, r = mm / g.OW;
-    px[i] = ox;
-    py[i] = r % g.OH;
-    pn[i] = r / g.OH;
   }
   const int pm_cls = a.pm ? m0 / a.McP : 0;
   const int pm_odd_y = (1 - (pm_cls >> 1) + g.pad) & 1, pm_odd_x = (1 - (pm_cls & 1) + g.pad) & 1;
@@ -379,121 +375,104 @@ __global__ void __launch_bounds__(256) igemm_hp_kernel(const IgemmArgs a) {
     const int ly = lt / pm_nx, lx = lt - ly * pm_nx;
     return (pm_odd_y ? 1 : 2 * ly) * 3 + (pm_odd_x ? 1 : 2 * lx);
   };
-  int pix[AV][4], pix1[AV];
-  auto set_tap = [&](int tap) {
-    const int ky = tap / g.KW, kx = tap - ky * g.KW;
-#pragma unroll
-    for (int i = 0; i < AV; ++i) {
-      fp_gather_tap(g, pn[i], py[i], px[i], ky, kx, pix[i], pix1[i]);
-      if (!pvalid[i]) { pix[i][0] = pix[i][1] = pix[i][2] = pix[i][3] = -1; pix1[i] = -1; }
-    }
-  };
-
-  // a "pair" = two consecutive K-steps (tap, chunk), staged and consumed together: one barrier per 32 channels
-  float4 areg[2][AV];
-  uint4 breg[2][TN][2];
-  int ltap, lcc, tap;
-  auto advance = [&]() {
-    if (++lcc == a.KC16) { lcc = 0; ++ltap; tap = a.pm ? pm_tap(ltap) : ltap; set_tap(tap); }
-  };
-  auto load_half = [&](int u, bool valid) {              // gathers for the current (tap, lcc) into register set u (zeros past the split's end)
-#pragma unroll
-    for (int i = 0; i < AV; ++i)
-      areg[u][i] = valid ? fp_gather_load4(g, a.src0, nullptr, pix[i], pix1[i], lcc * 16 + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    const unsigned short* ws = a.w_hp + (size_t)(tap * a.KC16 + lcc) * 2 * a.Nout * 16 + h * 8;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = min(n0 + (wn * TN + j) * 32 + idx, a.Nout - 1);
-#pragma unroll
-      for (int p = 0; p < 2; ++p)
-        breg[u][j][p] = valid ? *reinterpret_cast<const uint4*>(ws + ((size_t)p * a.Nout + n) * 16) : make_uint4(0u, 0u, 0u, 0u);
-    }
-  };
-  auto store_half = [&](int buf, int u) {                // fp32 -> scaled fp16 pair, 8 bytes per plane and slot
-#pragma unroll
-    for (int i = 0; i < AV; ++i) {
-      ig_f32x4 v = {areg[u][i].x, areg[u][i].y, areg[u][i].z, areg[u][i].w};
-      v = ig_f32x4{ldexpf(v.x, ka), ldexpf(v.y, ka), ldexpf(v.z, ka), ldexpf(v.w, ka)};
-      const ig_f16x4 vh = __builtin_convertvector(v, ig_f16x4);
-      const ig_f32x4 r1 = v - __builtin_convertvector(vh, ig_f32x4);
-      const ig_f16x4 vm = __builtin_convertvector(r1, ig_f16x4);
-      unsigned char* p = lds + (buf * 2 + u) * STEPB + ((t >> 2) + 64 * i) * HPROW + q * 8;
-      *reinterpret_cast<uint2*>(p) = __builtin_bit_cast(uint2, vh);
-      *reinterpret_cast<uint2*>(p + PLANE) = __builtin_bit_cast(uint2, vm);
-    }
-  };
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
   const int total_steps = (a.pm ? pm_ny * pm_nx : a.T) * a.KC16;
   const int s_begin = split * a.stepsPerSplit;
   const int steps = a.pm ? total_steps : min(a.stepsPerSplit, total_steps - s_begin);
-  const int pairs = (steps + 1) >> 1;
-  ltap = s_begin / a.KC16;
-  lcc = s_begin - ltap * a.KC16;
-  tap = a.pm ? pm_tap(ltap) : ltap;
-  set_tap(tap);
-  // the loads of a pair: step 2p (always valid) and step 2p + 1 (zeros when the split has an odd number of steps)
-  auto load_pair = [&](int pr) {
-    load_half(0, true);
-    const bool v1 = 2 * pr + 1 < steps;
-    if (v1) advance();
-    load_half(1, v1);
-    if (2 * pr + 2 < steps) advance();
-  };
-  uint4 bcur[2][TN][2];
-  load_pair(0);
-  store_half(0, 0);
-  store_half(0, 1);
-#pragma unroll
-  for (int u = 0; u < 2; ++u)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int p = 0; p < 2; ++p) bcur[u][j][p] = breg[u][j][p];
-  __syncthreads();
 
-  for (int pr = 0; pr < pairs; ++pr) {
-    const bool more = pr + 1 < pairs;
-    if (more) load_pair(pr + 1);                       // global loads of the next pair stay in flight under this pair's MFMAs
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const unsigned char* Ab = lds + ((pr & 1) * 2 + u) * STEPB + ((wm * TM) * 32 + idx) * HPROW + h * 16;
-      uint4 af[TM][2];
-#pragma unroll
-      for (int p = 0; p < 2; ++p)
-#pragma unroll
-        for (int i = 0; i < TM; ++i) af[i][p] = *reinterpret_cast<const uint4*>(Ab + p * PLANE + i * 32 * HPROW);
-      // products mh, hm, hh (smallest first), as in conv3x3_tile_bf3.hip
-      constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
-#pragma unroll
-      for (int qd = 0; qd < 3; ++qd)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(ig_f16x8, af[i][PA[qd]]), __builtin_bit_cast(ig_f16x8, bcur[u][j][PB[qd]]),
-                                                               acc[i][j], 0, 0, 0);
+  // load pointer: walks the K-steps (tap, 16-channel chunk) two ahead of the MFMAs
+  int ltap = s_begin / a.KC16, lcc = s_begin - ltap * a.KC16, tap = a.pm ? pm_tap(ltap) : ltap;
+  // this lane's source pixel for `tap`: loads are unconditional (padding / out-of-range rows read pixel 0 of the tensor, channel chunks
+  // past C0 its last 8 channels) and the fragment is zeroed in registers when it is consumed -- a conditional load compiles into eight
+  // scalar flat loads through a select of addresses
+  const float* prow = a.src0;
+  bool prow_ok = false;
+  auto set_tap = [&]() {                             // FP_GATHER_FWD_ZERO / FP_GATHER_DGRAD_ZERO of fp_gather_tap, strides 1 and 2 without divisions
+    const int ky = tap / g.KW, kx = tap - ky * g.KW;
+    int sy, sx;
+    bool ok = pvalid;
+    if (g.gather == FP_GATHER_FWD_ZERO) {
+      sy = py * g.stride + ky - g.pad;
+      sx = px * g.stride + kx - g.pad;
+    } else {
+      sy = py + g.pad - ky;
+      sx = px + g.pad - kx;
+      if (g.stride == 2) {
+        ok = ok && !((sy | sx) & 1);
+        sy >>= 1;
+        sx >>= 1;
+      } else if (g.stride != 1) {
+        ok = ok && sy >= 0 && sx >= 0 && sy % g.stride == 0 && sx % g.stride == 0;
+        sy /= g.stride;
+        sx /= g.stride;
+      }
     }
-    if (more) {
-      store_half((pr + 1) & 1, 0);
-      store_half((pr + 1) & 1, 1);
+    ok = ok && sy >= 0 && sy < g.IH && sx >= 0 && sx < g.IW;
+    sy = min(max(sy, 0), g.IH - 1);
+    sx = min(max(sx, 0), g.IW - 1);
+    prow_ok = ok;
+    prow = a.src0 + ((size_t)(pn * g.IH + sy) * g.IW + sx) * g.C0;
+  };
+  set_tap();
+  float4 ar[3][2];
+  bool aok[3][2];
+  uint4 br[3][TN][2];
+  const int cmax = max(g.C0 - 4, 0);
+  auto load_next = [&](int set) {
+    const int c8 = lcc * 16 + h * 8;
+    ar[set][0] = *reinterpret_cast<const float4*>(prow + min(c8, cmax));
+    ar[set][1] = *reinterpret_cast<const float4*>(prow + min(c8 + 4, cmax));
+    aok[set][0] = prow_ok && c8 < g.C0;
+    aok[set][1] = prow_ok && c8 + 4 < g.C0;
+    const unsigned short* ws = a.w_hp + (size_t)(tap * a.KC16 + lcc) * 2 * a.Nout * 16 + h * 8;
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
+    for (int j = 0; j < TN; ++j) {
+      const int n = min(n0 + j * 32 + idx, a.Nout - 1);
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-          for (int p = 0; p < 2; ++p) bcur[u][j][p] = breg[u][j][p];
+      for (int p = 0; p < 2; ++p) br[set][j][p] = *reinterpret_cast<const uint4*>(ws + ((size_t)p * a.Nout + n) * 16);
     }
-    __syncthreads();
+    if (++lcc == a.KC16) {                            // position the pointer for the following step
+      lcc = 0;
+      ++ltap;
+      tap = a.pm ? pm_tap(min(ltap, pm_ny * pm_nx - 1)) : min(ltap, a.T - 1);
+      set_tap();
+    }
+  };
+
+  f32x16 acc[1][TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
+
+  auto consume = [&](int set) {
+    const float4 a0 = aok[set][0] ? ar[set][0] : make_float4(0.f, 0.f, 0.f, 0.f), a1 = aok[set][1] ? ar[set][1] : make_float4(0.f, 0.f, 0.f, 0.f);
+    ig_f32x8 v = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = ldexpf(v[k], ka);
+    const ig_f16x8 vh = __builtin_convertvector(v, ig_f16x8);
+    const ig_f32x8 r1 = v - __builtin_convertvector(vh, ig_f32x8);
+    const ig_f16x8 vm = __builtin_convertvector(r1, ig_f16x8);
+    // products mh, hm, hh (smallest first), as in conv3x3_tile_bf3.hip
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vm, __builtin_bit_cast(ig_f16x8, br[set][j][0]), acc[0][j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, __builtin_bit_cast(ig_f16x8, br[set][j][1]), acc[0][j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, __builtin_bit_cast(ig_f16x8, br[set][j][0]), acc[0][j], 0, 0, 0);
+  };
+
+  if (steps > 0) load_next(0);
+  if (steps > 1) load_next(1);
+  for (int s = 0; s < steps; s += 3) {
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      if (s + u < steps) {                            // wave-uniform
+        if (s + u + 2 < steps) load_next((u + 2) % 3);
+        consume(u);
+      }
+    }
   }
-  igemm_store_tile<TM, TN>(a, acc, m0, n0, wm, wn, idx, h, split, ldexpf(1.f, kunscale));
+  igemm_store_tile<1, TN>(a, acc, m0, n0, wave, 0, idx, h, split, ldexpf(1.f, kunscale));
 }
 
 // y = epilogue(sum_s part[s]) -- fixed summation order
@@ -548,8 +527,9 @@ int launch(IgemmArgs& a, hipStream_t stream, int64_t ws_floats) {
   return fp_check_launch("fp_conv_igemm");
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int TN>
 int launch_hp(IgemmArgs& a, hipStream_t stream, int64_t ws_floats) {
+  constexpr int BM = 128, BN = 32 * TN;
   int tilesM = (int)fp_ceil_div(a.M, BM);
   if (a.pm) {
     a.McP = (int)fp_ceil_div(a.Mc, BM) * BM;
@@ -560,10 +540,9 @@ int launch_hp(IgemmArgs& a, hipStream_t stream, int64_t ws_floats) {
   const int steps = a.T * a.KC16;
   const int sk = pick_splitk((int64_t)tilesM * a.tilesN, steps, (int64_t)a.M * a.Nout, ws_floats);
   a.stepsPerSplit = (int)fp_ceil_div(steps, sk);
-  a.stepsPerSplit += a.stepsPerSplit & 1;            // whole pairs of K-steps per split
   a.SK = (int)fp_ceil_div(steps, a.stepsPerSplit);
   a.nwg = tilesM * a.tilesN * a.SK;
-  fp_launch((igemm_hp_kernel<BM, BN, WM, WN>), dim3(a.nwg), dim3(256), 0, stream, a);
+  fp_launch((igemm_hp_kernel<TN>), dim3(a.nwg), dim3(256), 0, stream, a);
   if (a.SK > 1) {
     int64_t g = fp_ceil_div((int64_t)a.M * a.Nout, 256);
     if (g > 4096) g = 4096;
@@ -708,9 +687,9 @@ extern "C" int fp_conv_igemm_hp(const fp_conv_desc* d, const float* src, const v
   a.McP = a.Mc;
   int64_t ws = workspace ? workspace_bytes / (int64_t)sizeof(float) : 0;
   if (ws > MAX_SK * M64 * d->Nout) ws = MAX_SK * M64 * d->Nout;
-  if (d->Nout <= 32) return launch_hp<128, 32, 4, 1>(a, stream, ws);
+  // wave tile 32 rows x 32 TN columns: wider tiles re-read the A rows less often, narrower ones fill the chip on small grids
+  if (d->Nout <= 32) return launch_hp<1>(a, stream, ws);
   const int64_t t128 = fp_ceil_div(M64, 128);
-  if (d->Nout % 128 == 0 && t128 * (d->Nout / 128) >= 256) return launch_hp<128, 128, 2, 2>(a, stream, ws);
-  if (M64 >= 256) return launch_hp<128, 64, 2, 2>(a, stream, ws);
-  return launch_hp<64, 64, 2, 2>(a, stream, ws);
+  if (d->Nout % 128 == 0 && t128 * (d->Nout / 128) >= 512) return launch_hp<4>(a, stream, ws);
+  return launch_hp<2>(a, stream, ws);
 }
