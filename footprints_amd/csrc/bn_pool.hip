@@ -252,7 +252,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restri
 struct BnGeom {
   int M, C, rows_per_wg;
 };
-constexpr int BN_UNROLL = 4;
+constexpr int BN_UNROLL = 8;
 
 int bn_fused_grid(int64_t M, int C, int* rows_per_wg) {
   const int R = 256 / (C / 4);
@@ -266,9 +266,27 @@ int bn_fused_grid(int64_t M, int C, int* rows_per_wg) {
   return (int)fp_ceil_div(M, rows);
 }
 
+// ticket form (statistics + combination in one launch, apply in the next): nobody waits, so the grid only has to keep the last
+// arriver's combine short -- G x C partials <= 8192 (two to four batches of loads) -- and the row loop deeply unrolled
+int bn_ticket_grid(int64_t M, int C, int* rows_per_wg) {
+  const int R = 256 / (C / 4);
+  static const int cap = getenv("FP_BN_TICKET_PARTIALS") ? atoi(getenv("FP_BN_TICKET_PARTIALS")) : 8192;
+  int g = cap / C;
+  if (g < 8) g = 8;
+  if (g > 256) g = 256;
+  int64_t rows = fp_ceil_div(M, g);
+  const int64_t min_rows = (int64_t)16 * 1024 / ((int64_t)C * 4);      // at least 16 KB per workgroup
+  if (rows < min_rows) rows = min_rows;
+  rows = fp_ceil_div(rows, R) * R;
+  if (rows < R) rows = R;
+  *rows_per_wg = (int)rows;
+  return (int)fp_ceil_div(M, rows);
+}
+
 // channel-major combine helpers of the last-arriving workgroup: work item i = (channel, sub) with P = max(1, 256 / C) threads per
 // channel; thread `sub` combines partials sub, sub + P, ... in order, then the P threads of a channel (adjacent lanes) merge in a
 // fixed shuffle tree
+template <bool APPLY>
 __global__ void __launch_bounds__(256) bn_fused_fwd_kernel(const float* __restrict__ z, const float* __restrict__ res, float* __restrict__ y,
                                                            const BnGeom g, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            float eps, float momentum, float* running_mean, float* running_var, long long* nbt,
@@ -325,10 +343,17 @@ __global__ void __launch_bounds__(256) bn_fused_fwd_kernel(const float* __restri
     for (int i = threadIdx.x; i < C * P; i += 256) {
       const int c = i / P, sub = i % P;
       Wf a{0, 0, 0};
-      for (int k = sub; k < G; k += P) {
-        const float* p = part + ((size_t)k * C + c) * 3;
-        Wf o{fp_gs_load(p), fp_gs_load(p + 1), fp_gs_load(p + 2)};
-        wf_merge(a, o);
+      for (int k0 = sub; k0 < G; k0 += 8 * P) {         // eight partial triples in flight per thread, merged in index order
+        Wf o[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int k = min(k0 + u * P, G - 1);
+          const float* p = part + ((size_t)k * C + c) * 3;
+          o[u] = Wf{fp_gs_load(p), fp_gs_load(p + 1), fp_gs_load(p + 2)};
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (k0 + u * P < G) wf_merge(a, o[u]);
       }
       for (int o = 1; o < P; o <<= 1) {               // P in {1, 2, 4}: lanes sub .. sub + P - 1 are adjacent
         Wf t{__shfl_down(a.n, o, 64), __shfl_down(a.mean, o, 64), __shfl_down(a.m2, o, 64)};
@@ -349,9 +374,12 @@ __global__ void __launch_bounds__(256) bn_fused_fwd_kernel(const float* __restri
       }
     }
     if (threadIdx.x == 0 && nbt) *nbt += 1;
-    fp_gs_publish();
-    fp_gs_release_all(sync);
+    if (APPLY) {
+      fp_gs_publish();
+      fp_gs_release_all(sync);
+    }
   }
+  if (!APPLY) return;                                // ticket form: statistics + their combination only (the apply launch follows)
   // ---- phase 2: y = act(z * scale + shift (+ residual)) over the same rows ---------------------------------------------------
   fp_gs_wait(sync);
   float4 sc, sh;
@@ -382,6 +410,7 @@ __global__ void __launch_bounds__(256) bn_fused_fwd_kernel(const float* __restri
 }
 
 // backward: (sum g, sum g * xhat) per workgroup -> combine -> coefficients, dgamma, dbeta -> dz over the same rows
+template <bool APPLY>
 __global__ void __launch_bounds__(256) bn_fused_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ ro, const float* __restrict__ z,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            const float* __restrict__ gamma, const BnGeom g, float* __restrict__ dz,
@@ -443,9 +472,17 @@ __global__ void __launch_bounds__(256) bn_fused_bwd_kernel(const float* __restri
     for (int i = threadIdx.x; i < C * P; i += 256) {
       const int c = i / P, sub = i % P;
       float a1 = 0.f, a2 = 0.f;
-      for (int k = sub; k < G; k += P) {
-        const float* p = part + ((size_t)k * C + c) * 2;
-        a1 += fp_gs_load(p); a2 += fp_gs_load(p + 1);
+      for (int k0 = sub; k0 < G; k0 += 8 * P) {
+        float o1[8], o2[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int k = min(k0 + u * P, G - 1);
+          const float* p = part + ((size_t)k * C + c) * 2;
+          o1[u] = fp_gs_load(p); o2[u] = fp_gs_load(p + 1);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (k0 + u * P < G) { a1 += o1[u]; a2 += o2[u]; }
       }
       for (int o = 1; o < P; o <<= 1) {
         const float t1 = __shfl_down(a1, o, 64), t2 = __shfl_down(a2, o, 64);
@@ -457,9 +494,12 @@ __global__ void __launch_bounds__(256) bn_fused_bwd_kernel(const float* __restri
       if (dgamma) dgamma[c] = accumulate ? dgamma[c] + a2 : a2;
       if (dbeta) dbeta[c] = accumulate ? dbeta[c] + a1 : a1;
     }
-    fp_gs_publish();
-    fp_gs_release_all(sync);
+    if (APPLY) {
+      fp_gs_publish();
+      fp_gs_release_all(sync);
+    }
   }
+  if (!APPLY) return;
   fp_gs_wait(sync);
   float c1[4], c2[4];
 #pragma unroll
@@ -590,7 +630,9 @@ int ew_grid(size_t total, size_t cap = 8192) {
 
 extern "C" int64_t fp_bn_workspace(int64_t M, int32_t C) {
   int rows = 0;
-  const int fused = bn_c_ok(C) ? bn_fused_grid(M, C, &rows) : 0;
+  int fused = bn_c_ok(C) ? bn_fused_grid(M, C, &rows) : 0;
+  const int ticket = bn_c_ok(C) ? bn_ticket_grid(M, C, &rows) : 0;
+  if (ticket > fused) fused = ticket;
   const int nb = bn_blocks(M, C) > fused ? bn_blocks(M, C) : fused;
   return (int64_t)nb * C * 3 * (int64_t)sizeof(float) + (int64_t)C * 2 * sizeof(float);
 }
@@ -662,7 +704,7 @@ extern "C" int fp_bn_train_fused(const float* z, const float* residual, float* y
   BnGeom g;
   g.M = (int)M; g.C = C;
   const int grid = bn_fused_grid(M, C, &g.rows_per_wg);
-  fp_launch(bn_fused_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, z, residual, y, g, gamma, beta, eps, momentum, running_mean,
+  fp_launch(bn_fused_fwd_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, z, residual, y, g, gamma, beta, eps, momentum, running_mean,
             running_var, (long long*)num_batches_tracked, save_mean, save_invstd, scale, shift, (float*)workspace, (unsigned*)sync, (int)relu,
             amax_out);
   return fp_check_launch("fp_bn_train_fused");
@@ -680,9 +722,47 @@ extern "C" int fp_bn_bwd_fused(const float* dy, const float* relu_out, const flo
   const int grid = bn_fused_grid(M, C, &g.rows_per_wg);
   float* part = (float*)workspace;
   float* coef = (float*)((char*)workspace + fp_bn_workspace(M, C)) - (size_t)C * 2;      // the last 2 C floats of the workspace
-  fp_launch(bn_fused_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, relu_out, z, save_mean, save_invstd, gamma, g, dz, g_out,
+  fp_launch(bn_fused_bwd_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, relu_out, z, save_mean, save_invstd, gamma, g, dz, g_out,
             dgamma, dbeta, accumulate, part, coef, (unsigned*)sync, amax_out);
   return fp_check_launch("fp_bn_bwd_fused");
+}
+
+// ticket forms: the statistics / reduction kernel and its per-channel combination in ONE launch (the last workgroup to arrive combines;
+// nobody waits), the element-wise apply launch as before: two launches per layer and direction instead of three
+extern "C" int fp_bn_train_stats_ticket(const float* z, int64_t M, int32_t C, const float* gamma, const float* beta, float eps, float momentum,
+                                        float* running_mean, float* running_var, int64_t* num_batches_tracked, float* save_mean,
+                                        float* save_invstd, float* scale, float* shift, void* workspace, int64_t workspace_bytes, uint32_t* sync,
+                                        fp_stream_t stream) {
+  FP_REQUIRE(z && gamma && beta && save_mean && save_invstd && scale && shift && workspace && sync, "fp_bn_train_stats_ticket: null pointer");
+  FP_REQUIRE(bn_c_ok(C) && M > 0 && M < ((int64_t)1 << 31), "fp_bn_train_stats_ticket: unsupported C=%d", C);
+  FP_REQUIRE(workspace_bytes >= fp_bn_workspace(M, C), "fp_bn_train_stats_ticket: workspace too small");
+  BnGeom g;
+  g.M = (int)M; g.C = C;
+  const int grid = bn_ticket_grid(M, C, &g.rows_per_wg);
+  fp_launch(bn_fused_fwd_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, z, (const float*)nullptr, (float*)nullptr, g, gamma, beta, eps,
+            momentum, running_mean, running_var, (long long*)num_batches_tracked, save_mean, save_invstd, scale, shift, (float*)workspace,
+            (unsigned*)sync, 0, (unsigned*)nullptr);
+  return fp_check_launch("fp_bn_train_stats_ticket");
+}
+
+extern "C" int fp_bn_bwd_ticket(const float* dy, const float* relu_out, const float* z, const float* save_mean, const float* save_invstd,
+                                const float* gamma, float* dz, float* g_out, float* dgamma, float* dbeta, int accumulate, int64_t M, int32_t C,
+                                void* workspace, int64_t workspace_bytes, uint32_t* sync, fp_stream_t stream) {
+  unsigned* amax_out = fp_take_amax_out();
+  FP_REQUIRE(dy && z && save_mean && save_invstd && gamma && dz && workspace && sync, "fp_bn_bwd_ticket: null pointer");
+  FP_REQUIRE(bn_c_ok(C) && M > 0 && M < ((int64_t)1 << 31), "fp_bn_bwd_ticket: unsupported C=%d", C);
+  FP_REQUIRE(workspace_bytes >= fp_bn_workspace(M, C), "fp_bn_bwd_ticket: workspace too small");
+  BnGeom g;
+  g.M = (int)M; g.C = C;
+  const int grid = bn_ticket_grid(M, C, &g.rows_per_wg);
+  float* part = (float*)workspace;
+  float* coef = (float*)((char*)workspace + fp_bn_workspace(M, C)) - (size_t)C * 2;
+  fp_launch(bn_fused_bwd_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, relu_out, z, save_mean, save_invstd, gamma, g,
+            (float*)nullptr, (float*)nullptr, dgamma, dbeta, accumulate, part, coef, (unsigned*)sync, (unsigned*)nullptr);
+  const size_t total4 = (size_t)M * (C / 4);
+  fp_launch(bn_bwd_apply_kernel, dim3(ew_grid(total4, 8192)), dim3(256), 0, (hipStream_t)stream, dy, relu_out, z, save_mean, save_invstd, gamma,
+            (const float*)coef, dz, g_out, total4, C / 4, amax_out);
+  return fp_check_launch("fp_bn_bwd_ticket");
 }
 
 extern "C" int fp_maxpool_fwd(const float* x, float* y, uint8_t* argmax, int32_t N, int32_t H, int32_t W, int32_t C,

@@ -559,6 +559,12 @@ def bn_train_stats(z2d, gamma, beta, running_mean, running_var, nbt, save_mean, 
     ws = workspace(lib.fp_bn_workspace(M, Cn), z2d.device)
     if nbt is not None and nbt.dtype != torch.int64:
         raise RuntimeError("num_batches_tracked must be int64")
+    if _BN_TICKET:
+        sync = grid_sync_block(z2d.device)
+        _lib.check(lib.fp_bn_train_stats_ticket(_f32(z2d), M, Cn, _f32(gamma), _f32(beta), eps, momentum, _f32(running_mean), _f32(running_var),
+                                                _chk(nbt), _f32(save_mean), _f32(save_invstd), _f32(scale), _f32(shift), ws.data_ptr(),
+                                                ws.numel(), sync.data_ptr(), stream()), "fp_bn_train_stats_ticket")
+        return
     _lib.check(lib.fp_bn_train_stats(_f32(z2d), M, Cn, _f32(gamma), _f32(beta), eps, momentum, _f32(running_mean), _f32(running_var),
                                      _chk(nbt), _f32(save_mean), _f32(save_invstd), _f32(scale), _f32(shift), ws.data_ptr(),
                                      ws.numel(), stream()), "fp_bn_train_stats")
@@ -569,6 +575,11 @@ def bn_train_stats(z2d, gamma, beta, running_mean, running_var, nbt, save_mean, 
 # per-XCD L2s are not coherent, so everything workgroups exchange goes through memory at 1-2 us per dependent hop, and the last
 # arriver's combine of G x C partials is a serial chain of such hops -- a dependent launch (~10 us) is cheaper (profiles/round3_notes.md)
 _BN_FUSED = bool(int(os.environ.get("FP_BN_FUSED", "0")))
+# ticket forms: statistics (backward: reduction) + per-channel combination in one launch, the last workgroup to arrive combines, nobody
+# waits; the apply launch follows -- two launches per layer and direction instead of three.  OPT-IN as well (FP_BN_TICKET=1): 14.69 vs
+# 13.67 ms per step -- one workgroup combining G x C partials through memory (sc1 loads, ~0.7 us per dependent batch) plus the smaller
+# grids the combine forces on the streaming phase cost more than the launch they save (profiles/round3_notes.md)
+_BN_TICKET = bool(int(os.environ.get("FP_BN_TICKET", "0")))
 _sync_blocks = {}
 
 
@@ -629,6 +640,13 @@ def bn_bwd(dy2d, relu_out, z2d, save_mean, save_invstd, gamma, dz2d, dgamma, dbe
         _lib.check(lib.fp_bn_bwd_fused(_f32(dy2d), _f32(relu_out), _f32(z2d), _f32(save_mean), _f32(save_invstd), _f32(gamma), _f32(dz2d),
                                        _f32(g_out), _f32(dgamma), _f32(dbeta), int(bool(accumulate)), M, Cn, ws.data_ptr(), ws.numel(),
                                        sync.data_ptr(), stream()), "fp_bn_bwd_fused")
+        return dz2d
+    if _BN_TICKET:
+        sync = grid_sync_block(z2d.device)
+        _sink(amax_out)
+        _lib.check(lib.fp_bn_bwd_ticket(_f32(dy2d), _f32(relu_out), _f32(z2d), _f32(save_mean), _f32(save_invstd), _f32(gamma), _f32(dz2d),
+                                        _f32(g_out), _f32(dgamma), _f32(dbeta), int(bool(accumulate)), M, Cn, ws.data_ptr(), ws.numel(),
+                                        sync.data_ptr(), stream()), "fp_bn_bwd_ticket")
         return dz2d
     _sink(amax_out)
     _lib.check(lib.fp_bn_bwd(_f32(dy2d), _f32(relu_out), _f32(z2d), _f32(save_mean), _f32(save_invstd), _f32(gamma), _f32(dz2d),

@@ -135,3 +135,39 @@ def test_fused_bn_on_two_streams_concurrently():
         torch.cuda.synchronize()
         for k in ("y", "dz", "dgamma", "rm", "rv"):
             assert torch.equal(ra[k], ref_a[k]) and torch.equal(rb[k], ref_b[k]), k
+
+
+@pytest.mark.parametrize("M,C", [(12 * 96 * 320, 64), (12 * 24 * 80, 128), (12 * 6 * 20, 512), (333, 512), (7, 64), (4097, 16)])
+def test_ticket_forms_against_float64_and_bit_reproducible(M, C):
+    """fp_bn_train_stats_ticket / fp_bn_bwd_ticket (the engine's default, ops._BN_TICKET): statistics / reduction + combination in one
+    launch, then the apply launches: float64 reference as above, and 20 repetitions bit-identical (arrival order must not matter)"""
+    ops = _ops()
+    case = _case(M, C, 17, True)
+    z, gamma, beta, rm, rv, res, dy = case
+    y64, dz64, dgam64, dbet64, rm64, rv64, tie = _reference(*case, True)
+    d = lambda t: t.detach().clone().cuda().contiguous()
+
+    def run():
+        was, ops._BN_TICKET = ops._BN_TICKET, True
+        wasf, ops._BN_FUSED = ops._BN_FUSED, False
+        try:
+            zs, rmd, rvd, nbt = d(z), d(rm), d(rv), torch.zeros((), dtype=torch.int64, device="cuda")
+            mean, invstd, scale, shift = (torch.empty(C, device="cuda") for _ in range(4))
+            ops.bn_train_stats(zs, d(gamma), d(beta), rmd, rvd, nbt, mean, invstd, scale, shift)
+            y = torch.empty_like(zs)
+            ops.bn_apply(zs, scale, shift, y, residual=d(res), relu=True)
+            dz, gout, dgam, dbet = torch.empty_like(zs), torch.empty_like(zs), torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+            ops.bn_bwd(d(dy), y, zs, mean, invstd, d(gamma), dz, dgam, dbet, g_out=gout)
+            return dict(y=y, dz=dz, dgamma=dgam, dbeta=dbet, rm=rmd, rv=rvd, mean=mean, invstd=invstd, nbt=nbt)
+        finally:
+            ops._BN_TICKET, ops._BN_FUSED = was, wasf
+    first = run()
+    assert _rel(first["y"], y64) <= 2e-6 and _rel(first["rm"], rm64) <= 1e-6 and _rel(first["rv"], rv64) <= 2e-6 and int(first["nbt"]) == 1
+    ok = ~tie
+    assert ((first["dz"].double().cpu() - dz64).abs() * ok).max().item() / dz64.abs().max().item() <= 1e-5
+    slack = lambda ref: 1e-5 + 4.0 * int(tie.sum()) / ref.abs().max().item()
+    assert _rel(first["dgamma"], dgam64) <= slack(dgam64) and _rel(first["dbeta"], dbet64) <= slack(dbet64)
+    for _ in range(20):
+        again = run()
+        for k in ("y", "dz", "dgamma", "dbeta", "rm", "rv", "mean", "invstd"):
+            assert torch.equal(first[k], again[k]), k
