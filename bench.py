@@ -6,9 +6,8 @@
 
 Started plainly with --gpus N > 1 (no WORLD_SIZE in the environment) it re-executes itself through torch.distributed.run with
 N ranks on 127.0.0.1 and a free port, passes the ranks' output through and exits with their status: rank 0 still prints the ONE
-JSON line.  The ranks rendezvous over a "cpu:gloo,cuda:nccl" group (host plumbing: unique-id exchange, barriers, the max over
-ranks of the timed region); the gradient buckets travel over RCCL through this library's own fp_comm_* entry points
-(footprints_amd/parallel.py).  On a box with fewer GPUs than ranks the ranks share the GPUs and exchange over gloo (RCCL refuses two
+JSON line.  The ranks rendezvous over a gloo group (host plumbing: unique-id exchange, barriers, the max over ranks of the timed
+region); the gradient buckets travel over RCCL through this library's own fp_comm_* entry points (footprints_amd/parallel.py).  On a box with fewer GPUs than ranks the ranks share the GPUs and exchange over gloo (RCCL refuses two
 ranks per device): a functional dry run of the launch path, flagged "shared_gpu" in the line, never a performance number.
 
 A "step" = one full training step of the hot path on one per-GPU batch of 12 synthetic 192x640 images:
@@ -453,9 +452,12 @@ def main():
     if os.environ.get("NCCL_DEBUG", "").upper() in ("", "VERSION"):
         os.environ["NCCL_DEBUG"] = "WARN"                          # RCCL's version banner goes to stdout, where the ONE JSON line belongs
     if world > 1:
-        # host-side group: rendezvous, unique-id exchange, barriers, max over ranks.  "cuda:nccl" is only instantiated if the
-        # library's own RCCL transport (fp_comm_*) is unavailable and the reducer falls back to framework collectives.
-        dist.init_process_group("gloo" if shared_gpu else "cpu:gloo,cuda:nccl", rank=rank, world_size=world)
+        # host-side group (gloo): rendezvous, unique-id exchange, barriers, max over ranks -- nothing of it touches the GPU.  The gradient
+        # buckets travel over RCCL through the library's own fp_comm_* entry points (one rank per GPU); ranks that share a GPU (a smaller
+        # box: RCCL refuses two ranks per device) exchange over the gloo group instead.  If fp_comm_init fails on any rank, all ranks
+        # agree to fall back to the gloo group as well (footprints_amd.parallel.get_communicator) and the line says so.
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        os.environ.setdefault("FP_DP_TRANSPORT", "torch" if shared_gpu else "rccl")      # read when footprints_amd.parallel is imported
     if args.dry_run_dist:
         t = torch.tensor([float(rank + 1)], dtype=torch.float64)
         if world > 1:

@@ -36,6 +36,8 @@ _DESC = C.POINTER(ConvDesc)
 
 # name -> (restype, argtypes); mirrors include/footprints_hip.h one to one
 SIGNATURES = {
+    "fp_seg_loss_workspace": (_I64, [_I32, _I32, _I32]),
+    "fp_seg_loss_fwd_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P, _P, _I64, _P]),
     "fp_comm_unique_id_bytes": (_I32, []),
     "fp_comm_unique_id": (C.c_int, [_P, _I32]),
     "fp_comm_init": (C.c_int, [_P, _I32, _I32, C.POINTER(C.c_void_p)]),

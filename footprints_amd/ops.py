@@ -801,3 +801,25 @@ def copy_channels(src, dst, C_, src_off=0, dst_off=0, accumulate=False):
     _lib.check(_lib.load().fp_copy_channels(_f32(src), _f32(dst), M, C_, srcC, src_off, dstC, dst_off, int(bool(accumulate)), stream()),
                "fp_copy_channels")
     return dst
+
+
+def seg_loss_fwd_bwd(preds, ground_mask, loss_mask, losses_out, dpreds=None):
+    """segmentation trainer's loss (+ gradient): preds = four logit maps [B,1,h,w] (any batch stride: channel slices of wider buffers
+    are fine as long as a map's rows are dense), masks [B,H,W]; losses_out: 5 B + 1 floats (per-scale / per-image means, their average,
+    batch mean); dpreds: four tensors addressed like preds, or None"""
+    lib = _lib.load()
+    B, H, W = ground_mask.shape
+    for t in list(preds) + (list(dpreds) if dpreds is not None else []):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 4 and t.shape[1] == 1 and t.stride(3) == 1 and t.stride(2) == t.shape[3]):
+            raise RuntimeError("footprints_amd.ops.seg_loss_fwd_bwd: maps must be float32 CUDA [B,1,h,w] with dense rows")
+    ws = workspace(lib.fp_seg_loss_workspace(B, H, W), ground_mask.device)
+    P = (C.c_void_p * 4)(*[p.data_ptr() for p in preds])
+    D = (C.c_void_p * 4)(*[p.data_ptr() for p in dpreds]) if dpreds is not None else None
+    hs = (C.c_int32 * 4)(*[p.shape[2] for p in preds])
+    wss = (C.c_int32 * 4)(*[p.shape[3] for p in preds])
+    bs = (C.c_int64 * 4)(*[p.stride(0) for p in preds])
+    if dpreds is not None and any(d.stride(0) != p.stride(0) for d, p in zip(dpreds, preds)):
+        raise RuntimeError("footprints_amd.ops.seg_loss_fwd_bwd: gradient maps must be addressed like the predictions")
+    _lib.check(lib.fp_seg_loss_fwd_bwd(P, D, hs, wss, bs, _f32(ground_mask), _f32(loss_mask), B, H, W, _f32(losses_out), ws.data_ptr(), ws.numel(),
+                                       stream()), "fp_seg_loss_fwd_bwd")
+    return losses_out

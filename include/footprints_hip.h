@@ -427,6 +427,16 @@ int fp_nchw_to_nhwc(const float* x, float* y, int32_t N, int32_t C, int32_t H, i
 int fp_nhwc_to_nchw(const float* x, float* y, int32_t N, int32_t C, int32_t H, int32_t W, fp_stream_t stream);
 int fp_fill(float* x, int64_t n, float value, fp_stream_t stream);
 
+/* ---- loss of the ground-segmentation trainer (footprints/preprocessing/segmentation/train.py:184-193, evaluation.py:39-58) ----------
+ * Forward and gradient in one call: preds[s] = logit map of scale s ([B][h_s][w_s], batch stride bstrides[s] elements -- a channel slice
+ * of a wider tensor is fine), up-sized bilinearly (align_corners = False) to H x W, per-image masked BCE-with-logits means, averaged over
+ * the four scales and the batch.  losses: 5 B + 1 floats = per image the four per-scale means [s * B + b], their average [4 B + b], and
+ * the batch mean [5 B]; dpreds (nullable): d losses[5 B] / d preds[s], same addressing.  workspace >= fp_seg_loss_workspace(B, H, W). */
+int64_t fp_seg_loss_workspace(int32_t B, int32_t H, int32_t W);
+int fp_seg_loss_fwd_bwd(const float* const* preds, float* const* dpreds, const int32_t* hs, const int32_t* ws, const int64_t* bstrides,
+                        const float* ground_mask, const float* loss_mask, int32_t B, int32_t H, int32_t W, float* losses, void* workspace,
+                        int64_t workspace_bytes, fp_stream_t stream);
+
 /* ---- data-parallel gradient exchange: RCCL over xGMI (the reference is single-GPU, README.md:128,136) -- */
 /* One process per GPU.  Rank 0 obtains a unique id (fp_comm_unique_id_bytes() bytes, ncclUniqueId) and hands it to every rank by
  * any host transport; every rank then calls fp_comm_init on its own device (collective: returns when all `world` ranks called it).

@@ -175,3 +175,37 @@ def test_segmentation_inference_dropin():
     got = im.test_batch({"image": image})
     ref = torch.sigmoid(R.segmentor(image, P, OrderedDict((k, v.clone()) for k, v in Bf.items()), False, True)[3]).numpy()
     assert got.shape == (B, 1, H, W) and np.abs(got - ref).max() <= 1e-5
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 64, 96), (3, 192, 640), (1, 32, 32)])
+def test_segmentation_loss_kernel_against_oracle(B, H, W):
+    """fp_seg_loss_fwd_bwd (csrc/seg_loss.hip) through SegmentationLoss: value, per-scale tracked means and the gradient with respect
+    to the four low-resolution logit maps against the oracle's restatement of segmentation/train.py:184-193 + evaluation.py:39-58 (torch
+    float64 autograd): 1e-6; on channel slices of wider buffers (how Segmentor hands its outputs out) and on dense tensors alike"""
+    from footprints_amd.preprocessing.segmentation.losses import SegmentationLoss
+    from oracle import restatement as R
+    g = torch.Generator().manual_seed(B * 100 + H)
+    outs = [(torch.rand(B, 1, H // s, W // s, generator=g) * 8 - 4).double().requires_grad_(True) for s in (8, 4, 2, 1)]
+    gm = (torch.rand(B, H, W, generator=g) < 0.4).float()
+    lm = (torch.rand(B, H, W, generator=g) < 0.7).float()
+    lm[0, : H // 2] = 0.0                                    # an image with a large unlabelled region
+    ref = R.seg_loss(outs, gm.double(), lm.double(), H, W)
+    ref.backward()
+    for sliced in (False, True):
+        if sliced:      # [B,2,h,w] buffers, channel 0 handed out
+            bufs = [torch.zeros(B, 2, o.shape[2], o.shape[3], device="cuda") for o in outs]
+            for bf, o in zip(bufs, outs):
+                bf[:, 0] = o.detach().float().cuda()[:, 0]
+            gp = [bf[:, :1].detach().requires_grad_(True) for bf in bufs]
+        else:
+            gp = [o.detach().float().cuda().requires_grad_(True) for o in outs]
+        sl = SegmentationLoss()
+        loss = sl(gp, gm.cuda(), lm.cuda())
+        loss.backward()
+        assert abs(float(loss) - float(ref)) <= 1e-6 * abs(float(ref))
+        for p, o in zip(gp, outs):
+            err = ((p.grad.double().cpu() - o.grad).norm() / o.grad.norm()).item()
+            assert err <= 2e-6, err
+        tr = sl.tracked()
+        assert set(tr) == {"loss"} | {"ground_loss_%d" % s for s in range(4)} and abs(float(tr["loss"]) - float(ref)) <= 1e-6 * abs(float(ref))
+        assert sl.tracked() == {}
