@@ -42,17 +42,44 @@ def _shard(rank):
     return {k: v.cuda() for k, v in R.make_batch(B, H, W, tag="dp.shard%d" % rank).items()}
 
 
-def _worker(rank, world, port, q, overlap):
+class _GlooBackedComm:
+    """stands in for footprints_amd.parallel.Communicator where RCCL cannot run (two ranks on one GPU): same interface, the collective
+    itself over the gloo group after draining the stream it was issued on -- so that GradReducer's "rccl" branch (library events
+    between the gradient-writing streams and the communication stream, all-reduces on the mask decoder's weight-gradient stream,
+    the compute stream joined before Adam) runs with a real world of two"""
+
+    def __init__(self, dist):
+        self.dist, self.rank, self.world, self.handle = dist, dist.get_rank(), dist.get_world_size(), None
+
+    def allreduce(self, t, stream):
+        stream.synchronize()
+        self.dist.all_reduce(t)
+
+    def broadcast(self, t, root, stream):
+        stream.synchronize()
+        self.dist.broadcast(t, src=root)
+
+    def destroy(self):
+        pass
+
+
+def _worker(rank, world, port, q, overlap, fake_rccl=False):
     try:
         import torch.distributed as dist
         os.environ["FP_DP_OVERLAP"] = "1" if overlap else "0"     # read when footprints_amd.parallel is imported
+        if fake_rccl:
+            os.environ["FP_DP_TRANSPORT"] = "rccl"
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
         torch.cuda.set_device(0)
         dist.init_process_group("gloo", rank=rank, world_size=world)
+        from footprints_amd import parallel
         from footprints_amd.model_manager import ModelManager
         from footprints_amd.parallel import broadcast_state
         from footprints_amd.training.train import TrainStep
+        if fake_rccl:
+            fake = _GlooBackedComm(dist)
+            parallel.get_communicator = lambda group=None, create=True: fake
         mm = ModelManager()
         P, Bf = _state("dp" if rank == 0 else "dp.other")     # rank 1 starts from different weights: broadcast_state must fix that
         _load(mm.model, P, Bf)
@@ -61,8 +88,11 @@ def _worker(rank, world, port, q, overlap):
             mm.model(_shard(rank)["image"])                     # of this rank's own weights, which broadcast_state has to invalidate
         mm.model.train()
         broadcast_state(mm.model)
-        ts = TrainStep(mm.model, mm.optimiser, distributed=True)
+        ts = TrainStep(mm.model, mm.optimiser, distributed=True, plan=False if fake_rccl else None)     # the stand-in is not recordable
         assert ts.reducer is not None and ts.reducer.world == 2 and ts.reducer.overlap == bool(overlap)
+        assert ts.reducer.transport == ("rccl" if fake_rccl else "torch")
+        if fake_rccl:
+            assert ts.reducer.stream.cuda_stream == ts.eng.dwg[0].cuda_stream        # the all-reduces ride an engine stream, not a sixth one
         batch = _shard(rank)
         losses = []
         for _ in range(STEPS):
@@ -77,14 +107,16 @@ def _worker(rank, world, port, q, overlap):
         q.put((rank, "error", traceback.format_exc(), repr(e)))
 
 
-@pytest.mark.parametrize("overlap", [False, True])     # buckets reduced after backward (FP_DP_OVERLAP=0) / as soon as each stage is complete (default)
-def test_two_ranks_share_weights_and_match_summed_shard_gradients(overlap):
+# buckets reduced after backward (FP_DP_OVERLAP=0) / as soon as each stage is complete (default); and the reducer's "rccl" branch with a
+# gloo-backed stand-in for the communicator (world of two)
+@pytest.mark.parametrize("overlap,fake_rccl", [(False, False), (True, False), (True, True), (False, True)])
+def test_two_ranks_share_weights_and_match_summed_shard_gradients(overlap, fake_rccl):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     try:
         port = _free_port()
-        procs = [ctx.Process(target=_worker, args=(r, 2, port, q, overlap)) for r in range(2)]
+        procs = [ctx.Process(target=_worker, args=(r, 2, port, q, overlap, fake_rccl)) for r in range(2)]
         for p in procs:
             p.start()
     except OSError as e:
