@@ -588,7 +588,7 @@ def main():
             pool.append((nrng.integers(0, 256, (H, W, 3), dtype=np.uint8), maps))
         nb = max(6, min(args.steps, 12))
         source = [[pool[(i * B + j) % len(pool)] for j in range(B)] for i in range(nb + 2)]
-        asm = DeviceBatchAssembler(B, H, W, dataset="kitti")
+        asm = DeviceBatchAssembler(B, H, W, dataset="kitti", stream=None if os.environ.get("FP_LOADER_OWN_STREAM") else step.eng.dwg[0])
         it = iter(DeviceLoader(source, asm, is_train=True, rng=_random.Random(SEED)))
         for _ in range(2):
             step(next(it))

@@ -817,8 +817,8 @@ def seg_loss_fwd_bwd(preds, ground_mask, loss_mask, losses_out, dpreds=None):
     D = (C.c_void_p * 4)(*[p.data_ptr() for p in dpreds]) if dpreds is not None else None
     hs = (C.c_int32 * 4)(*[p.shape[2] for p in preds])
     wss = (C.c_int32 * 4)(*[p.shape[3] for p in preds])
-    bs = (C.c_int64 * 4)(*[p.stride(0) for p in preds])
-    if dpreds is not None and any(d.stride(0) != p.stride(0) for d, p in zip(dpreds, preds)):
+    bs = (C.c_int64 * 4)(*[p.stride(0) if B > 1 else p.shape[2] * p.shape[3] for p in preds])      # a batch of one has no batch stride
+    if dpreds is not None and B > 1 and any(d.stride(0) != p.stride(0) for d, p in zip(dpreds, preds)):
         raise RuntimeError("footprints_amd.ops.seg_loss_fwd_bwd: gradient maps must be addressed like the predictions")
     _lib.check(lib.fp_seg_loss_fwd_bwd(P, D, hs, wss, bs, _f32(ground_mask), _f32(loss_mask), B, H, W, _f32(losses_out), ws.data_ptr(), ws.numel(),
                                        stream()), "fp_seg_loss_fwd_bwd")
