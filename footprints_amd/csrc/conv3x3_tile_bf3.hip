@@ -97,8 +97,13 @@ __device__ __forceinline__ void fp_tile_pixel(int pt, int& py, int& px) {
 // operands rounded to 16 significant bits, ~2^-17 relative) -- an opt-in INFERENCE mode (FP_EPI_BF16X2), never used for training
 // HP = the fp16-pair format of fp_common.h (NP = 2 planes, FP_HP_PRODUCTS = three products hh + hm + mh on v_mfma_f32_32x32x16_f16): operands carry
 // 22 significant bits after a per-tensor power-of-two scaling; two thirds of the MFMA work and of the LDS / weight traffic of the exact split.
-template <int TH, int TW, int BN, int WM, int WN, bool FLIP, bool FOLD, int NP = 3, bool HP = false>
-__global__ void __launch_bounds__(256, HP ? FP_TILE_HP_WAVES : 1) conv3x3_tile_bf3_kernel(const Tile3Args a) {
+// WPF ("weights per chunk in flight", round 3): the grids of the 6 x 20 ... 24 x 80 pyramid levels put less than two workgroups on a CU, so a
+// wave has its SIMD almost to itself and nothing hides the weight loads it issues two taps (2 x 192 MFMA cycles) ahead of their use:
+// SQ counters of 256 -> 256 @ 12 x 40 show the MFMA pipe 18 % busy and the waves parked on counters half of the time
+// (profiles/round3_pmc_sq_hp.txt).  With WPF the kernel gives up occupancy it does not have anyway (256 VGPRs) and keeps the NEXT chunk's
+// nine weight slices in flight in a second register set while the current chunk's are consumed: every load has a whole chunk to land.
+template <int TH, int TW, int BN, int WM, int WN, bool FLIP, bool FOLD, int NP = 3, bool HP = false, bool WPF = false>
+__global__ void __launch_bounds__(256, WPF ? 1 : (HP ? FP_TILE_HP_WAVES : 1)) conv3x3_tile_bf3_kernel(const Tile3Args a) {
   static_assert(!HP || NP == 2, "the fp16-pair format has two planes");
   constexpr int WPL = HP ? 2 : 3;                    // planes per weight slice in the packed buffer
   constexpr int BM128 = 128;
@@ -205,7 +210,8 @@ __global__ void __launch_bounds__(256, HP ? FP_TILE_HP_WAVES : 1) conv3x3_tile_b
   };
 
   // ---- weight slices: [tap][chunk][plane][n][16] bf16; lane (n = idx, k-group = h) reads 16 bytes per plane -----------------
-  uint4 bq[3][TN][NP];
+  uint4 bq[WPF ? 1 : 3][TN][NP];
+  uint4 bw[WPF ? 2 : 1][WPF ? 9 : 1][TN][NP];          // WPF: [chunk parity][tap]
   auto load_b = [&](int tap, int cc, uint4 (&bf)[TN][NP], bool prologue = false) {
 #if defined(FP_TILE_ABL) && FP_TILE_ABL == 3        // ablation: weight fragments loaded once
     if (!prologue) return;
@@ -295,11 +301,16 @@ __global__ void __launch_bounds__(256, HP ? FP_TILE_HP_WAVES : 1) conv3x3_tile_b
   st[12] = __builtin_amdgcn_s_memrealtime();       // 100 MHz constant clock: calibrates the shader clock under this kernel's load
 #endif
   load_halo(c_begin);
-  load_b(0, c_begin, bq[0], true);           // issued before the halo is consumed: one exposed load latency in the prologue, not two
-  load_b(1, c_begin, bq[1], true);
+  if constexpr (WPF) {
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) load_b(tp, c_begin, bw[0][tp], true);
+  } else {
+    load_b(0, c_begin, bq[0], true);           // issued before the halo is consumed: one exposed load latency in the prologue, not two
+    load_b(1, c_begin, bq[1], true);
 #if defined(FP_TILE_ABL) && FP_TILE_ABL == 3
-  load_b(2, c_begin, bq[2], true);
+    load_b(2, c_begin, bq[2], true);
 #endif
+  }
   store_halo(0);
   load_halo(min(c_begin + 1, c_end - 1));
   __syncthreads();
@@ -307,7 +318,8 @@ __global__ void __launch_bounds__(256, HP ? FP_TILE_HP_WAVES : 1) conv3x3_tile_b
 #ifdef FP_TILE_STAMPS
   st[1] = __builtin_readcyclecounter();
 #endif
-  for (int cc = c_begin; cc < c_end; ++cc) {
+  auto chunk = [&](auto par_tag, int cc) {
+    constexpr int PAR = decltype(par_tag)::value;          // (cc - c_begin) & 1, as a constant: register-set index of the WPF weights
     const unsigned char* Hb = lds + ((cc - c_begin) & 1) * BUF;
     const int ccn = min(cc + 1, c_end - 1);
     // A fragments are read one tap ahead (two register sets): with 32-cycle MFMAs an LDS read issued right before its
@@ -331,9 +343,14 @@ __global__ void __launch_bounds__(256, HP ? FP_TILE_HP_WAVES : 1) conv3x3_tile_b
       for (int tap = 0; tap < 9; ++tap) {
         __builtin_amdgcn_sched_barrier(0);
         if (tap < 8) load_a(tap + 1, af[(tap + 1) & 1]);
-        if (tap < 7) load_b(tap + 2, cc, bq[(tap + 2) % 3]);
-        else load_b(tap - 7, ccn, bq[(tap + 2) % 3]);
-        mma6(af[tap & 1], bq[tap % 3]);
+        if constexpr (WPF) {
+          load_b(tap, ccn, bw[PAR ^ 1][tap]);              // the next chunk's slice of this tap: a whole chunk ahead of its use
+          mma6(af[tap & 1], bw[PAR][tap]);
+        } else {
+          if (tap < 7) load_b(tap + 2, cc, bq[(tap + 2) % 3]);
+          else load_b(tap - 7, ccn, bq[(tap + 2) % 3]);
+          mma6(af[tap & 1], bq[tap % 3]);
+        }
         // issue order: one LDS / global read between consecutive MFMAs (this tap's MFMAs only depend on older reads)
         if (tap < 8) fp_sched_interleave<TM * NP, TN * NP, NPROD * TM * TN>();
         else fp_sched_interleave<0, TN * NP, NPROD * TM * TN>();
@@ -359,7 +376,8 @@ __global__ void __launch_bounds__(256, HP ? FP_TILE_HP_WAVES : 1) conv3x3_tile_b
                 ax[i][p] = v;
               }
             }
-            mma6(ax, bq[tap % 3]);
+            if constexpr (WPF) mma6(ax, bw[PAR][tap]);
+            else mma6(ax, bq[tap % 3]);
           }
         }
       }
@@ -379,6 +397,10 @@ __global__ void __launch_bounds__(256, HP ? FP_TILE_HP_WAVES : 1) conv3x3_tile_b
 #pragma unroll
       for (int k = 0; k < 6; ++k) if (cc - c_begin == k) st[8 + k] = now; }
 #endif
+  };
+  for (int cc = c_begin; cc < c_end; cc += 2) {
+    chunk(std::integral_constant<int, 0>{}, cc);
+    if (cc + 1 < c_end) chunk(std::integral_constant<int, 1>{}, cc + 1);
   }
 
   // ---- epilogue.  The flag tests are hoisted and every optional operand (addend, its mask, the activation source, the old
@@ -506,7 +528,7 @@ __global__ void __launch_bounds__(256, HP ? FP_TILE_HP_WAVES : 1) conv3x3_tile_b
 #endif
 }
 
-template <int TH, int TW, int BN, int WM, int WN, bool FLIP, bool FOLD, int NP = 3, bool HP = false>
+template <int TH, int TW, int BN, int WM, int WN, bool FLIP, bool FOLD, int NP = 3, bool HP = false, bool WPF = false>
 int launch3(Tile3Args& a, hipStream_t stream) {
   static const unsigned extra_lds = getenv("FP_TILE_EXTRA_LDS") ? (unsigned)atoi(getenv("FP_TILE_EXTRA_LDS")) : 0u;   // occupancy experiments
 #ifdef FP_TILE_STAMPS
@@ -515,7 +537,7 @@ int launch3(Tile3Args& a, hipStream_t stream) {
   if (!stamp_buf) (void)hipMalloc(&stamp_buf, (size_t)16384 * 4 * 16 * 8);
   a.stamps = stamp_file && a.nwg <= 16384 ? stamp_buf : nullptr;
 #endif
-  fp_launch((conv3x3_tile_bf3_kernel<TH, TW, BN, WM, WN, FLIP, FOLD, NP, HP>), dim3(a.nwg), dim3(256), extra_lds, stream, a);
+  fp_launch((conv3x3_tile_bf3_kernel<TH, TW, BN, WM, WN, FLIP, FOLD, NP, HP, WPF>), dim3(a.nwg), dim3(256), extra_lds, stream, a);
 #ifdef FP_TILE_STAMPS
   static int launch_no = 0;
   static const int dump_at = getenv("FP_TILE_STAMPS_AT") ? atoi(getenv("FP_TILE_STAMPS_AT")) : -1;     // dump only that launch (steady state)
@@ -647,7 +669,16 @@ int run_tile3(const char* who, const fp_conv_desc* d, const float* src, const fl
               : (fold ? launch3<TH_, TW_, 64, 2, 2, true, true, NP_, HP_>(a, stream)                                          \
                       : (flip ? launch3<TH_, TW_, 64, 2, 2, true, false, NP_, HP_>(a, stream)                                 \
                               : launch3<TH_, TW_, 64, 2, 2, false, false, NP_, HP_>(a, stream))))
-  if (hp) {
+  // small grids (64-channel tiles of the 6 x 20 ... 24 x 80 levels: under ~1.5 workgroups per CU): the weights-per-chunk-in-flight variant
+  static const int wpf_max = getenv("FP_TILE_WPF_MAX_WG") ? atoi(getenv("FP_TILE_WPF_MAX_WG")) : 400;
+  if (hp && p.bn == 64 && a.nwg <= wpf_max) {
+#define FP_L3W(TH_, TW_)                                                                                                     \
+  (fold ? launch3<TH_, TW_, 64, 2, 2, true, true, 2, true, true>(a, stream)                                                 \
+        : (flip ? launch3<TH_, TW_, 64, 2, 2, true, false, 2, true, true>(a, stream)                                        \
+                : launch3<TH_, TW_, 64, 2, 2, false, false, 2, true, true>(a, stream)))
+    rc = p.th == 8 ? FP_L3W(8, 16) : FP_L3W(6, 20);
+#undef FP_L3W
+  } else if (hp) {
     rc = p.th == 8 ? FP_L3X(8, 16, 2, true) : FP_L3X(6, 20, 2, true);
   } else if ((d->epi & FP_EPI_BF16X2) && !flip) {   // opt-in inference mode: two bf16 terms per operand, three products (forward only)
     if (p.th == 8) rc = p.bn == 32 ? launch3<8, 16, 32, 4, 1, false, false, 2>(a, stream) : launch3<8, 16, 64, 2, 2, false, false, 2>(a, stream);
