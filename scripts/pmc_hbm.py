@@ -40,7 +40,7 @@ def collect(d, counter):
                             key = entry
                             break
                     # fp16-pair instantiations of the same kernel templates (NP = 2 / HP = true) are their own entry points
-                    hp = ((key == "conv3x3_bf3" and ", 2, true>" in name) or
+                    hp = ((key == "conv3x3_bf3" and (", 2, true>" in name or ", 2, true, " in name)) or
                           (key == "conv_wgrad_bf3" and ", 2>(" in name) or (key == "conv_up2_phase_wgrad_bf3" and "<2>(" in name) or
                           (key in ("conv_up2_phase_fwd_bf3", "conv_up2_phase_dgrad_bf3") and ", 2>(" in name))
                     if hp:
