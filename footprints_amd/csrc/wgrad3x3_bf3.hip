@@ -14,6 +14,8 @@
 // current one (register prefetch, single LDS buffer, two barriers per chunk).  Sums across waves / splits: fixed order.
 #include <stdio.h>
 
+#include <type_traits>
+
 #include "fp_common.h"
 
 int fp_wgrad_reduce_launch(const float* part, float* dw, int S, int T, int Kc, int Nout, int stem, int accumulate, int kc_total,
@@ -42,6 +44,9 @@ struct W3Args {
 };
 
 constexpr int CH = 4, CW = 16, HR = CH + 2;
+#ifndef FP_WGRAD_PF_DEFAULT
+#define FP_WGRAD_PF_DEFAULT 2
+#endif
 constexpr int XROW = 48, ZROW = 48;                          // bytes per (row, channel) line: 20 / 16 bf16 + pad
 constexpr int XPLANE = HR * 32 * XROW, ZPLANE = CH * 32 * ZROW;
 constexpr int XBYTES = 3 * XPLANE, ZBYTES = 3 * ZPLANE;      // 27648 + 18432 = 46080
@@ -475,6 +480,242 @@ __global__ void __launch_bounds__(256, 2) wgrad3x3_bf3_v3_kernel(const W3Args a)
   }
 }
 
+// ---- fourth generation (fp16 pairs): the third's LDS layout and MFMA schedule, operands D chunks ahead in a register ring ----------
+// The third kernel runs one workgroup per CU (the planner's choice: fewer partial tensors, the other half of every SIMD's registers
+// stays with the data-gradient chain on the main stream) -- ONE wave per SIMD -- and its chunk period is a memory latency plus the
+// staging work: the next chunk's loads are issued at the top of a chunk and needed at its bottom, 27 MFMAs (~0.4 us) later.  Here a
+// chunk's loads are issued D chunk periods before they are staged: ring slot j holds chunk k + 1 + j while chunk k is multiplied;
+// the bottom of chunk k stages slot (k + 1) % D into the other LDS buffer and refills it with chunk k + 1 + D.  Every path issues the
+// same six vector loads (past the last chunk: from one cache line), so the wait counters the compiler derives are exact on all of
+// them; the staging has no branches either (the X plane is padded to 1024 items, the bias sum is masked by a multiplier).
+constexpr int XP4 = 1024 * 8;                                   // X plane: 864 staging items padded to 4 per thread
+constexpr int BUF4 = 2 * (XP4 + ZP3);                           // 24576 bytes per buffer
+
+template <int MODE, int D>
+__global__ void __launch_bounds__(256, D > 2 ? 1 : 2) wgrad3x3_hp_pf_kernel(const W3Args a) {
+  constexpr int XBN = 2 * XP4;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF4];
+  const int kx_ = fp_hp_exponent(fp_amax_bits(a.amax_x), FP_HP_TARGET_ACT);
+  const int kz_ = fp_hp_exponent(fp_amax_bits(a.amax_dz), FP_HP_TARGET_ACT);
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  int b = a.xcd ? fp_xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+  const int cot = b % a.cotiles; b /= a.cotiles;
+  const int cit = b % a.citiles; b /= a.citiles;
+  const int s = b;
+  const int ci0 = cit * 32, co0 = cot * 32;
+  const int cnt = s < a.nchunks ? (a.nchunks - 1 - s) / a.S + 1 : 0;     // this split's chunks: s, s + S, s + 2 S, ...
+  // coordinates of the next chunk to issue, advanced by S chunks with carries (no divisions in the loop)
+  int cx = s % a.chunksX, cy = (s / a.chunksX) % a.chunksY, cn = s / (a.chunksX * a.chunksY);
+  const int dcx = a.S % a.chunksX, dcy = (a.S / a.chunksX) % a.chunksY, dcn = a.S / (a.chunksX * a.chunksY);
+  int issued = 0;
+
+  // staging items e = t + 256 k: pixel e / 8 (row-major over the halo / the chunk), channel quad e % 8; X items past the halo's 108
+  // pixels re-load its last pixel into the plane's padding.
+  // Loads are raw buffer loads (`buffer_load_dwordx4 v, v_offset, s[rsrc], s_offset offen`): a 32-bit per-lane byte offset plus a
+  // wave-uniform one, no 64-bit address registers, and a lane whose offset has bit 31 set is out of the buffer's range and gets
+  // zeros without a memory access -- padding, masked-out corners and the loads past the last chunk need no branch around the load
+  // (tensors of 2 GB and more take the third-generation kernel).
+  const int q = t & 7;
+  unsigned xgb[4];                                                      // interior chunks: offsets from the halo's first pixel
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int p = min((t + 256 * k) >> 3, HR * HWD - 1);
+    const int hy = p / HWD, hx = p - hy * HWD;
+    xgb[k] = (unsigned)(((hy * a.W + hx) * a.C + ci0 + q * 4) * 4);
+  }
+  const unsigned zgb = (unsigned)((((t >> 7) * a.W + ((t >> 3) & 15)) * a.Nout + co0 + q * 4) * 4);
+  const unsigned zstep = (unsigned)(2 * a.W * a.Nout * 4);
+  const unsigned xbytes = (unsigned)((size_t)a.N * (MODE == 2 ? (a.H >> 1) * (a.W >> 1) : a.H * a.W) * a.C * 4);
+  const unsigned zbytes = (unsigned)((size_t)a.N * a.H * a.W * a.Nout * 4);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, xbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dz), 0, zbytes, 0x00020000);
+  constexpr unsigned OOB = 0x80000000u;
+  float4 xr[D][4], zv[D][2];
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) xr[j][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    zv[j][0] = zv[j][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const bool want_bias = a.bpart != nullptr && cit == 0;
+  float bs[4] = {0.f, 0.f, 0.f, 0.f};
+
+  auto issue = [&](auto slot_) {
+    constexpr int sl = decltype(slot_)::value;
+    unsigned vo[6], sox = 0, soz = 0;
+    if (issued >= cnt) {                               // past the last chunk: six loads that touch no memory
+#pragma unroll
+      for (int k = 0; k < 6; ++k) vo[k] = OOB;
+    } else {
+      ++issued;
+      const int y0 = cy * CH, x0 = cx * CW, n = cn;
+      cx += dcx;
+      int carry = cx >= a.chunksX ? 1 : 0;
+      cx -= carry * a.chunksX;
+      cy += dcy + carry;
+      carry = cy >= a.chunksY ? 1 : 0;
+      cy -= carry * a.chunksY;
+      cn += dcn + carry;
+      const bool fast = !a.nofast && MODE != 2 && y0 >= 1 && y0 + CH + 1 <= a.H && x0 >= 1 && x0 + CW + 1 <= a.W;
+      if (fast) {                                      // wave-uniform: no reflection, clamping or masks inside the image
+        const unsigned org = (unsigned)((n * a.H + y0) * a.W + x0);
+        sox = (org - a.W - 1) * a.C * 4;
+        soz = org * a.Nout * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) vo[k] = xgb[k];
+        vo[4] = zgb;
+        vo[5] = zgb + zstep;
+      } else {
+        int tt = t;                                    // opaque copy: the halo coordinates are recomputed here instead of living in
+        asm volatile("" : "+v"(tt));                   // eight registers (two of them spilled) across the whole kernel for the border chunks
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int p = min((tt + 256 * k) >> 3, HR * HWD - 1);
+          const int hy = p / HWD, hx = p - hy * HWD;
+          int sy = y0 + hy - 1, sx = x0 + hx - 1;
+          bool ok;
+          if (MODE == 0) ok = sy >= 0 && sy < a.H && sx >= 0 && sx < a.W;
+          else { ok = sy >= -1 && sy <= a.H && sx >= -1 && sx <= a.W; sy = fp_reflect(sy, a.H); sx = fp_reflect(sx, a.W); }
+          sy = min(max(sy, 0), a.H - 1);
+          sx = min(max(sx, 0), a.W - 1);
+          const unsigned xpix = MODE == 2 ? (unsigned)((n * (a.H >> 1) + (sy >> 1)) * (a.W >> 1) + (sx >> 1)) : (unsigned)((n * a.H + sy) * a.W + sx);
+          vo[k] = ((xpix * a.C + ci0 + q * 4) * 4) | (ok ? 0u : OOB);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int oy = y0 + (tt >> 7) + 2 * k, ox = x0 + ((tt >> 3) & 15);
+          const bool ok = oy < a.H && ox < a.W;
+          vo[4 + k] = ((unsigned)(((n * a.H + min(oy, a.H - 1)) * a.W + min(ox, a.W - 1)) * a.Nout + co0 + q * 4) * 4) | (ok ? 0u : OOB);
+        }
+      }
+    }
+    sox = __builtin_amdgcn_readfirstlane(sox);
+    soz = __builtin_amdgcn_readfirstlane(soz);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) xr[sl][k] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, vo[k], sox, 0));
+#pragma unroll
+    for (int k = 0; k < 2; ++k) zv[sl][k] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rz, vo[4 + k], soz, 0));
+  };
+  // `live` = 1.f when the slot holds a chunk of this split and the workgroup owns the bias partial, else 0.f
+  auto stage = [&](auto slot_, int buf, float live) {
+    constexpr int sl = decltype(slot_)::value;
+    unsigned char* const base = lds + buf * BUF4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      split_store_np<2>(base + (t + 256 * k) * 8, XP4, f32x4{xr[sl][k].x, xr[sl][k].y, xr[sl][k].z, xr[sl][k].w}, kx_);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      bs[0] = fmaf(zv[sl][k].x, live, bs[0]); bs[1] = fmaf(zv[sl][k].y, live, bs[1]);
+      bs[2] = fmaf(zv[sl][k].z, live, bs[2]); bs[3] = fmaf(zv[sl][k].w, live, bs[3]);
+      split_store_np<2>(base + XBN + (t + 256 * k) * 8, ZP3, f32x4{zv[sl][k].x, zv[sl][k].y, zv[sl][k].z, zv[sl][k].w}, kz_);
+    }
+  };
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[tp][r] = 0.f;
+
+  const float bias_on = want_bias ? 1.f : 0.f;
+  // prologue: chunk 0 through slot 0 into buffer 0, then chunks 1 .. D into slots 1 .. D - 1, 0
+  issue(std::integral_constant<int, 0>{});
+  stage(std::integral_constant<int, 0>{}, 0, cnt > 0 ? bias_on : 0.f);
+  if (D > 1) issue(std::integral_constant<int, 1 % D>{});
+  if (D > 2) issue(std::integral_constant<int, 2 % D>{});
+  issue(std::integral_constant<int, 0>{});
+  __syncthreads();
+
+  const int li = lane & 15;
+  const int lrow = 8 * (lane >> 5) + (li >> 2), lcol = 32 * ((lane >> 4) & 1) + 8 * (li & 3);
+  const int xrd = (wave * HWD + lrow) * PXB + lcol;
+  const int zrd = XBN + (wave * CW + lrow) * PXB + lcol;
+  // chunk k: multiply buffer k & 1; stage chunk k + 1 (slot (k + 1) % D, loaded D chunk periods ago) into the other buffer -- last
+  // read in chunk k - 1, before the barrier that ended it -- and refill the slot with chunk k + 1 + D
+  auto body = [&](auto slot_, int k) {
+    const unsigned char* const Bb = lds + (k & 1) * BUF4;
+    uint4 bz[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const uint2 lo = lds_tr16(Bb + zrd + p * ZP3), hi = lds_tr16(Bb + zrd + p * ZP3 + 4 * PXB);
+      bz[p] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    }
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      uint4 af[3][2];                                // [kx][plane]
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          const unsigned char* src = Bb + xrd + (ky * HWD + kx) * PXB + p * XP4;
+          const uint2 lo = lds_tr16(src), hi = lds_tr16(src + 4 * PXB);
+          af[kx][p] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
+      constexpr int PA[4] = {1, 1, 0, 0}, PB[4] = {1, 0, 1, 0};          // smallest products first
+#pragma unroll
+      for (int qq = 4 - FP_HP_PRODUCTS; qq < 4; ++qq)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+          acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[kx][PA[qq]]), __builtin_bit_cast(f16x8, bz[PB[qq]]),
+                                                                    acc[ky * 3 + kx], 0, 0, 0);
+    }
+    // nothing of the staging moves up among the MFMAs: its first instruction waits for the slot's loads, and every MFMA issued
+    // before that wait is time the loads have to land (D chunk periods instead of D - 1)
+    __builtin_amdgcn_sched_barrier(0);
+    stage(slot_, (k + 1) & 1, k + 1 < cnt ? bias_on : 0.f);
+    issue(slot_);
+    __syncthreads();
+  };
+  int k = 0;
+  if (D == 2) {
+    for (; k + 2 <= cnt; k += 2) {
+      body(std::integral_constant<int, 1 % D>{}, k);
+      body(std::integral_constant<int, 0>{}, k + 1);
+    }
+    if (k < cnt) body(std::integral_constant<int, 1 % D>{}, k);
+  } else {
+    for (; k + 3 <= cnt; k += 3) {
+      body(std::integral_constant<int, 1 % D>{}, k);
+      body(std::integral_constant<int, 2 % D>{}, k + 1);
+      body(std::integral_constant<int, 0>{}, k + 2);
+    }
+    if (k < cnt) body(std::integral_constant<int, 1 % D>{}, k);
+    if (k + 1 < cnt) body(std::integral_constant<int, 2 % D>{}, k + 1);
+  }
+
+  // ---- sum the four waves' tiles through LDS (fixed order), one tap at a time -----------------------------------------------------
+  float* red = reinterpret_cast<float*>(lds);        // [4 waves][16 regs][64 lanes] = 16 KB
+  float* out = a.part + (size_t)s * 9 * a.C * a.Nout;
+  if (want_bias) {                                   // 32 staging threads per channel quad -> one partial per output channel
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) red[(t >> 3) * 32 + q * 4 + kk] = bs[kk];
+    __syncthreads();
+    if (t < 32) {
+      float v = 0.f;
+#pragma unroll
+      for (int g = 0; g < 32; ++g) v += red[g * 32 + t];
+      a.bpart[(size_t)s * a.Nout + co0 + t] = v;
+    }
+    __syncthreads();
+  }
+  const float unscale = ldexpf(1.f, -(kx_ + kz_));
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[tp][r];
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int e = t + 256 * kk;
+      const float v = (((red[e] + red[1024 + e]) + red[2048 + e]) + red[3072 + e]) * unscale;
+      const int r = e >> 6, ln = e & 63;
+      const int ci = ci0 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
+      out[((size_t)tp * a.C + ci) * a.Nout + co0 + (ln & 31)] = v;
+    }
+    __syncthreads();
+  }
+}
+
 // dW_oihw[n][k_begin + k][tap] (+)= sum_s part[s][tap][k][n] and, in the SAME launch (tail blocks), db[n] (+)= sum_s bpart[s][n]: one
 // dependent launch instead of two behind every weight-gradient kernel (56 per training step).  Fixed combination order.
 __global__ void __launch_bounds__(256) wgrad_reduce_bias_kernel(const float* __restrict__ part, float* __restrict__ dw, int S, int Kc, int Nout,
@@ -617,7 +858,22 @@ static int wgrad_split(const fp_conv_desc* d, const float* x, const float* dz, f
     if (nwg <= 8192) a.stamps = stamp_buf;
   }
   static const int ver = getenv("FP_WGRAD_BF3_V") ? atoi(getenv("FP_WGRAD_BF3_V")) : 3;       // A/B switch: 1 = first generation, else third
-  if (hp) {
+  // FP_WGRAD_PF = depth of the register prefetch ring of the fourth generation (fp16 pairs only); 0 = third generation
+  static const int pf = getenv("FP_WGRAD_PF") ? atoi(getenv("FP_WGRAD_PF")) : FP_WGRAD_PF_DEFAULT;
+  const int64_t xbytes = (int64_t)d->N * (a.mode == 2 ? (d->OH / 2) * (int64_t)(d->OW / 2) : (int64_t)d->OH * d->OW) * d->C0 * 4;
+  const int64_t zbytes = (int64_t)d->N * d->OH * d->OW * d->Nout * 4;
+  const bool pf_fits = xbytes < (int64_t(1) << 31) && zbytes < (int64_t(1) << 31);       // 32-bit buffer offsets, bit 31 = "out of range"
+  if (hp && pf >= 1 && pf_fits && !a.stamps) {
+#define FP_W3_PF_LAUNCH(MODE_)                                                                                              \
+    do {                                                                                                                     \
+      if (pf <= 2) fp_launch((wgrad3x3_hp_pf_kernel<MODE_, 2>), dim3(nwg), dim3(256), 0, stream, a);                        \
+      else fp_launch((wgrad3x3_hp_pf_kernel<MODE_, 3>), dim3(nwg), dim3(256), 0, stream, a);                                \
+    } while (0)
+    if (a.mode == 0) FP_W3_PF_LAUNCH(0);
+    else if (a.mode == 1) FP_W3_PF_LAUNCH(1);
+    else FP_W3_PF_LAUNCH(2);
+#undef FP_W3_PF_LAUNCH
+  } else if (hp) {
     if (a.mode == 0) fp_launch((wgrad3x3_bf3_v3_kernel<0, 2>), dim3(nwg), dim3(256), 0, stream, a);
     else if (a.mode == 1) fp_launch((wgrad3x3_bf3_v3_kernel<1, 2>), dim3(nwg), dim3(256), 0, stream, a);
     else fp_launch((wgrad3x3_bf3_v3_kernel<2, 2>), dim3(nwg), dim3(256), 0, stream, a);
