@@ -754,6 +754,55 @@ __global__ void __launch_bounds__(256) wgrad_reduce_bias_kernel(const float* __r
   }
 }
 
+// The same sums (same combination order, bit for bit) for large weight tensors, written through an LDS transpose: the partial tiles
+// are [tap][k][n] (n fastest) while dW is OIHW ([n][k][tap]), so the kernel above writes every element into a cache line of its own
+// (stride 36 kc_total bytes) -- 590 k scattered 4-byte writes for 256 -> 256.  Here a workgroup owns 32 output x 8 input channels x
+// 9 taps: 128-byte reads along n, 288-byte runs along (k, tap) on the way out.
+__global__ void __launch_bounds__(256) wgrad_reduce_bias_t_kernel(const float* __restrict__ part, float* __restrict__ dw, int S, int Kc, int Nout,
+                                                                  int accumulate, int kc_total, int k_begin, int main_blocks,
+                                                                  const float* __restrict__ bpart, float* __restrict__ db) {
+  if ((int)blockIdx.x >= main_blocks) {
+    const int n = ((int)blockIdx.x - main_blocks) * 256 + threadIdx.x;
+    if (n >= Nout) return;
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    int s = 0;
+    for (; s + 3 < S; s += 4) {
+      v0 += bpart[(size_t)s * Nout + n]; v1 += bpart[(size_t)(s + 1) * Nout + n];
+      v2 += bpart[(size_t)(s + 2) * Nout + n]; v3 += bpart[(size_t)(s + 3) * Nout + n];
+    }
+    for (; s < S; ++s) v0 += bpart[(size_t)s * Nout + n];
+    const float v = (v0 + v1) + (v2 + v3);
+    db[n] = accumulate ? db[n] + v : v;
+    return;
+  }
+  __shared__ float tile[32][73];                       // [n][k * 9 + tap], odd row length: conflict-free both ways
+  const int nblocks = Nout >> 5;
+  const int n0 = ((int)blockIdx.x % nblocks) * 32, kk0 = ((int)blockIdx.x / nblocks) * 8;
+  const int ln = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const size_t total = (size_t)9 * Kc * Nout;
+#pragma unroll 3                                       // few splits (S = 1 .. 4 on the deep levels): three pairs' loads in flight together
+  for (int i = 0; i < 9; ++i) {
+    const int pair = g + 8 * i, tap = pair >> 3, kk = pair & 7;
+    const float* q0 = part + ((size_t)tap * Kc + kk0 + kk) * Nout + n0 + ln;
+    float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f, p4 = 0.f, p5 = 0.f, p6 = 0.f, p7 = 0.f;
+    int s = 0;
+    for (; s + 8 <= S; s += 8) {
+      const float* q = q0 + (size_t)s * total;
+      p0 += q[0]; p1 += q[total]; p2 += q[2 * total]; p3 += q[3 * total];
+      p4 += q[4 * total]; p5 += q[5 * total]; p6 += q[6 * total]; p7 += q[7 * total];
+    }
+    for (; s < S; ++s) p0 += q0[(size_t)s * total];
+    tile[ln][kk * 9 + tap] = ((p0 + p1) + (p2 + p3)) + ((p4 + p5) + (p6 + p7));
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const int idx = threadIdx.x + 256 * i, n = idx / 72, c = idx - n * 72;
+    const size_t o = ((size_t)(n0 + n) * kc_total + k_begin + kk0) * 9 + c;
+    dw[o] = accumulate ? dw[o] + tile[n][c] : tile[n][c];
+  }
+}
+
 // db[n] (+)= sum_s bpart[s][n], fixed order
 __global__ void __launch_bounds__(256) wgrad_bias_reduce_kernel(const float* __restrict__ bpart, int S, int Nout, float* __restrict__ db,
                                                                 int accumulate) {
@@ -905,9 +954,16 @@ static int wgrad_split(const fp_conv_desc* d, const float* x, const float* dz, f
     return fp_wgrad_reduce_launch((const float*)workspace, dw_oihw, p.S, 9, d->C0, d->Nout, 0, accumulate, kc_total, k_begin, stream);
   }
   const int64_t total = (int64_t)9 * d->C0 * d->Nout;
+  const int bias_blocks = db ? (d->Nout + 255) / 256 : 0;
+  static const int t_min = getenv("FP_WGRAD_REDUCE_T_MIN") ? atoi(getenv("FP_WGRAD_REDUCE_T_MIN")) : 512;   // 0 = never; measured: 512 -> 512 @ 6 x 20: 111 -> 90 us, but 256 -> 256 (256 workgroups): 60 -> 63 us
+  const int t_blocks = (d->Nout / 32) * (d->C0 / 8);
+  if (t_min > 0 && t_blocks >= t_min) {
+    fp_launch(wgrad_reduce_bias_t_kernel, dim3(t_blocks + bias_blocks), dim3(256), 0, stream, (const float*)workspace, dw_oihw, p.S,
+                       d->C0, d->Nout, accumulate, kc_total, k_begin, t_blocks, (const float*)a.bpart, db);
+    return fp_check_launch("fp_conv_wgrad_bf3(reduce)");
+  }
   int main_blocks = (int)fp_ceil_div(total, 256);
   if (main_blocks > 4096) main_blocks = 4096;
-  const int bias_blocks = db ? (d->Nout + 255) / 256 : 0;
   fp_launch(wgrad_reduce_bias_kernel, dim3(main_blocks + bias_blocks), dim3(256), 0, stream, (const float*)workspace, dw_oihw, p.S,
                      d->C0, d->Nout, accumulate, kc_total, k_begin, main_blocks, (const float*)a.bpart, db);
   return fp_check_launch("fp_conv_wgrad_bf3(reduce)");
