@@ -102,6 +102,9 @@ __device__ __forceinline__ void fp_tile_pixel(int pt, int& py, int& px) {
 // SQ counters of 256 -> 256 @ 12 x 40 show the MFMA pipe 18 % busy and the waves parked on counters half of the time
 // (profiles/round3_pmc_sq_hp.txt).  With WPF the kernel gives up occupancy it does not have anyway (256 VGPRs) and keeps the NEXT chunk's
 // nine weight slices in flight in a second register set while the current chunk's are consumed: every load has a whole chunk to land.
+#ifndef FP_TILE_WPF_HALO_SETS
+#define FP_TILE_WPF_HALO_SETS 2
+#endif
 template <int TH, int TW, int BN, int WM, int WN, bool FLIP, bool FOLD, int NP = 3, bool HP = false, bool WPF = false>
 __global__ void __launch_bounds__(256, WPF ? 1 : (HP ? FP_TILE_HP_WAVES : 1)) conv3x3_tile_bf3_kernel(const Tile3Args a) {
   static_assert(!HP || NP == 2, "the fp16-pair format has two planes");
@@ -167,27 +170,32 @@ __global__ void __launch_bounds__(256, WPF ? 1 : (HP ? FP_TILE_HP_WAVES : 1)) co
     pix[k] = (n_img * a.IH + sy) * a.IW + sx;
     pixlo[k] = (n_img * (a.IH >> 1) + (sy >> 1)) * (a.IW >> 1) + (sx >> 1);     // nearest x2: src = dst // 2 (after the reflection)
   }
-  float4 hreg[NS];
-  bool hzero = false;
-  auto load_halo = [&](int cc) {
+  // HD register sets: the small grids of the WPF variant (less than one wave per SIMD, nothing else to hide a load behind) keep the
+  // halos of the next TWO chunks in flight -- chunk j's halo lives in set (j - c_begin) & 1
+  constexpr int HD = WPF ? FP_TILE_WPF_HALO_SETS : 1;
+  float4 hreg[HD][NS];
+  bool hzero[HD] = {};
+  auto load_halo = [&](int cc, auto set_tag) {
+    constexpr int hs = decltype(set_tag)::value % HD;
     const int c4 = cc * 16 + (t & 3) * 4;
-    hzero = c4 >= a.C;
+    hzero[hs] = c4 >= a.C;
     if (cc * 16 < a.Clo) {                 // uniform: chunks of the upsampled half (Clo is a multiple of 16)
 #pragma unroll
-      for (int k = 0; k < NS; ++k) hreg[k] = *reinterpret_cast<const float4*>(a.src_lo + (size_t)pixlo[k] * a.Clo + c4);
+      for (int k = 0; k < NS; ++k) hreg[hs][k] = *reinterpret_cast<const float4*>(a.src_lo + (size_t)pixlo[k] * a.Clo + c4);
     } else {
-      const int cs = a.C - a.Clo, coff = hzero ? 0 : c4 - a.Clo;
+      const int cs = a.C - a.Clo, coff = hzero[hs] ? 0 : c4 - a.Clo;
 #pragma unroll
-      for (int k = 0; k < NS; ++k) hreg[k] = *reinterpret_cast<const float4*>(a.src + (size_t)pix[k] * cs + coff);
+      for (int k = 0; k < NS; ++k) hreg[hs][k] = *reinterpret_cast<const float4*>(a.src + (size_t)pix[k] * cs + coff);
     }
   };
   // fp32 -> three bf16 planes, 4 channels (8 bytes) per plane per slot
-  auto store_halo = [&](int buf) {
+  auto store_halo = [&](int buf, auto set_tag) {
+    constexpr int hs = decltype(set_tag)::value % HD;
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
       if (lds_off[k] < 0) continue;
-      f32x4 v = {hreg[k].x, hreg[k].y, hreg[k].z, hreg[k].w};
-      if (!hvalid[k] || hzero) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 v = {hreg[hs][k].x, hreg[hs][k].y, hreg[hs][k].z, hreg[hs][k].w};
+      if (!hvalid[k] || hzero[hs]) v = f32x4{0.f, 0.f, 0.f, 0.f};
       unsigned char* p = lds + buf * BUF + lds_off[k];
       if (HP) {
         v = f32x4{ldexpf(v.x, ka), ldexpf(v.y, ka), ldexpf(v.z, ka), ldexpf(v.w, ka)};
@@ -300,7 +308,7 @@ __global__ void __launch_bounds__(256, WPF ? 1 : (HP ? FP_TILE_HP_WAVES : 1)) co
   st[0] = __builtin_readcyclecounter();
   st[12] = __builtin_amdgcn_s_memrealtime();       // 100 MHz constant clock: calibrates the shader clock under this kernel's load
 #endif
-  load_halo(c_begin);
+  load_halo(c_begin, std::integral_constant<int, 0>{});
   if constexpr (WPF) {
 #pragma unroll
     for (int tp = 0; tp < 9; ++tp) load_b(tp, c_begin, bw[0][tp], true);
@@ -311,8 +319,9 @@ __global__ void __launch_bounds__(256, WPF ? 1 : (HP ? FP_TILE_HP_WAVES : 1)) co
     load_b(2, c_begin, bq[2], true);
 #endif
   }
-  store_halo(0);
-  load_halo(min(c_begin + 1, c_end - 1));
+  store_halo(0, std::integral_constant<int, 0>{});
+  load_halo(min(c_begin + 1, c_end - 1), std::integral_constant<int, 1>{});
+  if (HD == 2) load_halo(min(c_begin + 2, c_end - 1), std::integral_constant<int, 0>{});
   __syncthreads();
 
 #ifdef FP_TILE_STAMPS
@@ -388,8 +397,8 @@ __global__ void __launch_bounds__(256, WPF ? 1 : (HP ? FP_TILE_HP_WAVES : 1)) co
       for (int k = 0; k < 6; ++k) if (cc - c_begin == k) st[2 + k] = now; }
 #endif
     if (cc + 1 < c_end) {
-      store_halo((cc + 1 - c_begin) & 1);
-      load_halo(min(cc + 2, c_end - 1));
+      store_halo((cc + 1 - c_begin) & 1, std::integral_constant<int, PAR ^ 1>{});
+      load_halo(min(cc + 1 + HD, c_end - 1), std::integral_constant<int, PAR ^ 1>{});
       __syncthreads();
     }
 #ifdef FP_TILE_STAMPS
