@@ -229,7 +229,8 @@ GROUPS = {
                        products=HP_PRODUCTS),
     "conv_up2_phase_fwd_hp": dict(kernel="up2_phase_fwd_bf3_kernel<..., 2> (fp16-pair operands)", bf16x3=False, products=HP_PRODUCTS),
     "conv_up2_phase_dgrad_hp": dict(kernel="up2_phase_dgrad_bf3_kernel<..., 2> (fp16-pair operands)", bf16x3=False, products=HP_PRODUCTS),
-    "conv_wgrad_hp": dict(kernel="wgrad3x3_bf3_v3_kernel<MODE, 2> (fp16-pair operands; + wgrad_reduce_bias_kernel)", bf16x3=False, products=HP_PRODUCTS),
+    "conv_wgrad_hp": dict(kernel="wgrad3x3_hp_pf_kernel<MODE, 2> (fp16-pair operands, two-deep register prefetch ring; + wgrad_reduce_bias[_t]_kernel)", bf16x3=False,
+                          products=HP_PRODUCTS),
     "conv_up2_phase_wgrad_hp": dict(kernel="wgrad_up2_phase_bf3_kernel<2> (fp16-pair operands; + its sum / un-collapse / bias reduce launches)",
                                     bf16x3=False, products=HP_PRODUCTS),
     "conv_igemm": dict(kernel="igemm_kernel / stem_tile_kernel (7x7 stem, 4x4/2 phase dgrad of small levels; stride 2 / 1x1 with FP_HP_IGEMM=0)", bf16x3=False),
@@ -246,7 +247,7 @@ GROUPS = {
 # main kernel symbol(s) of each entry point (the name before the template arguments, as fp_ktime_row / rocprofv3 print it)
 GROUP_SYMBOL = {
     "conv3x3_hp": ("conv3x3_tile_bf3_kernel",), "conv3x3_bf3": ("conv3x3_tile_bf3_kernel",),
-    "conv_wgrad_hp": ("wgrad3x3_bf3_v3_kernel", "wgrad3x3_bf3_kernel"), "conv_wgrad_bf3": ("wgrad3x3_bf3_v3_kernel", "wgrad3x3_bf3_kernel"),
+    "conv_wgrad_hp": ("wgrad3x3_hp_pf_kernel", "wgrad3x3_bf3_v3_kernel", "wgrad3x3_bf3_kernel"), "conv_wgrad_bf3": ("wgrad3x3_bf3_v3_kernel", "wgrad3x3_bf3_kernel"),
     "conv_up2_phase_fwd_hp": ("up2_phase_fwd_bf3_kernel",), "conv_up2_phase_fwd_bf3": ("up2_phase_fwd_bf3_kernel",),
     "conv_up2_phase_dgrad_hp": ("up2_phase_dgrad_bf3_kernel",), "conv_up2_phase_dgrad_bf3": ("up2_phase_dgrad_bf3_kernel",),
     "conv_up2_phase_wgrad_hp": ("wgrad_up2_phase_bf3_kernel",), "conv_up2_phase_wgrad_bf3": ("wgrad_up2_phase_bf3_kernel",),

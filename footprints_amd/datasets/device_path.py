@@ -101,20 +101,21 @@ class DeviceBatchAssembler:
                 d_par=torch.empty_like(h_par, device=self.device), sums=torch.zeros(batch_size, dtype=torch.int64, device=self.device),
                 image=torch.empty((batch_size, 3, height, width), device=self.device),
                 out=torch.empty((len(OUT_KEYS), batch_size, height, width), device=self.device),
-                ready=torch.cuda.Event(), consumed=None))
+                ready=torch.cuda.Event(), consumed=None, launched=False))
         self._next = 0
         assert npx > 0
 
-    def submit(self, samples, params):
-        """stage one batch; returns the slot index to pass to collect().  Blocks only if that slot's previous batch is still being
-        read by the consumer stream (its `consumed` event)."""
+    def fill(self, samples, params):
+        """host half of staging one batch: copy the samples and augmentation draws into the next slot's pinned buffers (60 MB of numpy
+        copies for a KITTI batch with float64 maps -- DeviceLoader runs this in a worker thread).  Waits only for the slot's previous
+        H2D copies.  Returns the slot index for launch()."""
         if len(samples) != self.B or len(params) != self.B:
             raise ValueError("expected %d samples" % self.B)
         i = self._next
         self._next = (self._next + 1) % len(self.slots)
         s = self.slots[i]
-        if s["consumed"] is not None:
-            s["consumed"].synchronize()                      # the consumer finished reading this slot's outputs
+        if s["launched"]:
+            s["ready"].synchronize()                         # the pinned buffers are free once the slot's last copies have landed
         img_np, maps_np = s["h_img"].numpy(), s["h_maps"].numpy()
         for b, (img, maps) in enumerate(samples):
             img_np[b] = img
@@ -122,6 +123,14 @@ class DeviceBatchAssembler:
                 maps_np[k, b] = maps[key]
         arr = (AugParams * self.B)(*params)
         s["h_par"].numpy()[:] = np.frombuffer(bytes(arr), dtype=np.uint8)
+        return i
+
+    def launch(self, i):
+        """device half: H2D copies + assembly kernels of a filled slot on the copy stream, behind the consumer's last read of the slot's
+        device buffers (an event wait on the stream: the host does not block)."""
+        s = self.slots[i]
+        if s["consumed"] is not None:
+            self.stream.wait_event(s["consumed"])            # the consumer finished reading this slot's outputs
         with ops.on_stream(self.stream):
             s["d_img"].copy_(s["h_img"], non_blocking=True)
             s["d_maps"].copy_(s["h_maps"], non_blocking=True)
@@ -138,7 +147,12 @@ class DeviceBatchAssembler:
                                               self.B, self.H, self.W, 0 if kitti else 1, int(self.no_depth_mask), int(self.pdb),
                                               int(self.use_moving), self.threshold, self.fxb, self.depth_scaling, st), "fp_assemble_labels")
             s["ready"].record(self.stream)
+        s["launched"] = True
         return i
+
+    def submit(self, samples, params):
+        """stage one batch (fill + launch); returns the slot index to pass to collect()"""
+        return self.launch(self.fill(samples, params))
 
     def collect(self, slot):
         """batch dict (reference schema) of the slot; the current stream waits for the slot's kernels.  The tensors are views of the
@@ -170,24 +184,36 @@ class DeviceLoader:
     def __len__(self):
         return len(self.source)
 
-    def _stage(self, samples):
-        params = [draw_augmentation(self.is_train, self.rng) for _ in samples]
-        return self.asm.submit(samples, params)
-
     def __iter__(self):
+        # one worker thread does the host half of staging (augmentation draws in batch order + the copies into pinned memory: numpy
+        # releases the GIL for them), one batch ahead of the batch whose copies and kernels are in flight, two ahead of the consumer
+        from concurrent.futures import ThreadPoolExecutor
         it = iter(self.source)
-        try:
-            pending = self._stage(next(it))
-        except StopIteration:
-            return
-        for samples in it:
-            batch = self.asm.collect(pending)
-            nxt = self._stage(samples)                  # the OTHER slot: copied and assembled while the consumer works on `pending`
-            yield batch
-            self.asm.release(pending)                   # the step that used it has been queued: its completion frees the slot
-            pending = nxt
-        yield self.asm.collect(pending)
-        self.asm.release(pending)
+
+        def fill_next():
+            try:
+                samples = next(it)
+            except StopIteration:
+                return None
+            return self.asm.fill(samples, [draw_augmentation(self.is_train, self.rng) for _ in samples])
+
+        with ThreadPoolExecutor(1) as ex:
+            pending = fill_next()
+            if pending is None:
+                return
+            self.asm.launch(pending)
+            fut = ex.submit(fill_next)
+            while True:
+                batch = self.asm.collect(pending)
+                nxt = fut.result()
+                if nxt is not None:
+                    self.asm.launch(nxt)                  # the OTHER slot: copied and assembled while the consumer works on `pending`
+                    fut = ex.submit(fill_next)
+                yield batch
+                self.asm.release(pending)                 # the step that used it has been queued: its completion frees the slot
+                if nxt is None:
+                    return
+                pending = nxt
 
 
 class SyntheticSampleSource:
