@@ -36,3 +36,21 @@ unsigned* fp_take_amax_out() {
   g_amax_next = nullptr;
   return s;
 }
+
+// BatchNorm-statistics sink (fp_bn_stats_out_next): consumed -- and cleared -- by this thread's next convolution launch
+struct FpBnSink {
+  float* part;
+  int64_t cap_floats;
+  int32_t* nblk_out;
+};
+static thread_local FpBnSink g_bn_next = {nullptr, 0, nullptr};
+extern "C" int fp_bn_stats_out_next(float* part, int64_t capacity_floats, int32_t* nblk_out) {
+  g_bn_next = FpBnSink{part, capacity_floats, nblk_out};
+  if (nblk_out) *nblk_out = 0;
+  return FP_OK;
+}
+FpBnSink fp_take_bn_sink() {
+  FpBnSink s = g_bn_next;
+  g_bn_next = FpBnSink{nullptr, 0, nullptr};
+  return s;
+}

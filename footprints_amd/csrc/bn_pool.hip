@@ -13,24 +13,9 @@ namespace {
 #endif
 constexpr int BN_MAX_BLOCKS = FP_BN_MAX_BLOCKS;
 
-struct Wf {  // Welford triple
-  float n, mean, m2;
-};
-__device__ __forceinline__ void wf_add(Wf& a, float x, float n, float rn) {  // n = new count, rn = 1/n
-  a.n = n;
-  const float d = x - a.mean;
-  a.mean += d * rn;
-  a.m2 += d * (x - a.mean);
-}
-__device__ __forceinline__ void wf_merge(Wf& a, const Wf& b) {
-  const float n = a.n + b.n;
-  if (n == 0.f) return;
-  const float d = b.mean - a.mean;
-  const float f = b.n / n;
-  a.mean += d * f;
-  a.m2 += b.m2 + d * d * a.n * f;
-  a.n = n;
-}
+typedef FpWf Wf;   // Welford triple (fp_common.h)
+__device__ __forceinline__ void wf_add(Wf& a, float x, float n, float rn) { fp_wf_add(a, x, n, rn); }
+__device__ __forceinline__ void wf_merge(Wf& a, const Wf& b) { fp_wf_merge(a, b); }
 
 int bn_blocks(int64_t M, int C) {
   const int rows = 256 / (C / 4);
@@ -650,6 +635,18 @@ extern "C" int fp_bn_train_stats(const float* z, int64_t M, int32_t C, const flo
                      C, gamma, beta, eps, momentum, running_mean, running_var, (long long*)num_batches_tracked, save_mean,
                      save_invstd, scale, shift);
   return fp_check_launch("fp_bn_train_stats");
+}
+
+// the second half of fp_bn_train_stats on Welford partials somebody else wrote: part[blk][c] = (n, mean, M2), e.g. the tile convolution's
+// epilogue (fp_bn_stats_out_next) -- one launch instead of two, and the activation is not read again
+extern "C" int fp_bn_train_stats_partials(const float* part, int32_t nblk, int32_t C, const float* gamma, const float* beta, float eps,
+                                          float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                                          float* save_mean, float* save_invstd, float* scale, float* shift, fp_stream_t stream) {
+  FP_REQUIRE(part && gamma && beta && save_mean && save_invstd && scale && shift, "fp_bn_train_stats_partials: null pointer");
+  FP_REQUIRE(nblk > 0 && C > 0, "fp_bn_train_stats_partials: empty problem");
+  fp_launch(bn_stats_final_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, part, (int)nblk, C, gamma, beta, eps, momentum,
+            running_mean, running_var, (long long*)num_batches_tracked, save_mean, save_invstd, scale, shift);
+  return fp_check_launch("fp_bn_train_stats_partials");
 }
 
 extern "C" int fp_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,

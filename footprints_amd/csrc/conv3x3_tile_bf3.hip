@@ -61,6 +61,7 @@ struct Tile3Args {
   const unsigned* amax_a1;
   const unsigned* amax_w;
   unsigned* amax_out;
+  float* bn_part;     // forward conv in front of a train-mode BatchNorm (unsplit, no epilogue options): Welford partials [pixel tile][Nout][3], or null
 #ifdef FP_TILE_STAMPS
   unsigned long long* stamps;   // diagnostics build only (scripts/build_variant.sh ... -DFP_TILE_STAMPS): 16 clocks per workgroup
 #endif
@@ -422,6 +423,15 @@ __global__ void __launch_bounds__(256, WPF ? 1 : (HP ? FP_TILE_HP_WAVES : 1)) co
   const bool interior = NPIX == 128 && y0 + TH <= a.OH && x0 + TW <= a.OW;
   float ymax = 0.f;                                  // HP: largest stored magnitude of this lane (the consumer's scale)
   const float unscale = HP ? ldexpf(1.f, kunscale) : 1.f;      // wave-uniform power of two: one fused multiply-add per element un-scales and adds the bias
+  // accumulator register r of M block i -> tile pixel
+  auto acc_pixel = [&](int i, int r, int& py, int& px) {
+    if (TW == 16) {              // pt = blk*32 + (r&3) + 8*(r>>2) + 4h  =>  row = 2*blk + (r>>3), column from constants and h
+      py = 2 * (wm * TM + i) + (r >> 3);
+      px = ((r & 3) + 8 * ((r >> 2) & 1) + 4 * h - 2 * ((r >> 3) & 1)) & 15;
+    } else {
+      fp_tile_pixel<TW>((wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, py, px);
+    }
+  };
   auto rows8 = [&](auto full_tag, int i, int j, int n, float bias, int half) {
     constexpr bool FULL = decltype(full_tag)::value;
     int off[8];
@@ -430,12 +440,7 @@ __global__ void __launch_bounds__(256, WPF ? 1 : (HP ? FP_TILE_HP_WAVES : 1)) co
     for (int k = 0; k < 8; ++k) {
       const int r = half * 8 + k;
       int py, px;
-      if (TW == 16) {            // pt = blk*32 + (r&3) + 8*(r>>2) + 4h  =>  row = 2*blk + (r>>3), column from constants and h
-        py = 2 * (wm * TM + i) + (r >> 3);
-        px = ((r & 3) + 8 * ((r >> 2) & 1) + 4 * h - 2 * ((r >> 3) & 1)) & 15;
-      } else {
-        fp_tile_pixel<TW>((wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, py, px);
-      }
+      acc_pixel(i, r, py, px);
       const int oy = y0 + py, ox = x0 + px;
       ok[k] = FULL || ((wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h < NPIX && oy < a.OH && ox < a.OW);
       off[k] = ((n_img * a.OH + (FULL ? oy : min(oy, a.OH - 1))) * a.OW + (FULL ? ox : min(ox, a.OW - 1))) * a.Nout + n;
@@ -515,6 +520,69 @@ __global__ void __launch_bounds__(256, WPF ? 1 : (HP ? FP_TILE_HP_WAVES : 1)) co
         rows8(std::false_type{}, i, j, n, bias, 1);
       }
     }
+  if (!FLIP && a.bn_part) {                          // (compile time for the data-gradient variants: their register budgets are unchanged)
+    // BatchNorm statistics out of the epilogue (wave-uniform; the launcher sets bn_part only for unsplit grids without bias / addend /
+    // activation, so the stored value is acc * unscale): a lane's TM x 16 values of output channel n -> two-pass (count, mean, M2) in
+    // registers -> Chan merge with the other half-wave's pixels -> across the WM waves that share the channel through LDS, fixed order
+    // -> part[pixel tile][n].  bn_stats_final_kernel (bn_pool.hip) merges the tiles; the activation is never read for its statistics.
+    float* const st = reinterpret_cast<float*>(lds) + 16;          // [wave][TN * 32][3] floats behind the amax words
+    __syncthreads();                                               // every wave is done with the halo buffers
+    auto lane_stats = [&](auto full_tag, int j) {    // two passes over the lane's registers; validity recomputed, not kept
+      constexpr bool FULL = decltype(full_tag)::value;
+      auto ok_at = [&](int i, int r) {
+        if (FULL) return NPIX == 128 || (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h < NPIX;     // tile inside the image
+        int py, px;
+        acc_pixel(i, r, py, px);
+        return (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h < NPIX && y0 + py < a.OH && x0 + px < a.OW;
+      };
+      float cnt = 0.f, sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const bool ok = ok_at(i, r);
+          cnt += ok ? 1.f : 0.f;
+          sum += ok ? acc[i][j][r] * unscale : 0.f;
+        }
+      FpWf w{cnt, cnt > 0.f ? sum / cnt : 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float dv = acc[i][j][r] * unscale - w.mean;
+          w.m2 += ok_at(i, r) ? dv * dv : 0.f;
+        }
+      return w;
+    };
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const FpWf w = (y0 + TH <= a.OH && x0 + TW <= a.OW) ? lane_stats(std::true_type{}, j) : lane_stats(std::false_type{}, j);
+      const FpWf o{__shfl_xor(w.n, 32, 64), __shfl_xor(w.mean, 32, 64), __shfl_xor(w.m2, 32, 64)};
+      FpWf lo = h == 0 ? w : o;                                      // both half-waves form merge(h = 0, h = 1)
+      fp_wf_merge(lo, h == 0 ? o : w);
+      if (h == 0) {
+        float* q = st + ((wave * TN + j) * 32 + idx) * 3;
+        q[0] = lo.n; q[1] = lo.mean; q[2] = lo.m2;
+      }
+    }
+    __syncthreads();
+    if (t < BN) {                                                  // one thread per output channel of the tile: merge the WM waves in order
+      const int cw = t / (TN * 32), cj = (t / 32) % TN, ci = t & 31;   // wn, j, lane of the channel
+      const float* q = st + (((0 * WN + cw) * TN + cj) * 32 + ci) * 3;
+      FpWf m{q[0], q[1], q[2]};
+#pragma unroll
+      for (int k = 1; k < WM; ++k) {
+        const float* qk = st + (((k * WN + cw) * TN + cj) * 32 + ci) * 3;
+        fp_wf_merge(m, FpWf{qk[0], qk[1], qk[2]});
+      }
+      const int n = n0 + t;
+      if (n < a.Nout) {
+        float* o = a.bn_part + ((size_t)((n_img * a.tilesY + tile_y) * a.tilesX + tile_x) * a.Nout + n) * 3;
+        o[0] = m.n; o[1] = m.mean; o[2] = m.m2;
+      }
+    }
+    __syncthreads();                                               // the amax words below share the buffer's first bytes
+  }
   if (HP && a.amax_out && a.SK <= 1) {               // one publication per workgroup (the halo buffers are free by now)
     ymax = fp_wave_max(ymax);
     float* wmax = reinterpret_cast<float*>(lds);
@@ -642,6 +710,7 @@ struct HpSlots { const unsigned* a; const unsigned* a1; const unsigned* w; unsig
 int run_tile3(const char* who, const fp_conv_desc* d, const float* src, const float* src1, const void* wpacked, const float* bias,
               const float* addend, const float* addend_mask, const float* actsrc, float* y, void* workspace, int64_t workspace_bytes,
               const HpSlots* hp, hipStream_t stream) {
+  const FpBnSink bn_sink = fp_take_bn_sink();        // consumed first: an argument error below must not leave the sink armed
   FP_REQUIRE(d && src && wpacked && y, "fp_conv3x3_bf3 / fp_conv3x3_hp: null pointer");
   const Plan3 p = plan3(d);
   FP_REQUIRE(p.ok, "fp_conv3x3_bf3 / fp_conv3x3_hp: shape not supported (see fp_conv3x3_bf3_supported)");
@@ -652,6 +721,7 @@ int run_tile3(const char* who, const fp_conv_desc* d, const float* src, const fl
   FP_REQUIRE(p.SK <= 1 || (workspace && workspace_bytes >= fp_conv3x3_bf3_workspace(d)), "fp_conv3x3_bf3 / fp_conv3x3_hp: workspace too small");
   FP_REQUIRE((int64_t)d->N * d->OH * d->OW * d->Nout < ((int64_t)1 << 31), "fp_conv3x3_bf3 / fp_conv3x3_hp: output larger than 2^31 elements");
   Tile3Args a;
+  a.bn_part = nullptr;
   const bool up2 = d->gather == FP_GATHER_FWD_REFLECT_UP2;
   FP_REQUIRE(!up2 || d->C1 == 0 || src1, "fp_conv3x3_bf3 / fp_conv3x3_hp: the concat gather needs the skip tensor (src1)");
   a.src_lo = up2 ? src : nullptr; a.Clo = up2 ? d->C0 : 0;
@@ -667,6 +737,15 @@ int run_tile3(const char* who, const fp_conv_desc* d, const float* src, const fl
   a.part = (float*)workspace;
   a.amax_a = hp ? hp->a : nullptr; a.amax_a1 = hp && up2 && d->C1 ? hp->a1 : nullptr; a.amax_w = hp ? hp->w : nullptr;
   a.amax_out = hp ? hp->out : nullptr;
+  {
+    // BatchNorm-statistics sink (fp_bn_stats_out_next): only the plain forward form on an unsplit grid emits -- its stored value is the
+    // accumulator itself -- everything else reports 0 blocks and the caller runs fp_bn_train_stats as before
+    const int64_t blocks = (int64_t)d->N * p.tilesY * p.tilesX;
+    const bool emit = bn_sink.part && p.SK <= 1 && !flip && (d->epi & ~(unsigned)FP_EPI_BF16X2) == 0 && d->act == 0 &&
+                      blocks * d->Nout * 3 <= bn_sink.cap_floats;
+    if (emit) a.bn_part = bn_sink.part;
+    if (bn_sink.nblk_out) *bn_sink.nblk_out = emit ? (int32_t)blocks : 0;
+  }
   const int planes = hp ? 4 : 6;                    // bytes of packed weight per element
   a.wmajor = (int64_t)9 * (d->C0 + d->C1) * d->Nout * planes > ((int64_t)4 << 20);
   a.nwg = d->N * p.tilesY * p.tilesX * p.tilesN * p.SK;

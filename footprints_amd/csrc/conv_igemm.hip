@@ -579,6 +579,7 @@ extern "C" int64_t fp_conv_igemm_workspace(const fp_conv_desc* d) {
 extern "C" int fp_conv_igemm(const fp_conv_desc* d, const float* src0, const float* src1, const float* wpacked,
                              const float* bias, const float* addend, const float* addend_mask, const float* actsrc,
                              float* y, void* workspace, int64_t workspace_bytes, fp_stream_t stream_) {
+  (void)fp_take_bn_sink();                        // a statistics sink armed for a tile convolution must not outlive a launch that cannot emit
   hipStream_t stream = (hipStream_t)stream_;
   FP_REQUIRE(d && src0 && wpacked && y, "fp_conv_igemm: null pointer");
   FP_REQUIRE(d->N > 0 && d->OH > 0 && d->OW > 0 && d->Nout > 0, "fp_conv_igemm: empty problem");
@@ -661,6 +662,7 @@ extern "C" int fp_conv_igemm_hp_supported(const fp_conv_desc* d) {
 extern "C" int fp_conv_igemm_hp(const fp_conv_desc* d, const float* src, const void* wpacked_hp, const float* bias, const float* addend,
                                 const float* addend_mask, const float* actsrc, float* y, void* workspace, int64_t workspace_bytes,
                                 const uint32_t* amax_src, const uint32_t* amax_w, fp_stream_t stream_) {
+  (void)fp_take_bn_sink();                        // a statistics sink armed for a tile convolution must not outlive a launch that cannot emit
   hipStream_t stream = (hipStream_t)stream_;
   FP_REQUIRE(d && src && wpacked_hp && y && amax_src && amax_w, "fp_conv_igemm_hp: null pointer");
   FP_REQUIRE(fp_conv_igemm_hp_supported(d), "fp_conv_igemm_hp: shape / gather not supported (see fp_conv_igemm_hp_supported)");

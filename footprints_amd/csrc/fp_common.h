@@ -215,6 +215,32 @@ __device__ __forceinline__ void fp_amax_publish(unsigned* slot, unsigned id, flo
   const unsigned bits = __float_as_uint(m);
   if (bits) __hip_atomic_fetch_max(s, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+// ---- Welford / Chan triples (BatchNorm statistics: bn_pool.hip, and the tile kernel's epilogue partials) -------------------------------
+struct FpWf {  // count, mean, sum of squared deviations
+  float n, mean, m2;
+};
+__device__ __forceinline__ void fp_wf_add(FpWf& a, float x, float n, float rn) {  // n = new count, rn = 1/n
+  a.n = n;
+  const float d = x - a.mean;
+  a.mean += d * rn;
+  a.m2 += d * (x - a.mean);
+}
+__device__ __forceinline__ void fp_wf_merge(FpWf& a, const FpWf& b) {
+  const float n = a.n + b.n;
+  if (n == 0.f) return;
+  const float d = b.mean - a.mean;
+  const float f = b.n / n;
+  a.mean += d * f;
+  a.m2 += b.m2 + d * d * a.n * f;
+  a.n = n;
+}
+// BatchNorm-statistics sink (include/footprints_hip.h, fp_bn_stats_out_next): consumed -- and cleared -- by this thread's next convolution launch
+struct FpBnSink {
+  float* part;
+  int64_t cap_floats;
+  int32_t* nblk_out;
+};
+FpBnSink fp_take_bn_sink();       // api.cpp
 unsigned* fp_take_amax_out();     // api.cpp: the slot registered by fp_amax_out_next for this thread's next publishing launch (then cleared)
 __device__ __forceinline__ float fp_wave_max(float v);
 // one candidate per workgroup: every thread of the block calls this once (wave maxima through 64 bytes of shared scratch)

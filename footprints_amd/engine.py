@@ -524,7 +524,12 @@ class Engine:
     def _bn_coeffs(self, rec, z, training):
         bn = rec.bn
         M = z.numel() // rec.C
-        if training:
+        if training and getattr(rec, "stats_nblk", 0) > 0:     # the producing convolution wrote the partials (_conv_enc)
+            nblk, rec.stats_nblk = rec.stats_nblk, 0
+            ops.bn_train_stats_partials(rec.stats_part, nblk, rec.C, bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var,
+                                        bn.num_batches_tracked, rec.mean, rec.invstd, rec.scale, rec.shift, bn.eps,
+                                        bn.momentum if bn.momentum is not None else 0.1)
+        elif training:
             ops.bn_train_stats(z.view(M, rec.C), bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var,
                                bn.num_batches_tracked, rec.mean, rec.invstd, rec.scale, rec.shift, bn.eps,
                                bn.momentum if bn.momentum is not None else 0.1)
@@ -711,10 +716,24 @@ class Engine:
             ops.event_wait(ops.current_stream(), self._pack_ev)
             self._pack_ev = None
 
-    def _conv_enc(self, c, x, N, H, W, out):
+    def _conv_enc(self, c, x, N, H, W, out, bn=None):
+        """encoder convolution; `bn` = the BatchNorm record that follows in train mode: a tile-kernel launch then also writes the
+        Welford partials of its output (ops.bn_stats_out_next) and _bn_coeffs skips the statistics pass over the activation"""
         OH, OW = (H + 2 * c.pad - c.K) // c.stride + 1, (W + 2 * c.pad - c.K) // c.stride + 1
         d = ops.make_desc(N, OH, OW, H, W, c.Cin, 0, c.Cout, c.K, c.stride, c.pad, L.GATHER_FWD_ZERO)
-        return self._cv(d, x, c.wp, c.wp3, out, hp=(c.hp_f, c.wslot))
+        cell = None
+        if bn is not None:
+            bn.stats_nblk = 0
+            tile = (c.wp3 is not None or (_HP_TILE and c.hp_f is not None and not ops._bf16x2)) and ops.conv3x3_bf3_supported(d)
+            if tile and ops._BN_EPI and not (ops._BN_FUSED or ops._BN_TICKET):
+                # one (count, mean, M2) triple per pixel tile and channel: tiles of 8 x 16 or 6 x 20 pixels, bounded by 6 x 16-pixel ones
+                cap = N * ((OH + 5) // 6) * ((OW + 15) // 16) * c.Cout * 3
+                bn.stats_part = self.buf("bn.part", (max(cap, 1),))
+                cell = ops.bn_stats_out_next(bn.stats_part)
+        y = self._cv(d, x, c.wp, c.wp3, out, hp=(c.hp_f, c.wslot))
+        if cell is not None:
+            bn.stats_nblk = int(cell.value)
+        return y
 
     @staticmethod
     def _phase_ok(h, w):
@@ -813,9 +832,9 @@ class Engine:
                 with ops.on_stream(self.aux):
                     zd, idt = shortcut()
                     ev_idt = self._record(self.aux)
-            z1 = self._conv_enc(blk.c1, x, N, h, w, buf("b%d.z1" % i, (N, oh, ow, blk.Cout)))
+            z1 = self._conv_enc(blk.c1, x, N, h, w, buf("b%d.z1" % i, (N, oh, ow, blk.Cout)), bn=blk.bn1 if training else None)
             a1 = self._bn(blk.bn1, z1, buf("b%d.a1" % i, (N, oh, ow, blk.Cout)), training)
-            z2 = self._conv_enc(blk.c2, a1, N, oh, ow, buf("b%d.z2" % i, (N, oh, ow, blk.Cout)))
+            z2 = self._conv_enc(blk.c2, a1, N, oh, ow, buf("b%d.z2" % i, (N, oh, ow, blk.Cout)), bn=blk.bn2 if training else None)
             fused2 = training and ops._BN_FUSED
             if not fused2:
                 self._bn_coeffs(blk.bn2, z2, training)          # the statistics do not need the shortcut branch: before the join

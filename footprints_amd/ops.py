@@ -570,6 +570,27 @@ def bn_train_stats(z2d, gamma, beta, running_mean, running_var, nbt, save_mean, 
                                      ws.numel(), stream()), "fp_bn_train_stats")
 
 
+# statistics out of the producing tile convolution's epilogue (csrc/conv3x3_tile_bf3.hip, fp_bn_stats_out_next): FP_BN_EPI=0 switches it off
+_BN_EPI = bool(int(os.environ.get("FP_BN_EPI", "1")))
+
+
+def bn_stats_out_next(part):
+    """arm the statistics sink for this thread's next tile-convolution launch; returns the int32 cell the launch writes its number of
+    partial blocks into (0 = nothing emitted) -- read `.value` after the convolution call"""
+    n = C.c_int32(0)
+    _lib.check(_lib.load().fp_bn_stats_out_next(_f32(part, "part"), part.numel(), C.addressof(n)), "fp_bn_stats_out_next")
+    return n
+
+
+def bn_train_stats_partials(part, nblk, Cn, gamma, beta, running_mean, running_var, nbt, save_mean, save_invstd, scale, shift, eps=1e-5,
+                            momentum=0.1):
+    if nbt is not None and nbt.dtype != torch.int64:
+        raise RuntimeError("num_batches_tracked must be int64")
+    _lib.check(_lib.load().fp_bn_train_stats_partials(_f32(part), int(nblk), int(Cn), _f32(gamma), _f32(beta), eps, momentum,
+                                                      _f32(running_mean), _f32(running_var), _chk(nbt), _f32(save_mean), _f32(save_invstd),
+                                                      _f32(scale), _f32(shift), stream()), "fp_bn_train_stats_partials")
+
+
 # fused train-mode BatchNorm (one launch per layer and direction, in-kernel grid dependency: csrc/bn_pool.hip).  OPT-IN (FP_BN_FUSED=1):
 # correct and bit-reproducible (tests/test_gpu_bn_fused.py) but measured SLOWER in the training step (16.7 vs 13.9 ms, round 3): the
 # per-XCD L2s are not coherent, so everything workgroups exchange goes through memory at 1-2 us per dependent hop, and the last

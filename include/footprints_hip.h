@@ -279,6 +279,16 @@ int fp_bn_train_stats(const float* z, int64_t M, int32_t C, const float* gamma, 
                       float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked,
                       float* save_mean, float* save_invstd, float* scale, float* shift, void* workspace,
                       int64_t workspace_bytes, fp_stream_t stream);
+/* Statistics out of the producing convolution's epilogue (round 3): fp_bn_stats_out_next arms a per-thread sink that the NEXT
+ * fp_conv3x3_hp / fp_conv3x3_bf3 launch of this thread consumes (any other convolution entry point clears it).  A plain forward launch on
+ * an unsplit grid (no bias / addend / activation) then also writes Welford partials part[pixel tile][Nout] = (count, mean, M2) of what
+ * it stores and sets *nblk_out = number of pixel tiles (written before the call returns; 0 = nothing emitted: split-K grid, epilogue
+ * options, capacity_floats < tiles * Nout * 3).  fp_bn_train_stats_partials is fp_bn_train_stats's second launch on such partials:
+ * same outputs, the activation is not read for its statistics (torchvision BatchNorm2d behind footprints/network.py:38-44). */
+int fp_bn_stats_out_next(float* part, int64_t capacity_floats, int32_t* nblk_out);
+int fp_bn_train_stats_partials(const float* part, int32_t nblk, int32_t C, const float* gamma, const float* beta, float eps,
+                               float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                               float* save_mean, float* save_invstd, float* scale, float* shift, fp_stream_t stream);
 /* eval mode: scale/shift from running statistics */
 int fp_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                       float eps, int32_t C, float* scale, float* shift, fp_stream_t stream);

@@ -173,6 +173,57 @@ def test_conv3x3_hp_dynamic_range_and_specials():
     assert not bool(torch.isfinite(y[1, 6:9, 8:11]).all()) and bool(torch.isfinite(y[0]).all())
 
 
+@pytest.mark.parametrize("N,H,W,C0,Cout,emits", [
+    (12, 48, 160, 64, 64, True),         # encoder layer 1: 8 x 16 tiles, interior
+    (12, 24, 80, 128, 128, True),        # layer 2 (small-grid WPF variant, two channel tiles)
+    (12, 12, 40, 256, 256, True),        # layer 3: 6 x 20 tiles (120 of 128 MFMA rows valid)
+    (2, 44, 72, 32, 32, True),           # ragged: partial tiles on both borders, 32-channel variant (four M waves)
+    (3, 21, 45, 64, 128, True),          # ragged, two channel tiles
+    (12, 6, 20, 512, 512, False),        # split-K grid: nothing emitted, the caller falls back
+])
+def test_conv3x3_hp_emits_batchnorm_partials(N, H, W, C0, Cout, emits):
+    """fp_bn_stats_out_next: the forward tile convolution in front of a train-mode BatchNorm writes (count, mean, M2) per pixel tile and
+    channel of what it stores; fp_bn_train_stats_partials turns them into the same coefficients as fp_bn_train_stats on the tensor"""
+    ops, L = _ops()
+    w = rnd((Cout, C0, 3, 3), 601, -0.1, 0.1)
+    x = rnd((N, C0, H, W), 602) * 2.0 + 0.75                      # a mean of the order of the spread, like post-ReLU activations
+    d = ops.make_desc(N, H, W, H, W, C0, 0, Cout, 3, 1, 1, L.GATHER_FWD_ZERO)
+    y = torch.empty((N, H, W, Cout), device="cuda")
+    wp, sw = pack_hp(w)
+    xs = nhwc(x)
+    cap = N * ((H + 5) // 6) * ((W + 15) // 16) * Cout * 3
+    part = torch.full((cap,), float("nan"), device="cuda")
+    cell = ops.bn_stats_out_next(part)
+    ops.conv3x3_hp(d, xs, wp, y, slot_of(xs), sw)
+    torch.cuda.synchronize()
+    expect_tiles = cell.value
+    assert expect_tiles in ((N * ((H + 7) // 8) * ((W + 15) // 16), N * ((H + 5) // 6) * ((W + 19) // 20)) if emits else (0,))
+    check(nchw(y), F.conv2d(x.double(), w.double(), None, 1, 1), "hp forward with statistics sink", 2e-6)
+    y2 = torch.empty_like(y)                                       # the sink is one-shot: the next launch emits nothing
+    ops.conv3x3_hp(d, xs, wp, y2, slot_of(xs), sw)
+    assert torch.equal(y, y2)
+    if expect_tiles == 0:
+        assert bool(torch.isnan(part).all())
+        return
+    used = expect_tiles * Cout * 3
+    assert not bool(torch.isnan(part[:used]).any()) and bool(torch.isnan(part[used:]).all())
+    assert float(part[:used].view(expect_tiles, Cout, 3)[:, :, 0].sum(0).min()) == float(N * H * W)      # every pixel counted once per channel
+    g, b = rnd((Cout,), 603, 0.5, 1.5).cuda(), rnd((Cout,), 604).cuda()
+    outs = [[torch.zeros(Cout, device="cuda") for _ in range(4)] for _ in range(2)]
+    rms = [torch.zeros(Cout, device="cuda") for _ in range(2)]
+    rvs = [torch.ones(Cout, device="cuda") for _ in range(2)]
+    nbt = [torch.zeros((), dtype=torch.int64, device="cuda") for _ in range(2)]
+    ops.bn_train_stats_partials(part, expect_tiles, Cout, g, b, rms[0], rvs[0], nbt[0], *outs[0])
+    ops.bn_train_stats(y.view(-1, Cout), g, b, rms[1], rvs[1], nbt[1], *outs[1])
+    yd, gc, bc = y.double().cpu().view(-1, Cout), g.double().cpu(), b.double().cpu()
+    mean, var = yd.mean(0), yd.var(0, unbiased=False)
+    invstd = 1.0 / torch.sqrt(var + 1e-5)
+    for k, ref in enumerate((mean, invstd, gc * invstd, bc - mean * gc * invstd)):
+        for o in outs:
+            assert relerr(o[k], ref) < 2e-6, (k, relerr(o[k], ref))
+    assert relerr(rms[0], rms[1].cpu()) < 1e-6 and relerr(rvs[0], rvs[1].cpu()) < 1e-6 and int(nbt[0]) == int(nbt[1]) == 1
+
+
 @pytest.mark.parametrize("N,h,w,C0,C1,Cout", [(12, 6, 20, 256, 256, 256), (8, 24, 32, 32, 16, 32), (16, 16, 32, 32, 0, 64), (12, 4, 24, 64, 64, 96)])
 def test_conv3x3_hp_up2_concat_gather(N, h, w, C0, C1, Cout):
     """cat[nearest_x2(low), skip] inside the tile kernel: the two sources share one scale (the larger amax); sources of very different size"""

@@ -29,7 +29,7 @@ print("LOSSES " + json.dumps(out))
 
 def run(env_extra):
     env = dict(os.environ)
-    for k in ("FP_HP", "FP_NO_BF3", "FP_SERIAL", "FP_NO_PHASE", "FP_DS_AUX", "FP_PLAN", "FP_NO_WBF3", "FP_WGRAD_PF"):
+    for k in ("FP_HP", "FP_NO_BF3", "FP_SERIAL", "FP_NO_PHASE", "FP_DS_AUX", "FP_PLAN", "FP_NO_WBF3", "FP_WGRAD_PF", "FP_BN_EPI"):
         env.pop(k, None)
     env.update(env_extra)
     r = subprocess.run([sys.executable, "-c", PROG], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
@@ -52,6 +52,7 @@ def baseline():
     ({"FP_HP": "0"}, False),               # exact bf16x3 split instead of scaled fp16 pairs
     ({"FP_NO_BF3": "1"}, False),           # fp32-MFMA kernels everywhere
     ({"FP_NO_PHASE": "1"}, False),         # fused nearest-x2 gather instead of the phase decomposition
+    ({"FP_BN_EPI": "0"}, False),           # BatchNorm statistics by a pass over the activation instead of the conv epilogue's partials
     ({"FP_WGRAD_PF": "0"}, True),          # third-generation weight-gradient kernel: same products and summation order, other load schedule
     ({"FP_WGRAD_PF": "3"}, True),          # prefetch ring of depth three
 ])
