@@ -177,8 +177,8 @@ def test_conv3x3_hp_dynamic_range_and_specials():
     (12, 48, 160, 64, 64, True),         # encoder layer 1: 8 x 16 tiles, interior
     (12, 24, 80, 128, 128, True),        # layer 2 (small-grid WPF variant, two channel tiles)
     (12, 12, 40, 256, 256, True),        # layer 3: 6 x 20 tiles (120 of 128 MFMA rows valid)
-    (2, 44, 72, 32, 32, True),           # ragged: partial tiles on both borders, 32-channel variant (four M waves)
-    (3, 21, 45, 64, 128, True),          # ragged, two channel tiles
+    (6, 44, 72, 32, 32, True),           # ragged: partial tiles on both borders, 32-channel variant (four M waves); 180 workgroups (under 128 the shape goes to the flattened kernel)
+    (10, 21, 45, 64, 128, True),         # ragged, two channel tiles
     (12, 6, 20, 512, 512, False),        # split-K grid: nothing emitted, the caller falls back
 ])
 def test_conv3x3_hp_emits_batchnorm_partials(N, H, W, C0, Cout, emits):
