@@ -505,21 +505,7 @@ __global__ void __launch_bounds__(256, WPF ? 1 : (HP ? FP_TILE_HP_WAVES : 1)) co
         if (HP) ymax = fmaxf(ymax, fabsf(v[k]));
       }
   };
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = n0 + (wn * TN + j) * 32 + idx;
-      if (n >= a.Nout) continue;
-      const float bias = (epi & FP_EPI_BIAS) ? a.bias[n] : 0.f;
-      if (interior) {
-        rows8(std::true_type{}, i, j, n, bias, 0);
-        rows8(std::true_type{}, i, j, n, bias, 1);
-      } else {
-        rows8(std::false_type{}, i, j, n, bias, 0);
-        rows8(std::false_type{}, i, j, n, bias, 1);
-      }
-    }
+  // (before the stores: behind them the accumulators would have to outlive the whole store loop, and its address arithmetic spilled)
   if (!FLIP && a.bn_part) {                          // (compile time for the data-gradient variants: their register budgets are unchanged)
     // BatchNorm statistics out of the epilogue (wave-uniform; the launcher sets bn_part only for unsplit grids without bias / addend /
     // activation, so the stored value is acc * unscale): a lane's TM x 16 values of output channel n -> two-pass (count, mean, M2) in
@@ -583,6 +569,21 @@ __global__ void __launch_bounds__(256, WPF ? 1 : (HP ? FP_TILE_HP_WAVES : 1)) co
     }
     __syncthreads();                                               // the amax words below share the buffer's first bytes
   }
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + (wn * TN + j) * 32 + idx;
+      if (n >= a.Nout) continue;
+      const float bias = (epi & FP_EPI_BIAS) ? a.bias[n] : 0.f;
+      if (interior) {
+        rows8(std::true_type{}, i, j, n, bias, 0);
+        rows8(std::true_type{}, i, j, n, bias, 1);
+      } else {
+        rows8(std::false_type{}, i, j, n, bias, 0);
+        rows8(std::false_type{}, i, j, n, bias, 1);
+      }
+    }
   if (HP && a.amax_out && a.SK <= 1) {               // one publication per workgroup (the halo buffers are free by now)
     ymax = fp_wave_max(ymax);
     float* wmax = reinterpret_cast<float*>(lds);

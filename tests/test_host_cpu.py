@@ -183,6 +183,35 @@ def test_no_packed_fp32_valu_in_device_code(tmp_path):
     assert mfma > 0            # the disassembly really covered the MFMA kernels
 
 
+def test_no_register_spills_in_the_matrix_kernels(tmp_path):
+    """Tripwire.  The MFMA kernels are written to their register budgets (128 / 256 VGPRs: occupancy and co-residency of the tile and
+    weight-gradient kernels on a SIMD depend on them); a spill is a scratch round trip in an epilogue at best and a `s_waitcnt vmcnt(0)`
+    that drains a prefetch ring at worst (round 3: the statistics block behind the tile kernel's stores spilled 11 - 45 registers in every
+    forward launch until it moved in front of them).  Reads the spill counts out of the code objects' metadata."""
+    import shutil
+    import subprocess
+    from footprints_amd import _lib
+    objdump, readelf = "/opt/rocm/lib/llvm/bin/llvm-objdump", "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not (os.path.exists(objdump) and os.path.exists(readelf) and os.path.exists(_lib.LIB_PATH)):
+        pytest.skip("llvm tools or the built library are not available")
+    so = shutil.copy(_lib.LIB_PATH, tmp_path / "lib.so")
+    subprocess.run([objdump, "--offloading", str(so)], cwd=tmp_path, check=True, capture_output=True)
+    watched, seen = ("conv3x3_tile_bf3_kernel", "wgrad3x3_hp_pf_kernel", "wgrad3x3_bf3_v3_kernel", "igemm_hp_kernel", "up2_phase_"), 0
+    for pth in tmp_path.iterdir():
+        if not pth.name.endswith("gfx950"):
+            continue
+        notes = subprocess.run([readelf, "--notes", str(pth)], check=True, capture_output=True, text=True).stdout
+        name = None
+        for line in notes.splitlines():
+            line = line.strip()
+            if line.startswith(".name:"):
+                name = line.split(":", 1)[1].strip()
+            elif line.startswith(".vgpr_spill_count:") and name and any(w in name for w in watched):
+                seen += 1
+                assert int(line.split(":")[1]) == 0, "%s spills %s VGPRs" % (name, line.split(":")[1].strip())
+    assert seen >= 40            # the metadata really covered the kernels
+
+
 def test_options_surface_matches_reference_flags():
     """footprints_amd/options.py mirrors footprints/options.py:13-128: every reference flag with the same default (checked against
     the reference's own parser when /root/reference is present, else against the committed table)"""
