@@ -84,13 +84,18 @@ class Communicator:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         nbytes = lib.fp_comm_unique_id_bytes()
-        ident = [None]
+        ident, err = [None], None
         if self.rank == 0:
-            raw = C.create_string_buffer(nbytes)
-            _lib.check(lib.fp_comm_unique_id(raw, nbytes), "fp_comm_unique_id")
-            ident = [raw.raw]
+            try:
+                raw = C.create_string_buffer(nbytes)
+                _lib.check(lib.fp_comm_unique_id(raw, nbytes), "fp_comm_unique_id")
+                ident = [raw.raw]
+            except Exception as e:       # the other ranks are already waiting in the broadcast: let them see the failure too
+                err = e
         if self.world > 1:
             dist.broadcast_object_list(ident, src=0, group=group)
+        if ident[0] is None:
+            raise err if err is not None else RuntimeError("rank 0 could not create an RCCL unique id")
         handle = C.c_void_p()
         _lib.check(lib.fp_comm_init(ident[0], self.rank, self.world, C.byref(handle)), "fp_comm_init")
         self.handle = handle
@@ -120,19 +125,40 @@ def get_communicator(group=None, create=True):
     key = id(group)
     if key in _COMMS or not create:
         return _COMMS.get(key)
-    comm, ok = None, 1
-    try:
-        comm = Communicator(group)
-    except Exception as e:        # librccl missing, bootstrap failure, ...: agree on the fallback below, loudly
-        ok = 0
-        print("footprints_amd.parallel: fp_comm unavailable on rank %s (%s); falling back to torch.distributed collectives"
-              % (dist.get_rank(group) if dist.is_initialized() else 0, e), flush=True)
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    multi = dist.is_initialized() and dist.get_world_size(group) > 1
+
+    def agree(ok):                # MIN over the ranks (host tensor on a gloo group, device tensor otherwise)
+        if not multi:
+            return ok
         flag = torch.tensor([ok], dtype=torch.int32)
         if "gloo" not in str(dist.get_backend(group)):
             flag = flag.cuda()
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-        ok = int(flag.item())
+        return int(flag.item())
+
+    def complain(e):
+        print("footprints_amd.parallel: fp_comm unavailable on rank %s (%s); falling back to torch.distributed collectives"
+              % (dist.get_rank(group) if dist.is_initialized() else 0, e), flush=True)
+
+    # pre-flight: ncclCommInitRank blocks until EVERY rank has called it, so a rank that cannot even load RCCL must be found out before
+    # anybody enters it
+    comm, ok = None, 1
+    try:
+        from . import _lib
+        if _lib.load().fp_comm_version() < 0:
+            raise RuntimeError("librccl could not be loaded: " + _lib.load().fp_last_error_string().decode())
+    except Exception as e:
+        ok = 0
+        complain(e)
+    if not agree(ok):
+        _COMMS[key] = None
+        return None
+    try:
+        comm = Communicator(group)
+    except Exception as e:        # bootstrap failure, ...: agree on the fallback below, loudly
+        ok = 0
+        complain(e)
+    ok = agree(ok)
     if not ok and comm is not None:
         comm.destroy()
         comm = None

@@ -75,3 +75,34 @@ def test_two_rank_gradient_mean_matches_shard_oracle():
         ref = 0.5 * (g0[n] + g1[n]).flatten()
         got = res[0][o:o + ref.numel()]
         assert torch.allclose(got, ref, rtol=1e-6, atol=1e-9), n
+
+
+def _comm_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from footprints_amd import parallel
+    comm = parallel.get_communicator(None)                 # no GPU here: loading RCCL may work, creating a communicator cannot
+    q.put((rank, comm is None, parallel.get_communicator(None, create=False) is None))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_communicator_bootstrap_failure_is_agreed_upon_and_nobody_hangs():
+    """fp_comm bootstrap on a box without GPUs, two ranks: rank 0's unique id travels (or its failure does), every rank's
+    ncclCommInitRank fails, the ranks agree on the torch.distributed fallback through the MIN all-reduce -- no rank is left waiting in a
+    collective the other never enters (the pre-flight / broadcast-the-failure logic of footprints_amd/parallel.py)"""
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("needs a box without GPUs (with GPUs the communicator is created: tests/test_gpu_dp.py)")
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_comm_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got == [(0, True, True), (1, True, True)]
