@@ -1,6 +1,12 @@
-// 3x3 stride-1 weight gradient with exactly split bf16x3 operands (gfx950).
+// 3x3 stride-1 weight gradient with split operands (gfx950): exact bf16x3 (six products) or scaled fp16 pairs (three).
 //
 //   dW[tap][ci][co] = sum over pixels p of  X[p + tap][ci] * dZ[p][co]
+//
+// Kernels in this file, oldest first (the entry points pick: fp16 pairs -> wgrad3x3_hp_pf_kernel, exact split -> wgrad3x3_bf3_v3_kernel):
+//   wgrad3x3_bf3_kernel       first generation (FP_WGRAD_BF3_V=1), described right below
+//   wgrad3x3_bf3_v3_kernel    [pixel][channel] planes in LDS + hardware transpose reads (ds_read_b64_tr_b16); exact split and fp16 pairs
+//   wgrad3x3_hp_pf_kernel     the same LDS layout / MFMA order / sums, operands two chunks ahead in a register ring of raw buffer loads
+//   wgrad_reduce_bias[_t]_kernel   the fixed-order sum over the pixel splits into OIHW (+ bias gradient); _t: through an LDS transpose
 //
 // The contraction runs over PIXELS, so both MFMA operands want "8 consecutive pixels of one channel" per lane while the
 // tensors are NHWC.  The transposition happens once, on the way into LDS, together with the exact three-way bf16 split
@@ -907,7 +913,8 @@ static int wgrad_split(const fp_conv_desc* d, const float* x, const float* dz, f
     if (nwg <= 8192) a.stamps = stamp_buf;
   }
   static const int ver = getenv("FP_WGRAD_BF3_V") ? atoi(getenv("FP_WGRAD_BF3_V")) : 3;       // A/B switch: 1 = first generation, else third
-  // FP_WGRAD_PF = depth of the register prefetch ring of the fourth generation (fp16 pairs only); 0 = third generation
+  // FP_WGRAD_PF: 0 = third generation; 1, 2 = the ring kernel with two slots (the default); 3 = three slots (308 VGPRs: no faster alone,
+  // slower in the step -- it no longer shares a SIMD with the small-grid tile kernels; profiles/round3_notes.md)
   static const int pf = getenv("FP_WGRAD_PF") ? atoi(getenv("FP_WGRAD_PF")) : FP_WGRAD_PF_DEFAULT;
   const int64_t xbytes = (int64_t)d->N * (a.mode == 2 ? (d->OH / 2) * (int64_t)(d->OW / 2) : (int64_t)d->OH * d->OW) * d->C0 * 4;
   const int64_t zbytes = (int64_t)d->N * d->OH * d->OW * d->Nout * 4;
@@ -955,7 +962,9 @@ static int wgrad_split(const fp_conv_desc* d, const float* x, const float* dz, f
   }
   const int64_t total = (int64_t)9 * d->C0 * d->Nout;
   const int bias_blocks = db ? (d->Nout + 255) / 256 : 0;
-  static const int t_min = getenv("FP_WGRAD_REDUCE_T_MIN") ? atoi(getenv("FP_WGRAD_REDUCE_T_MIN")) : 512;   // 0 = never; measured: 512 -> 512 @ 6 x 20: 111 -> 90 us, but 256 -> 256 (256 workgroups): 60 -> 63 us
+  // transposing reduce from FP_WGRAD_REDUCE_T_MIN workgroups (0 = never).  Measured: 512 -> 512 @ 6 x 20: 111 -> 90 us per weight gradient,
+  // but 256 -> 256 (256 workgroups of it, S = 4): 60 -> 63 us
+  static const int t_min = getenv("FP_WGRAD_REDUCE_T_MIN") ? atoi(getenv("FP_WGRAD_REDUCE_T_MIN")) : 512;
   const int t_blocks = (d->Nout / 32) * (d->C0 / 8);
   if (t_min > 0 && t_blocks >= t_min) {
     fp_launch(wgrad_reduce_bias_t_kernel, dim3(t_blocks + bias_blocks), dim3(256), 0, stream, (const float*)workspace, dw_oihw, p.S,
