@@ -180,6 +180,21 @@ __global__ void __launch_bounds__(256, WPF ? 1 : (HP ? FP_TILE_HP_WAVES : 1)) co
     constexpr int hs = decltype(set_tag)::value % HD;
     const int c4 = cc * 16 + (t & 3) * 4;
     hzero[hs] = c4 >= a.C;
+#ifdef FP_TILE_PIX_SELECT
+    // A/B build (scripts/build_variant.sh pixsel conv3x3_tile_bf3.hip -DFP_TILE_PIX_SELECT; NOT validated on a GPU yet, see DESIGN.md "What
+    // comes next" 0): ONE form of the load, operands selected by the wave-uniform condition -- the two-branch form below makes LLVM merge a
+    // load of pix[] with a kernarg load through a pointer phi, which keeps pix[] in a private segment (a scratch load + s_waitcnt vmcnt(0)
+    // in front of every chunk's halo loads)
+    {
+      const bool lo = cc * 16 < a.Clo;     // uniform: chunks of the upsampled half (Clo is a multiple of 16)
+      const float* const base = lo ? a.src_lo : a.src;
+      const int stride = lo ? a.Clo : a.C - a.Clo;
+      const int coff = lo ? c4 : (hzero[hs] ? 0 : c4 - a.Clo);
+#pragma unroll
+      for (int k = 0; k < NS; ++k) hreg[hs][k] = *reinterpret_cast<const float4*>(base + (size_t)(lo ? pixlo[k] : pix[k]) * stride + coff);
+      return;
+    }
+#endif
     if (cc * 16 < a.Clo) {                 // uniform: chunks of the upsampled half (Clo is a multiple of 16)
 #pragma unroll
       for (int k = 0; k < NS; ++k) hreg[hs][k] = *reinterpret_cast<const float4*>(a.src_lo + (size_t)pixlo[k] * a.Clo + c4);
