@@ -62,9 +62,6 @@ struct Tile3Args {
   const unsigned* amax_w;
   unsigned* amax_out;
   float* bn_part;     // forward conv in front of a train-mode BatchNorm (unsplit, no epilogue options): Welford partials [pixel tile][Nout][3], or null
-#ifdef FP_TILE_STAMPS
-  unsigned long long* stamps;   // diagnostics build only (scripts/build_variant.sh ... -DFP_TILE_STAMPS): 16 clocks per workgroup
-#endif
 };
 
 struct FoldTap { int wtap, ao, bo, rsel, csel; };
@@ -106,42 +103,55 @@ __device__ __forceinline__ void fp_tile_pixel(int pt, int& py, int& px) {
 #ifndef FP_TILE_WPF_HALO_SETS
 #define FP_TILE_WPF_HALO_SETS 2
 #endif
+// the reflection-fold WPF instantiations keep ONE halo set: with two they need 260 registers, i.e. one workgroup per CU instead of two
+#ifndef FP_TILE_WPF_FOLD_HALO_SETS
+#define FP_TILE_WPF_FOLD_HALO_SETS 1
+#endif
+// waves per SIMD requested for the fp16-pair reflection-fold variants on the large grids (4 = 128 VGPRs)
+#ifndef FP_TILE_HP_FOLD_WAVES
+#define FP_TILE_HP_FOLD_WAVES FP_TILE_HP_WAVES
+#endif
+#ifndef FP_TILE_PERSIST_BUILD
+#define FP_TILE_PERSIST_BUILD 0     // 0: the tile loop compiled out (one tile per workgroup, as in rounds 1-3)
+#endif
+
+// Round 4.  (1) PERSISTENT workgroups: a launch of more tiles than the chip holds at once runs `gridDim.x` < nwg workgroups, each walking
+// tiles blockIdx.x, blockIdx.x + gridDim.x, ... (gridDim.x is a multiple of 8, so a workgroup stays inside the logical-id range of its XCD).
+// Per-wave clock stamps (profiles/round2_notes.md) put a tile's wave lifetime at prologue 5.4 k + epilogue 10.7 k cycles around 4 x ~2-3 k
+// cycles of its own MFMA work: the MFMA pipe is saturated while the co-resident waves are in their taps and idle while they sit in
+// prologues (kernarg -> amax slots -> first halo: three dependent memory latencies) and in epilogues that end with a store drain.  A
+// persistent workgroup pays the prologue once; the NEXT tile's first halo and weight slices are issued before the current tile's epilogue and
+// land under it; stores are fire-and-forget; the amax publication happens once per workgroup.
+// (2) Operands arrive through raw buffer loads: a 32-bit per-lane byte offset computed once per tile + a wave-uniform (SGPR) offset per
+// chunk / tap / plane.  The flat-address form cost five VALU (v_mad_u64_u32, v_lshl_add_u64 x2, v_mov, v_add) and six SALU instructions per
+// tap in the steady loop (20 non-MFMA instructions per 6 MFMAs); an offset with bit 31 set is out of range and returns zeros without touching
+// memory, which is the zero padding and the invalid halo of ragged tiles (no per-slot select at staging time).
+// (3) Tried and removed (profiles/round4_notes.md): 16 x 16 pixel tiles with 64 x 64 per-wave register tiles (half the LDS reads and weight
+// loads per MFMA, two workgroups per CU): 64 -> 64 @ 96 x 320 124.6 us against 95.9 with 8 x 16 tiles and four workgroups per CU.
+struct TileGeo { int split, tile_n, tile_x, tile_y, n_img, y0, x0, n0; };
+constexpr bool fp_tile_persistent(int tw, bool wpf, bool hp) { return FP_TILE_PERSIST_BUILD != 0 && !wpf && hp && tw == 16; }
+
 template <int TH, int TW, int BN, int WM, int WN, bool FLIP, bool FOLD, int NP = 3, bool HP = false, bool WPF = false>
-__global__ void __launch_bounds__(256, WPF ? 1 : (HP ? FP_TILE_HP_WAVES : 1)) conv3x3_tile_bf3_kernel(const Tile3Args a) {
+__global__ void __launch_bounds__(256, WPF ? 1 : (TH * TW > 128 ? 2 : (HP ? (FOLD ? FP_TILE_HP_FOLD_WAVES : FP_TILE_HP_WAVES) : 1)))
+conv3x3_tile_bf3_kernel(const Tile3Args a) {
   static_assert(!HP || NP == 2, "the fp16-pair format has two planes");
   constexpr int WPL = HP ? 2 : 3;                    // planes per weight slice in the packed buffer
-  constexpr int BM128 = 128;
-  constexpr int TM = BM128 / WM / 32, TN = BN / WN / 32;
+  constexpr int BM = (TH * TW + 127) / 128 * 128;    // rows of the M tile: 8x16 = 128; 6x20 = 120 (rows 120..127 idle); 16x16 = 256
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int HW2 = TW + 2, HPX = (TH + 2) * HW2;
   constexpr int NS = (HPX * 4 + 255) / 256;
   constexpr int PLANE = HPX * PIXB;                   // bytes per plane
   constexpr int BUF = NP * PLANE;                    // bytes per halo buffer
-  constexpr int NPIX = TH * TW;                      // valid rows of the 128-row M tile (8x16 = 128; 6x20 = 120, rows 120..127 idle)
-  static_assert(WM * WN == 4 && NPIX <= BM128 && BM128 == 128, "tile shape");
+  constexpr int NPIX = TH * TW;                      // valid rows of the M tile
+  constexpr bool PERSIST = fp_tile_persistent(TW, WPF, HP);   // (the WPF grids are at most 400 workgroups, the 6 x 20 levels at most 768: one tile per workgroup)
+  constexpr unsigned OOB = 0x80000000u;              // buffer offset of a load that must return zeros
+  static_assert(WM * WN == 4 && NPIX <= BM && TM >= 1 && TN >= 1, "tile shape");
   __shared__ __attribute__((aligned(16))) unsigned char lds[(2 * BUF + 1023) / 1024 * 1024];   // whole LDS allocation granules
 
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, idx = lane & 31, h = lane >> 5;
-  const int wm = wave / WN, wn = wave % WN;
-  int wg = fp_xcd_remap(blockIdx.x, a.nwg);
-  int split, tile_n, tile_x, tile_y, n_img;
-  if (a.wmajor) {
-    // layers whose bf16x3 weights do not fit an XCD's 4 MB L2 (512-channel 6x20 layers: 14 MB against 3 MB of activations):
-    // pixel tiles vary fastest and (output-channel tile, split) slowest, so the contiguous id range of an XCD covers a few weight
-    // slices for ALL pixel tiles and its private L2 keeps them -- with pixel-major ids every XCD streams every weight
-    // (512->512 @6x20: 56.2 -> 49.5 us; 256->256 @12x40, 3.5 MB of weights, is better off pixel-major: 53.8 vs 57.3 us)
-    tile_x = wg % a.tilesX; wg /= a.tilesX;
-    tile_y = wg % a.tilesY; wg /= a.tilesY;
-    n_img = wg % a.N; wg /= a.N;
-    split = wg % a.SK;
-    tile_n = wg / a.SK;
-  } else {
-    split = wg % a.SK; wg /= a.SK;
-    tile_n = wg % a.tilesN; wg /= a.tilesN;
-    tile_x = wg % a.tilesX; wg /= a.tilesX;
-    tile_y = wg % a.tilesY;
-    n_img = wg / a.tilesY;
-  }
-  const int y0 = tile_y * TH, x0 = tile_x * TW, n0 = tile_n * BN;
+  // lane geometry: re-derived from an OPAQUE copy of the thread id at the top of every tile, so that nothing computed from it is invariant
+  // of the tile loop -- left alone, loop-invariant code motion hoisted every tap's LDS address, every epilogue constant and the halo slot
+  // table out of the loop and kept them live across it (128-VGPR instantiations spilled 40-120 registers)
+  int t, lane, wave, idx, h, wm, wn;
 
   int ka = 0, kunscale = 0;                          // HP: source scale exponent, and -(ka + kw) for the epilogue (wave-uniform)
   if (HP) {
@@ -150,68 +160,138 @@ __global__ void __launch_bounds__(256, WPF ? 1 : (HP ? FP_TILE_HP_WAVES : 1)) co
     ka = fp_hp_exponent(ab, FP_HP_TARGET_ACT);
     kunscale = -(ka + fp_hp_exponent(fp_amax_bits(a.amax_w), FP_HP_TARGET_W));
   }
-  // ---- halo staging slots (unconditional loads; invalid slots read the nearest in-image pixel and are stored as zero) ----------
-  int pix[NS], pixlo[NS], lds_off[NS];
-  bool hvalid[NS];
+  // buffer resources (sizes checked on the host: every operand is smaller than 2^31 bytes, so bit 31 of an offset means "out of range")
+  const int cs = a.C - a.Clo;                        // channels of `src` (the skip tensor of the concat gather, else the whole input)
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src), 0, a.N * a.IH * a.IW * cs * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.src_lo ? a.src_lo : a.src), 0, a.src_lo ? a.N * (a.IH >> 1) * (a.IW >> 1) * a.Clo * 4 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.w), 0, 9 * a.KC16 * WPL * a.Nout * 32, 0x00020000);
+  const int wtap = a.KC16 * WPL * a.Nout * 32, wchunk = WPL * a.Nout * 32, wplane = a.Nout * 32;     // byte strides of the packed weights
+
+  // ---- tile-independent lane geometry ----------------------------------------------------------------------------------------
+  int lds_off[NS];
+  int abase[TM];
+  auto lane_setup = [&]() {
+    int tq = threadIdx.x;
+    if (PERSIST) asm volatile("" : "+v"(tq));
+    t = tq; lane = t & 63; wave = t >> 6; idx = lane & 31; h = lane >> 5;
+    wm = wave / WN; wn = wave % WN;
 #pragma unroll
-  for (int k = 0; k < NS; ++k) {
-    const int lin = t + 256 * k, hp = min(lin >> 2, HPX - 1);
-    lds_off[k] = (lin >> 2) < HPX ? hp * PIXB + (lin & 3) * 8 : -1;
-    const int hy = hp / HW2, hx = hp - hy * HW2;
-    int sy = y0 + hy - 1, sx = x0 + hx - 1;
-    if (a.mode == 0) {
-      hvalid[k] = sy >= 0 && sy < a.IH && sx >= 0 && sx < a.IW;
-    } else {
-      hvalid[k] = sy >= -1 && sy <= a.IH && sx >= -1 && sx <= a.IW;
-      sy = fp_reflect(sy, a.IH);
-      sx = fp_reflect(sx, a.IW);
+    for (int k = 0; k < NS; ++k) {
+      const int lin = t + 256 * k;
+      lds_off[k] = (lin >> 2) < HPX ? (lin >> 2) * PIXB + (lin & 3) * 8 : -1;
     }
-    sy = min(max(sy, 0), a.IH - 1);
-    sx = min(max(sx, 0), a.IW - 1);
-    pix[k] = (n_img * a.IH + sy) * a.IW + sx;
-    pixlo[k] = (n_img * (a.IH >> 1) + (sy >> 1)) * (a.IW >> 1) + (sx >> 1);     // nearest x2: src = dst // 2 (after the reflection)
-  }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int pt = min((wm * TM + i) * 32 + idx, NPIX - 1);
+      int py, px;
+      fp_tile_pixel<TW>(pt, py, px);
+      abase[i] = (py * HW2 + px) * PIXB + h * 16;
+    }
+  };
+  lane_setup();
+
+  // ---- per-tile state ------------------------------------------------------------------------------------------------------
+  TileGeo g;
+  unsigned voff[NS], vofflo[NS];                     // byte offsets of the halo slots into `src` / `src_lo` (OOB: stored as zero)
+  unsigned wvoff[TN];                                // byte offset of this lane's weight row inside a [n][16] plane
+  bool has_r1 = false, has_rH = false, has_c1 = false, has_cW = false;
+  unsigned m_r1[TM], m_rH[TM], m_c1[TM], m_cW[TM];   // all-ones / zero lane masks (reflection fold)
+  int c_begin = 0, c_end = 0;
+  auto decode = [&](int vb) {
+    int wg = fp_xcd_remap(vb, a.nwg);
+    TileGeo q;
+    if (a.wmajor) {
+      // layers whose bf16x3 weights do not fit an XCD's 4 MB L2 (512-channel 6x20 layers: 14 MB against 3 MB of activations):
+      // pixel tiles vary fastest and (output-channel tile, split) slowest, so the contiguous id range of an XCD covers a few weight
+      // slices for ALL pixel tiles and its private L2 keeps them -- with pixel-major ids every XCD streams every weight
+      // (512->512 @6x20: 56.2 -> 49.5 us; 256->256 @12x40, 3.5 MB of weights, is better off pixel-major: 53.8 vs 57.3 us)
+      q.tile_x = wg % a.tilesX; wg /= a.tilesX;
+      q.tile_y = wg % a.tilesY; wg /= a.tilesY;
+      q.n_img = wg % a.N; wg /= a.N;
+      q.split = wg % a.SK;
+      q.tile_n = wg / a.SK;
+    } else {
+      q.split = wg % a.SK; wg /= a.SK;
+      q.tile_n = wg % a.tilesN; wg /= a.tilesN;
+      q.tile_x = wg % a.tilesX; wg /= a.tilesX;
+      q.tile_y = wg % a.tilesY;
+      q.n_img = wg / a.tilesY;
+    }
+    q.y0 = q.tile_y * TH; q.x0 = q.tile_x * TW; q.n0 = q.tile_n * BN;
+    return q;
+  };
+  // halo staging slots (unconditional loads; invalid slots carry the out-of-range offset and arrive as zeros), weight rows, fold masks
+  auto setup = [&]() {
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      const int lin = t + 256 * k, hp = min(lin >> 2, HPX - 1);
+      const int hy = hp / HW2, hx = hp - hy * HW2;
+      int sy = g.y0 + hy - 1, sx = g.x0 + hx - 1;
+      bool valid;
+      if (a.mode == 0) {
+        valid = sy >= 0 && sy < a.IH && sx >= 0 && sx < a.IW;
+      } else {
+        valid = sy >= -1 && sy <= a.IH && sx >= -1 && sx <= a.IW;
+        sy = fp_reflect(sy, a.IH);
+        sx = fp_reflect(sx, a.IW);
+      }
+      sy = min(max(sy, 0), a.IH - 1);
+      sx = min(max(sx, 0), a.IW - 1);
+      const unsigned pix = (g.n_img * a.IH + sy) * a.IW + sx;
+      const unsigned pixlo = (g.n_img * (a.IH >> 1) + (sy >> 1)) * (a.IW >> 1) + (sx >> 1);     // nearest x2: src = dst // 2 (after the reflection)
+      voff[k] = valid ? pix * (unsigned)(cs * 4) + (t & 3) * 16 : OOB;
+      vofflo[k] = valid ? pixlo * (unsigned)(a.Clo * 4) + (t & 3) * 16 : OOB;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) wvoff[j] = (unsigned)(min(g.n0 + (wn * TN + j) * 32 + idx, a.Nout - 1) * 32 + h * 16);
+    if (FOLD) {
+      has_r1 = g.y0 <= 1 && 1 < g.y0 + TH; has_rH = g.y0 <= a.OH - 2 && a.OH - 2 < g.y0 + TH;
+      has_c1 = g.x0 <= 1 && 1 < g.x0 + TW; has_cW = g.x0 <= a.OW - 2 && a.OW - 2 < g.x0 + TW;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int pt = min((wm * TM + i) * 32 + idx, NPIX - 1);
+        int py, px;
+        fp_tile_pixel<TW>(pt, py, px);
+        const int yy = g.y0 + py, xx = g.x0 + px;
+        m_r1[i] = yy == 1 ? ~0u : 0u;
+        m_rH[i] = yy == a.OH - 2 ? ~0u : 0u;
+        m_c1[i] = xx == 1 ? ~0u : 0u;
+        m_cW[i] = xx == a.OW - 2 ? ~0u : 0u;
+      }
+    }
+    c_begin = g.split * a.chunksPerSplit;
+    c_end = min(a.KC16, c_begin + a.chunksPerSplit);
+  };
+
   // HD register sets: the small grids of the WPF variant (less than one wave per SIMD, nothing else to hide a load behind) keep the
   // halos of the next TWO chunks in flight -- chunk j's halo lives in set (j - c_begin) & 1
-  constexpr int HD = WPF ? FP_TILE_WPF_HALO_SETS : 1;
+  constexpr int HD = WPF ? (FOLD ? FP_TILE_WPF_FOLD_HALO_SETS : FP_TILE_WPF_HALO_SETS) : 1;
   float4 hreg[HD][NS];
   bool hzero[HD] = {};
   auto load_halo = [&](int cc, auto set_tag) {
     constexpr int hs = decltype(set_tag)::value % HD;
-    const int c4 = cc * 16 + (t & 3) * 4;
-    hzero[hs] = c4 >= a.C;
-#ifdef FP_TILE_PIX_SELECT
-    // A/B build (scripts/build_variant.sh pixsel conv3x3_tile_bf3.hip -DFP_TILE_PIX_SELECT; NOT validated on a GPU yet, see DESIGN.md "What
-    // comes next" 0): ONE form of the load, operands selected by the wave-uniform condition -- the two-branch form below makes LLVM merge a
-    // load of pix[] with a kernarg load through a pointer phi, which keeps pix[] in a private segment (a scratch load + s_waitcnt vmcnt(0)
-    // in front of every chunk's halo loads)
-    {
-      const bool lo = cc * 16 < a.Clo;     // uniform: chunks of the upsampled half (Clo is a multiple of 16)
-      const float* const base = lo ? a.src_lo : a.src;
-      const int stride = lo ? a.Clo : a.C - a.Clo;
-      const int coff = lo ? c4 : (hzero[hs] ? 0 : c4 - a.Clo);
-#pragma unroll
-      for (int k = 0; k < NS; ++k) hreg[hs][k] = *reinterpret_cast<const float4*>(base + (size_t)(lo ? pixlo[k] : pix[k]) * stride + coff);
-      return;
-    }
-#endif
+    hzero[hs] = cc * 16 + (t & 3) * 4 >= a.C;        // only ever true in the last chunk of a channel count that is not a multiple of 16
     if (cc * 16 < a.Clo) {                 // uniform: chunks of the upsampled half (Clo is a multiple of 16)
+      const int so = cc * 64;
 #pragma unroll
-      for (int k = 0; k < NS; ++k) hreg[hs][k] = *reinterpret_cast<const float4*>(a.src_lo + (size_t)pixlo[k] * a.Clo + c4);
+      for (int k = 0; k < NS; ++k) hreg[hs][k] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rl, vofflo[k], so, 0));
     } else {
-      const int cs = a.C - a.Clo, coff = hzero[hs] ? 0 : c4 - a.Clo;
+      const int so = (cc * 16 - a.Clo) * 4;
 #pragma unroll
-      for (int k = 0; k < NS; ++k) hreg[hs][k] = *reinterpret_cast<const float4*>(a.src + (size_t)pix[k] * cs + coff);
+      for (int k = 0; k < NS; ++k) hreg[hs][k] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff[k], so, 0));
     }
   };
   // fp32 -> three bf16 planes, 4 channels (8 bytes) per plane per slot
   auto store_halo = [&](int buf, auto set_tag) {
     constexpr int hs = decltype(set_tag)::value % HD;
+    const bool zero_tail = (a.C & 15) != 0 && hzero[hs];
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
       if (lds_off[k] < 0) continue;
       f32x4 v = {hreg[hs][k].x, hreg[hs][k].y, hreg[hs][k].z, hreg[hs][k].w};
-      if (!hvalid[k] || hzero[hs]) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (zero_tail) v = f32x4{0.f, 0.f, 0.f, 0.f};
       unsigned char* p = lds + buf * BUF + lds_off[k];
       if (HP) {
         v = f32x4{ldexpf(v.x, ka), ldexpf(v.y, ka), ldexpf(v.z, ka), ldexpf(v.w, ka)};
@@ -236,54 +316,15 @@ __global__ void __launch_bounds__(256, WPF ? 1 : (HP ? FP_TILE_HP_WAVES : 1)) co
   // ---- weight slices: [tap][chunk][plane][n][16] bf16; lane (n = idx, k-group = h) reads 16 bytes per plane -----------------
   uint4 bq[WPF ? 1 : 3][TN][NP];
   uint4 bw[WPF ? 2 : 1][WPF ? 9 : 1][TN][NP];          // WPF: [chunk parity][tap]
-  auto load_b = [&](int tap, int cc, uint4 (&bf)[TN][NP], bool prologue = false) {
-#if defined(FP_TILE_ABL) && FP_TILE_ABL == 3        // ablation: weight fragments loaded once
-    if (!prologue) return;
-#endif
-#if defined(FP_TILE_ABL) && FP_TILE_ABL == 1        // ablation: every weight fragment from one L1-resident slice
-    const unsigned short* ws = a.w + (size_t)((tap & 1) * a.KC16) * WPL * a.Nout * 16 + h * 8;
-#else
-    const unsigned short* ws = a.w + (size_t)(tap * a.KC16 + cc) * WPL * a.Nout * 16 + h * 8;
-#endif
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = min(n0 + (wn * TN + j) * 32 + idx, a.Nout - 1);
-#pragma unroll
-      for (int p = 0; p < NP; ++p) bf[j][p] = *reinterpret_cast<const uint4*>(ws + ((size_t)p * a.Nout + n) * 16);
-    }
-  };
-
-  int abase[TM];
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int pt = min((wm * TM + i) * 32 + idx, NPIX - 1);
-    int py, px;
-    fp_tile_pixel<TW>(pt, py, px);
-    abase[i] = (py * HW2 + px) * PIXB + h * 16;
-  }
-
-  const bool has_r1 = y0 <= 1 && 1 < y0 + TH, has_rH = y0 <= a.OH - 2 && a.OH - 2 < y0 + TH;
-  const bool has_c1 = x0 <= 1 && 1 < x0 + TW, has_cW = x0 <= a.OW - 2 && a.OW - 2 < x0 + TW;
-  unsigned m_r1[TM], m_rH[TM], m_c1[TM], m_cW[TM];       // all-ones / zero lane masks
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int pt = min((wm * TM + i) * 32 + idx, NPIX - 1);
-    int py, px;
-    fp_tile_pixel<TW>(pt, py, px);
-    const int yy = y0 + py, xx = x0 + px;
-    m_r1[i] = yy == 1 ? ~0u : 0u;
-    m_rH[i] = yy == a.OH - 2 ? ~0u : 0u;
-    m_c1[i] = xx == 1 ? ~0u : 0u;
-    m_cW[i] = xx == a.OW - 2 ? ~0u : 0u;
-  }
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
+  auto load_b = [&](int tap, int cc, uint4 (&bf)[TN][NP]) {
+    const int so = tap * wtap + cc * wchunk;
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int p = 0; p < NP; ++p) bf[j][p] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rw, wvoff[j], so + p * wplane, 0));
+  };
+
+  f32x16 acc[TM][TN];
 
   // six products, smallest first; consecutive MFMAs alternate accumulators (i, j)
   constexpr int NPROD = NP == 3 ? 6 : (HP ? FP_HP_PRODUCTS : (FP_BF2_PRODUCTS));
@@ -291,17 +332,6 @@ __global__ void __launch_bounds__(256, WPF ? 1 : (HP ? FP_TILE_HP_WAVES : 1)) co
     // NP == 2: four products in the order mm, mh, hm, hh; three: mh, hm, hh
     constexpr int PA[6] = {NP == 3 ? 2 : 1, NP == 3 ? 0 : (NPROD == 4 ? 1 : 0), NP == 3 ? 1 : 0, NP == 3 ? 1 : 0, 0, 0};
     constexpr int PB[6] = {NP == 3 ? 0 : (NPROD == 4 ? 1 : 0), NP == 3 ? 2 : (NPROD == 4 ? 0 : 1), NP == 3 ? 1 : (NPROD == 4 ? 1 : 0), 0, 1, 0};
-#if defined(FP_TILE_ABL) && FP_TILE_ABL == 2        // ablation: operands consumed, no MFMA
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int p = 0; p < NP; ++p) asm volatile("" ::"v"(af[i][p].x), "v"(af[i][p].y), "v"(af[i][p].z), "v"(af[i][p].w));
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int p = 0; p < NP; ++p) asm volatile("" ::"v"(bf[j][p].x), "v"(bf[j][p].y), "v"(bf[j][p].z), "v"(bf[j][p].w));
-    return;
-#endif
 #pragma unroll
     for (int q = 0; q < NPROD; ++q)
 #pragma unroll
@@ -316,33 +346,18 @@ __global__ void __launch_bounds__(256, WPF ? 1 : (HP ? FP_TILE_HP_WAVES : 1)) co
                                                                 acc[i][j], 0, 0, 0);
   };
 
-  const int c_begin = split * a.chunksPerSplit, c_end = min(a.KC16, c_begin + a.chunksPerSplit);
-#ifdef FP_TILE_STAMPS
-  unsigned long long st[16];
+  // the first halo chunk and the first weight slices of the current tile (g): issued before the previous tile's epilogue
+  auto prefetch_tile = [&]() {
+    load_halo(c_begin, std::integral_constant<int, 0>{});
+    if constexpr (WPF) {
 #pragma unroll
-  for (int k = 0; k < 16; ++k) st[k] = 0;
-  st[0] = __builtin_readcyclecounter();
-  st[12] = __builtin_amdgcn_s_memrealtime();       // 100 MHz constant clock: calibrates the shader clock under this kernel's load
-#endif
-  load_halo(c_begin, std::integral_constant<int, 0>{});
-  if constexpr (WPF) {
-#pragma unroll
-    for (int tp = 0; tp < 9; ++tp) load_b(tp, c_begin, bw[0][tp], true);
-  } else {
-    load_b(0, c_begin, bq[0], true);           // issued before the halo is consumed: one exposed load latency in the prologue, not two
-    load_b(1, c_begin, bq[1], true);
-#if defined(FP_TILE_ABL) && FP_TILE_ABL == 3
-    load_b(2, c_begin, bq[2], true);
-#endif
-  }
-  store_halo(0, std::integral_constant<int, 0>{});
-  load_halo(min(c_begin + 1, c_end - 1), std::integral_constant<int, 1>{});
-  if (HD == 2) load_halo(min(c_begin + 2, c_end - 1), std::integral_constant<int, 0>{});
-  __syncthreads();
+      for (int tp = 0; tp < 9; ++tp) load_b(tp, c_begin, bw[0][tp]);
+    } else {
+      load_b(0, c_begin, bq[0]);           // issued before the halo is consumed: one exposed load latency in the prologue, not two
+      load_b(1, c_begin, bq[1]);
+    }
+  };
 
-#ifdef FP_TILE_STAMPS
-  st[1] = __builtin_readcyclecounter();
-#endif
   auto chunk = [&](auto par_tag, int cc) {
     constexpr int PAR = decltype(par_tag)::value;          // (cc - c_begin) & 1, as a constant: register-set index of the WPF weights
     const unsigned char* Hb = lds + ((cc - c_begin) & 1) * BUF;
@@ -407,198 +422,230 @@ __global__ void __launch_bounds__(256, WPF ? 1 : (HP ? FP_TILE_HP_WAVES : 1)) co
         }
       }
     }
-#ifdef FP_TILE_STAMPS
-    { const unsigned long long now = __builtin_readcyclecounter();       // after the taps of chunk k (k < 6), before the next halo store
-#pragma unroll
-      for (int k = 0; k < 6; ++k) if (cc - c_begin == k) st[2 + k] = now; }
-#endif
     if (cc + 1 < c_end) {
       store_halo((cc + 1 - c_begin) & 1, std::integral_constant<int, PAR ^ 1>{});
       load_halo(min(cc + 1 + HD, c_end - 1), std::integral_constant<int, PAR ^ 1>{});
       __syncthreads();
     }
-#ifdef FP_TILE_STAMPS
-    { const unsigned long long now = __builtin_readcyclecounter();       // after the barrier that publishes chunk k + 1
-#pragma unroll
-      for (int k = 0; k < 6; ++k) if (cc - c_begin == k) st[8 + k] = now; }
-#endif
   };
-  for (int cc = c_begin; cc < c_end; cc += 2) {
-    chunk(std::integral_constant<int, 0>{}, cc);
-    if (cc + 1 < c_end) chunk(std::integral_constant<int, 1>{}, cc + 1);
-  }
 
-  // ---- epilogue.  The flag tests are hoisted and every optional operand (addend, its mask, the activation source, the old
+  float ymax = 0.f;                                  // HP: largest stored magnitude of this lane over all its tiles (the consumer's scale)
+  const float unscale = HP ? ldexpf(1.f, kunscale) : 1.f;      // wave-uniform power of two: one fused multiply-add per element un-scales and adds the bias
+
+  // ---- epilogue of one tile.  The flag tests are hoisted and every optional operand (addend, its mask, the activation source, the old
   // output) is loaded for eight rows BEFORE any arithmetic: element-at-a-time code serialised 16 dependent load latencies per
   // 32x32 block (and reloaded the bias 16 times).  Tiles that lie completely inside the image (all but the last row / column of
   // tiles) take a path without per-element bounds predication; for 16-wide tiles the row -> pixel map folds to constants.
-  const unsigned epi = a.SK > 1 ? 0u : a.epi;
-  const int act = a.SK > 1 ? 0 : a.act;
-  float* const dst = a.SK > 1 ? a.part + (size_t)split * a.N * a.OH * a.OW * a.Nout : a.y;
-  const bool interior = NPIX == 128 && y0 + TH <= a.OH && x0 + TW <= a.OW;
-  float ymax = 0.f;                                  // HP: largest stored magnitude of this lane (the consumer's scale)
-  const float unscale = HP ? ldexpf(1.f, kunscale) : 1.f;      // wave-uniform power of two: one fused multiply-add per element un-scales and adds the bias
-  // accumulator register r of M block i -> tile pixel
-  auto acc_pixel = [&](int i, int r, int& py, int& px) {
-    if (TW == 16) {              // pt = blk*32 + (r&3) + 8*(r>>2) + 4h  =>  row = 2*blk + (r>>3), column from constants and h
-      py = 2 * (wm * TM + i) + (r >> 3);
-      px = ((r & 3) + 8 * ((r >> 2) & 1) + 4 * h - 2 * ((r >> 3) & 1)) & 15;
-    } else {
-      fp_tile_pixel<TW>((wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, py, px);
+  auto epilogue = [&](const TileGeo& e) {
+    const unsigned epi = a.SK > 1 ? 0u : a.epi;
+    const int act = a.SK > 1 ? 0 : a.act;
+    float* const dst = a.SK > 1 ? a.part + (size_t)e.split * a.N * a.OH * a.OW * a.Nout : a.y;
+    const bool interior = NPIX == BM && e.y0 + TH <= a.OH && e.x0 + TW <= a.OW;
+    float bias_j[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = e.n0 + (wn * TN + j) * 32 + idx;
+      bias_j[j] = ((epi & FP_EPI_BIAS) && n < a.Nout) ? a.bias[n] : 0.f;
     }
-  };
-  auto rows8 = [&](auto full_tag, int i, int j, int n, float bias, int half) {
-    constexpr bool FULL = decltype(full_tag)::value;
-    int off[8];
-    bool ok[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int r = half * 8 + k;
-      int py, px;
-      acc_pixel(i, r, py, px);
-      const int oy = y0 + py, ox = x0 + px;
-      ok[k] = FULL || ((wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h < NPIX && oy < a.OH && ox < a.OW);
-      off[k] = ((n_img * a.OH + (FULL ? oy : min(oy, a.OH - 1))) * a.OW + (FULL ? ox : min(ox, a.OW - 1))) * a.Nout + n;
-    }
-    float ad[8], mk[8], sv[8], yo[8];
-    if (epi & FP_EPI_ADDEND) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) ad[k] = a.addend[off[k]];
-    }
-    if (epi & FP_EPI_ADDEND_MASK) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) mk[k] = a.addend_mask[off[k]];
-    }
-    if (epi & (FP_EPI_ACTGRAD_ELU | FP_EPI_ACTGRAD_RELU)) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) sv[k] = a.actsrc[off[k]];
-    }
-    if (epi & FP_EPI_ACCUM) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) yo[k] = a.y[off[k]];
-    }
-    // one wave-uniform branch per flag around an 8-element body (per-element tests get if-converted into selects that execute
-    // every option for every element)
-    float v[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = HP ? fmaf(acc[i][j][half * 8 + k], unscale, bias) : acc[i][j][half * 8 + k] + bias;   // * 2^kunscale is exact
-    if (epi & FP_EPI_ADDEND) {
-      if (epi & FP_EPI_ADDEND_MASK) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] += mk[k] > 0.f ? ad[k] : 0.f;
+    // accumulator register r of M block i -> tile pixel
+    auto acc_pixel = [&](int i, int r, int& py, int& px) {
+      if (TW == 16) {              // pt = blk*32 + (r&3) + 8*(r>>2) + 4h  =>  row = 2*blk + (r>>3), column from constants and h
+        py = 2 * (wm * TM + i) + (r >> 3);
+        px = ((r & 3) + 8 * ((r >> 2) & 1) + 4 * h - 2 * ((r >> 3) & 1)) & 15;
       } else {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] += ad[k];
+        fp_tile_pixel<TW>((wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, py, px);
       }
-    }
-    if (epi & FP_EPI_ACTGRAD_ELU) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] *= (sv[k] > 0.f ? 1.f : sv[k] + 1.f);
-    }
-    if (epi & FP_EPI_ACTGRAD_RELU) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] = sv[k] > 0.f ? v[k] : 0.f;
-    }
-    if (act == FP_ACT_ELU) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] = fp_elu(v[k]);
-    } else if (act == FP_ACT_RELU) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
-    }
-    if (epi & FP_EPI_ACCUM) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] += yo[k];
-    }
-#if defined(FP_TILE_ABL) && FP_TILE_ABL == 4        // ablation: epilogue arithmetic without the stores (a.mode is never negative)
-    if (a.mode >= 0) return;
-#endif
-#pragma unroll
-    for (int k = 0; k < 8; ++k)
-      if (FULL || ok[k]) {
-        dst[off[k]] = v[k];
-        if (HP) ymax = fmaxf(ymax, fabsf(v[k]));
-      }
-  };
-  // (before the stores: behind them the accumulators would have to outlive the whole store loop, and its address arithmetic spilled)
-  if (!FLIP && a.bn_part) {                          // (compile time for the data-gradient variants: their register budgets are unchanged)
-    // BatchNorm statistics out of the epilogue (wave-uniform; the launcher sets bn_part only for unsplit grids without bias / addend /
-    // activation, so the stored value is acc * unscale): a lane's TM x 16 values of output channel n -> two-pass (count, mean, M2) in
-    // registers -> Chan merge with the other half-wave's pixels -> across the WM waves that share the channel through LDS, fixed order
-    // -> part[pixel tile][n].  bn_stats_final_kernel (bn_pool.hip) merges the tiles; the activation is never read for its statistics.
-    float* const st = reinterpret_cast<float*>(lds) + 16;          // [wave][TN * 32][3] floats behind the amax words
-    __syncthreads();                                               // every wave is done with the halo buffers
-    auto lane_stats = [&](auto full_tag, int j) {    // two passes over the lane's registers; validity recomputed, not kept
+    };
+    auto rows8 = [&](auto full_tag, int i, int j, int n, float bias, int half) {
       constexpr bool FULL = decltype(full_tag)::value;
-      auto ok_at = [&](int i, int r) {
-        if (FULL) return NPIX == 128 || (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h < NPIX;     // tile inside the image
+      int off[8];
+      bool ok[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int r = half * 8 + k;
         int py, px;
         acc_pixel(i, r, py, px);
-        return (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h < NPIX && y0 + py < a.OH && x0 + px < a.OW;
-      };
-      float cnt = 0.f, sum = 0.f;
+        const int oy = e.y0 + py, ox = e.x0 + px;
+        ok[k] = FULL || ((wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h < NPIX && oy < a.OH && ox < a.OW);
+        off[k] = ((e.n_img * a.OH + (FULL ? oy : min(oy, a.OH - 1))) * a.OW + (FULL ? ox : min(ox, a.OW - 1))) * a.Nout + n;
+      }
+      float ad[8], mk[8], sv[8], yo[8];
+      if (epi & FP_EPI_ADDEND) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+        for (int k = 0; k < 8; ++k) ad[k] = a.addend[off[k]];
+      }
+      if (epi & FP_EPI_ADDEND_MASK) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const bool ok = ok_at(i, r);
-          cnt += ok ? 1.f : 0.f;
-          sum += ok ? acc[i][j][r] * unscale : 0.f;
+        for (int k = 0; k < 8; ++k) mk[k] = a.addend_mask[off[k]];
+      }
+      if (epi & (FP_EPI_ACTGRAD_ELU | FP_EPI_ACTGRAD_RELU)) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sv[k] = a.actsrc[off[k]];
+      }
+      if (epi & FP_EPI_ACCUM) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) yo[k] = a.y[off[k]];
+      }
+      // one wave-uniform branch per flag around an 8-element body (per-element tests get if-converted into selects that execute
+      // every option for every element)
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = HP ? fmaf(acc[i][j][half * 8 + k], unscale, bias) : acc[i][j][half * 8 + k] + bias;   // * 2^kunscale is exact
+      if (epi & FP_EPI_ADDEND) {
+        if (epi & FP_EPI_ADDEND_MASK) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] += mk[k] > 0.f ? ad[k] : 0.f;
+        } else {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] += ad[k];
         }
-      FpWf w{cnt, cnt > 0.f ? sum / cnt : 0.f, 0.f};
+      }
+      if (epi & FP_EPI_ACTGRAD_ELU) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+        for (int k = 0; k < 8; ++k) v[k] *= (sv[k] > 0.f ? 1.f : sv[k] + 1.f);
+      }
+      if (epi & FP_EPI_ACTGRAD_RELU) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float dv = acc[i][j][r] * unscale - w.mean;
-          w.m2 += ok_at(i, r) ? dv * dv : 0.f;
+        for (int k = 0; k < 8; ++k) v[k] = sv[k] > 0.f ? v[k] : 0.f;
+      }
+      if (act == FP_ACT_ELU) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = fp_elu(v[k]);
+      } else if (act == FP_ACT_RELU) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+      }
+      if (epi & FP_EPI_ACCUM) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] += yo[k];
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (FULL || ok[k]) {
+          dst[off[k]] = v[k];
+          if (HP) ymax = fmaxf(ymax, fabsf(v[k]));
         }
-      return w;
     };
+    // (before the stores: behind them the accumulators would have to outlive the whole store loop, and its address arithmetic spilled)
+    if (!FLIP && a.bn_part) {                          // (compile time for the data-gradient variants: their register budgets are unchanged)
+      // BatchNorm statistics out of the epilogue (wave-uniform; the launcher sets bn_part only for unsplit grids without bias / addend /
+      // activation, so the stored value is acc * unscale): a lane's TM x 16 values of output channel n -> two-pass (count, mean, M2) in
+      // registers -> Chan merge with the other half-wave's pixels -> across the WM waves that share the channel through LDS, fixed order
+      // -> part[pixel tile][n].  bn_stats_final_kernel (bn_pool.hip) merges the tiles; the activation is never read for its statistics.
+      float* const st = reinterpret_cast<float*>(lds) + 16;          // [wave][TN * 32][3] floats
+      __syncthreads();                                               // every wave is done with the halo buffers
+      auto lane_stats = [&](auto full_tag, int j) {    // two passes over the lane's registers; validity recomputed, not kept
+        constexpr bool FULL = decltype(full_tag)::value;
+        auto ok_at = [&](int i, int r) {
+          if (FULL) return NPIX == BM || (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h < NPIX;     // tile inside the image
+          int py, px;
+          acc_pixel(i, r, py, px);
+          return (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h < NPIX && e.y0 + py < a.OH && e.x0 + px < a.OW;
+        };
+        float cnt = 0.f, sum = 0.f;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const FpWf w = (y0 + TH <= a.OH && x0 + TW <= a.OW) ? lane_stats(std::true_type{}, j) : lane_stats(std::false_type{}, j);
-      const FpWf o{__shfl_xor(w.n, 32, 64), __shfl_xor(w.mean, 32, 64), __shfl_xor(w.m2, 32, 64)};
-      FpWf lo = h == 0 ? w : o;                                      // both half-waves form merge(h = 0, h = 1)
-      fp_wf_merge(lo, h == 0 ? o : w);
-      if (h == 0) {
-        float* q = st + ((wave * TN + j) * 32 + idx) * 3;
-        q[0] = lo.n; q[1] = lo.mean; q[2] = lo.m2;
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const bool ok = ok_at(i, r);
+            cnt += ok ? 1.f : 0.f;
+            sum += ok ? acc[i][j][r] * unscale : 0.f;
+          }
+        FpWf w{cnt, cnt > 0.f ? sum / cnt : 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float dv = acc[i][j][r] * unscale - w.mean;
+            w.m2 += ok_at(i, r) ? dv * dv : 0.f;
+          }
+        return w;
+      };
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const FpWf w = (e.y0 + TH <= a.OH && e.x0 + TW <= a.OW) ? lane_stats(std::true_type{}, j) : lane_stats(std::false_type{}, j);
+        const FpWf o{__shfl_xor(w.n, 32, 64), __shfl_xor(w.mean, 32, 64), __shfl_xor(w.m2, 32, 64)};
+        FpWf lo = h == 0 ? w : o;                                      // both half-waves form merge(h = 0, h = 1)
+        fp_wf_merge(lo, h == 0 ? o : w);
+        if (h == 0) {
+          float* q = st + ((wave * TN + j) * 32 + idx) * 3;
+          q[0] = lo.n; q[1] = lo.mean; q[2] = lo.m2;
+        }
+      }
+      __syncthreads();
+      if (t < BN) {                                                  // one thread per output channel of the tile: merge the WM waves in order
+        const int cw = t / (TN * 32), cj = (t / 32) % TN, ci = t & 31;   // wn, j, lane of the channel
+        const float* q = st + (((0 * WN + cw) * TN + cj) * 32 + ci) * 3;
+        FpWf m{q[0], q[1], q[2]};
+#pragma unroll
+        for (int k = 1; k < WM; ++k) {
+          const float* qk = st + (((k * WN + cw) * TN + cj) * 32 + ci) * 3;
+          fp_wf_merge(m, FpWf{qk[0], qk[1], qk[2]});
+        }
+        const int n = e.n0 + t;
+        if (n < a.Nout) {
+          float* o = a.bn_part + ((size_t)((e.n_img * a.tilesY + e.tile_y) * a.tilesX + e.tile_x) * a.Nout + n) * 3;
+          o[0] = m.n; o[1] = m.mean; o[2] = m.m2;
+        }
       }
     }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = e.n0 + (wn * TN + j) * 32 + idx;
+        if (n >= a.Nout) continue;
+        if (interior) {
+          rows8(std::true_type{}, i, j, n, bias_j[j], 0);
+          rows8(std::true_type{}, i, j, n, bias_j[j], 1);
+        } else {
+          rows8(std::false_type{}, i, j, n, bias_j[j], 0);
+          rows8(std::false_type{}, i, j, n, bias_j[j], 1);
+        }
+      }
+  };
+
+  // ---- the tile loop ---------------------------------------------------------------------------------------------------------
+  int vb = blockIdx.x;
+  g = decode(vb);
+  setup();
+  prefetch_tile();
+  for (;;) {
+    if (PERSIST) lane_setup();
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    store_halo(0, std::integral_constant<int, 0>{});
+    load_halo(min(c_begin + 1, c_end - 1), std::integral_constant<int, 1>{});
+    if (HD == 2) load_halo(min(c_begin + 2, c_end - 1), std::integral_constant<int, 0>{});
     __syncthreads();
-    if (t < BN) {                                                  // one thread per output channel of the tile: merge the WM waves in order
-      const int cw = t / (TN * 32), cj = (t / 32) % TN, ci = t & 31;   // wn, j, lane of the channel
-      const float* q = st + (((0 * WN + cw) * TN + cj) * 32 + ci) * 3;
-      FpWf m{q[0], q[1], q[2]};
-#pragma unroll
-      for (int k = 1; k < WM; ++k) {
-        const float* qk = st + (((k * WN + cw) * TN + cj) * 32 + ci) * 3;
-        fp_wf_merge(m, FpWf{qk[0], qk[1], qk[2]});
-      }
-      const int n = n0 + t;
-      if (n < a.Nout) {
-        float* o = a.bn_part + ((size_t)((n_img * a.tilesY + tile_y) * a.tilesX + tile_x) * a.Nout + n) * 3;
-        o[0] = m.n; o[1] = m.mean; o[2] = m.m2;
-      }
+    for (int cc = c_begin; cc < c_end; cc += 2) {
+      chunk(std::integral_constant<int, 0>{}, cc);
+      if (cc + 1 < c_end) chunk(std::integral_constant<int, 1>{}, cc + 1);
     }
-    __syncthreads();                                               // the amax words below share the buffer's first bytes
+    const TileGeo e = g;
+    vb += gridDim.x;
+    const bool more = PERSIST && vb < a.nwg;
+#ifndef FP_TILE_PREFETCH_LATE
+    if (more) {                            // the next tile's first operands travel while this tile's epilogue runs
+      g = decode(vb);
+      setup();
+      prefetch_tile();
+    }
+    epilogue(e);
+    if (!more) break;
+#else
+    epilogue(e);
+    if (!more) break;
+    g = decode(vb);
+    setup();
+    prefetch_tile();
+#endif
+    __syncthreads();                       // every wave has left the halo buffers (and the statistics scratch) of tile e
   }
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = n0 + (wn * TN + j) * 32 + idx;
-      if (n >= a.Nout) continue;
-      const float bias = (epi & FP_EPI_BIAS) ? a.bias[n] : 0.f;
-      if (interior) {
-        rows8(std::true_type{}, i, j, n, bias, 0);
-        rows8(std::true_type{}, i, j, n, bias, 1);
-      } else {
-        rows8(std::false_type{}, i, j, n, bias, 0);
-        rows8(std::false_type{}, i, j, n, bias, 1);
-      }
-    }
   if (HP && a.amax_out && a.SK <= 1) {               // one publication per workgroup (the halo buffers are free by now)
     ymax = fp_wave_max(ymax);
     float* wmax = reinterpret_cast<float*>(lds);
@@ -607,53 +654,33 @@ __global__ void __launch_bounds__(256, WPF ? 1 : (HP ? FP_TILE_HP_WAVES : 1)) co
     __syncthreads();
     if (t == 0) fp_amax_publish(a.amax_out, blockIdx.x, fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3])));
   }
-#ifdef FP_TILE_STAMPS
-  if (a.stamps && lane == 0) {
-    st[14] = __builtin_readcyclecounter();
-    st[13] = __builtin_amdgcn_s_memrealtime();
-    unsigned hwid;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-    st[15] = hwid;
-    unsigned long long* o = a.stamps + ((size_t)blockIdx.x * 4 + wave) * 16;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) o[k] = st[k];
-  }
-#endif
 }
 
+// workgroups of a launch: every tile its own workgroup, or -- when the chip cannot hold them at once -- an even share of whole rounds
+// (a multiple of 8: a persistent workgroup keeps to the logical-id range of its XCD, see fp_xcd_remap)
 template <int TH, int TW, int BN, int WM, int WN, bool FLIP, bool FOLD, int NP = 3, bool HP = false, bool WPF = false>
 int launch3(Tile3Args& a, hipStream_t stream) {
-  static const unsigned extra_lds = getenv("FP_TILE_EXTRA_LDS") ? (unsigned)atoi(getenv("FP_TILE_EXTRA_LDS")) : 0u;   // occupancy experiments
-#ifdef FP_TILE_STAMPS
-  static unsigned long long* stamp_buf = nullptr;
-  const char* stamp_file = getenv("FP_TILE_STAMPS_FILE");
-  if (!stamp_buf) (void)hipMalloc(&stamp_buf, (size_t)16384 * 4 * 16 * 8);
-  a.stamps = stamp_file && a.nwg <= 16384 ? stamp_buf : nullptr;
-#endif
-  fp_launch((conv3x3_tile_bf3_kernel<TH, TW, BN, WM, WN, FLIP, FOLD, NP, HP, WPF>), dim3(a.nwg), dim3(256), extra_lds, stream, a);
-#ifdef FP_TILE_STAMPS
-  static int launch_no = 0;
-  static const int dump_at = getenv("FP_TILE_STAMPS_AT") ? atoi(getenv("FP_TILE_STAMPS_AT")) : -1;     // dump only that launch (steady state)
-  ++launch_no;
-  if (a.stamps && (dump_at < 0 || launch_no == dump_at)) {      // synchronous dump of this launch: one line per wave
-    (void)hipStreamSynchronize(stream);
-    const size_t n = (size_t)a.nwg * 4 * 16;
-    unsigned long long* hbuf = (unsigned long long*)malloc(n * 8);
-    (void)hipMemcpy(hbuf, stamp_buf, n * 8, hipMemcpyDeviceToHost);
-    FILE* f = fopen(stamp_file, "w");
-    if (f) {
-      for (size_t i = 0; i < (size_t)a.nwg * 4; ++i) {
-        fprintf(f, "%zu", i);
-        for (int k = 0; k < 16; ++k) fprintf(f, " %llu", hbuf[i * 16 + k]);
-        fprintf(f, "\n");
-      }
-      fclose(f);
-    }
-    free(hbuf);
+  static const int persist = getenv("FP_TILE_PERSIST") ? atoi(getenv("FP_TILE_PERSIST")) : 1;   // 0: one workgroup per tile (rounds 1-3)
+  static int resident = 0;                           // workgroups of THIS instantiation the chip holds at once
+  if (!resident) {
+    int per_cu = 0, dev = 0, cus = 256;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)conv3x3_tile_bf3_kernel<TH, TW, BN, WM, WN, FLIP, FOLD, NP, HP, WPF>, 256, 0) != hipSuccess ||
+        per_cu < 1)
+      per_cu = 1;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    resident = per_cu * (cus > 0 ? cus : 256);
+    if (persist > 1) resident = persist;             // experiments: an explicit workgroup budget
   }
-#endif
+  int grid = a.nwg;
+  if (persist && fp_tile_persistent(TW, WPF, HP) && a.nwg > resident) {
+    const int rounds = (a.nwg + resident - 1) / resident;
+    grid = ((a.nwg + rounds - 1) / rounds + 7) & ~7;
+    if (grid > a.nwg) grid = a.nwg;
+  }
+  fp_launch((conv3x3_tile_bf3_kernel<TH, TW, BN, WM, WN, FLIP, FOLD, NP, HP, WPF>), dim3(grid), dim3(256), 0u, stream, a);
   return fp_check_launch("fp_conv3x3_bf3");
 }
+
 
 // tile geometry + split factor for a problem, or ok = false
 struct Plan3 { bool ok; int th, tw, bn, tilesX, tilesY, tilesN, SK, chunksPerSplit; };
@@ -736,6 +763,8 @@ int run_tile3(const char* who, const fp_conv_desc* d, const float* src, const fl
   FP_REQUIRE(!(d->epi & (FP_EPI_ACTGRAD_ELU | FP_EPI_ACTGRAD_RELU)) || actsrc, "fp_conv3x3_bf3 / fp_conv3x3_hp: actsrc missing");
   FP_REQUIRE(p.SK <= 1 || (workspace && workspace_bytes >= fp_conv3x3_bf3_workspace(d)), "fp_conv3x3_bf3 / fp_conv3x3_hp: workspace too small");
   FP_REQUIRE((int64_t)d->N * d->OH * d->OW * d->Nout < ((int64_t)1 << 31), "fp_conv3x3_bf3 / fp_conv3x3_hp: output larger than 2^31 elements");
+  // operands are addressed with 32-bit byte offsets (raw buffer loads; bit 31 = "out of range, reads zero")
+  FP_REQUIRE((int64_t)d->N * d->IH * d->IW * (d->C0 + d->C1) * 4 < ((int64_t)1 << 31), "fp_conv3x3_bf3 / fp_conv3x3_hp: input larger than 2^31 bytes");
   Tile3Args a;
   a.bn_part = nullptr;
   const bool up2 = d->gather == FP_GATHER_FWD_REFLECT_UP2;

@@ -24,6 +24,8 @@ def main(argv=None):
         else:
             train = SyntheticLoader(opt.batch_size, opt.height, opt.width, opt.synthetic_steps)
         val = SyntheticLoader(opt.batch_size, opt.height, opt.width, max(1, opt.val_batches), seed=11)
+        # under torch.distributed.run (WORLD_SIZE > 1) TrainManager turns into one replica of a data-parallel run: --batch_size is the
+        # per-GPU batch, --synthetic_steps the number of GLOBAL batches per epoch (each rank trains on every world-th one)
         TrainManager(opt, train_loader=train, val_loader=val).train()
     elif opt.mode == "inference":
         raise SystemExit("inference mode needs a dataset loader: use footprints_amd.evaluation.inference.InferenceManager")

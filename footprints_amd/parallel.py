@@ -111,29 +111,44 @@ class Communicator:
 
     def destroy(self):
         if self.handle:
+            # recorded launch plans hold this communicator by raw pointer (csrc/plan.cpp NODE_ALLREDUCE): make every TrainStep drop its plans
+            # before one could be replayed on the freed handle
+            from . import ops
+            ops.bump_alloc_generation()
             self._lib.load().fp_comm_destroy(self.handle)
             self.handle = None
 
 
-_COMMS = {}
+_COMMS = {}          # group (None = the default group) -> Communicator or None; the key keeps the group object alive (id() values are recycled)
+_HOST_GROUPS = {}
+
+
+def _host_group(group):
+    """a group whose collectives run on the host (gloo): `group` itself when it is gloo-backed, else a gloo twin created once by all ranks
+    together -- the few bytes of host plumbing (flags, device census, logged losses) must not instantiate the framework's own NCCL
+    communicator with its watchdog thread and streams (they would take hardware queues from the engine, profiles/round3_notes.md)"""
+    if "gloo" in str(dist.get_backend(group)):
+        return group
+    if group not in _HOST_GROUPS:
+        ranks = dist.get_process_group_ranks(group) if group is not None else None
+        _HOST_GROUPS[group] = dist.new_group(ranks=ranks, backend="gloo")
+    return _HOST_GROUPS[group]
 
 
 def get_communicator(group=None, create=True):
     """the process's fp_comm communicator for `group`, created on first use by ALL ranks together; None when it cannot be used: every
     rank reports whether its fp_comm_init succeeded and the transport is only chosen if all did (else everyone falls back to
     torch.distributed collectives on the group)."""
-    key = id(group)
+    key = group
     if key in _COMMS or not create:
         return _COMMS.get(key)
     multi = dist.is_initialized() and dist.get_world_size(group) > 1
 
-    def agree(ok):                # MIN over the ranks (host tensor on a gloo group, device tensor otherwise)
+    def agree(ok):                # MIN over the ranks, on the host
         if not multi:
             return ok
         flag = torch.tensor([ok], dtype=torch.int32)
-        if "gloo" not in str(dist.get_backend(group)):
-            flag = flag.cuda()
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=_host_group(group))
         return int(flag.item())
 
     def complain(e):
@@ -171,18 +186,41 @@ def destroy_communicators():
         if c is not None:
             c.destroy()
     _COMMS.clear()
+    _SHARED_DEVICE.clear()
+
+
+_SHARED_DEVICE = {}
+
+
+def ranks_share_a_device(group=None):
+    """True when two ranks of the group sit on the same GPU of the same host (RCCL refuses that: the 1-GPU test box).  A collective over
+    the host group on first use -- every rank calls it at the same points (GradReducer / broadcast_state construction)."""
+    if group not in _SHARED_DEVICE:
+        import socket
+        mine = (socket.gethostname(), torch.cuda.current_device())
+        everyone = [None] * dist.get_world_size(group)
+        dist.all_gather_object(everyone, mine, group=_host_group(group))
+        _SHARED_DEVICE[group] = len(set(everyone)) < len(everyone)
+    return _SHARED_DEVICE[group]
 
 
 def _pick_transport(flat_grad, group, force):
+    """"rccl" (the library's fp_comm_* entry points) whenever every rank has a GPU of its own -- whatever backend the torch.distributed
+    group uses for its host plumbing; "torch" collectives on the group for CPU tensors and for ranks that share a device, and that choice
+    is announced: gloo stages every bucket through the host."""
     if not flat_grad.is_cuda:
         return "torch"
     if _TRANSPORT in ("torch", "rccl"):
         return _TRANSPORT
-    if not dist.is_initialized():
-        return "rccl" if force else "torch"
-    backend = str(dist.get_backend(group))
-    # a pure-gloo group over CUDA tensors = several test ranks sharing one GPU (RCCL refuses two ranks per device)
-    return "rccl" if "nccl" in backend else "torch"
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return "rccl" if (force or dist.is_initialized()) else "torch"
+    if ranks_share_a_device(group):
+        if dist.get_rank(group) == 0:
+            print("footprints_amd.parallel: several ranks share one GPU -- RCCL needs a device per rank; gradients travel over "
+                  "torch.distributed (%s), staged through the host.  This is a test configuration, not a data-parallel run."
+                  % dist.get_backend(group), flush=True)
+        return "torch"
+    return "rccl"
 
 
 class GradReducer:
@@ -276,11 +314,13 @@ def broadcast_state(model, src=0, group=None):
     done = set()
     comm = get_communicator(group) if (first.is_cuda and _pick_transport(first.data, group, False) == "rccl") else None
 
+    root = dist.get_group_rank(group, src) if group is not None else src      # `src` is a global rank; the communicator counts inside the group
+
     def bcast(t):
         if comm is None:
             dist.broadcast(t, src=src, group=group)
         elif t.dtype == torch.float32 and t.is_contiguous() and t.numel():
-            comm.broadcast(t, src, torch.cuda.current_stream())
+            comm.broadcast(t, root, torch.cuda.current_stream())
         elif "gloo" in str(dist.get_backend(group)):
             c = t.cpu()            # the few integer buffers (num_batches_tracked): through the host, so that the group's own CUDA
             dist.broadcast(c, src=src, group=group)      # backend (its communicator, watchdog and streams) is never instantiated
@@ -297,3 +337,76 @@ def broadcast_state(model, src=0, group=None):
         torch.cuda.current_stream().synchronize()
     if eng is not None:
         eng.invalidate()
+
+
+class DistContext:
+    """Host-side context of a data-parallel training run: rank / world from the launcher's environment
+    (`python -m torch.distributed.run --nproc-per-node N -m footprints_amd.main ...`), one process per GPU.  torch.distributed is host
+    plumbing only -- a gloo group for the rendezvous, the RCCL unique id, barriers and the 21 logged losses; gradients and the initial
+    weights travel through the library's own communicator (fp_comm_*).  The reference trainer is single-process
+    (footprints/training/train.py:42-215); everything here is what turns its loop into N replicas: per-rank shard of the loader,
+    rank-0-only console line and checkpoint (eight ranks would race on `weights_{epoch}`, train.py:190), one all-reduce per log event."""
+
+    def __init__(self, rank=0, world=1, local_rank=0, group=None):
+        self.rank, self.world, self.local_rank, self.group = rank, world, local_rank, group
+
+    @classmethod
+    def from_env(cls, use_cuda=True):
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        if world <= 1 and not dist.is_initialized():
+            return cls()
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        if use_cuda and torch.cuda.is_available():
+            torch.cuda.set_device(local % torch.cuda.device_count())      # before anything touches the GPU: one device per rank
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo", init_method="env://", rank=int(os.environ.get("RANK", "0")), world_size=world)
+        return cls(dist.get_rank(), dist.get_world_size(), local, None)
+
+    @property
+    def is_main(self):
+        return self.rank == 0
+
+    @property
+    def active(self):
+        return self.world > 1
+
+    def shard(self, loader):
+        return ShardedLoader(loader, self.rank, self.world) if self.active else loader
+
+    def mean_losses(self, losses):
+        """dict of floats -> the same keys averaged over the ranks (one small all-reduce on the host group; every rank calls it)"""
+        if not self.active:
+            return losses
+        keys = list(losses)                 # the same insertion order on every rank (LOSS_KEYS)
+        v = torch.tensor([float(losses[k]) for k in keys], dtype=torch.float64)
+        dist.all_reduce(v, op=dist.ReduceOp.SUM, group=_host_group(self.group))
+        v /= self.world
+        return {k: float(x) for k, x in zip(keys, v)}
+
+    def barrier(self):
+        if self.active:
+            dist.barrier(group=_host_group(self.group))
+
+
+class ShardedLoader:
+    """rank r of `world` sees batches r, r + world, r + 2 world, ... of the wrapped iterable, and every rank the same number of them
+    (the tail that does not fill a round is dropped: a rank with one batch more would wait in an all-reduce nobody else enters)"""
+
+    def __init__(self, loader, rank, world):
+        self.loader, self.rank, self.world = loader, rank, world
+        self.dataset = getattr(loader, "dataset", None)
+
+    def __len__(self):
+        return len(self.loader) // self.world
+
+    def __iter__(self):
+        n = len(self) if hasattr(self.loader, "__len__") else None
+        pending, out = [], 0
+        for b in self.loader:
+            pending.append(b)
+            if len(pending) == self.world:          # a full round: hand out this rank's batch
+                yield pending[self.rank]
+                pending, out = [], out + 1
+                if n is not None and out >= n:
+                    return

@@ -14,7 +14,7 @@ import torch
 
 from .. import ops
 from ..model_manager import ModelManager
-from ..parallel import GradReducer
+from ..parallel import DistContext, GradReducer, broadcast_state
 from .evaluation import Evaluator
 from .losses import LOSS_KEYS, SCALES, TARGET_KEYS
 
@@ -263,9 +263,15 @@ class TrainManager:
     `log_freq` steps a validation pass over `val_batches` batches in eval mode (train.py:174-185, 193-215: forward + loss
     through the drop-in `model(x)` / `Evaluator.compute_losses` surface under no_grad); per epoch the checkpoint and
     `scheduler.step()` (train.py:189-191).  Tensorboard writing is out of scope: `self.history` keeps
-    what `log(...)` would have received."""
+    what `log(...)` would have received.
 
-    def __init__(self, options=None, train_loader=None, val_loader=None, log=print, **kw):
+    Data-parallel training (north_star config #4; the reference is single-process): started through `python -m torch.distributed.run
+    --nproc-per-node N -m footprints_amd.main ...`, every rank builds the same manager on its own GPU; `DistContext` (parallel.py)
+    shards the loader, `broadcast_state` makes the replicas identical, `TrainStep(distributed=True)` all-reduces the gradient buckets
+    over RCCL under the backward pass, rank 0 alone prints and saves, logged losses are averaged over the ranks."""
+
+    def __init__(self, options=None, train_loader=None, val_loader=None, log=print, dist_context=None, model_manager=None,
+                 train_step=None, **kw):
         if options is not None and not hasattr(options, "epochs"):       # keyword style: first positional is the loader
             train_loader, options = options, None
         self.opt = options if options is not None else _Opts(**kw)
@@ -276,13 +282,18 @@ class TrainManager:
         if "loader" in kw:
             train_loader = kw["loader"]
         torch.manual_seed(SEED)                                          # train.py:33-35
-        self.train_loader, self.val_loader, self.log = train_loader, val_loader, log
-        self.loader = train_loader
+        # data-parallel context (launched through torch.distributed.run: WORLD_SIZE > 1 in the environment): one process per GPU, the
+        # device is selected BEFORE the model is built; rank r trains on every world-th batch of the loader, only rank 0 talks and saves
+        self.dist = dist_context if dist_context is not None else DistContext.from_env()
+        self.train_loader, self.val_loader = self.dist.shard(train_loader), val_loader
+        self.log = log if self.dist.is_main else (lambda *a, **k: None)
+        self.loader = self.train_loader
         save_folder = kw.get("save_folder")
         if save_folder is None and getattr(self.opt, "log_path", None):
             save_folder = os.path.join(self.opt.log_path, self.opt.model_name, "models")     # train.py:57-59
-        self.model_manager = ModelManager(save_folder=save_folder, use_cuda=True, learning_rate=self.opt.lr,
-                                          lr_step_size=kw.get("lr_step_size", 10))
+        # (model_manager / train_step can be injected: the CPU tests drive this loop with stand-ins, there is no CPU compute path)
+        self.model_manager = model_manager if model_manager is not None else ModelManager(
+            save_folder=save_folder, use_cuda=True, learning_rate=self.opt.lr, lr_step_size=kw.get("lr_step_size", 10))
         if getattr(self.opt, "load_path", None) is not None:
             self.model_manager.load_model(weights_path=self.opt.load_path, load_optimiser=True)   # train.py:63-64
         self.model = self.model_manager.model
@@ -290,7 +301,10 @@ class TrainManager:
         self.val_iter = iter(self.val_loader) if self.val_loader is not None else None
         depth_range = tuple(self.opt.depth_range)
         self.evaluator = Evaluator(depth_range, self.opt.footprint_prior, compute_viz=False)
-        self.train_step = TrainStep(self.model, self.optimiser, depth_range, self.opt.footprint_prior)
+        if self.dist.active and train_step is None:
+            broadcast_state(self.model, src=0, group=self.dist.group)     # every replica starts from rank 0's weights, buffers and Adam-free state
+        self.train_step = train_step if train_step is not None else TrainStep(
+            self.model, self.optimiser, depth_range, self.opt.footprint_prior, distributed=self.dist.active)
         self.epochs = self.opt.epochs
         self.step = 0
         self.lr = self.opt.lr
@@ -306,24 +320,30 @@ class TrainManager:
     def run_epoch(self):
         for batch_idx, inputs in enumerate(self.train_loader):
             t0 = time.time()
-            inputs = {k: v.cuda(non_blocking=True) for k, v in inputs.items()}     # process_batch: train.py:220-222
+            if torch.cuda.is_available():
+                inputs = {k: v.cuda(non_blocking=True) for k, v in inputs.items()}     # process_batch: train.py:220-222
             losses = self.train_step(inputs)                                       # train.py:150-156 in one schedule
             self.evaluator.add_loss_vector(losses, mode="train")
             self.lr = self.scheduler.get_last_lr()[0]
             self.train_network_time += time.time() - t0
             if self.step % 100 == 0:                                               # train.py:161-185
-                avg = self.evaluator.get_averaged_losses(mode="train", reset=False)
+                # data-parallel: the logged numbers are the mean over the ranks' shards (one 21-float all-reduce per log event,
+                # entered by every rank -- the step counter is the same everywhere)
+                avg = self.dist.mean_losses(self.evaluator.get_averaged_losses(mode="train", reset=False))
                 self.log("Epoch {} -- Batch {} -- Loss {}".format(self.epoch, batch_idx, avg["loss"]))
                 if self.step % self.opt.log_freq == 0:
-                    avg = self.evaluator.get_averaged_losses(mode="train", reset=True)
+                    avg = self.dist.mean_losses(self.evaluator.get_averaged_losses(mode="train", reset=True))
                     self.history["train"].append((self.step, avg))
                     if self.val_loader is not None:
                         self.model.eval()
                         self.val()
                         self.model.train()
             self.step += 1
-        if self.model_manager.save_folder is not None:
+        # checkpoint: rank 0 only (weights are bit-identical on every rank after each step; BatchNorm running statistics are per
+        # replica and rank 0's are the ones kept -- SURVEY.md section 8e); the others wait so that nobody races ahead into a load
+        if self.model_manager.save_folder is not None and self.dist.is_main:
             self.model_manager.save_model(folder_name="weights_{}".format(self.epoch))   # train.py:190
+        self.dist.barrier()
         self.scheduler.step()                                                             # train.py:191
 
     def val(self):
@@ -337,14 +357,15 @@ class TrainManager:
                     self.val_iter = iter(self.val_loader)
                     inputs = next(self.val_iter)
                 self.process_batch(inputs, mode="val", return_batch_loss=False)
-        avg = self.evaluator.get_averaged_losses(mode="val", reset=True)
+        avg = self.dist.mean_losses(self.evaluator.get_averaged_losses(mode="val", reset=True))
         self.history["val"].append((self.step, avg))
         self.val_time += time.time() - t0
         return avg
 
     def process_batch(self, inputs, mode="train", return_batch_loss=False):
         """train.py:217-227: the drop-in surface -- model(x) then Evaluator.compute_losses"""
-        inputs = {k: v.cuda(non_blocking=True) for k, v in inputs.items()}
+        if torch.cuda.is_available():
+            inputs = {k: v.cuda(non_blocking=True) for k, v in inputs.items()}
         outputs = self.model(inputs["image"])
         losses = self.evaluator.compute_losses(inputs, outputs, mode=mode, return_batch_loss=return_batch_loss)
         return outputs, losses

@@ -248,3 +248,151 @@ def test_engine_invalidate_after_data_write():
         a, b = m(img), fresh(img)
     for k in a:
         assert torch.equal(a[k], b[k]), k
+
+
+# ---- one rank per device over RCCL: runs by itself wherever pytest sees two or more GPUs ------------------------------------------------
+def _rccl_worker(rank, world, port, q):
+    try:
+        import torch.distributed as dist
+        os.environ.pop("FP_DP_TRANSPORT", None)                   # the default choice must be rccl when every rank has a device
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        torch.cuda.set_device(rank)
+        dist.init_process_group("gloo", rank=rank, world_size=world)      # host plumbing only: rendezvous, unique id, barriers
+        from footprints_amd.model_manager import ModelManager
+        from footprints_amd.parallel import broadcast_state, destroy_communicators, get_communicator
+        from footprints_amd.training.train import TrainStep
+        mm = ModelManager()
+        P, Bf = _state("dp" if rank == 0 else "dp.other")
+        _load(mm.model, P, Bf)
+        broadcast_state(mm.model)
+        ts = TrainStep(mm.model, mm.optimiser, distributed=True)
+        comm = get_communicator(None, create=False)
+        info = {"transport": ts.reducer.transport, "comm_world": comm.world if comm is not None else 0, "reducer_world": ts.reducer.world,
+                "recordable": ts.reducer.plan_recordable, "device": torch.cuda.current_device()}
+        batch = _shard(rank)
+        losses = [float(ts(batch)[20]) for _ in range(STEPS)]     # 2 eager + record + 2 replays, the all-reduces inside the plan
+        info["plans"] = len(ts._plans)
+        torch.cuda.synchronize()
+        flat = torch.cat([p.detach().flatten() for p in mm.model.parameters()]).cpu().numpy()
+        q.put((rank, "ok", flat, losses, info))
+        dist.barrier()
+        destroy_communicators()
+        dist.destroy_process_group()
+    except Exception as e:
+        import traceback
+        q.put((rank, "error", traceback.format_exc(), repr(e), {}))
+
+
+def test_one_rank_per_device_over_rccl_matches_the_n_shard_oracle():
+    """SURVEY.md section 8(e) / north_star config #4 at whatever size the box offers: N = min(device_count, 8) ranks, one per GPU, gradients
+    over the library's own RCCL communicator (fp_comm_*).  Bit-identical weights on every rank after 5 steps (2 eager + the recorded launch
+    plan + 2 replays), equal to the single-process N-shard emulation (sum of the shards' gradients, Adam with grad_scale 1/N) at 1e-6, the
+    transport really is "rccl" and the communicator really spans N ranks.  The reference has no counterpart (README.md:128: one GPU)."""
+    n = min(torch.cuda.device_count(), 8)
+    if n < 2:
+        pytest.skip("ONE GPU visible: RCCL with more than one rank cannot run here (RCCL refuses two ranks per device); this case runs "
+                    "by itself on any box with >= 2 GPUs")
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rccl_worker, args=(r, n, port, q)) for r in range(n)]
+    for p in procs:
+        p.start()
+    res = {}
+    try:
+        for _ in range(n):
+            r = q.get(timeout=900)
+            res[r[0]] = r
+    finally:
+        for p in procs:
+            p.join(timeout=120)
+            if p.is_alive():
+                p.terminate()
+    for r in res.values():
+        assert r[1] == "ok", "rank %d failed:\n%s" % (r[0], r[2])
+    for r in range(n):
+        info = res[r][4]
+        assert info["transport"] == "rccl" and info["recordable"] and info["comm_world"] == n and info["reducer_world"] == n, info
+        assert info["device"] == r and info["plans"] == 1, info
+        assert np.array_equal(res[0][2], res[r][2]), "rank %d diverged from rank 0" % r
+    from footprints_amd.model_manager import ModelManager
+    from footprints_amd.training.losses import LossManager
+    mm = ModelManager()
+    P, Bf = _state("dp")
+    _load(mm.model, P, Bf)
+    mm.optimiser.grad_scale = 1.0 / n
+    lm = LossManager((0.1, 100), 0.25, compute_viz=False)
+    shards = [_shard(r) for r in range(n)]
+    for _ in range(STEPS):
+        mm.model.train()
+        mm.model.zero_grad()
+        for sh in shards:
+            lm(mm.model(sh["image"]), sh)["loss"].backward()
+        mm.optimiser.step()
+    ref = torch.cat([p.detach().flatten() for p in mm.model.parameters()]).cpu().numpy()
+    err = np.abs(res[0][2].astype(np.float64) - ref).max() / np.abs(ref).max()
+    assert err < 1e-6, err
+
+
+# ---- the trainer itself as one replica of two (ranks share the test box's GPU: gloo transport) -------------------------------------------
+def _trainer_worker(rank, world, port, folder, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK="0")
+        torch.cuda.set_device(0)
+        from footprints_amd.main import main
+        from footprints_amd.training import train as T
+        made = []
+        orig = T.TrainManager.__init__
+
+        def spy(self, *a, **k):
+            orig(self, *a, **k)
+            made.append(self)
+        T.TrainManager.__init__ = spy
+        main(["--mode", "train", "--synthetic_steps", "8", "--epochs", "1", "--batch_size", "2", "--height", "64", "--width", "96",
+              "--val_batches", "1", "--log_path", folder, "--model_name", "dp"])
+        tm = made[0]
+        torch.cuda.synchronize()
+        flat = torch.cat([p.detach().flatten() for p in tm.model.parameters()]).cpu().numpy()
+        q.put((rank, "ok", flat, tm.step, tm.train_step.reducer is not None and tm.train_step.reducer.world, tm.history))
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+    except BaseException as e:
+        import traceback
+        q.put((rank, "error", traceback.format_exc(), repr(e), None, None))
+
+
+def test_main_trains_data_parallel_under_a_launcher_environment(tmp_path):
+    """`python -m footprints_amd.main --mode train ...` under WORLD_SIZE = 2 (what torch.distributed.run sets): each rank trains on every
+    second batch, weights stay bit-identical, rank 0 alone writes the epoch checkpoint, both hold the same rank-averaged loss history."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_trainer_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    try:
+        for _ in range(2):
+            r = q.get(timeout=600)
+            res[r[0]] = r
+    except Exception:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+        pytest.skip("the two ranks did not report within 600 s (rendezvous / transport problem on this box)")
+    for p in procs:
+        p.join(timeout=120)
+    for r in res.values():
+        if r[1] == "error":
+            if "Connection" in r[2] or "Address already in use" in r[2]:
+                pytest.skip("gloo rendezvous failed: " + r[3])
+            raise AssertionError("rank %d failed:\n%s" % (r[0], r[2]))
+    assert np.array_equal(res[0][2], res[1][2]), "ranks diverged"
+    assert res[0][3] == res[1][3] == 4 and res[0][4] == res[1][4] == 2          # 8 global batches -> 4 steps per rank; reducer world 2
+    assert res[0][5]["train"] == res[1][5]["train"] and res[0][5]["val"] == res[1][5]["val"]
+    models = os.path.join(str(tmp_path), "dp", "models")
+    assert sorted(os.listdir(models)) == ["weights_0"] and sorted(os.listdir(os.path.join(models, "weights_0"))) == ["model.pth", "optimiser.pth"]
