@@ -160,6 +160,7 @@ conv3x3_tile_bf3_kernel(const Tile3Args a) {
     ka = fp_hp_exponent(ab, FP_HP_TARGET_ACT);
     kunscale = -(ka + fp_hp_exponent(fp_amax_bits(a.amax_w), FP_HP_TARGET_W));
   }
+  const float sa = ldexpf(1.f, ka);                  // 2^ka, the source's scale
   // buffer resources (sizes checked on the host: every operand is smaller than 2^31 bytes, so bit 31 of an offset means "out of range")
   const int cs = a.C - a.Clo;                        // channels of `src` (the skip tensor of the concat gather, else the whole input)
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src), 0, a.N * a.IH * a.IW * cs * 4, 0x00020000);
@@ -294,12 +295,10 @@ conv3x3_tile_bf3_kernel(const Tile3Args a) {
       if (zero_tail) v = f32x4{0.f, 0.f, 0.f, 0.f};
       unsigned char* p = lds + buf * BUF + lds_off[k];
       if (HP) {
-        v = f32x4{ldexpf(v.x, ka), ldexpf(v.y, ka), ldexpf(v.z, ka), ldexpf(v.w, ka)};
-        const f16x4 vh = __builtin_convertvector(v, f16x4);
-        const f32x4 r1 = v - __builtin_convertvector(vh, f32x4);
-        const f16x4 vm = __builtin_convertvector(r1, f16x4);
-        *reinterpret_cast<uint2*>(p) = __builtin_bit_cast(uint2, vh);
-        *reinterpret_cast<uint2*>(p + PLANE) = __builtin_bit_cast(uint2, vm);
+        uint2 hq, mq;
+        fp_hp_split4(v.x, v.y, v.z, v.w, sa, hq, mq);
+        *reinterpret_cast<uint2*>(p) = hq;
+        *reinterpret_cast<uint2*>(p + PLANE) = mq;
         continue;
       }
       const bf16x4 vh = __builtin_convertvector(v, bf16x4);
@@ -316,8 +315,11 @@ conv3x3_tile_bf3_kernel(const Tile3Args a) {
   // ---- weight slices: [tap][chunk][plane][n][16] bf16; lane (n = idx, k-group = h) reads 16 bytes per plane -----------------
   uint4 bq[WPF ? 1 : 3][TN][NP];
   uint4 bw[WPF ? 2 : 1][WPF ? 9 : 1][TN][NP];          // WPF: [chunk parity][tap]
-  auto load_b = [&](int tap, int cc, uint4 (&bf)[TN][NP]) {
-    const int so = tap * wtap + cc * wchunk;
+  int wtapoff[9];                                     // tap * wtap: nine SGPRs instead of a scalar multiply per load
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp) wtapoff[tp] = tp * wtap;
+  auto load_b = [&](int tap, int cbase, uint4 (&bf)[TN][NP]) {      // cbase = chunk * wchunk
+    const int so = wtapoff[tap] + cbase;
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -351,10 +353,10 @@ conv3x3_tile_bf3_kernel(const Tile3Args a) {
     load_halo(c_begin, std::integral_constant<int, 0>{});
     if constexpr (WPF) {
 #pragma unroll
-      for (int tp = 0; tp < 9; ++tp) load_b(tp, c_begin, bw[0][tp]);
+      for (int tp = 0; tp < 9; ++tp) load_b(tp, c_begin * wchunk, bw[0][tp]);
     } else {
-      load_b(0, c_begin, bq[0]);           // issued before the halo is consumed: one exposed load latency in the prologue, not two
-      load_b(1, c_begin, bq[1]);
+      load_b(0, c_begin * wchunk, bq[0]);  // issued before the halo is consumed: one exposed load latency in the prologue, not two
+      load_b(1, c_begin * wchunk, bq[1]);
     }
   };
 
@@ -362,6 +364,7 @@ conv3x3_tile_bf3_kernel(const Tile3Args a) {
     constexpr int PAR = decltype(par_tag)::value;          // (cc - c_begin) & 1, as a constant: register-set index of the WPF weights
     const unsigned char* Hb = lds + ((cc - c_begin) & 1) * BUF;
     const int ccn = min(cc + 1, c_end - 1);
+    const int wb = cc * wchunk, wbn = ccn * wchunk;
     // A fragments are read one tap ahead (two register sets): with 32-cycle MFMAs an LDS read issued right before its
     // consumer costs ~150 cycles per 384-cycle tap
     uint4 af[2][TM][NP];
@@ -384,11 +387,11 @@ conv3x3_tile_bf3_kernel(const Tile3Args a) {
         __builtin_amdgcn_sched_barrier(0);
         if (tap < 8) load_a(tap + 1, af[(tap + 1) & 1]);
         if constexpr (WPF) {
-          load_b(tap, ccn, bw[PAR ^ 1][tap]);              // the next chunk's slice of this tap: a whole chunk ahead of its use
+          load_b(tap, wbn, bw[PAR ^ 1][tap]);              // the next chunk's slice of this tap: a whole chunk ahead of its use
           mma6(af[tap & 1], bw[PAR][tap]);
         } else {
-          if (tap < 7) load_b(tap + 2, cc, bq[(tap + 2) % 3]);
-          else load_b(tap - 7, ccn, bq[(tap + 2) % 3]);
+          if (tap < 7) load_b(tap + 2, wb, bq[(tap + 2) % 3]);
+          else load_b(tap - 7, wbn, bq[(tap + 2) % 3]);
           mma6(af[tap & 1], bq[tap % 3]);
         }
         // issue order: one LDS / global read between consecutive MFMAs (this tap's MFMAs only depend on older reads)

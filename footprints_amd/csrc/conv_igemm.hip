@@ -350,6 +350,7 @@ __global__ void __launch_bounds__(256) igemm_hp_kernel(const IgemmArgs a) {
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const FpGeom& g = a.g;
   const int ka = fp_hp_exponent(fp_amax_bits(a.amax_a), FP_HP_TARGET_ACT);
+  const float sa = ldexpf(1.f, ka);
   const int kunscale = -(ka + fp_hp_exponent(fp_amax_bits(a.amax_w), FP_HP_TARGET_W));
 
   // this lane's row of the GEMM = one output pixel (forward) / one input-gradient pixel (data gradient)
@@ -446,12 +447,11 @@ __global__ void __launch_bounds__(256) igemm_hp_kernel(const IgemmArgs a) {
 
   auto consume = [&](int set) {
     const float4 a0 = aok[set][0] ? ar[set][0] : make_float4(0.f, 0.f, 0.f, 0.f), a1 = aok[set][1] ? ar[set][1] : make_float4(0.f, 0.f, 0.f, 0.f);
-    ig_f32x8 v = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-#pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = ldexpf(v[k], ka);
-    const ig_f16x8 vh = __builtin_convertvector(v, ig_f16x8);
-    const ig_f32x8 r1 = v - __builtin_convertvector(vh, ig_f32x8);
-    const ig_f16x8 vm = __builtin_convertvector(r1, ig_f16x8);
+    uint2 h0, m0, h1, m1;
+    fp_hp_split4(a0.x, a0.y, a0.z, a0.w, sa, h0, m0);
+    fp_hp_split4(a1.x, a1.y, a1.z, a1.w, sa, h1, m1);
+    const ig_f16x8 vh = __builtin_bit_cast(ig_f16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));
+    const ig_f16x8 vm = __builtin_bit_cast(ig_f16x8, make_uint4(m0.x, m0.y, m1.x, m1.y));
     // products mh, hm, hh (smallest first), as in conv3x3_tile_bf3.hip
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vm, __builtin_bit_cast(ig_f16x8, br[set][j][0]), acc[0][j], 0, 0, 0);

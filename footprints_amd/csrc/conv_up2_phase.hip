@@ -179,12 +179,10 @@ constexpr int PIXB = 48, PLANE3 = HP * PIXB;      // bytes per halo pixel and pe
 template <int NP>
 __device__ __forceinline__ void phase_store_split(unsigned char* p, f32x4_t v, int ka) {
   if (NP == 2) {
-    v = f32x4_t{ldexpf(v.x, ka), ldexpf(v.y, ka), ldexpf(v.z, ka), ldexpf(v.w, ka)};
-    const f16x4_t vh = __builtin_convertvector(v, f16x4_t);
-    const f32x4_t r1 = v - __builtin_convertvector(vh, f32x4_t);
-    const f16x4_t vm = __builtin_convertvector(r1, f16x4_t);
-    *reinterpret_cast<uint2*>(p) = __builtin_bit_cast(uint2, vh);
-    *reinterpret_cast<uint2*>(p + PLANE3) = __builtin_bit_cast(uint2, vm);
+    uint2 hq, mq;
+    fp_hp_split4(v.x, v.y, v.z, v.w, ldexpf(1.f, ka), hq, mq);
+    *reinterpret_cast<uint2*>(p) = hq;
+    *reinterpret_cast<uint2*>(p + PLANE3) = mq;
   } else {
     const bf16x4_t vh = __builtin_convertvector(v, bf16x4_t);
     const f32x4_t r1 = v - __builtin_convertvector(vh, f32x4_t);

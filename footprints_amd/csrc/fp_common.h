@@ -198,7 +198,23 @@ __device__ __forceinline__ unsigned fp_amax_bits(const unsigned* __restrict__ sl
 }
 // exponent k with amax * 2^k in [2^target, 2^(target+1)); 0 for an all-zero tensor; inf / nan propagate through the data itself
 __device__ __forceinline__ int fp_hp_exponent(unsigned amax_bits, int target) {
-  return amax_bits ? target - ((int)(amax_bits >> 23) - 127) : 0;
+  // (clamped so that 2^k is a finite float: the staging code multiplies by it; tensors whose largest element is below 2^-114 lose
+  // low-order bits instead -- they are beyond any gradient this network produces)
+  return amax_bits ? min(target - ((int)(amax_bits >> 23) - 127), 126) : 0;
+}
+// x * s = h + m (s = 2^k, wave-uniform): the two fp16 planes of four floats in TWO VALU instructions per element --
+// v_fma_mixlo/hi_f16 form fp16(x * s) and fp16(x * s - h) with the fp32 intermediate exact and one rounding each -- bit-identical to
+// the round-3 sequence ldexp, cvt_pk, cvt back, subtract, cvt_pk (4.5 per element; the conversion was ~40 % of the weight gradient's
+// instruction stream and a fifth of the tile kernel's main loop)
+typedef _Float16 fp_f16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void fp_hp_split4(float x0, float x1, float x2, float x3, float s, uint2& hq, uint2& mq) {
+  fp_f16x4 h, m;
+  h.x = (_Float16)__builtin_fmaf(x0, s, 0.f); h.y = (_Float16)__builtin_fmaf(x1, s, 0.f);
+  h.z = (_Float16)__builtin_fmaf(x2, s, 0.f); h.w = (_Float16)__builtin_fmaf(x3, s, 0.f);
+  m.x = (_Float16)__builtin_fmaf(x0, s, -(float)h.x); m.y = (_Float16)__builtin_fmaf(x1, s, -(float)h.y);
+  m.z = (_Float16)__builtin_fmaf(x2, s, -(float)h.z); m.w = (_Float16)__builtin_fmaf(x3, s, -(float)h.w);
+  hq = __builtin_bit_cast(uint2, h);
+  mq = __builtin_bit_cast(uint2, m);
 }
 // publish a magnitude into an amax slot.  Agent-scope atomics execute at the memory side and same-address ones serialise at ~90 ns
 // each (measured: 11 520 publishing waves = +64 us; 1 024 workgroups of an element-wise kernel finishing together = +20 us), so a
@@ -288,80 +304,4 @@ __device__ __forceinline__ void fp_sched_interleave() {
     __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
   }
   if (NM - NDS - NVM > 0) __builtin_amdgcn_sched_group_barrier(0x008, NM - NDS - NVM > 0 ? NM - NDS - NVM : 1, 0);
-}
-
-
-// ---- in-kernel grid synchronisation (fused BatchNorm, fused split reductions) ---------------------------------------------------
-// A kernel whose workgroups are all co-resident (grid <= a few workgroups per CU) can contain a grid-wide dependency: every
-// workgroup publishes a partial result, takes a ticket, and the LAST one to arrive combines the partials in a fixed order (so the
-// result does not depend on who was last: run-to-run bit-identical) and raises a flag the others spin on -- one launch instead of
-// three on the encoder's serial spine, where a dependent launch costs as much as these small kernels themselves.
-//  * Visibility without cache flushes: partials are written with agent-scope relaxed atomic stores (sc1: written through to
-//    memory; the per-XCD L2s are not coherent with each other), the writer waits for vmcnt(0) before its ticket, readers use
-//    agent-scope atomic loads (sc1: never served from a stale L1 / L2 line).  -DFP_GSYNC_FORMAL builds the same protocol with
-//    agent-scope release / acquire fences (buffer_wbl2 / buffer_inv) instead, for A/B runs.
-//  * Tickets: same-address agent-scope atomics execute at the memory side and serialise at ~90 ns each, so arrivals go up a tree
-//    of fan-in 8 (distinct addresses proceed in parallel): ~0.7 us per level.  A node's last arriver re-arms it, the last
-//    workgroup to leave re-arms the flag: the sync block is zeroed once by its owner and reusable by every later launch on the
-//    same stream.
-constexpr int FP_GSYNC_TREE = 640;                      // counters of one arrival tree: up to 4096 workgroups (512 + 64 + 8 + 1)
-constexpr int FP_GSYNC_WORDS = 2 * FP_GSYNC_TREE + 64;  // arrival tree, exit tree, flag (its own 128-byte line)
-__device__ __forceinline__ void fp_gs_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float fp_gs_load(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// every thread, after its fp_gs_store calls and before the workgroup's ticket
-__device__ __forceinline__ void fp_gs_publish() {
-#ifdef FP_GSYNC_FORMAL
-  __atomic_thread_fence(__ATOMIC_RELEASE);              // agent scope: buffer_wbl2 sc1 + s_waitcnt
-#else
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-  __syncthreads();
-}
-// every thread of the workgroup that is about to read what others published
-__device__ __forceinline__ void fp_gs_acquire() {
-#ifdef FP_GSYNC_FORMAL
-  __atomic_thread_fence(__ATOMIC_ACQUIRE);              // agent scope: buffer_inv sc1
-#endif
-}
-// one thread per workgroup: true for exactly one workgroup of the grid, the last to call
-__device__ __forceinline__ bool fp_gs_ticket(unsigned* tree, int wg, int nwg) {
-  int idx = wg, n = nwg, off = 0;
-  while (n > 1) {
-    const int g = idx >> 3, gsize = min(8, n - (g << 3));
-    unsigned* c = tree + off + g;
-    const unsigned old = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (old != (unsigned)(gsize - 1)) return false;
-    __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int ng = (n + 7) >> 3;
-    off += ng;
-    idx = g;
-    n = ng;
-  }
-  return true;
-}
-// whole workgroup: did THIS workgroup arrive last?  (call after fp_gs_publish)
-__device__ __forceinline__ bool fp_gs_arrive_last(unsigned* sync, int wg, int nwg) {
-  __shared__ int fp_gs_last;
-  if (threadIdx.x == 0) fp_gs_last = fp_gs_ticket(sync, wg, nwg) ? 1 : 0;
-  __syncthreads();
-  const bool last = fp_gs_last != 0;
-  if (last) fp_gs_acquire();
-  return last;
-}
-__device__ __forceinline__ unsigned* fp_gs_flag(unsigned* sync) { return sync + 2 * FP_GSYNC_TREE; }
-// last arriver, after its own fp_gs_publish of the combined result
-__device__ __forceinline__ void fp_gs_release_all(unsigned* sync) {
-  if (threadIdx.x == 0) __hip_atomic_store(fp_gs_flag(sync), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// every workgroup: wait until the combined result is published
-__device__ __forceinline__ void fp_gs_wait(unsigned* sync) {
-  if (threadIdx.x == 0)
-    while (__hip_atomic_load(fp_gs_flag(sync), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(4);
-  __syncthreads();
-  fp_gs_acquire();
-}
-// every workgroup, once it no longer needs the flag: the last one out re-arms it
-__device__ __forceinline__ void fp_gs_leave(unsigned* sync, int wg, int nwg) {
-  if (threadIdx.x == 0 && fp_gs_ticket(sync + FP_GSYNC_TREE, wg, nwg))
-    __hip_atomic_store(fp_gs_flag(sync), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

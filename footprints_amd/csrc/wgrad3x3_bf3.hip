@@ -265,12 +265,10 @@ __device__ __forceinline__ void split_store_np(unsigned char* p, int plane_strid
     split_store(p, plane_stride, v);
     return;
   }
-  v = f32x4{ldexpf(v.x, kscale), ldexpf(v.y, kscale), ldexpf(v.z, kscale), ldexpf(v.w, kscale)};
-  const f16x4 vh = __builtin_convertvector(v, f16x4);
-  const f32x4 r1 = v - __builtin_convertvector(vh, f32x4);
-  const f16x4 vm = __builtin_convertvector(r1, f16x4);
-  *reinterpret_cast<uint2*>(p) = __builtin_bit_cast(uint2, vh);
-  *reinterpret_cast<uint2*>(p + plane_stride) = __builtin_bit_cast(uint2, vm);
+  uint2 hq, mq;
+  fp_hp_split4(v.x, v.y, v.z, v.w, ldexpf(1.f, kscale), hq, mq);      // (kscale is wave-uniform: the power of two is formed once by the scalar unit)
+  *reinterpret_cast<uint2*>(p) = hq;
+  *reinterpret_cast<uint2*>(p + plane_stride) = mq;
 }
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint2 lds_tr16(const unsigned char* p) {

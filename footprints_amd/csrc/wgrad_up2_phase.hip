@@ -136,12 +136,10 @@ typedef _Float16 pf16x4 __attribute__((ext_vector_type(4)));
 template <int NP>
 __device__ __forceinline__ void psplit_store(unsigned char* p, int plane_stride, pf32x4 v, int kscale) {
   if (NP == 2) {
-    v = pf32x4{ldexpf(v.x, kscale), ldexpf(v.y, kscale), ldexpf(v.z, kscale), ldexpf(v.w, kscale)};
-    const pf16x4 vh = __builtin_convertvector(v, pf16x4);
-    const pf32x4 r1 = v - __builtin_convertvector(vh, pf32x4);
-    const pf16x4 vm = __builtin_convertvector(r1, pf16x4);
-    *reinterpret_cast<uint2*>(p) = __builtin_bit_cast(uint2, vh);
-    *reinterpret_cast<uint2*>(p + plane_stride) = __builtin_bit_cast(uint2, vm);
+    uint2 hq, mq;
+    fp_hp_split4(v.x, v.y, v.z, v.w, ldexpf(1.f, kscale), hq, mq);
+    *reinterpret_cast<uint2*>(p) = hq;
+    *reinterpret_cast<uint2*>(p + plane_stride) = mq;
     return;
   }
   const pbf16x4 vh = __builtin_convertvector(v, pbf16x4);

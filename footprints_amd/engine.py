@@ -546,20 +546,10 @@ class Engine:
         return out
 
     def _bn(self, rec, z, out, training, residual=None, relu=True):
-        """BatchNorm of one encoder conv output: train mode = batch statistics + normalisation (statistics, their combination, normalisation: three launches; FP_BN_FUSED=1: one fused launch)"""
-        if not (training and ops._BN_FUSED):
-            self._bn_coeffs(rec, z, training)
-            return self._bn_apply(rec, z, out, residual=residual, relu=relu)
-        bn = rec.bn
-        M = z.numel() // rec.C
-        so = self.amax.out_slot(out) if _HP else None
-        ops.bn_train_fused(z.view(M, rec.C), out.view(M, rec.C), bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var,
-                           bn.num_batches_tracked, rec.mean, rec.invstd, rec.scale, rec.shift,
-                           residual=None if residual is None else residual.view(M, rec.C), relu=relu, eps=bn.eps,
-                           momentum=bn.momentum if bn.momentum is not None else 0.1, amax_out=so)
-        if so is not None:
-            self.amax.published(out, so)
-        return out
+        """BatchNorm of one encoder conv output: train mode = batch statistics + normalisation (statistics -- out of the producing tile
+        convolution's epilogue where that applies --, their combination, normalisation)"""
+        self._bn_coeffs(rec, z, training)
+        return self._bn_apply(rec, z, out, residual=residual, relu=relu)
 
     @staticmethod
     def _head_wb(hd):
@@ -725,7 +715,7 @@ class Engine:
         if bn is not None:
             bn.stats_nblk = 0
             tile = (c.wp3 is not None or (_HP_TILE and c.hp_f is not None and not ops._bf16x2)) and ops.conv3x3_bf3_supported(d)
-            if tile and ops._BN_EPI and not (ops._BN_FUSED or ops._BN_TICKET):
+            if tile and ops._BN_EPI:
                 # one (count, mean, M2) triple per pixel tile and channel: tiles of 8 x 16 or 6 x 20 pixels, bounded by 6 x 16-pixel ones
                 cap = N * ((OH + 5) // 6) * ((OW + 15) // 16) * c.Cout * 3
                 bn.stats_part = self.buf("bn.part", (max(cap, 1),))
@@ -835,15 +825,13 @@ class Engine:
             z1 = self._conv_enc(blk.c1, x, N, h, w, buf("b%d.z1" % i, (N, oh, ow, blk.Cout)), bn=blk.bn1 if training else None)
             a1 = self._bn(blk.bn1, z1, buf("b%d.a1" % i, (N, oh, ow, blk.Cout)), training)
             z2 = self._conv_enc(blk.c2, a1, N, oh, ow, buf("b%d.z2" % i, (N, oh, ow, blk.Cout)), bn=blk.bn2 if training else None)
-            fused2 = training and ops._BN_FUSED
-            if not fused2:
-                self._bn_coeffs(blk.bn2, z2, training)          # the statistics do not need the shortcut branch: before the join
+            self._bn_coeffs(blk.bn2, z2, training)              # the statistics do not need the shortcut branch: before the join
             if blk.ds is not None and ev_idt is None:
                 zd, idt = shortcut()
             if ev_idt is not None:
                 ops.event_wait(ops.current_stream(), ev_idt)
             ob = buf("b%d.out" % i, (N, oh, ow, blk.Cout))
-            out = self._bn(blk.bn2, z2, ob, training, residual=idt) if fused2 else self._bn_apply(blk.bn2, z2, ob, residual=idt)
+            out = self._bn_apply(blk.bn2, z2, ob, residual=idt)
             S["blocks"].append(dict(x=x, z1=z1, a1=a1, z2=z2, zd=zd, out=out, hin=h, win=w, h=oh, w=ow))
             x, h, w = out, oh, ow
             last_of_layer = (i + 1 == len(self.blocks)) or (self.blocks[i + 1].stride == 2)

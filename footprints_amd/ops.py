@@ -559,12 +559,6 @@ def bn_train_stats(z2d, gamma, beta, running_mean, running_var, nbt, save_mean, 
     ws = workspace(lib.fp_bn_workspace(M, Cn), z2d.device)
     if nbt is not None and nbt.dtype != torch.int64:
         raise RuntimeError("num_batches_tracked must be int64")
-    if _BN_TICKET:
-        sync = grid_sync_block(z2d.device)
-        _lib.check(lib.fp_bn_train_stats_ticket(_f32(z2d), M, Cn, _f32(gamma), _f32(beta), eps, momentum, _f32(running_mean), _f32(running_var),
-                                                _chk(nbt), _f32(save_mean), _f32(save_invstd), _f32(scale), _f32(shift), ws.data_ptr(),
-                                                ws.numel(), sync.data_ptr(), stream()), "fp_bn_train_stats_ticket")
-        return
     _lib.check(lib.fp_bn_train_stats(_f32(z2d), M, Cn, _f32(gamma), _f32(beta), eps, momentum, _f32(running_mean), _f32(running_var),
                                      _chk(nbt), _f32(save_mean), _f32(save_invstd), _f32(scale), _f32(shift), ws.data_ptr(),
                                      ws.numel(), stream()), "fp_bn_train_stats")
@@ -591,46 +585,6 @@ def bn_train_stats_partials(part, nblk, Cn, gamma, beta, running_mean, running_v
                                                       _f32(scale), _f32(shift), stream()), "fp_bn_train_stats_partials")
 
 
-# fused train-mode BatchNorm (one launch per layer and direction, in-kernel grid dependency: csrc/bn_pool.hip).  OPT-IN (FP_BN_FUSED=1):
-# correct and bit-reproducible (tests/test_gpu_bn_fused.py) but measured SLOWER in the training step (16.7 vs 13.9 ms, round 3): the
-# per-XCD L2s are not coherent, so everything workgroups exchange goes through memory at 1-2 us per dependent hop, and the last
-# arriver's combine of G x C partials is a serial chain of such hops -- a dependent launch (~10 us) is cheaper (profiles/round3_notes.md)
-_BN_FUSED = bool(int(os.environ.get("FP_BN_FUSED", "0")))
-# ticket forms: statistics (backward: reduction) + per-channel combination in one launch, the last workgroup to arrive combines, nobody
-# waits; the apply launch follows -- two launches per layer and direction instead of three.  OPT-IN as well (FP_BN_TICKET=1): 14.69 vs
-# 13.67 ms per step -- one workgroup combining G x C partials through memory (sc1 loads, ~0.7 us per dependent batch) plus the smaller
-# grids the combine forces on the streaming phase cost more than the launch they save (profiles/round3_notes.md)
-_BN_TICKET = bool(int(os.environ.get("FP_BN_TICKET", "0")))
-_sync_blocks = {}
-
-
-def grid_sync_block(device):
-    """the zeroed, self re-arming sync words of the in-kernel grid dependencies: one block per (device, stream) -- kernels on one
-    stream are ordered, kernels on different streams may run concurrently and must not share one"""
-    key = (device.index, stream())
-    b = _sync_blocks.get(key)
-    if b is None:
-        b = _sync_blocks[key] = torch.zeros(_lib.load().fp_grid_sync_words(), dtype=torch.int32, device=device)
-        bump_alloc_generation()
-    return b
-
-
-def bn_train_fused(z2d, y2d, gamma, beta, running_mean, running_var, nbt, save_mean, save_invstd, scale, shift, residual=None, relu=True,
-                   eps=1e-5, momentum=0.1, amax_out=None):
-    """train-mode BatchNorm in one launch: batch statistics (+ running statistics), then y = act(z * scale + shift (+ residual))"""
-    lib = _lib.load()
-    M, Cn = z2d.shape
-    ws = workspace(lib.fp_bn_workspace(M, Cn), z2d.device)
-    if nbt is not None and nbt.dtype != torch.int64:
-        raise RuntimeError("num_batches_tracked must be int64")
-    sync = grid_sync_block(z2d.device)
-    _sink(amax_out)
-    _lib.check(lib.fp_bn_train_fused(_f32(z2d), _f32(residual), _f32(y2d), M, Cn, _f32(gamma), _f32(beta), eps, momentum, _f32(running_mean),
-                                     _f32(running_var), _chk(nbt), _f32(save_mean), _f32(save_invstd), _f32(scale), _f32(shift),
-                                     int(bool(relu)), ws.data_ptr(), ws.numel(), sync.data_ptr(), stream()), "fp_bn_train_fused")
-    return y2d
-
-
 def bn_eval_coeffs(gamma, beta, rm, rv, scale, shift, eps=1e-5):
     _lib.check(_lib.load().fp_bn_eval_coeffs(_f32(gamma), _f32(beta), _f32(rm), _f32(rv), eps, gamma.numel(), _f32(scale), _f32(shift),
                                              stream()), "fp_bn_eval_coeffs")
@@ -655,20 +609,6 @@ def bn_bwd(dy2d, relu_out, z2d, save_mean, save_invstd, gamma, dz2d, dgamma, dbe
     lib = _lib.load()
     M, Cn = z2d.shape
     ws = workspace(lib.fp_bn_workspace(M, Cn), z2d.device)
-    if _BN_FUSED:
-        sync = grid_sync_block(z2d.device)
-        _sink(amax_out)
-        _lib.check(lib.fp_bn_bwd_fused(_f32(dy2d), _f32(relu_out), _f32(z2d), _f32(save_mean), _f32(save_invstd), _f32(gamma), _f32(dz2d),
-                                       _f32(g_out), _f32(dgamma), _f32(dbeta), int(bool(accumulate)), M, Cn, ws.data_ptr(), ws.numel(),
-                                       sync.data_ptr(), stream()), "fp_bn_bwd_fused")
-        return dz2d
-    if _BN_TICKET:
-        sync = grid_sync_block(z2d.device)
-        _sink(amax_out)
-        _lib.check(lib.fp_bn_bwd_ticket(_f32(dy2d), _f32(relu_out), _f32(z2d), _f32(save_mean), _f32(save_invstd), _f32(gamma), _f32(dz2d),
-                                        _f32(g_out), _f32(dgamma), _f32(dbeta), int(bool(accumulate)), M, Cn, ws.data_ptr(), ws.numel(),
-                                        sync.data_ptr(), stream()), "fp_bn_bwd_ticket")
-        return dz2d
     _sink(amax_out)
     _lib.check(lib.fp_bn_bwd(_f32(dy2d), _f32(relu_out), _f32(z2d), _f32(save_mean), _f32(save_invstd), _f32(gamma), _f32(dz2d),
                              _f32(g_out), _f32(dgamma), _f32(dbeta), int(bool(accumulate)), M, Cn, ws.data_ptr(), ws.numel(), stream()),

@@ -306,27 +306,6 @@ int fp_conv_igemm_hp(const fp_conv_desc* d, const float* src, const void* wpacke
                      const float* addend_mask, const float* actsrc, float* y, void* workspace, int64_t workspace_bytes,
                      const uint32_t* amax_src, const uint32_t* amax_w, fp_stream_t stream);
 
-/* Fused train-mode BatchNorm: statistics, their combination and the normalisation (fp_bn_train_stats + fp_bn_apply; fp_bn_bwd's three
- * stages) in ONE launch with an in-kernel grid dependency -- every workgroup is resident, the last one to arrive combines the partials
- * in a fixed order (results independent of arrival order).  `sync`: fp_grid_sync_words() uint32 owned by ONE stream, zeroed once by
- * the caller; the kernels re-arm it.  Same outputs and amax sink as the unfused entry points. */
-int32_t fp_grid_sync_words(void);
-int fp_bn_train_fused(const float* z, const float* residual, float* y, int64_t M, int32_t C, const float* gamma, const float* beta,
-                      float eps, float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked,
-                      float* save_mean, float* save_invstd, float* scale, float* shift, int32_t relu, void* workspace,
-                      int64_t workspace_bytes, uint32_t* sync, fp_stream_t stream);
-int fp_bn_bwd_fused(const float* dy, const float* relu_out, const float* z, const float* save_mean, const float* save_invstd,
-                    const float* gamma, float* dz, float* g_out, float* dgamma, float* dbeta, int accumulate, int64_t M, int32_t C,
-                    void* workspace, int64_t workspace_bytes, uint32_t* sync, fp_stream_t stream);
-/* Ticket forms (round 3): the statistics (backward: reduction) kernel AND the per-channel combination in one launch -- the last workgroup
- * to arrive combines the partials in a fixed order, nobody waits --, the element-wise apply as a second launch: two dependent launches per
- * layer and direction instead of three.  Same outputs as fp_bn_train_stats / fp_bn_bwd; `sync` as above. */
-int fp_bn_train_stats_ticket(const float* z, int64_t M, int32_t C, const float* gamma, const float* beta, float eps, float momentum,
-                             float* running_mean, float* running_var, int64_t* num_batches_tracked, float* save_mean, float* save_invstd,
-                             float* scale, float* shift, void* workspace, int64_t workspace_bytes, uint32_t* sync, fp_stream_t stream);
-int fp_bn_bwd_ticket(const float* dy, const float* relu_out, const float* z, const float* save_mean, const float* save_invstd,
-                     const float* gamma, float* dz, float* g_out, float* dgamma, float* dbeta, int accumulate, int64_t M, int32_t C,
-                     void* workspace, int64_t workspace_bytes, uint32_t* sync, fp_stream_t stream);
 int fp_bn_apply(const float* z, const float* scale, const float* shift, const float* residual, float* y, int64_t M,
                 int32_t C, int32_t relu, fp_stream_t stream);
 /* backward: g = dy * (relu_out > 0 if relu_out) ; dgamma (+)= sum g*xhat ; dbeta (+)= sum g ;
