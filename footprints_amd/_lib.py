@@ -127,6 +127,8 @@ SIGNATURES = {
     "fp_bn_train_stats": (C.c_int, [_P, _I64, _I32, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
     "fp_bn_stats_out_next": (C.c_int, [_P, _I64, _P]),
     "fp_bn_train_stats_partials": (C.c_int, [_P, _I32, _I32, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "fp_bn_bwd_out_next": (C.c_int, [_P, _I64, _P, _P, _P, _P]),
+    "fp_bn_bwd_partials": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int, _I64, _I32, _P, _I32, _P, _P]),
     "fp_bn_eval_coeffs": (C.c_int, [_P, _P, _P, _P, _F, _I32, _P, _P, _P]),
     "fp_conv_igemm_hp_supported": (C.c_int, [_DESC]),
     "fp_conv_igemm_hp": (C.c_int, [_DESC, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P]),

@@ -387,6 +387,22 @@ extern "C" int fp_bn_bwd(const float* dy, const float* relu_out, const float* z,
   return fp_check_launch("fp_bn_bwd");
 }
 
+// fp_bn_bwd's second and third launch on partial sums (sum g, sum g * xhat) that a data-gradient epilogue already wrote (fp_bn_bwd_out_next):
+// `g` is the masked gradient as stored by that launch (no relu_out here), `part` = [nblk][C][2], `coef` = 2 C floats of scratch
+extern "C" int fp_bn_bwd_partials(const float* g, const float* z, const float* save_mean, const float* save_invstd, const float* gamma,
+                                  float* dz, float* dgamma, float* dbeta, int accumulate, int64_t M, int32_t C, const float* part,
+                                  int32_t nblk, float* coef, fp_stream_t stream) {
+  unsigned* amax_out = fp_take_amax_out();     // consumed first: an argument error below must not leave the sink armed
+  FP_REQUIRE(g && z && save_mean && save_invstd && gamma && dz && part && coef, "fp_bn_bwd_partials: null pointer");
+  FP_REQUIRE(bn_c_ok(C) && M > 0 && M < ((int64_t)1 << 31) && nblk > 0, "fp_bn_bwd_partials: unsupported C=%d / nblk=%d", C, nblk);
+  fp_launch(bn_bwd_final_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, part, (int)nblk, C, 1.f / (float)M, coef, dgamma,
+            dbeta, accumulate);
+  const size_t total4 = (size_t)M * (C / 4);
+  fp_launch(bn_bwd_apply_kernel, dim3(ew_grid(total4, 8192)), dim3(256), 0, (hipStream_t)stream, g, (const float*)nullptr, z, save_mean,
+            save_invstd, gamma, (const float*)coef, dz, (float*)nullptr, total4, C / 4, amax_out);
+  return fp_check_launch("fp_bn_bwd_partials");
+}
+
 extern "C" int fp_maxpool_fwd(const float* x, float* y, uint8_t* argmax, int32_t N, int32_t H, int32_t W, int32_t C,
                               fp_stream_t stream) {
   unsigned* amax_out = fp_take_amax_out();     // consumed first: an argument error below must not leave the sink armed

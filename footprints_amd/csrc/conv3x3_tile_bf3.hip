@@ -62,6 +62,12 @@ struct Tile3Args {
   const unsigned* amax_w;
   unsigned* amax_out;
   float* bn_part;     // forward conv in front of a train-mode BatchNorm (unsplit, no epilogue options): Welford partials [pixel tile][Nout][3], or null
+  // data gradient whose output is the masked gradient g entering a train-mode BatchNorm's backward (unsplit grids): partial sums
+  // [pixel tile][Nout][2] = (sum g, sum g * xhat), xhat = (z - mean) * invstd of THAT BatchNorm -- or null (fp_bn_bwd_out_next)
+  float* bnb_part;
+  const float* bnb_z;
+  const float* bnb_mean;
+  const float* bnb_invstd;
 };
 
 struct FoldTap { int wtap, ao, bo, rsel, csel; };
@@ -450,6 +456,17 @@ conv3x3_tile_bf3_kernel(const Tile3Args a) {
       const int n = e.n0 + (wn * TN + j) * 32 + idx;
       bias_j[j] = ((epi & FP_EPI_BIAS) && n < a.Nout) ? a.bias[n] : 0.f;
     }
+    // BatchNorm-backward reduction out of the data gradient's epilogue (wave-uniform; compile time for the forward variants): what this
+    // workgroup stores IS g = dy * (relu_out > 0) of the BatchNorm below it, so its per-channel sums need no pass of their own
+    const bool bnb = FLIP && !FOLD && a.bnb_part != nullptr;     // (encoder data gradients: zero padding; the reflection-fold variants belong to the decoders)
+    float bs1[TN], bs2[TN], bmu[TN], bis[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = min(e.n0 + (wn * TN + j) * 32 + idx, a.Nout - 1);
+      bs1[j] = bs2[j] = 0.f;
+      bmu[j] = bnb ? a.bnb_mean[n] : 0.f;
+      bis[j] = bnb ? a.bnb_invstd[n] : 0.f;
+    }
     // accumulator register r of M block i -> tile pixel
     auto acc_pixel = [&](int i, int r, int& py, int& px) {
       if (TW == 16) {              // pt = blk*32 + (r&3) + 8*(r>>2) + 4h  =>  row = 2*blk + (r>>3), column from constants and h
@@ -488,6 +505,11 @@ conv3x3_tile_bf3_kernel(const Tile3Args a) {
       if (epi & FP_EPI_ACCUM) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) yo[k] = a.y[off[k]];
+      }
+      float zb[8];
+      if (bnb) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) zb[k] = a.bnb_z[off[k]];
       }
       // one wave-uniform branch per flag around an 8-element body (per-element tests get if-converted into selects that execute
       // every option for every element)
@@ -528,6 +550,14 @@ conv3x3_tile_bf3_kernel(const Tile3Args a) {
           dst[off[k]] = v[k];
           if (HP) ymax = fmaxf(ymax, fabsf(v[k]));
         }
+      if (bnb) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float gk = (FULL || ok[k]) ? v[k] : 0.f;
+          bs1[j] += gk;
+          bs2[j] += gk * ((zb[k] - bmu[j]) * bis[j]);       // the arithmetic form of bn_bwd_reduce_kernel
+        }
+      }
     };
     // (before the stores: behind them the accumulators would have to outlive the whole store loop, and its address arithmetic spilled)
     if (!FLIP && a.bn_part) {                          // (compile time for the data-gradient variants: their register budgets are unchanged)
@@ -606,6 +636,33 @@ conv3x3_tile_bf3_kernel(const Tile3Args a) {
           rows8(std::false_type{}, i, j, n, bias_j[j], 1);
         }
       }
+    if (bnb) {       // lane -> half-wave pair -> the WM waves that share the channel (through LDS), fixed order -> part[pixel tile][n]
+      float* const st = reinterpret_cast<float*>(lds) + 16;          // [wave][TN * 32][2] floats
+      __syncthreads();                                               // every wave is done with the halo buffers
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const float t1 = bs1[j] + __shfl_xor(bs1[j], 32, 64), t2 = bs2[j] + __shfl_xor(bs2[j], 32, 64);
+        if (h == 0) {
+          float* q = st + ((wave * TN + j) * 32 + idx) * 2;
+          q[0] = t1; q[1] = t2;
+        }
+      }
+      __syncthreads();
+      if (t < BN) {
+        const int cw = t / (TN * 32), cj = (t / 32) % TN, ci = t & 31;   // wn, j, lane of the channel
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < WM; ++k) {
+          const float* qk = st + (((k * WN + cw) * TN + cj) * 32 + ci) * 2;
+          t1 += qk[0]; t2 += qk[1];
+        }
+        const int n = e.n0 + t;
+        if (n < a.Nout) {
+          float* o = a.bnb_part + ((size_t)((e.n_img * a.tilesY + e.tile_y) * a.tilesX + e.tile_x) * a.Nout + n) * 2;
+          o[0] = t1; o[1] = t2;
+        }
+      }
+    }
   };
 
   // ---- the tile loop ---------------------------------------------------------------------------------------------------------
@@ -770,6 +827,7 @@ int run_tile3(const char* who, const fp_conv_desc* d, const float* src, const fl
   FP_REQUIRE((int64_t)d->N * d->IH * d->IW * (d->C0 + d->C1) * 4 < ((int64_t)1 << 31), "fp_conv3x3_bf3 / fp_conv3x3_hp: input larger than 2^31 bytes");
   Tile3Args a;
   a.bn_part = nullptr;
+  a.bnb_part = nullptr; a.bnb_z = a.bnb_mean = a.bnb_invstd = nullptr;
   const bool up2 = d->gather == FP_GATHER_FWD_REFLECT_UP2;
   FP_REQUIRE(!up2 || d->C1 == 0 || src1, "fp_conv3x3_bf3 / fp_conv3x3_hp: the concat gather needs the skip tensor (src1)");
   a.src_lo = up2 ? src : nullptr; a.Clo = up2 ? d->C0 : 0;
@@ -789,9 +847,15 @@ int run_tile3(const char* who, const fp_conv_desc* d, const float* src, const fl
     // BatchNorm-statistics sink (fp_bn_stats_out_next): only the plain forward form on an unsplit grid emits -- its stored value is the
     // accumulator itself -- everything else reports 0 blocks and the caller runs fp_bn_train_stats as before
     const int64_t blocks = (int64_t)d->N * p.tilesY * p.tilesX;
-    const bool emit = bn_sink.part && p.SK <= 1 && !flip && (d->epi & ~(unsigned)FP_EPI_BF16X2) == 0 && d->act == 0 &&
-                      blocks * d->Nout * 3 <= bn_sink.cap_floats;
-    if (emit) a.bn_part = bn_sink.part;
+    bool emit;
+    if (bn_sink.z) {       // backward form (fp_bn_bwd_out_next): a data gradient on an unsplit grid that overwrites its output
+      emit = bn_sink.part && p.SK <= 1 && flip && !fold && !(d->epi & FP_EPI_ACCUM) && d->act == 0 && blocks * d->Nout * 2 <= bn_sink.cap_floats;
+      if (emit) { a.bnb_part = bn_sink.part; a.bnb_z = bn_sink.z; a.bnb_mean = bn_sink.mean; a.bnb_invstd = bn_sink.invstd; }
+    } else {
+      emit = bn_sink.part && p.SK <= 1 && !flip && (d->epi & ~(unsigned)FP_EPI_BF16X2) == 0 && d->act == 0 &&
+             blocks * d->Nout * 3 <= bn_sink.cap_floats;
+      if (emit) a.bn_part = bn_sink.part;
+    }
     if (bn_sink.nblk_out) *bn_sink.nblk_out = emit ? (int32_t)blocks : 0;
   }
   const int planes = hp ? 4 : 6;                    // bytes of packed weight per element

@@ -255,6 +255,9 @@ struct FpBnSink {
   float* part;
   int64_t cap_floats;
   int32_t* nblk_out;
+  const float* z;        // backward form (fp_bn_bwd_out_next): the BatchNorm's input and its saved statistics; null = forward statistics
+  const float* mean;
+  const float* invstd;
 };
 FpBnSink fp_take_bn_sink();       // api.cpp
 unsigned* fp_take_amax_out();     // api.cpp: the slot registered by fp_amax_out_next for this thread's next publishing launch (then cleared)

@@ -1069,6 +1069,15 @@ class Engine:
                 feat_of_block[i] = fi
                 fi += 1
         dnext = None       # gradient wrt this block's output coming from the next block (same layer)
+        dnext_part = None  # (partials, blocks) when `dnext` already IS g = dout * (out > 0) and its producer wrote bn2's backward sums
+        bwd_epi = ops._BN_BWD_EPI and _HP_TILE and not ops._bf16x2
+
+        def bnb_arm(name, h_, w_, C_, z, rec):
+            """arm the BatchNorm-backward sink for the next tile data gradient at (h_, w_, C_): partial sums per pixel tile (8 x 16 or 6 x 20
+            pixels, bounded by 6 x 16-pixel ones) and channel"""
+            cap = N * ((h_ + 5) // 6) * ((w_ + 15) // 16) * C_ * 2
+            part = buf(name, (max(cap, 1),))
+            return part, ops.bn_bwd_out_next(part, z.view(-1, C_), rec.mean, rec.invstd)
         for i in range(nblk - 1, -1, -1):
             blk, B = self.blocks[i], S["blocks"][i]
             h, w, hin, win = B["h"], B["w"], B["hin"], B["win"]
@@ -1076,9 +1085,17 @@ class Engine:
             M = N * h * w
             dout = dF[feat_of_block[i]] if i in feat_of_block else dnext
             dz2 = buf("g.dz2.%d" % i, (N, h, w, C))      # per-block: read later by the side-stream wgrad
-            g = buf("g.g", (N, h, w, C))
-            ops.bn_bwd(dout.view(M, C), B["out"].view(M, C), B["z2"].view(M, C), blk.bn2.mean, blk.bn2.invstd, blk.bn2.bn.weight.data,
-                       dz2.view(M, C), blk.bn2.gg, blk.bn2.gb, g_out=g.view(M, C), accumulate=accumulate, amax_out=self._sink_slot(dz2))
+            if i not in feat_of_block and dnext_part is not None:
+                # the next block's conv1 data gradient stored g = (its sum + the residual gradient) * (out > 0) and the two per-channel sums
+                # of this BatchNorm's backward with it: no reduction pass, no separate g
+                g = dout
+                ops.bn_bwd_partials(g.view(M, C), B["z2"].view(M, C), blk.bn2.mean, blk.bn2.invstd, blk.bn2.bn.weight.data, dz2.view(M, C),
+                                    blk.bn2.gg, blk.bn2.gb, dnext_part[0], dnext_part[1], accumulate=accumulate, amax_out=self._sink_slot(dz2))
+            else:
+                g = buf("g.g", (N, h, w, C))
+                ops.bn_bwd(dout.view(M, C), B["out"].view(M, C), B["z2"].view(M, C), blk.bn2.mean, blk.bn2.invstd, blk.bn2.bn.weight.data,
+                           dz2.view(M, C), blk.bn2.gg, blk.bn2.gb, g_out=g.view(M, C), accumulate=accumulate, amax_out=self._sink_slot(dz2))
+            dnext_part = None
             self._sink_done(dz2)
             ev_ds = None
             if blk.ds is not None and self.concurrent and _DS_AUX:
@@ -1099,11 +1116,24 @@ class Engine:
                     ev_ds = self._record(self.aux)
             self._wgrad(blk.c2, L.GATHER_FWD_ZERO, B["a1"], None, dz2, N, h, w, h, w, C, 0, accumulate, side)
             da1 = buf("g.da1", (N, h, w, C))
-            self._cv(ops.make_desc(N, h, w, h, w, C, 0, C, 3, 1, 1, L.GATHER_DGRAD_ZERO), dz2, blk.c2.wpd, blk.c2.wpd3, da1,
-                     hp=(blk.c2.hp_d, blk.c2.wslot))
             dz1 = buf("g.dz1.%d" % i, (N, h, w, C))
-            ops.bn_bwd(da1.view(M, C), B["a1"].view(M, C), B["z1"].view(M, C), blk.bn1.mean, blk.bn1.invstd, blk.bn1.bn.weight.data,
-                       dz1.view(M, C), blk.bn1.gg, blk.bn1.gb, accumulate=accumulate, amax_out=self._sink_slot(dz1))
+            d2 = ops.make_desc(N, h, w, h, w, C, 0, C, 3, 1, 1, L.GATHER_DGRAD_ZERO)
+            if bwd_epi and blk.c2.hp_d is not None and ops.conv3x3_bf3_supported(d2):
+                # conv2's data gradient applies bn1's ReLU mask itself (da1 = gradient * (a1 > 0)) and emits bn1's backward sums
+                d2.epi = L.EPI_ACTGRAD_RELU
+                part, cell = bnb_arm("bnb.part1", h, w, C, B["z1"], blk.bn1)
+                self._cv(d2, dz2, blk.c2.wpd, blk.c2.wpd3, da1, hp=(blk.c2.hp_d, blk.c2.wslot), actsrc=B["a1"])
+                if cell.value > 0:
+                    ops.bn_bwd_partials(da1.view(M, C), B["z1"].view(M, C), blk.bn1.mean, blk.bn1.invstd, blk.bn1.bn.weight.data,
+                                        dz1.view(M, C), blk.bn1.gg, blk.bn1.gb, part, cell.value, accumulate=accumulate,
+                                        amax_out=self._sink_slot(dz1))
+                else:                                   # split grid: the mask is applied, the sums are not there
+                    ops.bn_bwd(da1.view(M, C), None, B["z1"].view(M, C), blk.bn1.mean, blk.bn1.invstd, blk.bn1.bn.weight.data,
+                               dz1.view(M, C), blk.bn1.gg, blk.bn1.gb, accumulate=accumulate, amax_out=self._sink_slot(dz1))
+            else:
+                self._cv(d2, dz2, blk.c2.wpd, blk.c2.wpd3, da1, hp=(blk.c2.hp_d, blk.c2.wslot))
+                ops.bn_bwd(da1.view(M, C), B["a1"].view(M, C), B["z1"].view(M, C), blk.bn1.mean, blk.bn1.invstd, blk.bn1.bn.weight.data,
+                           dz1.view(M, C), blk.bn1.gg, blk.bn1.gb, accumulate=accumulate, amax_out=self._sink_slot(dz1))
             self._sink_done(dz1)
             self._wgrad(blk.c1, L.GATHER_FWD_ZERO, B["x"], None, dz1, N, h, w, hin, win, Cin, 0, accumulate, side)
             first_of_layer = (i == 0) or blk.stride == 2
@@ -1134,7 +1164,19 @@ class Engine:
                 dnext = None
             else:
                 dx = buf("g.dx%d" % (i & 1), (N, hin, win, Cin))
-                self._cv(dgd, dz1, blk.c1.wpd, blk.c1.wpd3, dx, hp=(blk.c1.hp_d, blk.c1.wslot), addend=g)
+                if bwd_epi and blk.c1.hp_d is not None and ops.conv3x3_bf3_supported(dgd):
+                    # this block's input is the previous block's output (after its ReLU): conv1's data gradient + the residual gradient,
+                    # masked by (input > 0), IS the g of the previous block's bn2 -- stored as such, with that BatchNorm's backward sums
+                    Bp, blkp = S["blocks"][i - 1], self.blocks[i - 1]
+                    dgd.epi = L.EPI_ACTGRAD_RELU
+                    part, cell = bnb_arm("bnb.part2", hin, win, Cin, Bp["z2"], blkp.bn2)
+                    self._cv(dgd, dz1, blk.c1.wpd, blk.c1.wpd3, dx, hp=(blk.c1.hp_d, blk.c1.wslot), addend=g, actsrc=B["x"])
+                    if cell.value > 0:
+                        dnext_part = (part, cell.value)
+                    else:                               # masked, no sums: the regular backward below must not mask again -- it would not
+                        dnext_part = None               # change anything (g * (out > 0) is idempotent), so it simply runs as before
+                else:
+                    self._cv(dgd, dz1, blk.c1.wpd, blk.c1.wpd3, dx, hp=(blk.c1.hp_d, blk.c1.wslot), addend=g)
                 dnext = dx
             if self.debug_hook is not None:
                 self.debug_hook(i, dict(dout=dout, g=g, dz2=dz2, da1=da1, dz1=dz1, dnext=dnext, B=B))

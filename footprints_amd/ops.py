@@ -585,6 +585,32 @@ def bn_train_stats_partials(part, nblk, Cn, gamma, beta, running_mean, running_v
                                                       _f32(scale), _f32(shift), stream()), "fp_bn_train_stats_partials")
 
 
+# the BatchNorm-backward reduction out of the producing data gradient's epilogue (csrc/conv3x3_tile_bf3.hip, fp_bn_bwd_out_next): FP_BN_BWD_EPI=0
+# keeps fp_bn_bwd's own reduction pass
+_BN_BWD_EPI = bool(int(os.environ.get("FP_BN_BWD_EPI", "1")))
+
+
+def bn_bwd_out_next(part, z2d, save_mean, save_invstd):
+    """arm the backward sink for this thread's next tile data-gradient launch; returns the int32 cell it writes its number of partial
+    blocks into (0 = nothing emitted) -- read `.value` after the convolution call"""
+    n = C.c_int32(0)
+    _lib.check(_lib.load().fp_bn_bwd_out_next(_f32(part, "part"), part.numel(), C.addressof(n), _f32(z2d, "z"), _f32(save_mean), _f32(save_invstd)),
+               "fp_bn_bwd_out_next")
+    return n
+
+
+def bn_bwd_partials(g2d, z2d, save_mean, save_invstd, gamma, dz2d, dgamma, dbeta, part, nblk, accumulate=False, amax_out=None):
+    """fp_bn_bwd without its reduction pass: g2d is already masked, `part` holds (sum g, sum g * xhat) per pixel tile and channel"""
+    lib = _lib.load()
+    M, Cn = z2d.shape
+    coef = workspace(lib.fp_bn_workspace(M, Cn), z2d.device)
+    _sink(amax_out)
+    _lib.check(lib.fp_bn_bwd_partials(_f32(g2d), _f32(z2d), _f32(save_mean), _f32(save_invstd), _f32(gamma), _f32(dz2d), _f32(dgamma),
+                                      _f32(dbeta), int(bool(accumulate)), M, Cn, _f32(part), int(nblk), coef.data_ptr(), stream()),
+               "fp_bn_bwd_partials")
+    return dz2d
+
+
 def bn_eval_coeffs(gamma, beta, rm, rv, scale, shift, eps=1e-5):
     _lib.check(_lib.load().fp_bn_eval_coeffs(_f32(gamma), _f32(beta), _f32(rm), _f32(rv), eps, gamma.numel(), _f32(scale), _f32(shift),
                                              stream()), "fp_bn_eval_coeffs")

@@ -289,6 +289,17 @@ int fp_bn_stats_out_next(float* part, int64_t capacity_floats, int32_t* nblk_out
 int fp_bn_train_stats_partials(const float* part, int32_t nblk, int32_t C, const float* gamma, const float* beta, float eps,
                                float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked,
                                float* save_mean, float* save_invstd, float* scale, float* shift, fp_stream_t stream);
+/* The backward counterpart (round 4): fp_bn_bwd_out_next arms the same per-thread sink for the NEXT fp_conv3x3_hp / fp_conv3x3_bf3 launch when
+ * that launch is a data gradient whose stored output IS g = dy * (relu_out > 0) of a train-mode BatchNorm (its ReLU mask applied by the
+ * launch's own FP_EPI_ACTGRAD_RELU epilogue): on an unsplit grid without FP_EPI_ACCUM it also writes part[pixel tile][Nout] = (sum g,
+ * sum g * xhat), xhat = (z - save_mean) * save_invstd, and sets *nblk_out = number of pixel tiles (0 = nothing emitted).
+ * fp_bn_bwd_partials then runs fp_bn_bwd's combination + apply launches on them: fp_bn_bwd's reduction pass over (dy, relu_out, z) and its
+ * launch are gone (the backward of torchvision BatchNorm2d behind footprints/network.py:38-44; coef = 2 C floats of scratch). */
+int fp_bn_bwd_out_next(float* part, int64_t capacity_floats, int32_t* nblk_out, const float* z, const float* save_mean,
+                       const float* save_invstd);
+int fp_bn_bwd_partials(const float* g, const float* z, const float* save_mean, const float* save_invstd, const float* gamma, float* dz,
+                       float* dgamma, float* dbeta, int accumulate, int64_t M, int32_t C, const float* part, int32_t nblk, float* coef,
+                       fp_stream_t stream);
 /* eval mode: scale/shift from running statistics */
 int fp_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                       float eps, int32_t C, float* scale, float* shift, fp_stream_t stream);

@@ -224,6 +224,78 @@ def test_conv3x3_hp_emits_batchnorm_partials(N, H, W, C0, Cout, emits):
     assert relerr(rms[0], rms[1].cpu()) < 1e-6 and relerr(rvs[0], rvs[1].cpu()) < 1e-6 and int(nbt[0]) == int(nbt[1]) == 1
 
 
+@pytest.mark.parametrize("N,H,W,C,emits", [
+    (12, 48, 160, 64, True),             # layer 1: 8 x 16 tiles, 720 workgroups
+    (12, 24, 80, 128, True),             # layer 2 (small-grid WPF variant, two channel tiles)
+    (12, 12, 40, 256, True),             # layer 3: 6 x 20 tiles
+    (10, 21, 45, 64, True),              # ragged tiles on both borders
+    (12, 6, 20, 512, False),             # split-K grid: nothing emitted, the caller falls back to fp_bn_bwd's own reduction
+])
+def test_conv3x3_hp_data_gradient_emits_batchnorm_backward_sums(N, H, W, C, emits):
+    """fp_bn_bwd_out_next: a tile data gradient whose epilogue applies the ReLU mask stores g = (dgrad + residual) * (out > 0) of the
+    BatchNorm below it AND that BatchNorm's backward sums (sum g, sum g * xhat) per pixel tile and channel; fp_bn_bwd_partials turns them into
+    the same dz / dgamma / dbeta as fp_bn_bwd on (dy, relu_out, z) -- against float64 (torchvision BatchNorm2d backward)."""
+    ops, L = _ops()
+    w = rnd((C, C, 3, 3), 701, -0.1, 0.1)                          # the forward conv C -> C whose data gradient is taken
+    gz = rnd((N, C, H, W), 702)                                    # gradient wrt its output
+    resid = rnd((N, C, H, W), 703)                                 # residual-branch gradient added on top (addend)
+    out = rnd((N, C, H, W), 704)                                   # the BatchNorm block's output after ReLU (sign = mask)
+    z = rnd((N, C, H, W), 705) * 1.5 + 0.3                         # the BatchNorm's input
+    gamma = rnd((C,), 706, 0.5, 1.5)
+    # float64 reference: dy = conv_transpose(gz) + resid; g = dy * (out > 0); batch-norm backward on (g, z)
+    xin = torch.zeros((N, C, H, W), dtype=torch.float64, requires_grad=True)
+    F.conv2d(xin, w.double(), None, 1, 1).backward(gz.double())
+    g64 = (xin.grad + resid.double()) * (out > 0).double()
+    zd = z.double()
+    mean, var = zd.mean((0, 2, 3)), zd.var((0, 2, 3), unbiased=False)
+    invstd = 1.0 / torch.sqrt(var + 1e-5)
+    xhat = (zd - mean.view(1, C, 1, 1)) * invstd.view(1, C, 1, 1)
+    s1, s2 = g64.sum((0, 2, 3)), (g64 * xhat).sum((0, 2, 3))
+    M = N * H * W
+    dz64 = gamma.double().view(1, C, 1, 1) * invstd.view(1, C, 1, 1) * (g64 - (s1 / M).view(1, C, 1, 1) - xhat * (s2 / M).view(1, C, 1, 1))
+    # device
+    d = ops.make_desc(N, H, W, H, W, C, 0, C, 3, 1, 1, L.GATHER_DGRAD_ZERO, epi=L.EPI_ACTGRAD_RELU)
+    wp, sw = pack_hp(w, dgrad=True)
+    gzs, zs = nhwc(gz), nhwc(z)
+    mean_d, invstd_d = mean.float().cuda(), invstd.float().cuda()
+    cap = N * ((H + 5) // 6) * ((W + 15) // 16) * C * 2
+    part = torch.full((cap,), float("nan"), device="cuda")
+    gout = torch.empty((N, H, W, C), device="cuda")
+    cell = ops.bn_bwd_out_next(part, zs.view(-1, C), mean_d, invstd_d)
+    so = ops.new_slot()
+    ops.conv3x3_hp(d, gzs, wp, gout, slot_of(gzs), sw, amax_out=so, addend=nhwc(resid), actsrc=nhwc(out))
+    torch.cuda.synchronize()
+    tiles = cell.value
+    assert tiles in ((N * ((H + 7) // 8) * ((W + 15) // 16), N * ((H + 5) // 6) * ((W + 19) // 20)) if emits else (0,))
+    check(nchw(gout), g64, "masked data gradient", 2e-6)
+    assert ops.amax_value(so) == float(gout.abs().max())
+    g2 = torch.empty_like(gout)                                    # the sink is one-shot
+    part_before = part.clone()
+    ops.conv3x3_hp(d, gzs, wp, g2, slot_of(gzs), sw, addend=nhwc(resid), actsrc=nhwc(out))
+    torch.cuda.synchronize()
+    assert torch.equal(gout, g2) and torch.equal(torch.nan_to_num(part, nan=7.0), torch.nan_to_num(part_before, nan=7.0))
+    dz_ref, dg_ref, db_ref = (torch.empty((N, H, W, C), device="cuda"), torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda"))
+    ops.bn_bwd(gout.view(-1, C), None, zs.view(-1, C), mean_d, invstd_d, gamma.cuda(), dz_ref.view(-1, C), dg_ref, db_ref)
+    if tiles == 0:
+        assert bool(torch.isnan(part).all())
+        check(nchw(dz_ref), dz64, "bn backward after the masked data gradient", 3e-6)
+        return
+    used = tiles * C * 2
+    assert not bool(torch.isnan(part[:used]).any()) and bool(torch.isnan(part[used:]).all())
+    sums = part[:used].view(tiles, C, 2).double().sum(0).cpu()
+    assert relerr(sums[:, 0], s1) < 2e-6 and relerr(sums[:, 1], s2) < 2e-6
+    dz, dg, db = torch.empty((N, H, W, C), device="cuda"), torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    sz = ops.new_slot()
+    ops.bn_bwd_partials(gout.view(-1, C), zs.view(-1, C), mean_d, invstd_d, gamma.cuda(), dz.view(-1, C), dg, db, part, tiles, amax_out=sz)
+    check(nchw(dz), dz64, "bn backward from the epilogue's sums", 3e-6)
+    check(nchw(dz_ref), dz64, "bn backward, own reduction", 3e-6)
+    assert relerr(dg, s2) < 2e-6 and relerr(db, s1) < 2e-6 and relerr(dg_ref, s2) < 2e-6 and relerr(db_ref, s1) < 2e-6
+    assert ops.amax_value(sz) == float(dz.abs().max())
+    dg2, db2 = dg.clone(), db.clone()                               # accumulate = True adds on top
+    ops.bn_bwd_partials(gout.view(-1, C), zs.view(-1, C), mean_d, invstd_d, gamma.cuda(), dz.view(-1, C), dg2, db2, part, tiles, accumulate=True)
+    assert relerr(dg2, 2 * s2) < 2e-6 and relerr(db2, 2 * s1) < 2e-6
+
+
 @pytest.mark.parametrize("N,h,w,C0,C1,Cout", [(12, 6, 20, 256, 256, 256), (8, 24, 32, 32, 16, 32), (16, 16, 32, 32, 0, 64), (12, 4, 24, 64, 64, 96)])
 def test_conv3x3_hp_up2_concat_gather(N, h, w, C0, C1, Cout):
     """cat[nearest_x2(low), skip] inside the tile kernel: the two sources share one scale (the larger amax); sources of very different size"""
