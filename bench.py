@@ -296,17 +296,34 @@ class Instrument:
             setattr(self.ops, n, f)
 
 
+def kernel_source_digest():
+    """sha256 over the sources of the dominant kernel (csrc/conv3x3_tile_bf3.hip + fp_common.h): ties a committed counter file to the build
+    it was measured on without needing .git (the GPU box receives a snapshot without it)"""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("conv3x3_tile_bf3.hip", "fp_common.h"):
+        with open(os.path.join(ROOT, "footprints_amd", "csrc", name), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def load_traffic(workload, entry_point):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (scripts/pmc_hbm.sh -> profiles/), or None"""
-    path = os.path.join(ROOT, "profiles", "round3_pmc_hbm_%s.json" % workload)
-    if not os.path.exists(path):
-        path = os.path.join(ROOT, "profiles", "round2_pmc_hbm_%s.json" % workload)
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (scripts/pmc_hbm_session.sh -> profiles/round4_pmc_hbm_*.json;
+    the counters need rocprofv3 around the process, so they cannot be collected inside this one), or None.  The file records the digest of
+    the kernel source it was measured on: a file from another build is NOT attached (its figure would describe a different kernel)."""
+    path = os.path.join(ROOT, "profiles", "round4_pmc_hbm_%s.json" % workload)
     try:
         with open(path) as fh:
-            t = json.load(fh).get(entry_point)
+            doc = json.load(fh)
     except (OSError, ValueError):
-        return None
-    return t
+        return None, "no counter file for this round (profiles/round4_pmc_hbm_%s.json)" % workload
+    t = doc.get(entry_point)
+    if not t:
+        return None, "counter file has no entry for " + entry_point
+    have, want = doc.get("kernel_source_sha16"), kernel_source_digest()
+    if have != want:
+        return None, "counter file was measured on another build of the kernel (source digest %s, this tree %s): not attached" % (have, want)
+    return t, None
 
 
 def _pick_threads():
@@ -352,15 +369,17 @@ def cpu_baseline():
         f0 = time.time()
         R.footprint_network(batch["image"], tr.P, tr.B, training=False)
         fwd_ms_img = (time.time() - f0) / B * 1e3
-    torch.set_num_threads(1)
+    torch.set_num_threads(1)                          # the shipped trainer's own setting (training/train.py:12-14), at the line's batch size
+    tr.step(batch)
     t1 = time.time()
-    tr.step(R.make_batch(1, H, W, tag="bench.warm"))
+    tr.step(batch)
     dt1 = time.time() - t1
     torch.set_num_threads(cores)
     return {"value": round(B / dt, 4), "unit": "img/s", "cores": cores, "kind": "port",
             "eval_fwd_ms_per_img": round(fwd_ms_img, 2),
-            "single_thread": {"value": round(1.0 / dt1, 4), "unit": "img/s", "cores": 1,
-                              "sample": "1 full train step at batch 1 with torch.set_num_threads(1), the reference trainer's own setting"},
+            "single_thread": {"value": round(B / dt1, 4), "unit": "img/s", "cores": 1, "s_per_step": round(dt1, 2),
+                              "sample": "1 timed full train step at batch %d after 1 warm-up step with torch.set_num_threads(1), the reference "
+                                        "trainer's own setting (BASELINE.md section 4)" % B},
             "sample": "mean of 3 timed full train steps (fwd+loss+bwd+Adam) of the CPU oracle at %dx%d, batch %d (the GPU line's workload and "
                       "batch size) after 1 warm-up step at the same shape, then 1 timed eval-mode forward of the same batch; "
                       "torch.set_num_threads(%d) = fastest of {8,16,32,64,%d} on this host (%d effective cores)" % (H, W, B, cores, eff, eff),
@@ -420,8 +439,8 @@ def main():
     global B, H, W
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)      # >= 50 timed steps after >= 10 warm-up steps
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="kitti", help="kitti = BASELINE configs[2] (the metric's config); "
                     "matterport = configs[4] (512x640 bs=4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -689,10 +708,13 @@ def main():
                     g["achieved_kernel_only"] = round(ex_gflop_step / k_ms, 1) if k_ms > 0 else 0.0      # GFLOP / ms = TFLOP/s
                     g["frac_kernel_only"] = round(g["achieved_kernel_only"] / g["peak"], 4)
             dom = groups[0]
-            tr = load_traffic(args.workload, dom["entry_point"])
+            tr, tr_why = load_traffic(args.workload, dom["entry_point"])
             ach = dom.get("achieved_kernel_only", dom["achieved"])
+            tr_bytes = (tr["fetch_bytes_per_launch"] + tr["write_bytes_per_launch"]) if tr else None
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": dom["peak"], "unit": "TFLOP/s", "frac": round(ach / dom["peak"], 4),
-                               "traffic": tr,
+                               "traffic": tr_bytes,                 # HBM bytes per launch (read + write) from the PMC passes, or null
+                               "traffic_ratio": round(tr_bytes / (dom["algorithmic_mb_per_launch"] * 1e6), 3) if tr_bytes else None,
+                               "traffic_detail": tr if tr else {"attached": False, "why": tr_why},
                                "kernel": dom["kernel"], "entry_point": "fp_" + dom["entry_point"], "mfma": dom["mfma"],
                                "launches_per_step": dom["launches_per_step"], "avg_launch_us": dom["avg_launch_us"],
                                "avg_kernel_us": dom.get("avg_kernel_us"), "kernel_launches_per_step": dom.get("kernel_launches_per_step"),
@@ -726,9 +748,16 @@ def main():
             out["shared_gpu"] = {"gpus_visible": have, "note": "fewer GPUs than ranks: the ranks share them and exchange gradients over gloo -- a "
                                                                "functional dry run of the launch path, NOT a performance number"}
         if step.reducer is not None:
+            comm = step.reducer.comm
+            ar_rows = [r for r in (ktable_conc or []) if r["kernel"].startswith("rccl_allreduce")]
             out["config"]["gradient_exchange"] = {"transport": step.reducer.transport, "buckets": len(step.reducer.buckets),
                                                   "overlap_with_backward": bool(step.reducer.overlap),
-                                                  "in_launch_plan": bool(step.reducer.plan_recordable and step.use_plan)}
+                                                  "in_launch_plan": bool(step.reducer.plan_recordable and step.use_plan),
+                                                  # from the communicator itself (ncclCommCount), not from WORLD_SIZE
+                                                  "rccl_ranks": comm.count() if (comm is not None and hasattr(comm, "count")) else 0,
+                                                  "allreduce_us": [{"bucket": r["kernel"], "per_step": r["launches_per_step"], "avg_us": r["avg_us"]}
+                                                                   for r in ar_rows]}
+            out["rccl_ranks"] = out["config"]["gradient_exchange"]["rccl_ranks"]
         if world == 1 and not args.force_dist and not args.no_exact_split:
             del step, mm                                               # free this process's arena before the child builds its own
             torch.cuda.empty_cache()

@@ -42,6 +42,7 @@ SIGNATURES = {
     "fp_comm_unique_id": (C.c_int, [_P, _I32]),
     "fp_comm_init": (C.c_int, [_P, _I32, _I32, C.POINTER(C.c_void_p)]),
     "fp_comm_version": (_I32, []),
+    "fp_comm_count": (_I32, [_P]),
     "fp_comm_allreduce_async": (C.c_int, [_P, _P, _I64, _P]),
     "fp_comm_broadcast": (C.c_int, [_P, _P, _I64, _I32, _P]),
     "fp_comm_wait": (C.c_int, [_P, _P, _P]),

@@ -11,16 +11,32 @@
 // link-time dependency on it and single-GPU users never load it.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <string.h>
 
 #include "footprints_hip.h"
+
+// The handful of NCCL / RCCL ABI items this file uses, declared here instead of through <rccl/rccl.h>: the library is resolved at run time,
+// so a box without the RCCL development headers can still BUILD libfootprints_hip.so.  Values are the public NCCL ABI.
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef int ncclResult_t;
+typedef int ncclDataType_t;
+typedef int ncclRedOp_t;
+}
+static constexpr ncclResult_t ncclSuccess = 0;
+static constexpr ncclDataType_t ncclFloat = 7;      // ncclFloat32
+static constexpr ncclRedOp_t ncclSum = 0;
 
 int fp_set_error(int code, const char* fmt, ...);
 bool fp_plan_recording();
 void fp_plan_push_allreduce(void* comm, float* buf, int64_t count, hipStream_t stream);
 void fp_plan_mark_failed();
+bool fp_ktime_active();                                             // plan.cpp: bench.py's per-kernel event timing is collecting
+hipEvent_t fp_ktime_open(hipStream_t stream);
+void fp_ktime_close(const char* name, hipStream_t stream, hipEvent_t opened);
 
 namespace {
 
@@ -33,6 +49,7 @@ struct Rccl {
   ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   ncclResult_t (*GetVersion)(int*) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
 };
 Rccl g_rccl;
 
@@ -60,6 +77,7 @@ int load_rccl() {
   *(void**)&r.Broadcast = dlsym(h, "ncclBroadcast");
   *(void**)&r.GetErrorString = dlsym(h, "ncclGetErrorString");
   *(void**)&r.GetVersion = dlsym(h, "ncclGetVersion");
+  *(void**)&r.CommCount = dlsym(h, "ncclCommCount");
   if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce || !r.Broadcast || !r.GetErrorString)
     return fp_set_error(FP_EINVAL, "fp_comm: librccl.so lacks an expected symbol");
   g_rccl = r;
@@ -75,8 +93,24 @@ int nccl_fail(const char* what, ncclResult_t e) {
 // used by fp_plan_replay (plan.cpp): the collective of a recorded node
 int fp_comm_allreduce_raw(void* comm_, float* buf, int64_t count, hipStream_t stream) {
   Comm* c = (Comm*)comm_;
+  const bool timed = fp_ktime_active();                // bench.py: the collective's duration on its stream, one row per bucket size
+  hipEvent_t opened = timed ? fp_ktime_open(stream) : nullptr;
   const ncclResult_t e = g_rccl.AllReduce(buf, buf, (size_t)count, ncclFloat, ncclSum, c->comm, stream);
+  if (timed) {
+    char name[96];
+    snprintf(name, sizeof(name), "rccl_allreduce(%lld floats, %d ranks)", (long long)count, c->world);
+    fp_ktime_close(name, stream, opened);
+  }
   return e == ncclSuccess ? FP_OK : nccl_fail("ncclAllReduce", e);
+}
+
+// ranks of the communicator as RCCL itself counts them (ncclCommCount), or the world it was created with when the symbol is missing
+extern "C" int32_t fp_comm_count(void* comm) {
+  Comm* c = (Comm*)comm;
+  if (!c) return 0;
+  int n = 0;
+  if (g_rccl.CommCount && g_rccl.CommCount(c->comm, &n) == ncclSuccess) return (int32_t)n;
+  return (int32_t)c->world;
 }
 
 extern "C" int32_t fp_comm_unique_id_bytes(void) { return (int32_t)sizeof(ncclUniqueId); }

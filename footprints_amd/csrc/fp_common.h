@@ -202,17 +202,27 @@ __device__ __forceinline__ int fp_hp_exponent(unsigned amax_bits, int target) {
   // low-order bits instead -- they are beyond any gradient this network produces)
   return amax_bits ? min(target - ((int)(amax_bits >> 23) - 127), 126) : 0;
 }
-// x * s = h + m (s = 2^k, wave-uniform): the two fp16 planes of four floats in TWO VALU instructions per element --
-// v_fma_mixlo/hi_f16 form fp16(x * s) and fp16(x * s - h) with the fp32 intermediate exact and one rounding each -- bit-identical to
-// the round-3 sequence ldexp, cvt_pk, cvt back, subtract, cvt_pk (4.5 per element; the conversion was ~40 % of the weight gradient's
-// instruction stream and a fifth of the tile kernel's main loop)
+// x * s = h + m (s = 2^k, wave-uniform): the two fp16 planes of four floats -- scale, convert (packed), convert back, subtract, convert
+// (packed): 4 VALU per element.  Round 4 measured the two-instruction form (v_fma_mixlo/hi_f16: fp16(x * s), then fp16(x * s - h) with the
+// fp16 term read in place; bit-identical, -DFP_HP_SPLIT_MIX) SLOWER in the training step: 12.39 vs 12.17 ms, alternating runs, and
+// 97.2 vs 95.9 us on the 64 -> 64 @ 96 x 320 tile convolution -- the mix instructions are VOP3P-encoded like the MFMAs they sit between,
+// and half as many of them cost more than the plain VALU sequence (profiles/round4_notes.md; MI355X_MICROARCH.md prices packed-fp32 VALU
+// beside MFMAs the same way).
 typedef _Float16 fp_f16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void fp_hp_split4(float x0, float x1, float x2, float x3, float s, uint2& hq, uint2& mq) {
   fp_f16x4 h, m;
+#ifndef FP_HP_SPLIT_MIX
+  typedef float fp_f32x4 __attribute__((ext_vector_type(4)));
+  const fp_f32x4 v = {x0 * s, x1 * s, x2 * s, x3 * s};
+  h = __builtin_convertvector(v, fp_f16x4);
+  const fp_f32x4 r1 = v - __builtin_convertvector(h, fp_f32x4);
+  m = __builtin_convertvector(r1, fp_f16x4);
+#else
   h.x = (_Float16)__builtin_fmaf(x0, s, 0.f); h.y = (_Float16)__builtin_fmaf(x1, s, 0.f);
   h.z = (_Float16)__builtin_fmaf(x2, s, 0.f); h.w = (_Float16)__builtin_fmaf(x3, s, 0.f);
   m.x = (_Float16)__builtin_fmaf(x0, s, -(float)h.x); m.y = (_Float16)__builtin_fmaf(x1, s, -(float)h.y);
   m.z = (_Float16)__builtin_fmaf(x2, s, -(float)h.z); m.w = (_Float16)__builtin_fmaf(x3, s, -(float)h.w);
+#endif
   hq = __builtin_bit_cast(uint2, h);
   mq = __builtin_bit_cast(uint2, m);
 }

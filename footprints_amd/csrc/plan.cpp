@@ -83,6 +83,23 @@ hipEvent_t kt_event() {
 }
 }  // namespace
 
+// work that is not one of the library's kernels (the RCCL collectives of comm.cpp): the same event pair, a row named by the caller
+namespace {
+std::map<std::string, int> g_kt_names;                 // the key's address identifies the row (std::map nodes do not move)
+}
+bool fp_ktime_active() { return g_kt_on; }
+hipEvent_t fp_ktime_open(hipStream_t stream) {
+  hipEvent_t a = kt_event();
+  (void)hipEventRecord(a, stream);
+  return a;
+}
+void fp_ktime_close(const char* name, hipStream_t stream, hipEvent_t opened) {
+  hipEvent_t b = kt_event();
+  (void)hipEventRecord(b, stream);
+  auto it = g_kt_names.emplace(std::string(name), 0).first;
+  g_kt.push_back(TimedLaunch{(const void*)&it->first, opened, b});
+}
+
 hipError_t fp_launch_timed(const void* func, dim3 grid, dim3 block, void** args, unsigned shmem, hipStream_t stream) {
   if (!g_kt_on) return hipLaunchKernel(func, grid, block, args, shmem, stream);
   TimedLaunch t{func, kt_event(), kt_event()};
@@ -113,12 +130,18 @@ extern "C" int32_t fp_ktime_end(void) {
     if (hipEventElapsedTime(&ms, t.a, t.b) != hipSuccess) ms = 0.f;
     auto it = index.find(t.func);
     if (it == index.end()) {
-      const char* mangled = hipKernelNameRefByPtr(t.func, nullptr);
-      std::string name = mangled ? mangled : "?";
-      int st = 0;
-      char* dm = mangled ? abi::__cxa_demangle(mangled, nullptr, nullptr, &st) : nullptr;
-      if (dm && st == 0) name = dm;
-      free(dm);
+      std::string name;
+      bool named = false;
+      for (auto& kv : g_kt_names)
+        if ((const void*)&kv.first == t.func) { name = kv.first; named = true; break; }
+      if (!named) {
+        const char* mangled = hipKernelNameRefByPtr(t.func, nullptr);
+        name = mangled ? mangled : "?";
+        int st = 0;
+        char* dm = mangled ? abi::__cxa_demangle(mangled, nullptr, nullptr, &st) : nullptr;
+        if (dm && st == 0) name = dm;
+        free(dm);
+      }
       it = index.emplace(t.func, g_kt_rows.size()).first;
       g_kt_rows.push_back(KRow{name, 0, 0.0});
     }

@@ -100,6 +100,10 @@ class Communicator:
         _lib.check(lib.fp_comm_init(ident[0], self.rank, self.world, C.byref(handle)), "fp_comm_init")
         self.handle = handle
 
+    def count(self):
+        """ranks of the communicator as RCCL itself counts them (ncclCommCount)"""
+        return int(self._lib.load().fp_comm_count(self.handle)) if self.handle else 0
+
     def allreduce(self, t, stream):
         """in-place sum over the ranks, asynchronous on `stream` (a torch stream)"""
         self._lib.check(self._lib.load().fp_comm_allreduce_async(self.handle, t.data_ptr(), t.numel(), stream.cuda_stream),

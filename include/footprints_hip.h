@@ -449,6 +449,7 @@ int32_t fp_comm_unique_id_bytes(void);
 int fp_comm_unique_id(void* id_out, int32_t cap);
 int fp_comm_init(const void* id_bytes, int32_t rank, int32_t world, void** comm_out);
 int32_t fp_comm_version(void); /* ncclGetVersion, or -1 */
+int32_t fp_comm_count(void* comm); /* ranks of the communicator as RCCL counts them (ncclCommCount) */
 int fp_comm_allreduce_async(void* comm, float* buf, int64_t count, fp_stream_t stream);
 int fp_comm_broadcast(void* comm, float* buf, int64_t count, int32_t root, fp_stream_t stream);
 int fp_comm_wait(void* comm, fp_stream_t comm_stream, fp_stream_t consumer);

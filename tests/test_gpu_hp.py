@@ -228,7 +228,7 @@ def test_conv3x3_hp_emits_batchnorm_partials(N, H, W, C0, Cout, emits):
     (12, 48, 160, 64, True),             # layer 1: 8 x 16 tiles, 720 workgroups
     (12, 24, 80, 128, True),             # layer 2 (small-grid WPF variant, two channel tiles)
     (12, 12, 40, 256, True),             # layer 3: 6 x 20 tiles
-    (10, 21, 45, 64, True),              # ragged tiles on both borders
+    (10, 21, 45, 128, True),             # ragged tiles on both borders, two channel tiles (180 workgroups: unsplit)
     (12, 6, 20, 512, False),             # split-K grid: nothing emitted, the caller falls back to fp_bn_bwd's own reduction
 ])
 def test_conv3x3_hp_data_gradient_emits_batchnorm_backward_sums(N, H, W, C, emits):
