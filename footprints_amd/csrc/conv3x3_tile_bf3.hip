@@ -182,7 +182,7 @@ conv3x3_tile_bf3_kernel(const Tile3Args a) {
   auto lane_setup = [&]() {
     int tq = threadIdx.x;
     if (PERSIST) asm volatile("" : "+v"(tq));
-    t = tq; lane = t & 63; wave = t >> 6; idx = lane & 31; h = lane >> 5;
+    t = tq; lane = t & 63; wave = __builtin_amdgcn_readfirstlane(t >> 6); idx = lane & 31; h = lane >> 5;     // the wave index lives in an SGPR
     wm = wave / WN; wn = wave % WN;
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
@@ -476,9 +476,12 @@ conv3x3_tile_bf3_kernel(const Tile3Args a) {
         fp_tile_pixel<TW>((wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, py, px);
       }
     };
+    // byte offsets are 32-bit and unsigned (the host checks that the output is smaller than 2^29 elements): every access is
+    // `global_* v, v_offset, s[base]` -- no 64-bit address arithmetic per element
+    auto ldf = [](const float* base, unsigned boff) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + boff); };
     auto rows8 = [&](auto full_tag, int i, int j, int n, float bias, int half) {
       constexpr bool FULL = decltype(full_tag)::value;
-      int off[8];
+      unsigned off[8];
       bool ok[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
@@ -487,29 +490,29 @@ conv3x3_tile_bf3_kernel(const Tile3Args a) {
         acc_pixel(i, r, py, px);
         const int oy = e.y0 + py, ox = e.x0 + px;
         ok[k] = FULL || ((wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h < NPIX && oy < a.OH && ox < a.OW);
-        off[k] = ((e.n_img * a.OH + (FULL ? oy : min(oy, a.OH - 1))) * a.OW + (FULL ? ox : min(ox, a.OW - 1))) * a.Nout + n;
+        off[k] = (unsigned)(((e.n_img * a.OH + (FULL ? oy : min(oy, a.OH - 1))) * a.OW + (FULL ? ox : min(ox, a.OW - 1))) * a.Nout + n) * 4u;
       }
       float ad[8], mk[8], sv[8], yo[8];
       if (epi & FP_EPI_ADDEND) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) ad[k] = a.addend[off[k]];
+        for (int k = 0; k < 8; ++k) ad[k] = ldf(a.addend, off[k]);
       }
       if (epi & FP_EPI_ADDEND_MASK) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) mk[k] = a.addend_mask[off[k]];
+        for (int k = 0; k < 8; ++k) mk[k] = ldf(a.addend_mask, off[k]);
       }
       if (epi & (FP_EPI_ACTGRAD_ELU | FP_EPI_ACTGRAD_RELU)) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) sv[k] = a.actsrc[off[k]];
+        for (int k = 0; k < 8; ++k) sv[k] = ldf(a.actsrc, off[k]);
       }
       if (epi & FP_EPI_ACCUM) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) yo[k] = a.y[off[k]];
+        for (int k = 0; k < 8; ++k) yo[k] = ldf(a.y, off[k]);
       }
       float zb[8];
       if (bnb) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) zb[k] = a.bnb_z[off[k]];
+        for (int k = 0; k < 8; ++k) zb[k] = ldf(a.bnb_z, off[k]);
       }
       // one wave-uniform branch per flag around an 8-element body (per-element tests get if-converted into selects that execute
       // every option for every element)
@@ -547,7 +550,7 @@ conv3x3_tile_bf3_kernel(const Tile3Args a) {
 #pragma unroll
       for (int k = 0; k < 8; ++k)
         if (FULL || ok[k]) {
-          dst[off[k]] = v[k];
+          *reinterpret_cast<float*>(reinterpret_cast<char*>(dst) + off[k]) = v[k];
           if (HP) ymax = fmaxf(ymax, fabsf(v[k]));
         }
       if (bnb) {
@@ -822,7 +825,7 @@ int run_tile3(const char* who, const fp_conv_desc* d, const float* src, const fl
   FP_REQUIRE(!(d->epi & FP_EPI_ADDEND_MASK) || addend_mask, "fp_conv3x3_bf3 / fp_conv3x3_hp: addend_mask missing");
   FP_REQUIRE(!(d->epi & (FP_EPI_ACTGRAD_ELU | FP_EPI_ACTGRAD_RELU)) || actsrc, "fp_conv3x3_bf3 / fp_conv3x3_hp: actsrc missing");
   FP_REQUIRE(p.SK <= 1 || (workspace && workspace_bytes >= fp_conv3x3_bf3_workspace(d)), "fp_conv3x3_bf3 / fp_conv3x3_hp: workspace too small");
-  FP_REQUIRE((int64_t)d->N * d->OH * d->OW * d->Nout < ((int64_t)1 << 31), "fp_conv3x3_bf3 / fp_conv3x3_hp: output larger than 2^31 elements");
+  FP_REQUIRE((int64_t)d->N * d->OH * d->OW * d->Nout < ((int64_t)1 << 29), "fp_conv3x3_bf3 / fp_conv3x3_hp: output larger than 2^29 elements");
   // operands are addressed with 32-bit byte offsets (raw buffer loads; bit 31 = "out of range, reads zero")
   FP_REQUIRE((int64_t)d->N * d->IH * d->IW * (d->C0 + d->C1) * 4 < ((int64_t)1 << 31), "fp_conv3x3_bf3 / fp_conv3x3_hp: input larger than 2^31 bytes");
   Tile3Args a;

@@ -237,23 +237,29 @@ __global__ void __launch_bounds__(256) up2_phase_fwd_bf3_kernel(const PhaseArgs 
     kunscale = -(ka + fp_hp_exponent(fp_amax_bits(a.amax_w), FP_HP_TARGET_W));
   }
 
-  int pix[NS], lds_off[NS];
+  // operands through raw buffer loads: a 32-bit per-lane byte offset + a wave-uniform one (conv3x3_tile_bf3.hip, round 4)
+  const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.low), 0, a.N * a.h * a.w_ * a.C0 * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(wq), 0, 16 * a.KC16 * NP * a.Nout * 32, 0x00020000);
+  const int wchunk = NP * a.Nout * 32, wplane = a.Nout * 32;
+  int wtapoff[4];
+#pragma unroll
+  for (int tp = 0; tp < 4; ++tp) wtapoff[tp] = (phase * 4 + tp) * a.KC16 * wchunk;
+  unsigned voff[NS];
+  int lds_off[NS];
 #pragma unroll
   for (int k = 0; k < NS; ++k) {
     const int lin = t + 256 * k, hp = min(lin >> 2, HP - 1);
     lds_off[k] = (lin >> 2) < HP ? hp * PIXB + (lin & 3) * 8 : -1;
     const int hy = hp / HW2, hx = hp - hy * HW2;
     const int sy = min(max(y0 + hy - 1, 0), a.h - 1), sx = min(max(x0 + hx - 1, 0), a.w_ - 1);   // replicate padding
-    pix[k] = (n_img * a.h + sy) * a.w_ + sx;
+    voff[k] = (unsigned)((n_img * a.h + sy) * a.w_ + sx) * (unsigned)(a.C0 * 4) + (t & 3) * 16;
   }
   float4 hreg[NS];
   bool hzero = false;
   auto load_halo = [&](int cc) {
-    const int c4 = cc * 16 + (t & 3) * 4;
-    hzero = c4 >= a.C0;
-    const int coff = hzero ? 0 : c4;
+    hzero = (a.C0 & 15) != 0 && cc * 16 + (t & 3) * 4 >= a.C0;
 #pragma unroll
-    for (int k = 0; k < NS; ++k) hreg[k] = *reinterpret_cast<const float4*>(a.low + (size_t)pix[k] * a.C0 + coff);
+    for (int k = 0; k < NS; ++k) hreg[k] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rl, voff[k], cc * 64, 0));
   };
   auto store_halo = [&](int buf) {
 #pragma unroll
@@ -265,14 +271,15 @@ __global__ void __launch_bounds__(256) up2_phase_fwd_bf3_kernel(const PhaseArgs 
     }
   };
   uint4 bq[4][TN][NP];
+  unsigned wvoff[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) wvoff[j] = (unsigned)(min(n0 + (wn * TN + j) * 32 + idx, a.Nout - 1) * 32 + h * 16);
   auto load_b = [&](int tap, int cc, uint4 (&bf)[TN][NP]) {
-    const unsigned short* ws = wq + (size_t)((phase * 4 + tap) * a.KC16 + cc) * NP * a.Nout * 16 + h * 8;
+    const int so = wtapoff[tap] + cc * wchunk;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = min(n0 + (wn * TN + j) * 32 + idx, a.Nout - 1);
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int p = 0; p < NP; ++p) bf[j][p] = *reinterpret_cast<const uint4*>(ws + ((size_t)p * a.Nout + n) * 16);
-    }
+      for (int p = 0; p < NP; ++p) bf[j][p] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rw, wvoff[j], so + p * wplane, 0));
   };
   int abase[TM];
 #pragma unroll
@@ -331,8 +338,9 @@ __global__ void __launch_bounds__(256) up2_phase_fwd_bf3_kernel(const PhaseArgs 
       const int n = n0 + (wn * TN + j) * 32 + idx;
       if (n >= a.Nout) continue;
       const float bias = (a.epi & FP_EPI_BIAS) ? a.bias[n] : 0.f;
-      // addend loads of all 16 rows first, then the arithmetic and the stores (see conv3x3_tile_bf3.hip)
-      int off[16];
+      // addend loads of all 16 rows first, then the arithmetic and the stores (see conv3x3_tile_bf3.hip); 32-bit unsigned byte offsets
+      // (the host checks the output size): `global_* v, v_offset, s[base]`, no 64-bit address arithmetic per element
+      unsigned off[16];
       bool ok[16];
       float ad[16];
 #pragma unroll
@@ -340,19 +348,20 @@ __global__ void __launch_bounds__(256) up2_phase_fwd_bf3_kernel(const PhaseArgs 
         const int pt = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         const int ly = y0 + pt / TW, lx = x0 + pt % TW;
         ok[r] = ly < a.h && lx < a.w_;
-        off[r] = ((n_img * OH + 2 * min(ly, a.h - 1) + dy) * OW + 2 * min(lx, a.w_ - 1) + dx) * a.Nout + n;
+        off[r] = (unsigned)(((n_img * OH + 2 * min(ly, a.h - 1) + dy) * OW + 2 * min(lx, a.w_ - 1) + dx) * a.Nout + n) * 4u;
       }
       if (a.epi & FP_EPI_ADDEND) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ad[r] = a.addend[off[r]];
+        for (int r = 0; r < 16; ++r) ad[r] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.addend) + off[r]);
       }
+      const float unscale = NP == 2 ? ldexpf(1.f, kunscale) : 1.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float v = (NP == 2 ? ldexpf(acc[i][j][r], kunscale) : acc[i][j][r]) + bias;
+        float v = NP == 2 ? fmaf(acc[i][j][r], unscale, bias) : acc[i][j][r] + bias;       // * 2^kunscale is exact
         if (a.epi & FP_EPI_ADDEND) v += ad[r];
         if (a.act == FP_ACT_ELU) v = fp_elu(v);
         if (ok[r]) {
-          a.y[off[r]] = v;
+          *reinterpret_cast<float*>(reinterpret_cast<char*>(a.y) + off[r]) = v;
           ymax = fmaxf(ymax, fabsf(v));
         }
       }
@@ -397,47 +406,51 @@ __global__ void __launch_bounds__(256) up2_phase_dgrad_bf3_kernel(const PhaseDgr
     kunscale = -(ka + fp_hp_exponent(fp_amax_bits(a.amax_w), FP_HP_TARGET_W));
   }
 
-  int pix[NS], lds_off[NS];
-  bool hvalid[NS];
+  // operands through raw buffer loads (32-bit lane offset + wave-uniform offset; an offset with bit 31 set reads zeros: the zero padding
+  // of the phase planes needs no select at staging time); (phase, chunk) of a step advance by carries instead of a division per use
+  constexpr unsigned OOB = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dz), 0, a.N * H2 * W2 * a.Cout * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.w), 0, 16 * a.KC16 * NP * a.C0 * 32, 0x00020000);
+  const int wchunk = NP * a.C0 * 32, wplane = a.C0 * 32, wtap = a.KC16 * wchunk;
+  unsigned voff[NS];
+  int lds_off[NS];
 #pragma unroll
   for (int k = 0; k < NS; ++k) {
     const int lin = t + 256 * k, hp = min(lin >> 2, HP - 1);
     lds_off[k] = (lin >> 2) < HP ? hp * PIXB + (lin & 3) * 8 : -1;
     const int hy = hp / HW2, hx = hp - hy * HW2;
     const int yp = y0 + hy - 2, xp = x0 + hx - 2;                      // phase-plane coordinates
-    hvalid[k] = yp >= 0 && yp < a.h && xp >= 0 && xp < a.w_;
-    pix[k] = (n_img * H2 + 2 * min(max(yp, 0), a.h - 1)) * W2 + 2 * min(max(xp, 0), a.w_ - 1);   // + py * W2 + px per phase
+    const bool valid = yp >= 0 && yp < a.h && xp >= 0 && xp < a.w_;
+    const unsigned pix = (unsigned)((n_img * H2 + 2 * min(max(yp, 0), a.h - 1)) * W2 + 2 * min(max(xp, 0), a.w_ - 1));   // + py * W2 + px per phase
+    voff[k] = valid ? pix * (unsigned)(a.Cout * 4) + (t & 3) * 16 : OOB;
   }
   float4 hreg[NS];
   bool hzero = false;
-  auto load_halo = [&](int step) {
-    const int ph = step / a.KC16, cc = step - ph * a.KC16;
-    const int poff = (ph >> 1) * W2 + (ph & 1);
-    const int c4 = cc * 16 + (t & 3) * 4;
-    hzero = c4 >= a.Cout;
-    const int coff = hzero ? 0 : c4;
+  auto load_halo = [&](int ph, int cc) {
+    const int so = (((ph >> 1) * W2 + (ph & 1)) * a.Cout + cc * 16) * 4;
+    hzero = (a.Cout & 15) != 0 && cc * 16 + (t & 3) * 4 >= a.Cout;
 #pragma unroll
-    for (int k = 0; k < NS; ++k) hreg[k] = *reinterpret_cast<const float4*>(a.dz + (size_t)(pix[k] + poff) * a.Cout + coff);
+    for (int k = 0; k < NS; ++k) hreg[k] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rz, voff[k], so, 0));
   };
   auto store_halo = [&](int buf) {
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
       if (lds_off[k] < 0) continue;
       f32x4_t v = {hreg[k].x, hreg[k].y, hreg[k].z, hreg[k].w};
-      if (hzero || !hvalid[k]) v = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      if (hzero) v = f32x4_t{0.f, 0.f, 0.f, 0.f};
       phase_store_split<NP>(lds + buf * BUFN + lds_off[k], v, ka);
     }
   };
   uint4 bq[4][TN][NP];
-  auto load_b = [&](int tap, int step, uint4 (&bf)[TN][NP]) {
-    const int ph = step / a.KC16, cc = step - ph * a.KC16;
-    const unsigned short* ws = a.w + (size_t)((ph * 4 + tap) * a.KC16 + cc) * NP * a.C0 * 16 + h * 8;
+  unsigned wvoff[TN];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = min(n0 + (wn * TN + j) * 32 + idx, a.C0 - 1);
+  for (int j = 0; j < TN; ++j) wvoff[j] = (unsigned)(min(n0 + (wn * TN + j) * 32 + idx, a.C0 - 1) * 32 + h * 16);
+  auto load_b = [&](int tap, int ph, int cc, uint4 (&bf)[TN][NP]) {
+    const int so = (ph * 4 + tap) * wtap + cc * wchunk;
 #pragma unroll
-      for (int p = 0; p < NP; ++p) bf[j][p] = *reinterpret_cast<const uint4*>(ws + ((size_t)p * a.C0 + n) * 16);
-    }
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int p = 0; p < NP; ++p) bf[j][p] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rw, wvoff[j], so + p * wplane, 0));
   };
   int abase[TM];
 #pragma unroll
@@ -453,16 +466,23 @@ __global__ void __launch_bounds__(256) up2_phase_dgrad_bf3_kernel(const PhaseDgr
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  load_halo(0);
-  load_b(0, 0, bq[0]);
-  load_b(1, 0, bq[1]);
+  // (ph, cc) of step, step + 1 and step + 2 (clamped to the last step), advanced by carries
+  auto advance = [&](int& ph_, int& cc_) {
+    if (ph_ * a.KC16 + cc_ + 1 >= nsteps) return;      // stay on the last step (its operands are re-loaded, harmlessly)
+    if (++cc_ == a.KC16) { cc_ = 0; ++ph_; }
+  };
+  int ph = 0, cc = 0, ph1 = 0, cc1 = 0, ph2 = 0, cc2 = 0;
+  advance(ph1, cc1);
+  ph2 = ph1; cc2 = cc1;
+  advance(ph2, cc2);
+  load_halo(0, 0);
+  load_b(0, 0, 0, bq[0]);
+  load_b(1, 0, 0, bq[1]);
   store_halo(0);
-  load_halo(min(1, nsteps - 1));
+  load_halo(ph1, cc1);
   __syncthreads();
   for (int step = 0; step < nsteps; ++step) {
     const unsigned char* Hb = lds + (step & 1) * BUFN;
-    const int stepn = min(step + 1, nsteps - 1);
-    const int ph = step / a.KC16;
     const int poff = ((1 - (ph >> 1)) * HW2 + (1 - (ph & 1))) * PIXB;     // tap (a, b) reads halo offset (a + 1 - py, b + 1 - px)
     uint4 af[2][TM][NP];
     auto load_a = [&](int tap, uint4 (&dst)[TM][NP]) {
@@ -477,18 +497,21 @@ __global__ void __launch_bounds__(256) up2_phase_dgrad_bf3_kernel(const PhaseDgr
     for (int tap = 0; tap < 4; ++tap) {
       __builtin_amdgcn_sched_barrier(0);
       if (tap < 3) load_a(tap + 1, af[(tap + 1) & 1]);
-      if (tap < 2) load_b(tap + 2, step, bq[tap + 2]);
-      else load_b(tap - 2, stepn, bq[tap - 2]);
+      if (tap < 2) load_b(tap + 2, ph, cc, bq[tap + 2]);
+      else load_b(tap - 2, ph1, cc1, bq[tap - 2]);
       phase_mma<NP, TM, TN>(acc, af[tap & 1], bq[tap]);
       if (tap < 3) fp_sched_interleave<TM * NP, TN * NP, (NP == 3 ? 6 : FP_HP_PRODUCTS) * TM * TN>();      // one read between consecutive MFMAs (fp_common.h)
       else fp_sched_interleave<0, TN * NP, (NP == 3 ? 6 : FP_HP_PRODUCTS) * TM * TN>();
     }
     if (step + 1 < nsteps) {
       store_halo((step + 1) & 1);
-      load_halo(min(step + 2, nsteps - 1));
+      load_halo(ph2, cc2);
       __syncthreads();
     }
+    ph = ph1; cc = cc1; ph1 = ph2; cc1 = cc2;
+    advance(ph2, cc2);
   }
+  const float unscale_d = NP == 2 ? ldexpf(1.f, kunscale) : 1.f;      // * 2^kunscale is exact
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -499,7 +522,9 @@ __global__ void __launch_bounds__(256) up2_phase_dgrad_bf3_kernel(const PhaseDgr
       for (int r = 0; r < 16; ++r) {
         const int pt = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         const int ey = y0 + pt / TW, ex = x0 + pt % TW;
-        if (ey < EH && ex < EW) a.ext[((size_t)(n_img * EH + ey) * EW + ex) * a.C0 + n] = NP == 2 ? ldexpf(acc[i][j][r], kunscale) : acc[i][j][r];
+        const unsigned boff = (unsigned)(((n_img * EH + ey) * EW + ex) * a.C0 + n) * 4u;     // (output smaller than 2^29 elements: host check)
+        if (ey < EH && ex < EW)
+          *reinterpret_cast<float*>(reinterpret_cast<char*>(a.ext) + boff) = NP == 2 ? acc[i][j][r] * unscale_d : acc[i][j][r];
       }
     }
 }
@@ -585,7 +610,8 @@ static int phase_fwd_split(const float* low, const void* wphase_bf3, const float
                            uint32_t* amax_out, fp_stream_t stream) {
   FP_REQUIRE(low && wphase_bf3 && y && N > 0 && h >= 1 && w >= 1 && C0 > 0 && C0 % 4 == 0 && Nout > 0,
              "fp_conv_up2_phase_fwd_bf3 / _hp: bad arguments");
-  FP_REQUIRE((int64_t)N * 4 * h * w * Nout < ((int64_t)1 << 31), "fp_conv_up2_phase_fwd_bf3 / _hp: output larger than 2^31 elements");
+  FP_REQUIRE((int64_t)N * 4 * h * w * Nout < ((int64_t)1 << 29) && (int64_t)N * h * w * C0 < ((int64_t)1 << 29),
+             "fp_conv_up2_phase_fwd_bf3 / _hp: tensor larger than 2^29 elements (operands are addressed with 32-bit byte offsets)");
   PhaseArgs a;
   a.amax_a = amax_low; a.amax_w = amax_w; a.amax_out = amax_out;
   const bool hp = amax_low != nullptr;
@@ -622,7 +648,8 @@ static int phase_dgrad_split(const float* dz, const void* wpacked_bf3, float* ex
                              const uint32_t* amax_dz, const uint32_t* amax_w, fp_stream_t stream) {
   FP_REQUIRE(dz && wpacked_bf3 && ext && N > 0 && h >= 1 && w >= 1 && Cout > 0 && Cout % 4 == 0 && C0 > 0,
              "fp_conv_up2_phase_dgrad_bf3 / _hp: bad arguments");
-  FP_REQUIRE((int64_t)N * 4 * h * w * Cout < ((int64_t)1 << 31), "fp_conv_up2_phase_dgrad_bf3 / _hp: dZ larger than 2^31 elements");
+  FP_REQUIRE((int64_t)N * 4 * h * w * Cout < ((int64_t)1 << 29) && (int64_t)N * (h + 2) * (w + 2) * C0 < ((int64_t)1 << 29),
+             "fp_conv_up2_phase_dgrad_bf3 / _hp: tensor larger than 2^29 elements (operands are addressed with 32-bit byte offsets)");
   PhaseDgradArgs a;
   a.amax_a = amax_dz; a.amax_w = amax_w;
   const bool hp = amax_dz != nullptr;

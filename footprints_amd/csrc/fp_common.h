@@ -165,9 +165,13 @@ __device__ __forceinline__ float fp_elu(float v) {
   const float e = __builtin_amdgcn_exp2f(v * 1.44269504088896341f) - 1.f;
   return v > 0.f ? v : e;
 #else
-  if (v > 0.f) return v;
+  // branch-free: with the early return `if (v > 0) return v` every element of an epilogue got its own exec-masked region (two
+  // s_and_saveexec / s_cbranch pairs, ~25 instructions per element of which 9 scalar); both candidates and two selects are 15 VALU
+  // and the same values (round 4)
   const float p = v * (1.f + v * (0.5f + v * (1.f / 6.f + v * (1.f / 24.f + v * (1.f / 120.f + v * (1.f / 720.f + v * (1.f / 5040.f)))))));
-  return v > -0.25f ? p : __expf(v) - 1.f;
+  const float e = __expf(v) - 1.f;
+  const float neg = v > -0.25f ? p : e;
+  return v > 0.f ? v : neg;
 #endif
 }
 
@@ -216,6 +220,13 @@ __device__ __forceinline__ void fp_hp_split4(float x0, float x1, float x2, float
   const fp_f32x4 v = {x0 * s, x1 * s, x2 * s, x3 * s};
   h = __builtin_convertvector(v, fp_f16x4);
   const fp_f32x4 r1 = v - __builtin_convertvector(h, fp_f32x4);
+  m = __builtin_convertvector(r1, fp_f16x4);
+#elif FP_HP_SPLIT_MIX == 2      // A/B: only the residual through v_fma_mix_f32 (fp32 result, the fp16 term read in place): 3 VALU per element
+  typedef float fp_f32x4 __attribute__((ext_vector_type(4)));
+  const fp_f32x4 v = {x0 * s, x1 * s, x2 * s, x3 * s};
+  h = __builtin_convertvector(v, fp_f16x4);
+  const fp_f32x4 r1 = {__builtin_fmaf((float)h.x, -1.f, v.x), __builtin_fmaf((float)h.y, -1.f, v.y), __builtin_fmaf((float)h.z, -1.f, v.z),
+                       __builtin_fmaf((float)h.w, -1.f, v.w)};
   m = __builtin_convertvector(r1, fp_f16x4);
 #else
   h.x = (_Float16)__builtin_fmaf(x0, s, 0.f); h.y = (_Float16)__builtin_fmaf(x1, s, 0.f);
