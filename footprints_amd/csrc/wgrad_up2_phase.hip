@@ -10,8 +10,6 @@
 // channels), de-interleaved by phase on the way into LDS (the DMA picks the source pixel per 8-lane group), and wave p runs
 // the four taps of phase p over both rows: 64 MFMAs per wave per chunk.  No cross-wave reduction: every wave writes its own
 // four 32 x 32 tiles; up2_wgrad_reduce_kernel sums the S splits and un-collapses in a fixed order => deterministic.
-#include <type_traits>
-
 #include "fp_common.h"
 
 namespace {
@@ -164,7 +162,7 @@ __global__ void __launch_bounds__(256, 3) wgrad_up2_phase_bf3_kernel(const PWArg
     kx_ = fp_hp_exponent(fp_amax_bits(a.amax_low), FP_HP_TARGET_ACT);
     kz_ = fp_hp_exponent(fp_amax_bits(a.amax_dz), FP_HP_TARGET_ACT);
   }
-  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), idx = lane & 31, h = lane >> 5;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, idx = lane & 31, h = lane >> 5;
   // XCD-contiguous logical ids: the ci x co tile workgroups of one pixel split stage the same X / dZ chunks and then share that XCD's
   // L2 (consecutive hardware ids go to different XCDs; PMC showed 3x the fused-minimum HBM bytes per launch); split s walks chunks
   // s, s + S, ... so that neighbouring workgroups of an XCD work on neighbouring chunks at the same time
@@ -176,6 +174,7 @@ __global__ void __launch_bounds__(256, 3) wgrad_up2_phase_bf3_kernel(const PWArg
   const int c_begin = s, c_end = a.nchunks, c_step = a.S;
   const int H2 = 2 * a.h, W2 = 2 * a.w;
   const int dy = wave >> 1, dx = wave & 1;
+  const bool dxb = dx != 0;
 
   // staging items: X: (halo row, column group of 4, channel quad) for t < 160;  dZ: (phase = wave, row, column group, channel quad)
   const int q = t & 7;
@@ -248,48 +247,44 @@ __global__ void __launch_bounds__(256, 3) wgrad_up2_phase_bf3_kernel(const PWArg
   __syncthreads();
   for (int c = c_begin; c < c_end; c += c_step) {
     if (c + c_step < c_end) issue(c + c_step);       // next chunk's global loads fly under this chunk's MFMAs
-    // the wave's column phase dx picks the halo columns of its two taps: (d, shifted by one) or (shifted by one, shifted by two).  A wave-uniform
-    // branch around two straight-line bodies: round 3 selected per 32-bit word with and / or masks (16 VALU per fragment pair, 128 per chunk)
-    auto taps = [&](auto dx_tag) {
-      constexpr int DX = decltype(dx_tag)::value;
 #pragma unroll
-      for (int r = 0; r < CHL; ++r) {
-        uint4 bz[NP];
+    for (int r = 0; r < CHL; ++r) {
+      uint4 bz[NP];
 #pragma unroll
-        for (int p = 0; p < NP; ++p) bz[p] = *reinterpret_cast<const uint4*>(Zs + p * PZPLANE + ((wave * CHL + r) * 32 + idx) * PZROW + h * 16);
+      for (int p = 0; p < NP; ++p) bz[p] = *reinterpret_cast<const uint4*>(Zs + p * PZPLANE + ((wave * CHL + r) * 32 + idx) * PZROW + h * 16);
 #pragma unroll
-        for (int ta = 0; ta < 2; ++ta) {
-          uint4 a0[NP], a1[NP];           // taps b = 0, 1: halo columns shifted by dx, dx + 1
+      for (int ta = 0; ta < 2; ++ta) {
+        uint4 a0[NP], a1[NP];           // taps b = 0, 1: halo columns shifted by dx, dx + 1
 #pragma unroll
-          for (int p = 0; p < NP; ++p) {
-            const unsigned char* row = Xs + p * PXPLANE + ((r + dy + ta) * 32 + idx) * PXROW + h * 16;
-            const uint4 d = *reinterpret_cast<const uint4*>(row);                  // columns 8h .. 8h+7
-            const unsigned e = *reinterpret_cast<const unsigned*>(row + 16);       // columns 8h+8, 8h+9
-            const uint4 s1 = make_uint4(__builtin_amdgcn_alignbit(d.y, d.x, 16), __builtin_amdgcn_alignbit(d.z, d.y, 16),
-                                        __builtin_amdgcn_alignbit(d.w, d.z, 16), __builtin_amdgcn_alignbit(e, d.w, 16));
-            a0[p] = DX ? s1 : d;
-            a1[p] = DX ? make_uint4(d.y, d.z, d.w, e) : s1;
-          }
-          constexpr int NPROD = NP == 3 ? 6 : 4;       // smallest products first
-          constexpr int PA[6] = {NP == 3 ? 2 : 1, NP == 3 ? 0 : 1, NP == 3 ? 1 : 0, NP == 3 ? 1 : 0, 0, 0};
-          constexpr int PB[6] = {NP == 3 ? 0 : 1, NP == 3 ? 2 : 0, 1, 0, 1, 0};
+        for (int p = 0; p < NP; ++p) {
+          const unsigned char* row = Xs + p * PXPLANE + ((r + dy + ta) * 32 + idx) * PXROW + h * 16;
+          const uint4 d = *reinterpret_cast<const uint4*>(row);                  // columns 8h .. 8h+7
+          const unsigned e = *reinterpret_cast<const unsigned*>(row + 16);       // columns 8h+8, 8h+9
+          const uint4 s1 = make_uint4(__builtin_amdgcn_alignbit(d.y, d.x, 16), __builtin_amdgcn_alignbit(d.z, d.y, 16),
+                                      __builtin_amdgcn_alignbit(d.w, d.z, 16), __builtin_amdgcn_alignbit(e, d.w, 16));
+          const uint4 s2 = make_uint4(d.y, d.z, d.w, e);
+          // wave-uniform choice, one v_cndmask per 32-bit word (a ?: on whole vectors was compiled to a scratch-memory indexed select; the
+          // and / or form of round 3 cost two instructions per word; two straight-line bodies behind a uniform branch spilled 64 registers)
+          a0[p] = make_uint4(dxb ? s1.x : d.x, dxb ? s1.y : d.y, dxb ? s1.z : d.z, dxb ? s1.w : d.w);
+          a1[p] = make_uint4(dxb ? s2.x : s1.x, dxb ? s2.y : s1.y, dxb ? s2.z : s1.z, dxb ? s2.w : s1.w);
+        }
+        constexpr int NPROD = NP == 3 ? 6 : 4;       // smallest products first
+        constexpr int PA[6] = {NP == 3 ? 2 : 1, NP == 3 ? 0 : 1, NP == 3 ? 1 : 0, NP == 3 ? 1 : 0, 0, 0};
+        constexpr int PB[6] = {NP == 3 ? 0 : 1, NP == 3 ? 2 : 0, 1, 0, 1, 0};
 #pragma unroll
-          for (int qq = (NP == 2 ? 4 - FP_HP_PRODUCTS : 0); qq < NPROD; ++qq) {
-            if (NP == 2) {
-              const pf16x8 bb = __builtin_bit_cast(pf16x8, bz[PB[qq]]);
-              acc[ta * 2 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(pf16x8, a0[PA[qq]]), bb, acc[ta * 2 + 0], 0, 0, 0);
-              acc[ta * 2 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(pf16x8, a1[PA[qq]]), bb, acc[ta * 2 + 1], 0, 0, 0);
-            } else {
-              const pbf16x8 bb = __builtin_bit_cast(pbf16x8, bz[PB[qq]]);
-              acc[ta * 2 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(pbf16x8, a0[PA[qq]]), bb, acc[ta * 2 + 0], 0, 0, 0);
-              acc[ta * 2 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(pbf16x8, a1[PA[qq]]), bb, acc[ta * 2 + 1], 0, 0, 0);
-            }
+        for (int qq = (NP == 2 ? 4 - FP_HP_PRODUCTS : 0); qq < NPROD; ++qq) {
+          if (NP == 2) {
+            const pf16x8 bb = __builtin_bit_cast(pf16x8, bz[PB[qq]]);
+            acc[ta * 2 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(pf16x8, a0[PA[qq]]), bb, acc[ta * 2 + 0], 0, 0, 0);
+            acc[ta * 2 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(pf16x8, a1[PA[qq]]), bb, acc[ta * 2 + 1], 0, 0, 0);
+          } else {
+            const pbf16x8 bb = __builtin_bit_cast(pbf16x8, bz[PB[qq]]);
+            acc[ta * 2 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(pbf16x8, a0[PA[qq]]), bb, acc[ta * 2 + 0], 0, 0, 0);
+            acc[ta * 2 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(pbf16x8, a1[PA[qq]]), bb, acc[ta * 2 + 1], 0, 0, 0);
           }
         }
       }
-    };
-    if (dx) taps(std::integral_constant<int, 1>{});
-    else taps(std::integral_constant<int, 0>{});
+    }
     __syncthreads();                                  // every wave has read this chunk
     if (c + c_step < c_end) stage();
     __syncthreads();                                  // next chunk visible
