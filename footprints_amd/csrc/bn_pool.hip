@@ -74,17 +74,31 @@ __global__ void __launch_bounds__(256) bn_stats_final_kernel(const float* __rest
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
   if (c >= C) return;
-  Wf w{0, 0, 0};
+  // the merge of the per-block triples runs in double (round 4): the blocks' own fp32 means carry independent round-off that averages out
+  // over the blocks, but a chain of fp32 Chan merges adds a few 1e-7 sigma of its own to the mean -- and the backward pass amplifies a mean
+  // off by delta into d gamma off by delta * sum(g) / sigma, which is sum(g) / sum(g xhat) ~ 10^2..10^3 times the relative error
+  // (profiles/round4_notes.md: encoder.layer4.2.bn2.weight sat at 9-33x the fp32 CPU path's error for two rounds; ATen's CPU BatchNorm
+  // accumulates in double, at::acc_type<float, false>)
+  struct Wd { double n, mean, m2; };
+  auto merge = [](Wd& a, const Wd& b) {
+    const double n = a.n + b.n;
+    if (n == 0.0) return;
+    const double d = b.mean - a.mean, f = b.n / n;
+    a.mean += d * f;
+    a.m2 += b.m2 + d * d * a.n * f;
+    a.n = n;
+  };
+  Wd wd{0.0, 0.0, 0.0};
   for (int b = lane; b < nblk; b += 64) {
     const float* p = part + ((size_t)b * C + c) * 3;
-    Wf o{p[0], p[1], p[2]};
-    wf_merge(w, o);
+    merge(wd, Wd{(double)p[0], (double)p[1], (double)p[2]});
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
-    Wf t{__shfl_down(w.n, o, 64), __shfl_down(w.mean, o, 64), __shfl_down(w.m2, o, 64)};
-    wf_merge(w, t);
+    const Wd t{__shfl_down(wd.n, o, 64), __shfl_down(wd.mean, o, 64), __shfl_down(wd.m2, o, 64)};
+    merge(wd, t);
   }
+  const Wf w{(float)wd.n, (float)wd.mean, (float)wd.m2};
   if (lane != 0) return;
   const float var = w.m2 / w.n;                       // biased: used for normalisation
   const float invstd = 1.f / sqrtf(var + eps);
@@ -183,14 +197,18 @@ __global__ void __launch_bounds__(256) bn_bwd_final_kernel(const float* __restri
   const int lane = threadIdx.x & 63;
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= C) return;
-  float s1 = 0.f, s2 = 0.f;
+  double d1 = 0.0, d2 = 0.0;                          // the per-block sums are combined in double (cheap: nblk values per channel)
   for (int b = lane; b < nblk; b += 64) {
     const float* p = part + ((size_t)b * C + c) * 2;
-    s1 += p[0]; s2 += p[1];
+    d1 += (double)p[0]; d2 += (double)p[1];
   }
-  s1 = fp_wave_sum(s1);
-  s2 = fp_wave_sum(s2);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    d1 += __shfl_down(d1, o, 64);
+    d2 += __shfl_down(d2, o, 64);
+  }
   if (lane != 0) return;
+  const float s1 = (float)d1, s2 = (float)d2;
   coef[c * 2 + 0] = s1 * invM;
   coef[c * 2 + 1] = s2 * invM;
   if (dgamma) dgamma[c] = accumulate ? dgamma[c] + s2 : s2;

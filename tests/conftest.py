@@ -20,3 +20,45 @@ def pytest_configure(config):
 def have_gpu():
     import torch
     return torch.cuda.is_available()
+
+
+# ---- the parity ratio tables of a GPU session, assembled by the suite itself ---------------------------------------
+_SESSION_T0 = [0.0]
+
+
+def pytest_sessionstart(session):
+    import time
+    _SESSION_T0[0] = time.time()
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """tests/test_gpu_parity_fullsize.py leaves one JSON per case under gpurun_out/parity/ (err(GPU) / err(CPU fp32) per parameter tensor,
+    both against the float64 oracle); this writes the markdown table of the cases THIS session produced next to them --
+    `parity_ratios_<operand format>.md`, copied into profiles/round<N>_parity_ratios.md by hand, never assembled by hand."""
+    import glob
+    import json
+    out_dir = os.environ.get("FP_PARITY_DUMP", os.path.join(ROOT, "gpurun_out", "parity"))
+    docs = []
+    for path in sorted(glob.glob(os.path.join(out_dir, "*.json"))):
+        try:
+            if os.path.getmtime(path) >= _SESSION_T0[0] - 1.0:
+                docs.append(json.load(open(path)))
+        except (OSError, ValueError):
+            pass
+    if not docs:
+        return
+    fmt = "exact bf16x3 split (FP_HP=0)" if os.environ.get("FP_HP", "1") == "0" else "scaled fp16 pairs (default)"
+    lines = ["# err(GPU) / err(CPU fp32) per parameter tensor, both against the float64 oracle -- written by the test session itself",
+             "", "operand format: %s; gates: tests/parity.py (median inside [0.4, 1.5]; natural-statistics case [0.2, 1.5])" % fmt, "",
+             "| case | tensors | median | p90 | tensors > 2 | kink pixels removed | worst tensors (ratio; err GPU / err CPU fp32) |", "|---|---|---|---|---|---|---|"]
+    for d in docs:
+        worst = ", ".join("%s %.1f (%.1e / %.1e)" % (t["tensor"].replace("encoder.", "enc.").replace("_decoder", "_dec"), t["ratio"], t["err_gpu"],
+                                                     t["err_cpu32"]) for t in d.get("top6", [])[:3])
+        lines.append("| %s | %s | %.2f | %.2f | %s | %s | %s |" % (d.get("case"), d.get("tensors"), d.get("median_ratio", float("nan")),
+                                                                 d.get("p90_ratio", float("nan")), d.get("count_ratio_gt_2"),
+                                                                 d.get("kink_pixels_removed", d.get("failures_under_single_run_rule", "")), worst))
+    try:
+        with open(os.path.join(out_dir, "parity_ratios_%s.md" % ("exact" if "exact" in fmt else "hp")), "w") as fh:
+            fh.write("\n".join(lines) + "\n")
+    except OSError:
+        pass

@@ -21,11 +21,17 @@ depth crosses the target.  A pixel with |d - depth| within reach of fp32 output 
 implementation and, sitting at the steepest point of the loss, carries ~30x a typical pixel's gradient: one such pixel among
 327 680 moved every depth-decoder gradient by 1.5e-4 (1x512x640).  `tie_free_batch` removes those pixels from the valid masks
 (depth / ground_depth := 0 where the float64 prediction is within TIE of the target at any scale) for all three runs alike.
-Round 3: the band is also as wide as the depth moves under an OUTPUT perturbation of the parity tolerance itself (TIE_SIGMA = 1e-4 on
-the sigmoid: (hi - lo) d^2 * 1e-4 metres).  With saturated predictions (sigmoid ~ 0, d ~ 100 m: the natural-statistics case) a
-relative band of 1 % is 1 m while two conforming implementations may differ by 10 m there; the fp16-pair path lost that lottery on
-one pixel (gradient ratios up to 54 in layer3/4) while the exact split and the fp32 CPU path happened to win it, with all three
-within 5e-5 of the float64 outputs (profiles/round3_notes.md)."""
+Round 3 added a second band for ONE test: as wide as the depth moves under an OUTPUT perturbation of the parity tolerance itself
+(TIE_SIGMA = 1e-4 on the sigmoid: (hi - lo) d^2 * 1e-4 metres).  With saturated predictions (sigmoid ~ 0, d ~ 100 m: the
+natural-statistics case) a relative band of 1 % is 1 m while two conforming implementations may differ by 10 m there.  Round 4 (ADVICE
+r3): that band is OPT-IN (`tie_sigma=TIE_SIGMA`, used by the natural-statistics / wide-range test only); the standard cases run with the
+1 % band alone, as in round 2, and every caller asserts an upper bound on the number of pixels it removed.
+
+The gates are fixed (round 4; a change needs a written reason under profiles/): per tensor the rule above; per case the median of
+err(GPU) / err(CPU fp32) inside [0.4, 1.5] ([0.2, 1.5] for the natural-statistics case, whose bound comes from five fp32 runs).  The lower
+end is not a defect -- split operands with exact products are MORE accurate than an fp32 accumulation chain, a median of 0.5 says the
+engine sits twice as close to float64 as the CPU path -- it is there so that a change of the distribution in either direction gets
+looked at.  KINK_MAX_FRACTION bounds the masked pixels (measured: 0.03-0.09 % standard, 0.76 % natural)."""
 from collections import OrderedDict
 
 import torch
@@ -33,7 +39,11 @@ import torch
 FACTOR = 4.0
 FLOOR = 2e-5          # relative L2; both implementations at fp32 round-off
 TIE = 1e-2            # |predicted depth - target| (metres, relative to max(depth, 1)) below which the L1 kink is undetermined in fp32
-TIE_SIGMA = 1e-4      # ... and the output tolerance of the parity contract itself (north_star: depth / mask tensors within 1e-4): a sigmoid
+MEDIAN_GATE = (0.4, 1.5)           # median err(GPU) / err(CPU fp32) per case (see the module docstring)
+MEDIAN_GATE_NATURAL = (0.2, 1.5)
+KINK_MAX_FRACTION = 0.005          # of the 2 B H W depth-target pixels, standard cases
+KINK_MAX_FRACTION_NATURAL = 0.02
+TIE_SIGMA = 1e-4      # (opt-in) ... and the output tolerance of the parity contract itself (north_star: depth / mask tensors within 1e-4): a sigmoid
                       # output may move by this much between two conforming implementations, which moves the predicted depth
                       # d = 1 / (lo + (hi - lo) sigma) by (hi - lo) d^2 * 1e-4 -- 10 m at d = 100 m: far pixels sit on the kink for any target
 
@@ -109,7 +119,7 @@ def anchored_report(gpu, cpu32, ref64, factor=FACTOR, floor=FLOOR, spread=()):
     return bad, rows
 
 
-def tie_free_batch(cpu_batch, out64, depth_range=(0.1, 100.0), tie=TIE, tie_sigma=TIE_SIGMA):
+def tie_free_batch(cpu_batch, out64, depth_range=(0.1, 100.0), tie=TIE, tie_sigma=0.0):
     """copy of the batch with the |.|-kink pixels of the depth losses removed from the valid masks (see the module docstring);
     out64: the float64 oracle's outputs (they do not depend on the targets).  Returns (batch, number of pixels removed)."""
     batch = OrderedDict((k, v.clone()) for k, v in cpu_batch.items())

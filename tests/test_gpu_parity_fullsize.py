@@ -20,7 +20,8 @@ import numpy as np
 import pytest
 import torch
 
-from tests.parity import anchored_report, chan_relerr, oracle_grads, rel_l2, tie_free_batch
+from tests.parity import (KINK_MAX_FRACTION, KINK_MAX_FRACTION_NATURAL, MEDIAN_GATE, MEDIAN_GATE_NATURAL, TIE_SIGMA, anchored_report, chan_relerr,
+                          oracle_grads, rel_l2, tie_free_batch)
 
 pytestmark = pytest.mark.gpu
 
@@ -29,8 +30,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _keep_ratio_table(tag, rows, extra=None):
     """err(GPU) / err(CPU fp32) per parameter tensor (both against the float64 oracle) -> gpurun_out/parity/<tag>.json: the table
-    travels back from the GPU box and is committed under profiles/ every round, so drift of the distribution is visible.  Returns
-    the median, which the callers hold inside [0.7, 1.3]: the two fp32 implementations must be EQUALLY far from the truth."""
+    travels back from the GPU box and is committed under profiles/ every round (tests/conftest.py assembles the markdown table at the end
+    of the session), so drift of the distribution is visible.  Returns the median, which the callers hold inside tests.parity.MEDIAN_GATE =
+    [0.4, 1.5] ([0.2, 1.5] for the natural-statistics case): fixed in round 4, see tests/parity.py."""
     ratios = [r for r, *_ in rows]
     med = float(np.median(ratios))
     doc = {"case": tag, "tensors": len(rows), "median_ratio": round(med, 4), "count_ratio_gt_2": int(sum(r > 2 for r in ratios)),
@@ -78,6 +80,7 @@ def test_train_step_fp64_anchored(Bn, Hn, Wn):
     out32, l32, g32, tr32, _ = oracle_grads(P, B, cpu_batch, torch.float32)
     model, out, losses, g_gpu = _gpu_step(P, B, cpu_batch)
     print("\n[%dx%dx%d] |.|-kink pixels removed from the depth masks: %d of %d" % (Bn, Hn, Wn, removed[0], 2 * Bn * Hn * Wn))
+    assert removed[0] <= KINK_MAX_FRACTION * 2 * Bn * Hn * Wn, "the tie band removed %d of %d depth-target pixels" % (removed[0], 2 * Bn * Hn * Wn)
     # ---- outputs: per channel, against the reference's fp32 CPU arithmetic and against the float64 truth ---------------
     for k in R.SCALES:
         e32, e64 = chan_relerr(out[k], out32[k]), chan_relerr(out[k], out64[k])
@@ -101,7 +104,7 @@ def test_train_step_fp64_anchored(Bn, Hn, Wn):
     # measured spread of the median over the five cases and both operand formats (profiles/round3_parity_ratios.md): 0.72 .. 1.34
     # (the lower end is not a defect -- the split-operand kernels are MORE accurate than an fp32 accumulation chain -- it is there so
     # that a change of the distribution in either direction gets looked at)
-    assert 0.4 <= med <= 1.5, "median err(GPU) / err(CPU fp32) = %.3f: the engine's arithmetic drifted away from fp32-equivalent" % med
+    assert MEDIAN_GATE[0] <= med <= MEDIAN_GATE[1], "median err(GPU) / err(CPU fp32) = %.3f: the engine's arithmetic drifted away from fp32-equivalent" % med
     # ---- BatchNorm running statistics after the step (train-mode side effect, network.py:40-44 / nn.BatchNorm2d) ----------
     sd = model.state_dict()
     for k, v in tr32.B.items():
@@ -173,10 +176,11 @@ def test_natural_statistics_wide_dynamic_range_fp64_anchored():
     removed = []
 
     def fix(batch, out64):
-        b, n = tie_free_batch(batch, out64)
+        b, n = tie_free_batch(batch, out64, tie_sigma=TIE_SIGMA)          # the only case with the output-tolerance band (tests/parity.py)
         removed.append(n)
         return b
     out64, l64, g64, _, cpu_batch = oracle_grads(P, B, cpu_batch, torch.float64, fix_batch=fix)
+    assert removed[0] <= KINK_MAX_FRACTION_NATURAL * 2 * Bn * Hn * Wn, "the tie band removed %d of %d depth-target pixels" % (removed[0], 2 * Bn * Hn * Wn)
     out32, l32, g32, _, _ = oracle_grads(P, B, cpu_batch, torch.float32)
     # four more fp32 CPU runs on images perturbed by 1e-6 (relative) -- the level at which the fp32 implementations' own features sit
     # from the float64 ones on this input (f1 .. f4: 7e-7 .. 6e-6, scripts/debug_parity_stage.py): how far conforming fp32
@@ -208,7 +212,9 @@ def test_natural_statistics_wide_dynamic_range_fp64_anchored():
                              "out_1_1_worst_pixel_err_cpu32": [float("%.3e" % v) for v in worst32.tolist()]})
     print("\n[natural / wide range] worst ratios:", ["%s %.2f (gpu %.1e cpu %.1e)" % (n, r, eg, ec) for r, n, eg, ec in rows[:6]], "median %.2f" % med)
     assert not bad, bad[:10]
-    assert 0.2 <= med <= 1.5, med
+    if os.environ.get("FP_HP", "1") == "0":           # exactly split operands: the single-run rule holds as well (rounds 2-3), and stays asserted
+        assert not bad1, bad1[:10]
+    assert MEDIAN_GATE_NATURAL[0] <= med <= MEDIAN_GATE_NATURAL[1], med
 
 
 def test_g5_gradients_and_adam_state_fp64_anchored():
