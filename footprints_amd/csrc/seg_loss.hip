@@ -155,6 +155,10 @@ extern "C" int fp_seg_loss_fwd_bwd(const float* const* preds, float* const* dpre
   for (int s = 0; s < 4; ++s) {
     FP_REQUIRE(preds[s] && hs[s] > 0 && ws[s] > 0 && hs[s] <= H && ws[s] <= W && bstrides[s] >= (int64_t)hs[s] * ws[s],
                "fp_seg_loss_fwd_bwd: bad map %d", s);
+    // the gradient's gather window [S (l - 1), S (l + 2)) with S = H / h covers every contributing full-resolution pixel only for integer
+    // scales (for H = 100, h = 40 rows would be missed silently); the segmentation decoder's maps are H / 8 ... H / 1
+    FP_REQUIRE(!dpreds || (H % hs[s] == 0 && W % ws[s] == 0), "fp_seg_loss_fwd_bwd: map %d (%d x %d) is not an integer fraction of %d x %d",
+               s, hs[s], ws[s], H, W);
     m.p[s] = preds[s]; m.g[s] = dpreds ? dpreds[s] : nullptr; m.h[s] = hs[s]; m.w[s] = ws[s]; m.bstride[s] = bstrides[s];
     FP_REQUIRE(!dpreds || dpreds[s], "fp_seg_loss_fwd_bwd: gradient map %d missing", s);
   }

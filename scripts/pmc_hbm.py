@@ -1,5 +1,5 @@
 """Turn the two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE -- they do not fit one pass on gfx950) over scripts/step_loop.py
-into profiles/round2_pmc_hbm_<workload>.json, the file bench.py's `roofline.traffic` is filled from.
+into profiles/round<N>_pmc_hbm_<workload>.json, the file bench.py's `roofline.traffic` is filled from.
 
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_f -o pmc -- python scripts/step_loop.py kitti 2 1
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_w -o pmc -- python scripts/step_loop.py kitti 2 1
@@ -63,7 +63,14 @@ def main():
         for g in json.load(open(kj))["groups"]:
             alg[g["entry_point"]] = g["algorithmic_mb_per_launch"] * 1e6
     f, w = collect(df, "FETCH_SIZE"), collect(dw, "WRITE_SIZE")
-    res = {"_units": "bytes per launch, averaged over every launch of the kernel family in `python scripts/step_loop.py %s` (train steps only); "
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hsh = hashlib.sha256()
+    for name in ("conv3x3_tile_bf3.hip", "fp_common.h"):        # the same digest bench.py computes (kernel_source_digest): ties this file to its build
+        with open(os.path.join(root, "footprints_amd", "csrc", name), "rb") as fh:
+            hsh.update(fh.read())
+    res = {"kernel_source_sha16": hsh.hexdigest()[:16],
+           "_units": "bytes per launch, averaged over every launch of the kernel family in `python scripts/step_loop.py %s` (train steps only); "
                      "fetch = FETCH_SIZE KB x 1024 x 2 (gfx950 reports half of wide coalesced reads), write = WRITE_SIZE KB x 1024 (uncalibrated)" % wl}
     for key in sorted(set(f) | set(w)):
         nf, vf = f.get(key, (0, 0.0))
