@@ -53,9 +53,7 @@ constexpr int CH = 4, CW = 16, HR = CH + 2;
 #ifndef FP_WGRAD_PF_DEFAULT
 #define FP_WGRAD_PF_DEFAULT 2
 #endif
-#ifndef FP_WGRAD_WS_DEFAULT
-#define FP_WGRAD_WS_DEFAULT 0
-#endif
+
 constexpr int XROW = 48, ZROW = 48;                          // bytes per (row, channel) line: 20 / 16 bf16 + pad
 constexpr int XPLANE = HR * 32 * XROW, ZPLANE = CH * 32 * ZROW;
 constexpr int XBYTES = 3 * XPLANE, ZBYTES = 3 * ZPLANE;      // 27648 + 18432 = 46080
@@ -723,238 +721,11 @@ __global__ void __launch_bounds__(256, D > 2 ? 1 : 2) wgrad3x3_hp_pf_kernel(cons
   }
 }
 
-// ---- fifth generation (round 4, fp16 pairs): wave-specialised -- three MFMA waves, one loader wave ------------------------------------
-// The fourth generation runs one wave per SIMD and every wave does everything: per chunk 27 MFMAs (864 cycles), the conversion of its
-// share of the operands (~100 VALU), 40 transpose reads behind single-buffered fragment registers (144 of its 256 VGPRs are the nine
-// taps' accumulators) and a barrier: a chunk period of ~2 500 cycles, the MFMA pipe a third busy.  Here the work is cut the other way:
-//   * wave ky (0, 1, 2) owns the three taps (ky, 0..2) for ALL four rows of a chunk: 36 MFMAs per chunk, 48 accumulator registers, no
-//     cross-wave sum at the end (a wave writes its own three tap tiles), X / dZ fragments double-buffered across the rows;
-//   * wave 3 multiplies nothing: it loads and converts the X halo (864 of the chunk's 1 376 staging items: 14 per lane) -- the conversion
-//     runs on a SIMD whose matrix pipe is idle anyway, beside the three SIMDs that multiply; the MFMA waves stage dZ (512 items: 3 per
-//     lane) and sum the bias gradient from it.
-// Same LDS image, same partial-sum layout [split][tap][ci][co], same reduce kernels, same two-slot register ring of raw buffer loads
-// (the ring is one overlaid array: X items in the loader, dZ items in the others); one barrier per chunk.  The sum over a chunk's rows now
-// happens inside one accumulator (row 0 .. 3, then the next chunk) instead of across four waves: deterministic, but not bit-identical
-// to the fourth generation (FP_WGRAD_WS=0 selects it).
-template <int MODE>
-__global__ void __launch_bounds__(256, 2) wgrad3x3_hp_ws_kernel(const W3Args a) {
-  constexpr int XBN = 2 * XP4;
-  constexpr int XK = 14;                 // X staging items per loader lane: 14 x 64 = 896 >= 864 (the plane is padded to 1024 items)
-  constexpr int ZK = 3;                  // dZ staging items per lane of the three MFMA waves: 3 x 192 = 576 >= 512
-  constexpr unsigned OOB = 0x80000000u;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF4];
-  const int kx_ = fp_hp_exponent(fp_amax_bits(a.amax_x), FP_HP_TARGET_ACT);
-  const int kz_ = fp_hp_exponent(fp_amax_bits(a.amax_dz), FP_HP_TARGET_ACT);
-  const int t = threadIdx.x, lane = t & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const bool loader = wave == 3;
-  int b = a.xcd ? fp_xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
-  const int cot = b % a.cotiles; b /= a.cotiles;
-  const int cit = b % a.citiles; b /= a.citiles;
-  const int s = b;
-  const int ci0 = cit * 32, co0 = cot * 32;
-  const int cnt = s < a.nchunks ? (a.nchunks - 1 - s) / a.S + 1 : 0;     // this split's chunks: s, s + S, s + 2 S, ...
-  int cx = s % a.chunksX, cy = (s / a.chunksX) % a.chunksY, cn = s / (a.chunksX * a.chunksY);
-  const int dcx = a.S % a.chunksX, dcy = (a.S / a.chunksX) % a.chunksY, dcn = a.S / (a.chunksX * a.chunksY);
-  int issued = 0;
-
-  const int q = lane & 7;                // channel quad of every staging item of this lane (64 and 192 are multiples of 8)
-  const int tz = wave * 64 + lane;       // MFMA waves: index among their 192 lanes
-  unsigned xgb[XK];                      // loader, interior chunks: offsets from the halo's first pixel
-#pragma unroll
-  for (int k = 0; k < XK; ++k) {
-    const int p = min((lane + 64 * k) >> 3, HR * HWD - 1);
-    const int hy = p / HWD, hx = p - hy * HWD;
-    xgb[k] = (unsigned)(((hy * a.W + hx) * a.C + ci0 + q * 4) * 4);
-  }
-  unsigned zgb[ZK];                      // MFMA waves, interior chunks: offsets from the chunk's first pixel (items past 512: no load)
-#pragma unroll
-  for (int k = 0; k < ZK; ++k) {
-    const int e = tz + 192 * k, zp = min(e >> 3, CH * CW - 1);
-    zgb[k] = e < CH * CW * 8 ? (unsigned)((((zp >> 4) * a.W + (zp & 15)) * a.Nout + co0 + q * 4) * 4) : OOB;
-  }
-  const unsigned xbytes = (unsigned)((size_t)a.N * (MODE == 2 ? (a.H >> 1) * (a.W >> 1) : a.H * a.W) * a.C * 4);
-  const unsigned zbytes = (unsigned)((size_t)a.N * a.H * a.W * a.Nout * 4);
-  // ONE resource, chosen by the wave's role (a wave only ever loads X or dZ): one form of the load for both roles -- two branches with
-  // two resources made the compiler merge the stores into the ring through a pointer phi, which put ring entries into scratch
-  const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(loader ? a.x : a.dz), 0, loader ? xbytes : zbytes, 0x00020000);
-  float4 ring[2][XK];                    // two slots; X items (loader) or dZ items (the first ZK entries, MFMA waves)
-#pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int k = 0; k < XK; ++k) ring[j][k] = make_float4(0.f, 0.f, 0.f, 0.f);
-  const bool want_bias = a.bpart != nullptr && cit == 0;
-  float bs[4] = {0.f, 0.f, 0.f, 0.f};
-
-  auto issue = [&](auto slot_) __attribute__((always_inline)) {
-    constexpr int sl = decltype(slot_)::value;
-    unsigned vo[XK], so = 0;
-#pragma unroll
-    for (int k = 0; k < XK; ++k) vo[k] = OOB;
-    if (issued < cnt) {                              // past the last chunk: loads that touch no memory
-      ++issued;
-      const int y0 = cy * CH, x0 = cx * CW, n = cn;
-      cx += dcx;
-      int carry = cx >= a.chunksX ? 1 : 0;
-      cx -= carry * a.chunksX;
-      cy += dcy + carry;
-      carry = cy >= a.chunksY ? 1 : 0;
-      cy -= carry * a.chunksY;
-      cn += dcn + carry;
-      const bool fast = !a.nofast && MODE != 2 && y0 >= 1 && y0 + CH + 1 <= a.H && x0 >= 1 && x0 + CW + 1 <= a.W;
-      const unsigned org = (unsigned)((n * a.H + y0) * a.W + x0);
-      if (loader) {
-        if (fast) {                                  // wave-uniform: no reflection, clamping or masks inside the image
-          so = (org - a.W - 1) * a.C * 4;
-#pragma unroll
-          for (int k = 0; k < XK; ++k) vo[k] = xgb[k];
-        } else {
-          int tt = lane;                             // opaque copy: the halo coordinates are recomputed, not kept in registers
-          asm volatile("" : "+v"(tt));
-#pragma unroll
-          for (int k = 0; k < XK; ++k) {
-            const int p = min((tt + 64 * k) >> 3, HR * HWD - 1);
-            const int hy = p / HWD, hx = p - hy * HWD;
-            int sy = y0 + hy - 1, sx = x0 + hx - 1;
-            bool ok;
-            if (MODE == 0) ok = sy >= 0 && sy < a.H && sx >= 0 && sx < a.W;
-            else { ok = sy >= -1 && sy <= a.H && sx >= -1 && sx <= a.W; sy = fp_reflect(sy, a.H); sx = fp_reflect(sx, a.W); }
-            sy = min(max(sy, 0), a.H - 1);
-            sx = min(max(sx, 0), a.W - 1);
-            const unsigned xpix = MODE == 2 ? (unsigned)((n * (a.H >> 1) + (sy >> 1)) * (a.W >> 1) + (sx >> 1)) : (unsigned)((n * a.H + sy) * a.W + sx);
-            vo[k] = ((xpix * a.C + ci0 + q * 4) * 4) | (ok ? 0u : OOB);
-          }
-        }
-      } else {
-        if (fast) {
-          so = org * a.Nout * 4;
-#pragma unroll
-          for (int k = 0; k < ZK; ++k) vo[k] = zgb[k];
-        } else {
-          int tt = tz;
-          asm volatile("" : "+v"(tt));
-#pragma unroll
-          for (int k = 0; k < ZK; ++k) {
-            const int e = tt + 192 * k, zp = min(e >> 3, CH * CW - 1);
-            const int oy = y0 + (zp >> 4), ox = x0 + (zp & 15);
-            const bool ok = e < CH * CW * 8 && oy < a.H && ox < a.W;
-            vo[k] = ((unsigned)(((n * a.H + min(oy, a.H - 1)) * a.W + min(ox, a.W - 1)) * a.Nout + co0 + q * 4) * 4) | (ok ? 0u : OOB);
-          }
-        }
-      }
-    }
-    so = __builtin_amdgcn_readfirstlane(so);
-    // (the MFMA waves' entries ZK .. XK - 1 carry the out-of-range offset: eleven loads per chunk that touch no memory, in exchange for one
-    // straight-line form whose s_waitcnt counts are exact for both roles)
-#pragma unroll
-    for (int k = 0; k < XK; ++k) ring[sl][k] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rr, vo[k], so, 0));
-  };
-  // `live` = 1.f when the slot holds a chunk of this split and the workgroup owns the bias partial, else 0.f
-  auto stage = [&](auto slot_, int buf, float live) __attribute__((always_inline)) {
-    constexpr int sl = decltype(slot_)::value;
-    unsigned char* const base = lds + buf * BUF4;
-    if (loader) {
-#pragma unroll
-      for (int k = 0; k < XK; ++k)
-        split_store_np<2>(base + (lane + 64 * k) * 8, XP4, f32x4{ring[sl][k].x, ring[sl][k].y, ring[sl][k].z, ring[sl][k].w}, kx_);
-    } else {
-#pragma unroll
-      for (int k = 0; k < ZK; ++k) {
-        const int e = tz + 192 * k;
-        if (e < CH * CW * 8) {
-          bs[0] = fmaf(ring[sl][k].x, live, bs[0]); bs[1] = fmaf(ring[sl][k].y, live, bs[1]);
-          bs[2] = fmaf(ring[sl][k].z, live, bs[2]); bs[3] = fmaf(ring[sl][k].w, live, bs[3]);
-          split_store_np<2>(base + XBN + e * 8, ZP3, f32x4{ring[sl][k].x, ring[sl][k].y, ring[sl][k].z, ring[sl][k].w}, kz_);
-        }
-      }
-    }
-  };
-
-  f32x16 acc[3];                                     // taps (ky = wave, kx = 0 .. 2)
-#pragma unroll
-  for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[kx][r] = 0.f;
-
-  const float bias_on = want_bias ? 1.f : 0.f;
-  issue(std::integral_constant<int, 0>{});
-  stage(std::integral_constant<int, 0>{}, 0, cnt > 0 ? bias_on : 0.f);
-  issue(std::integral_constant<int, 1>{});
-  issue(std::integral_constant<int, 0>{});
-  __syncthreads();
-
-  const int li = lane & 15;
-  const int lrow = 8 * (lane >> 5) + (li >> 2), lcol = 32 * ((lane >> 4) & 1) + 8 * (li & 3);
-  const int lofs = lrow * PXB + lcol;
-  auto body = [&](auto slot_, int k) __attribute__((always_inline)) {
-    if (!loader) {
-      const unsigned char* const Bb = lds + (k & 1) * BUF4;
-#pragma unroll
-      for (int r = 0; r < CH; ++r) {
-        uint4 bz[2];
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-          const unsigned char* src = Bb + XBN + r * CW * PXB + lofs + p * ZP3;
-          const uint2 lo = lds_tr16(src), hi = lds_tr16(src + 4 * PXB);
-          bz[p] = make_uint4(lo.x, lo.y, hi.x, hi.y);
-        }
-        uint4 af[3][2];                              // [kx][plane] of halo row r + ky
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-          for (int p = 0; p < 2; ++p) {
-            const unsigned char* src = Bb + ((r + wave) * HWD + kx) * PXB + lofs + p * XP4;
-            const uint2 lo = lds_tr16(src), hi = lds_tr16(src + 4 * PXB);
-            af[kx][p] = make_uint4(lo.x, lo.y, hi.x, hi.y);
-          }
-        constexpr int PA[4] = {1, 1, 0, 0}, PB[4] = {1, 0, 1, 0};          // smallest products first
-#pragma unroll
-        for (int qq = 4 - FP_HP_PRODUCTS; qq < 4; ++qq)
-#pragma unroll
-          for (int kx = 0; kx < 3; ++kx)
-            acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[kx][PA[qq]]), __builtin_bit_cast(f16x8, bz[PB[qq]]),
-                                                             acc[kx], 0, 0, 0);
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);               // the staging's first instruction waits for the slot's loads: keep it behind the MFMAs
-    stage(slot_, (k + 1) & 1, k + 1 < cnt ? bias_on : 0.f);
-    issue(slot_);
-    __syncthreads();
-  };
-  int k = 0;
-  for (; k + 2 <= cnt; k += 2) {
-    body(std::integral_constant<int, 1>{}, k);
-    body(std::integral_constant<int, 0>{}, k + 1);
-  }
-  if (k < cnt) body(std::integral_constant<int, 1>{}, k);
-
-  // ---- every MFMA wave writes its own three tap tiles; the bias partial is summed over the 192 staging lanes ----------------------
-  if (want_bias) {                                   // (the loop ended with a barrier: the planes are dead)
-    float* red = reinterpret_cast<float*>(lds);
-    if (!loader) {
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) red[(tz >> 3) * 32 + q * 4 + kk] = bs[kk];
-    }
-    __syncthreads();
-    if (t < 32) {
-      float v = 0.f;
-#pragma unroll
-      for (int g = 0; g < 24; ++g) v += red[g * 32 + t];
-      a.bpart[(size_t)s * a.Nout + co0 + t] = v;
-    }
-  }
-  if (!loader) {
-    const float unscale = ldexpf(1.f, -(kx_ + kz_));
-    float* out = a.part + (size_t)s * 9 * a.C * a.Nout;
-#pragma unroll
-    for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ci = ci0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        out[((size_t)(wave * 3 + kx) * a.C + ci) * a.Nout + co0 + (lane & 31)] = acc[kx][r] * unscale;
-      }
-  }
-}
+// (A fifth generation -- wave-specialised: three MFMA waves owning the taps of one ky for all four rows of a chunk with 48 accumulator
+// registers each, the fourth wave loading and converting the X halo -- was built in round 4, passed every weight-gradient and network parity
+// test, and measured SLOWER: 164.7 vs 133.3 us on 64 -> 64 @ 96 x 320, 72.5 vs 58.8 on 256 -> 256 @ 12 x 40, step 12.35 vs 11.98 ms.  One
+// wave converting 14 float4 per chunk is a longer serial chain than the 36 MFMAs it feeds: the conversion parallelises over four waves
+// better than it hides behind three.  Commit 8701f82 has the kernel, profiles/round4_notes.md the table.)
 
 // dW_oihw[n][k_begin + k][tap] (+)= sum_s part[s][tap][k][n] and, in the SAME launch (tail blocks), db[n] (+)= sum_s bpart[s][n]: one
 // dependent launch instead of two behind every weight-gradient kernel (56 per training step).  Fixed combination order.
@@ -1153,13 +924,7 @@ static int wgrad_split(const fp_conv_desc* d, const float* x, const float* dz, f
   const int64_t xbytes = (int64_t)d->N * (a.mode == 2 ? (d->OH / 2) * (int64_t)(d->OW / 2) : (int64_t)d->OH * d->OW) * d->C0 * 4;
   const int64_t zbytes = (int64_t)d->N * d->OH * d->OW * d->Nout * 4;
   const bool pf_fits = xbytes < (int64_t(1) << 31) && zbytes < (int64_t(1) << 31);       // 32-bit buffer offsets, bit 31 = "out of range"
-  // FP_WGRAD_WS: the wave-specialised fifth generation (three MFMA waves + one loader wave); 0 = the fourth generation's ring kernel
-  static const int ws = getenv("FP_WGRAD_WS") ? atoi(getenv("FP_WGRAD_WS")) : FP_WGRAD_WS_DEFAULT;
-  if (hp && ws >= 1 && pf_fits && !a.stamps) {
-    if (a.mode == 0) fp_launch((wgrad3x3_hp_ws_kernel<0>), dim3(nwg), dim3(256), 0, stream, a);
-    else if (a.mode == 1) fp_launch((wgrad3x3_hp_ws_kernel<1>), dim3(nwg), dim3(256), 0, stream, a);
-    else fp_launch((wgrad3x3_hp_ws_kernel<2>), dim3(nwg), dim3(256), 0, stream, a);
-  } else if (hp && pf >= 1 && pf_fits && !a.stamps) {
+  if (hp && pf >= 1 && pf_fits && !a.stamps) {
 #define FP_W3_PF_LAUNCH(MODE_)                                                                                              \
     do {                                                                                                                     \
       if (pf <= 2) fp_launch((wgrad3x3_hp_pf_kernel<MODE_, 2>), dim3(nwg), dim3(256), 0, stream, a);                        \
