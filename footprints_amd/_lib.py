@@ -85,6 +85,7 @@ SIGNATURES = {
     "fp_conv_up2_phase_wgrad_bf3": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, C.c_int, _P, _I64, _P]),
     "fp_pack_job_blocks": (_I32, [_I32, _I32, _I32, _I32, _I32]),
     "fp_pack_weights_batched": (C.c_int, [_P, _P, _I32, _P]),
+    "fp_pack_weights_batched_capped": (C.c_int, [_P, _P, _I32, _I32, _P]),
     "fp_pack_up2_weight_bf3": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P]),
     "fp_pack_up2_weight_dgrad_bf3": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P]),
     "fp_conv_up2_phase_dgrad_bf3": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P]),

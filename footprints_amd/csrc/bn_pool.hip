@@ -74,11 +74,9 @@ __global__ void __launch_bounds__(256) bn_stats_final_kernel(const float* __rest
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
   if (c >= C) return;
-  // the merge of the per-block triples runs in double (round 4): the blocks' own fp32 means carry independent round-off that averages out
-  // over the blocks, but a chain of fp32 Chan merges adds a few 1e-7 sigma of its own to the mean -- and the backward pass amplifies a mean
-  // off by delta into d gamma off by delta * sum(g) / sigma, which is sum(g) / sum(g xhat) ~ 10^2..10^3 times the relative error
-  // (profiles/round4_notes.md: encoder.layer4.2.bn2.weight sat at 9-33x the fp32 CPU path's error for two rounds; ATen's CPU BatchNorm
-  // accumulates in double, at::acc_type<float, false>)
+  // the merge of the per-block triples runs in double (round 4; ATen's CPU BatchNorm accumulates in double too, at::acc_type<float, false>): a
+  // few hundred double operations per channel.  It was introduced as a suspect for encoder.layer4.2.bn2.weight sitting at 9-33x the fp32 CPU
+  // path's error and turned out NOT to be the cause (one ReLU decision is: profiles/round4_notes.md section 8); kept because it is free.
   struct Wd { double n, mean, m2; };
   auto merge = [](Wd& a, const Wd& b) {
     const double n = a.n + b.n;

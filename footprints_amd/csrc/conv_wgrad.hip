@@ -235,6 +235,41 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
   }
 }
 
+// few outputs, many partial tensors (the stem: 9 408 outputs x 768 partials = 29 MB, which 37 workgroups of the kernel above read in 35 us at
+// the very end of the step, alone on the GPU): 32 outputs x 8 slices of the partials per workgroup, four loads in flight per thread, the
+// slices combined through LDS in a fixed order
+__global__ void __launch_bounds__(256) wgrad_reduce_wide_kernel(const float* __restrict__ part, float* __restrict__ dw, int S, int T,
+                                                                int Kc, int Nout, int stem, int accumulate, int kc_total, int k_begin) {
+  __shared__ float red[8][32];
+  const int total = T * Kc * Nout;
+  const int l = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int e = blockIdx.x * 32 + l;
+  float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+  if (e < total) {
+    int s = sl;
+    for (; s + 24 < S; s += 32) {
+      const float* q = part + (size_t)s * total + e;
+      p0 += q[0]; p1 += q[(size_t)8 * total]; p2 += q[(size_t)16 * total]; p3 += q[(size_t)24 * total];
+    }
+    for (; s < S; s += 8) p0 += part[(size_t)s * total + e];
+  }
+  red[sl][l] = (p0 + p1) + (p2 + p3);
+  __syncthreads();
+  if (sl != 0 || e >= total) return;
+  const float sum = ((red[0][l] + red[1][l]) + (red[2][l] + red[3][l])) + ((red[4][l] + red[5][l]) + (red[6][l] + red[7][l]));
+  const int n = e % Nout;
+  const int r = e / Nout;
+  const int k = r % Kc, tap = r / Kc;
+  size_t o;
+  if (stem) {
+    const int ci = k % 3, kpos = k / 3;
+    o = ((size_t)n * 3 + ci) * 49 + kpos;
+  } else {
+    o = ((size_t)n * kc_total + k_begin + k) * T + tap;
+  }
+  dw[o] = accumulate ? dw[o] + sum : sum;
+}
+
 struct Plan {
   int BI, BJ, kblocks, nblocks, T, Kc, S, chunksPerSplit;
 };
@@ -277,6 +312,11 @@ bool use_tile() {
 int fp_wgrad_reduce_launch(const float* part, float* dw, int S, int T, int Kc, int Nout, int stem, int accumulate, int kc_total,
                            int k_begin, hipStream_t stream) {
   const int64_t total = (int64_t)T * Kc * Nout;
+  if (total <= 32768 && S >= 64) {
+    fp_launch(wgrad_reduce_wide_kernel, dim3((int)fp_ceil_div(total, 32)), dim3(256), 0, stream, part, dw, S, T, Kc, Nout, stem, accumulate, kc_total,
+              k_begin);
+    return fp_check_launch("fp_conv_wgrad(reduce)");
+  }
   int rgrid = (int)fp_ceil_div(total, 256);
   if (rgrid > 4096) rgrid = 4096;
   fp_launch(wgrad_reduce_kernel, dim3(rgrid), dim3(256), 0, stream, part, dw, S, T, Kc, Nout, stem, accumulate,

@@ -362,40 +362,149 @@ __global__ void __launch_bounds__(256) head_dgrad_kernel(const float* __restrict
   if (amax_out) fp_amax_publish_block(amax_out, ymax);
 }
 
-// Weight gradient, gather form with a grid-stride pixel loop (measured faster than row-walk variants with a register window, in
-// either gather or scatter form: 81 / 49 / 25 us vs 87-104 / 61-68 / 31-36 us on the 192x640 / 96x320 / 48x160 heads).
+// Weight gradient.  Round 4: SCATTER form over the input pixels -- a thread reads its four channels of x ONCE and multiplies them with the nine
+// neighbouring dZ values (two floats per pixel: 1/16 of x at 32 channels), instead of gathering x nine times per output pixel (nine float4
+// loads per thread: 17 TB/s through the L1s at 192 x 640, the kernel ran at 26 % of the HBM roof, profiles/round4_hbm_kernels.txt).  In terms
+// of the reflection-padded image xp (H+2 x W+2): dW[t] = sum over padded positions p of xp(p) * dZ(p - t); an input pixel (iy, ix) sits at the
+// padded position (iy+1, ix+1) and, when it is a mirror source, also at row 0 (iy == 1) / row H+1 (iy == H-2) and column 0 / W+1 likewise.
+// The pixel coordinates advance by carries (no division in the loop).
 // partial[block][(tap*Cin + c)*2 + o] and partial_b[block][2]
+typedef float fp_v2f __attribute__((ext_vector_type(2)));
+// acc (two output channels of one tap and input channel) += x * (z.x, z.y).  FP_HEAD_WGRAD_FMA: 0 = two v_fma_f32 (default: the library keeps
+// packed fp32 VALU out of its code objects until round 1's run-to-run differences of THIS kernel's SLP-vectorised build next to the bf16 tile
+// convolution are understood, tests/test_host_cpu.py); 1 = one v_pk_fma_f32 with the x operand broadcast by op_sel (the form the SLP build
+// had); 2 = v_pk_fma_f32 on a materialised (x, x) register pair, no op_sel -- the two A/B builds of scripts/debug_head_wgrad_det.py.  The
+// loop is latency-bound, the forms time the same.
+#ifndef FP_HEAD_WGRAD_FMA
+#define FP_HEAD_WGRAD_FMA 0
+#endif
+__device__ __forceinline__ void head_wfma(fp_v2f& acc, float xv, const fp_v2f& zz) {
+#if FP_HEAD_WGRAD_FMA == 0 || FP_HEAD_WGRAD_FMA == 5
+  acc[0] = fmaf(xv, zz[0], acc[0]);
+  acc[1] = fmaf(xv, zz[1], acc[1]);
+#elif FP_HEAD_WGRAD_FMA == 1
+  acc = __builtin_elementwise_fma(fp_v2f{xv, xv}, zz, acc);
+#elif FP_HEAD_WGRAD_FMA == 2
+  fp_v2f xx = {xv, xv};
+  asm volatile("" : "+v"(xx));
+  acc = __builtin_elementwise_fma(xx, zz, acc);
+#else       // 3: the broadcast on the SECOND source operand (op_sel_hi:[1,0,1] / op_sel:[0,1,0], the forms of round 1's SLP build), by inline asm
+#if FP_HEAD_WGRAD_FMA == 3
+  const fp_v2f xx = {xv, 0.f};
+  asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(zz), "v"(xx));
+#else      // 4: ... and the other one, op_sel:[0,1,0] (both results read the HIGH half of the second source): the accumulators that differed
+  const fp_v2f xx = {FP_HEAD_WGRAD_FMA == 4 ? 0.f : 3.f * xv, xv};      // 6: a low half that shows when it is read instead (scripts/pk_opsel_probe.py)
+  asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(acc) : "v"(zz), "v"(xx));
+#endif
+#endif
+}
+// all four input channels of one tap.  FP_HEAD_WGRAD_FMA == 5 (A/B build): pairs over CHANNELS instead -- a[0] = (c0, c1) x z.x, a[1] = (c0, c1) x z.y,
+// a[2] / a[3] likewise for (c2, c3) -- so that the broadcast operand is the dZ pair as the load wrote it, selected by op_sel_hi:[1,0,1] (low
+// half) and op_sel:[0,1,0] (high half): instruction for instruction the inner loop of round 1's SLP build
+__device__ __forceinline__ void head_wfma4(fp_v2f (&a)[4], const float4& v, const fp_v2f& zz) {
+#if FP_HEAD_WGRAD_FMA == 5
+  const fp_v2f x01 = {v.x, v.y}, x23 = {v.z, v.w};
+  asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(a[0]) : "v"(x01), "v"(zz));
+  asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(a[1]) : "v"(x01), "v"(zz));
+  asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(a[2]) : "v"(x23), "v"(zz));
+  asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(a[3]) : "v"(x23), "v"(zz));
+#else
+  head_wfma(a[0], v.x, zz);
+  head_wfma(a[1], v.y, zz);
+  head_wfma(a[2], v.z, zz);
+  head_wfma(a[3], v.w, zz);
+#endif
+}
 __global__ void __launch_bounds__(256) head_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dz,
                                                          float* __restrict__ part, int N, int H, int W, int Cin) {
   __shared__ float red[4 * 32 * 74];
   const int Q = Cin >> 2, PPB = 256 / Q;
   const int q = threadIdx.x % Q, slot = threadIdx.x / Q;
   const int M = N * H * W;
-  float acc[9][4][2];
-  float bsum0 = 0.f, bsum1 = 0.f;
+  fp_v2f acc[9][4];
+  fp_v2f bsum = {0.f, 0.f};
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) acc[t][c][0] = acc[t][c][1] = 0.f;
-  for (int m = blockIdx.x * PPB + slot; m < M; m += gridDim.x * PPB) {
-    const int ox = m % W, r = m / W, oy = r % H, n = r / H;
-    const float2 z = *reinterpret_cast<const float2*>(dz + (size_t)m * 2);
-    bsum0 += z.x;
-    bsum1 += z.y;
+    for (int c = 0; c < 4; ++c) acc[t][c] = fp_v2f{0.f, 0.f};
+  // all nine taps of the padded position (py, px) that input pixel m occupies; dZ(oy, ox) = dz[m + (oy - iy) * W + (ox - ix)]
+  auto accum = [&](const float4& v, int m, int iy, int ix, int py, int px) __attribute__((always_inline)) {
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
-      const int iy = fp_reflect(oy + ky - 1, H);
+      const int oy = py - ky;
+      const bool vy = (unsigned)oy < (unsigned)H;
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) {
-        const int ix = fp_reflect(ox + kx - 1, W);
-        const float4 v = *reinterpret_cast<const float4*>(x + ((size_t)(n * H + iy) * W + ix) * Cin + q * 4);
+        const int ox = px - kx;
+        const bool ok = vy && (unsigned)ox < (unsigned)W;
+        const int mo = ok ? m + (oy - iy) * W + (ox - ix) : m;
+        float2 z = *reinterpret_cast<const float2*>(dz + (size_t)mo * 2);
+        z.x = ok ? z.x : 0.f;
+        z.y = ok ? z.y : 0.f;
+        const fp_v2f zz = {z.x, z.y};
         const int t = ky * 3 + kx;
-        acc[t][0][0] += v.x * z.x; acc[t][0][1] += v.x * z.y;
-        acc[t][1][0] += v.y * z.x; acc[t][1][1] += v.y * z.y;
-        acc[t][2][0] += v.z * z.x; acc[t][2][1] += v.z * z.y;
-        acc[t][3][0] += v.w * z.x; acc[t][3][1] += v.w * z.y;
+        head_wfma4(acc[t], v, zz);
       }
     }
+  };
+  const int stride = gridDim.x * PPB;
+  const int sx = stride % W, sr = stride / W, sy = sr % H;       // per-iteration advance of (ix, iy) with carries
+  int m = blockIdx.x * PPB + slot;
+  int ix = m % W, iy = (m / W) % H;
+  // the x operand of the NEXT pixel is in flight while this one is multiplied (the loop is latency-bound: one float4 per lane and iteration)
+  float4 vnext = m < M ? *reinterpret_cast<const float4*>(x + (size_t)m * Cin + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (; m < M; m += stride) {
+    const float4 v = vnext;
+    if (m + stride < M) vnext = *reinterpret_cast<const float4*>(x + (size_t)(m + stride) * Cin + q * 4);
+    const float2 zc = *reinterpret_cast<const float2*>(dz + (size_t)m * 2);
+    bsum[0] += zc.x;
+    bsum[1] += zc.y;
+    const bool inner = iy >= 2 && iy <= H - 3 && ix >= 2 && ix <= W - 3;       // all nine taps inside the image, not a mirror source
+    const bool fast = __builtin_amdgcn_ballot_w64(!inner) == 0;             // the whole wave: nine loads at fixed offsets, no selects
+    float2 z9[9];
+    if (fast) {
+      const float* zr = dz + (size_t)m * 2;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) z9[ky * 3 + kx] = *reinterpret_cast<const float2*>(zr + ((1 - ky) * W + (1 - kx)) * 2);
+    } else {
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int oy = iy + 1 - ky;
+        const bool vy = (unsigned)oy < (unsigned)H;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int ox = ix + 1 - kx;
+          const bool ok = vy && (unsigned)ox < (unsigned)W;
+          const int mo = ok ? m + (1 - ky) * W + (1 - kx) : m;
+          float2 z = *reinterpret_cast<const float2*>(dz + (size_t)mo * 2);
+          z.x = ok ? z.x : 0.f;
+          z.y = ok ? z.y : 0.f;
+          z9[ky * 3 + kx] = z;
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const fp_v2f zz = {z9[t].x, z9[t].y};
+      head_wfma4(acc[t], v, zz);
+    }
+    const bool my0 = iy == 1, my1 = iy == H - 2, mx0 = ix == 1, mx1 = ix == W - 2;
+    if (my0 | my1 | mx0 | mx1) {                                  // mirror sources: the extra padded rows / columns this pixel also fills
+      for (int a = 0; a < 3; ++a) {
+        if ((a == 1 && !my0) || (a == 2 && !my1)) continue;
+        const int py = a == 0 ? iy + 1 : (a == 1 ? 0 : H + 1);
+        for (int b = 0; b < 3; ++b) {
+          if ((a == 0 && b == 0) || (b == 1 && !mx0) || (b == 2 && !mx1)) continue;
+          accum(v, m, iy, ix, py, b == 0 ? ix + 1 : (b == 1 ? 0 : W + 1));
+        }
+      }
+    }
+    ix += sx;
+    iy += sy;
+    if (ix >= W) { ix -= W; iy += 1; }
+    if (iy >= H) iy -= H;
   }
   // reduce over the pixel slots of this wave (lanes q, q+Q, q+2Q, ...), fixed xor tree
   for (int o = Q; o < 64; o <<= 1) {
@@ -403,11 +512,16 @@ __global__ void __launch_bounds__(256) head_wgrad_kernel(const float* __restrict
     for (int t = 0; t < 9; ++t)
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
+#if defined(FP_HEAD_WGRAD_PKRED)      // A/B build: the shuffle tree's additions as v_pk_add_f32 on the two ds_bpermute results (round 1's SLP form)
+        const fp_v2f o2 = {__shfl_xor(acc[t][c][0], o, 64), __shfl_xor(acc[t][c][1], o, 64)};
+        acc[t][c] += o2;
+#else
         acc[t][c][0] += __shfl_xor(acc[t][c][0], o, 64);
         acc[t][c][1] += __shfl_xor(acc[t][c][1], o, 64);
+#endif
       }
-    bsum0 += __shfl_xor(bsum0, o, 64);
-    bsum1 += __shfl_xor(bsum1, o, 64);
+    bsum[0] += __shfl_xor(bsum[0], o, 64);
+    bsum[1] += __shfl_xor(bsum[1], o, 64);
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (lane < Q) {
@@ -416,11 +530,16 @@ __global__ void __launch_bounds__(256) head_wgrad_kernel(const float* __restrict
     for (int t = 0; t < 9; ++t)
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
+#if FP_HEAD_WGRAD_FMA == 5
+        dst[(t * 4 + c) * 2 + 0] = acc[t][(c >> 1) * 2 + 0][c & 1];
+        dst[(t * 4 + c) * 2 + 1] = acc[t][(c >> 1) * 2 + 1][c & 1];
+#else
         dst[(t * 4 + c) * 2 + 0] = acc[t][c][0];
         dst[(t * 4 + c) * 2 + 1] = acc[t][c][1];
+#endif
       }
-    dst[72] = bsum0;
-    dst[73] = bsum1;
+    dst[72] = bsum[0];
+    dst[73] = bsum[1];
   }
   __syncthreads();
   float* out = part + (size_t)blockIdx.x * (9 * Cin * 2 + 2);

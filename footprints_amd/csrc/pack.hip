@@ -7,6 +7,8 @@
 //   STEM       wp[10][64][16]: k = (ky*7 + kx)*3 + ci over the 7x7x3 stem
 //   UP2_FWD    wp[phase 4][tap 4][ceil(Cs/16)][Cout][16]: row/column-collapsed weights of the nearest-x2 phase decomposition
 //   UP2_DGRAD  wp[16 taps r*4+s][ceil(Cout/16)][Cs][16]: the 4x4 stride-2 kernel of its data gradient   (conv_up2_phase.hip)
+#include <stdlib.h>
+
 #include "fp_common.h"
 
 namespace {
@@ -160,14 +162,174 @@ __global__ void __launch_bounds__(256) pack_one_kernel(const fp_pack_job j, size
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) pack_store(j, e, pack_elem(j, e), kw);
 }
 
-// block b serves job blk2job[b]; a job's blocks are contiguous starting at jobs[job].block_begin
-__global__ void __launch_bounds__(256) pack_batched_kernel(const fp_pack_job* __restrict__ jobs, const int32_t* __restrict__ blk2job) {
-  const int ji = blk2job[blockIdx.x];
-  const fp_pack_job j = jobs[ji];
+// ---- the batched repack, tile form (round 4) ---------------------------------------------------------------------------------------
+// The element-wise form above reads OIHW with a stride of KH*KW floats between neighbouring lanes and stores two bytes per lane: 443 us per
+// step for 31 M weights on an idle GPU, and -- launched under the first encoder layers of the next step with ~25 k workgroups -- it took the
+// wave slots of the latency-bound chain it was meant to hide under (first layer-1 convolutions 142 / 107 us instead of 30; the ordered trace
+// in profiles/round4_notes.md).  Here a workgroup moves a tile of 16 output channels x 32 input channels x all taps: rows of 32*T contiguous
+// floats in (coalesced), through LDS, and out as runs of 512 contiguous bytes per (tap, 16-channel chunk, plane); the values and their
+// arithmetic (scaling, fp16 / bf16 splits, the tap sums of the phase layouts in their old order) are those of pack_elem / pack_store, bit for
+// bit.  The launch is persistent: `gridDim.x` workgroups walk the virtual blocks b = blockIdx.x, + gridDim.x, ... so the caller bounds how many
+// CUs a repack on a side stream may occupy.
+constexpr int PT_N = 16, PT_K = 32;
+
+__host__ __device__ inline bool pack_is_dgrad_layout(int kind) {
+  return kind == FP_PACK_DGRAD || kind == FP_PACK_DGRAD_BF3 || kind == FP_PACK_DGRAD_HP || kind == FP_PACK_UP2_DGRAD || kind == FP_PACK_UP2_DGRAD_BF3 ||
+         kind == FP_PACK_UP2_DGRAD_HP;
+}
+__host__ __device__ inline bool pack_is_up2(int kind) {
+  return kind == FP_PACK_UP2_FWD || kind == FP_PACK_UP2_FWD_BF3 || kind == FP_PACK_UP2_FWD_HP || kind == FP_PACK_UP2_DGRAD || kind == FP_PACK_UP2_DGRAD_BF3 ||
+         kind == FP_PACK_UP2_DGRAD_HP;
+}
+__host__ __device__ inline int pack_tiles(int kind, int Cout, int c_count) {
+  return kind == FP_PACK_STEM ? 0 : ((Cout + PT_N - 1) / PT_N) * ((c_count + PT_K - 1) / PT_K);
+}
+
+// value of virtual tap `vt` from the nine (T = 9) or one (T = 1) taps of one (n, k) at `wk` (stride 1 between taps)
+template <int T>
+__device__ __forceinline__ float pack_tap_value(int kind, const float* wk, int vt) {
+  if (T == 1) return wk[0];
+  int ky_lo, ky_hi, kx_lo, kx_hi;
+  switch (kind) {
+    case FP_PACK_UP2_FWD_HP:
+    case FP_PACK_UP2_FWD_BF3:
+    case FP_PACK_UP2_FWD: {
+      const int tap = vt & 3, phase = vt >> 2;
+      const int dy = phase >> 1, dx = phase & 1, ta = tap >> 1, tb = tap & 1;
+      ky_lo = dy == 0 ? (ta == 0 ? 0 : 1) : (ta == 0 ? 0 : 2); ky_hi = dy == 0 ? (ta == 0 ? 0 : 2) : (ta == 0 ? 1 : 2);
+      kx_lo = dx == 0 ? (tb == 0 ? 0 : 1) : (tb == 0 ? 0 : 2); kx_hi = dx == 0 ? (tb == 0 ? 0 : 2) : (tb == 0 ? 1 : 2);
+      break;
+    }
+    case FP_PACK_UP2_DGRAD:
+    case FP_PACK_UP2_DGRAD_HP:
+    case FP_PACK_UP2_DGRAD_BF3: {
+      int tr, ts;
+      if (kind == FP_PACK_UP2_DGRAD) { tr = vt >> 2; ts = vt & 3; }
+      else { const int tap = vt & 3, ph = vt >> 2; tr = ((ph >> 1) + 1) % 2 + 2 * (tap >> 1); ts = ((ph & 1) + 1) % 2 + 2 * (tap & 1); }
+      ky_lo = tr == 0 ? 2 : (tr == 1 ? 1 : 0); ky_hi = tr == 0 ? 2 : (tr == 1 ? 2 : (tr == 2 ? 1 : 0));
+      kx_lo = ts == 0 ? 2 : (ts == 1 ? 1 : 0); kx_hi = ts == 0 ? 2 : (ts == 1 ? 2 : (ts == 2 ? 1 : 0));
+      break;
+    }
+    default: return wk[vt];
+  }
+  float v = 0.f;
+  for (int ky = ky_lo; ky <= ky_hi; ++ky)
+    for (int kx = kx_lo; kx <= kx_hi; ++kx) v += wk[ky * 3 + kx];
+  return v;
+}
+
+template <int T>
+__device__ __forceinline__ void pack_tile(const fp_pack_job& j, int ti, float* __restrict__ tile, int kw) {
+  constexpr int KT = PT_K * T, RS = KT + 1;          // row stride odd: conflict-free for lanes that walk n as for lanes that walk k
+  const int t = threadIdx.x;
+  const int ntk = (j.c_count + PT_K - 1) / PT_K;
+  const int n0 = (ti / ntk) * PT_N, k0 = (ti % ntk) * PT_K;
+  const int klen = min(PT_K, j.c_count - k0) * T;
+  constexpr int NLD = PT_N * KT / 256;               // 18 (3 x 3) or 2 (1 x 1) loads per thread, all in flight before the first LDS write
+  float ld[NLD];
+  const float* __restrict__ src = j.w + ((size_t)n0 * j.Cin + j.c_begin + k0) * T;      // wave-uniform base, 32-bit per-lane offsets
+  const unsigned rowstride = (unsigned)j.Cin * T;
+  const int nrows = min(PT_N, j.Cout - n0);
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) {
+    const int f = t + i * 256, r = f / KT, c = f - r * KT;
+    const bool ok = r < nrows && c < klen;
+    const unsigned off = ok ? (unsigned)r * rowstride + (unsigned)c : 0u;
+    const float v = src[off];
+    ld[i] = ok ? v : 0.f;
+  }
+  __syncthreads();                                   // the previous tile's readers are done
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) {
+    const int f = t + i * 256, r = f / KT;
+    tile[r * RS + (f - r * KT)] = ld[i];
+  }
+  __syncthreads();
+  const int kind = j.kind;
+  const bool dg = pack_is_dgrad_layout(kind);
+  const int VT = pack_is_up2(kind) ? 16 : T;
+  const int ncols = dg ? j.c_count : j.Cout;
+  const int KC16 = ((dg ? j.Cout : j.c_count) + 15) / 16;
+  const bool hp = pack_is_hp(kind);
+  const bool bf3 = kind == FP_PACK_FWD_BF3 || kind == FP_PACK_DGRAD_BF3 || kind == FP_PACK_UP2_FWD_BF3 || kind == FP_PACK_UP2_DGRAD_BF3;
+  for (int kc2 = 0; kc2 < PT_K / 16; ++kc2) {
+    // FWD layouts: chunk = 16 input channels, column = output channel; DGRAD layouts: chunk = the tile's 16 output channels, column = input channel
+    const int chunk = dg ? n0 / 16 : k0 / 16 + kc2;
+    if (!dg && chunk >= KC16) break;
+    if (!hp && !bf3) {                               // fp32: one element per thread, 1 KB contiguous per (tap, chunk)
+      const int col_l = t >> 4, kr = t & 15;
+      const int n_l = dg ? kr : col_l, k_l = kc2 * 16 + (dg ? col_l : kr);
+      const int col = dg ? k0 + k_l : n0 + n_l;
+      if (col < ncols)
+        for (int vt = 0; vt < VT; ++vt)
+          j.wp[((size_t)(vt * KC16 + chunk) * ncols + col) * 16 + kr] = pack_tap_value<T>(kind, tile + n_l * RS + k_l * T, vt);
+      continue;
+    }
+    // split layouts: two neighbouring kr per thread, one 32-bit store per plane
+    const int idx = t & 127, col_l = idx >> 3, kr0 = (idx & 7) * 2;
+    const int col = dg ? k0 + kc2 * 16 + col_l : n0 + col_l;
+    if (col >= ncols) continue;
+    const float* a0 = dg ? tile + kr0 * RS + (kc2 * 16 + col_l) * T : tile + col_l * RS + (kc2 * 16 + kr0) * T;
+    const float* a1 = a0 + (dg ? RS : T);
+    if (hp) {
+      const int plane = t >> 7;
+      for (int vt = 0; vt < VT; ++vt) {
+        const float s0 = ldexpf(pack_tap_value<T>(kind, a0, vt), kw), s1 = ldexpf(pack_tap_value<T>(kind, a1, vt), kw);
+        const _Float16 h0 = (_Float16)s0, h1 = (_Float16)s1;
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        h2 o;
+        if (plane == 0) { o[0] = h0; o[1] = h1; }
+        else { o[0] = (_Float16)(s0 - (float)h0); o[1] = (_Float16)(s1 - (float)h1); }
+        _Float16* dst = reinterpret_cast<_Float16*>(j.wp) + ((size_t)(vt * KC16 + chunk) * 2 * ncols + col) * 16 + kr0 + (size_t)plane * ncols * 16;
+        *reinterpret_cast<h2*>(dst) = o;
+      }
+    } else if (t < 128) {
+      for (int vt = 0; vt < VT; ++vt) {
+        unsigned short* dst = reinterpret_cast<unsigned short*>(j.wp) + ((size_t)(vt * KC16 + chunk) * 3 * ncols + col) * 16 + kr0;
+        unsigned pl[3] = {0u, 0u, 0u};
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const float v = pack_tap_value<T>(kind, q ? a1 : a0, vt);
+          const unsigned short h = bf16_rne(v);
+          const float r1 = v - __uint_as_float((unsigned)h << 16);
+          const unsigned short m = bf16_rne(r1);
+          const float r2 = r1 - __uint_as_float((unsigned)m << 16);
+          pl[0] |= (unsigned)h << (16 * q); pl[1] |= (unsigned)m << (16 * q); pl[2] |= (unsigned)bf16_rne(r2) << (16 * q);
+        }
+        *reinterpret_cast<unsigned*>(dst) = pl[0];
+        *reinterpret_cast<unsigned*>(dst + (size_t)ncols * 16) = pl[1];
+        *reinterpret_cast<unsigned*>(dst + (size_t)2 * ncols * 16) = pl[2];
+      }
+    }
+  }
+}
+
+// virtual block b serves job blk2job[b]; a job's virtual blocks are contiguous starting at jobs[job].block_begin and share its tiles
+__global__ void __launch_bounds__(256) pack_batched_kernel(const fp_pack_job* __restrict__ jobs, const int32_t* __restrict__ blk2job, int nblocks) {
+  __shared__ float tile[PT_N * (PT_K * 9 + 1)];
+  for (int vb = blockIdx.x; vb < nblocks; vb += gridDim.x) {
+    const fp_pack_job j = jobs[blk2job[vb]];
+    const int kw = pack_is_hp(j.kind) ? fp_hp_exponent(fp_amax_bits(j.amax), FP_HP_TARGET_W) : 0;
+    const int T = j.KH * j.KW;
+    if (j.kind == FP_PACK_STEM || (T != 9 && T != 1)) {          // the stem's 7 x 7 x 3 table (10 K elements): element-wise as before
+      const size_t total = (size_t)pack_elems(j.kind, j.Cout, j.KH, j.KW, j.c_count);
+      for (size_t e = (size_t)(vb - j.block_begin) * 256 + threadIdx.x; e < total; e += (size_t)j.block_count * 256) pack_store(j, e, pack_elem(j, e), kw);
+      continue;
+    }
+    const int ntiles = pack_tiles(j.kind, j.Cout, j.c_count);
+    for (int ti = vb - j.block_begin; ti < ntiles; ti += j.block_count) {
+      if (T == 9) pack_tile<9>(j, ti, tile, kw);
+      else pack_tile<1>(j, ti, tile, kw);
+    }
+  }
+}
+
+// the element-wise form of rounds 2-3, kept for A/B runs (FP_PACK_TILED=0): one workgroup per virtual block, eight elements per thread
+__global__ void __launch_bounds__(256) pack_batched_elem_kernel(const fp_pack_job* __restrict__ jobs, const int32_t* __restrict__ blk2job) {
+  const fp_pack_job j = jobs[blk2job[blockIdx.x]];
   const size_t total = (size_t)pack_elems(j.kind, j.Cout, j.KH, j.KW, j.c_count);
-  const size_t stride = (size_t)j.block_count * 256;
   const int kw = pack_is_hp(j.kind) ? fp_hp_exponent(fp_amax_bits(j.amax), FP_HP_TARGET_W) : 0;
-  for (size_t e = (size_t)(blockIdx.x - j.block_begin) * 256 + threadIdx.x; e < total; e += stride) pack_store(j, e, pack_elem(j, e), kw);
+  for (size_t e = (size_t)(blockIdx.x - j.block_begin) * 256 + threadIdx.x; e < total; e += (size_t)j.block_count * 256) pack_store(j, e, pack_elem(j, e), kw);
 }
 
 // amax of every fp16-pair job's raw weight tensor into the job's slot (jobs of one tensor share a slot; slots zeroed by the caller)
@@ -303,14 +465,27 @@ extern "C" int fp_pack_up2_weight_dgrad(const float* w_oihw, float* wp, int32_t 
 }
 
 extern "C" int32_t fp_pack_job_blocks(int32_t kind, int32_t Cout, int32_t KH, int32_t KW, int32_t c_count) {
-  int64_t b = (pack_elems(kind, Cout, KH, KW, c_count) + 2047) / 2048;     // ~8 elements per thread
+  int64_t b;
+  if (kind == FP_PACK_STEM || (KH * KW != 9 && KH * KW != 1)) b = (pack_elems(kind, Cout, KH, KW, c_count) + 2047) / 2048;     // element-wise: ~8 elements per thread
+  else b = pack_tiles(kind, Cout, c_count);                                                                                   // one virtual block per tile ...
   if (b < 1) b = 1;
-  if (b > 256) b = 256;
+  if (b > 512) b = 512;                                                                                                       // ... up to 512 (a 512 x 512 x 3 x 3 tensor)
   return (int32_t)b;
 }
 
-extern "C" int fp_pack_weights_batched(const fp_pack_job* jobs_dev, const int32_t* blk2job_dev, int32_t nblocks, fp_stream_t stream) {
+// max_wgs > 0: at most that many workgroups walk the `nblocks` virtual blocks (a repack beside a latency-bound chain: Engine.refresh_packed)
+extern "C" int fp_pack_weights_batched_capped(const fp_pack_job* jobs_dev, const int32_t* blk2job_dev, int32_t nblocks, int32_t max_wgs,
+                                              fp_stream_t stream) {
   FP_REQUIRE(jobs_dev && blk2job_dev && nblocks > 0, "fp_pack_weights_batched: bad arguments");
-  fp_launch(pack_batched_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, jobs_dev, blk2job_dev);
+  static const bool tiled = !getenv("FP_PACK_TILED") || atoi(getenv("FP_PACK_TILED")) != 0;
+  if (!tiled) {
+    fp_launch(pack_batched_elem_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, jobs_dev, blk2job_dev);
+    return fp_check_launch("fp_pack_weights_batched");
+  }
+  const int grid = max_wgs > 0 && max_wgs < nblocks ? max_wgs : nblocks;
+  fp_launch(pack_batched_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, jobs_dev, blk2job_dev, nblocks);
   return fp_check_launch("fp_pack_weights_batched");
+}
+extern "C" int fp_pack_weights_batched(const fp_pack_job* jobs_dev, const int32_t* blk2job_dev, int32_t nblocks, fp_stream_t stream) {
+  return fp_pack_weights_batched_capped(jobs_dev, blk2job_dev, nblocks, 0, stream);
 }

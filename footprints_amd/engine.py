@@ -52,6 +52,10 @@ _PHASE = not bool(int(os.environ.get("FP_NO_PHASE", "0")))
 
 # role -> side-stream pool index: aux, encoder weight gradients, mask decoder's / depth decoder's weight gradients (see Engine.__init__)
 _STREAM_LAYOUT = "0,1,2,2"
+_WGRAD_PAIR_FORK = bool(int(os.environ.get("FP_WGRAD_PAIR_FORK", "1")))   # one stream fork per residual block for its two weight gradients (0: one each)
+_LAZY32 = bool(int(os.environ.get("FP_PACK_LAZY32", "1")))     # 0: every fp32 packed layout is refreshed every step (rounds 1-3)
+_PACK_SIDE_WGS = int(os.environ.get("FP_PACK_SIDE_WGS", "0"))        # workgroups of the side-stream weight repack (0 = one per tile)
+_PACK_DGRAD_LATE = bool(int(os.environ.get("FP_PACK_DGRAD_LATE", "0")))   # 1: the data-gradient layouts are repacked under the decoders' forward instead of the encoder's
 
 SCALE_KEYS = ("1/8", "1/4", "1/2", "1/1")
 _ALL_SCALES = frozenset(range(4))
@@ -271,6 +275,16 @@ class Engine:
         self._pack_table = None
         self._pack_table_key = None
         self._pack_ev = None
+        self._pack_ev_dgrad = None
+        self._pack_dgrad_pending = False
+        # fp32 packed layouts are repacked LAZILY (round 4): with fp16-pair operands nearly every convolution reads only its *_hp layouts, and
+        # refreshing the fp32 FWD / DGRAD / phase layouts of all 31 M weights as well was half of the repack's 1 GB of traffic per step.  A
+        # layout joins the batched repack the first time a launch reads it (_need32: packed on the spot, on every later refresh by the
+        # table); the packed buffer starts as NaN, so a reader this bookkeeping does not know about fails loudly instead of reading stale weights.
+        self._w32_lazy = {}         # data_ptr of an fp32 layout -> its pack job
+        self._w32_used = set()      # ... that some launch has read: part of the batched table
+        self._w32_fresh = set()     # ... packed since the weights last changed
+        self._w32_tables = {}
         self.fold_eval = _FOLD
         # opt-in inference precision: "bf16x2" runs the 3x3 stride-1 tile convolutions of an eval / no-grad forward with two bf16 terms per
         # operand (three MFMA products instead of six).  NOT exact (measured output error in profiles/round2_notes.md); never used when
@@ -404,7 +418,7 @@ class Engine:
                 ex += [0, 0, 0, 0, 0, 0]
             plan.append((c, total, nf, nd, ex))
             total += nf + nd + sum(ex)
-        self.packed = torch.empty(total, device=self.device)
+        self.packed = torch.full((total,), float("nan"), device=self.device)      # see _need32
         for c, o, nf, nd, ex in plan:
             c.wp = self.packed[o:o + nf]
             c.wpd = self.packed[o + nf:o + nf + nd] if nd else None
@@ -462,31 +476,51 @@ class Engine:
                         if C1:
                             jobs.append((L.PACK_FWD, c.w.data, c.wsk, C0, C1))
                             jobs.append((L.PACK_DGRAD, c.w.data, c.wds, C0, C1))
-                return jobs
-            # two launches: the stem and layer1 (0.2 M parameters) on the calling stream, everything else (31 M) on a side
-            # stream under the stem / layer1 kernels; the forward waits for it where layer2 starts (self._pack_ev)
+                keep = []
+                for j in jobs:
+                    if _LAZY32 and j[0] in (L.PACK_FWD, L.PACK_DGRAD, L.PACK_UP2_FWD, L.PACK_UP2_DGRAD):
+                        self._w32_lazy[j[2].data_ptr()] = j
+                        if j[2].data_ptr() not in self._w32_used:
+                            continue
+                    keep.append(j)
+                return keep
+            # the stem and layer1 (0.2 M parameters) on the calling stream; everything else (31 M) on a side stream under the stem / layer1
+            # kernels, in two parts with an event each: the forward layouts (the forward waits for them where layer2 starts, self._pack_ev) and
+            # the data-gradient layouts (first read by the decoder backward, self._pack_ev_dgrad).  The side-stream launches are persistent
+            # with at most _PACK_SIDE_WGS workgroups: a repack that fills every wave slot of the chip stretched the first layer-1
+            # convolutions from 30 to 142 us (ordered trace, profiles/round4_notes.md)
             first = [self.stem] + [c for blk in self.blocks if blk.Cout == 64 and blk.stride == 1 for c in (blk.c1, blk.c2)]
             rest = [c for c in self.all_convs() if not any(c is f for f in first)]
-            self._pack_table = (ops.build_pack_table(jobs_of(first), self.device), ops.build_pack_table(jobs_of(rest), self.device))
+            rest_jobs = jobs_of(rest)
+            is_dgrad = lambda j: j[0] in (L.PACK_DGRAD, L.PACK_DGRAD_BF3, L.PACK_DGRAD_HP, L.PACK_UP2_DGRAD, L.PACK_UP2_DGRAD_BF3, L.PACK_UP2_DGRAD_HP)
+            self._pack_table = (ops.build_pack_table(jobs_of(first), self.device), ops.build_pack_table(rest_jobs, self.device),
+                                ops.build_pack_table([j for j in rest_jobs if not is_dgrad(j)], self.device),
+                                ops.build_pack_table([j for j in rest_jobs if is_dgrad(j)], self.device))
             self._pack_table_key = key      # parameters live in self.flat_param: pointers are stable
             ops.bump_alloc_generation()     # the previous tables (device-resident job lists) are gone
+        first_t, rest_all, rest_fwd, rest_dgrad = self._pack_table
         if _HP:
             ops.zero_u32(self.wamax)
-            ops.pack_weights_amax(self._pack_table[0])
-        ops.pack_weights_batched(self._pack_table[0])
+            ops.pack_weights_amax(first_t)
+        ops.pack_weights_batched(first_t)
         cur = ops.current_stream()
         if self.concurrent and overlap:
             ops.event_wait(self.wg, self._record(cur))
             with ops.on_stream(self.wg):
                 if _HP:
-                    ops.pack_weights_amax(self._pack_table[1])
-                ops.pack_weights_batched(self._pack_table[1])
+                    ops.pack_weights_amax(rest_all)
+                ops.pack_weights_batched(rest_fwd, max_wgs=_PACK_SIDE_WGS)
                 self._pack_ev = self._record(self.wg)
+                if _PACK_DGRAD_LATE:
+                    self._pack_dgrad_pending = True
+                else:
+                    ops.pack_weights_batched(rest_dgrad, max_wgs=_PACK_SIDE_WGS)
+                    self._pack_ev_dgrad = self._record(self.wg)
         else:
             if _HP:
-                ops.pack_weights_amax(self._pack_table[1])
-            ops.pack_weights_batched(self._pack_table[1])
-            self._pack_ev = None
+                ops.pack_weights_amax(rest_all)
+            ops.pack_weights_batched(rest_all)
+            self._pack_ev = self._pack_ev_dgrad = None
         for d in self.decoders:
             for hd in d.heads:
                 if hd.pad:
@@ -495,6 +529,7 @@ class Engine:
         self._fold_ready = False
         self._versions = vers
         self.weights_dirty = False
+        self._w32_fresh = set(self._w32_used)       # exactly the lazy layouts the tables above contain
 
     # ------------------------------------------------------------------------------------------------
     # activation arena
@@ -577,7 +612,7 @@ class Engine:
             return ops.conv3x3_bf3(d, src, w3, out, **kw)
         if _HP_IGEMM and hp is not None and hp[0] is not None and not ops._bf16x2 and ops.conv_igemm_hp_supported(d):
             return ops.conv_igemm_hp(d, src, hp[0], out, self.amax.get(src), hp[1], **kw)
-        return ops.conv_igemm(d, src, None, w32, out, **kw)
+        return ops.conv_igemm(d, src, None, self._need32(w32), out, **kw)
 
     def _sink_slot(self, t):
         """amax slot the producer of `t` publishes into (None with the bf16 operand format); follow the launch with _sink_done(t)"""
@@ -706,6 +741,40 @@ class Engine:
             ops.event_wait(ops.current_stream(), self._pack_ev)
             self._pack_ev = None
 
+    def _need32(self, t):
+        """`t`: an fp32 packed layout about to be read by a launch on the current stream (see __init__)"""
+        if t is None:
+            return t
+        key = t.data_ptr()
+        if key in self._w32_fresh or key not in self._w32_lazy:
+            return t
+        tab = self._w32_tables.get(key)
+        if tab is None:
+            tab = self._w32_tables[key] = ops.build_pack_table([self._w32_lazy[key]], self.device)
+        ops.pack_weights_batched(tab)
+        torch.cuda.synchronize(self.device)         # first touch only: readers on other streams of this step must see it too
+        self._w32_fresh.add(key)
+        if key not in self._w32_used:
+            self._w32_used.add(key)
+            self._pack_table = None                 # the next refresh rebuilds the tables with this layout in them
+        return t
+
+    def _launch_pack_dgrad(self):
+        """FP_PACK_DGRAD_LATE: the deferred part of refresh_packed, on the repack stream behind everything queued on the calling stream"""
+        if self._pack_dgrad_pending:
+            self._pack_dgrad_pending = False
+            ops.event_wait(self.wg, self._record(ops.current_stream()))
+            with ops.on_stream(self.wg):
+                ops.pack_weights_batched(self._pack_table[3], max_wgs=_PACK_SIDE_WGS)
+                self._pack_ev_dgrad = self._record(self.wg)
+
+    def _wait_pack_dgrad(self):
+        """... and the data-gradient layouts, before the first backward kernel that reads one"""
+        self._launch_pack_dgrad()
+        if self._pack_ev_dgrad is not None:
+            ops.event_wait(ops.current_stream(), self._pack_ev_dgrad)
+            self._pack_ev_dgrad = None
+
     def _conv_enc(self, c, x, N, H, W, out, bn=None):
         """encoder convolution; `bn` = the BatchNorm record that follows in train mode: a tile-kernel launch then also writes the
         Welford partials of its output (ops.bn_stats_out_next) and _bn_coeffs skips the statistics pass over the activation"""
@@ -742,7 +811,7 @@ class Engine:
                 self.amax.published(out, so)
                 return out
             phase_fwd = ops.conv_up2_phase_fwd_bf3 if c.wph3 is not None else ops.conv_up2_phase_fwd
-            return phase_fwd(x0, c.wph3 if c.wph3 is not None else c.wph, c.b.data, out, act=L.ACT_ELU, addend=out if C1 else None)
+            return phase_fwd(x0, c.wph3 if c.wph3 is not None else self._need32(c.wph), c.b.data, out, act=L.ACT_ELU, addend=out if C1 else None)
         gather = L.GATHER_FWD_REFLECT_UP2 if up2 else L.GATHER_FWD_REFLECT
         d = ops.make_desc(N, H, W, H, W, C0, C1, c.Cout, 3, 1, 1, gather, act=L.ACT_ELU)
         if x1 is None and not up2:
@@ -751,7 +820,7 @@ class Engine:
             if c.hp_f is not None and not ops._bf16x2 and _HP_TILE:
                 return self._cv_hp(d, x0, c.hp_f, c.wslot, out, src1=x1, bias=c.b.data)
             return ops.conv3x3_bf3(d, x0, c.wp3, out, bias=c.b.data, src1=x1)
-        return ops.conv_igemm(d, x0, x1, c.wp, out, bias=c.b.data)
+        return ops.conv_igemm(d, x0, x1, self._need32(c.wp), out, bias=c.b.data)
 
     # ------------------------------------------------------------------------------------------------
     # forward
@@ -850,6 +919,7 @@ class Engine:
                 outputs = [torch.empty((N, 4, H, W), device=self.device) for _ in range(4)]
         S["dec"] = [{} for _ in self.decoders]
         main = ops.current_stream()
+        self._launch_pack_dgrad()
         if _HP:
             for f in S["feats"]:                     # both decoders read the features: one reduction each, before the streams fork
                 self.amax.get(f, any_stream=True)
@@ -874,7 +944,7 @@ class Engine:
         for P, c, off in dec.psp.blocks:
             pooled = ops.adaptive_avgpool_fwd(f4, buf("%s.psp.pool%d" % (dec.name, P), (N, P, P, 512)))
             d = ops.make_desc(N, P, P, P, P, 512, 0, 128, 1, 1, 0, L.GATHER_FWD_ZERO)
-            red = ops.conv_igemm(d, pooled, None, c.wp, buf("%s.psp.red%d" % (dec.name, P), (N, P, P, 128)))
+            red = ops.conv_igemm(d, pooled, None, self._need32(c.wp), buf("%s.psp.red%d" % (dec.name, P), (N, P, P, 128)))
             ops.bilinear_ac_fwd(red, cat, off)
             D["psp"].append(pooled)
         return cat
@@ -888,7 +958,7 @@ class Engine:
             dw = ops.make_desc(N, P, P, P, P, 512, 0, 128, 1, 1, 0, L.GATHER_FWD_ZERO)
             ops.conv_wgrad(dw, pooled, None, dred, c.gw, accumulate=acc)
             dd = ops.make_desc(N, P, P, P, P, 128, 0, 512, 1, 1, 0, L.GATHER_DGRAD_ZERO)
-            dpool = ops.conv_igemm(dd, dred, None, c.wpd, buf("g.%s.psp.dpool%d" % (dec.name, P), (N, P, P, 512)))
+            dpool = ops.conv_igemm(dd, dred, None, self._need32(c.wpd), buf("g.%s.psp.dpool%d" % (dec.name, P), (N, P, P, 512)))
             ops.adaptive_avgpool_bwd(dpool, dF4, accumulate=True)
 
     def _decoder_forward(self, dec, S, outputs, D):
@@ -938,9 +1008,12 @@ class Engine:
     # ------------------------------------------------------------------------------------------------
     # backward
     # ------------------------------------------------------------------------------------------------
-    def _wgrad(self, c, gather, src0, src1, dz, N, OH, OW, IH, IW, C0, C1, acc, side=None):
+    def _wgrad(self, c, gather, src0, src1, dz, N, OH, OW, IH, IW, C0, C1, acc, side=None, fork=True):
         """Weight (+bias) gradient of one conv.  side = a stream: launch there, ordered after everything already
-        queued on the current stream (dz is ready) -- the caller guarantees dz / src stay untouched until the join."""
+        queued on the current stream (dz is ready) -- the caller guarantees dz / src stay untouched until the join.
+        fork=False: no new event -- the caller has just forked `side` from this stream (the previous _wgrad call) and launched nothing since.
+        Every fork is a barrier packet on the launching stream: ~6 us in which the data-gradient chain does not advance (ordered trace,
+        profiles/round4_notes.md), so the two weight gradients of a residual block share one."""
         d = ops.make_desc(N, OH, OW, IH, IW, C0, C1, c.Cout, c.K, c.stride, c.pad, gather)
         split = _WBF3 and src1 is None and ops.conv_wgrad_bf3_supported(d)
         # fp16-pair operands: both amax slots are settled on THIS stream (the producers', or a reduction here) before the side stream forks
@@ -955,19 +1028,20 @@ class Engine:
                 ops.colsum(dz.view(-1, c.Cout), c.gb, accumulate=acc)
         if side is None:
             return launch()
-        ops.event_wait(side, self._record(ops.current_stream()))
+        if fork:
+            ops.event_wait(side, self._record(ops.current_stream()))
         with ops.on_stream(side):
             launch()
 
-    def _wgrad_up2(self, c, low, skip, dz, N, hl, wl, C0, C1, acc, side=None):
+    def _wgrad_up2(self, c, low, skip, dz, N, hl, wl, C0, C1, acc, side=None, fork=True):
         """weight (+bias) gradient of a conv over cat[nearest_x2(low), skip]: upsampled half by output phase, skip half as a
-        channel slice of the same gradient tensor; shapes the phase kernel does not take keep the fused-gather kernel."""
+        channel slice of the same gradient tensor; shapes the phase kernel does not take keep the fused-gather kernel.  fork: see _wgrad."""
         H, W = 2 * hl, 2 * wl
         if c.up2 is None or not ops.up2_phase_wgrad_supported(N, hl, wl, C0, c.Cout):
             d_lo = ops.make_desc(N, H, W, H, W, C0, 0, c.Cout, 3, 1, 1, L.GATHER_FWD_REFLECT_UP2)
             d_sk = ops.make_desc(N, H, W, H, W, C1, 0, c.Cout, 3, 1, 1, L.GATHER_FWD_REFLECT) if C1 else None
             if not (_WBF3 and ops.conv_wgrad_bf3_supported(d_lo) and (d_sk is None or ops.conv_wgrad_bf3_supported(d_sk))):
-                return self._wgrad(c, L.GATHER_FWD_REFLECT_UP2, low, skip, dz, N, H, W, H, W, C0, C1, acc, side)
+                return self._wgrad(c, L.GATHER_FWD_REFLECT_UP2, low, skip, dz, N, H, W, H, W, C0, C1, acc, side, fork=fork)
             s_dz = self.amax.get(dz) if _HP_WGRAD else None
             am_lo = (self.amax.get(low), s_dz) if _HP_WGRAD else None
             am_sk = (self.amax.get(skip), s_dz) if (_HP_WGRAD and d_sk is not None) else None
@@ -978,7 +1052,8 @@ class Engine:
                     ops.conv_wgrad_bf3(d_sk, skip, dz, c.gw, C0, accumulate=acc, amax=am_sk)
             if side is None:
                 return launch_small()
-            ops.event_wait(side, self._record(ops.current_stream()))
+            if fork:
+                ops.event_wait(side, self._record(ops.current_stream()))
             with ops.on_stream(side):
                 return launch_small()
 
@@ -1006,7 +1081,8 @@ class Engine:
                 ops.colsum(dz.view(-1, c.Cout), c.gb, accumulate=acc)
         if side is None:
             return launch()
-        ops.event_wait(side, self._record(ops.current_stream()))
+        if fork:
+            ops.event_wait(side, self._record(ops.current_stream()))
         with ops.on_stream(side):
             launch()
 
@@ -1023,7 +1099,7 @@ class Engine:
                 return ops.conv_up2_phase_dgrad_hp(dz, c.hp_du, ext, self.amax.get(dz), c.wslot)
             return ops.conv_up2_phase_dgrad_bf3(dz, c.wdu3, ext)
         d = ops.make_desc(N, hl + 2, wl + 2, 2 * hl, 2 * wl, c.Cout, 0, C0, 4, 2, 3, L.GATHER_FWD_ZERO)
-        return ops.conv_igemm(d, dz, None, c.wdu, ext)
+        return ops.conv_igemm(d, dz, None, self._need32(c.wdu), ext)
 
     def stage_streams(self):
         """every stream that may still be writing parameter gradients when `on_stage` fires (None: everything is on the caller's stream)"""
@@ -1114,7 +1190,8 @@ class Engine:
                     d1 = ops.make_desc(N, hin, win, h, w, C, 0, Cin, 1, blk.stride, 0, L.GATHER_DGRAD_ZERO, epi=L.EPI_ACCUM)
                     self._cv(d1, dzd, blk.ds.wpd, None, tgt, hp=(blk.ds.hp_d, blk.ds.wslot))
                     ev_ds = self._record(self.aux)
-            self._wgrad(blk.c2, L.GATHER_FWD_ZERO, B["a1"], None, dz2, N, h, w, h, w, C, 0, accumulate, side)
+            if not _WGRAD_PAIR_FORK:
+                self._wgrad(blk.c2, L.GATHER_FWD_ZERO, B["a1"], None, dz2, N, h, w, h, w, C, 0, accumulate, side)
             da1 = buf("g.da1", (N, h, w, C))
             dz1 = buf("g.dz1.%d" % i, (N, h, w, C))
             d2 = ops.make_desc(N, h, w, h, w, C, 0, C, 3, 1, 1, L.GATHER_DGRAD_ZERO)
@@ -1135,7 +1212,13 @@ class Engine:
                 ops.bn_bwd(da1.view(M, C), B["a1"].view(M, C), B["z1"].view(M, C), blk.bn1.mean, blk.bn1.invstd, blk.bn1.bn.weight.data,
                            dz1.view(M, C), blk.bn1.gg, blk.bn1.gb, accumulate=accumulate, amax_out=self._sink_slot(dz1))
             self._sink_done(dz1)
-            self._wgrad(blk.c1, L.GATHER_FWD_ZERO, B["x"], None, dz1, N, h, w, hin, win, Cin, 0, accumulate, side)
+            if _WGRAD_PAIR_FORK:                         # both weight gradients of the block behind ONE fork (dz2 has its own buffer per block)
+                if _HP_WGRAD and side is not None:       # a missing amax slot is reduced on THIS stream: before the fork, not between the two launches
+                    self.amax.get(B["x"])
+                    self.amax.get(dz1)
+                self._wgrad(blk.c2, L.GATHER_FWD_ZERO, B["a1"], None, dz2, N, h, w, h, w, C, 0, accumulate, side)
+            self._wgrad(blk.c1, L.GATHER_FWD_ZERO, B["x"], None, dz1, N, h, w, hin, win, Cin, 0, accumulate, side,
+                        fork=not (_WGRAD_PAIR_FORK and side is not None))
             first_of_layer = (i == 0) or blk.stride == 2
             dgd = ops.make_desc(N, hin, win, h, w, C, 0, Cin, 3, blk.stride, 1, L.GATHER_DGRAD_ZERO)
             if blk.ds is not None and ev_ds is not None:
@@ -1201,6 +1284,7 @@ class Engine:
     def _decoders_backward(self, S, gouts, dF, accumulate, on_stage, join=False):
         """both decoders, from d loss / d outputs to the feature gradients dF[0..4] plus every decoder weight gradient"""
         main = ops.current_stream()
+        self._wait_pack_dgrad()
         if self.concurrent and len(self.decoders) == 2:
             # mask decoder on the main stream, depth decoder on the aux stream; the depth decoder ACCUMULATES into the
             # feature gradients, so each of its accumulate launches waits for the mask decoder's write of that level
@@ -1316,9 +1400,16 @@ class Engine:
             skip = feats[3 - bi]
             xin = D["x"][bi - 1] if bi > 0 else D["x0"]          # block1's input: the 1/32 feature map (or its pyramid-pooling concatenation)
             # A = dZ of post2 at (hh, ww)
-            self._wgrad(blk["post2"], L.GATHER_FWD_REFLECT, y3, None, A, N, hh, ww, hh, ww, cout, 0, acc, side)
+            pair = _WGRAD_PAIR_FORK and side is not None      # the two weight gradients of each half of the block behind one fork (see _wgrad)
+            if not pair:
+                self._wgrad(blk["post2"], L.GATHER_FWD_REFLECT, y3, None, A, N, hh, ww, hh, ww, cout, 0, acc, side)
             Bz = self._dgrad_dec(blk["post2"], A, N, hh, ww, buf(pfx + "dz.post1.%d" % bi, (N, hh, ww, cout)), actsrc=y3)
-            self._wgrad_up2(blk["post1"], y2, skip, Bz, N, hl, wl, cout, cout, acc, side)
+            if pair:
+                if _HP_WGRAD:
+                    for t in (Bz, y2, skip):
+                        self.amax.get(t)
+                self._wgrad(blk["post2"], L.GATHER_FWD_REFLECT, y3, None, A, N, hh, ww, hh, ww, cout, 0, acc, side)
+            self._wgrad_up2(blk["post1"], y2, skip, Bz, N, hl, wl, cout, cout, acc, side, fork=not pair)
             A = buf(pfx + "dz.pre2.%d" % bi, (N, hl, wl, cout))
             if blk["post1"].up2 is not None:
                 # d(low) = 4x4 stride-2 conv over dZ + border fold (* ELU'); d(skip) straight into the feature gradient
@@ -1337,9 +1428,16 @@ class Engine:
             if first:
                 order_dF(3 - bi)
             yield
-            self._wgrad(blk["pre2"], L.GATHER_FWD_REFLECT, y1, None, A, N, hl, wl, hl, wl, cout, 0, acc, side)
+            if not pair:
+                self._wgrad(blk["pre2"], L.GATHER_FWD_REFLECT, y1, None, A, N, hl, wl, hl, wl, cout, 0, acc, side)
+            A2 = A
             Bz = self._dgrad_dec(blk["pre2"], A, N, hl, wl, buf(pfx + "dz.pre1.%d" % bi, (N, hl, wl, cout)), actsrc=y1)
-            self._wgrad(blk["pre1"], L.GATHER_FWD_REFLECT, xin, None, Bz, N, hl, wl, hl, wl, cin, 0, acc, side)
+            if pair:
+                if _HP_WGRAD:
+                    self.amax.get(Bz)
+                    self.amax.get(xin)
+                self._wgrad(blk["pre2"], L.GATHER_FWD_REFLECT, y1, None, A2, N, hl, wl, hl, wl, cout, 0, acc, side)
+            self._wgrad(blk["pre1"], L.GATHER_FWD_REFLECT, xin, None, Bz, N, hl, wl, hl, wl, cin, 0, acc, side, fork=not pair)
             if bi == 0:
                 if not first:
                     order_dF(4)

@@ -477,6 +477,8 @@ def build_pack_table(jobs, device):
     """jobs: list of (kind, w, wp, c_begin, c_count) over torch tensors that never move.  Returns the device-resident table
     (jobs, blk2job, nblocks) for pack_weights_batched."""
     lib = _lib.load()
+    if not jobs:
+        return None, None, 0
     arr = (_lib.PackJob * len(jobs))()
     blk2job = []
     for i, job in enumerate(jobs):
@@ -497,12 +499,17 @@ def build_pack_table(jobs, device):
 def pack_weights_amax(table):
     """max |w| of every fp16-pair job's weight tensor into its slot (zeroed by the caller); before pack_weights_batched"""
     raw, b2j, nblocks = table
+    if nblocks == 0:
+        return
     _lib.check(_lib.load().fp_pack_weights_amax(raw.data_ptr(), b2j.data_ptr(), nblocks, stream()), "fp_pack_weights_amax")
 
 
-def pack_weights_batched(table):
+def pack_weights_batched(table, max_wgs=0):
+    """max_wgs > 0: a persistent launch of at most that many workgroups (a repack on a side stream beside a latency-bound chain)"""
     raw, b2j, nblocks = table
-    _lib.check(_lib.load().fp_pack_weights_batched(raw.data_ptr(), b2j.data_ptr(), nblocks, stream()), "fp_pack_weights_batched")
+    if nblocks == 0:
+        return
+    _lib.check(_lib.load().fp_pack_weights_batched_capped(raw.data_ptr(), b2j.data_ptr(), nblocks, int(max_wgs), stream()), "fp_pack_weights_batched")
 
 
 def colsum(x2d, out, accumulate=False):

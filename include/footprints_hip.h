@@ -107,6 +107,10 @@ typedef struct fp_pack_job {
 } fp_pack_job;
 int32_t fp_pack_job_blocks(int32_t kind, int32_t Cout, int32_t KH, int32_t KW, int32_t c_count);
 int fp_pack_weights_batched(const fp_pack_job* jobs_dev, const int32_t* blk2job_dev, int32_t nblocks, fp_stream_t stream);
+/* the same launch, persistent: at most `max_wgs` workgroups (> 0) walk the nblocks virtual blocks -- a repack on a side stream must not take
+ * the wave slots of the chain it runs beside (Engine.refresh_packed; 0 = one workgroup per virtual block) */
+int fp_pack_weights_batched_capped(const fp_pack_job* jobs_dev, const int32_t* blk2job_dev, int32_t nblocks, int32_t max_wgs,
+                                   fp_stream_t stream);
 
 /* packed-weight sizes (floats) and packers; w_oihw is the torch Conv2d.weight [Cout][Cin][KH][KW] */
 int64_t fp_packed_weight_elems(int32_t Cout, int32_t Cin, int32_t KH, int32_t KW, int32_t for_dgrad, int32_t stem);

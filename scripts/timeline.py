@@ -101,3 +101,14 @@ if len(sys.argv) > 3 and sys.argv[3] == "buckets":
             last = t
         top = sorted(names.items(), key=lambda kv: -kv[1])[:3]
         print("%3d ms: [%3.0f%% %3.0f%%] %s" % (b, c1 / 1e4, c2 / 1e4, "  ".join("%s %.0f" % kv for kv in top)))
+
+if len(sys.argv) > 3 and sys.argv[3] == "trace":
+    # the whole step in launch order: start / end in us from the step's start, stream, kernels running when it started, name
+    print("\nordered trace of the step (us from the previous Adam's end):")
+    import bisect
+    ends = sorted(e for _, _, e, _ in step)
+    for k, (n, s, e, st) in enumerate(step):
+        running = sum(1 for (n2, s2, e2, st2) in step[max(0, k - 12):k] if e2 > s)
+        nm = n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+        nm = nm.replace("conv3x3_tile_bf3_kernel", "tile").replace("wgrad3x3_hp_pf_kernel", "wgrad_pf")
+        print("%9.1f %9.1f %7.1f s%d +%d %s" % ((s - t0) / 1e3, (e - t0) / 1e3, (e - s) / 1e3, st, running, nm[:90]))

@@ -62,11 +62,12 @@ def chan_relerr(got, ref):
     return (d / s).tolist()
 
 
-def oracle_grads(P, B, cpu_batch, dtype, fix_batch=None, perturb=0.0, seed=0):
+def oracle_grads(P, B, cpu_batch, dtype, fix_batch=None, perturb=0.0, seed=0, record=None):
     """one train-mode fwd + loss + bwd of the CPU oracle in `dtype` -> (outputs, losses, {name: grad}, trainer, batch used).
     fix_batch(batch, outputs) -> batch: applied between the forward and the loss (the outputs do not depend on the targets).
     perturb > 0: the image is multiplied by (1 + perturb * u), u uniform in [-1, 1) (seeded) -- "another conforming fp32
-    implementation": a perturbation at round-off level draws a different set of ReLU-kink decisions (see fp32_spread)"""
+    implementation": a perturbation at round-off level draws a different set of ReLU-kink decisions (see fp32_spread).
+    record (optional list): receives every encoder BasicBlock output with its gradient retained (oracle/restatement.py resnet_encoder)"""
     from oracle import restatement as R
     Pd = OrderedDict((k, v.to(dtype)) for k, v in P.items())
     Bd = OrderedDict((k, v.to(dtype) if v.is_floating_point() else v.clone()) for k, v in B.items())
@@ -75,7 +76,7 @@ def oracle_grads(P, B, cpu_batch, dtype, fix_batch=None, perturb=0.0, seed=0):
         g = torch.Generator().manual_seed(1234 + seed)
         cpu_batch = OrderedDict(cpu_batch)
         cpu_batch["image"] = cpu_batch["image"] * (1.0 + perturb * (torch.rand(cpu_batch["image"].shape, generator=g) * 2 - 1))
-    out = R.footprint_network(cpu_batch["image"].to(dtype), tr.P, tr.B, True)
+    out = R.footprint_network(cpu_batch["image"].to(dtype), tr.P, tr.B, True, record=record)
     used = cpu_batch if fix_batch is None else fix_batch(cpu_batch, out)
     losses, _ = R.loss_manager(out, OrderedDict((k, v.to(dtype)) for k, v in used.items()))
     for p in tr.P.values():

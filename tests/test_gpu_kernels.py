@@ -262,10 +262,55 @@ def test_pack_weights_batched_matches_single_launches():
     add(L.PACK_DGRAD, w, ops.packed_weight_elems(64, 64, 3, True), 64, 64, lambda o: ops.pack_conv_weight_dgrad_slice(w, o, 64, 64))
     w2 = ws[1]
     add(L.PACK_UP2_FWD, w2, ops.up2_packed_weight_elems(48, 24), 8, 24, lambda o: ops.pack_up2_weight(w2, o, 8, 24))
+    # split layouts (bf16 triples, scaled fp16 pairs): the tile form of the batched kernel against the element-wise single-tensor kernels
+    for w in ws[1:]:
+        Cout, Cin, K, _ = w.shape
+        for dg in (False, True):
+            add(L.PACK_DGRAD_BF3 if dg else L.PACK_FWD_BF3, w, ops.packed_weight_elems_bf3(Cout, Cin, K, dg), 0, Cin,
+                lambda o, w=w, dg=dg: ops.pack_conv_weight_bf3(w, o, dg))
+    add(L.PACK_UP2_FWD_BF3, w, ops.up2_packed_weight_elems(64, 64) * 3 // 2, 0, 64, lambda o: ops.pack_up2_weight_bf3(w, o, 0, 64))
+    add(L.PACK_UP2_DGRAD_BF3, w, ops.up2_packed_weight_elems(64, 64) * 3 // 2, 0, 64, lambda o: ops.pack_up2_weight_dgrad_bf3(w, o, 0, 64))
+    nplain = len(jobs)
+    for w in ws[1:]:
+        Cout, Cin, K, _ = w.shape
+        for dg in (False, True):
+            slot_a, slot_b = ops.new_slot(), ops.new_slot()
+            a, b = (torch.full((ops.packed_weight_elems_hp(Cout, Cin, K, dg),), float("nan"), device="cuda") for _ in range(2))
+            ops.pack_conv_weight_hp(w, a, slot_a, dg)
+            single.append(a)
+            jobs.append((L.PACK_DGRAD_HP if dg else L.PACK_FWD_HP, w, b, 0, Cin, slot_b))
     table = ops.build_pack_table(jobs, "cuda")
-    ops.pack_weights_batched(table)
-    for a, (_, _, b, _, _) in zip(single, jobs):
-        assert not torch.isnan(a).any() and torch.equal(a, b)
+    for max_wgs in (0, 3):                                  # one workgroup per virtual block; three persistent workgroups
+        for j in jobs:
+            j[2].fill_(float("nan"))
+        ops.pack_weights_amax(table)
+        ops.pack_weights_batched(table, max_wgs=max_wgs)
+        for i, (a, j) in enumerate(zip(single, jobs)):
+            assert not torch.isnan(a).any() and torch.equal(a.view(torch.int32), j[2].view(torch.int32)), (max_wgs, i, j[0], tuple(j[1].shape), j[3:5])
+    # the phase layouts as fp16 pairs have no single-tensor packer: (h + m) * 2^-k must reproduce the fp32 phase layout to 2^-21, with one power
+    # of two per tensor, in the same [virtual tap][chunk][column][16] order with the two planes interleaved per (tap, chunk)
+    for kind32, kind_hp, dg in ((L.PACK_UP2_FWD, L.PACK_UP2_FWD_HP, False), (L.PACK_UP2_DGRAD, L.PACK_UP2_DGRAD_HP, True)):
+        n = ops.up2_packed_weight_elems(64, 64)
+        ref, hp_, s = torch.empty(n, device="cuda"), torch.full((n,), float("nan"), device="cuda"), ops.new_slot()
+        t32 = ops.build_pack_table([(kind32, w, ref, 0, 64)], "cuda")
+        thp = ops.build_pack_table([(kind_hp, w, hp_, 0, 64, s)], "cuda")
+        ops.pack_weights_batched(t32)
+        ops.pack_weights_amax(thp)
+        ops.pack_weights_batched(thp, max_wgs=2)
+        ncols = 64
+        pair = hp_.view(torch.float16).view(-1, 2, ncols, 16).float()
+        got = pair[:, 0] + pair[:, 1]
+        if kind32 == L.PACK_UP2_DGRAD:                      # fp32 layout: taps r*4+s; fp16-pair layout: [phase][tap] with r = (py+1)%2 + 2a, s = (px+1)%2 + 2b
+            r32 = ref.view(16, -1, ncols, 16)
+            order = [(((ph >> 1) + 1) % 2 + 2 * (tp >> 1)) * 4 + ((ph & 1) + 1) % 2 + 2 * (tp & 1) for ph in range(4) for tp in range(4)]
+            want = r32[order].reshape(-1, ncols, 16)
+        else:
+            want = ref.view(-1, ncols, 16)
+        big = want.abs() > 0.1 * want.abs().max()
+        ratio = float((got[big] / want[big]).median())
+        scale = 2.0 ** round(float(np.log2(ratio)))
+        assert abs(ratio / scale - 1.0) < 1e-5, ratio
+        assert ((got / scale - want).abs() <= want.abs() * 2.0 ** -21 + 1e-30).all(), kind_hp
 
 
 # ----------------------------------------------------------------------------------------------------------
