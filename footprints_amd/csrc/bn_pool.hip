@@ -65,13 +65,17 @@ __global__ void __launch_bounds__(256) bn_stats_kernel(const float* __restrict__
 }
 
 // one wave per channel: lane l merges partials l, l+64, ... in order, then a fixed shuffle tree merges the lanes
+// WPC = waves per channel: 1 (four channels per workgroup) or 4 (one channel per workgroup: the 720 .. 2 880 tile partials of the layer-1 / stem
+// convolutions took one wave 10-14 us, on the critical path of the encoder's forward chain; the four waves' results merge through LDS in order)
+template <int WPC>
 __global__ void __launch_bounds__(256) bn_stats_final_kernel(const float* __restrict__ part, int nblk, int C,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              float eps, float momentum, float* running_mean, float* running_var,
                                                              long long* nbt, float* save_mean, float* save_invstd, float* scale,
                                                              float* shift) {
-  const int lane = threadIdx.x & 63;
-  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  __shared__ double wsm[WPC == 4 ? 12 : 1];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = WPC == 4 ? blockIdx.x : blockIdx.x * 4 + wave;
   if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
   if (c >= C) return;
   // the merge of the per-block triples runs in double (round 4; ATen's CPU BatchNorm accumulates in double too, at::acc_type<float, false>): a
@@ -87,7 +91,7 @@ __global__ void __launch_bounds__(256) bn_stats_final_kernel(const float* __rest
     a.n = n;
   };
   Wd wd{0.0, 0.0, 0.0};
-  for (int b = lane; b < nblk; b += 64) {
+  for (int b = WPC == 4 ? threadIdx.x : lane; b < nblk; b += 64 * WPC) {
     const float* p = part + ((size_t)b * C + c) * 3;
     merge(wd, Wd{(double)p[0], (double)p[1], (double)p[2]});
   }
@@ -95,6 +99,12 @@ __global__ void __launch_bounds__(256) bn_stats_final_kernel(const float* __rest
   for (int o = 32; o > 0; o >>= 1) {
     const Wd t{__shfl_down(wd.n, o, 64), __shfl_down(wd.mean, o, 64), __shfl_down(wd.m2, o, 64)};
     merge(wd, t);
+  }
+  if (WPC == 4) {                                     // (the whole workgroup serves one channel: no thread has left)
+    if (lane == 0 && wave > 0) { wsm[wave * 3 + 0] = wd.n; wsm[wave * 3 + 1] = wd.mean; wsm[wave * 3 + 2] = wd.m2; }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    for (int k = 1; k < 4; ++k) merge(wd, Wd{wsm[k * 3 + 0], wsm[k * 3 + 1], wsm[k * 3 + 2]});
   }
   const Wf w{(float)wd.n, (float)wd.mean, (float)wd.m2};
   if (lane != 0) return;
@@ -347,7 +357,7 @@ extern "C" int fp_bn_train_stats(const float* z, int64_t M, int32_t C, const flo
   FP_REQUIRE(workspace_bytes >= fp_bn_workspace(M, C), "fp_bn_train_stats: workspace too small");
   const int nblk = bn_blocks(M, C);
   fp_launch(bn_stats_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, z, (int)M, C, (float*)workspace);
-  fp_launch(bn_stats_final_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, nblk,
+  fp_launch(bn_stats_final_kernel<1>, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, nblk,
                      C, gamma, beta, eps, momentum, running_mean, running_var, (long long*)num_batches_tracked, save_mean,
                      save_invstd, scale, shift);
   return fp_check_launch("fp_bn_train_stats");
@@ -360,7 +370,11 @@ extern "C" int fp_bn_train_stats_partials(const float* part, int32_t nblk, int32
                                           float* save_mean, float* save_invstd, float* scale, float* shift, fp_stream_t stream) {
   FP_REQUIRE(part && gamma && beta && save_mean && save_invstd && scale && shift, "fp_bn_train_stats_partials: null pointer");
   FP_REQUIRE(nblk > 0 && C > 0, "fp_bn_train_stats_partials: empty problem");
-  fp_launch(bn_stats_final_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, part, (int)nblk, C, gamma, beta, eps, momentum,
+  if (nblk > 256)
+    fp_launch(bn_stats_final_kernel<4>, dim3(C), dim3(256), 0, (hipStream_t)stream, part, (int)nblk, C, gamma, beta, eps, momentum,
+            running_mean, running_var, (long long*)num_batches_tracked, save_mean, save_invstd, scale, shift);
+  else
+    fp_launch(bn_stats_final_kernel<1>, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, part, (int)nblk, C, gamma, beta, eps, momentum,
             running_mean, running_var, (long long*)num_batches_tracked, save_mean, save_invstd, scale, shift);
   return fp_check_launch("fp_bn_train_stats_partials");
 }

@@ -21,7 +21,8 @@
 
 #include "fp_common.h"
 
-int fp_stem_tile_dispatch(const fp_conv_desc* d, const float* img, const float* wpacked, const float* bias, float* y, hipStream_t stream);
+int fp_stem_tile_dispatch(const fp_conv_desc* d, const float* img, const float* wpacked, const float* bias, float* y, hipStream_t stream,
+                          const FpBnSink& sink);
 int fp_conv3x3_tile_dispatch(const fp_conv_desc* d, const float* src0, const float* src1, const float* wpacked, const float* bias,
                              const float* addend, const float* addend_mask, const float* actsrc, float* y, hipStream_t stream);
 
@@ -579,7 +580,7 @@ extern "C" int64_t fp_conv_igemm_workspace(const fp_conv_desc* d) {
 extern "C" int fp_conv_igemm(const fp_conv_desc* d, const float* src0, const float* src1, const float* wpacked,
                              const float* bias, const float* addend, const float* addend_mask, const float* actsrc,
                              float* y, void* workspace, int64_t workspace_bytes, fp_stream_t stream_) {
-  (void)fp_take_bn_sink();                        // a statistics sink armed for a tile convolution must not outlive a launch that cannot emit
+  const FpBnSink bn_sink = fp_take_bn_sink();     // a statistics sink must not outlive a launch that cannot emit; the stem's tile kernel can
   hipStream_t stream = (hipStream_t)stream_;
   FP_REQUIRE(d && src0 && wpacked && y, "fp_conv_igemm: null pointer");
   FP_REQUIRE(d->N > 0 && d->OH > 0 && d->OW > 0 && d->Nout > 0, "fp_conv_igemm: empty problem");
@@ -606,7 +607,7 @@ extern "C" int fp_conv_igemm(const fp_conv_desc* d, const float* src0, const flo
              "fp_conv_igemm: problem too large");
 
   if (stem) {    // patch-in-LDS kernel (stem_tile.hip); shapes / epilogues it does not take stay on the flattened path
-    const int rc = fp_stem_tile_dispatch(d, src0, wpacked, bias, y, stream);
+    const int rc = fp_stem_tile_dispatch(d, src0, wpacked, bias, y, stream, bn_sink);
     if (rc != -1000) return rc;
   }
   if (!stem) {   // 3x3 stride-1 convs on large grids: halo-tile kernel (conv3x3_tile.hip)

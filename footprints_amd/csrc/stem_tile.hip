@@ -18,14 +18,21 @@ struct StemArgs {
   const float* bias;   // optional (folded BatchNorm shift)
   float* y;            // [N][OH][OW][64]
   int N, IH, IW, OH, OW, tilesX, tilesY, act;
+  float* bn_part;      // train-mode BatchNorm behind the stem (no bias, no activation): Welford partials [pixel tile][64][3], or null
 };
 
 constexpr int TH = 8, TW = 16, PH = 2 * TH + 5, PW = 2 * TW + 5, PWS = 40;   // 21 x 37 patch, row stride 40
 
 __global__ void __launch_bounds__(256) stem_tile_kernel(const StemArgs a) {
   __shared__ float P[3 * PH * PWS];
+  __shared__ __attribute__((aligned(16))) int KT[2 * 80];      // patch offset of k = 2 * step + h, [h][step]; -1 beyond the 147 taps
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, idx = lane & 31, h = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
+  if (t < 160) {                                    // (ky, kx, ci) of every K index once per workgroup: two divisions per K-step and lane otherwise
+    const int hh = t / 80, st = t - hh * 80, kk = 2 * st + hh;
+    const int ky = kk / 21, rem = kk - ky * 21, kx = rem / 3, ci = rem - kx * 3;
+    KT[t] = kk < 147 ? (ci * PH + ky) * PWS + (kx & 1) * (PWS / 2) + (kx >> 1) : -1;
+  }
   int b = blockIdx.x;
   const int tx = b % a.tilesX; b /= a.tilesX;
   const int ty = b % a.tilesY;
@@ -61,13 +68,13 @@ __global__ void __launch_bounds__(256) stem_tile_kernel(const StemArgs a) {
     const float4 w3 = *reinterpret_cast<const float4*>(wl + (size_t)cc * 64 * 16 + 12);
     // lane-parity select of the weight pair of every K-step by bit-select (a ?: over an array element was lowered to scratch)
     const unsigned hm = 0u - (unsigned)h;
+    const int4 ko0 = *reinterpret_cast<const int4*>(KT + h * 80 + cc * 8), ko1 = *reinterpret_cast<const int4*>(KT + h * 80 + cc * 8 + 4);
+    const int kos[8] = {ko0.x, ko0.y, ko0.z, ko0.w, ko1.x, ko1.y, ko1.z, ko1.w};
     auto step = [&](int s, float we, float wo) {
-      const int kk = cc * 16 + 2 * s + h;
-      const int kc = min(kk, 146);
-      const int ky = kc / 21, rem = kc - ky * 21, kx = rem / 3, ci = rem - kx * 3;
-      const int koff = (ci * PH + ky) * PWS + (kx & 1) * (PWS / 2) + (kx >> 1);   // adjacent lanes -> adjacent banks (stride-2 reads conflicted)
-      const float bv = __uint_as_float((__float_as_uint(wo) & hm) | (__float_as_uint(we) & ~hm));   // zero for kk >= 147 (packed zeros)
-      const float a0 = kk < 147 ? P[pbase[0] + koff] : 0.f, a1 = kk < 147 ? P[pbase[1] + koff] : 0.f;
+      const int koff = kos[s];                         // adjacent lanes -> adjacent banks (stride-2 reads conflicted)
+      const float bv = __uint_as_float((__float_as_uint(wo) & hm) | (__float_as_uint(we) & ~hm));   // zero beyond the 147 taps (packed zeros)
+      const int kq = max(koff, 0);
+      const float a0 = koff >= 0 ? P[pbase[0] + kq] : 0.f, a1 = koff >= 0 ? P[pbase[1] + kq] : 0.f;
       acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc[0], 0, 0, 0);
       acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc[1], 0, 0, 0);
     };
@@ -76,6 +83,50 @@ __global__ void __launch_bounds__(256) stem_tile_kernel(const StemArgs a) {
   }
   const int co = wn * 32 + idx;
   const float bias = a.bias ? a.bias[co] : 0.f;
+  if (a.bn_part) {
+    // BatchNorm statistics out of the epilogue, as in conv3x3_tile_bf3.hip (round 4: the statistics pass over the 94 MB activation was 35-50 us
+    // at the very start of the step, alone on the GPU): a lane's 32 pixels of channel `co` -> two-pass (count, mean, M2) -> Chan merge with the
+    // other half-wave -> across the two waves that share the channel through LDS, fixed order -> part[pixel tile][co]
+    auto ok_at = [&](int i, int r) {
+      const int pt = (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      return y0 + pt / TW < a.OH && x0 + pt % TW < a.OW;
+    };
+    float cnt = 0.f, sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const bool ok = ok_at(i, r);
+        cnt += ok ? 1.f : 0.f;
+        sum += ok ? acc[i][r] : 0.f;
+      }
+    FpWf w{cnt, cnt > 0.f ? sum / cnt : 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float dv = acc[i][r] - w.mean;
+        w.m2 += ok_at(i, r) ? dv * dv : 0.f;
+      }
+    const FpWf o{__shfl_xor(w.n, 32, 64), __shfl_xor(w.mean, 32, 64), __shfl_xor(w.m2, 32, 64)};
+    FpWf lo = h == 0 ? w : o;                            // both half-waves form merge(h = 0, h = 1)
+    fp_wf_merge(lo, h == 0 ? o : w);
+    __syncthreads();                                     // every wave is done with the patch
+    float* st = P;                                       // [wave][32][3]
+    if (h == 0) {
+      float* q = st + (wave * 32 + idx) * 3;
+      q[0] = lo.n; q[1] = lo.mean; q[2] = lo.m2;
+    }
+    __syncthreads();
+    if (t < 64) {                                        // channel t: waves (wm = 0, wn) then (wm = 1, wn)
+      const float* q0 = st + ((t >> 5) * 32 + (t & 31)) * 3;
+      const float* q1 = st + ((2 + (t >> 5)) * 32 + (t & 31)) * 3;
+      FpWf m{q0[0], q0[1], q0[2]};
+      fp_wf_merge(m, FpWf{q1[0], q1[1], q1[2]});
+      float* out = a.bn_part + ((size_t)blockIdx.x * 64 + t) * 3;
+      out[0] = m.n; out[1] = m.mean; out[2] = m.m2;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -192,13 +243,21 @@ int fp_stem_wgrad_tile_dispatch(const fp_conv_desc* d, const float* img, const f
 }
 
 // -1000 = not handled (caller falls back to the flattened kernel)
-int fp_stem_tile_dispatch(const fp_conv_desc* d, const float* img, const float* wpacked, const float* bias, float* y, hipStream_t stream) {
+int fp_stem_tile_dispatch(const fp_conv_desc* d, const float* img, const float* wpacked, const float* bias, float* y, hipStream_t stream,
+                          const FpBnSink& sink) {
   static const bool off = getenv("FP_NO_STEM_TILE") && atoi(getenv("FP_NO_STEM_TILE"));
   if (off || d->Nout != 64 || (d->epi & ~(unsigned)FP_EPI_BIAS) || d->IH != 2 * d->OH || d->IW != 2 * d->OW) return -1000;
   StemArgs a;
   a.img = img; a.w = wpacked; a.bias = (d->epi & FP_EPI_BIAS) ? bias : nullptr; a.y = y;
   a.N = d->N; a.IH = d->IH; a.IW = d->IW; a.OH = d->OH; a.OW = d->OW; a.act = d->act;
   a.tilesX = (int)fp_ceil_div(d->OW, TW); a.tilesY = (int)fp_ceil_div(d->OH, TH);
+  a.bn_part = nullptr;
+  // statistics sink (fp_bn_stats_out_next, forward form): the stored value is the accumulator itself only without bias / activation
+  const int64_t ntiles = (int64_t)d->N * a.tilesX * a.tilesY;
+  if (sink.part && !sink.z && !a.bias && d->act == FP_ACT_NONE && ntiles * 64 * 3 <= sink.cap_floats) {
+    a.bn_part = sink.part;
+    if (sink.nblk_out) *sink.nblk_out = (int32_t)ntiles;
+  }
   fp_launch(stem_tile_kernel, dim3(d->N * a.tilesX * a.tilesY), dim3(256), 0, stream, a);
   return fp_check_launch("fp_conv_igemm(stem)");
 }

@@ -861,7 +861,14 @@ class Engine:
         # ---- encoder --------------------------------------------------------------------------------
         h, w = H // 2, W // 2
         z0 = buf("z0", (N, h, w, 64))
+        cell = None
+        if training and ops._BN_EPI:            # the stem's tile kernel writes the Welford partials of its output (one per 8 x 16 pixel tile and channel)
+            self.bn0.stats_nblk = 0
+            self.bn0.stats_part = buf("bn.part0", (N * ((h + 7) // 8) * ((w + 15) // 16) * 64 * 3,))
+            cell = ops.bn_stats_out_next(self.bn0.stats_part)
         ops.conv_igemm(ops.make_desc(N, h, w, H, W, 3, 0, 64, 7, 2, 3, L.GATHER_STEM), image, None, self.stem.wp, z0)
+        if cell is not None:
+            self.bn0.stats_nblk = int(cell.value)
         f0 = self._bn(self.bn0, z0, buf("f0", (N, h, w, 64)), training)
         hp, wp_ = (h + 1) // 2, (w + 1) // 2
         pool = buf("pool", (N, hp, wp_, 64))

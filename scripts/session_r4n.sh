@@ -1,0 +1,17 @@
+#!/bin/bash
+# GPU box: stem statistics out of the epilogue + K-offset table, four-wave statistics merge
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r4n; mkdir -p $O
+cd $R
+t0=$(date +%s)
+timeout 600 python -m pytest tests/test_gpu_kernels.py -x -q -k "stem or bn or head" > $O/pytest_kernels.log 2>&1
+echo "pytest kernels rc=$? t=$(( $(date +%s)-t0 ))"
+timeout 900 python -m pytest tests/test_gpu_hp.py tests/test_gpu_network.py tests/test_gpu_trainer.py tests/test_gpu_segmentation.py -x -q > $O/pytest_net.log 2>&1
+echo "pytest net rc=$? t=$(( $(date +%s)-t0 ))"
+bash scripts/ab_lib_step.sh kitti rounds=2 default default@FP_BN_EPI=0 > $O/ab_step.txt 2>&1
+echo "ab done t=$(( $(date +%s)-t0 ))"
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/pc; rocprofv3 --kernel-trace --stats -d /tmp/pc -- python $R/scripts/step_loop.py kitti 5 3 > /dev/null 2>&1
+python $R/scripts/timeline.py $(find /tmp/pc -name "*.db" | head -1) -2 trace > $O/trace_step.txt 2>&1
+echo "trace done t=$(( $(date +%s)-t0 ))"
+cd $R
+tail -3 $O/pytest_kernels.log; tail -3 $O/pytest_net.log; cat $O/ab_step.txt; head -3 $O/trace_step.txt

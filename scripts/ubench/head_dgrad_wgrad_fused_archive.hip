@@ -296,79 +296,6 @@ struct HeadDzWindow {
   }
 };
 
-__global__ void __launch_bounds__(256) head_dgrad_kernel(const float* __restrict__ dz, const float* __restrict__ w,
-                                                         const float* __restrict__ elu_src, float* __restrict__ dx, int H, int W,
-                                                         int Cin, int rows, int gpi, unsigned* amax_out) {
-  float ymax = 0.f;
-  __shared__ __attribute__((aligned(16))) float Ws0[9 * MAXC];
-  __shared__ __attribute__((aligned(16))) float Ws1[9 * MAXC];
-  load_head_weights(w, Cin, Ws0, Ws1);
-  __syncthreads();
-  const HeadLane l = head_lane(H, W, Cin, rows, gpi);
-  float4 w0[9], w1[9];
-#pragma unroll
-  for (int t = 0; t < 9; ++t) {
-    w0[t] = *reinterpret_cast<const float4*>(Ws0 + t * Cin + l.q * 4);
-    w1[t] = *reinterpret_cast<const float4*>(Ws1 + t * Cin + l.q * 4);
-  }
-  HeadDzWindow win;
-  win.init(dz, l.n, H, W, l.ox);
-  const size_t pix0 = ((size_t)l.n * H * W + l.ox) * Cin + l.q * 4;
-  const size_t rowstride = (size_t)W * Cin;
-  // dz rows py-1, py, py+1 in registers, row py+2 and the next row's ELU operand in flight (ring rotated by unrolling)
-  auto body = [&](int py, float2(&up)[3], float2(&md)[3], float2(&dn)[3], float2(&nxt)[3], float4& s_use, float4& s_load) {
-    win.row(py + 2, nxt);
-    if (elu_src) s_load = *reinterpret_cast<const float4*>(elu_src + pix0 + (size_t)min(py + 1, H - 1) * rowstride);
-    const HeadFold fy = head_fold(py, H);
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const float2 z[3] = {make_float2(fy.p * dn[k].x + fy.m1 * up[k].x, fy.p * dn[k].y + fy.m1 * up[k].y), md[k],
-                           make_float2(fy.m * up[k].x + fy.p2 * dn[k].x, fy.m * up[k].y + fy.p2 * dn[k].y)};
-#pragma unroll
-      for (int ky = 0; ky < 3; ++ky) {
-        const float4 a = w0[ky * 3 + k], b = w1[ky * 3 + k];
-        acc.x += z[ky].x * a.x + z[ky].y * b.x;
-        acc.y += z[ky].x * a.y + z[ky].y * b.y;
-        acc.z += z[ky].x * a.z + z[ky].y * b.z;
-        acc.w += z[ky].x * a.w + z[ky].y * b.w;
-      }
-    }
-    if (elu_src) {
-      const float4 s = s_use;
-      acc.x *= (s.x > 0.f ? 1.f : s.x + 1.f); acc.y *= (s.y > 0.f ? 1.f : s.y + 1.f);
-      acc.z *= (s.z > 0.f ? 1.f : s.z + 1.f); acc.w *= (s.w > 0.f ? 1.f : s.w + 1.f);
-    }
-    if (l.live) {
-      *reinterpret_cast<float4*>(dx + pix0 + (size_t)py * rowstride) = acc;
-      ymax = fp_amax4(ymax, acc);
-    }
-  };
-  float2 r0[3], r1[3], r2[3], r3[3];
-  float4 e0 = make_float4(0.f, 0.f, 0.f, 0.f), e1 = e0;
-  win.row(l.row0 - 1, r0);
-  win.row(l.row0, r1);
-  win.row(l.row0 + 1, r2);
-  if (elu_src) e0 = *reinterpret_cast<const float4*>(elu_src + pix0 + (size_t)l.row0 * rowstride);
-  for (int py = l.row0; py < l.rend; py += 4) {
-    body(py, r0, r1, r2, r3, e0, e1);
-    if (py + 1 >= l.rend) break;
-    body(py + 1, r1, r2, r3, r0, e1, e0);
-    if (py + 2 >= l.rend) break;
-    body(py + 2, r2, r3, r0, r1, e0, e1);
-    if (py + 3 >= l.rend) break;
-    body(py + 3, r3, r0, r1, r2, e1, e0);
-  }
-  if (amax_out) fp_amax_publish_block(amax_out, ymax);
-}
-
-// Weight gradient.  Round 4: SCATTER form over the input pixels -- a thread reads its four channels of x ONCE and multiplies them with the nine
-// neighbouring dZ values (two floats per pixel: 1/16 of x at 32 channels), instead of gathering x nine times per output pixel (nine float4
-// loads per thread: 17 TB/s through the L1s at 192 x 640, the kernel ran at 26 % of the HBM roof, profiles/round4_hbm_kernels.txt).  In terms
-// of the reflection-padded image xp (H+2 x W+2): dW[t] = sum over padded positions p of xp(p) * dZ(p - t); an input pixel (iy, ix) sits at the
-// padded position (iy+1, ix+1) and, when it is a mirror source, also at row 0 (iy == 1) / row H+1 (iy == H-2) and column 0 / W+1 likewise.
-// The pixel coordinates advance by carries (no division in the loop).
-// partial[block][(tap*Cin + c)*2 + o] and partial_b[block][2]
 // the two output channels of one (tap, input channel): a plain pair of floats in the library build -- a vector type invites the backend to
 // emit v_pk_add_f32 / v_pk_fma_f32 wherever both elements see the same operation -- and a two-element vector in the A/B builds below
 #if !defined(FP_HEAD_WGRAD_FMA) || FP_HEAD_WGRAD_FMA == 0
@@ -430,6 +357,175 @@ __device__ __forceinline__ void head_wfma4(fp_v2f (&a)[4], const float4& v, cons
   head_wfma(a[3], v.w, zz);
 #endif
 }
+// per-workgroup partial sums of the weight gradient: over the pixel slots of a wave (lanes q, q + Q, ...) by a fixed xor tree, over the four
+// waves through LDS in a fixed order -> out[(tap * Cin + c) * 2 + o], out[9 * Cin * 2 + o] (bias)
+__device__ __forceinline__ void head_wgrad_block_sums(fp_v2f (&acc)[9][4], fp_v2f bsum, int Cin, float* red, float* __restrict__ out) {
+  const int Q = Cin >> 2;
+  for (int o = Q; o < 64; o <<= 1) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+#if defined(FP_HEAD_WGRAD_PKRED)      // A/B build: the shuffle tree's additions as v_pk_add_f32 on the two ds_bpermute results (round 1's SLP form)
+        const fp_v2f o2 = {__shfl_xor(acc[t][c][0], o, 64), __shfl_xor(acc[t][c][1], o, 64)};
+        acc[t][c] += o2;
+#else
+        acc[t][c][0] += __shfl_xor(acc[t][c][0], o, 64);
+        acc[t][c][1] += __shfl_xor(acc[t][c][1], o, 64);
+#endif
+      }
+    bsum[0] += __shfl_xor(bsum[0], o, 64);
+    bsum[1] += __shfl_xor(bsum[1], o, 64);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();                                   // `red` may still be read as something else by a slower wave
+  if (lane < Q) {
+    float* dst = red + (wave * 32 + lane) * 74;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+#if FP_HEAD_WGRAD_FMA == 5
+        dst[(t * 4 + c) * 2 + 0] = acc[t][(c >> 1) * 2 + 0][c & 1];
+        dst[(t * 4 + c) * 2 + 1] = acc[t][(c >> 1) * 2 + 1][c & 1];
+#else
+        dst[(t * 4 + c) * 2 + 0] = acc[t][c][0];
+        dst[(t * 4 + c) * 2 + 1] = acc[t][c][1];
+#endif
+      }
+    dst[72] = bsum[0];
+    dst[73] = bsum[1];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < Q * 72; e += 256) {
+    const int qq = e / 72, j = e - qq * 72;
+    const float s = red[(0 * 32 + qq) * 74 + j] + red[(1 * 32 + qq) * 74 + j] + red[(2 * 32 + qq) * 74 + j] +
+                    red[(3 * 32 + qq) * 74 + j];
+    const int t = j / 8, c = (j >> 1) & 3, o = j & 1;
+    out[(t * Cin + qq * 4 + c) * 2 + o] = s;
+  }
+  if (threadIdx.x < 2) {
+    // each wave's Q lanes hold the same wave-total bias sum (all slots reduced): take lane 0 of each wave
+    const int o = threadIdx.x;
+    out[9 * Cin * 2 + o] = red[(0 * 32) * 74 + 72 + o] + red[(1 * 32) * 74 + 72 + o] + red[(2 * 32) * 74 + 72 + o] +
+                           red[(3 * 32) * 74 + 72 + o];
+  }
+}
+
+// WG: the head's weight gradient from the same pass (round 4).  The folded dZ window this kernel builds for the data gradient -- Z[t] = the
+// sum of dZ over the output pixels that read THIS input pixel through tap t -- is exactly what the weight gradient multiplies with the input
+// pixel: dW[o][c][t] = sum over pixels of x[c] * Z[t][o].  So the stand-alone weight-gradient pass (one more read of x, nine dZ loads per pixel,
+// latency-bound at 30 % of the HBM roof) becomes 72 multiply-adds per lane on registers the data gradient already holds; x is the ELU source
+// where the data gradient has one (the head's input IS the activation whose ELU' it applies), else `wg_x`.  The weights then come from LDS at
+// their use (their 72 registers go to the accumulators); per-workgroup partial sums as in head_wgrad_kernel, same reduce launch.
+template <bool WG>
+__global__ void __launch_bounds__(256) head_dgrad_kernel(const float* __restrict__ dz, const float* __restrict__ w,
+                                                         const float* __restrict__ elu_src, float* __restrict__ dx, int H, int W,
+                                                         int Cin, int rows, int gpi, unsigned* amax_out, const float* __restrict__ wg_x,
+                                                         float* __restrict__ wg_part) {
+  float ymax = 0.f;
+  __shared__ __attribute__((aligned(16))) float Ws0[9 * MAXC];
+  __shared__ __attribute__((aligned(16))) float Ws1[9 * MAXC];
+  __shared__ float red[WG ? 4 * 32 * 74 : 1];
+  load_head_weights(w, Cin, Ws0, Ws1);
+  __syncthreads();
+  const HeadLane l = head_lane(H, W, Cin, rows, gpi);
+  float4 w0[WG ? 1 : 9], w1[WG ? 1 : 9];
+  if (!WG) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      w0[t] = *reinterpret_cast<const float4*>(Ws0 + t * Cin + l.q * 4);
+      w1[t] = *reinterpret_cast<const float4*>(Ws1 + t * Cin + l.q * 4);
+    }
+  }
+  fp_v2f wacc[WG ? 9 : 1][4];
+  fp_v2f bsum = {0.f, 0.f};
+  if (WG) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) wacc[t][c] = fp_v2f{0.f, 0.f};
+  }
+  const float* xsrc = WG ? (elu_src ? elu_src : wg_x) : elu_src;        // the tensor whose row py + 1 is prefetched below
+  HeadDzWindow win;
+  win.init(dz, l.n, H, W, l.ox);
+  const size_t pix0 = ((size_t)l.n * H * W + l.ox) * Cin + l.q * 4;
+  const size_t rowstride = (size_t)W * Cin;
+  // dz rows py-1, py, py+1 in registers, row py+2 and the next row's ELU operand in flight (ring rotated by unrolling)
+  auto body = [&](int py, float2(&up)[3], float2(&md)[3], float2(&dn)[3], float2(&nxt)[3], float4& s_use, float4& s_load) {
+    win.row(py + 2, nxt);
+    if (xsrc) s_load = *reinterpret_cast<const float4*>(xsrc + pix0 + (size_t)min(py + 1, H - 1) * rowstride);
+    const HeadFold fy = head_fold(py, H);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 xw = WG && l.live ? s_use : make_float4(0.f, 0.f, 0.f, 0.f);    // clamped duplicate columns contribute nothing
+    int wo = l.q * 4;
+    if (WG) asm volatile("" : "+v"(wo));             // the weights are re-read from LDS per pixel: hoisted out of the row loop they cost 72 registers
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float2 z[3] = {make_float2(fy.p * dn[k].x + fy.m1 * up[k].x, fy.p * dn[k].y + fy.m1 * up[k].y), md[k],
+                           make_float2(fy.m * up[k].x + fy.p2 * dn[k].x, fy.m * up[k].y + fy.p2 * dn[k].y)};
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const float4 a = WG ? *reinterpret_cast<const float4*>(Ws0 + wo + (ky * 3 + k) * Cin) : w0[WG ? 0 : ky * 3 + k];
+        const float4 b = WG ? *reinterpret_cast<const float4*>(Ws1 + wo + (ky * 3 + k) * Cin) : w1[WG ? 0 : ky * 3 + k];
+        acc.x += z[ky].x * a.x + z[ky].y * b.x;
+        acc.y += z[ky].x * a.y + z[ky].y * b.y;
+        acc.z += z[ky].x * a.z + z[ky].y * b.z;
+        acc.w += z[ky].x * a.w + z[ky].y * b.w;
+        if constexpr (WG) head_wfma4(wacc[ky * 3 + k], xw, fp_v2f{z[ky].x, z[ky].y});
+      }
+    }
+    if (WG && l.live) {
+      bsum[0] += md[1].x;
+      bsum[1] += md[1].y;
+    }
+    if (elu_src) {
+      const float4 s = s_use;
+      acc.x *= (s.x > 0.f ? 1.f : s.x + 1.f); acc.y *= (s.y > 0.f ? 1.f : s.y + 1.f);
+      acc.z *= (s.z > 0.f ? 1.f : s.z + 1.f); acc.w *= (s.w > 0.f ? 1.f : s.w + 1.f);
+    }
+    if (l.live) {
+      *reinterpret_cast<float4*>(dx + pix0 + (size_t)py * rowstride) = acc;
+      ymax = fp_amax4(ymax, acc);
+    }
+  };
+  float2 r0[3], r1[3], r2[3], r3[3];
+  float4 e0 = make_float4(0.f, 0.f, 0.f, 0.f), e1 = e0;
+  win.row(l.row0 - 1, r0);
+  win.row(l.row0, r1);
+  win.row(l.row0 + 1, r2);
+  if (xsrc) e0 = *reinterpret_cast<const float4*>(xsrc + pix0 + (size_t)l.row0 * rowstride);
+  if constexpr (WG) {
+    // ONE body in the loop (the ring rotates by register copies: 26 moves per pixel): four unrolled bodies with exits between them made the
+    // compiler keep a copy of the 72 accumulators per path (256 VGPRs)
+    for (int py = l.row0; py < l.rend; ++py) {
+      body(py, r0, r1, r2, r3, e0, e1);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { r0[k] = r1[k]; r1[k] = r2[k]; r2[k] = r3[k]; }
+      e0 = e1;
+    }
+  } else {
+  for (int py = l.row0; py < l.rend; py += 4) {
+    body(py, r0, r1, r2, r3, e0, e1);
+    if (py + 1 >= l.rend) break;
+    body(py + 1, r1, r2, r3, r0, e1, e0);
+    if (py + 2 >= l.rend) break;
+    body(py + 2, r2, r3, r0, r1, e0, e1);
+    if (py + 3 >= l.rend) break;
+    body(py + 3, r3, r0, r1, r2, e1, e0);
+  }
+  }
+  if (amax_out) fp_amax_publish_block(amax_out, ymax);
+  if constexpr (WG) head_wgrad_block_sums(wacc, bsum, Cin, red, wg_part + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (9 * Cin * 2 + 2));
+}
+
+// Weight gradient.  Round 4: SCATTER form over the input pixels -- a thread reads its four channels of x ONCE and multiplies them with the nine
+// neighbouring dZ values (two floats per pixel: 1/16 of x at 32 channels), instead of gathering x nine times per output pixel (nine float4
+// loads per thread: 17 TB/s through the L1s at 192 x 640, the kernel ran at 26 % of the HBM roof, profiles/round4_hbm_kernels.txt).  In terms
+// of the reflection-padded image xp (H+2 x W+2): dW[t] = sum over padded positions p of xp(p) * dZ(p - t); an input pixel (iy, ix) sits at the
+// padded position (iy+1, ix+1) and, when it is a mirror source, also at row 0 (iy == 1) / row H+1 (iy == H-2) and column 0 / W+1 likewise.
+// The pixel coordinates advance by carries (no division in the loop).
+// partial[block][(tap*Cin + c)*2 + o] and partial_b[block][2]
 __global__ void __launch_bounds__(256) head_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dz,
                                                          float* __restrict__ part, int N, int H, int W, int Cin) {
   __shared__ float red[4 * 32 * 74];
@@ -521,56 +617,7 @@ __global__ void __launch_bounds__(256) head_wgrad_kernel(const float* __restrict
     if (ix >= W) { ix -= W; iy += 1; }
     if (iy >= H) iy -= H;
   }
-  // reduce over the pixel slots of this wave (lanes q, q+Q, q+2Q, ...), fixed xor tree
-  for (int o = Q; o < 64; o <<= 1) {
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-#if defined(FP_HEAD_WGRAD_PKRED)      // A/B build: the shuffle tree's additions as v_pk_add_f32 on the two ds_bpermute results (round 1's SLP form)
-        const fp_v2f o2 = {__shfl_xor(acc[t][c][0], o, 64), __shfl_xor(acc[t][c][1], o, 64)};
-        acc[t][c] += o2;
-#else
-        acc[t][c][0] += __shfl_xor(acc[t][c][0], o, 64);
-        acc[t][c][1] += __shfl_xor(acc[t][c][1], o, 64);
-#endif
-      }
-    bsum[0] += __shfl_xor(bsum[0], o, 64);
-    bsum[1] += __shfl_xor(bsum[1], o, 64);
-  }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane < Q) {
-    float* dst = red + (wave * 32 + lane) * 74;
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-#if FP_HEAD_WGRAD_FMA == 5
-        dst[(t * 4 + c) * 2 + 0] = acc[t][(c >> 1) * 2 + 0][c & 1];
-        dst[(t * 4 + c) * 2 + 1] = acc[t][(c >> 1) * 2 + 1][c & 1];
-#else
-        dst[(t * 4 + c) * 2 + 0] = acc[t][c][0];
-        dst[(t * 4 + c) * 2 + 1] = acc[t][c][1];
-#endif
-      }
-    dst[72] = bsum[0];
-    dst[73] = bsum[1];
-  }
-  __syncthreads();
-  float* out = part + (size_t)blockIdx.x * (9 * Cin * 2 + 2);
-  for (int e = threadIdx.x; e < Q * 72; e += 256) {
-    const int qq = e / 72, j = e - qq * 72;
-    const float s = red[(0 * 32 + qq) * 74 + j] + red[(1 * 32 + qq) * 74 + j] + red[(2 * 32 + qq) * 74 + j] +
-                    red[(3 * 32 + qq) * 74 + j];
-    const int t = j / 8, c = (j >> 1) & 3, o = j & 1;
-    out[(t * Cin + qq * 4 + c) * 2 + o] = s;
-  }
-  if (threadIdx.x < 2) {
-    // each wave's Q lanes hold the same wave-total bias sum (all slots reduced): take lane 0 of each wave
-    const int o = threadIdx.x;
-    out[9 * Cin * 2 + o] = red[(0 * 32) * 74 + 72 + o] + red[(1 * 32) * 74 + 72 + o] + red[(2 * 32) * 74 + 72 + o] +
-                           red[(3 * 32) * 74 + 72 + o];
-  }
+  head_wgrad_block_sums(acc, bsum, Cin, red, part + (size_t)blockIdx.x * (9 * Cin * 2 + 2));
 }
 
 __global__ void __launch_bounds__(256) head_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
@@ -666,9 +713,36 @@ extern "C" int fp_head_dgrad(const float* dzlow, const float* w_oihw, const floa
   FP_REQUIRE(dzlow && w_oihw && dx, "fp_head_dgrad: null pointer");
   FP_REQUIRE(head_cin_ok(Cin) && h >= 2 && w >= 2, "fp_head_dgrad: unsupported Cin=%d", Cin);
   const HeadGrid g = head_grid(N, h, w, Cin, 16);
-  fp_launch(head_dgrad_kernel, dim3(g.colblocks, N * g.gpi), dim3(256), 0, (hipStream_t)stream, dzlow, w_oihw, elu_src, dx, h, w,
-                     Cin, g.rows, g.gpi, amax_out);
+  fp_launch(head_dgrad_kernel<false>, dim3(g.colblocks, N * g.gpi), dim3(256), 0, (hipStream_t)stream, dzlow, w_oihw, elu_src, dx, h, w,
+                     Cin, g.rows, g.gpi, amax_out, (const float*)nullptr, (float*)nullptr);
   return fp_check_launch("fp_head_dgrad");
+}
+
+// fp_head_dgrad and fp_head_wgrad of the same head in one pass over dZ and x (head_dgrad_kernel<true>): `x` = the head's input (the tensor
+// fp_head_wgrad would be given); where the data gradient applies ELU' (`elu_src` != NULL) it must BE that tensor.  Workspace:
+// fp_head_dgrad_wgrad_workspace bytes of per-workgroup partial sums, reduced in a fixed order by the second launch.
+extern "C" int64_t fp_head_dgrad_wgrad_workspace(int32_t N, int32_t h, int32_t w, int32_t Cin) {
+  if (!head_cin_ok(Cin)) return -1;
+  const HeadGrid g = head_grid(N, h, w, Cin, 16);
+  return (int64_t)g.colblocks * N * g.gpi * (9 * Cin * 2 + 2) * (int64_t)sizeof(float);
+}
+extern "C" int fp_head_dgrad_wgrad(const float* dzlow, const float* w_oihw, const float* elu_src, const float* x, float* dx, float* dw_oihw,
+                                   float* db, int32_t N, int32_t h, int32_t w, int32_t Cin, int accumulate, void* workspace,
+                                   int64_t workspace_bytes, fp_stream_t stream) {
+  unsigned* amax_out = fp_take_amax_out();     // consumed first: an argument error below must not leave the sink armed
+  FP_REQUIRE(dzlow && w_oihw && x && dx && dw_oihw && db && workspace, "fp_head_dgrad_wgrad: null pointer");
+  FP_REQUIRE(head_cin_ok(Cin) && h >= 2 && w >= 2, "fp_head_dgrad_wgrad: unsupported Cin=%d", Cin);
+  FP_REQUIRE(!elu_src || elu_src == x, "fp_head_dgrad_wgrad: the ELU source must be the head's input");
+  FP_REQUIRE(workspace_bytes >= fp_head_dgrad_wgrad_workspace(N, h, w, Cin), "fp_head_dgrad_wgrad: workspace too small");
+  const HeadGrid g = head_grid(N, h, w, Cin, 16);
+  fp_launch(head_dgrad_kernel<true>, dim3(g.colblocks, N * g.gpi), dim3(256), 0, (hipStream_t)stream, dzlow, w_oihw, elu_src, dx, h, w,
+                     Cin, g.rows, g.gpi, amax_out, x, (float*)workspace);
+  int rc = fp_check_launch("fp_head_dgrad_wgrad");
+  if (rc) return rc;
+  const int per = 9 * Cin * 2 + 2;
+  fp_launch(head_wgrad_reduce_kernel, dim3((int)fp_ceil_div(per, 4)), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, dw_oihw, db,
+                     g.colblocks * N * g.gpi, Cin, accumulate);
+  return fp_check_launch("fp_head_dgrad_wgrad(reduce)");
 }
 
 extern "C" int64_t fp_head_wgrad_workspace(int32_t N, int32_t h, int32_t w, int32_t Cin) {

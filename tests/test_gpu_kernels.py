@@ -106,6 +106,34 @@ def test_conv_stem(N, H, W):
     d = ops.make_desc(N, OH, OW, H, W, 3, 0, 64, 7, 2, 3, L.GATHER_STEM)
     ops.conv_igemm(d, img.cuda(), None, pack(w, stem=True), y)
     check(nchw(y), ref, "conv_stem")
+    # the statistics sink (fp_bn_stats_out_next): (count, mean, M2) per 8 x 16 pixel tile and channel out of the stem's epilogue -> the same
+    # BatchNorm coefficients as the reduction over the stored tensor; one-shot; ragged tiles at the right / bottom edge count only real pixels
+    tiles = N * ((OH + 7) // 8) * ((OW + 15) // 16)
+    part = torch.full((tiles * 64 * 3 + 5,), float("nan"), device="cuda")
+    cell = ops.bn_stats_out_next(part)
+    y2 = torch.empty_like(y)
+    ops.conv_igemm(d, img.cuda(), None, pack(w, stem=True), y2)
+    torch.cuda.synchronize()
+    assert cell.value == tiles and torch.equal(y, y2)
+    used = tiles * 64 * 3
+    assert not bool(torch.isnan(part[:used]).any()) and bool(torch.isnan(part[used:]).all())
+    assert float(part[:used].view(tiles, 64, 3)[:, :, 0].sum(0).min()) == float(N * OH * OW) == float(part[:used].view(tiles, 64, 3)[:, :, 0].sum(0).max())
+    g, b = rnd((64,), 12, 0.5, 1.5).cuda(), rnd((64,), 13).cuda()
+    outs = [[torch.zeros(64, device="cuda") for _ in range(4)] for _ in range(2)]
+    rms, rvs = [torch.zeros(64, device="cuda") for _ in range(2)], [torch.ones(64, device="cuda") for _ in range(2)]
+    nbt = [torch.zeros((), dtype=torch.int64, device="cuda") for _ in range(2)]
+    ops.bn_train_stats_partials(part, tiles, 64, g, b, rms[0], rvs[0], nbt[0], *outs[0])
+    ops.bn_train_stats(y.view(-1, 64), g, b, rms[1], rvs[1], nbt[1], *outs[1])
+    yd = y.double().cpu().view(-1, 64)
+    mean, invstd = yd.mean(0), 1.0 / torch.sqrt(yd.var(0, unbiased=False) + 1e-5)
+    for k, want in enumerate((mean, invstd, g.double().cpu() * invstd, b.double().cpu() - mean * g.double().cpu() * invstd)):
+        for o in outs:
+            assert float((o[k].double().cpu() - want).abs().max() / want.abs().max()) < 2e-6, k
+    assert torch.allclose(rms[0], rms[1], rtol=1e-6, atol=1e-7) and torch.allclose(rvs[0], rvs[1], rtol=1e-6, atol=1e-7)
+    cell = ops.bn_stats_out_next(part)                             # a launch that cannot emit (bias) consumes the sink and reports 0
+    d.epi = L.EPI_BIAS
+    ops.conv_igemm(d, img.cuda(), None, pack(w, stem=True), y2, bias=b)
+    assert cell.value == 0
 
 
 # ----------------------------------------------------------------------------------------------------------
