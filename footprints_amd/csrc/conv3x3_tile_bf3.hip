@@ -160,13 +160,19 @@ conv3x3_tile_bf3_kernel(const Tile3Args a) {
   int t, lane, wave, idx, h, wm, wn;
 
   int ka = 0, kunscale = 0;                          // HP: source scale exponent, and -(ka + kw) for the epilogue (wave-uniform)
-  if (HP) {
-    unsigned ab = fp_amax_bits(a.amax_a);
-    if (a.amax_a1) ab = max(ab, fp_amax_bits(a.amax_a1));
-    ka = fp_hp_exponent(ab, FP_HP_TARGET_ACT);
-    kunscale = -(ka + fp_hp_exponent(fp_amax_bits(a.amax_w), FP_HP_TARGET_W));
-  }
-  const float sa = ldexpf(1.f, ka);                  // 2^ka, the source's scale
+  float sa = 1.f;                                    // 2^ka, the source's scale
+  float unscale = 1.f;                               // 2^kunscale: one fused multiply-add per element un-scales and adds the bias (wave-uniform)
+  // the three amax slots: one vector load now, reduced behind the first tile's operand loads (fp_amax3_issue, fp_common.h)
+  const unsigned amax_raw = HP ? fp_amax3_issue(a.amax_a, a.amax_a1, a.amax_w) : 0u;
+  auto scales_ready = [&]() __attribute__((always_inline)) {
+    if (!HP) return;
+    unsigned ma, ma1, mw;
+    fp_amax3_reduce(amax_raw, ma, ma1, mw);
+    ka = fp_hp_exponent(max(ma, ma1), FP_HP_TARGET_ACT);
+    kunscale = -(ka + fp_hp_exponent(mw, FP_HP_TARGET_W));
+    sa = ldexpf(1.f, ka);
+    unscale = ldexpf(1.f, kunscale);
+  };
   // buffer resources (sizes checked on the host: every operand is smaller than 2^31 bytes, so bit 31 of an offset means "out of range")
   const int cs = a.C - a.Clo;                        // channels of `src` (the skip tensor of the concat gather, else the whole input)
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src), 0, a.N * a.IH * a.IW * cs * 4, 0x00020000);
@@ -439,7 +445,6 @@ conv3x3_tile_bf3_kernel(const Tile3Args a) {
   };
 
   float ymax = 0.f;                                  // HP: largest stored magnitude of this lane over all its tiles (the consumer's scale)
-  const float unscale = HP ? ldexpf(1.f, kunscale) : 1.f;      // wave-uniform power of two: one fused multiply-add per element un-scales and adds the bias
 
   // ---- epilogue of one tile.  The flag tests are hoisted and every optional operand (addend, its mask, the activation source, the old
   // output) is loaded for eight rows BEFORE any arithmetic: element-at-a-time code serialised 16 dependent load latencies per
@@ -673,6 +678,7 @@ conv3x3_tile_bf3_kernel(const Tile3Args a) {
   g = decode(vb);
   setup();
   prefetch_tile();
+  scales_ready();
   for (;;) {
     if (PERSIST) lane_setup();
 #pragma unroll

@@ -350,9 +350,11 @@ __global__ void __launch_bounds__(256) igemm_hp_kernel(const IgemmArgs a) {
   const int tile_n = tile % a.tilesN, tile_m = tile / a.tilesN;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const FpGeom& g = a.g;
-  const int ka = fp_hp_exponent(fp_amax_bits(a.amax_a), FP_HP_TARGET_ACT);
+  unsigned ma, mw, unused;
+  fp_amax3_reduce(fp_amax3_issue(a.amax_a, a.amax_w, nullptr), ma, mw, unused);             // one round trip for both slots (fp_common.h)
+  const int ka = fp_hp_exponent(ma, FP_HP_TARGET_ACT);
   const float sa = ldexpf(1.f, ka);
-  const int kunscale = -(ka + fp_hp_exponent(fp_amax_bits(a.amax_w), FP_HP_TARGET_W));
+  const int kunscale = -(ka + fp_hp_exponent(mw, FP_HP_TARGET_W));
 
   // this lane's row of the GEMM = one output pixel (forward) / one input-gradient pixel (data gradient)
   int pn, py, px;

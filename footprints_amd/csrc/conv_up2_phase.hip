@@ -233,8 +233,10 @@ __global__ void __launch_bounds__(256) up2_phase_fwd_bf3_kernel(const PhaseArgs 
   const unsigned short* wq = reinterpret_cast<const unsigned short*>(a.w);
   int ka = 0, kunscale = 0;
   if (NP == 2) {
-    ka = fp_hp_exponent(fp_amax_bits(a.amax_a), FP_HP_TARGET_ACT);
-    kunscale = -(ka + fp_hp_exponent(fp_amax_bits(a.amax_w), FP_HP_TARGET_W));
+    unsigned ma, mw, unused;
+    fp_amax3_reduce(fp_amax3_issue(a.amax_a, a.amax_w, nullptr), ma, mw, unused);           // one round trip for both slots (fp_common.h)
+    ka = fp_hp_exponent(ma, FP_HP_TARGET_ACT);
+    kunscale = -(ka + fp_hp_exponent(mw, FP_HP_TARGET_W));
   }
 
   // operands through raw buffer loads: a 32-bit per-lane byte offset + a wave-uniform one (conv3x3_tile_bf3.hip, round 4)
@@ -402,8 +404,10 @@ __global__ void __launch_bounds__(256) up2_phase_dgrad_bf3_kernel(const PhaseDgr
   const int nsteps = 4 * a.KC16;
   int ka = 0, kunscale = 0;
   if (NP == 2) {
-    ka = fp_hp_exponent(fp_amax_bits(a.amax_a), FP_HP_TARGET_ACT);
-    kunscale = -(ka + fp_hp_exponent(fp_amax_bits(a.amax_w), FP_HP_TARGET_W));
+    unsigned ma, mw, unused;
+    fp_amax3_reduce(fp_amax3_issue(a.amax_a, a.amax_w, nullptr), ma, mw, unused);           // one round trip for both slots (fp_common.h)
+    ka = fp_hp_exponent(ma, FP_HP_TARGET_ACT);
+    kunscale = -(ka + fp_hp_exponent(mw, FP_HP_TARGET_W));
   }
 
   // operands through raw buffer loads (32-bit lane offset + wave-uniform offset; an offset with bit 31 set reads zeros: the zero padding

@@ -200,6 +200,28 @@ __device__ __forceinline__ unsigned fp_amax_bits(const unsigned* __restrict__ sl
   for (int i = 0; i < FP_AMAX_SLOTS; ++i) m = max(m, slot[i * FP_AMAX_STRIDE]);
   return m;
 }
+// Up to three slots in ONE memory round trip, issued early and reduced late (round 4).  fp_amax_bits reads a slot's sixteen sub-slots
+// through the scalar cache, eight at a time: a kernel that needs the source's, the skip tensor's and the weights' amax waited for four
+// DEPENDENT scalar round trips (2-3 us) before it issued its first operand load -- in front of every one of the ~250 split-operand launches
+// of a step, most of them 25-45 us long and alone on the GPU.  Here lanes 0-15 / 16-31 / 32-47 of the calling wave load one sub-slot each
+// with ONE vector load (`fp_amax3_issue`, result not waited for); the kernel sets up its addresses and issues its first operand loads; then
+// `fp_amax3_reduce` folds the sixteen lanes of each group by DPP row shifts and broadcasts the three maxima.  A null slot reads as 0.
+__device__ __forceinline__ unsigned fp_amax3_issue(const unsigned* __restrict__ s0, const unsigned* __restrict__ s1,
+                                                   const unsigned* __restrict__ s2) {
+  const int ln = (int)(threadIdx.x & 63), grp = ln >> 4;
+  const unsigned* sp = grp == 0 ? s0 : (grp == 1 ? s1 : (grp == 2 ? s2 : nullptr));
+  return sp ? sp[(ln & 15) * FP_AMAX_STRIDE] : 0u;
+}
+__device__ __forceinline__ void fp_amax3_reduce(unsigned raw, unsigned& m0, unsigned& m1, unsigned& m2) {
+  int v = (int)raw;                                  // bit patterns of non-negative floats: signed and unsigned order agree
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true));      // row_shr:1 (zero fill at the row start)
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true));      // row_shr:2
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true));      // row_shr:4
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true));      // row_shr:8 -> lane 15 of each row holds the row's maximum
+  m0 = (unsigned)__builtin_amdgcn_readlane(v, 15);
+  m1 = (unsigned)__builtin_amdgcn_readlane(v, 31);
+  m2 = (unsigned)__builtin_amdgcn_readlane(v, 47);
+}
 // exponent k with amax * 2^k in [2^target, 2^(target+1)); 0 for an all-zero tensor; inf / nan propagate through the data itself
 __device__ __forceinline__ int fp_hp_exponent(unsigned amax_bits, int target) {
   // (clamped so that 2^k is a finite float: the staging code multiplies by it; tensors whose largest element is below 2^-114 lose

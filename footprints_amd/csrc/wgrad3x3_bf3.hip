@@ -285,8 +285,10 @@ __global__ void __launch_bounds__(256, 2) wgrad3x3_bf3_v3_kernel(const W3Args a)
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUFN];
   int kx_ = 0, kz_ = 0;
   if (NP == 2) {
-    kx_ = fp_hp_exponent(fp_amax_bits(a.amax_x), FP_HP_TARGET_ACT);
-    kz_ = fp_hp_exponent(fp_amax_bits(a.amax_dz), FP_HP_TARGET_ACT);
+    unsigned mx, mz, unused;
+    fp_amax3_reduce(fp_amax3_issue(a.amax_x, a.amax_dz, nullptr), mx, mz, unused);
+    kx_ = fp_hp_exponent(mx, FP_HP_TARGET_ACT);
+    kz_ = fp_hp_exponent(mz, FP_HP_TARGET_ACT);
   }
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   int b = a.xcd ? fp_xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
@@ -500,8 +502,8 @@ template <int MODE, int D>
 __global__ void __launch_bounds__(256, D > 2 ? 1 : 2) wgrad3x3_hp_pf_kernel(const W3Args a) {
   constexpr int XBN = 2 * XP4;
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF4];
-  const int kx_ = fp_hp_exponent(fp_amax_bits(a.amax_x), FP_HP_TARGET_ACT);
-  const int kz_ = fp_hp_exponent(fp_amax_bits(a.amax_dz), FP_HP_TARGET_ACT);
+  const unsigned amax_raw = fp_amax3_issue(a.amax_x, a.amax_dz, nullptr);     // both amax slots: one vector load, reduced behind the first chunk's loads
+  int kx_ = 0, kz_ = 0;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   int b = a.xcd ? fp_xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
   const int cot = b % a.cotiles; b /= a.cotiles;
@@ -625,6 +627,12 @@ __global__ void __launch_bounds__(256, D > 2 ? 1 : 2) wgrad3x3_hp_pf_kernel(cons
   const float bias_on = want_bias ? 1.f : 0.f;
   // prologue: chunk 0 through slot 0 into buffer 0, then chunks 1 .. D into slots 1 .. D - 1, 0
   issue(std::integral_constant<int, 0>{});
+  {
+    unsigned mx, mz, unused;
+    fp_amax3_reduce(amax_raw, mx, mz, unused);
+    kx_ = fp_hp_exponent(mx, FP_HP_TARGET_ACT);
+    kz_ = fp_hp_exponent(mz, FP_HP_TARGET_ACT);
+  }
   stage(std::integral_constant<int, 0>{}, 0, cnt > 0 ? bias_on : 0.f);
   if (D > 1) issue(std::integral_constant<int, 1 % D>{});
   if (D > 2) issue(std::integral_constant<int, 2 % D>{});

@@ -159,8 +159,10 @@ __global__ void __launch_bounds__(256, 3) wgrad_up2_phase_bf3_kernel(const PWArg
   unsigned char* const Zs = lds + NP * PXPLANE;
   int kx_ = 0, kz_ = 0;
   if (NP == 2) {
-    kx_ = fp_hp_exponent(fp_amax_bits(a.amax_low), FP_HP_TARGET_ACT);
-    kz_ = fp_hp_exponent(fp_amax_bits(a.amax_dz), FP_HP_TARGET_ACT);
+    unsigned mx, mz, unused;
+    fp_amax3_reduce(fp_amax3_issue(a.amax_low, a.amax_dz, nullptr), mx, mz, unused);      // one round trip for both slots (fp_common.h)
+    kx_ = fp_hp_exponent(mx, FP_HP_TARGET_ACT);
+    kz_ = fp_hp_exponent(mz, FP_HP_TARGET_ACT);
   }
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, idx = lane & 31, h = lane >> 5;
   // XCD-contiguous logical ids: the ci x co tile workgroups of one pixel split stage the same X / dZ chunks and then share that XCD's
