@@ -18,6 +18,11 @@
 
 int fp_splitk_reduce_launch(const float* part, int SK, int64_t M, int Nout, const float* bias, const float* addend, const float* addend_mask,
                             const float* actsrc, float* y, int act, unsigned epi, hipStream_t stream, unsigned* amax_out = nullptr);
+int fp_splitk_reduce_bnb_launch(const float* part, int SK, int64_t M, int Nout, const float* bias, const float* addend, const float* addend_mask,
+                                const float* actsrc, float* y, int act, unsigned epi, hipStream_t stream, unsigned* amax_out, const float* z,
+                                const float* mean, const float* invstd, float* bpart, int64_t cap_floats, int* rc_out);
+int fp_splitk_reduce_stats_launch(const float* part, int SK, int64_t M, int Nout, float* y, hipStream_t stream, unsigned* amax_out, float* stats,
+                                  int64_t cap_floats, int* rc_out);
 
 // waves per SIMD requested from the register allocator for the fp16-pair variants: 4 = 128 VGPRs (34 KB of LDS per workgroup allow four
 // workgroups per CU; the reflection-fold variants spill 3-4 registers).  Training step 15.16 / 15.24 vs 15.30 / 15.40 ms with 1 (= 160
@@ -867,6 +872,9 @@ int run_tile3(const char* who, const fp_conv_desc* d, const float* src, const fl
     }
     if (bn_sink.nblk_out) *bn_sink.nblk_out = emit ? (int32_t)blocks : 0;
   }
+  // a split forward grid with the statistics sink armed: its reduce launch writes the statistics (fp_splitk_reduce_stats_launch below)
+  const bool bnb_in_reduce = bn_sink.part && bn_sink.z && p.SK > 1 && flip && !fold && !(d->epi & FP_EPI_ACCUM) && d->act == 0;
+  const bool stats_in_reduce = bn_sink.part && !bn_sink.z && p.SK > 1 && !flip && (d->epi & ~(unsigned)FP_EPI_BF16X2) == 0 && d->act == 0;
   const int planes = hp ? 4 : 6;                    // bytes of packed weight per element
   a.wmajor = (int64_t)9 * (d->C0 + d->C1) * d->Nout * planes > ((int64_t)4 << 20);
   a.nwg = d->N * p.tilesY * p.tilesX * p.tilesN * p.SK;
@@ -898,6 +906,25 @@ int run_tile3(const char* who, const fp_conv_desc* d, const float* src, const fl
 #undef FP_L3X
   (void)who;
   if (rc || p.SK <= 1) return rc;
+  if (bnb_in_reduce) {
+    int rc2 = 0;
+    const int nb = fp_splitk_reduce_bnb_launch(a.part, p.SK, (int64_t)d->N * d->OH * d->OW, d->Nout, bias, addend, addend_mask, actsrc, y, d->act,
+                                               d->epi & ~FP_EPI_BF16X2, stream, hp ? hp->out : nullptr, bn_sink.z, bn_sink.mean, bn_sink.invstd,
+                                               bn_sink.part, bn_sink.cap_floats, &rc2);
+    if (nb > 0) {
+      if (bn_sink.nblk_out) *bn_sink.nblk_out = nb;
+      return rc2;
+    }
+  }
+  if (stats_in_reduce) {
+    int rc2 = 0;
+    const int nb = fp_splitk_reduce_stats_launch(a.part, p.SK, (int64_t)d->N * d->OH * d->OW, d->Nout, y, stream, hp ? hp->out : nullptr, bn_sink.part,
+                                                 bn_sink.cap_floats, &rc2);
+    if (nb > 0) {
+      if (bn_sink.nblk_out) *bn_sink.nblk_out = nb;
+      return rc2;
+    }
+  }
   return fp_splitk_reduce_launch(a.part, p.SK, (int64_t)d->N * d->OH * d->OW, d->Nout, bias, addend, addend_mask, actsrc, y, d->act,
                                  d->epi & ~FP_EPI_BF16X2, stream, hp ? hp->out : nullptr);      // split-K launches publish max |y| here
 }

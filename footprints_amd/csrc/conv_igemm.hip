@@ -23,6 +23,8 @@
 
 int fp_stem_tile_dispatch(const fp_conv_desc* d, const float* img, const float* wpacked, const float* bias, float* y, hipStream_t stream,
                           const FpBnSink& sink);
+int fp_splitk_reduce_stats_launch(const float* part, int SK, int64_t M, int Nout, float* y, hipStream_t stream, unsigned* amax_out,
+                                  float* stats, int64_t cap_floats, int* rc_out);
 int fp_conv3x3_tile_dispatch(const fp_conv_desc* d, const float* src0, const float* src1, const float* wpacked, const float* bias,
                              const float* addend, const float* addend_mask, const float* actsrc, float* y, hipStream_t stream);
 
@@ -497,6 +499,131 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const IgemmArgs a) {
   if (a.amax_out) fp_amax_publish_block(a.amax_out, ymax);
 }
 
+// the same sum for a forward convolution in front of a train-mode BatchNorm (no epilogue options): y = sum_s part[s], plus the (count, mean,
+// M2) of the block's rows per channel -> stats[block][Nout][3] (round 4: the statistics of the split-K levels, layer 4 and the 6 x 20 ... 12 x 40
+// grids, were a pass of their own behind every such convolution).  Rows and columns as in bn_stats_kernel: a thread owns four channels and
+// walks rows blockIdx.x * R + rr, + gridDim.x * R, ...; the R row groups of a block merge through LDS in a fixed order.
+__global__ void __launch_bounds__(256) splitk_reduce_stats_kernel(const float* __restrict__ part, int SK, int M, int Nout, float* __restrict__ y,
+                                                                  float* __restrict__ stats, unsigned* amax_out) {
+  __shared__ float sm[3 * 256 * 4];
+  const int C4 = Nout >> 2, R = 256 / C4;
+  const int cq = threadIdx.x % C4, rr = threadIdx.x / C4;
+  const size_t total = (size_t)M * Nout;
+  FpWf w[4] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+  float cnt = 0.f, ymax = 0.f;
+  for (int m = blockIdx.x * R + rr; m < M; m += gridDim.x * R) {
+    const size_t o = (size_t)m * Nout + cq * 4;
+    float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0, p2 = p0, p3 = p0;      // four loads in flight, fixed combination order (as above)
+    int s = 0;
+    for (; s + 4 <= SK; s += 4) {
+      const float* q = part + (size_t)s * total + o;
+      const float4 a0 = *reinterpret_cast<const float4*>(q), a1 = *reinterpret_cast<const float4*>(q + total),
+                   a2 = *reinterpret_cast<const float4*>(q + 2 * total), a3 = *reinterpret_cast<const float4*>(q + 3 * total);
+      p0.x += a0.x; p0.y += a0.y; p0.z += a0.z; p0.w += a0.w;
+      p1.x += a1.x; p1.y += a1.y; p1.z += a1.z; p1.w += a1.w;
+      p2.x += a2.x; p2.y += a2.y; p2.z += a2.z; p2.w += a2.w;
+      p3.x += a3.x; p3.y += a3.y; p3.z += a3.z; p3.w += a3.w;
+    }
+    for (; s < SK; ++s) {
+      const float4 a0 = *reinterpret_cast<const float4*>(part + (size_t)s * total + o);
+      p0.x += a0.x; p0.y += a0.y; p0.z += a0.z; p0.w += a0.w;
+    }
+    const float4 v = make_float4((p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y), (p0.z + p1.z) + (p2.z + p3.z),
+                                 (p0.w + p1.w) + (p2.w + p3.w));
+    *reinterpret_cast<float4*>(y + o) = v;
+    ymax = fp_amax4(ymax, v);
+    cnt += 1.f;
+    const float rn = 1.f / cnt;
+    fp_wf_add(w[0], v.x, cnt, rn); fp_wf_add(w[1], v.y, cnt, rn); fp_wf_add(w[2], v.z, cnt, rn); fp_wf_add(w[3], v.w, cnt, rn);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    sm[(0 * 256 + threadIdx.x) * 4 + j] = w[j].n;
+    sm[(1 * 256 + threadIdx.x) * 4 + j] = w[j].mean;
+    sm[(2 * 256 + threadIdx.x) * 4 + j] = w[j].m2;
+  }
+  __syncthreads();
+  if (rr == 0) {
+    for (int r = 1; r < R; ++r) {
+      const int tt = r * C4 + cq;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fp_wf_merge(w[j], FpWf{sm[(0 * 256 + tt) * 4 + j], sm[(1 * 256 + tt) * 4 + j], sm[(2 * 256 + tt) * 4 + j]});
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float* p = stats + ((size_t)blockIdx.x * Nout + cq * 4 + j) * 3;
+      p[0] = w[j].n; p[1] = w[j].mean; p[2] = w[j].m2;
+    }
+  }
+  if (amax_out) fp_amax_publish_block(amax_out, ymax);
+}
+
+// ... and for a data gradient whose output is the masked gradient g entering a train-mode BatchNorm's backward (fp_bn_bwd_out_next): y =
+// epilogue(sum_s part[s]) as in splitk_reduce_kernel, plus (sum g, sum g * xhat) of the block's rows per channel -> bpart[block][Nout][2],
+// xhat = (z - mean) * invstd of that BatchNorm in the arithmetic form of bn_bwd_reduce_kernel
+__global__ void __launch_bounds__(256) splitk_reduce_bnb_kernel(const IgemmArgs a, const float* __restrict__ z, const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd, float* __restrict__ bpart) {
+  __shared__ float sm[2 * 256 * 4];
+  const int C4 = a.Nout >> 2, R = 256 / C4;
+  const int cq = threadIdx.x % C4, rr = threadIdx.x / C4;
+  const size_t total = (size_t)a.M * a.Nout;
+  const float4 mu = reinterpret_cast<const float4*>(mean)[cq], is = reinterpret_cast<const float4*>(invstd)[cq];
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  float ymax = 0.f;
+  for (int m = blockIdx.x * R + rr; m < a.M; m += gridDim.x * R) {
+    const size_t o = (size_t)m * a.Nout + cq * 4;
+    float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0, p2 = p0, p3 = p0;
+    int s = 0;
+    for (; s + 4 <= a.SK; s += 4) {
+      const float* q = a.part + (size_t)s * total + o;
+      const float4 a0 = *reinterpret_cast<const float4*>(q), a1 = *reinterpret_cast<const float4*>(q + total),
+                   a2 = *reinterpret_cast<const float4*>(q + 2 * total), a3 = *reinterpret_cast<const float4*>(q + 3 * total);
+      p0.x += a0.x; p0.y += a0.y; p0.z += a0.z; p0.w += a0.w;
+      p1.x += a1.x; p1.y += a1.y; p1.z += a1.z; p1.w += a1.w;
+      p2.x += a2.x; p2.y += a2.y; p2.z += a2.z; p2.w += a2.w;
+      p3.x += a3.x; p3.y += a3.y; p3.z += a3.z; p3.w += a3.w;
+    }
+    for (; s < a.SK; ++s) {
+      const float4 a0 = *reinterpret_cast<const float4*>(a.part + (size_t)s * total + o);
+      p0.x += a0.x; p0.y += a0.y; p0.z += a0.z; p0.w += a0.w;
+    }
+    const float4 zv = *reinterpret_cast<const float4*>(z + o);
+    float4 g;
+    g.x = igemm_epilogue(a, o + 0, cq * 4 + 0, (p0.x + p1.x) + (p2.x + p3.x));
+    g.y = igemm_epilogue(a, o + 1, cq * 4 + 1, (p0.y + p1.y) + (p2.y + p3.y));
+    g.z = igemm_epilogue(a, o + 2, cq * 4 + 2, (p0.z + p1.z) + (p2.z + p3.z));
+    g.w = igemm_epilogue(a, o + 3, cq * 4 + 3, (p0.w + p1.w) + (p2.w + p3.w));
+    *reinterpret_cast<float4*>(a.y + o) = g;
+    ymax = fp_amax4(ymax, g);
+    s1[0] += g.x; s2[0] += g.x * ((zv.x - mu.x) * is.x);
+    s1[1] += g.y; s2[1] += g.y * ((zv.y - mu.y) * is.y);
+    s1[2] += g.z; s2[2] += g.z * ((zv.z - mu.z) * is.z);
+    s1[3] += g.w; s2[3] += g.w * ((zv.w - mu.w) * is.w);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    sm[(0 * 256 + threadIdx.x) * 4 + j] = s1[j];
+    sm[(1 * 256 + threadIdx.x) * 4 + j] = s2[j];
+  }
+  __syncthreads();
+  if (rr == 0) {
+    for (int r = 1; r < R; ++r) {
+      const int tt = r * C4 + cq;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        s1[j] += sm[(0 * 256 + tt) * 4 + j];
+        s2[j] += sm[(1 * 256 + tt) * 4 + j];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float* p = bpart + ((size_t)blockIdx.x * a.Nout + cq * 4 + j) * 2;
+      p[0] = s1[j]; p[1] = s2[j];
+    }
+  }
+  if (a.amax_out) fp_amax_publish_block(a.amax_out, ymax);
+}
+
 // split-K factor for a grid of `tiles` workgroups over `steps` K-steps: fill ~3 workgroups per CU, >= 8 steps each
 int pick_splitk(int64_t tiles, int steps, int64_t MN, int64_t ws_floats) {
   static const int sk1_from = getenv("FP_IGEMM_SK1_FROM") ? atoi(getenv("FP_IGEMM_SK1_FROM")) : 160;     // as in conv3x3_tile_bf3.hip (plan3)
@@ -531,7 +658,7 @@ int launch(IgemmArgs& a, hipStream_t stream, int64_t ws_floats) {
 }
 
 template <int TN>
-int launch_hp(IgemmArgs& a, hipStream_t stream, int64_t ws_floats) {
+int launch_hp(IgemmArgs& a, hipStream_t stream, int64_t ws_floats, const FpBnSink& sink) {
   constexpr int BM = 128, BN = 32 * TN;
   int tilesM = (int)fp_ceil_div(a.M, BM);
   if (a.pm) {
@@ -546,6 +673,15 @@ int launch_hp(IgemmArgs& a, hipStream_t stream, int64_t ws_floats) {
   a.SK = (int)fp_ceil_div(steps, a.stepsPerSplit);
   a.nwg = tilesM * a.tilesN * a.SK;
   fp_launch((igemm_hp_kernel<TN>), dim3(a.nwg), dim3(256), 0, stream, a);
+  if (a.SK > 1 && sink.part && !sink.z && a.epi == 0 && a.act == FP_ACT_NONE && !a.pm) {
+    // a strided / 1 x 1 forward convolution in front of a train-mode BatchNorm: the statistics out of the reduce launch (fp_bn_stats_out_next)
+    int rc2 = 0;
+    const int nb = fp_splitk_reduce_stats_launch(a.part, a.SK, a.M, a.Nout, a.y, stream, a.amax_out, sink.part, sink.cap_floats, &rc2);
+    if (nb > 0) {
+      if (sink.nblk_out) *sink.nblk_out = nb;
+      return rc2 ? rc2 : fp_check_launch("fp_conv_igemm_hp");
+    }
+  }
   if (a.SK > 1) {
     int64_t g = fp_ceil_div((int64_t)a.M * a.Nout, 256);
     if (g > 4096) g = 4096;
@@ -570,6 +706,42 @@ int fp_splitk_reduce_launch(const float* part, int SK, int64_t M, int Nout, cons
   if (g > 4096) g = 4096;
   fp_launch(splitk_reduce_kernel, dim3((int)g), dim3(256), 0, stream, a);
   return fp_check_launch("splitk_reduce");
+}
+
+// ... with BatchNorm statistics of y (splitk_reduce_stats_kernel); returns the number of partial blocks written to `stats` (capacity
+// `cap_floats`), 0 = shape not handled / capacity too small: the caller then uses fp_splitk_reduce_launch
+int fp_splitk_reduce_stats_launch(const float* part, int SK, int64_t M, int Nout, float* y, hipStream_t stream, unsigned* amax_out,
+                                  float* stats, int64_t cap_floats, int* rc_out) {
+  *rc_out = 0;
+  const int C4 = Nout / 4;
+  if (Nout % 4 || C4 < 1 || C4 > 256 || 256 % C4 || M >= ((int64_t)1 << 31)) return 0;
+  const int R = 256 / C4;
+  int64_t blocks = fp_ceil_div(M, (int64_t)R * 4);           // four rows per thread, as fp_bn_train_stats on these small tensors
+  if (blocks > 512) blocks = 512;
+  if (blocks * Nout * 3 > cap_floats) return 0;
+  fp_launch(splitk_reduce_stats_kernel, dim3((int)blocks), dim3(256), 0, stream, part, SK, (int)M, Nout, y, stats, amax_out);
+  *rc_out = fp_check_launch("splitk_reduce(stats)");
+  return (int)blocks;
+}
+
+// ... with the BatchNorm-backward sums of y (splitk_reduce_bnb_kernel); returns the number of partial blocks written, 0 = not handled
+int fp_splitk_reduce_bnb_launch(const float* part, int SK, int64_t M, int Nout, const float* bias, const float* addend, const float* addend_mask,
+                                const float* actsrc, float* y, int act, unsigned epi, hipStream_t stream, unsigned* amax_out, const float* z,
+                                const float* mean, const float* invstd, float* bpart, int64_t cap_floats, int* rc_out) {
+  *rc_out = 0;
+  const int C4 = Nout / 4;
+  if (Nout % 4 || C4 < 1 || C4 > 256 || 256 % C4 || M >= ((int64_t)1 << 31)) return 0;
+  const int R = 256 / C4;
+  int64_t blocks = fp_ceil_div(M, (int64_t)R * 4);
+  if (blocks > 512) blocks = 512;
+  if (blocks * Nout * 2 > cap_floats) return 0;
+  IgemmArgs a = {};
+  a.amax_out = amax_out;
+  a.part = const_cast<float*>(part); a.SK = SK; a.M = (int)M; a.Nout = Nout;
+  a.bias = bias; a.addend = addend; a.addend_mask = addend_mask; a.actsrc = actsrc; a.y = y; a.act = act; a.epi = epi;
+  fp_launch(splitk_reduce_bnb_kernel, dim3((int)blocks), dim3(256), 0, stream, a, z, mean, invstd, bpart);
+  *rc_out = fp_check_launch("splitk_reduce(bn backward)");
+  return (int)blocks;
 }
 
 extern "C" int64_t fp_conv_igemm_workspace(const fp_conv_desc* d) {
@@ -665,7 +837,7 @@ extern "C" int fp_conv_igemm_hp_supported(const fp_conv_desc* d) {
 extern "C" int fp_conv_igemm_hp(const fp_conv_desc* d, const float* src, const void* wpacked_hp, const float* bias, const float* addend,
                                 const float* addend_mask, const float* actsrc, float* y, void* workspace, int64_t workspace_bytes,
                                 const uint32_t* amax_src, const uint32_t* amax_w, fp_stream_t stream_) {
-  (void)fp_take_bn_sink();                        // a statistics sink armed for a tile convolution must not outlive a launch that cannot emit
+  const FpBnSink bn_sink = fp_take_bn_sink();     // consumed by this launch: only a split grid's reduce launch can emit (launch_hp)
   hipStream_t stream = (hipStream_t)stream_;
   FP_REQUIRE(d && src && wpacked_hp && y && amax_src && amax_w, "fp_conv_igemm_hp: null pointer");
   FP_REQUIRE(fp_conv_igemm_hp_supported(d), "fp_conv_igemm_hp: shape / gather not supported (see fp_conv_igemm_hp_supported)");
@@ -693,8 +865,8 @@ extern "C" int fp_conv_igemm_hp(const fp_conv_desc* d, const float* src, const v
   int64_t ws = workspace ? workspace_bytes / (int64_t)sizeof(float) : 0;
   if (ws > MAX_SK * M64 * d->Nout) ws = MAX_SK * M64 * d->Nout;
   // wave tile 32 rows x 32 TN columns: wider tiles re-read the A rows less often, narrower ones fill the chip on small grids
-  if (d->Nout <= 32) return launch_hp<1>(a, stream, ws);
+  if (d->Nout <= 32) return launch_hp<1>(a, stream, ws, bn_sink);
   const int64_t t128 = fp_ceil_div(M64, 128);
-  if (d->Nout % 128 == 0 && t128 * (d->Nout / 128) >= 512) return launch_hp<4>(a, stream, ws);
-  return launch_hp<2>(a, stream, ws);
+  if (d->Nout % 128 == 0 && t128 * (d->Nout / 128) >= 512) return launch_hp<4>(a, stream, ws, bn_sink);
+  return launch_hp<2>(a, stream, ws, bn_sink);
 }

@@ -775,7 +775,7 @@ class Engine:
             ops.event_wait(ops.current_stream(), self._pack_ev_dgrad)
             self._pack_ev_dgrad = None
 
-    def _conv_enc(self, c, x, N, H, W, out, bn=None):
+    def _conv_enc(self, c, x, N, H, W, out, bn=None, part="bn.part"):
         """encoder convolution; `bn` = the BatchNorm record that follows in train mode: a tile-kernel launch then also writes the
         Welford partials of its output (ops.bn_stats_out_next) and _bn_coeffs skips the statistics pass over the activation"""
         OH, OW = (H + 2 * c.pad - c.K) // c.stride + 1, (W + 2 * c.pad - c.K) // c.stride + 1
@@ -784,10 +784,15 @@ class Engine:
         if bn is not None:
             bn.stats_nblk = 0
             tile = (c.wp3 is not None or (_HP_TILE and c.hp_f is not None and not ops._bf16x2)) and ops.conv3x3_bf3_supported(d)
+            # ... or a strided / 1 x 1 convolution through the fp16-pair implicit GEMM: its split grids emit from their reduce launch
+            tile = tile or (_HP_IGEMM and c.hp_f is not None and not ops._bf16x2 and ops.conv_igemm_hp_supported(d))
             if tile and ops._BN_EPI:
                 # one (count, mean, M2) triple per pixel tile and channel: tiles of 8 x 16 or 6 x 20 pixels, bounded by 6 x 16-pixel ones
                 cap = N * ((OH + 5) // 6) * ((OW + 15) // 16) * c.Cout * 3
-                bn.stats_part = self.buf("bn.part", (max(cap, 1),))
+                if c.Cout % 4 == 0 and 256 % (c.Cout // 4) == 0:       # split-K grids: one triple per block of the reduce launch (fp_splitk_reduce_stats_launch)
+                    rows = 256 // (c.Cout // 4) * 4
+                    cap = max(cap, min(512, (N * OH * OW + rows - 1) // rows) * c.Cout * 3)
+                bn.stats_part = self.buf(part, (max(cap, 1),))      # (`part`: the shortcut branch runs beside conv1 on another stream: its own buffer)
                 cell = ops.bn_stats_out_next(bn.stats_part)
         y = self._cv(d, x, c.wp, c.wp3, out, hp=(c.hp_f, c.wslot))
         if cell is not None:
@@ -889,7 +894,7 @@ class Engine:
             zd, idt, ev_idt = None, x, None
 
             def shortcut():
-                zd_ = self._conv_enc(blk.ds, x, N, h, w, buf("b%d.zd" % i, (N, oh, ow, blk.Cout)))
+                zd_ = self._conv_enc(blk.ds, x, N, h, w, buf("b%d.zd" % i, (N, oh, ow, blk.Cout)), bn=blk.bnd if training else None, part="bn.part.ds")
                 return zd_, self._bn(blk.bnd, zd_, buf("b%d.idt" % i, (N, oh, ow, blk.Cout)), training, relu=False)
             if blk.ds is not None and self.concurrent and _DS_AUX:       # downsample branch beside conv1 / conv2 (joined before the residual add)
                 if _HP_IGEMM:
@@ -1159,6 +1164,9 @@ class Engine:
             """arm the BatchNorm-backward sink for the next tile data gradient at (h_, w_, C_): partial sums per pixel tile (8 x 16 or 6 x 20
             pixels, bounded by 6 x 16-pixel ones) and channel"""
             cap = N * ((h_ + 5) // 6) * ((w_ + 15) // 16) * C_ * 2
+            if C_ % 4 == 0 and 256 % (C_ // 4) == 0:              # split-K grids: one pair per block of the reduce launch (fp_splitk_reduce_bnb_launch)
+                rows = 256 // (C_ // 4) * 4
+                cap = max(cap, min(512, (N * h_ * w_ + rows - 1) // rows) * C_ * 2)
             part = buf(name, (max(cap, 1),))
             return part, ops.bn_bwd_out_next(part, z.view(-1, C_), rec.mean, rec.invstd)
         for i in range(nblk - 1, -1, -1):

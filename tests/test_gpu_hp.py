@@ -179,7 +179,8 @@ def test_conv3x3_hp_dynamic_range_and_specials():
     (12, 12, 40, 256, 256, True),        # layer 3: 6 x 20 tiles (120 of 128 MFMA rows valid)
     (6, 44, 72, 32, 32, True),           # ragged: partial tiles on both borders, 32-channel variant (four M waves); 180 workgroups (under 128 the shape goes to the flattened kernel)
     (10, 21, 45, 64, 128, True),         # ragged, two channel tiles
-    (12, 6, 20, 512, 512, False),        # split-K grid: nothing emitted, the caller falls back
+    (12, 6, 20, 512, 512, "reduce"),     # split-K grid: the statistics come out of the reduce launch, one triple per block of 8 rows
+    (12, 6, 20, 256, 512, "reduce"),
 ])
 def test_conv3x3_hp_emits_batchnorm_partials(N, H, W, C0, Cout, emits):
     """fp_bn_stats_out_next: the forward tile convolution in front of a train-mode BatchNorm writes (count, mean, M2) per pixel tile and
@@ -192,12 +193,19 @@ def test_conv3x3_hp_emits_batchnorm_partials(N, H, W, C0, Cout, emits):
     wp, sw = pack_hp(w)
     xs = nhwc(x)
     cap = N * ((H + 5) // 6) * ((W + 15) // 16) * Cout * 3
+    rows = 256 // (Cout // 4) * 4
+    nred = min(512, (N * H * W + rows - 1) // rows)
+    if emits == "reduce":
+        cap = max(cap, nred * Cout * 3)
     part = torch.full((cap,), float("nan"), device="cuda")
     cell = ops.bn_stats_out_next(part)
     ops.conv3x3_hp(d, xs, wp, y, slot_of(xs), sw)
     torch.cuda.synchronize()
     expect_tiles = cell.value
-    assert expect_tiles in ((N * ((H + 7) // 8) * ((W + 15) // 16), N * ((H + 5) // 6) * ((W + 19) // 20)) if emits else (0,))
+    if emits == "reduce":
+        assert expect_tiles == nred
+    else:
+        assert expect_tiles in ((N * ((H + 7) // 8) * ((W + 15) // 16), N * ((H + 5) // 6) * ((W + 19) // 20)) if emits else (0,))
     check(nchw(y), F.conv2d(x.double(), w.double(), None, 1, 1), "hp forward with statistics sink", 2e-6)
     y2 = torch.empty_like(y)                                       # the sink is one-shot: the next launch emits nothing
     ops.conv3x3_hp(d, xs, wp, y2, slot_of(xs), sw)
@@ -229,7 +237,7 @@ def test_conv3x3_hp_emits_batchnorm_partials(N, H, W, C0, Cout, emits):
     (12, 24, 80, 128, True),             # layer 2 (small-grid WPF variant, two channel tiles)
     (12, 12, 40, 256, True),             # layer 3: 6 x 20 tiles
     (10, 21, 45, 128, True),             # ragged tiles on both borders, two channel tiles (180 workgroups: unsplit)
-    (12, 6, 20, 512, False),             # split-K grid: nothing emitted, the caller falls back to fp_bn_bwd's own reduction
+    (12, 6, 20, 512, "reduce"),          # split-K grid: the sums come out of the reduce launch, one pair per block of 8 rows
 ])
 def test_conv3x3_hp_data_gradient_emits_batchnorm_backward_sums(N, H, W, C, emits):
     """fp_bn_bwd_out_next: a tile data gradient whose epilogue applies the ReLU mask stores g = (dgrad + residual) * (out > 0) of the
@@ -259,6 +267,10 @@ def test_conv3x3_hp_data_gradient_emits_batchnorm_backward_sums(N, H, W, C, emit
     gzs, zs = nhwc(gz), nhwc(z)
     mean_d, invstd_d = mean.float().cuda(), invstd.float().cuda()
     cap = N * ((H + 5) // 6) * ((W + 15) // 16) * C * 2
+    rows = 256 // (C // 4) * 4
+    nred = min(512, (N * H * W + rows - 1) // rows)
+    if emits == "reduce":
+        cap = max(cap, nred * C * 2)
     part = torch.full((cap,), float("nan"), device="cuda")
     gout = torch.empty((N, H, W, C), device="cuda")
     cell = ops.bn_bwd_out_next(part, zs.view(-1, C), mean_d, invstd_d)
@@ -266,7 +278,10 @@ def test_conv3x3_hp_data_gradient_emits_batchnorm_backward_sums(N, H, W, C, emit
     ops.conv3x3_hp(d, gzs, wp, gout, slot_of(gzs), sw, amax_out=so, addend=nhwc(resid), actsrc=nhwc(out))
     torch.cuda.synchronize()
     tiles = cell.value
-    assert tiles in ((N * ((H + 7) // 8) * ((W + 15) // 16), N * ((H + 5) // 6) * ((W + 19) // 20)) if emits else (0,))
+    if emits == "reduce":
+        assert tiles == nred
+    else:
+        assert tiles in ((N * ((H + 7) // 8) * ((W + 15) // 16), N * ((H + 5) // 6) * ((W + 19) // 20)) if emits else (0,))
     check(nchw(gout), g64, "masked data gradient", 2e-6)
     assert ops.amax_value(so) == float(gout.abs().max())
     g2 = torch.empty_like(gout)                                    # the sink is one-shot
