@@ -716,8 +716,8 @@ int fp_splitk_reduce_stats_launch(const float* part, int SK, int64_t M, int Nout
   const int C4 = Nout / 4;
   if (Nout % 4 || C4 < 1 || C4 > 256 || 256 % C4 || M >= ((int64_t)1 << 31)) return 0;
   const int R = 256 / C4;
-  int64_t blocks = fp_ceil_div(M, (int64_t)R * 4);           // four rows per thread, as fp_bn_train_stats on these small tensors
-  if (blocks > 512) blocks = 512;
+  int64_t blocks = fp_ceil_div(M, (int64_t)R * 4);           // four rows per thread, as fp_bn_train_stats on these small tensors (one row per thread: four
+  if (blocks > 512) blocks = 512;                            // times the partial triples for the final stage, measured +0.05 ms per step)
   if (blocks * Nout * 3 > cap_floats) return 0;
   fp_launch(splitk_reduce_stats_kernel, dim3((int)blocks), dim3(256), 0, stream, part, SK, (int)M, Nout, y, stats, amax_out);
   *rc_out = fp_check_launch("splitk_reduce(stats)");

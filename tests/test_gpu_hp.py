@@ -179,7 +179,7 @@ def test_conv3x3_hp_dynamic_range_and_specials():
     (12, 12, 40, 256, 256, True),        # layer 3: 6 x 20 tiles (120 of 128 MFMA rows valid)
     (6, 44, 72, 32, 32, True),           # ragged: partial tiles on both borders, 32-channel variant (four M waves); 180 workgroups (under 128 the shape goes to the flattened kernel)
     (10, 21, 45, 64, 128, True),         # ragged, two channel tiles
-    (12, 6, 20, 512, 512, "reduce"),     # split-K grid: the statistics come out of the reduce launch, one triple per block of 8 rows
+    (12, 6, 20, 512, 512, "reduce"),     # split-K grid: the statistics come out of the reduce launch, one triple per block of the reduce launch
     (12, 6, 20, 256, 512, "reduce"),
 ])
 def test_conv3x3_hp_emits_batchnorm_partials(N, H, W, C0, Cout, emits):
@@ -237,7 +237,7 @@ def test_conv3x3_hp_emits_batchnorm_partials(N, H, W, C0, Cout, emits):
     (12, 24, 80, 128, True),             # layer 2 (small-grid WPF variant, two channel tiles)
     (12, 12, 40, 256, True),             # layer 3: 6 x 20 tiles
     (10, 21, 45, 128, True),             # ragged tiles on both borders, two channel tiles (180 workgroups: unsplit)
-    (12, 6, 20, 512, "reduce"),          # split-K grid: the sums come out of the reduce launch, one pair per block of 8 rows
+    (12, 6, 20, 512, "reduce"),          # split-K grid: the sums come out of the reduce launch, one pair per block of the reduce launch
 ])
 def test_conv3x3_hp_data_gradient_emits_batchnorm_backward_sums(N, H, W, C, emits):
     """fp_bn_bwd_out_next: a tile data gradient whose epilogue applies the ReLU mask stores g = (dgrad + residual) * (out > 0) of the
