@@ -22,7 +22,7 @@ class ConvDesc(C.Structure):
 
 
 PACK_FWD, PACK_DGRAD, PACK_STEM, PACK_UP2_FWD, PACK_UP2_DGRAD, PACK_FWD_BF3, PACK_DGRAD_BF3, PACK_UP2_FWD_BF3, PACK_UP2_DGRAD_BF3 = range(9)
-PACK_FWD_HP, PACK_DGRAD_HP, PACK_UP2_FWD_HP, PACK_UP2_DGRAD_HP = range(9, 13)
+PACK_FWD_HP, PACK_DGRAD_HP, PACK_UP2_FWD_HP, PACK_UP2_DGRAD_HP, PACK_STEM_HP = range(9, 14)
 
 
 class PackJob(C.Structure):
@@ -123,6 +123,9 @@ SIGNATURES = {
     "fp_head_upsample": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
     "fp_head_upsample_bwd": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
     "fp_head_dgrad": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
+    "fp_conv_stem_hp_supported": (C.c_int, [_P]),
+    "fp_conv_stem_hp": (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
+    "fp_conv_stem_wgrad_hp": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, _I64, _P, _P]),
     "fp_head_wgrad_workspace": (_I64, [_I32, _I32, _I32, _I32]),
     "fp_head_wgrad": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, C.c_int, _P, _I64, _P]),
     "fp_bn_workspace": (_I64, [_I64, _I32]),

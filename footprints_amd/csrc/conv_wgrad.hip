@@ -342,6 +342,25 @@ extern "C" int fp_conv_wgrad(const fp_conv_desc* d, const float* src0, const flo
   return fp_conv_wgrad_slice(d, src0, src1, dz, dw_oihw, kc, 0, accumulate, workspace, workspace_bytes, stream_);
 }
 
+// the stem's weight gradient with fp16-pair operands (stem_tile.hip, stem_wgrad_hp_kernel): same desc, workspace (fp_conv_wgrad_workspace) and
+// fixed-order reduce as fp_conv_wgrad on the STEM gather; `amax_dz` = the amax slot of dz
+int fp_stem_wgrad_hp_dispatch(const fp_conv_desc* d, const float* img, const float* dz, float* part, int splits, const uint32_t* amax_dz,
+                              hipStream_t stream);
+extern "C" int fp_conv_stem_wgrad_hp(const fp_conv_desc* d, const float* img_nchw, const float* dz, float* dw_oihw, int accumulate, void* workspace,
+                                     int64_t workspace_bytes, const uint32_t* amax_dz, fp_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  FP_REQUIRE(d && img_nchw && dz && dw_oihw && workspace && amax_dz, "fp_conv_stem_wgrad_hp: null pointer");
+  FP_REQUIRE(d->gather == FP_GATHER_STEM && d->KH == 7 && d->KW == 7 && d->stride == 2 && d->pad == 3 && d->C0 == 3 && d->C1 == 0 && d->Nout == 64 &&
+                 d->IH == 2 * d->OH && d->IW == 2 * d->OW,
+             "fp_conv_stem_wgrad_hp: the 7x7 / 2 stem on even image dims only");
+  const Plan p = make_plan(d);
+  FP_REQUIRE(workspace_bytes >= fp_conv_wgrad_workspace(d), "fp_conv_stem_wgrad_hp: workspace too small");
+  const int rc = fp_stem_wgrad_hp_dispatch(d, img_nchw, dz, (float*)workspace, p.S, amax_dz, stream);
+  FP_REQUIRE(rc != -1000, "fp_conv_stem_wgrad_hp: shape not handled");
+  if (rc) return rc;
+  return fp_wgrad_reduce_launch((const float*)workspace, dw_oihw, p.S, p.T, p.Kc, d->Nout, 1, accumulate, 3, 0, stream);
+}
+
 extern "C" int fp_conv_wgrad_slice(const fp_conv_desc* d, const float* src0, const float* src1, const float* dz, float* dw_oihw,
                                    int32_t kc_total, int32_t k_begin, int accumulate, void* workspace, int64_t workspace_bytes,
                                    fp_stream_t stream_) {

@@ -43,6 +43,13 @@ __device__ __forceinline__ float pack_elem(const fp_pack_job& j, size_t e) {
       const int ky = kk / 21, rem = kk - ky * 21, kx = rem / 3, ci = rem - kx * 3;
       return w[((n * 3 + ci) * 7 + ky) * 7 + kx];
     }
+    case FP_PACK_STEM_HP: {     // K index = ky * 24 + (kx * 3 + ci): a row of the 7 x 7 x 3 patch is 21 consecutive elements, padded to 24
+      const int n = (int)(r % 64), st = (int)(r / 64);
+      const int kq = st * 16 + kr, ky = kq / 24, jj = kq - ky * 24;
+      if (ky >= 7 || jj >= 21) return 0.f;
+      const int kx = jj / 3, ci = jj - kx * 3;
+      return w[((n * 3 + ci) * 7 + ky) * 7 + kx];
+    }
     case FP_PACK_UP2_FWD_HP:
     case FP_PACK_UP2_FWD_BF3:
     case FP_PACK_UP2_FWD: {
@@ -109,6 +116,7 @@ __host__ __device__ inline int64_t pack_elems(int kind, int Cout, int KH, int KW
     case FP_PACK_DGRAD_BF3:
     case FP_PACK_DGRAD: return T * ((Cout + 15) / 16) * c_count * 16;
     case FP_PACK_STEM: return 10 * 64 * 16;
+    case FP_PACK_STEM_HP: return 11 * 64 * 16;
     case FP_PACK_UP2_FWD_HP:
     case FP_PACK_UP2_FWD_BF3:
     case FP_PACK_UP2_FWD: return (int64_t)16 * ((c_count + 15) / 16) * Cout * 16;
@@ -127,7 +135,7 @@ __device__ __forceinline__ unsigned short bf16_rne(float x) {
   return (unsigned short)(u >> 16);
 }
 __device__ __forceinline__ bool pack_is_hp(int kind) {
-  return kind == FP_PACK_FWD_HP || kind == FP_PACK_DGRAD_HP || kind == FP_PACK_UP2_FWD_HP || kind == FP_PACK_UP2_DGRAD_HP;
+  return kind == FP_PACK_FWD_HP || kind == FP_PACK_DGRAD_HP || kind == FP_PACK_UP2_FWD_HP || kind == FP_PACK_UP2_DGRAD_HP || kind == FP_PACK_STEM_HP;
 }
 // *_HP layouts: v * 2^kw (kw from the weight tensor's amax slot, FP_HP_TARGET_W) as an fp16 pair, planes [tap][chunk][2][ncols][16]
 __device__ __forceinline__ void pack_store(const fp_pack_job& j, size_t e, float v, int kw) {
@@ -182,7 +190,7 @@ __host__ __device__ inline bool pack_is_up2(int kind) {
          kind == FP_PACK_UP2_DGRAD_HP;
 }
 __host__ __device__ inline int pack_tiles(int kind, int Cout, int c_count) {
-  return kind == FP_PACK_STEM ? 0 : ((Cout + PT_N - 1) / PT_N) * ((c_count + PT_K - 1) / PT_K);
+  return (kind == FP_PACK_STEM || kind == FP_PACK_STEM_HP) ? 0 : ((Cout + PT_N - 1) / PT_N) * ((c_count + PT_K - 1) / PT_K);
 }
 
 // value of virtual tap `vt` from the nine (T = 9) or one (T = 1) taps of one (n, k) at `wk` (stride 1 between taps)
@@ -311,7 +319,7 @@ __global__ void __launch_bounds__(256) pack_batched_kernel(const fp_pack_job* __
     const fp_pack_job j = jobs[blk2job[vb]];
     const int kw = pack_is_hp(j.kind) ? fp_hp_exponent(fp_amax_bits(j.amax), FP_HP_TARGET_W) : 0;
     const int T = j.KH * j.KW;
-    if (j.kind == FP_PACK_STEM || (T != 9 && T != 1)) {          // the stem's 7 x 7 x 3 table (10 K elements): element-wise as before
+    if (j.kind == FP_PACK_STEM || j.kind == FP_PACK_STEM_HP || (T != 9 && T != 1)) {          // the stem's 7 x 7 x 3 table (10 K elements): element-wise as before
       const size_t total = (size_t)pack_elems(j.kind, j.Cout, j.KH, j.KW, j.c_count);
       for (size_t e = (size_t)(vb - j.block_begin) * 256 + threadIdx.x; e < total; e += (size_t)j.block_count * 256) pack_store(j, e, pack_elem(j, e), kw);
       continue;
@@ -466,7 +474,7 @@ extern "C" int fp_pack_up2_weight_dgrad(const float* w_oihw, float* wp, int32_t 
 
 extern "C" int32_t fp_pack_job_blocks(int32_t kind, int32_t Cout, int32_t KH, int32_t KW, int32_t c_count) {
   int64_t b;
-  if (kind == FP_PACK_STEM || (KH * KW != 9 && KH * KW != 1)) b = (pack_elems(kind, Cout, KH, KW, c_count) + 2047) / 2048;     // element-wise: ~8 elements per thread
+  if (kind == FP_PACK_STEM || kind == FP_PACK_STEM_HP || (KH * KW != 9 && KH * KW != 1)) b = (pack_elems(kind, Cout, KH, KW, c_count) + 2047) / 2048;     // element-wise: ~8 elements per thread
   else b = pack_tiles(kind, Cout, c_count);                                                                                   // one virtual block per tile ...
   if (b < 1) b = 1;
   if (b > 512) b = 512;                                                                                                       // ... up to 512 (a 512 x 512 x 3 x 3 tensor)

@@ -53,6 +53,7 @@ _PHASE = not bool(int(os.environ.get("FP_NO_PHASE", "0")))
 # role -> side-stream pool index: aux, encoder weight gradients, mask decoder's / depth decoder's weight gradients (see Engine.__init__)
 _STREAM_LAYOUT = "0,1,2,2"
 _WGRAD_PAIR_FORK = bool(int(os.environ.get("FP_WGRAD_PAIR_FORK", "1")))   # one stream fork per residual block for its two weight gradients (0: one each)
+_HP_STEM = bool(int(os.environ.get("FP_HP_STEM", "1")))        # 0: the stem convolution on fp32 MFMA (rounds 1-3)
 _LAZY32 = bool(int(os.environ.get("FP_PACK_LAZY32", "1")))     # 0: every fp32 packed layout is refreshed every step (rounds 1-3)
 _PACK_SIDE_WGS = int(os.environ.get("FP_PACK_SIDE_WGS", "0"))        # workgroups of the side-stream weight repack (0 = one per tile)
 _PACK_DGRAD_LATE = bool(int(os.environ.get("FP_PACK_DGRAD_LATE", "0")))   # 1: the data-gradient layouts are repacked under the decoders' forward instead of the encoder's
@@ -432,6 +433,8 @@ class Engine:
         self.wamax = torch.zeros(len(convs) * ops.amax_elems(), dtype=torch.int32, device=self.device)
         for i, c in enumerate(convs):
             c.wslot = self.wamax[i * ops.amax_elems():(i + 1) * ops.amax_elems()]
+        if _HP and _HP_STEM:        # the stem's fp16-pair layout (FP_PACK_STEM_HP: 11 K-steps x 2 planes x 64 x 16 halves)
+            self.stem.hp_f = torch.full((11 * 64 * 16,), float("nan"), device=self.device)
 
     def refresh_packed(self, force=False, overlap=False):
         """repack every convolution's weights if they changed.  overlap=True (Engine.forward only): all but the stem / layer1
@@ -445,6 +448,8 @@ class Engine:
                 jobs = []
                 for c in convs:
                     jobs.append((L.PACK_STEM if c.stem else L.PACK_FWD, c.w.data, c.wp, 0, c.Cin))
+                    if c.stem and c.hp_f is not None:
+                        jobs.append((L.PACK_STEM_HP, c.w.data, c.hp_f, 0, c.Cin, c.wslot))
                     if c.wpd is not None:
                         jobs.append((L.PACK_DGRAD, c.w.data, c.wpd, 0, c.Cin))
                     if c.hp or c.hp_ig:      # fp16-pair packings, scaled by the weight tensor's amax slot
@@ -871,7 +876,11 @@ class Engine:
             self.bn0.stats_nblk = 0
             self.bn0.stats_part = buf("bn.part0", (N * ((h + 7) // 8) * ((w + 15) // 16) * 64 * 3,))
             cell = ops.bn_stats_out_next(self.bn0.stats_part)
-        ops.conv_igemm(ops.make_desc(N, h, w, H, W, 3, 0, 64, 7, 2, 3, L.GATHER_STEM), image, None, self.stem.wp, z0)
+        d0 = ops.make_desc(N, h, w, H, W, 3, 0, 64, 7, 2, 3, L.GATHER_STEM)
+        if self.stem.hp_f is not None and not ops._bf16x2 and ops.conv_stem_hp_supported(d0):
+            ops.conv_stem_hp(d0, image, self.stem.hp_f, z0, self.stem.wslot)
+        else:
+            ops.conv_igemm(d0, image, None, self.stem.wp, z0)
         if cell is not None:
             self.bn0.stats_nblk = int(cell.value)
         f0 = self._bn(self.bn0, z0, buf("f0", (N, h, w, 64)), training)
@@ -1285,10 +1294,15 @@ class Engine:
         M0 = N * h0 * w0
         z0 = self._bufs["z0"][:M0 * 64].view(M0, 64)
         dz0 = buf("g.dz0", (N, h0, w0, 64))
-        ops.bn_bwd(dF[0].view(M0, 64), feats[0].view(M0, 64), z0, self.bn0.mean, self.bn0.invstd, self.bn0.bn.weight.data,
-                   dz0.view(M0, 64), self.bn0.gg, self.bn0.gb, accumulate=accumulate)
         d = ops.make_desc(N, h0, w0, S["H"], S["W"], 3, 0, 64, 7, 2, 3, L.GATHER_STEM)
-        ops.conv_wgrad(d, S["image"], None, dz0, self.stem.gw, accumulate=accumulate)
+        stem_hp = self.stem.hp_f is not None and ops.conv_stem_hp_supported(d)         # fp16-pair weight gradient: dz0's amax out of bn_bwd
+        ops.bn_bwd(dF[0].view(M0, 64), feats[0].view(M0, 64), z0, self.bn0.mean, self.bn0.invstd, self.bn0.bn.weight.data,
+                   dz0.view(M0, 64), self.bn0.gg, self.bn0.gb, accumulate=accumulate, amax_out=self._sink_slot(dz0) if stem_hp else None)
+        if stem_hp:
+            self._sink_done(dz0)
+            ops.conv_stem_wgrad_hp(d, S["image"], dz0, self.stem.gw, self.amax.get(dz0), accumulate=accumulate)
+        else:
+            ops.conv_wgrad(d, S["image"], None, dz0, self.stem.gw, accumulate=accumulate)
         if side is not None:
             ops.stream_wait_stream(main, side)                # join: every weight gradient is complete
             ops.stream_wait_stream(main, self.dwg[0])

@@ -141,6 +141,29 @@ def conv_igemm(desc, src0, src1, wpacked, y, bias=None, addend=None, addend_mask
     return y
 
 
+def conv_stem_hp_supported(desc):
+    return bool(_cached_query("fp_conv_stem_hp_supported", desc))
+
+
+def conv_stem_hp(desc, img, wpacked_hp, y, amax_w, bias=None, amax_out=None):
+    """the 7x7 / 2 stem on the NCHW image with fp16-pair operands (weights from a PACK_STEM_HP job); honors the statistics and amax sinks"""
+    d = ConvDesc.from_buffer_copy(desc)
+    if bias is not None:
+        d.epi |= _lib.EPI_BIAS
+    _sink(amax_out)
+    _lib.check(_lib.load().fp_conv_stem_hp(C.byref(d), _f32(img), _f32(wpacked_hp), _f32(bias), _f32(y), _u32(amax_w, "amax_w"), stream()),
+               "fp_conv_stem_hp")
+    return y
+
+
+def conv_stem_wgrad_hp(desc, img, dz, dw, amax_dz, accumulate=False):
+    lib = _lib.load()
+    ws = workspace(_cached_query("fp_conv_wgrad_workspace", desc), dz.device)
+    _lib.check(lib.fp_conv_stem_wgrad_hp(C.byref(desc), _f32(img), _f32(dz), _f32(dw), int(bool(accumulate)), ws.data_ptr(), ws.numel(),
+                                         _u32(amax_dz, "amax_dz"), stream()), "fp_conv_stem_wgrad_hp")
+    return dw
+
+
 def conv_igemm_hp_supported(desc):
     return bool(_cached_query("fp_conv_igemm_hp_supported", desc))
 

@@ -95,7 +95,8 @@ int fp_conv_wgrad(const fp_conv_desc* d, const float* src0, const float* src1, c
  * optimizer step (the table lives in device memory and is built once: parameter and packed buffers never move). */
 enum { FP_PACK_FWD = 0, FP_PACK_DGRAD = 1, FP_PACK_STEM = 2, FP_PACK_UP2_FWD = 3, FP_PACK_UP2_DGRAD = 4,
        FP_PACK_FWD_BF3 = 5, FP_PACK_DGRAD_BF3 = 6, FP_PACK_UP2_FWD_BF3 = 7, FP_PACK_UP2_DGRAD_BF3 = 8, /* bf16x3 split planes, see fp_conv3x3_bf3 */
-       FP_PACK_FWD_HP = 9, FP_PACK_DGRAD_HP = 10, FP_PACK_UP2_FWD_HP = 11, FP_PACK_UP2_DGRAD_HP = 12 /* scaled fp16 pairs, see fp_conv3x3_hp */ };
+       FP_PACK_FWD_HP = 9, FP_PACK_DGRAD_HP = 10, FP_PACK_UP2_FWD_HP = 11, FP_PACK_UP2_DGRAD_HP = 12, /* scaled fp16 pairs, see fp_conv3x3_hp */
+       FP_PACK_STEM_HP = 13 /* the 7x7x3 stem as fp16 pairs, K = 7 rows x 24 (21 taps + 3 zeros): [11 K-steps][2 planes][64][16], see fp_conv_stem_hp */ };
 typedef struct fp_pack_job {
   const float* w;  /* [Cout][Cin][KH][KW] */
   float* wp;       /* packed destination */
@@ -273,6 +274,19 @@ int fp_head_dgrad(const float* dzlow, const float* w_oihw, const float* elu_src,
 int64_t fp_head_wgrad_workspace(int32_t N, int32_t h, int32_t w, int32_t Cin);
 int fp_head_wgrad(const float* x, const float* dzlow, float* dw_oihw, float* db, int32_t N, int32_t h, int32_t w,
                   int32_t Cin, int accumulate, void* workspace, int64_t workspace_bytes, fp_stream_t stream);
+
+/* The stem (7x7 / stride 2 / pad 3 on the NCHW image, (x - 0.45) / 0.225 applied before the zero padding; network.py:48-52) with fp16-pair
+ * operands: the image patch of an 8 x 16 output tile is normalised, scaled by 2^12 (|x| <= 2.45) and split into its two fp16 planes once in
+ * LDS; weights from an FP_PACK_STEM_HP job with the slot they were scaled by.  Same desc / epilogue rules as fp_conv_igemm's STEM gather
+ * (bias flag, act); honors the statistics and amax sinks.  fp_conv_stem_hp_supported: Nout == 64, IH == 2 OH, IW == 2 OW. */
+int fp_conv_stem_hp_supported(const fp_conv_desc* d);
+int fp_conv_stem_hp(const fp_conv_desc* d, const float* img_nchw, const void* wpacked_hp, const float* bias, float* y,
+                    const uint32_t* amax_w, fp_stream_t stream);
+
+/* ... and the stem's weight gradient likewise (dW [64][3][7][7] (+)= ...; desc / workspace of fp_conv_wgrad on the STEM gather): the image
+ * patch and the dZ tile are split into fp16 pairs in LDS, fragments by gfx950's transposing LDS read; `amax_dz` = amax slot of dz */
+int fp_conv_stem_wgrad_hp(const fp_conv_desc* d, const float* img_nchw, const float* dz, float* dw_oihw, int accumulate, void* workspace,
+                          int64_t workspace_bytes, const uint32_t* amax_dz, fp_stream_t stream);
 
 /* ---- BatchNorm (train-mode batch statistics; torchvision BN in the encoder) ---- */
 /* stats over z[M][C]: save_mean, save_invstd, fused scale = gamma*invstd, shift = beta - mean*scale;

@@ -36,6 +36,70 @@ def pack_job_hp(kind, w, elems, c_begin, c_count):
     return wp, s
 
 
+@pytest.mark.parametrize("N,H,W", [(2, 64, 96), (1, 192, 640), (3, 34, 50)])
+def test_conv_stem_hp(N, H, W):
+    """fp_conv_stem_hp: the 7x7 / 2 stem with fp16-pair operands (K re-indexed as 7 rows x 24, image scaled by 2^12) against float64, at the
+    tolerance of the other fp16-pair kernels; statistics sink; bias + ReLU epilogue; amax of the output published"""
+    ops, L = _ops()
+    img, w = rnd((N, 3, H, W), 810, 0.0, 1.0), rnd((64, 3, 7, 7), 811, -0.1, 0.1)
+    ref = F.conv2d((img.double() - 0.45) / 0.225, w.double(), None, 2, 3)
+    OH, OW = ref.shape[2:]
+    wp, sw = pack_job_hp(L.PACK_STEM_HP, w, 11 * 64 * 16, 0, 3)
+    d = ops.make_desc(N, OH, OW, H, W, 3, 0, 64, 7, 2, 3, L.GATHER_STEM)
+    assert ops.conv_stem_hp_supported(d)
+    y = torch.full((N, OH, OW, 64), float("nan"), device="cuda")
+    tiles = N * ((OH + 7) // 8) * ((OW + 15) // 16)
+    part = torch.full((tiles * 64 * 3,), float("nan"), device="cuda")
+    cell = ops.bn_stats_out_next(part)
+    so = ops.new_slot()
+    ops.conv_stem_hp(d, img.cuda(), wp, y, sw, amax_out=so)
+    torch.cuda.synchronize()
+    check(nchw(y), ref, "stem hp", 2e-6)
+    assert cell.value == tiles and ops.amax_value(so) == float(y.abs().max())
+    assert float(part.view(tiles, 64, 3)[:, :, 0].sum(0).min()) == float(N * OH * OW)
+    g, b = rnd((64,), 812, 0.5, 1.5).cuda(), rnd((64,), 813).cuda()
+    outs = [[torch.zeros(64, device="cuda") for _ in range(4)] for _ in range(2)]
+    rms, rvs = [torch.zeros(64, device="cuda") for _ in range(2)], [torch.ones(64, device="cuda") for _ in range(2)]
+    nbt = [torch.zeros((), dtype=torch.int64, device="cuda") for _ in range(2)]
+    ops.bn_train_stats_partials(part, tiles, 64, g, b, rms[0], rvs[0], nbt[0], *outs[0])
+    ops.bn_train_stats(y.view(-1, 64), g, b, rms[1], rvs[1], nbt[1], *outs[1])
+    yd = y.double().cpu().view(-1, 64)
+    mean, invstd = yd.mean(0), 1.0 / torch.sqrt(yd.var(0, unbiased=False) + 1e-5)
+    for k, want in enumerate((mean, invstd)):
+        for o in outs:
+            assert relerr(o[k], want) < 2e-6, k
+    y2 = torch.empty_like(y)                                       # bias + ReLU (the eval path's folded BatchNorm), no statistics
+    cell = ops.bn_stats_out_next(part)
+    d2 = ops.make_desc(N, OH, OW, H, W, 3, 0, 64, 7, 2, 3, L.GATHER_STEM, act=L.ACT_RELU)
+    ops.conv_stem_hp(d2, img.cuda(), wp, y2, sw, bias=b)
+    assert cell.value == 0
+    check(nchw(y2), torch.relu(ref + b.double().cpu().view(1, 64, 1, 1)), "stem hp + bias + relu", 2e-6)
+
+
+@pytest.mark.parametrize("N,H,W", [(2, 64, 96), (1, 192, 640), (3, 34, 50), (12, 192, 640)])
+def test_conv_stem_wgrad_hp(N, H, W):
+    """fp_conv_stem_wgrad_hp: the stem's weight gradient with fp16-pair operands (transposing LDS reads, K blocks of one kernel row) against
+    float64; ragged tiles at the right / bottom edge; accumulate"""
+    ops, L = _ops()
+    img = rnd((N, 3, H, W), 820, 0.0, 1.0)
+    w = rnd((64, 3, 7, 7), 821, -0.1, 0.1).double().requires_grad_(True)
+    y = F.conv2d((img.double() - 0.45) / 0.225, w, None, 2, 3)
+    g = rnd(tuple(y.shape), 822)
+    y.backward(g.double())
+    OH, OW = y.shape[2:]
+    d = ops.make_desc(N, OH, OW, H, W, 3, 0, 64, 7, 2, 3, L.GATHER_STEM)
+    gz = nhwc(g)
+    dw = torch.full((64, 3, 7, 7), float("nan"), device="cuda")
+    ops.conv_stem_wgrad_hp(d, img.cuda(), gz, dw, slot_of(gz))
+    check(dw, w.grad, "stem wgrad hp", 2e-6)
+    first = dw.clone()
+    ops.conv_stem_wgrad_hp(d, img.cuda(), gz, dw, slot_of(gz), accumulate=True)
+    assert torch.equal(dw, first + first)                            # bit-reproducible, and accumulate adds exactly
+    dw32 = torch.empty_like(dw)                                      # the fp32-MFMA kernel on the same inputs: the fp16-pair form is at least as close
+    ops.conv_wgrad(d, img.cuda(), None, gz, dw32)
+    assert relerr(first, w.grad) <= max(2.0 * relerr(dw32, w.grad), 5e-7)
+
+
 def test_amax_reduction_and_zeroing():
     ops, _ = _ops()
     for n, scale in ((1, 1.0), (3, 1e-30), (1000, 1e30), (12 * 96 * 320 * 64, 7.0), (1 << 20, 1e-3)):
