@@ -168,37 +168,16 @@ __global__ void __launch_bounds__(256) stem_tile_hp_kernel(const StemHpArgs a) {
   const unsigned amax_raw = fp_amax3_issue(a.amax_w, nullptr, nullptr);
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, idx = lane & 31, h = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
-  int b = blockIdx.x;
-  const int tx = b % a.tilesX; b /= a.tilesX;
-  const int ty = b % a.tilesY;
-  const int n = b / a.tilesY;
-  const int y0 = ty * TH, x0 = tx * TW;
-  for (int e = t; e < HROWS * 40; e += 256) {          // (row, column): three channels each; rows / columns without a source pixel are zeros
-    const int r = e / 40, c = e - r * 40;
-    const int iy = 2 * y0 + r - 3, ix = 2 * x0 + c - 3;
-    const bool ok = r < PH && c < PW && iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW;
-#pragma unroll
-    for (int ci = 0; ci < 3; ++ci) {
-      const float v = ok ? (a.img[((size_t)(n * 3 + ci) * a.IH + iy) * a.IW + ix] - 0.45f) / 0.225f : 0.f;
-      const float sc = v * (float)(1 << STEM_KA);
-      const _Float16 hh = (_Float16)sc;
-      Ph[r * HRS + c * 3 + ci] = hh;
-      Pm[r * HRS + c * 3 + ci] = (_Float16)(sc - (float)hh);
-    }
-  }
   int pbase[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int pt = (wm * 2 + i) * 32 + idx;
     pbase[i] = (2 * (pt / TW)) * HRS + 6 * (pt % TW);
   }
-  f32x16 acc[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  // persistent workgroups (tiles blockIdx.x, + gridDim.x, ...): the lane's weights of all eleven K-steps stay in 88 registers, the amax slot and
+  // the tile-independent geometry are read once -- a tile is then staging, 66 MFMAs per wave and the stores
   const unsigned short* wl = a.w + (size_t)(wn * 32 + idx) * 16 + h * 8;
-  uint4 bh[STEM_STEPS], bm[STEM_STEPS];                // the lane's weights of all eleven K-steps: 88 registers, loaded under the patch staging
+  uint4 bh[STEM_STEPS], bm[STEM_STEPS];
 #pragma unroll
   for (int st = 0; st < STEM_STEPS; ++st) {
     bh[st] = *reinterpret_cast<const uint4*>(wl + (size_t)(st * 2 + 0) * 64 * 16);
@@ -207,83 +186,110 @@ __global__ void __launch_bounds__(256) stem_tile_hp_kernel(const StemHpArgs a) {
   unsigned mw, u1, u2;
   fp_amax3_reduce(amax_raw, mw, u1, u2);
   const float unscale = ldexpf(1.f, -(STEM_KA + fp_hp_exponent(mw, FP_HP_TARGET_W)));
-  __syncthreads();
-#pragma unroll
-  for (int st = 0; st < STEM_STEPS; ++st) {
-    const int k0 = st * 16, k1 = st * 16 + 8;          // first K index of the lane's group: h = 0 / h = 1
-    const int koff = h ? (k1 / 24) * HRS + k1 % 24 : (k0 / 24) * HRS + k0 % 24;
-    uint4 ah[2], am[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const unsigned* ph = reinterpret_cast<const unsigned*>(Ph + pbase[i] + koff);
-      const unsigned* pm = reinterpret_cast<const unsigned*>(Pm + pbase[i] + koff);
-      ah[i] = make_uint4(ph[0], ph[1], ph[2], ph[3]);
-      am[i] = make_uint4(pm[0], pm[1], pm[2], pm[3]);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {                      // smallest products first, as in the tile kernel
-      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(st_f16x8, am[i]), __builtin_bit_cast(st_f16x8, bh[st]), acc[i], 0, 0, 0);
-      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(st_f16x8, ah[i]), __builtin_bit_cast(st_f16x8, bm[st]), acc[i], 0, 0, 0);
-      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(st_f16x8, ah[i]), __builtin_bit_cast(st_f16x8, bh[st]), acc[i], 0, 0, 0);
-    }
-  }
   const int co = wn * 32 + idx;
   const float bias = a.bias ? a.bias[co] : 0.f;
-  if (a.bn_part) {                                     // statistics of what is stored (acc * unscale): as in stem_tile_kernel
-    auto ok_at = [&](int i, int r) {
-      const int pt = (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      return y0 + pt / TW < a.OH && x0 + pt % TW < a.OW;
-    };
-    float cnt = 0.f, sum = 0.f;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const bool ok = ok_at(i, r);
-        cnt += ok ? 1.f : 0.f;
-        sum += ok ? acc[i][r] * unscale : 0.f;
-      }
-    FpWf w{cnt, cnt > 0.f ? sum / cnt : 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float dv = acc[i][r] * unscale - w.mean;
-        w.m2 += ok_at(i, r) ? dv * dv : 0.f;
-      }
-    const FpWf o{__shfl_xor(w.n, 32, 64), __shfl_xor(w.mean, 32, 64), __shfl_xor(w.m2, 32, 64)};
-    FpWf lo = h == 0 ? w : o;
-    fp_wf_merge(lo, h == 0 ? o : w);
-    __syncthreads();                                   // every wave is done with the patch
-    float* st = reinterpret_cast<float*>(Ph);          // [wave][32][3]
-    if (h == 0) {
-      float* q = st + (wave * 32 + idx) * 3;
-      q[0] = lo.n; q[1] = lo.mean; q[2] = lo.m2;
-    }
-    __syncthreads();
-    if (t < 64) {
-      const float* q0 = st + ((t >> 5) * 32 + (t & 31)) * 3;
-      const float* q1 = st + ((2 + (t >> 5)) * 32 + (t & 31)) * 3;
-      FpWf m{q0[0], q0[1], q0[2]};
-      fp_wf_merge(m, FpWf{q1[0], q1[1], q1[2]});
-      float* out = a.bn_part + ((size_t)blockIdx.x * 64 + t) * 3;
-      out[0] = m.n; out[1] = m.mean; out[2] = m.m2;
-    }
-  }
   float ymax = 0.f;
+  const int ntiles = a.N * a.tilesX * a.tilesY;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int b = tile;
+    const int tx = b % a.tilesX; b /= a.tilesX;
+    const int ty = b % a.tilesY;
+    const int n = b / a.tilesY;
+    const int y0 = ty * TH, x0 = tx * TW;
+    __syncthreads();                                   // the previous tile's patch (and statistics scratch) has been read by every wave
+    for (int e = t; e < HROWS * 40; e += 256) {        // (row, column): three channels each; rows / columns without a source pixel are zeros
+      const int r = e / 40, c = e - r * 40;
+      const int iy = 2 * y0 + r - 3, ix = 2 * x0 + c - 3;
+      const bool ok = r < PH && c < PW && iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int pt = (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      const int oy = y0 + pt / TW, ox = x0 + pt % TW;
-      if (oy >= a.OH || ox >= a.OW) continue;
-      float v = fmaf(acc[i][r], unscale, bias);
-      if (a.act == FP_ACT_RELU) v = fmaxf(v, 0.f);
-      else if (a.act == FP_ACT_ELU) v = fp_elu(v);
-      a.y[((size_t)(n * a.OH + oy) * a.OW + ox) * 64 + co] = v;
-      ymax = fmaxf(ymax, fabsf(v));
+      for (int ci = 0; ci < 3; ++ci) {
+        const float v = ok ? (a.img[((size_t)(n * 3 + ci) * a.IH + iy) * a.IW + ix] - 0.45f) / 0.225f : 0.f;
+        const float sc = v * (float)(1 << STEM_KA);
+        const _Float16 hh = (_Float16)sc;
+        Ph[r * HRS + c * 3 + ci] = hh;
+        Pm[r * HRS + c * 3 + ci] = (_Float16)(sc - (float)hh);
+      }
     }
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int st = 0; st < STEM_STEPS; ++st) {
+      const int k0 = st * 16, k1 = st * 16 + 8;        // first K index of the lane's group: h = 0 / h = 1
+      const int koff = h ? (k1 / 24) * HRS + k1 % 24 : (k0 / 24) * HRS + k0 % 24;
+      uint4 ah[2], am[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const unsigned* ph = reinterpret_cast<const unsigned*>(Ph + pbase[i] + koff);
+        const unsigned* pm = reinterpret_cast<const unsigned*>(Pm + pbase[i] + koff);
+        ah[i] = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+        am[i] = make_uint4(pm[0], pm[1], pm[2], pm[3]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {                    // smallest products first, as in the tile kernel
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(st_f16x8, am[i]), __builtin_bit_cast(st_f16x8, bh[st]), acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(st_f16x8, ah[i]), __builtin_bit_cast(st_f16x8, bm[st]), acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(st_f16x8, ah[i]), __builtin_bit_cast(st_f16x8, bh[st]), acc[i], 0, 0, 0);
+      }
+    }
+    if (a.bn_part) {                                   // statistics of what is stored (acc * unscale): as in stem_tile_kernel
+      auto ok_at = [&](int i, int r) {
+        const int pt = (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        return y0 + pt / TW < a.OH && x0 + pt % TW < a.OW;
+      };
+      float cnt = 0.f, sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const bool ok = ok_at(i, r);
+          cnt += ok ? 1.f : 0.f;
+          sum += ok ? acc[i][r] * unscale : 0.f;
+        }
+      FpWf w{cnt, cnt > 0.f ? sum / cnt : 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float dv = acc[i][r] * unscale - w.mean;
+          w.m2 += ok_at(i, r) ? dv * dv : 0.f;
+        }
+      const FpWf o{__shfl_xor(w.n, 32, 64), __shfl_xor(w.mean, 32, 64), __shfl_xor(w.m2, 32, 64)};
+      FpWf lo = h == 0 ? w : o;
+      fp_wf_merge(lo, h == 0 ? o : w);
+      __syncthreads();                                 // every wave is done with the patch
+      float* st = reinterpret_cast<float*>(Ph);        // [wave][32][3]
+      if (h == 0) {
+        float* q = st + (wave * 32 + idx) * 3;
+        q[0] = lo.n; q[1] = lo.mean; q[2] = lo.m2;
+      }
+      __syncthreads();
+      if (t < 64) {
+        const float* q0 = st + ((t >> 5) * 32 + (t & 31)) * 3;
+        const float* q1 = st + ((2 + (t >> 5)) * 32 + (t & 31)) * 3;
+        FpWf m{q0[0], q0[1], q0[2]};
+        fp_wf_merge(m, FpWf{q1[0], q1[1], q1[2]});
+        float* out = a.bn_part + ((size_t)tile * 64 + t) * 3;
+        out[0] = m.n; out[1] = m.mean; out[2] = m.m2;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int pt = (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int oy = y0 + pt / TW, ox = x0 + pt % TW;
+        if (oy >= a.OH || ox >= a.OW) continue;
+        float v = fmaf(acc[i][r], unscale, bias);
+        if (a.act == FP_ACT_RELU) v = fmaxf(v, 0.f);
+        else if (a.act == FP_ACT_ELU) v = fp_elu(v);
+        a.y[((size_t)(n * a.OH + oy) * a.OW + ox) * 64 + co] = v;
+        ymax = fmaxf(ymax, fabsf(v));
+      }
+  }
   if (a.amax_out) fp_amax_publish_block(a.amax_out, ymax);
 }
 
@@ -561,7 +567,8 @@ extern "C" int fp_conv_stem_hp(const fp_conv_desc* d, const float* img, const vo
     a.bn_part = sink.part;
     if (sink.nblk_out) *sink.nblk_out = (int32_t)ntiles;
   }
-  fp_launch(stem_tile_hp_kernel, dim3((unsigned)ntiles), dim3(256), 0, (hipStream_t)stream, a);
+  static const int wgs = getenv("FP_STEM_HP_WGS") ? atoi(getenv("FP_STEM_HP_WGS")) : 512;          // persistent: two workgroups per CU (194 VGPRs)
+  fp_launch(stem_tile_hp_kernel, dim3((unsigned)(ntiles < wgs ? ntiles : wgs)), dim3(256), 0, (hipStream_t)stream, a);
   return fp_check_launch("fp_conv_stem_hp");
 }
 
