@@ -236,6 +236,8 @@ GROUPS = {
     "conv_igemm": dict(kernel="igemm_kernel / stem_tile_kernel (7x7 stem, 4x4/2 phase dgrad of small levels; stride 2 / 1x1 with FP_HP_IGEMM=0)", bf16x3=False),
     "conv_igemm_hp": dict(kernel="igemm_hp_kernel (fp16-pair operands: 3x3 stride 2, 1x1, their data gradients; + splitk_reduce_kernel on small grids)",
                           bf16x3=False, products=HP_PRODUCTS),
+    "conv_stem_hp": dict(kernel="stem_tile_hp_kernel / stem_wgrad_hp_kernel (the 7x7 / 2 stem and its weight gradient with fp16-pair operands; + wgrad_reduce_wide_kernel)",
+                         bf16x3=False, products=HP_PRODUCTS),
     "conv_up2_phase_fwd_bf3": dict(kernel="up2_phase_fwd_bf3_kernel", bf16x3=True),
     "conv_up2_phase_fwd": dict(kernel="up2_phase_fwd_kernel", bf16x3=False),
     "conv_up2_phase_dgrad_bf3": dict(kernel="up2_phase_dgrad_bf3_kernel", bf16x3=True),
@@ -251,11 +253,14 @@ GROUP_SYMBOL = {
     "conv_up2_phase_fwd_hp": ("up2_phase_fwd_bf3_kernel",), "conv_up2_phase_fwd_bf3": ("up2_phase_fwd_bf3_kernel",),
     "conv_up2_phase_dgrad_hp": ("up2_phase_dgrad_bf3_kernel",), "conv_up2_phase_dgrad_bf3": ("up2_phase_dgrad_bf3_kernel",),
     "conv_up2_phase_wgrad_hp": ("wgrad_up2_phase_bf3_kernel",), "conv_up2_phase_wgrad_bf3": ("wgrad_up2_phase_bf3_kernel",),
+    "conv_stem_hp": ("stem_tile_hp_kernel", "stem_wgrad_hp_kernel"),
     "conv_igemm": ("igemm_kernel", "stem_tile_kernel"), "conv_igemm_hp": ("igemm_hp_kernel",), "conv_wgrad": ("wgrad_kernel", "wgrad3x3_tile_kernel", "stem_wgrad_tile_kernel"),
 }
 CONV_OPS = {
     "conv_igemm": dict(group="conv_igemm", dense=conv_flops, exec=conv_flops, bytes=conv_bytes),
     "conv_igemm_hp": dict(group="conv_igemm_hp", dense=conv_flops, exec=conv_flops, bytes=conv_bytes),
+    "conv_stem_hp": dict(group="conv_stem_hp", dense=conv_flops, exec=conv_flops, bytes=conv_bytes),
+    "conv_stem_wgrad_hp": dict(group="conv_stem_hp", dense=conv_flops, exec=conv_flops, bytes=conv_bytes),
     "conv3x3_bf3": dict(group="conv3x3_bf3", dense=conv_flops, exec=conv_flops, bytes=conv_bytes),
     "conv3x3_hp": dict(group="conv3x3_hp", dense=conv_flops, exec=conv_flops, bytes=conv_bytes),
     "conv_up2_phase_fwd": dict(group="conv_up2_phase_fwd", dense=phase_fwd_dense, exec=_frac(phase_fwd_dense, 4.0 / 9.0), bytes=phase_fwd_bytes,

@@ -355,10 +355,12 @@ extern "C" int fp_conv_stem_wgrad_hp(const fp_conv_desc* d, const float* img_nch
              "fp_conv_stem_wgrad_hp: the 7x7 / 2 stem on even image dims only");
   const Plan p = make_plan(d);
   FP_REQUIRE(workspace_bytes >= fp_conv_wgrad_workspace(d), "fp_conv_stem_wgrad_hp: workspace too small");
-  const int rc = fp_stem_wgrad_hp_dispatch(d, img_nchw, dz, (float*)workspace, p.S, amax_dz, stream);
+  static const int hp_wgs = getenv("FP_STEM_WGRAD_HP_WGS") ? atoi(getenv("FP_STEM_WGRAD_HP_WGS")) : 512;      // two resident workgroups per CU (184 registers)
+  const int S = p.S < hp_wgs ? p.S : hp_wgs;         // persistent workgroups = partial tensors (the workspace holds p.S of them)
+  const int rc = fp_stem_wgrad_hp_dispatch(d, img_nchw, dz, (float*)workspace, S, amax_dz, stream);
   FP_REQUIRE(rc != -1000, "fp_conv_stem_wgrad_hp: shape not handled");
   if (rc) return rc;
-  return fp_wgrad_reduce_launch((const float*)workspace, dw_oihw, p.S, p.T, p.Kc, d->Nout, 1, accumulate, 3, 0, stream);
+  return fp_wgrad_reduce_launch((const float*)workspace, dw_oihw, S, p.T, p.Kc, d->Nout, 1, accumulate, 3, 0, stream);
 }
 
 extern "C" int fp_conv_wgrad_slice(const fp_conv_desc* d, const float* src0, const float* src1, const float* dz, float* dw_oihw,

@@ -162,7 +162,7 @@ struct StemHpArgs {
   int N, IH, IW, OH, OW, tilesX, tilesY, act;
 };
 
-__global__ void __launch_bounds__(256) stem_tile_hp_kernel(const StemHpArgs a) {
+__global__ void __launch_bounds__(256, 2) stem_tile_hp_kernel(const StemHpArgs a) {
   __shared__ __attribute__((aligned(16))) _Float16 Ph[HROWS * HRS];
   __shared__ __attribute__((aligned(16))) _Float16 Pm[HROWS * HRS];
   const unsigned amax_raw = fp_amax3_issue(a.amax_w, nullptr, nullptr);
@@ -190,6 +190,25 @@ __global__ void __launch_bounds__(256) stem_tile_hp_kernel(const StemHpArgs a) {
   const float bias = a.bias ? a.bias[co] : 0.f;
   float ymax = 0.f;
   const int ntiles = a.N * a.tilesX * a.tilesY;
+  // the patch of a tile: (row, column) entries t, t + 256, ... of the 22 x 40 grid, three channels each, raw image values in registers (NaN marks
+  // "no source pixel": zero AFTER the normalisation) -- loaded for the NEXT tile while the current one is multiplied and stored
+  constexpr int NE = (HROWS * 40 + 255) / 256;         // 4 entries per thread
+  float raw[NE][3];
+  auto load_patch = [&](int tile) __attribute__((always_inline)) {
+    int b = tile;
+    const int tx = b % a.tilesX; b /= a.tilesX;
+    const int ty = b % a.tilesY;
+    const int n = b / a.tilesY;
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+      const int e = t + 256 * k, r = e / 40, c = e - r * 40;
+      const int iy = 2 * ty * TH + r - 3, ix = 2 * tx * TW + c - 3;
+      const bool ok = tile < ntiles && r < PH && c < PW && iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW;
+#pragma unroll
+      for (int ci = 0; ci < 3; ++ci) raw[k][ci] = ok ? a.img[((size_t)(n * 3 + ci) * a.IH + iy) * a.IW + ix] : __builtin_nanf("");
+    }
+  };
+  load_patch(blockIdx.x);
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     int b = tile;
     const int tx = b % a.tilesX; b /= a.tilesX;
@@ -197,19 +216,20 @@ __global__ void __launch_bounds__(256) stem_tile_hp_kernel(const StemHpArgs a) {
     const int n = b / a.tilesY;
     const int y0 = ty * TH, x0 = tx * TW;
     __syncthreads();                                   // the previous tile's patch (and statistics scratch) has been read by every wave
-    for (int e = t; e < HROWS * 40; e += 256) {        // (row, column): three channels each; rows / columns without a source pixel are zeros
-      const int r = e / 40, c = e - r * 40;
-      const int iy = 2 * y0 + r - 3, ix = 2 * x0 + c - 3;
-      const bool ok = r < PH && c < PW && iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW;
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+      const int e = t + 256 * k, r = e / 40, c = e - r * 40;
+      if (e >= HROWS * 40) break;
 #pragma unroll
       for (int ci = 0; ci < 3; ++ci) {
-        const float v = ok ? (a.img[((size_t)(n * 3 + ci) * a.IH + iy) * a.IW + ix] - 0.45f) / 0.225f : 0.f;
+        const float v = raw[k][ci] == raw[k][ci] ? (raw[k][ci] - 0.45f) / 0.225f : 0.f;
         const float sc = v * (float)(1 << STEM_KA);
         const _Float16 hh = (_Float16)sc;
         Ph[r * HRS + c * 3 + ci] = hh;
         Pm[r * HRS + c * 3 + ci] = (_Float16)(sc - (float)hh);
       }
     }
+    load_patch(tile + gridDim.x);                      // in flight under the MFMAs and the stores below
     f32x16 acc[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -425,36 +445,57 @@ __global__ void __launch_bounds__(256) stem_wgrad_hp_kernel(const StemWHpArgs a)
   const int zoff = (8 * kg + r4) * ZPX + 16 * b4 + 4 * q;
   const int poff = (2 * (8 * kg + r4) + 4 * b4 + q) * 4;
 
-  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+  // a tile's operands in registers (raw image values, NaN = no source pixel; dZ quads), loaded for the NEXT tile while this one is multiplied
+  constexpr int NE = (WROWS * 38 + 255) / 256;         // 4 patch entries per thread
+  float raw[NE][3];
+  float4 zr[8];
+  auto load_tile = [&](int tile) __attribute__((always_inline)) {
     int b = tile;
     const int tx = b % a.tilesX; b /= a.tilesX;
     const int ty = b % a.tilesY;
     const int n = b / a.tilesY;
-    const int y0 = ty * TH, x0 = tx * TW;
+    const bool live = tile < a.ntiles;
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+      const int e = t + 256 * k, r = e / 38, c = e - r * 38;
+      const int iy = 2 * ty * TH + r - 3, ix = 2 * tx * TW + c - 3;
+      const bool ok = live && r < WROWS && c < PW && iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW;
+#pragma unroll
+      for (int ci = 0; ci < 3; ++ci) raw[k][ci] = ok ? a.img[((size_t)(n * 3 + ci) * a.IH + iy) * a.IW + ix] : __builtin_nanf("");
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int e = t + 256 * k, pt = e >> 4, q4 = e & 15;
+      const int oy = ty * TH + pt / TW, ox = tx * TW + pt % TW;
+      zr[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (live && oy < a.OH && ox < a.OW) zr[k] = *reinterpret_cast<const float4*>(a.dz + ((size_t)(n * a.OH + oy) * a.OW + ox) * 64 + q4 * 4);
+    }
+  };
+  load_tile(blockIdx.x);
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     __syncthreads();                                   // the previous tile has been read by every wave
-    for (int e = t; e < WROWS * 38; e += 256) {
-      const int r = e / 38, c = e - r * 38;
-      const int iy = 2 * y0 + r - 3, ix = 2 * x0 + c - 3;
-      const bool ok = c < PW && iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW;
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+      const int e = t + 256 * k, r = e / 38, c = e - r * 38;
+      if (e >= WROWS * 38) break;
       float v[3];
 #pragma unroll
-      for (int ci = 0; ci < 3; ++ci) v[ci] = ok ? (a.img[((size_t)(n * 3 + ci) * a.IH + iy) * a.IW + ix] - 0.45f) / 0.225f : 0.f;
+      for (int ci = 0; ci < 3; ++ci) v[ci] = raw[k][ci] == raw[k][ci] ? (raw[k][ci] - 0.45f) / 0.225f : 0.f;
       uint2 hq, mq;
       fp_hp_split4(v[0], v[1], v[2], 0.f, (float)(1 << STEM_KA), hq, mq);
       *reinterpret_cast<uint2*>(Ph + r * WRS + c * 4) = hq;
       *reinterpret_cast<uint2*>(Pm + r * WRS + c * 4) = mq;
     }
-    for (int e = t; e < TH * TW * 16; e += 256) {
-      const int pt = e >> 4, q4 = e & 15;
-      const int oy = y0 + pt / TW, ox = x0 + pt % TW;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (oy < a.OH && ox < a.OW) v = *reinterpret_cast<const float4*>(a.dz + ((size_t)(n * a.OH + oy) * a.OW + ox) * 64 + q4 * 4);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int e = t + 256 * k, pt = e >> 4, q4 = e & 15;
       uint2 hq, mq;
-      fp_hp_split4(v.x, v.y, v.z, v.w, sz, hq, mq);
+      fp_hp_split4(zr[k].x, zr[k].y, zr[k].z, zr[k].w, sz, hq, mq);
       *reinterpret_cast<uint2*>(Zh + pt * ZPX + q4 * 4) = hq;
       *reinterpret_cast<uint2*>(Zm + pt * ZPX + q4 * 4) = mq;
     }
     __syncthreads();
+    load_tile(tile + gridDim.x);                       // in flight under the MFMAs below
 #pragma unroll
     for (int s = 0; s < TH; ++s) {                     // K-step = tile row s (sixteen pixels)
       uint4 zh[2], zm[2];
