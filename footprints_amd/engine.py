@@ -953,6 +953,11 @@ class Engine:
             for di, dec in enumerate(self.decoders):
                 for _ in self._decoder_forward(dec, S, outputs, S["dec"][di]):
                     pass
+        # the repack of the data-gradient layouts (refresh_packed) is the one piece of side-stream work a forward pass can leave behind: join
+        # it here, not only where the backward starts -- a caller that drops the model after a forward (inference, tests) frees the packed
+        # buffer on THIS stream's timeline, and the allocator may hand the memory to the next model while the repack still writes into it
+        # (seen once as a 1e-1 error in the next test's first decoder output).  The repack finished milliseconds ago: the wait costs a packet.
+        self._wait_pack_dgrad()
         self.saved = S if save_for_backward else None
         return outputs
 

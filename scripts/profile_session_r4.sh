@@ -19,7 +19,7 @@ done
 rm -rf /tmp/pc; rocprofv3 --kernel-trace --stats -d /tmp/pc -- python $R/scripts/step_loop.py kitti 5 3 > /dev/null 2>&1
 DB=$(find /tmp/pc -name "*.db" | head -1)
 python $R/scripts/rocprof_summary.py $DB $O/round4_kernel_stats_concurrent_kitti.txt "rocprofv3 --kernel-trace --stats -- python scripts/step_loop.py kitti 5 3   (default schedule: four hardware queues, recorded launch plan; 8 train steps)"
-python $R/scripts/timeline.py $DB > $O/round4_timeline_concurrent_step.txt 2>&1
+python $R/scripts/timeline.py $DB -2 trace > $O/round4_timeline_concurrent_step.txt 2>&1
 echo "timeline done t=$(( $(date +%s)-t0 ))"
 # ---- SQ counters: three counters-only passes per kernel on its microbenchmark
 P1="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU"

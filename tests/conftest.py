@@ -42,7 +42,9 @@ def pytest_sessionfinish(session, exitstatus):
     for path in sorted(glob.glob(os.path.join(out_dir, "*.json"))):
         try:
             if os.path.getmtime(path) >= _SESSION_T0[0] - 1.0:
-                docs.append(json.load(open(path)))
+                doc = json.load(open(path))
+                if isinstance(doc, dict) and "case" in doc:          # (the directory also holds last_bn_decomposition.json)
+                    docs.append(doc)
         except (OSError, ValueError):
             pass
     if not docs:
