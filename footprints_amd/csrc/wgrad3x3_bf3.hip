@@ -2,22 +2,15 @@
 //
 //   dW[tap][ci][co] = sum over pixels p of  X[p + tap][ci] * dZ[p][co]
 //
-// Kernels in this file, oldest first (the entry points pick: fp16 pairs -> wgrad3x3_hp_pf_kernel, exact split -> wgrad3x3_bf3_v3_kernel):
-//   wgrad3x3_bf3_kernel       first generation (FP_WGRAD_BF3_V=1), described right below
+// Kernels in this file (the entry points pick: fp16 pairs -> wgrad3x3_hp_pf_kernel, exact split -> wgrad3x3_bf3_v3_kernel):
 //   wgrad3x3_bf3_v3_kernel    [pixel][channel] planes in LDS + hardware transpose reads (ds_read_b64_tr_b16); exact split and fp16 pairs
 //   wgrad3x3_hp_pf_kernel     the same LDS layout / MFMA order / sums, operands two chunks ahead in a register ring of raw buffer loads
 //   wgrad_reduce_bias[_t]_kernel   the fixed-order sum over the pixel splits into OIHW (+ bias gradient); _t: through an LDS transpose
 //
-// The contraction runs over PIXELS, so both MFMA operands want "8 consecutive pixels of one channel" per lane while the
-// tensors are NHWC.  The transposition happens once, on the way into LDS, together with the exact three-way bf16 split
-// (x = h + m + l, see conv3x3_tile_bf3.hip): a thread takes 4 consecutive pixels x 4 channels (four float4 loads), regroups
-// the registers per channel (free), converts and writes one 8-byte [4 pixels] group per channel and plane:
-//     Xs[plane][halo row 6][ci 32][20 cols]   Zs[plane][row 4][co 32][16 cols]   (48-byte rows: conflict-free ds_read_b128)
-// A workgroup owns a (32 ci x 32 co) block of all nine taps and walks 4 x 16 pixel chunks; wave w takes chunk row w: ONE
-// 16-pixel k-step per tap, six v_mfma_f32_32x32x16_bf16 each (54 MFMAs x 32 cycles per wave per chunk instead of 72 x 64 of the
-// fp32 kernel, wgrad3x3_tile.hip).  The kx = 1, 2 taps are the kx = 0 operand shifted by one / two bf16: a funnel shift
-// (v_alignbit) of the aligned 16-byte read plus the next dword.  Global loads of the next chunk fly under the MFMAs of the
-// current one (register prefetch, single LDS buffer, two barriers per chunk).  Sums across waves / splits: fixed order.
+// The contraction runs over PIXELS, so both MFMA operands want "8 consecutive pixels of one channel" per lane while the tensors are NHWC.
+// A workgroup owns a (32 ci x 32 co) block of all nine taps and walks 4 x 16 pixel chunks; wave w takes chunk row w: ONE 16-pixel k-step per
+// tap.  The first generation (transposition at staging time, funnel shifts for the kx taps; rounds 1-3 behind FP_WGRAD_BF3_V=1) and the second
+// (fp32 transposed in LDS) have left the tree: commits ea6fa4d / df15caf hold them, profiles/round2_notes.md their counters.
 #include <stdio.h>
 
 #include <type_traits>
@@ -54,9 +47,6 @@ constexpr int CH = 4, CW = 16, HR = CH + 2;
 #define FP_WGRAD_PF_DEFAULT 2
 #endif
 
-constexpr int XROW = 48, ZROW = 48;                          // bytes per (row, channel) line: 20 / 16 bf16 + pad
-constexpr int XPLANE = HR * 32 * XROW, ZPLANE = CH * 32 * ZROW;
-constexpr int XBYTES = 3 * XPLANE, ZBYTES = 3 * ZPLANE;      // 27648 + 18432 = 46080
 
 __device__ __forceinline__ void split_store(unsigned char* p, int plane_stride, const f32x4 v) {
   const bf16x4 vh = __builtin_convertvector(v, bf16x4);
@@ -69,170 +59,8 @@ __device__ __forceinline__ void split_store(unsigned char* p, int plane_stride, 
   *reinterpret_cast<uint2*>(p + 2 * plane_stride) = __builtin_bit_cast(uint2, vl);
 }
 
-__global__ void __launch_bounds__(256) wgrad3x3_bf3_kernel(const W3Args a) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[XBYTES + ZBYTES];
-  unsigned char* const Xs = lds;
-  unsigned char* const Zs = lds + XBYTES;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, idx = lane & 31, h = lane >> 5;
-  int b = blockIdx.x;
-  const int cot = b % a.cotiles; b /= a.cotiles;
-  const int cit = b % a.citiles; b /= a.citiles;
-  const int s = b;
-  const int ci0 = cit * 32, co0 = cot * 32;
-  const int c_begin = s * a.chunksPerSplit;
-  const int c_end = min(a.nchunks, c_begin + a.chunksPerSplit);
-
-  // staging items: X: (halo row hr, column group cg of 4, channel quad q) for t < 240;  dZ: (row, cg, q) for t < 128
-  const int q = t & 7;
-  const int xcg = (t >> 3) % 5, xhr = t / 40;
-  const int zcg = (t >> 3) & 3, zr = t >> 5;
-  const bool xitem = t < 240, zitem = t < 128;
-  float4 xr[4], zv[4];
-  unsigned xmask = 0, zmask = 0;      // bit j: pixel j of the group is real data (else zero)
-  const bool want_bias = a.bpart != nullptr && cit == 0;     // dZ passes through this workgroup's registers exactly once
-  float bs[4] = {0.f, 0.f, 0.f, 0.f};
-
-  auto issue = [&](int c) {
-    const int cx = c % a.chunksX;
-    const int r = c / a.chunksX;
-    const int cy = r % a.chunksY, n = r / a.chunksY;
-    const int y0 = cy * CH, x0 = cx * CW;
-    xmask = zmask = 0;
-    {
-      int sy = y0 + xhr - 1;
-      bool rowok = xitem;
-      if (a.mode == 0) rowok = rowok && sy >= 0 && sy < a.H;
-      else { rowok = rowok && sy >= -1 && sy <= a.H; sy = fp_reflect(sy, a.H); }
-      sy = min(max(sy, 0), a.H - 1);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int hx = xcg * 4 + j;                    // halo column 0..19 (18, 19 are padding)
-        int sx = x0 + hx - 1;
-        bool ok = rowok && hx < CW + 2;
-        if (a.mode == 0) ok = ok && sx >= 0 && sx < a.W;
-        else { ok = ok && sx >= -1 && sx <= a.W; sx = fp_reflect(sx, a.W); }
-        sx = min(max(sx, 0), a.W - 1);
-        const size_t xpix = a.mode == 2 ? (size_t)(n * (a.H >> 1) + (sy >> 1)) * (a.W >> 1) + (sx >> 1) : (size_t)(n * a.H + sy) * a.W + sx;
-        xr[j] = *reinterpret_cast<const float4*>(a.x + xpix * a.C + ci0 + q * 4);
-        xmask |= ok ? (1u << j) : 0u;
-      }
-    }
-    {
-      const int oy = min(y0 + zr, a.H - 1);
-      const bool rowok = zitem && y0 + zr < a.H;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int ox = x0 + zcg * 4 + j;
-        const bool ok = rowok && ox < a.W;
-        zv[j] = *reinterpret_cast<const float4*>(a.dz + ((size_t)(n * a.H + oy) * a.W + min(ox, a.W - 1)) * a.Nout + co0 + q * 4);
-        zmask |= ok ? (1u << j) : 0u;
-      }
-    }
-  };
-  auto stage = [&]() {
-    if (xitem) {
-      unsigned char* p = Xs + (xhr * 32 + q * 4) * XROW + xcg * 8;
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (!(xmask & (1u << j))) xr[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      split_store(p, XPLANE, f32x4{xr[0].x, xr[1].x, xr[2].x, xr[3].x});
-      split_store(p + XROW, XPLANE, f32x4{xr[0].y, xr[1].y, xr[2].y, xr[3].y});
-      split_store(p + 2 * XROW, XPLANE, f32x4{xr[0].z, xr[1].z, xr[2].z, xr[3].z});
-      split_store(p + 3 * XROW, XPLANE, f32x4{xr[0].w, xr[1].w, xr[2].w, xr[3].w});
-    }
-    if (zitem) {
-      unsigned char* p = Zs + (zr * 32 + q * 4) * ZROW + zcg * 8;
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (!(zmask & (1u << j))) zv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (want_bias) {
-        bs[0] += (zv[0].x + zv[1].x) + (zv[2].x + zv[3].x); bs[1] += (zv[0].y + zv[1].y) + (zv[2].y + zv[3].y);
-        bs[2] += (zv[0].z + zv[1].z) + (zv[2].z + zv[3].z); bs[3] += (zv[0].w + zv[1].w) + (zv[2].w + zv[3].w);
-      }
-      split_store(p, ZPLANE, f32x4{zv[0].x, zv[1].x, zv[2].x, zv[3].x});
-      split_store(p + ZROW, ZPLANE, f32x4{zv[0].y, zv[1].y, zv[2].y, zv[3].y});
-      split_store(p + 2 * ZROW, ZPLANE, f32x4{zv[0].z, zv[1].z, zv[2].z, zv[3].z});
-      split_store(p + 3 * ZROW, ZPLANE, f32x4{zv[0].w, zv[1].w, zv[2].w, zv[3].w});
-    }
-  };
-
-  f32x16 acc[9];
-#pragma unroll
-  for (int tp = 0; tp < 9; ++tp)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[tp][r] = 0.f;
-
-  if (c_begin < c_end) {
-    issue(c_begin);
-    stage();
-  }
-  __syncthreads();
-  for (int c = c_begin; c < c_end; ++c) {
-    if (c + 1 < c_end) issue(c + 1);                 // next chunk's global loads fly under this chunk's MFMAs
-    // B fragments: dZ row `wave`, lane (co = idx, pixel group h)
-    uint4 bz[3];
-#pragma unroll
-    for (int p = 0; p < 3; ++p) bz[p] = *reinterpret_cast<const uint4*>(Zs + p * ZPLANE + (wave * 32 + idx) * ZROW + h * 16);
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      uint4 a0[3], a1[3], a2[3];
-#pragma unroll
-      for (int p = 0; p < 3; ++p) {
-        const unsigned char* row = Xs + p * XPLANE + ((wave + ky) * 32 + idx) * XROW + h * 16;
-        const uint4 d = *reinterpret_cast<const uint4*>(row);                  // columns 8h .. 8h+7
-        const unsigned e = *reinterpret_cast<const unsigned*>(row + 16);       // columns 8h+8, 8h+9
-        a0[p] = d;
-        a1[p] = make_uint4(__builtin_amdgcn_alignbit(d.y, d.x, 16), __builtin_amdgcn_alignbit(d.z, d.y, 16),
-                           __builtin_amdgcn_alignbit(d.w, d.z, 16), __builtin_amdgcn_alignbit(e, d.w, 16));   // shifted by one column
-        a2[p] = make_uint4(d.y, d.z, d.w, e);                                                                  // by two
-      }
-      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-      for (int qq = 0; qq < 6; ++qq) {
-        const bf16x8 bb = __builtin_bit_cast(bf16x8, bz[PB[qq]]);
-        acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a0[PA[qq]]), bb, acc[ky * 3 + 0], 0, 0, 0);
-        acc[ky * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a1[PA[qq]]), bb, acc[ky * 3 + 1], 0, 0, 0);
-        acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a2[PA[qq]]), bb, acc[ky * 3 + 2], 0, 0, 0);
-      }
-    }
-    __syncthreads();                                  // every wave has read this chunk
-    if (c + 1 < c_end) stage();
-    __syncthreads();                                  // next chunk visible
-  }
-
-  // ---- sum the four waves' tiles through LDS (fixed order), one tap at a time ----------------------------------
-  float* red = reinterpret_cast<float*>(lds);        // [4 waves][16 regs][64 lanes] = 16 KB
-  float* out = a.part + (size_t)s * 9 * a.C * a.Nout;
-  if (want_bias) {                                   // 16 staging threads per channel quad -> one partial per output channel
-    if (zitem) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) red[(t >> 3) * 32 + q * 4 + k] = bs[k];
-    }
-    __syncthreads();
-    if (t < 32) {
-      float v = 0.f;
-#pragma unroll
-      for (int g = 0; g < 16; ++g) v += red[g * 32 + t];
-      a.bpart[(size_t)s * a.Nout + co0 + t] = v;
-    }
-    __syncthreads();
-  }
-#pragma unroll
-  for (int tp = 0; tp < 9; ++tp) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[tp][r];
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int e = t + 256 * k;
-      const float v = ((red[e] + red[1024 + e]) + red[2048 + e]) + red[3072 + e];
-      const int r = e >> 6, ln = e & 63;
-      const int ci = ci0 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
-      out[((size_t)tp * a.C + ci) * a.Nout + co0 + (ln & 31)] = v;
-    }
-    __syncthreads();
-  }
-}
+// (The first generation -- bf16 planes transposed at staging time, funnel shifts for the kx taps -- was kept behind FP_WGRAD_BF3_V=1 through round 3
+// and left the tree in round 4: commit ea6fa4d still has it.)
 
 // (A second generation -- fp32 transposed in LDS, exact split at read time, double-buffered, one barrier per chunk -- measured the same
 // as the first in the training step and is gone from the tree: commit df15caf still has it, profiles/round2_notes.md its counters.)
@@ -925,7 +753,6 @@ static int wgrad_split(const fp_conv_desc* d, const float* x, const float* dz, f
     if (!stamp_buf) (void)hipMalloc(&stamp_buf, (size_t)8192 * 6 * 8);
     if (nwg <= 8192) a.stamps = stamp_buf;
   }
-  static const int ver = getenv("FP_WGRAD_BF3_V") ? atoi(getenv("FP_WGRAD_BF3_V")) : 3;       // A/B switch: 1 = first generation, else third
   // FP_WGRAD_PF: 0 = third generation; 1, 2 = the ring kernel with two slots (the default); 3 = three slots (308 VGPRs: no faster alone,
   // slower in the step -- it no longer shares a SIMD with the small-grid tile kernels; profiles/round3_notes.md)
   static const int pf = getenv("FP_WGRAD_PF") ? atoi(getenv("FP_WGRAD_PF")) : FP_WGRAD_PF_DEFAULT;
@@ -946,8 +773,7 @@ static int wgrad_split(const fp_conv_desc* d, const float* x, const float* dz, f
     if (a.mode == 0) fp_launch((wgrad3x3_bf3_v3_kernel<0, 2>), dim3(nwg), dim3(256), 0, stream, a);
     else if (a.mode == 1) fp_launch((wgrad3x3_bf3_v3_kernel<1, 2>), dim3(nwg), dim3(256), 0, stream, a);
     else fp_launch((wgrad3x3_bf3_v3_kernel<2, 2>), dim3(nwg), dim3(256), 0, stream, a);
-  } else if (ver == 1) fp_launch(wgrad3x3_bf3_kernel, dim3(nwg), dim3(256), 0, stream, a);
-  else if (a.mode == 0) fp_launch((wgrad3x3_bf3_v3_kernel<0, 3>), dim3(nwg), dim3(256), 0, stream, a);
+  } else if (a.mode == 0) fp_launch((wgrad3x3_bf3_v3_kernel<0, 3>), dim3(nwg), dim3(256), 0, stream, a);
   else if (a.mode == 1) fp_launch((wgrad3x3_bf3_v3_kernel<1, 3>), dim3(nwg), dim3(256), 0, stream, a);
   else fp_launch((wgrad3x3_bf3_v3_kernel<2, 3>), dim3(nwg), dim3(256), 0, stream, a);
   int rc = fp_check_launch("fp_conv_wgrad_bf3");
