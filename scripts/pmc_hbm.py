@@ -13,7 +13,7 @@ import json
 import os
 import sys
 
-KERNEL_TO_ENTRY = [("wgrad3x3_hp_pf_kernel", "conv_wgrad_hp"), ("wgrad3x3_bf3_kernel", "conv_wgrad_bf3"), ("wgrad3x3_bf3_v", "conv_wgrad_bf3"), ("wgrad_up2_phase_bf3_kernel", "conv_up2_phase_wgrad_bf3"),
+KERNEL_TO_ENTRY = [("wgrad3x3_hp_pf_kernel", "conv_wgrad_hp"), ("wgrad3x3_bf3_v", "conv_wgrad_bf3"), ("wgrad_up2_phase_bf3_kernel", "conv_up2_phase_wgrad_bf3"),
                    ("conv3x3_tile_bf3_kernel", "conv3x3_bf3"), ("up2_phase_fwd_bf3_kernel", "conv_up2_phase_fwd_bf3"),
                    ("up2_phase_dgrad_bf3_kernel", "conv_up2_phase_dgrad_bf3"), ("igemm_hp_kernel", "conv_igemm_hp"), ("igemm_kernel", "conv_igemm"), ("stem_tile_kernel", "conv_igemm"),
                    ("wgrad3x3_tile_kernel", "conv_wgrad"), ("wgrad_kernel", "conv_wgrad")]
