@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box, round 4 session A: the rewritten tile kernel (buffer loads; persistent / 16x16-tile options) against round 3's
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 out=gpurun_out/r4a; mkdir -p $out; : > $out/summary.txt
 B=$PWD/scripts/ubench/bin
 t0=$(date +%s)

@@ -2,7 +2,7 @@
 # GPU box, round 4 session B: whole GPU suite on the current build; step A/B of the two-instruction fp16-pair split and of the BatchNorm
 # backward sums out of the data-gradient epilogue
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 out=gpurun_out/r4b; mkdir -p $out; : > $out/summary.txt
 t0=$(date +%s)
 timeout 1200 python -m pytest tests -m gpu -x -q > $out/pytest_all.log 2>&1; echo "pytest all rc=$? t=$(( $(date +%s)-t0 ))" >> $out/summary.txt

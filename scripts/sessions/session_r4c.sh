@@ -2,7 +2,7 @@
 # GPU box, round 4 session C: whole GPU suite on the current build; step A/B against the previous build (before the branch-free ELU /
 # 32-bit epilogue offsets / phase-kernel buffer loads) and against the v_fma_mix_f32-residual variant of the fp16-pair split
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 out=gpurun_out/r4c; mkdir -p $out; : > $out/summary.txt
 t0=$(date +%s)
 timeout 1500 python -m pytest tests -m gpu -q > $out/pytest_all.log 2>&1; echo "pytest all rc=$? t=$(( $(date +%s)-t0 ))" >> $out/summary.txt

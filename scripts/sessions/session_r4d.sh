@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box, round 4 session D: planner thresholds re-measured on the faster kernels (environment knobs, no rebuild) + a timeline of the step
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 out=gpurun_out/r4d; mkdir -p $out; : > $out/summary.txt
 t0=$(date +%s)
 scripts/ab_lib_step.sh kitti rounds=2 default default@FP_TILE_SK1_FROM=256 default@FP_TILE_SK1_FROM=400 default@FP_TILE_WPF_MAX_WG=800 default@FP_WGRAD_TARGET_WGS=384 default@FP_BN_ROWS_PER_THREAD=8 default@FP_TILE_SK1_FROM=100 > $out/ab_step.txt 2>&1

@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box, round 4 session F: the wave-specialised weight gradient (FP_WGRAD_WS=1) -- kernel tests, per-shape times, step A/B
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 out=gpurun_out/r4f; mkdir -p $out; : > $out/summary.txt
 t0=$(date +%s)
 FP_WGRAD_WS=1 timeout 600 python -m pytest tests/test_gpu_hp.py tests/test_gpu_kernels.py -x -q -k "wgrad" > $out/pytest_ws.log 2>&1; echo "pytest ws rc=$? t=$(( $(date +%s)-t0 ))" >> $out/summary.txt

@@ -2,7 +2,7 @@
 # GPU box, round 4 session G: the whole GPU suite on the final build (default operand format), the full-size parity cases with exactly split
 # operands (FP_HP=0), the N = 2 bench line on the shared GPU (launch path + fields of the line, not a performance number)
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 out=gpurun_out/r4g; mkdir -p $out; : > $out/summary.txt
 t0=$(date +%s)
 timeout 1500 python -m pytest tests -m gpu -q > $out/pytest_all.log 2>&1; echo "pytest all rc=$? t=$(( $(date +%s)-t0 ))" >> $out/summary.txt

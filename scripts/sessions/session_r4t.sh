@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box, final build of round 4: the whole GPU suite, smoke, the N = 2 shared-GPU bench line, FP_HP=0 network tests
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 out=gpurun_out/r4t; mkdir -p $out; : > $out/summary.txt
 t0=$(date +%s)
 timeout 1500 python -m pytest tests -m gpu -q > $out/pytest_all.log 2>&1; echo "pytest all rc=$? t=$(( $(date +%s)-t0 ))" >> $out/summary.txt

@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box, final build of round 4: the whole GPU suite + smoke, then the round's profile set from the same build
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 out=gpurun_out/r4v; mkdir -p $out; : > $out/summary.txt
 t0=$(date +%s)
 timeout 1500 python -m pytest tests -m gpu -q > $out/pytest_all.log 2>&1; echo "pytest all rc=$? t=$(( $(date +%s)-t0 ))" >> $out/summary.txt

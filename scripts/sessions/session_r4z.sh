@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box, final tree of round 4: the whole GPU suite + smoke + one default bench line
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 out=gpurun_out/r4z; mkdir -p $out; : > $out/summary.txt
 t0=$(date +%s)
 timeout 1200 python -m pytest tests -m gpu -q > $out/pytest_all.log 2>&1; echo "pytest all rc=$? t=$(( $(date +%s)-t0 ))" >> $out/summary.txt
