@@ -56,6 +56,26 @@ class FusedAdam(torch.optim.Optimizer):
         eng.weights_dirty = True
         self._opt_called = True                      # what lr_scheduler's wrapper of step() records (no "scheduler before optimizer" warning)
 
+    # ---- the same update in pieces: a range of the flat buffer as soon as its gradients are complete (TrainStep, FP_ADAM_STAGED) ----
+    def begin_fused_step(self, eng):
+        """what fused_step does before its launch: moments allocated, step counter advanced once for all ranges of this step"""
+        self._buffers(eng)
+        self._step += 1
+        self._opt_called = True
+
+    def fused_range(self, eng, lo, hi, hyper_dev=None):
+        """Adam on elements [lo, hi) of the flat buffers (multiples of 4: parameter slots are 16-byte aligned) on the current launch
+        stream.  Element-wise, so any partition of [0, total) gives the bits of the one-launch form.  hyper_dev: the step's scalars in
+        device memory (recorded plans / graph replay); None: host scalars of the step begin_fused_step opened."""
+        m, v = self._buffers(eng)
+        if hyper_dev is not None:
+            ops.adam_step_dev(eng.flat_param[lo:hi], eng.flat_grad[lo:hi], m[lo:hi], v[lo:hi], hyper_dev)
+        else:
+            g = self.param_groups[0]
+            ops.adam_step(eng.flat_param[lo:hi], eng.flat_grad[lo:hi], m[lo:hi], v[lo:hi], g["lr"], g["betas"][0], g["betas"][1], g["eps"],
+                          self._step, self.grad_scale)
+        eng.weights_dirty = True
+
     # ---- graph replay: launch with device-resident scalars, refreshed by the host before each replay ----------
     def graph_step(self, eng, hyper_dev):
         """captured once by TrainStep: the update with its scalars read from `hyper_dev`"""

@@ -25,6 +25,13 @@ _GRAPH = bool(int(os.environ.get("FP_GRAPH", "0")))     # hipGraph replay of the
 # recorded launch plan (csrc/plan.cpp): after two eager steps the step's ~740 launches + ~150 stream-ordering edges are recorded once
 # per distinct set of input buffers and replayed from C with their original streams; FP_PLAN=0 keeps issuing every step from Python
 _PLAN = bool(int(os.environ.get("FP_PLAN", "1")))
+# Adam in pieces (FP_ADAM_STAGED=1, opt-in): a stage's slice of the flat buffers is updated on a side stream as soon as that stage's gradients
+# are complete, under the rest of the backward pass, instead of one launch alone on the GPU after it (element-wise: the same bits,
+# tests/test_gpu_switches.py).  Single-GPU steps with the concurrent schedule only -- in data-parallel steps the update has to follow the
+# buckets' all-reduces.  Measured -0.03 ms of 11.37 per step (profiles/round4_notes.md section 18): the 141 us launch leaves the end of the step,
+# but the kernels it now runs beside give most of that back; not the default until a timeline says where the rest went.
+_ADAM_STAGED = bool(int(os.environ.get("FP_ADAM_STAGED", "0")))
+_ADAM_STAGE_MIN = 1 << 20        # stages below this many elements stay in the closing launch
 
 
 class TrainStep:
@@ -53,6 +60,12 @@ class TrainStep:
         self.outputs = None
         self.dpreds = None
         self.reducer = None
+        self._adam_ranges = None    # stage -> (lo, hi) of the flat buffers, for the staged update
+        if _ADAM_STAGED and not distributed and not self.use_graph:
+            from ..parallel import bucket_ranges
+            eng = self.eng
+            self._adam_ranges = {s: (lo, hi) for s, lo, hi in bucket_ranges(eng.live_names, eng.offsets, eng.flat_grad.numel(),
+                                                                            max_elems=eng.flat_grad.numel())}
         if distributed:
             from ..parallel import _COMM_STREAM
             eng = self.eng
@@ -192,17 +205,44 @@ class TrainStep:
         ops.loss_fwd_bwd(self.outputs, batch, self.losses, self.dpreds, self.depth_range, self.prior)
         # zero_grad + backward: gradients are overwritten; buckets are all-reduced as soon as they are complete
         on_stage = None
+        staged, armed = [], False                         # stages whose slice of the parameters was updated under the backward pass
         if self.reducer is not None and self.reducer.overlap:
             def on_stage(stage):                          # recording: remember where the stage's gradients are complete
                 if on_mark is not None:
                     on_mark(stage)
                 self.reducer.stage_ready(stage, eng.stage_streams())
+        elif self.reducer is None and self._adam_ranges is not None and eng.stage_streams() is not None:
+            armed = True
+            opt, side = self.optimiser, eng.dwg[0]        # the mask decoder's weight-gradient stream: idle for most of the encoder's backward
+            if hyper_dev is None:
+                opt.begin_fused_step(eng)
+            else:
+                opt._buffers(eng)
+
+            def on_stage(stage):
+                lo, hi = self._adam_ranges.get(stage, (0, 0))
+                if hi - lo < _ADAM_STAGE_MIN or stage in staged:
+                    return
+                # nothing later in the step reads these parameters: the convolutions use the packed copies of the step's start, and a
+                # stage's BatchNorm backward (which reads gamma in place) has been launched on a stream waited for here
+                for st in eng.stage_streams():
+                    if st.cuda_stream != side.cuda_stream:
+                        ops.event_wait(side, ops.event_record(st))
+                with ops.on_stream(side):
+                    opt.fused_range(eng, lo, hi, hyper_dev)
+                staged.append(stage)
         eng.backward(self.dpreds, accumulate=False, on_stage=on_stage)
         if before_adam is not None:
             before_adam()
         if self.reducer is not None:
             self.reducer.finish()
-        if hyper_dev is None:
+        if armed:
+            # the rest in flat order (adjacent stages merge into one launch); the step ends when the side stream's pieces have, too
+            for lo, hi in _complement([self._adam_ranges[s] for s in staged], eng.flat_grad.numel()):
+                self.optimiser.fused_range(eng, lo, hi, hyper_dev)
+            if staged:
+                ops.stream_wait_stream(ops.current_stream(), eng.dwg[0])
+        elif hyper_dev is None:
             self.optimiser.fused_step(eng)
         else:
             self.optimiser.graph_step(eng, hyper_dev)
@@ -211,6 +251,18 @@ class TrainStep:
     def losses_dict(self):
         host = self.losses.cpu()
         return {k: float(host[i]) for i, k in enumerate(LOSS_KEYS)}
+
+
+def _complement(ranges, total):
+    """[lo, hi) pieces of [0, total) not covered by `ranges` (disjoint), in ascending order"""
+    out, p = [], 0
+    for lo, hi in sorted(ranges):
+        if lo > p:
+            out.append((p, lo))
+        p = max(p, hi)
+    if p < total:
+        out.append((p, total))
+    return out
 
 
 def synthetic_batch(B, H, W, device, seed=SEED):

@@ -29,7 +29,7 @@ print("LOSSES " + json.dumps(out))
 
 def run(env_extra):
     env = dict(os.environ)
-    for k in ("FP_HP", "FP_NO_BF3", "FP_SERIAL", "FP_NO_PHASE", "FP_DS_AUX", "FP_PLAN", "FP_NO_WBF3", "FP_WGRAD_PF", "FP_BN_EPI"):
+    for k in ("FP_HP", "FP_NO_BF3", "FP_SERIAL", "FP_NO_PHASE", "FP_DS_AUX", "FP_PLAN", "FP_NO_WBF3", "FP_WGRAD_PF", "FP_BN_EPI", "FP_ADAM_STAGED"):
         env.pop(k, None)
     env.update(env_extra)
     r = subprocess.run([sys.executable, "-c", PROG], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
@@ -55,6 +55,7 @@ def baseline():
     ({"FP_BN_EPI": "0"}, False),           # BatchNorm statistics by a pass over the activation instead of the conv epilogue's partials
     ({"FP_WGRAD_PF": "0"}, True),          # third-generation weight-gradient kernel: same products and summation order, other load schedule
     ({"FP_WGRAD_PF": "3"}, True),          # prefetch ring of depth three
+    ({"FP_ADAM_STAGED": "1"}, True),       # a piece of the Adam update per stage under the backward pass instead of one launch after it (element-wise)
 ])
 def test_switch_reproduces_the_default_losses(baseline, env, exact):
     got = run(env)

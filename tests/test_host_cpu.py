@@ -157,6 +157,30 @@ def test_bucket_ranges_cover_flat_buffer_in_backward_order():
     assert order.index("depth_decoder") < order.index("encoder.layer4") < order.index("encoder.layer1")
 
 
+def test_staged_adam_ranges_partition_the_flat_buffer():
+    """TrainStep's staged update: one range per stage (16-byte aligned), and whatever subset of stages reports, the closing launches cover
+    exactly the rest"""
+    from footprints_amd import FootprintNetwork
+    from footprints_amd.parallel import bucket_ranges
+    from footprints_amd.training.train import _ADAM_STAGE_MIN, _complement
+    m = FootprintNetwork(pretrained=False)
+    names, offs, total = [], [], 0
+    for n, p in m.live_named_parameters():
+        names.append(n)
+        offs.append(total)
+        total += (p.numel() + 3) // 4 * 4
+    ranges = {s: (lo, hi) for s, lo, hi in bucket_ranges(names, offs, total, max_elems=total)}
+    assert len(ranges) == 7 and all(lo % 4 == 0 and hi % 4 == 0 for lo, hi in ranges.values())
+    big = [s for s, (lo, hi) in ranges.items() if hi - lo >= _ADAM_STAGE_MIN]
+    assert {"mask_decoder", "depth_decoder", "encoder.layer4", "encoder.layer3"} <= set(big) and "encoder.layer0" not in big
+    for reported in ([], big[:1], big, list(ranges)):
+        done = [ranges[s] for s in reported]
+        rest = _complement(done, total)
+        cover = sorted(done + rest)
+        assert cover[0][0] == 0 and cover[-1][1] == total and all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
+        assert all(hi > lo for lo, hi in rest)
+
+
 def test_no_packed_fp32_valu_in_device_code(tmp_path):
     """Tripwire.  Round 1 saw head_wgrad_kernel, built with clang's SLP vectoriser, return different sums from run to run next to the
     bf16-MFMA convolution.  Round 4 narrowed it to ONE instruction form (profiles/round4_notes.md section 12): `v_pk_fma_f32 ... op_sel:[0,1,0]`
