@@ -1,6 +1,7 @@
 """Timeline analysis of a rocprofv3 --kernel-trace rocpd database: one steady-state training step (adam to adam).
 
-    python scripts/timeline.py gpurun_out/prof/x_results.db [step_index]
+    python scripts/timeline.py gpurun_out/prof/x_results.db [step_index] [trace] [delim=<kernel name fragment>]
+delim: the once-per-step kernel that bounds a step (default: the Adam launch; `delim=loss_kernel` for FP_ADAM_STAGED=1, whose update is six launches).
 Prints wall time of the step, GPU-busy union, time at concurrency 0/1/2/3+, the largest idle gaps and per-kernel sums.
 """
 import sqlite3
@@ -11,14 +12,15 @@ db = sys.argv[1]
 which = int(sys.argv[2]) if len(sys.argv) > 2 else -2
 cur = sqlite3.connect(db).cursor()
 rows = list(cur.execute("select name, start, end, stream_id from kernels order by start"))
-adam = [i for i, r in enumerate(rows) if "adam_kernel" in r[0] or "adam_dev_kernel" in r[0]]
+delim = next((a.split("=", 1)[1] for a in sys.argv[2:] if a.startswith("delim=")), None)
+adam = [i for i, r in enumerate(rows) if ((delim in r[0]) if delim else ("adam_kernel" in r[0] or "adam_dev_kernel" in r[0]))]
 if len(adam) < 3:
-    sys.exit("need >= 3 adam_kernel launches")
+    sys.exit("need >= 3 launches of the step delimiter")
 a0, a1 = adam[which - 1], adam[which]
 step = rows[a0 + 1:a1 + 1]
 t0, t1 = rows[a0][2], rows[a1][2]
 wall = (t1 - t0) / 1e3
-print("step: %d kernels, wall %.1f us (adam end -> adam end)" % (len(step), wall))
+print("step: %d kernels, wall %.1f us (%s end -> %s end)" % (len(step), wall, delim or "adam", delim or "adam"))
 ev = []
 for n, s, e, st in step:
     ev.append((max(s, t0), 1))
