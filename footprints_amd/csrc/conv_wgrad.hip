@@ -356,7 +356,7 @@ extern "C" int fp_conv_stem_wgrad_hp(const fp_conv_desc* d, const float* img_nch
   const Plan p = make_plan(d);
   FP_REQUIRE(workspace_bytes >= fp_conv_wgrad_workspace(d), "fp_conv_stem_wgrad_hp: workspace too small");
   static const int hp_wgs = getenv("FP_STEM_WGRAD_HP_WGS") ? atoi(getenv("FP_STEM_WGRAD_HP_WGS")) : 512;      // two resident workgroups per CU (184 registers)
-  const int S = p.S < hp_wgs ? p.S : hp_wgs;         // persistent workgroups = partial tensors (the workspace holds p.S of them)
+  const int S = (hp_wgs < 1 || p.S < hp_wgs) ? p.S : hp_wgs;   // persistent workgroups = partial tensors (the workspace holds p.S of them)
   const int rc = fp_stem_wgrad_hp_dispatch(d, img_nchw, dz, (float*)workspace, S, amax_dz, stream);
   FP_REQUIRE(rc != -1000, "fp_conv_stem_wgrad_hp: shape not handled");
   if (rc) return rc;

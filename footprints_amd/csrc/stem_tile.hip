@@ -609,7 +609,8 @@ extern "C" int fp_conv_stem_hp(const fp_conv_desc* d, const float* img, const vo
     if (sink.nblk_out) *sink.nblk_out = (int32_t)ntiles;
   }
   static const int wgs = getenv("FP_STEM_HP_WGS") ? atoi(getenv("FP_STEM_HP_WGS")) : 512;          // persistent: two workgroups per CU (194 VGPRs)
-  fp_launch(stem_tile_hp_kernel, dim3((unsigned)(ntiles < wgs ? ntiles : wgs)), dim3(256), 0, (hipStream_t)stream, a);
+  const int64_t budget = wgs > 0 ? wgs : 512;        // (an unusable value of the experiment knob falls back to the default)
+  fp_launch(stem_tile_hp_kernel, dim3((unsigned)(ntiles < budget ? ntiles : budget)), dim3(256), 0, (hipStream_t)stream, a);
   return fp_check_launch("fp_conv_stem_hp");
 }
 
