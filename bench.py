@@ -36,8 +36,16 @@ Extra objects in the line:
   cpu_baseline  the CPU oracle (a restatement of the reference's PyTorch CPU path, kind "port") timed on this box's host cores:
                 1 warm-up + 3 timed full train steps of the same workload at the same batch size, plus the eval-mode forward in
                 ms per image (rank 0, N = 1 only).
-  exact_split   the same training step with FP_HP=0 (exactly split bf16x3 operands: >= 24 significant bits in every product
-                sum), timed in a child process outside the timed region: the strictly-fp32-or-better number beside `value`.
+  dtype / operand formats (round 5)   `value`, `roofline` and every other top-level figure are measured in the DEFAULT operand format, the
+                exact bf16x3 split (footprints_amd/_format.py: every fp32 operand bit is kept, six MFMA products; the arithmetic the
+                reference's fp32 step is compared with).  `fp16_pair` is the same command re-run in a child process in the OPT-IN format
+                (FP_OPERANDS=fp16_pair: 22 significant bits, three products) with the caller's --steps / --warmup / --sustain and the same
+                instrumentation (value, ms_per_step, step_ms, roofline with its own kernel events and counter file, kernels, decoder_backward,
+                sustained) -- a faster mode below fp32 that has to be asked for, never the headline.  Started with FP_OPERANDS=fp16_pair the
+                roles swap and `dtype` says so.
+  sustained     --sustain S (default 10 s): the step looped for S seconds of wall clock after the timed region: img/s over the whole span,
+                per-second img/s, step_ms percentiles, and the GPU's sclk / power / busy % sampled from sysfs every 100 ms (what a trainer
+                that runs for hours sees; the timed region above is 0.2-0.6 s).
 """
 import argparse
 import json
@@ -52,6 +60,7 @@ import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+from footprints_amd._format import DTYPE_LABEL, FORMATS, format_env, operand_format      # noqa: E402  (no torch / HIP import)
 
 MFMA_F32_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
 BF16X6_PEAK_TFLOPS = 2500.0 / 6   # dense bf16 MFMA peak / 6 products per fp32-equivalent multiply-add (the split kernels' own roof)
@@ -222,7 +231,9 @@ def phase_key(tag):
 # entry point (footprints_amd.ops name) -> how its launches are counted.  `exec` = multiply-adds x2 the kernel really executes
 # (the phase kernels run 4/9 of the dense conv), `dense` = the reference graph's conv, `bytes` = fused-minimum HBM bytes.
 HP_PRODUCTS = 3      # csrc/fp_common.h: FP_HP_PRODUCTS of the default build
-HP_ON = os.environ.get("FP_HP", "1") != "0" and os.environ.get("FP_NO_BF3", "0") == "0"      # mirrors footprints_amd.engine._HP
+FMT = operand_format()              # "exact" (default) | "fp16_pair" (opt-in): footprints_amd/_format.py
+HP_ON = FMT == "fp16_pair" and os.environ.get("FP_NO_BF3", "0") == "0"      # mirrors footprints_amd.engine._HP
+PROFILE_ROUND = 5                   # profiles/round<N>_*: the counter files bench.py may attach
 GROUPS = {
     "conv3x3_bf3": dict(kernel="conv3x3_tile_bf3_kernel (+ splitk_reduce_kernel on small grids)", bf16x3=True),
     "conv3x3_hp": dict(kernel="conv3x3_tile_bf3_kernel<..., HP> (fp16-pair operands; + splitk_reduce_kernel / amax_kernel on small grids)", bf16x3=False,
@@ -313,15 +324,15 @@ def kernel_source_digest():
 
 
 def load_traffic(workload, entry_point):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (scripts/pmc_hbm_session.sh -> profiles/round4_pmc_hbm_*.json;
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (scripts/profile_session_r5.sh -> profiles/round5_pmc_hbm_*.json;
     the counters need rocprofv3 around the process, so they cannot be collected inside this one), or None.  The file records the digest of
     the kernel source it was measured on: a file from another build is NOT attached (its figure would describe a different kernel)."""
-    path = os.path.join(ROOT, "profiles", "round4_pmc_hbm_%s.json" % workload)
+    name = "round%d_pmc_hbm_%s_%s.json" % (PROFILE_ROUND, workload, FMT)
     try:
-        with open(path) as fh:
+        with open(os.path.join(ROOT, "profiles", name)) as fh:
             doc = json.load(fh)
     except (OSError, ValueError):
-        return None, "no counter file for this round (profiles/round4_pmc_hbm_%s.json)" % workload
+        return None, "no counter file for this round and operand format (profiles/%s)" % name
     t = doc.get(entry_point)
     if not t:
         return None, "counter file has no entry for " + entry_point
@@ -410,18 +421,135 @@ def spawn_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
-def exact_split_leg(workload, steps=10, warmup=4):
-    """child process with FP_HP=0 (the operand format is fixed when footprints_amd.engine is imported): `steps` training steps of
-    the same workload with exactly split bf16x3 operands -> img/s, or None"""
+def other_format_leg(fmt, args):
+    """the same command in a child process in the OTHER operand format (fixed when footprints_amd.engine is imported): caller's workload,
+    --steps, --warmup and --sustain, same instrumentation (kernel events, roofline, decoder backward, sustained) -> its JSON line, trimmed"""
     env = dict(os.environ)
-    env["FP_HP"] = "0"
+    env.update(format_env(fmt))
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", args.workload, "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--sustain", str(args.sustain), "--no-cpu-baseline", "--no-loader", "--no-other-format"]
     try:
-        p = subprocess.run([sys.executable, os.path.abspath(__file__), "--leg", "train-only", "--workload", workload, "--steps", str(steps),
-                            "--warmup", str(warmup)], env=env, capture_output=True, text=True, timeout=600)
+        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
         line = [l for l in p.stdout.splitlines() if l.startswith("{")]
-        return json.loads(line[-1]) if line else {"error": (p.stderr or "")[-300:]}
+        if not line:
+            return {"error": (p.stderr or "")[-400:]}
+        doc = json.loads(line[-1])
     except Exception as e:      # the headline must not die with a side leg
         return {"error": repr(e)}
+    keep = ("value", "unit", "steps", "warmup", "ms_per_step", "dtype", "operand_format", "arithmetic", "fwd_ms_per_img", "final_loss", "step_ms",
+            "sustained", "decoder_backward", "step_conv_tflops", "roofline")
+    leg = {k: doc[k] for k in keep if k in doc}
+    if "kernels" in doc:
+        leg["kernels"] = {"serial": doc["kernels"]["serial"][:12], "concurrent": doc["kernels"]["concurrent"][:12]}
+    return leg
+
+
+class GpuSampler:
+    """sclk (MHz), socket power (W) and busy % of one GPU from sysfs every `period` seconds on a host thread (no subprocess per sample:
+    rocm-smi takes ~0.3 s a call).  Files that do not exist on a box are skipped; `summary()` says which were read."""
+
+    def __init__(self, index=0, period=0.1):
+        import glob
+        import threading
+        self.period, self.rows, self._stop = period, [], threading.Event()
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/gpu_busy_percent"))
+        self.dev = os.path.dirname(cards[index]) if index < len(cards) else None
+        hw = sorted(glob.glob(os.path.join(self.dev, "hwmon", "hwmon*"))) if self.dev else []
+        self.hw = hw[0] if hw else None
+        self._thr = threading.Thread(target=self._run, daemon=True)
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as fh:
+                return fh.read()
+        except OSError:
+            return None
+
+    def _sample(self):
+        sclk = power = busy = None
+        if self.hw:
+            v = self._read(os.path.join(self.hw, "freq1_input"))
+            sclk = float(v) / 1e6 if v and v.strip().isdigit() else None
+            for f in ("power1_average", "power1_input"):
+                v = self._read(os.path.join(self.hw, f))
+                if v and v.strip().isdigit():
+                    power = float(v) / 1e6
+                    break
+        if self.dev:
+            if sclk is None:
+                v = self._read(os.path.join(self.dev, "pp_dpm_sclk")) or ""
+                for ln in v.splitlines():
+                    if ln.strip().endswith("*"):
+                        try:
+                            sclk = float(ln.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
+                        except (IndexError, ValueError):
+                            pass
+            v = self._read(os.path.join(self.dev, "gpu_busy_percent"))
+            busy = float(v) if v and v.strip().isdigit() else None
+        return (time.perf_counter(), sclk, power, busy)
+
+    def _run(self):
+        while not self._stop.is_set():
+            self.rows.append(self._sample())
+            self._stop.wait(self.period)
+
+    def start(self):
+        self._thr.start()
+        return self
+
+    def stop(self):
+        self._stop.set()
+        self._thr.join(timeout=2.0)
+
+    def summary(self):
+        def stat(i, nd=1):
+            v = sorted(r[i] for r in self.rows if r[i] is not None)
+            if not v:
+                return None
+            return {"mean": round(sum(v) / len(v), nd), "p10": round(v[len(v) // 10], nd), "median": round(v[len(v) // 2], nd),
+                    "p90": round(v[min(len(v) - 1, len(v) * 9 // 10)], nd), "samples": len(v)}
+        return {"sclk_mhz": stat(1), "power_w": stat(2), "busy_percent": stat(3), "period_s": self.period,
+                "source": "sysfs: %s (hwmon freq1_input / power1_average, gpu_busy_percent)" % (self.dev or "no amdgpu device node found")}
+
+
+def sustained_leg(step, batch, seconds, world, local_rank):
+    """loop the training step for `seconds` of wall clock (what a trainer sees: clocks and power settle over seconds, the timed region lasts
+    a fraction of one); per-step HIP events, per-second img/s, sysfs samples of the GPU this rank runs on"""
+    sampler = GpuSampler(index=local_rank).start()
+    marks = [torch.cuda.Event(enable_timing=True)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    marks[0].record()
+    host_t = []
+    while True:
+        step(batch)
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        marks.append(e)
+        host_t.append(time.perf_counter() - t0)
+        if host_t[-1] >= seconds or len(marks) > 200000:
+            break
+        if len(marks) % 64 == 0:
+            marks[-32].synchronize()          # keep the host at most ~32 steps ahead: the loop ends on GPU time, not on queue depth
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    sampler.stop()
+    n = len(marks) - 1
+    ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(n)]
+    ends, acc = [], 0.0
+    for v in ms:
+        acc += v
+        ends.append(acc / 1e3)
+    per_sec = []
+    for sec in range(int(ends[-1])):
+        k = sum(1 for e in ends if sec <= e < sec + 1)
+        per_sec.append(round(k * B * world, 1))
+    srt = sorted(ms)
+    return {"seconds": round(dt, 2), "steps": n, "img_per_s": round(world * B * n / dt, 2), "ms_per_step": round(dt / n * 1e3, 3),
+            "step_ms": {"p10": round(srt[n // 10], 3), "median": round(srt[n // 2], 3), "p90": round(srt[min(n - 1, n * 9 // 10)], 3), "max": round(srt[-1], 3)},
+            "img_per_s_each_second": per_sec, "gpu": sampler.summary(),
+            "note": "the same step looped for --sustain seconds right after the timed region (rank 0's GPU sampled every 100 ms)"}
 
 
 def kernel_table(lib, steps):
@@ -454,9 +582,10 @@ def main():
                     "bucketed all-reduces in a world of one rank) -- a dry run of the code path the N > 1 launches take")
     ap.add_argument("--dump-kernels", type=str, default=None, help="write the per-launch-shape timing tables (JSON) here")
     ap.add_argument("--no-loader", action="store_true", help="skip the extra leg that feeds the step from the device-side data path")
-    ap.add_argument("--no-exact-split", action="store_true", help="skip the FP_HP=0 (exactly split bf16x3 operands) leg")
-    ap.add_argument("--leg", choices=["train-only"], default=None, help="internal: time the training step only and print a small "
-                    "JSON object (what the exact-split leg runs in its child process)")
+    ap.add_argument("--no-other-format", "--no-exact-split", dest="no_other_format", action="store_true",
+                    help="skip the child-process leg in the other operand format (default run: the opt-in fp16 pairs)")
+    ap.add_argument("--sustain", type=float, default=10.0, help="seconds of the sustained-throughput leg after the timed region (0: skip)")
+    ap.add_argument("--leg", choices=["train-only"], default=None, help="internal: time the training step only and print a small JSON object")
     ap.add_argument("--dry-run-dist", action="store_true", help="N > 1: spawn / rendezvous / one collective / ONE JSON line, no GPU "
                     "work (what the CPU test of the launch path runs)")
     args = ap.parse_args()
@@ -540,8 +669,14 @@ def main():
         if rank == 0:
             print(json.dumps({"img_per_s": round(world * B * args.steps / dt, 2), "ms_per_step": round(dt / args.steps * 1e3, 3),
                               "steps": args.steps, "warmup": args.warmup, "final_loss": round(final_loss, 5),
-                              "FP_HP": os.environ.get("FP_HP", "1")}), flush=True)
+                              "operand_format": FMT}), flush=True)
         return
+
+    sustained = None
+    if args.sustain > 0:
+        sustained = sustained_leg(step, batch, args.sustain, world, local_rank % have)          # every rank loops (the steps contain the all-reduces)
+        if world > 1:
+            dist.barrier()
 
     # kernel-exclusive pass (outside the timed region): same steps on ONE stream, HIP events around every convolution launch
     # (every rank runs it when data-parallel: the steps contain the bucket all-reduces; rank 0 reports)
@@ -669,13 +804,12 @@ def main():
         out = {"metric": "training images/sec at %dx%d bs=%d" % (H, W, B), "value": round(world * B * args.steps / dt, 2), "unit": "img/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": ("f32 tensors; fp16x2-split operands (22-bit), fp32 accumulate" if HP_ON else
-                         "f32 tensors; bf16x3-split operands (exact 24-bit), fp32 accumulate"), "data": "synthetic",
+               "dtype": DTYPE_LABEL[FMT], "operand_format": FMT, "data": "synthetic",
                "arithmetic": ("fp32 tensors and accumulation; 3x3 stride-1 convs (fwd, dgrad, wgrad) multiply operands split into scaled fp16 "
                               "pairs (x * 2^k = h + m, per-tensor k from the tensor's largest magnitude, 22 significant bits, three fp16 MFMA "
                               "products hh + hm + mh, fp32 accumulate: measured error vs float64 equal to the exact bf16x3 split's and to fp32 "
-                              "MIOpen's); "
-                              "remaining convs native fp32 MFMA" if HP_ON else
+                              "MIOpen's), the 7x7 stem, the stride-2 3x3 and the 1x1 convs likewise; the few remaining shapes native fp32 MFMA -- "
+                              "OPT-IN format, below fp32" if HP_ON else
                               "fp32 tensors and accumulation; 3x3 stride-1 convs (fwd, dgrad, wgrad) multiply exactly split operands "
                               "(x = h + m + l in bf16, 6 of 9 bf16 MFMA products: error <= fp32 MFMA); remaining convs native fp32 MFMA"),
                "config": {"workload": wl["name"], "per_gpu_batch": B, "global_batch": B * world, "height": H, "width": W,
@@ -687,7 +821,7 @@ def main():
                "step_ms": {"median": round(step_ms[len(step_ms) // 2], 3), "p10": round(step_ms[len(step_ms) // 10], 3),
                            "p90": round(step_ms[min(len(step_ms) - 1, (len(step_ms) * 9) // 10)], 3),
                            "note": "GPU-side durations between per-step HIP events inside the timed region (rank 0)"},
-               "decoder_backward": dec_bwd, "device_data_path": loader_leg}
+               "sustained": sustained, "decoder_backward": dec_bwd, "device_data_path": loader_leg}
         gf_fwd, gf_step = network_conv_gflop(B, H, W)
         # whole-step figure: the reference graph's conv FLOPs (fwd + dgrad + wgrad) over the measured step time, i.e. including
         # every non-conv kernel, launch gap and the FLOPs the nearest-x2 phase decomposition does not execute
@@ -763,12 +897,12 @@ def main():
                                                   "allreduce_us": [{"bucket": r["kernel"], "per_step": r["launches_per_step"], "avg_us": r["avg_us"]}
                                                                    for r in ar_rows]}
             out["rccl_ranks"] = out["config"]["gradient_exchange"]["rccl_ranks"]
-        if world == 1 and not args.force_dist and not args.no_exact_split:
+        if world == 1 and not args.force_dist and not args.no_other_format:
             del step, mm                                               # free this process's arena before the child builds its own
             torch.cuda.empty_cache()
-            out["exact_split"] = {"what": "the same training step with FP_HP=0: 3x3 stride-1 convs multiply EXACTLY split operands (x = h + m + l in "
-                                          "bf16, six MFMA products: every operand keeps its 24 significant bits), timed in a child process",
-                                  "result": exact_split_leg(args.workload)}
+            other = [f for f in FORMATS if f != FMT][0]
+            out[other] = {"what": "the same command re-run in a child process with FP_OPERANDS=%s (%s): same steps / warm-up / sustain, same "
+                                  "instrumentation; `value` above is NOT this leg" % (other, DTYPE_LABEL[other]), **other_format_leg(other, args)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
     destroy_communicators()

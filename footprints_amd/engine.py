@@ -3,10 +3,11 @@
 Design (MI355X-first, not an autograd graph):
   * activations NHWC fp32, resident in a named arena that is allocated once and reused every step (static
     addresses => the whole step is capturable in a hipGraph: TrainStep(graph=True));
-  * 3x3 stride-1 convolutions (forward, data- and weight-gradient) multiply split operands: scaled fp16 pairs (22 significant bits
-    after a per-tensor power-of-two scaling, three fp16 MFMA products, fp32 accumulation; the scale comes from amax slots that the
-    producing kernels publish, AmaxBook below) or, with FP_HP=0, the exact three-term bf16 split (six products) -- one kernel
-    template for both (conv3x3_tile_bf3.hip); the rest uses the fp32 MFMA kernels;
+  * 3x3 stride-1 convolutions (forward, data- and weight-gradient) multiply split operands: by default the exact three-term bf16 split
+    (x = h + m + l, six MFMA products, fp32 accumulation: every operand bit of fp32 is kept) with the rest on the fp32 MFMA kernels; with
+    FP_OPERANDS=fp16_pair (opt-in, _format.py) scaled fp16 pairs (22 significant bits after a per-tensor power-of-two scaling, three fp16
+    MFMA products; the scale comes from amax slots that the producing kernels publish, AmaxBook below) -- one kernel template for both
+    (conv3x3_tile_bf3.hip);
   * nearest-x2 upsample, skip concat, reflection / zero padding, ELU / ReLU, residual adds and their
     gradients never exist as tensors -- they are loader / epilogue modes of the implicit-GEMM kernels;
   * all live parameters are views of ONE flat fp32 buffer (same for gradients) in forward order, so Adam is
@@ -24,6 +25,7 @@ import torch
 
 from . import _lib as L
 from . import ops
+from ._format import operand_format
 
 # Concurrency: the two decoders are independent, and every weight gradient is off the critical dgrad chain.
 # Running them on side streams lets workgroups of 2-3 kernels share the CUs, which fills the occupancy ramp /
@@ -36,8 +38,9 @@ _BF3 = not bool(int(os.environ.get("FP_NO_BF3", "0")))
 _WBF3 = _BF3 and not bool(int(os.environ.get("FP_NO_WBF3", "0")))      # ... and for the weight-gradient kernel
 _PWBF3 = not bool(int(os.environ.get("FP_NO_PHASE_WBF3", "0")))           # ... and for the phase weight-gradient kernel (A/B switch)
 # fp16-pair operands (two fp16 terms after a per-tensor power-of-two scaling, three MFMA products, 22 significant bits) for the same
-# kernels, with the scaling taken from amax slots that producers publish / a reduction fills (csrc/fp_common.h); FP_HP=0 keeps bf16x3
-_HP = _BF3 and bool(int(os.environ.get("FP_HP", "1")))
+# kernels, with the scaling taken from amax slots that producers publish / a reduction fills (csrc/fp_common.h).  OPT-IN since round 5
+# (FP_OPERANDS=fp16_pair; footprints_amd/_format.py): the default is the exact bf16x3 split, which keeps every operand bit of fp32
+_HP = _BF3 and operand_format() == "fp16_pair"
 # per kernel family (A/B and precision studies, profiles/round3_notes.md): FP_HP_WGRAD=0 keeps the weight-gradient kernels on the exact
 # bf16 split while forward / data-gradient use fp16 pairs; FP_HP_TILE=0 the other way round
 _HP_WGRAD = _HP and bool(int(os.environ.get("FP_HP_WGRAD", "1")))

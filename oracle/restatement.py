@@ -140,9 +140,32 @@ def _bn(x, P, B, prefix, training, momentum=0.1, eps=1e-5):
     return y
 
 
-def _basic_block(x, P, B, prefix, stride, has_ds, training):
+class ReluDecisions:
+    """impose: list of boolean masks consumed in call order (None: the network decides itself); taken: the masks actually used"""
+
+    def __init__(self, impose=None):
+        self.impose = None if impose is None else iter(impose)
+        self.taken = []
+
+
+def _relu(x, decisions):
+    """F.relu, or -- decisions.impose given -- x * mask with the NEXT imposed mask: the piecewise-linear network evaluated with somebody
+    else's ReLU decisions (tests/parity.py: the float64 truth under the decisions a float32 implementation took; where the mask equals
+    x > 0 this IS relu, forward and backward).  A ReluDecisions without `impose` only records what F.relu decided."""
+    if decisions is None:
+        return F.relu(x)
+    if decisions.impose is None:
+        decisions.taken.append((x > 0).detach())
+        return F.relu(x)
+    m = next(decisions.impose)
+    assert m.shape == x.shape, (tuple(m.shape), tuple(x.shape))
+    decisions.taken.append(m)
+    return x * m.to(x.dtype)
+
+
+def _basic_block(x, P, B, prefix, stride, has_ds, training, decisions=None):
     out = F.conv2d(x, P[prefix + ".conv1.weight"], None, stride, 1)
-    out = F.relu(_bn(out, P, B, prefix + ".bn1", training))
+    out = _relu(_bn(out, P, B, prefix + ".bn1", training), decisions)
     out = F.conv2d(out, P[prefix + ".conv2.weight"], None, 1, 1)
     out = _bn(out, P, B, prefix + ".bn2", training)
     if has_ds:
@@ -150,15 +173,18 @@ def _basic_block(x, P, B, prefix, stride, has_ds, training):
         idt = _bn(idt, P, B, prefix + ".downsample.1", training)
     else:
         idt = x
-    return F.relu(out + idt)
+    return _relu(out + idt, decisions)
 
 
-def resnet_encoder(image, P, B, training, record=None):
+def resnet_encoder(image, P, B, training, record=None, relu_decisions=None):
     """network.py:48-59 -- normalise, layer0 (conv7x7/2+BN+ReLU), layer1 (maxpool + 3 blocks), layer2..4.
-    record (optional list): receives every BasicBlock output (grad retained) for block-level debugging."""
+    record (optional list): receives every BasicBlock output (grad retained) for block-level debugging.
+    relu_decisions (optional ReluDecisions; 33 boolean NCHW masks: stem, then (bn1's ReLU, block output ReLU) per BasicBlock): evaluate
+    the encoder with imposed ReLU decisions instead of its own and / or record the decisions taken (see _relu)."""
+    decisions = relu_decisions
     x = (image - 0.45) / 0.225                                            # network.py:50
     x = F.conv2d(x, P["encoder.layer0.0.weight"], None, 2, 3)
-    x = F.relu(_bn(x, P, B, "encoder.layer0.1", training))
+    x = _relu(_bn(x, P, B, "encoder.layer0.1", training), decisions)
     feats = [x]
     blocks = encoder_block_prefixes()
     bi = 0
@@ -167,7 +193,7 @@ def resnet_encoder(image, P, B, training, record=None):
             x = F.max_pool2d(x, 3, 2, 1)                                  # encoder.maxpool (network.py:41)
         for _ in range(nblk):
             prefix, cin, cout, stride, ds = blocks[bi]
-            x = _basic_block(x, P, B, prefix, stride, ds, training)
+            x = _basic_block(x, P, B, prefix, stride, ds, training, decisions)
             if record is not None:
                 if x.requires_grad:
                     x.retain_grad()
@@ -222,9 +248,9 @@ def skip_decoder(feats, P, prefix, apply_sigmoid):
     return out
 
 
-def footprint_network(image, P, B, training=True, return_features=False, record=None):
+def footprint_network(image, P, B, training=True, return_features=False, record=None, relu_decisions=None):
     """FootprintNetwork.forward network.py:21-30."""
-    feats = resnet_encoder(image, P, B, training, record)
+    feats = resnet_encoder(image, P, B, training, record, relu_decisions)
     m = skip_decoder(feats, P, "mask_decoder", False)       # network.py:18
     d = skip_decoder(feats, P, "depth_decoder", True)       # network.py:19
     out = OrderedDict((k, torch.cat([m[k], d[k]], 1)) for k in m)

@@ -34,7 +34,7 @@ def pytest_sessionstart(session):
 def pytest_sessionfinish(session, exitstatus):
     """tests/test_gpu_parity_fullsize.py leaves one JSON per case under gpurun_out/parity/ (err(GPU) / err(CPU fp32) per parameter tensor,
     both against the float64 oracle); this writes the markdown table of the cases THIS session produced next to them --
-    `parity_ratios_<operand format>.md`, copied into profiles/round<N>_parity_ratios.md by hand, never assembled by hand."""
+    `parity_ratios.md` (both operand formats since round 5), copied into profiles/round<N>_parity_ratios.md by hand, never assembled by hand."""
     import glob
     import json
     out_dir = os.environ.get("FP_PARITY_DUMP", os.path.join(ROOT, "gpurun_out", "parity"))
@@ -49,18 +49,26 @@ def pytest_sessionfinish(session, exitstatus):
             pass
     if not docs:
         return
-    fmt = "exact bf16x3 split (FP_HP=0)" if os.environ.get("FP_HP", "1") == "0" else "scaled fp16 pairs (default)"
     lines = ["# err(GPU) / err(CPU fp32) per parameter tensor, both against the float64 oracle -- written by the test session itself",
-             "", "operand format: %s; gates: tests/parity.py (median inside [0.4, 1.5]; natural-statistics case [0.2, 1.5])" % fmt, "",
-             "| case | tensors | median | p90 | tensors > 2 | kink pixels removed | worst tensors (ratio; err GPU / err CPU fp32) |", "|---|---|---|---|---|---|---|"]
+             "", "operand formats: exact = bf16x3 split, the default (footprints_amd/_format.py); fp16_pair = scaled fp16 pairs, opt-in.  Gates: tests/parity.py "
+             "(median inside [0.4, 1.5]; natural-statistics case [0.2, 1.5]).  `forced` = the same tensors against the float64 oracle evaluated under the "
+             "ENGINE's own ReLU decisions (tests/parity.py decision_forced_report): failures / max err / median err; evaluated for the headline case and "
+             "wherever the single-run rule failed.", "",
+             "| case | format | tensors | median | p90 | tensors > 2 | kink pixels removed | single-run failures | forced: failures / max / median | ReLU decisions != float64 | worst tensors (ratio; err GPU / err CPU fp32) |",
+             "|---|---|---|---|---|---|---|---|---|---|---|"]
     for d in docs:
         worst = ", ".join("%s %.1f (%.1e / %.1e)" % (t["tensor"].replace("encoder.", "enc.").replace("_decoder", "_dec"), t["ratio"], t["err_gpu"],
                                                      t["err_cpu32"]) for t in d.get("top6", [])[:3])
-        lines.append("| %s | %s | %.2f | %.2f | %s | %s | %s |" % (d.get("case"), d.get("tensors"), d.get("median_ratio", float("nan")),
-                                                                 d.get("p90_ratio", float("nan")), d.get("count_ratio_gt_2"),
-                                                                 d.get("kink_pixels_removed", d.get("failures_under_single_run_rule", "")), worst))
+        f = d.get("decision_forced")
+        forced = "%d / %.1e / %.1e" % (len(f["failures"]), f["max_err"], f["median_err"]) if f else ""
+        fl = d.get("relu_decisions_differing_from_float64")
+        lines.append("| %s | %s | %s | %.2f | %.2f | %s | %s | %s | %s | %s | %s |" % (
+            d.get("case"), d.get("operand_format", ""), d.get("tensors"), d.get("median_ratio", float("nan")), d.get("p90_ratio", float("nan")),
+            d.get("count_ratio_gt_2"), d.get("kink_pixels_removed", ""),
+            len(d["single_run_rule_failures"]) if "single_run_rule_failures" in d else d.get("failures_under_single_run_rule", 0),
+            forced, ("%d of %d" % (fl["engine"], fl["of"])) if fl else "", worst))
     try:
-        with open(os.path.join(out_dir, "parity_ratios_%s.md" % ("exact" if "exact" in fmt else "hp")), "w") as fh:
+        with open(os.path.join(out_dir, "parity_ratios.md"), "w") as fh:
             fh.write("\n".join(lines) + "\n")
     except OSError:
         pass

@@ -62,12 +62,14 @@ def chan_relerr(got, ref):
     return (d / s).tolist()
 
 
-def oracle_grads(P, B, cpu_batch, dtype, fix_batch=None, perturb=0.0, seed=0, record=None):
+def oracle_grads(P, B, cpu_batch, dtype, fix_batch=None, perturb=0.0, seed=0, record=None, relu_decisions=None):
     """one train-mode fwd + loss + bwd of the CPU oracle in `dtype` -> (outputs, losses, {name: grad}, trainer, batch used).
     fix_batch(batch, outputs) -> batch: applied between the forward and the loss (the outputs do not depend on the targets).
     perturb > 0: the image is multiplied by (1 + perturb * u), u uniform in [-1, 1) (seeded) -- "another conforming fp32
     implementation": a perturbation at round-off level draws a different set of ReLU-kink decisions (see fp32_spread).
-    record (optional list): receives every encoder BasicBlock output with its gradient retained (oracle/restatement.py resnet_encoder)"""
+    record (optional list): receives every encoder BasicBlock output with its gradient retained (oracle/restatement.py resnet_encoder)
+    relu_decisions (optional oracle.restatement.ReluDecisions): the encoder is evaluated with imposed ReLU decisions instead of its own
+    and / or its decisions are recorded (round 5, see `decision_forced_report`)"""
     from oracle import restatement as R
     Pd = OrderedDict((k, v.to(dtype)) for k, v in P.items())
     Bd = OrderedDict((k, v.to(dtype) if v.is_floating_point() else v.clone()) for k, v in B.items())
@@ -76,7 +78,7 @@ def oracle_grads(P, B, cpu_batch, dtype, fix_batch=None, perturb=0.0, seed=0, re
         g = torch.Generator().manual_seed(1234 + seed)
         cpu_batch = OrderedDict(cpu_batch)
         cpu_batch["image"] = cpu_batch["image"] * (1.0 + perturb * (torch.rand(cpu_batch["image"].shape, generator=g) * 2 - 1))
-    out = R.footprint_network(cpu_batch["image"].to(dtype), tr.P, tr.B, True, record=record)
+    out = R.footprint_network(cpu_batch["image"].to(dtype), tr.P, tr.B, True, record=record, relu_decisions=relu_decisions)
     used = cpu_batch if fix_batch is None else fix_batch(cpu_batch, out)
     losses, _ = R.loss_manager(out, OrderedDict((k, v.to(dtype)) for k, v in used.items()))
     for p in tr.P.values():
@@ -92,8 +94,10 @@ def stage_of(name):
     return ".".join(p[:2])
 
 
-def anchored_report(gpu, cpu32, ref64, factor=FACTOR, floor=FLOOR, spread=()):
+def anchored_report(gpu, cpu32, ref64, factor=FACTOR, floor=FLOOR, spread=(), cpu_ref64=None):
     """gpu / cpu32 / ref64: {name: tensor or None}.  Returns (failures, rows) with rows = (ratio, name, err_gpu, err_cpu).
+    cpu_ref64 (optional): the truth the fp32 CPU runs are measured against when it differs from the engine's (decision_forced_report:
+    the engine against the float64 oracle under the ENGINE's ReLU decisions, the CPU runs against the float64 oracle's own).
     spread: further fp32 CPU runs on inputs perturbed at round-off level (oracle_grads(perturb=...)): a tensor's fp32 error is then
     the LARGEST over all fp32 runs -- where the network is chaotic (extreme BatchNorm scales over a few hundred samples: one ReLU
     decision within round-off of zero moves a whole channel's statistics) one fp32 run is a single draw of a heavy-tailed lottery,
@@ -104,7 +108,8 @@ def anchored_report(gpu, cpu32, ref64, factor=FACTOR, floor=FLOOR, spread=()):
             assert gpu.get(n) is None, "%s: the oracle has no gradient here, the engine produced one" % n
             continue
         assert gpu.get(n) is not None, "%s: missing gradient" % n
-        ec = max([rel_l2(cpu32[n], r)] + [rel_l2(sp[n], r) for sp in spread])
+        rc = r if cpu_ref64 is None else cpu_ref64[n]
+        ec = max([rel_l2(cpu32[n], rc)] + [rel_l2(sp[n], rc) for sp in spread])
         errs[n] = (rel_l2(gpu[n], r), ec)
     stages = {}
     for n, (_, ec) in errs.items():
@@ -118,6 +123,30 @@ def anchored_report(gpu, cpu32, ref64, factor=FACTOR, floor=FLOOR, spread=()):
             bad.append("%s gpu %.2e cpu32 %.2e stage median %.2e bound %.2e" % (n, eg, ec, med[stage_of(n)], bound))
     rows.sort(reverse=True)
     return bad, rows
+
+
+def decision_forced_report(P, B, cpu_batch, decisions, gpu, cpu32, ref64, spread=()):
+    """Round 5 (VERDICT r4 "Next" 1b): separate an implementation's DECISIONS from its ARITHMETIC.
+
+    The encoder is piecewise linear: 33 ReLUs behind train-mode BatchNorms.  An activation within fp32 round-off of zero lands on either
+    side of its ReLU depending on the summation order of whoever computes it, and a flipped element moves a whole BatchNorm channel's
+    gradient sums (profiles/round4_notes.md section 8: ONE element of 737 280 moved `encoder.layer4.2.bn2.weight` by 1e-4) -- the single-run
+    rule of anchored_report then compares one draw of that lottery (the engine's) with another (the CPU fp32 run's).  Here the float64
+    oracle is evaluated once more with the ENGINE's own ReLU decisions imposed (oracle/restatement.py `_relu`; forward values are
+    unchanged to ~1e-7, a flipped element being ~0 on either side; the backward pass follows the engine's masks).  Against THAT truth the
+    engine's gradients carry arithmetic error only, and every tensor has to pass the same bound as before: a tensor that fails the
+    single-run rule but passes here differs from float64 by decisions at round-off distance from zero, which no fp32 implementation
+    determines; one that fails here too is a defect.  Returns (failures, rows, grads of the forced oracle)."""
+    from oracle.restatement import ReluDecisions
+    g64f = oracle_grads(P, B, cpu_batch, torch.float64, relu_decisions=ReluDecisions(impose=decisions))[2]
+    bad, rows = anchored_report(gpu, cpu32, g64f, spread=spread, cpu_ref64=ref64)
+    return bad, rows, g64f
+
+
+def count_decision_flips(decisions, decisions_ref):
+    """number of ReLU decisions that differ between two runs, total number"""
+    flips = sum(int((a != b).sum()) for a, b in zip(decisions, decisions_ref))
+    return flips, sum(a.numel() for a in decisions)
 
 
 def tie_free_batch(cpu_batch, out64, depth_range=(0.1, 100.0), tie=TIE, tie_sigma=0.0):
