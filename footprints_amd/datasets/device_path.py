@@ -82,6 +82,10 @@ class DeviceBatchAssembler:
         self.fxb = float(np.float32(0.58 * width) * baseline) if dataset == "kitti" else 0.0
         self.depth_scaling = float(depth_scaling)
         self.device = torch.device(device)
+        if self.device.type == "cuda" and self.device.index is None:
+            # "cuda" means the CURRENT device at construction, pinned to an explicit index: under a launcher the current device
+            # changes when DistContext.from_env selects LOCAL_RANK, and a bare "cuda" stream / buffer created before that lives on GPU 0
+            self.device = torch.device("cuda", torch.cuda.current_device())
         # the copy / assembly stream.  A process owns four hardware queues and the engine uses all four (footprints_amd/engine.py): a
         # stream of its own is a fifth one and shares a queue with whichever engine stream the runtime picks -- a 3.6 ms H2D copy then
         # sits in front of that stream's kernels (637 vs 851 img/s on two boxes of the pool).  Pass the engine's decoder weight-gradient
@@ -184,6 +188,13 @@ class DeviceLoader:
     def __len__(self):
         return len(self.source)
 
+    def shard(self, rank, world):
+        """per-rank view for parallel.ShardedLoader: the SOURCE is sharded by index (a rank decodes, stages and assembles only its own
+        batches), the assembler and its slots stay this process's"""
+        if not hasattr(self.source, "shard"):
+            raise TypeError("DeviceLoader.shard: the sample source has no shard(rank, world)")
+        return DeviceLoader(self.source.shard(rank, world), self.asm, self.is_train, self.rng)
+
     def __iter__(self):
         # one worker thread does the host half of staging (augmentation draws in batch order + the copies into pinned memory: numpy
         # releases the GIL for them), one batch ahead of the batch whose copies and kernels are in flight, two ahead of the consumer
@@ -222,7 +233,7 @@ class SyntheticSampleSource:
 
     def __init__(self, batch_size, height, width, steps, seed=10, pool=24):
         rng = np.random.default_rng(seed)
-        self.B, self.steps = batch_size, steps
+        self.B, self.steps, self.first, self.stride = batch_size, steps, 0, 1
         self.pool = []
         for _ in range(pool):
             maps = {"visible_ground": rng.random((height, width)), "ground_depth": rng.random((height, width)) * 30 * (rng.random((height, width)) < 0.5),
@@ -232,8 +243,15 @@ class SyntheticSampleSource:
         self.dataset = range(steps * batch_size)
 
     def __len__(self):
-        return self.steps
+        return len(range(self.first, self.steps, self.stride))
+
+    def shard(self, rank, world):
+        import copy
+        v = copy.copy(self)
+        v.steps = (self.steps // world) * world
+        v.first, v.stride = rank, world
+        return v
 
     def __iter__(self):
-        for i in range(self.steps):
+        for i in range(self.first, self.steps, self.stride):
             yield [self.pool[(i * self.B + j) % len(self.pool)] for j in range(self.B)]

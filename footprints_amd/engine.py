@@ -760,7 +760,16 @@ class Engine:
         if tab is None:
             tab = self._w32_tables[key] = ops.build_pack_table([self._w32_lazy[key]], self.device)
         ops.pack_weights_batched(tab)
-        torch.cuda.synchronize(self.device)         # first touch only: readers on other streams of this step must see it too
+        # first touch only.  Readers on the engine's other streams must see the layout too: an event edge from this stream to each of them
+        # (round 5, ADVICE r4: the device-wide synchronize that stood here is illegal under stream capture and invisible to a recording
+        # launch plan).  And a plan that is recording RIGHT NOW would bake this one-off launch into every replay: bumping the allocation
+        # generation makes TrainStep discard it and record again on the next step, when the layout is part of the regular repack.
+        ev = self._record(ops.current_stream())
+        cur = ops.current_stream().cuda_stream
+        for st in {s.cuda_stream: s for s in (self.aux, self.wg, self.dwg[0], self.dwg[1])}.values():
+            if st.cuda_stream != cur:
+                ops.event_wait(st, ev)
+        ops.bump_alloc_generation()
         self._w32_fresh.add(key)
         if key not in self._w32_used:
             self._w32_used.add(key)

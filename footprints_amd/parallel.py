@@ -66,6 +66,7 @@ def bucket_ranges(names, offsets, total, max_elems=8 << 20):
 # collectives on the group (gloo in the CPU tests and when two test ranks share one GPU; "nccl" as the fallback when fp_comm_init
 # fails on some rank).  FP_DP_TRANSPORT=torch|rccl overrides the choice.
 _TRANSPORT = os.environ.get("FP_DP_TRANSPORT", "")
+_ALLOW_SHARED = bool(int(os.environ.get("FP_DP_ALLOW_SHARED_GPU", "0")))     # several ranks on one physical GPU (gloo transport): tests only
 # which stream carries the all-reduces: "own" = a dedicated stream; "dwg0" / "dwg1" / "aux" / "wg" = that engine stream (ROCm maps a
 # process's streams onto a handful of hardware queues -- every extra stream that is busy during the backward pass can end up sharing
 # a queue with one of the five the schedule already uses, and streams that share a queue serialise)
@@ -134,9 +135,22 @@ def _host_group(group):
     if "gloo" in str(dist.get_backend(group)):
         return group
     if group not in _HOST_GROUPS:
-        ranks = dist.get_process_group_ranks(group) if group is not None else None
-        _HOST_GROUPS[group] = dist.new_group(ranks=ranks, backend="gloo")
+        # dist.new_group must be entered by ALL ranks of the default group: created lazily from inside a sub-group's collective, the
+        # non-members would never call it and the members would wait forever.  The default group is always complete here;
+        # a non-gloo SUB-group needs its twin made up front by everybody: prepare_host_group(group), called by DistContext.from_env
+        if group is not None:
+            raise RuntimeError("footprints_amd.parallel: the gloo twin of a non-gloo sub-group has to be created by all ranks of the default "
+                               "group together: call parallel.prepare_host_group(group) on every rank right after creating the group")
+        _HOST_GROUPS[group] = dist.new_group(ranks=None, backend="gloo")
     return _HOST_GROUPS[group]
+
+
+def prepare_host_group(group=None):
+    """create the gloo twin of `group` NOW; every rank of the DEFAULT group has to call this (members and non-members alike)"""
+    if "gloo" in str(dist.get_backend(group)) or group in _HOST_GROUPS:
+        return
+    ranks = dist.get_process_group_ranks(group) if group is not None else None
+    _HOST_GROUPS[group] = dist.new_group(ranks=ranks, backend="gloo")
 
 
 def get_communicator(group=None, create=True):
@@ -191,9 +205,27 @@ def destroy_communicators():
             c.destroy()
     _COMMS.clear()
     _SHARED_DEVICE.clear()
+    _HOST_GROUPS.clear()          # a re-initialised process group must not find the gloo twin of the destroyed one
 
 
 _SHARED_DEVICE = {}
+
+
+def _physical_device_id(index=None):
+    """identity of the PHYSICAL GPU behind the current logical device: its uuid, else its PCI address.  The logical index is not enough
+    (ADVICE r4): launchers that bind one GPU per rank through HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES (SLURM --gpus-per-task, some
+    k8s device plugins) give EVERY rank logical device 0 -- a census of (host, 0) would call that "all ranks share one GPU" and downgrade a
+    healthy 8-GPU run to gloo."""
+    index = torch.cuda.current_device() if index is None else index
+    p = torch.cuda.get_device_properties(index)
+    uuid = getattr(p, "uuid", None)
+    if uuid is not None and str(uuid).strip("0-") != "":
+        return "uuid:%s" % uuid
+    pci = tuple(getattr(p, k, None) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
+    if any(v is not None for v in pci):
+        return "pci:%s" % (pci,)
+    vis = os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES", os.environ.get("CUDA_VISIBLE_DEVICES", "")))
+    return "logical:%s/%d" % (vis, index)
 
 
 def ranks_share_a_device(group=None):
@@ -201,7 +233,7 @@ def ranks_share_a_device(group=None):
     the host group on first use -- every rank calls it at the same points (GradReducer / broadcast_state construction)."""
     if group not in _SHARED_DEVICE:
         import socket
-        mine = (socket.gethostname(), torch.cuda.current_device())
+        mine = (socket.gethostname(), _physical_device_id())
         everyone = [None] * dist.get_world_size(group)
         dist.all_gather_object(everyone, mine, group=_host_group(group))
         _SHARED_DEVICE[group] = len(set(everyone)) < len(everyone)
@@ -219,8 +251,15 @@ def _pick_transport(flat_grad, group, force):
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return "rccl" if (force or dist.is_initialized()) else "torch"
     if ranks_share_a_device(group):
+        # RCCL needs a device per rank.  Ranks sharing a GPU is a TEST configuration (the one-GPU test box): it has to be asked for
+        # (FP_DP_ALLOW_SHARED_GPU=1 or FP_DP_TRANSPORT=torch), a production launch that ends up here by a binding mistake must not
+        # silently train over gloo staged through the host at a fraction of the speed
+        if not _ALLOW_SHARED:
+            raise RuntimeError("footprints_amd.parallel: several ranks of the group sit on the same physical GPU; RCCL needs one device per "
+                               "rank.  Fix the launcher's GPU binding, or set FP_DP_ALLOW_SHARED_GPU=1 (gradients then travel over "
+                               "torch.distributed %s, staged through the host: a test configuration, not a data-parallel run)" % dist.get_backend(group))
         if dist.get_rank(group) == 0:
-            print("footprints_amd.parallel: several ranks share one GPU -- RCCL needs a device per rank; gradients travel over "
+            print("footprints_amd.parallel: several ranks share one GPU (FP_DP_ALLOW_SHARED_GPU=1) -- gradients travel over "
                   "torch.distributed (%s), staged through the host.  This is a test configuration, not a data-parallel run."
                   % dist.get_backend(group), flush=True)
         return "torch"
@@ -376,7 +415,7 @@ class DistContext:
         return self.world > 1
 
     def shard(self, loader):
-        return ShardedLoader(loader, self.rank, self.world) if self.active else loader
+        return ShardedLoader(loader, self.rank, self.world, group=self.group) if self.active else loader
 
     def mean_losses(self, losses):
         """dict of floats -> the same keys averaged over the ranks (one small all-reduce on the host group; every rank calls it)"""
@@ -394,23 +433,159 @@ class DistContext:
 
 
 class ShardedLoader:
-    """rank r of `world` sees batches r, r + world, r + 2 world, ... of the wrapped iterable, and every rank the same number of them
-    (the tail that does not fill a round is dropped: a rank with one batch more would wait in an all-reduce nobody else enters)"""
+    """rank r's share of a loader's batches in a data-parallel run: every rank the same number of them (the tail that does not fill a round
+    is dropped: a rank with one batch more would wait in an all-reduce nobody else enters).
 
-    def __init__(self, loader, rank, world):
-        self.loader, self.rank, self.world = loader, rank, world
+    Sharding happens at the INDEX level wherever the wrapped loader allows it (round 5) -- a rank then pays the input pipeline
+    (decode, augmentation, collation, H2D) for its own batches only, and disjointness does not depend on every rank drawing a bit-identical
+    batch order:
+      1. a loader with `shard(rank, world)` (SyntheticLoader, DeviceLoader / SyntheticSampleSource here) returns its own per-rank view:
+         batches r, r + world, ... by index;
+      2. a `torch.utils.data.DataLoader` is rebuilt over a rank-strided `EpochShardSampler` (epoch-seeded permutation shared by all ranks,
+         `set_epoch` called from `__iter__`: the DistributedSampler contract, drop_last so that the ranks' counts agree);
+      3. anything else is iterated completely by every rank, each keeping every world-th batch (the rounds 3-4 behaviour).  That is only
+         correct when all ranks see the same order, so the first batch of every epoch is fingerprinted and the fingerprints are compared
+         over the host group: ranks that disagree raise instead of silently training on overlapping shards."""
+
+    def __init__(self, loader, rank, world, seed=0, group=None):
+        self.loader, self.rank, self.world, self.group = loader, rank, world, group
         self.dataset = getattr(loader, "dataset", None)
+        self.epoch = 0
+        self.mode, self.inner = "stride", None
+        if hasattr(loader, "shard") and callable(loader.shard):
+            self.mode, self.inner = "index", loader.shard(rank, world)
+        else:
+            try:
+                from torch.utils.data import DataLoader
+            except Exception:                       # pragma: no cover
+                DataLoader = ()
+            if DataLoader and isinstance(loader, DataLoader) and loader.batch_size is not None and hasattr(loader.dataset, "__len__"):
+                self.sampler = EpochShardSampler(len(loader.dataset), rank, world, loader.batch_size, shuffle=_is_shuffling(loader), seed=seed)
+                self.inner = DataLoader(loader.dataset, batch_size=loader.batch_size, sampler=self.sampler, num_workers=loader.num_workers,
+                                        collate_fn=loader.collate_fn, pin_memory=loader.pin_memory, drop_last=True,
+                                        worker_init_fn=loader.worker_init_fn, persistent_workers=getattr(loader, "persistent_workers", False))
+                self.mode = "sampler"
 
     def __len__(self):
+        if self.inner is not None:
+            return len(self.inner)
         return len(self.loader) // self.world
 
+    def set_epoch(self, epoch):
+        self.epoch = int(epoch)
+
+    def _agreed(self, mine):
+        """the number of batches EVERY rank will train on this epoch: the minimum over the ranks of what each one has (one small collective
+        on the host group per epoch).  Loaders whose lengths disagree between ranks (a file missing on one host, a dataset of another
+        size) would otherwise leave the better-supplied ranks waiting in a gradient all-reduce that the others never enter."""
+        if mine is None or not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+            return mine
+        v = torch.tensor([int(mine)], dtype=torch.int64)
+        dist.all_reduce(v, op=dist.ReduceOp.MIN, group=_host_group(self.group))
+        return int(v[0])
+
+    def _bounded(self, it, n):
+        out = 0
+        for b in it:
+            if n is not None and out >= n:
+                return
+            yield b
+            out += 1
+        if n is not None and out < n:
+            raise RuntimeError("ShardedLoader: rank %d ran out of batches after %d of the %d the ranks agreed on for this epoch -- the "
+                               "other ranks are about to wait for its gradients; aborting this rank so that the launcher stops the run" % (self.rank, out, n))
+
     def __iter__(self):
-        n = len(self) if hasattr(self.loader, "__len__") else None
+        epoch, self.epoch = self.epoch, self.epoch + 1
+        if self.mode == "index":
+            yield from self._bounded(self.inner, self._agreed(len(self.inner) if hasattr(self.inner, "__len__") else None))
+            return
+        if self.mode == "sampler":
+            self.sampler.set_epoch(epoch)
+            yield from self._bounded(self.inner, self._agreed(len(self.inner)))
+            return
+        n = self._agreed(len(self) if hasattr(self.loader, "__len__") else None)
         pending, out = [], 0
         for b in self.loader:
+            if not pending and out == 0:
+                _assert_same_first_batch(b, self.group)
             pending.append(b)
             if len(pending) == self.world:          # a full round: hand out this rank's batch
                 yield pending[self.rank]
                 pending, out = [], out + 1
                 if n is not None and out >= n:
                     return
+
+
+def _is_shuffling(loader):
+    try:
+        from torch.utils.data import RandomSampler
+        return isinstance(loader.sampler, RandomSampler)
+    except Exception:                               # pragma: no cover
+        return False
+
+
+class EpochShardSampler:
+    """indices of rank r for one epoch: the (optionally shuffled, epoch-seeded -- identical on every rank) permutation of range(n), cut to a
+    multiple of world * batch_size, dealt out batch-wise: global batch g goes to rank g % world.  torch's DistributedSampler deals out single
+    indices; dealing out whole batches keeps a rank's batches equal to the ones the single-process loader would have formed."""
+
+    def __init__(self, n, rank, world, batch_size, shuffle=True, seed=0):
+        self.n, self.rank, self.world, self.bs, self.shuffle, self.seed, self.epoch = n, rank, world, batch_size, shuffle, seed, 0
+        self.rounds = n // (world * batch_size)
+
+    def set_epoch(self, epoch):
+        self.epoch = int(epoch)
+
+    def __len__(self):
+        return self.rounds * self.bs
+
+    def __iter__(self):
+        if self.shuffle:
+            g = torch.Generator()
+            g.manual_seed(self.seed + self.epoch)
+            order = torch.randperm(self.n, generator=g).tolist()
+        else:
+            order = list(range(self.n))
+        for r in range(self.rounds):
+            base = (r * self.world + self.rank) * self.bs
+            yield from order[base:base + self.bs]
+
+
+def _fingerprint(obj):
+    import hashlib
+    h = hashlib.sha256()
+
+    def feed(o):
+        if isinstance(o, dict):
+            for k in sorted(o):
+                h.update(str(k).encode())
+                feed(o[k])
+        elif isinstance(o, (list, tuple)):
+            for v in o:
+                feed(v)
+        elif torch.is_tensor(o):
+            t = o.detach()
+            h.update(str(tuple(t.shape)).encode())
+            flat = t.reshape(-1)
+            step = max(1, flat.numel() // 4096)
+            h.update(flat[::step].cpu().contiguous().numpy().tobytes())
+        elif hasattr(o, "tobytes"):
+            h.update(o.tobytes()[:1 << 16])
+        else:
+            h.update(repr(o).encode())
+    feed(obj)
+    return int.from_bytes(h.digest()[:7], "little")
+
+
+def _assert_same_first_batch(batch, group=None):
+    """fallback sharding only: every rank must draw the same batch order -- compare a fingerprint of the epoch's first batch over the host group"""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    fp = _fingerprint(batch)
+    v = torch.tensor([fp, -fp], dtype=torch.int64)
+    dist.all_reduce(v, op=dist.ReduceOp.MAX, group=_host_group(group))
+    if int(v[0]) != -int(v[1]):
+        raise RuntimeError("ShardedLoader: the ranks drew different first batches from a loader that is sharded by iteration (it has no "
+                           "shard(rank, world) and is not a torch DataLoader): their shards would overlap.  Seed the loader identically on "
+                           "every rank or give it a shard(rank, world) method")

@@ -284,16 +284,24 @@ class SyntheticLoader:
     batches resident on the device, cycled.  Stands in for the KITTI / Matterport DataLoaders, which are out of scope."""
 
     def __init__(self, batch_size, height, width, steps, seed=SEED, pool=2, device="cuda"):
-        self.steps = steps
+        self.steps, self.first, self.stride = steps, 0, 1
         self.batches = [synthetic_batch(batch_size, height, width, device, seed=seed + i) for i in range(pool)]
         self.dataset = range(steps * batch_size)           # len(loader.dataset) is what the reference logs (train.py:76-77)
 
     def __len__(self):
-        return self.steps
+        return len(range(self.first, self.steps, self.stride))
 
     def __iter__(self):
-        for i in range(self.steps):
+        for i in range(self.first, self.steps, self.stride):
             yield dict(self.batches[i % len(self.batches)])
+
+    def shard(self, rank, world):
+        """the per-rank view parallel.ShardedLoader asks for: batches rank, rank + world, ... of the same pool, equal counts on every rank"""
+        import copy
+        v = copy.copy(self)
+        v.steps = (self.steps // world) * world
+        v.first, v.stride = rank, world
+        return v
 
 
 class _Opts:

@@ -67,6 +67,7 @@ def _worker(rank, world, port, q, overlap, fake_rccl=False):
     try:
         import torch.distributed as dist
         os.environ["FP_DP_OVERLAP"] = "1" if overlap else "0"     # read when footprints_amd.parallel is imported
+        os.environ["FP_DP_ALLOW_SHARED_GPU"] = "1"                # two ranks on the test box's single GPU: has to be asked for (round 5)
         if fake_rccl:
             os.environ["FP_DP_TRANSPORT"] = "rccl"
         os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -339,7 +340,8 @@ def test_one_rank_per_device_over_rccl_matches_the_n_shard_oracle():
 # ---- the trainer itself as one replica of two (ranks share the test box's GPU: gloo transport) -------------------------------------------
 def _trainer_worker(rank, world, port, folder, q):
     try:
-        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK="0")
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK="0",
+                          FP_DP_ALLOW_SHARED_GPU="1")
         torch.cuda.set_device(0)
         from footprints_amd.main import main
         from footprints_amd.training import train as T
@@ -396,3 +398,44 @@ def test_main_trains_data_parallel_under_a_launcher_environment(tmp_path):
     assert res[0][5]["train"] == res[1][5]["train"] and res[0][5]["val"] == res[1][5]["val"]
     models = os.path.join(str(tmp_path), "dp", "models")
     assert sorted(os.listdir(models)) == ["weights_0"] and sorted(os.listdir(os.path.join(models, "weights_0"))) == ["model.pth", "optimiser.pth"]
+
+
+# ---- ranks that share a physical GPU without having asked for it: an error, not a silent downgrade to gloo ---------------------
+def _shared_worker(rank, world, port, q):
+    try:
+        import torch.distributed as dist
+        os.environ.pop("FP_DP_ALLOW_SHARED_GPU", None)
+        os.environ.pop("FP_DP_TRANSPORT", None)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from footprints_amd import parallel
+        ident = parallel._physical_device_id()
+        try:
+            parallel._pick_transport(torch.zeros(4, device="cuda"), None, False)
+            q.put((rank, "no error", ident))
+        except RuntimeError as e:
+            q.put((rank, "raised", ident, str(e)[:80]))
+        dist.barrier()
+        dist.destroy_process_group()
+    except BaseException as e:
+        import traceback
+        q.put((rank, "error", traceback.format_exc()))
+
+
+def test_ranks_on_one_physical_gpu_are_refused_unless_asked_for():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shared_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        r = q.get(timeout=300)
+        res[r[0]] = r
+    for p in procs:
+        p.join(timeout=60)
+    assert res[0][1] == res[1][1] == "raised", res
+    assert res[0][2] == res[1][2] and not res[0][2].startswith("logical:"), res        # the same PHYSICAL identity (uuid / PCI address) on both ranks
