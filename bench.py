@@ -672,6 +672,40 @@ def main():
                               "operand_format": FMT}), flush=True)
         return
 
+    # data-parallel only: what the gradient exchange adds to a step -- the same step WITH its bucket all-reduces and WITHOUT them (a second
+    # TrainStep on the same engine with no reducer), alternating blocks of 10 steps, medians of the GPU-side step durations.  In a world of
+    # one (--force-dist) it prices the branch itself (event edges, the communicator's launches); with N ranks it is the exposed, i.e.
+    # un-overlapped, communication.  (The replicas' weights drift apart during the blocks without exchange: nothing after this reads them.)
+    exposed = None
+    if step.reducer is not None:
+        step_nc = TrainStep(mm.model, mm.optimiser, distributed=False)
+        mm.optimiser.grad_scale = step.reducer.grad_scale
+
+        def block(fn, n=10):
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+            ev[0].record()
+            for i in range(n):
+                fn(batch)
+                ev[i + 1].record()
+            barrier()
+            return [ev[i].elapsed_time(ev[i + 1]) for i in range(n)]
+        for fn in (step_nc, step):
+            for _ in range(4):
+                fn(batch)
+        barrier()
+        with_ms, without_ms = [], []
+        for _ in range(3):
+            without_ms += block(step_nc)
+            with_ms += block(step)
+        med = lambda v: sorted(v)[len(v) // 2]
+        tt = torch.tensor([med(with_ms), med(without_ms)], dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        exposed = {"step_ms_with_exchange": round(float(tt[0]), 3), "step_ms_without_exchange": round(float(tt[1]), 3),
+                   "exposed_ms": round(float(tt[0] - tt[1]), 3),
+                   "how": "3 x (10 steps without the bucket all-reduces, 10 steps with them), medians of per-step HIP-event durations, max over ranks"}
+        del step_nc
+
     sustained = None
     if args.sustain > 0:
         sustained = sustained_leg(step, batch, args.sustain, world, local_rank % have)          # every rank loops (the steps contain the all-reduces)
@@ -896,7 +930,13 @@ def main():
                                                   "rccl_ranks": comm.count() if (comm is not None and hasattr(comm, "count")) else 0,
                                                   "allreduce_us": [{"bucket": r["kernel"], "per_step": r["launches_per_step"], "avg_us": r["avg_us"]}
                                                                    for r in ar_rows]}
+            out["config"]["gradient_exchange"]["exposed_communication"] = exposed
             out["rccl_ranks"] = out["config"]["gradient_exchange"]["rccl_ranks"]
+            if step.reducer.transport == "rccl" and not shared_gpu and out["rccl_ranks"] != world:
+                raise SystemExit("bench.py --gpus %d: the RCCL communicator counts %d ranks (ncclCommCount), expected %d -- not a valid "
+                                 "data-parallel measurement" % (args.gpus, out["rccl_ranks"], world))
+            if world > 1 and not shared_gpu and step.reducer.transport != "rccl":
+                raise SystemExit("bench.py --gpus %d: one GPU per rank but the gradient exchange runs over %r instead of RCCL" % (args.gpus, step.reducer.transport))
         if world == 1 and not args.force_dist and not args.no_other_format:
             del step, mm                                               # free this process's arena before the child builds its own
             torch.cuda.empty_cache()

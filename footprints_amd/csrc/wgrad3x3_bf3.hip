@@ -323,14 +323,18 @@ __global__ void __launch_bounds__(256, 2) wgrad3x3_bf3_v3_kernel(const W3Args a)
 // the bottom of chunk k stages slot (k + 1) % D into the other LDS buffer and refills it with chunk k + 1 + D.  Every path issues the
 // same six vector loads (past the last chunk: from one cache line), so the wait counters the compiler derives are exact on all of
 // them; the staging has no branches either (the X plane is padded to 1024 items, the bias sum is masked by a multiplier).
+// Round 5: NP = 3 runs the same ring with the EXACT bf16 split (three planes, six products, no amax slots, no un-scaling) -- the default
+// operand format's weight gradient had stayed on the third generation; same LDS layout per plane, same MFMA order per accumulator, so its
+// results are bit-identical to wgrad3x3_bf3_v3_kernel<MODE, 3> (tests/test_gpu_switches.py: FP_WGRAD_PF=0 against the default).
 constexpr int XP4 = 1024 * 8;                                   // X plane: 864 staging items padded to 4 per thread
-constexpr int BUF4 = 2 * (XP4 + ZP3);                           // 24576 bytes per buffer
 
-template <int MODE, int D>
+template <int MODE, int D, int NP = 2>
 __global__ void __launch_bounds__(256, D > 2 ? 1 : 2) wgrad3x3_hp_pf_kernel(const W3Args a) {
-  constexpr int XBN = 2 * XP4;
+  constexpr int XBN = NP * XP4;
+  constexpr int BUF4 = NP * (XP4 + ZP3);                        // 24576 bytes per buffer (fp16 pairs), 36864 (bf16 split)
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF4];
-  const unsigned amax_raw = fp_amax3_issue(a.amax_x, a.amax_dz, nullptr);     // both amax slots: one vector load, reduced behind the first chunk's loads
+  // (fp16 pairs) both amax slots: one vector load, reduced behind the first chunk's loads
+  const unsigned amax_raw = NP == 2 ? fp_amax3_issue(a.amax_x, a.amax_dz, nullptr) : 0u;
   int kx_ = 0, kz_ = 0;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   int b = a.xcd ? fp_xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
@@ -437,12 +441,12 @@ __global__ void __launch_bounds__(256, D > 2 ? 1 : 2) wgrad3x3_hp_pf_kernel(cons
     unsigned char* const base = lds + buf * BUF4;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-      split_store_np<2>(base + (t + 256 * k) * 8, XP4, f32x4{xr[sl][k].x, xr[sl][k].y, xr[sl][k].z, xr[sl][k].w}, kx_);
+      split_store_np<NP>(base + (t + 256 * k) * 8, XP4, f32x4{xr[sl][k].x, xr[sl][k].y, xr[sl][k].z, xr[sl][k].w}, kx_);
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       bs[0] = fmaf(zv[sl][k].x, live, bs[0]); bs[1] = fmaf(zv[sl][k].y, live, bs[1]);
       bs[2] = fmaf(zv[sl][k].z, live, bs[2]); bs[3] = fmaf(zv[sl][k].w, live, bs[3]);
-      split_store_np<2>(base + XBN + (t + 256 * k) * 8, ZP3, f32x4{zv[sl][k].x, zv[sl][k].y, zv[sl][k].z, zv[sl][k].w}, kz_);
+      split_store_np<NP>(base + XBN + (t + 256 * k) * 8, ZP3, f32x4{zv[sl][k].x, zv[sl][k].y, zv[sl][k].z, zv[sl][k].w}, kz_);
     }
   };
 
@@ -455,7 +459,7 @@ __global__ void __launch_bounds__(256, D > 2 ? 1 : 2) wgrad3x3_hp_pf_kernel(cons
   const float bias_on = want_bias ? 1.f : 0.f;
   // prologue: chunk 0 through slot 0 into buffer 0, then chunks 1 .. D into slots 1 .. D - 1, 0
   issue(std::integral_constant<int, 0>{});
-  {
+  if (NP == 2) {
     unsigned mx, mz, unused;
     fp_amax3_reduce(amax_raw, mx, mz, unused);
     kx_ = fp_hp_exponent(mx, FP_HP_TARGET_ACT);
@@ -475,12 +479,35 @@ __global__ void __launch_bounds__(256, D > 2 ? 1 : 2) wgrad3x3_hp_pf_kernel(cons
   // read in chunk k - 1, before the barrier that ended it -- and refill the slot with chunk k + 1 + D
   auto body = [&](auto slot_, int k) {
     const unsigned char* const Bb = lds + (k & 1) * BUF4;
-    uint4 bz[2];
+    uint4 bz[NP];
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
+    for (int p = 0; p < NP; ++p) {
       const uint2 lo = lds_tr16(Bb + zrd + p * ZP3), hi = lds_tr16(Bb + zrd + p * ZP3 + 4 * PXB);
       bz[p] = make_uint4(lo.x, lo.y, hi.x, hi.y);
     }
+    if constexpr (NP == 3) {
+      // exact split: one tap at a time -- three A planes (12 registers) and the six products of that tap's accumulator in the third
+      // generation's order (smallest first: the same sums, bit for bit).  A dependent chain on one accumulator issues back to back on
+      // gfx950 (scripts/ubench/mfma_bf16_chain.hip), and keeping one tap's planes live instead of a row's 36 registers is what lets the
+      // ring's two register slots fit beside 144 accumulator registers
+      constexpr int PA3[6] = {2, 0, 1, 1, 0, 0}, PB3[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          uint4 a3[3];
+#pragma unroll
+          for (int p = 0; p < 3; ++p) {
+            const unsigned char* src = Bb + xrd + (ky * HWD + kx) * PXB + p * XP4;
+            const uint2 lo = lds_tr16(src), hi = lds_tr16(src + 4 * PXB);
+            a3[p] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+          }
+#pragma unroll
+          for (int qq = 0; qq < 6; ++qq)
+            acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a3[PA3[qq]]), __builtin_bit_cast(bf16x8, bz[PB3[qq]]),
+                                                                       acc[ky * 3 + kx], 0, 0, 0);
+        }
+    } else {
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
       uint4 af[3][2];                                // [kx][plane]
@@ -499,6 +526,7 @@ __global__ void __launch_bounds__(256, D > 2 ? 1 : 2) wgrad3x3_hp_pf_kernel(cons
         for (int kx = 0; kx < 3; ++kx)
           acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[kx][PA[qq]]), __builtin_bit_cast(f16x8, bz[PB[qq]]),
                                                                     acc[ky * 3 + kx], 0, 0, 0);
+    }
     }
     // nothing of the staging moves up among the MFMAs: its first instruction waits for the slot's loads, and every MFMA issued
     // before that wait is time the loads have to land (D chunk periods instead of D - 1)
@@ -539,7 +567,7 @@ __global__ void __launch_bounds__(256, D > 2 ? 1 : 2) wgrad3x3_hp_pf_kernel(cons
     }
     __syncthreads();
   }
-  const float unscale = ldexpf(1.f, -(kx_ + kz_));
+  const float unscale = NP == 2 ? ldexpf(1.f, -(kx_ + kz_)) : 1.f;
 #pragma unroll
   for (int tp = 0; tp < 9; ++tp) {
 #pragma unroll
@@ -548,7 +576,8 @@ __global__ void __launch_bounds__(256, D > 2 ? 1 : 2) wgrad3x3_hp_pf_kernel(cons
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const int e = t + 256 * kk;
-      const float v = (((red[e] + red[1024 + e]) + red[2048 + e]) + red[3072 + e]) * unscale;
+      float v = ((red[e] + red[1024 + e]) + red[2048 + e]) + red[3072 + e];
+      if (NP == 2) v *= unscale;
       const int r = e >> 6, ln = e & 63;
       const int ci = ci0 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
       out[((size_t)tp * a.C + ci) * a.Nout + co0 + (ln & 31)] = v;
@@ -769,6 +798,11 @@ static int wgrad_split(const fp_conv_desc* d, const float* x, const float* dz, f
     else if (a.mode == 1) FP_W3_PF_LAUNCH(1);
     else FP_W3_PF_LAUNCH(2);
 #undef FP_W3_PF_LAUNCH
+  } else if (!hp && pf >= 1 && pf_fits && !a.stamps && a.mode != 2) {
+    // exact split on the ring (round 5); FP_WGRAD_PF=0: third generation.  The nearest-x2 gather form (two launches per step) stays on the
+    // third generation: its border-chunk address math does not fit beside three operand planes without 12 bytes of scratch
+    if (a.mode == 0) fp_launch((wgrad3x3_hp_pf_kernel<0, 2, 3>), dim3(nwg), dim3(256), 0, stream, a);
+    else fp_launch((wgrad3x3_hp_pf_kernel<1, 2, 3>), dim3(nwg), dim3(256), 0, stream, a);
   } else if (hp) {
     if (a.mode == 0) fp_launch((wgrad3x3_bf3_v3_kernel<0, 2>), dim3(nwg), dim3(256), 0, stream, a);
     else if (a.mode == 1) fp_launch((wgrad3x3_bf3_v3_kernel<1, 2>), dim3(nwg), dim3(256), 0, stream, a);

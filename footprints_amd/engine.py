@@ -1184,7 +1184,8 @@ class Engine:
                 fi += 1
         dnext = None       # gradient wrt this block's output coming from the next block (same layer)
         dnext_part = None  # (partials, blocks) when `dnext` already IS g = dout * (out > 0) and its producer wrote bn2's backward sums
-        bwd_epi = ops._BN_BWD_EPI and _HP_TILE and not ops._bf16x2
+        # (round 5: also with the exact bf16x3 operands -- the sink is a property of the tile kernel's epilogue, not of the operand format)
+        bwd_epi = ops._BN_BWD_EPI and (_HP_TILE or _BF3) and not ops._bf16x2
 
         def bnb_arm(name, h_, w_, C_, z, rec):
             """arm the BatchNorm-backward sink for the next tile data gradient at (h_, w_, C_): partial sums per pixel tile (8 x 16 or 6 x 20
@@ -1236,7 +1237,7 @@ class Engine:
             da1 = buf("g.da1", (N, h, w, C))
             dz1 = buf("g.dz1.%d" % i, (N, h, w, C))
             d2 = ops.make_desc(N, h, w, h, w, C, 0, C, 3, 1, 1, L.GATHER_DGRAD_ZERO)
-            if bwd_epi and blk.c2.hp_d is not None and ops.conv3x3_bf3_supported(d2):
+            if bwd_epi and (blk.c2.hp_d is not None or blk.c2.wpd3 is not None) and ops.conv3x3_bf3_supported(d2):
                 # conv2's data gradient applies bn1's ReLU mask itself (da1 = gradient * (a1 > 0)) and emits bn1's backward sums
                 d2.epi = L.EPI_ACTGRAD_RELU
                 part, cell = bnb_arm("bnb.part1", h, w, C, B["z1"], blk.bn1)
@@ -1288,7 +1289,7 @@ class Engine:
                 dnext = None
             else:
                 dx = buf("g.dx%d" % (i & 1), (N, hin, win, Cin))
-                if bwd_epi and blk.c1.hp_d is not None and ops.conv3x3_bf3_supported(dgd):
+                if bwd_epi and (blk.c1.hp_d is not None or blk.c1.wpd3 is not None) and ops.conv3x3_bf3_supported(dgd):
                     # this block's input is the previous block's output (after its ReLU): conv1's data gradient + the residual gradient,
                     # masked by (input > 0), IS the g of the previous block's bn2 -- stored as such, with that BatchNorm's backward sums
                     Bp, blkp = S["blocks"][i - 1], self.blocks[i - 1]

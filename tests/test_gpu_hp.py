@@ -303,7 +303,8 @@ def test_conv3x3_hp_emits_batchnorm_partials(N, H, W, C0, Cout, emits):
     (10, 21, 45, 128, True),             # ragged tiles on both borders, two channel tiles (180 workgroups: unsplit)
     (12, 6, 20, 512, "reduce"),          # split-K grid: the sums come out of the reduce launch, one pair per block of the reduce launch
 ])
-def test_conv3x3_hp_data_gradient_emits_batchnorm_backward_sums(N, H, W, C, emits):
+@pytest.mark.parametrize("fmt", ["fp16_pair", "exact"])
+def test_conv3x3_hp_data_gradient_emits_batchnorm_backward_sums(N, H, W, C, emits, fmt):
     """fp_bn_bwd_out_next: a tile data gradient whose epilogue applies the ReLU mask stores g = (dgrad + residual) * (out > 0) of the
     BatchNorm below it AND that BatchNorm's backward sums (sum g, sum g * xhat) per pixel tile and channel; fp_bn_bwd_partials turns them into
     the same dz / dgamma / dbeta as fp_bn_bwd on (dy, relu_out, z) -- against float64 (torchvision BatchNorm2d backward)."""
@@ -327,8 +328,19 @@ def test_conv3x3_hp_data_gradient_emits_batchnorm_backward_sums(N, H, W, C, emit
     dz64 = gamma.double().view(1, C, 1, 1) * invstd.view(1, C, 1, 1) * (g64 - (s1 / M).view(1, C, 1, 1) - xhat * (s2 / M).view(1, C, 1, 1))
     # device
     d = ops.make_desc(N, H, W, H, W, C, 0, C, 3, 1, 1, L.GATHER_DGRAD_ZERO, epi=L.EPI_ACTGRAD_RELU)
-    wp, sw = pack_hp(w, dgrad=True)
+    hp = fmt == "fp16_pair"             # "exact": the same sink behind fp_conv3x3_bf3 (bf16x3 operands; the engine's default since round 5)
+    if hp:
+        wp, sw = pack_hp(w, dgrad=True)
+    else:
+        from tests.test_gpu_kernels import pack_bf3
+        wp, sw = pack_bf3(w, dgrad=True), None
     gzs, zs = nhwc(gz), nhwc(z)
+
+    def conv(dst, amax_out=None):
+        if hp:
+            ops.conv3x3_hp(d, gzs, wp, dst, slot_of(gzs), sw, amax_out=amax_out, addend=nhwc(resid), actsrc=nhwc(out))
+        else:
+            ops.conv3x3_bf3(d, gzs, wp, dst, addend=nhwc(resid), actsrc=nhwc(out))
     mean_d, invstd_d = mean.float().cuda(), invstd.float().cuda()
     cap = N * ((H + 5) // 6) * ((W + 15) // 16) * C * 2
     rows = 256 // (C // 4) * 4
@@ -339,7 +351,7 @@ def test_conv3x3_hp_data_gradient_emits_batchnorm_backward_sums(N, H, W, C, emit
     gout = torch.empty((N, H, W, C), device="cuda")
     cell = ops.bn_bwd_out_next(part, zs.view(-1, C), mean_d, invstd_d)
     so = ops.new_slot()
-    ops.conv3x3_hp(d, gzs, wp, gout, slot_of(gzs), sw, amax_out=so, addend=nhwc(resid), actsrc=nhwc(out))
+    conv(gout, so)
     torch.cuda.synchronize()
     tiles = cell.value
     if emits == "reduce":
@@ -347,10 +359,11 @@ def test_conv3x3_hp_data_gradient_emits_batchnorm_backward_sums(N, H, W, C, emit
     else:
         assert tiles in ((N * ((H + 7) // 8) * ((W + 15) // 16), N * ((H + 5) // 6) * ((W + 19) // 20)) if emits else (0,))
     check(nchw(gout), g64, "masked data gradient", 2e-6)
-    assert ops.amax_value(so) == float(gout.abs().max())
+    if hp:
+        assert ops.amax_value(so) == float(gout.abs().max())
     g2 = torch.empty_like(gout)                                    # the sink is one-shot
     part_before = part.clone()
-    ops.conv3x3_hp(d, gzs, wp, g2, slot_of(gzs), sw, addend=nhwc(resid), actsrc=nhwc(out))
+    conv(g2)
     torch.cuda.synchronize()
     assert torch.equal(gout, g2) and torch.equal(torch.nan_to_num(part, nan=7.0), torch.nan_to_num(part_before, nan=7.0))
     dz_ref, dg_ref, db_ref = (torch.empty((N, H, W, C), device="cuda"), torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda"))
