@@ -245,6 +245,8 @@ GROUPS = {
     "conv_up2_phase_wgrad_hp": dict(kernel="wgrad_up2_phase_bf3_kernel<2> (fp16-pair operands; + its sum / un-collapse / bias reduce launches)",
                                     bf16x3=False, products=HP_PRODUCTS),
     "conv_igemm": dict(kernel="igemm_kernel / stem_tile_kernel (7x7 stem, 4x4/2 phase dgrad of small levels; stride 2 / 1x1 with FP_HP_IGEMM=0)", bf16x3=False),
+    "conv_igemm_bf3": dict(kernel="igemm_hp_kernel<TN, 3> (exactly split bf16x3 operands: 3x3 stride 2, 1x1, their data gradients; + splitk_reduce_kernel on small grids)",
+                           bf16x3=True),
     "conv_igemm_hp": dict(kernel="igemm_hp_kernel (fp16-pair operands: 3x3 stride 2, 1x1, their data gradients; + splitk_reduce_kernel on small grids)",
                           bf16x3=False, products=HP_PRODUCTS),
     "conv_stem_hp": dict(kernel="stem_tile_hp_kernel / stem_wgrad_hp_kernel (the 7x7 / 2 stem and its weight gradient with fp16-pair operands; + wgrad_reduce_wide_kernel)",
@@ -265,11 +267,12 @@ GROUP_SYMBOL = {
     "conv_up2_phase_dgrad_hp": ("up2_phase_dgrad_bf3_kernel",), "conv_up2_phase_dgrad_bf3": ("up2_phase_dgrad_bf3_kernel",),
     "conv_up2_phase_wgrad_hp": ("wgrad_up2_phase_bf3_kernel",), "conv_up2_phase_wgrad_bf3": ("wgrad_up2_phase_bf3_kernel",),
     "conv_stem_hp": ("stem_tile_hp_kernel", "stem_wgrad_hp_kernel"),
-    "conv_igemm": ("igemm_kernel", "stem_tile_kernel"), "conv_igemm_hp": ("igemm_hp_kernel",), "conv_wgrad": ("wgrad_kernel", "wgrad3x3_tile_kernel", "stem_wgrad_tile_kernel"),
+    "conv_igemm": ("igemm_kernel", "stem_tile_kernel"), "conv_igemm_hp": ("igemm_hp_kernel",), "conv_igemm_bf3": ("igemm_hp_kernel",), "conv_wgrad": ("wgrad_kernel", "wgrad3x3_tile_kernel", "stem_wgrad_tile_kernel"),
 }
 CONV_OPS = {
     "conv_igemm": dict(group="conv_igemm", dense=conv_flops, exec=conv_flops, bytes=conv_bytes),
     "conv_igemm_hp": dict(group="conv_igemm_hp", dense=conv_flops, exec=conv_flops, bytes=conv_bytes),
+    "conv_igemm_bf3": dict(group="conv_igemm_bf3", dense=conv_flops, exec=conv_flops, bytes=conv_bytes),
     "conv_stem_hp": dict(group="conv_stem_hp", dense=conv_flops, exec=conv_flops, bytes=conv_bytes),
     "conv_stem_wgrad_hp": dict(group="conv_stem_hp", dense=conv_flops, exec=conv_flops, bytes=conv_bytes),
     "conv3x3_bf3": dict(group="conv3x3_bf3", dense=conv_flops, exec=conv_flops, bytes=conv_bytes),
@@ -516,11 +519,24 @@ class GpuSampler:
 def sustained_leg(step, batch, seconds, world, local_rank):
     """loop the training step for `seconds` of wall clock (what a trainer sees: clocks and power settle over seconds, the timed region lasts
     a fraction of one); per-step HIP events, per-second img/s, sysfs samples of the GPU this rank runs on"""
+    from footprints_amd import _lib
+    lib = _lib.load()
     sampler = GpuSampler(index=local_rank).start()
+    # the chip's own counters (fp_clock_probe: shader cycles + constant-rate ticks per XCD) every 32 steps: d cycles / d ticks x wall-clock
+    # rate = the shader clock really sustained in between, independent of what the SMU's sysfs nodes report
+    probes = torch.zeros((4096, 16), dtype=torch.int64, device="cuda")
+    n_probe = 0
+
+    def probe():
+        nonlocal n_probe
+        if n_probe < probes.shape[0]:
+            _lib.check(lib.fp_clock_probe(probes[n_probe].data_ptr(), torch.cuda.current_stream().cuda_stream), "fp_clock_probe")
+            n_probe += 1
     marks = [torch.cuda.Event(enable_timing=True)]
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     marks[0].record()
+    probe()
     host_t = []
     while True:
         step(batch)
@@ -528,13 +544,30 @@ def sustained_leg(step, batch, seconds, world, local_rank):
         e.record()
         marks.append(e)
         host_t.append(time.perf_counter() - t0)
+        if (len(marks) - 1) % 32 == 0:
+            probe()
         if host_t[-1] >= seconds or len(marks) > 200000:
             break
         if len(marks) % 64 == 0:
             marks[-32].synchronize()          # keep the host at most ~32 steps ahead: the loop ends on GPU time, not on queue depth
+    probe()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     sampler.stop()
+    khz = int(lib.fp_wall_clock_khz())
+    pr = probes[:n_probe].cpu().view(n_probe, 8, 2).double()
+    clocks = []
+    if khz > 0 and n_probe >= 2:
+        for i in range(n_probe - 1):
+            per_xcd = [(pr[i + 1, x, 0] - pr[i, x, 0]) / (pr[i + 1, x, 1] - pr[i, x, 1]) * khz / 1e3
+                       for x in range(8) if pr[i, x, 1] > 0 and pr[i + 1, x, 1] > pr[i, x, 1]]
+            if per_xcd:
+                clocks.append(float(sum(per_xcd) / len(per_xcd)))
+    cs = sorted(clocks)
+    shader_clock = ({"mean": round(sum(cs) / len(cs), 1), "p10": round(cs[len(cs) // 10], 1), "median": round(cs[len(cs) // 2], 1),
+                     "p90": round(cs[min(len(cs) - 1, len(cs) * 9 // 10)], 1), "intervals": len(cs), "wall_clock_khz": khz,
+                     "how": "fp_clock_probe every 32 steps: d s_memtime / d s_memrealtime x wall-clock rate, mean over the XCDs, per interval"}
+                    if cs else None)
     n = len(marks) - 1
     ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(n)]
     ends, acc = [], 0.0
@@ -548,7 +581,7 @@ def sustained_leg(step, batch, seconds, world, local_rank):
     srt = sorted(ms)
     return {"seconds": round(dt, 2), "steps": n, "img_per_s": round(world * B * n / dt, 2), "ms_per_step": round(dt / n * 1e3, 3),
             "step_ms": {"p10": round(srt[n // 10], 3), "median": round(srt[n // 2], 3), "p90": round(srt[min(n - 1, n * 9 // 10)], 3), "max": round(srt[-1], 3)},
-            "img_per_s_each_second": per_sec, "gpu": sampler.summary(),
+            "img_per_s_each_second": per_sec, "shader_clock_mhz": shader_clock, "gpu": sampler.summary(),
             "note": "the same step looped for --sustain seconds right after the timed region (rank 0's GPU sampled every 100 ms)"}
 
 

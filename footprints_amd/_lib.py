@@ -137,6 +137,7 @@ SIGNATURES = {
     "fp_bn_eval_coeffs": (C.c_int, [_P, _P, _P, _P, _F, _I32, _P, _P, _P]),
     "fp_conv_igemm_hp_supported": (C.c_int, [_DESC]),
     "fp_conv_igemm_hp": (C.c_int, [_DESC, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P]),
+    "fp_conv_igemm_bf3": (C.c_int, [_DESC, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
     "fp_bn_apply": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _I32, _P]),
     "fp_bn_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, _I64, _I32, _P, _I64, _P]),
     "fp_maxpool_fwd": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _P]),
@@ -148,6 +149,8 @@ SIGNATURES = {
     "fp_nchw_to_nhwc": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P]),
     "fp_nhwc_to_nchw": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P]),
     "fp_fill": (C.c_int, [_P, _I64, _F, _P]),
+    "fp_clock_probe": (C.c_int, [_P, _P]),
+    "fp_wall_clock_khz": (C.c_int, []),
     "fp_version": (C.c_int, []),
     "fp_last_error_string": (C.c_char_p, []),
 }

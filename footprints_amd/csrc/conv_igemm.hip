@@ -341,7 +341,10 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmArgs a) {
 typedef _Float16 ig_f16x8 __attribute__((ext_vector_type(8)));
 typedef float ig_f32x8 __attribute__((ext_vector_type(8)));
 
-template <int TN>
+// NP = 2: scaled fp16 pairs (three products).  NP = 3 (round 5): the EXACT bf16 split -- x = h + m + l, six products, no amax slots, no
+// scaling -- for the default operand format: the stride-2 3x3 / 1x1 convolutions of the encoder and their data gradients leave the fp32
+// MFMA (1/16 of the bf16 rate) without giving up an operand bit.  Weights [tap][chunk][NP planes][Nout][16] from FP_PACK_{FWD,DGRAD}_BF3 jobs.
+template <int TN, int NP = 2>
 __global__ void __launch_bounds__(256) igemm_hp_kernel(const IgemmArgs a) {
   constexpr int BM = 128, BN = 32 * TN;
   const int t = threadIdx.x;
@@ -352,11 +355,15 @@ __global__ void __launch_bounds__(256) igemm_hp_kernel(const IgemmArgs a) {
   const int tile_n = tile % a.tilesN, tile_m = tile / a.tilesN;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const FpGeom& g = a.g;
-  unsigned ma, mw, unused;
-  fp_amax3_reduce(fp_amax3_issue(a.amax_a, a.amax_w, nullptr), ma, mw, unused);             // one round trip for both slots (fp_common.h)
-  const int ka = fp_hp_exponent(ma, FP_HP_TARGET_ACT);
-  const float sa = ldexpf(1.f, ka);
-  const int kunscale = -(ka + fp_hp_exponent(mw, FP_HP_TARGET_W));
+  float sa = 1.f;
+  int kunscale = 0;
+  if constexpr (NP == 2) {
+    unsigned ma, mw, unused;
+    fp_amax3_reduce(fp_amax3_issue(a.amax_a, a.amax_w, nullptr), ma, mw, unused);           // one round trip for both slots (fp_common.h)
+    const int ka = fp_hp_exponent(ma, FP_HP_TARGET_ACT);
+    sa = ldexpf(1.f, ka);
+    kunscale = -(ka + fp_hp_exponent(mw, FP_HP_TARGET_W));
+  }
 
   // this lane's row of the GEMM = one output pixel (forward) / one input-gradient pixel (data gradient)
   int pn, py, px;
@@ -421,7 +428,7 @@ __global__ void __launch_bounds__(256) igemm_hp_kernel(const IgemmArgs a) {
   set_tap();
   float4 ar[3][2];
   bool aok[3][2];
-  uint4 br[3][TN][2];
+  uint4 br[3][TN][NP];
   const int cmax = max(g.C0 - 4, 0);
   auto load_next = [&](int set) {
     const int c8 = lcc * 16 + h * 8;
@@ -429,12 +436,12 @@ __global__ void __launch_bounds__(256) igemm_hp_kernel(const IgemmArgs a) {
     ar[set][1] = *reinterpret_cast<const float4*>(prow + min(c8 + 4, cmax));
     aok[set][0] = prow_ok && c8 < g.C0;
     aok[set][1] = prow_ok && c8 + 4 < g.C0;
-    const unsigned short* ws = a.w_hp + (size_t)(tap * a.KC16 + lcc) * 2 * a.Nout * 16 + h * 8;
+    const unsigned short* ws = a.w_hp + (size_t)(tap * a.KC16 + lcc) * NP * a.Nout * 16 + h * 8;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int n = min(n0 + j * 32 + idx, a.Nout - 1);
 #pragma unroll
-      for (int p = 0; p < 2; ++p) br[set][j][p] = *reinterpret_cast<const uint4*>(ws + ((size_t)p * a.Nout + n) * 16);
+      for (int p = 0; p < NP; ++p) br[set][j][p] = *reinterpret_cast<const uint4*>(ws + ((size_t)p * a.Nout + n) * 16);
     }
     if (++lcc == a.KC16) {                            // position the pointer for the following step
       lcc = 0;
@@ -452,6 +459,37 @@ __global__ void __launch_bounds__(256) igemm_hp_kernel(const IgemmArgs a) {
 
   auto consume = [&](int set) {
     const float4 a0 = aok[set][0] ? ar[set][0] : make_float4(0.f, 0.f, 0.f, 0.f), a1 = aok[set][1] ? ar[set][1] : make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (NP == 3) {
+      // exact split of the lane's eight channels: h = bf16(x), m = bf16(x - h), l = bf16(x - h - m); each difference is exact in fp32
+      typedef float ig_f32x4 __attribute__((ext_vector_type(4)));
+      typedef __bf16 ig_bf16x4 __attribute__((ext_vector_type(4)));
+      typedef __bf16 ig_bf16x8 __attribute__((ext_vector_type(8)));
+      uint2 pl[3][2];
+#pragma unroll
+      for (int q2 = 0; q2 < 2; ++q2) {
+        const float4 af = q2 ? a1 : a0;
+        const ig_f32x4 v = {af.x, af.y, af.z, af.w};
+        const ig_bf16x4 vh = __builtin_convertvector(v, ig_bf16x4);
+        const ig_f32x4 r1 = v - __builtin_convertvector(vh, ig_f32x4);
+        const ig_bf16x4 vm = __builtin_convertvector(r1, ig_bf16x4);
+        const ig_f32x4 r2 = r1 - __builtin_convertvector(vm, ig_f32x4);
+        const ig_bf16x4 vl = __builtin_convertvector(r2, ig_bf16x4);
+        pl[0][q2] = __builtin_bit_cast(uint2, vh);
+        pl[1][q2] = __builtin_bit_cast(uint2, vm);
+        pl[2][q2] = __builtin_bit_cast(uint2, vl);
+      }
+      ig_bf16x8 va[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) va[p] = __builtin_bit_cast(ig_bf16x8, make_uint4(pl[p][0].x, pl[p][0].y, pl[p][1].x, pl[p][1].y));
+      // six of the nine products, smallest first (conv3x3_tile_bf3.hip): l*h, h*l, m*m, m*h, h*m, h*h
+      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+      for (int qq = 0; qq < 6; ++qq)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[PA[qq]], __builtin_bit_cast(ig_bf16x8, br[set][j][PB[qq]]), acc[0][j], 0, 0, 0);
+      return;
+    }
     uint2 h0, m0, h1, m1;
     fp_hp_split4(a0.x, a0.y, a0.z, a0.w, sa, h0, m0);
     fp_hp_split4(a1.x, a1.y, a1.z, a1.w, sa, h1, m1);
@@ -657,7 +695,7 @@ int launch(IgemmArgs& a, hipStream_t stream, int64_t ws_floats) {
   return fp_check_launch("fp_conv_igemm");
 }
 
-template <int TN>
+template <int TN, int NP = 2>
 int launch_hp(IgemmArgs& a, hipStream_t stream, int64_t ws_floats, const FpBnSink& sink) {
   constexpr int BM = 128, BN = 32 * TN;
   int tilesM = (int)fp_ceil_div(a.M, BM);
@@ -672,7 +710,7 @@ int launch_hp(IgemmArgs& a, hipStream_t stream, int64_t ws_floats, const FpBnSin
   a.stepsPerSplit = (int)fp_ceil_div(steps, sk);
   a.SK = (int)fp_ceil_div(steps, a.stepsPerSplit);
   a.nwg = tilesM * a.tilesN * a.SK;
-  fp_launch((igemm_hp_kernel<TN>), dim3(a.nwg), dim3(256), 0, stream, a);
+  fp_launch((igemm_hp_kernel<TN, NP>), dim3(a.nwg), dim3(256), 0, stream, a);
   if (a.SK > 1 && sink.part && !sink.z && a.epi == 0 && a.act == FP_ACT_NONE && !a.pm) {
     // a strided / 1 x 1 forward convolution in front of a train-mode BatchNorm: the statistics out of the reduce launch (fp_bn_stats_out_next)
     int rc2 = 0;
@@ -834,21 +872,22 @@ extern "C" int fp_conv_igemm_hp_supported(const fp_conv_desc* d) {
   return 1;
 }
 
-extern "C" int fp_conv_igemm_hp(const fp_conv_desc* d, const float* src, const void* wpacked_hp, const float* bias, const float* addend,
+static int igemm_split_operands(const char* who, const fp_conv_desc* d, const float* src, const void* wpacked, const float* bias, const float* addend,
                                 const float* addend_mask, const float* actsrc, float* y, void* workspace, int64_t workspace_bytes,
-                                const uint32_t* amax_src, const uint32_t* amax_w, fp_stream_t stream_) {
+                                const uint32_t* amax_src, const uint32_t* amax_w, bool exact, fp_stream_t stream_) {
   const FpBnSink bn_sink = fp_take_bn_sink();     // consumed by this launch: only a split grid's reduce launch can emit (launch_hp)
   hipStream_t stream = (hipStream_t)stream_;
-  FP_REQUIRE(d && src && wpacked_hp && y && amax_src && amax_w, "fp_conv_igemm_hp: null pointer");
-  FP_REQUIRE(fp_conv_igemm_hp_supported(d), "fp_conv_igemm_hp: shape / gather not supported (see fp_conv_igemm_hp_supported)");
-  FP_REQUIRE(!(d->epi & FP_EPI_BIAS) || bias, "fp_conv_igemm_hp: bias flag without pointer");
-  FP_REQUIRE(!(d->epi & FP_EPI_ADDEND) || addend, "fp_conv_igemm_hp: addend flag without pointer");
-  FP_REQUIRE(!(d->epi & FP_EPI_ADDEND_MASK) || addend_mask, "fp_conv_igemm_hp: addend_mask flag without pointer");
-  FP_REQUIRE(!(d->epi & (FP_EPI_ACTGRAD_ELU | FP_EPI_ACTGRAD_RELU)) || actsrc, "fp_conv_igemm_hp: actgrad flag without pointer");
+  (void)who;
+  FP_REQUIRE(d && src && wpacked && y && (exact || (amax_src && amax_w)), "fp_conv_igemm_hp / _bf3: null pointer");
+  FP_REQUIRE(fp_conv_igemm_hp_supported(d), "fp_conv_igemm_hp / _bf3: shape / gather not supported (see fp_conv_igemm_hp_supported)");
+  FP_REQUIRE(!(d->epi & FP_EPI_BIAS) || bias, "fp_conv_igemm_hp / _bf3: bias flag without pointer");
+  FP_REQUIRE(!(d->epi & FP_EPI_ADDEND) || addend, "fp_conv_igemm_hp / _bf3: addend flag without pointer");
+  FP_REQUIRE(!(d->epi & FP_EPI_ADDEND_MASK) || addend_mask, "fp_conv_igemm_hp / _bf3: addend_mask flag without pointer");
+  FP_REQUIRE(!(d->epi & (FP_EPI_ACTGRAD_ELU | FP_EPI_ACTGRAD_RELU)) || actsrc, "fp_conv_igemm_hp / _bf3: actgrad flag without pointer");
   const int64_t M64 = (int64_t)d->N * d->OH * d->OW;
-  FP_REQUIRE(M64 > 0 && M64 < (int64_t)1 << 31 && M64 * d->Nout < (int64_t)1 << 40, "fp_conv_igemm_hp: problem too large / empty");
+  FP_REQUIRE(M64 > 0 && M64 < (int64_t)1 << 31 && M64 * d->Nout < (int64_t)1 << 40, "fp_conv_igemm_hp / _bf3: problem too large / empty");
   IgemmArgs a = {};
-  a.src0 = src; a.w_hp = (const unsigned short*)wpacked_hp; a.bias = bias; a.addend = addend; a.addend_mask = addend_mask; a.actsrc = actsrc; a.y = y;
+  a.src0 = src; a.w_hp = (const unsigned short*)wpacked; a.bias = bias; a.addend = addend; a.addend_mask = addend_mask; a.actsrc = actsrc; a.y = y;
   a.amax_a = amax_src; a.amax_w = amax_w; a.amax_out = nullptr;
   a.g = FpGeom{d->N, d->OH, d->OW, d->IH, d->IW, d->C0, 0, d->KH, d->KW, d->stride, d->pad, d->gather};
   a.Nout = d->Nout; a.act = d->act; a.epi = d->epi;
@@ -865,8 +904,29 @@ extern "C" int fp_conv_igemm_hp(const fp_conv_desc* d, const float* src, const v
   int64_t ws = workspace ? workspace_bytes / (int64_t)sizeof(float) : 0;
   if (ws > MAX_SK * M64 * d->Nout) ws = MAX_SK * M64 * d->Nout;
   // wave tile 32 rows x 32 TN columns: wider tiles re-read the A rows less often, narrower ones fill the chip on small grids
+  if (exact) {                                    // three planes of weights in flight per K-step: two column blocks per wave at most
+    if (d->Nout <= 32) return launch_hp<1, 3>(a, stream, ws, bn_sink);
+    return launch_hp<2, 3>(a, stream, ws, bn_sink);
+  }
   if (d->Nout <= 32) return launch_hp<1>(a, stream, ws, bn_sink);
   const int64_t t128 = fp_ceil_div(M64, 128);
   if (d->Nout % 128 == 0 && t128 * (d->Nout / 128) >= 512) return launch_hp<4>(a, stream, ws, bn_sink);
   return launch_hp<2>(a, stream, ws, bn_sink);
+}
+
+extern "C" int fp_conv_igemm_hp(const fp_conv_desc* d, const float* src, const void* wpacked_hp, const float* bias, const float* addend,
+                                const float* addend_mask, const float* actsrc, float* y, void* workspace, int64_t workspace_bytes,
+                                const uint32_t* amax_src, const uint32_t* amax_w, fp_stream_t stream_) {
+  return igemm_split_operands("fp_conv_igemm_hp", d, src, wpacked_hp, bias, addend, addend_mask, actsrc, y, workspace, workspace_bytes, amax_src,
+                              amax_w, false, stream_);
+}
+
+// The same operation with EXACTLY split bf16x3 operands (round 5; the default operand format's path for the encoder's stride-2 3x3 and 1x1
+// convolutions and their data gradients, footprints/network.py:38-44): weights from FP_PACK_FWD_BF3 / FP_PACK_DGRAD_BF3 jobs (any kernel
+// size; fp_packed_weight_elems_bf3 floats), no amax slots.  Shapes: fp_conv_igemm_hp_supported.
+extern "C" int fp_conv_igemm_bf3(const fp_conv_desc* d, const float* src, const void* wpacked_bf3, const float* bias, const float* addend,
+                                 const float* addend_mask, const float* actsrc, float* y, void* workspace, int64_t workspace_bytes,
+                                 fp_stream_t stream_) {
+  return igemm_split_operands("fp_conv_igemm_bf3", d, src, wpacked_bf3, bias, addend, addend_mask, actsrc, y, workspace, workspace_bytes, nullptr,
+                              nullptr, true, stream_);
 }

@@ -450,6 +450,32 @@ __global__ void __launch_bounds__(256) zero_u32_kernel(unsigned* __restrict__ p,
 
 extern "C" int32_t fp_amax_slot_elems(void) { return FP_AMAX_ELEMS; }
 
+// ---- clock probe (bench.py --sustain): the shader clock the chip REALLY sustains, from its own counters --------------------------------------
+// One workgroup per XCD slot writes (s_memtime = shader cycles, s_memrealtime = constant-rate ticks) into out[xcc][2]; between two probes on
+// one stream,  d cycles / d ticks x (wall-clock rate) = the average shader clock of that XCD over the interval -- no sysfs, no SMU sampling
+// period (on the test boxes hwmon's freq1_input reads the idle clock while a process keeps the GPU busy; rounds 2-4 derived 1.65-1.74 GHz
+// under the tile kernels from per-workgroup stamps of the same counter, profiles/round2_notes.md).
+__global__ void __launch_bounds__(64) clock_probe_kernel(unsigned long long* __restrict__ out) {
+  if (threadIdx.x == 0) {
+    const unsigned x = fp_xcc_id() & 7u;
+    const unsigned long long c = __builtin_readcyclecounter(), r = __builtin_amdgcn_s_memrealtime();
+    out[x * 2] = c;                      // any workgroup of the XCD: they run within microseconds of each other
+    out[x * 2 + 1] = r;
+  }
+}
+
+extern "C" int fp_clock_probe(uint64_t* out16, fp_stream_t stream) {
+  FP_REQUIRE(out16, "fp_clock_probe: null pointer");
+  fp_launch(clock_probe_kernel, dim3(64), dim3(64), 0, (hipStream_t)stream, (unsigned long long*)out16);
+  return fp_check_launch("fp_clock_probe");
+}
+
+extern "C" int fp_wall_clock_khz(void) {
+  int dev = 0, khz = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess) return -1;
+  return khz;
+}
+
 extern "C" int fp_zero_u32(uint32_t* p, int64_t n, fp_stream_t stream) {
   FP_REQUIRE(p && n > 0, "fp_zero_u32: bad arguments");
   fp_launch(zero_u32_kernel, dim3(ew_grid((size_t)n, 64)), dim3(256), 0, (hipStream_t)stream, p, (size_t)n);

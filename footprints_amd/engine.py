@@ -47,6 +47,8 @@ _HP_WGRAD = _HP and bool(int(os.environ.get("FP_HP_WGRAD", "1")))
 _HP_TILE = _HP and bool(int(os.environ.get("FP_HP_TILE", "1")))
 # fp16 pairs also for the stride-2 3x3 / 1x1 convolutions and their data gradients (fp_conv_igemm_hp, round 3); FP_HP_IGEMM=0: fp32 MFMA
 _HP_IGEMM = _HP and bool(int(os.environ.get("FP_HP_IGEMM", "1")))
+# exact operand format (round 5): the same convolutions with exactly split bf16x3 operands (fp_conv_igemm_bf3); FP_BF3_IGEMM=0: fp32 MFMA
+_BF3_IGEMM = _BF3 and not _HP and bool(int(os.environ.get("FP_BF3_IGEMM", "1")))
 # the 1x1 downsample branch of a BasicBlock (conv -> BN, and its gradients) on the aux stream beside the block's main branch: the encoder
 # is the serial spine of the step (one kernel on the GPU at a time), the aux stream idles until the decoders start.  FP_DS_AUX=0: in line
 _DS_AUX = bool(int(os.environ.get("FP_DS_AUX", "1")))
@@ -87,6 +89,8 @@ class ConvRec:
         self.hp = self.bf3 and _HP
         # ... and of the flattened-kernel packings for the convolutions the tile kernel does not take (3x3 stride 2, 1x1): fp_conv_igemm_hp
         self.hp_ig = _HP_IGEMM and not self.bf3 and not stem and not head and self.K in (1, 3)
+        # ... or, with the exact operand format, bf16x3 copies of the same packings in the wp3 / wpd3 slots: fp_conv_igemm_bf3
+        self.bf3_ig = _BF3_IGEMM and not self.bf3 and not stem and not head and self.K in (1, 3) and self.Cin % 4 == 0
         self.hp_f = self.hp_d = self.hp_sk = self.hp_ds = self.hp_ph = self.hp_du = None      # + phase forward / phase data-gradient
         self.wslot = None
         self.gw = None    # gradient views (flat grad buffer)
@@ -408,6 +412,8 @@ class Engine:
                            ops.packed_weight_elems_bf3(c.Cout, C1, 3, False) if C1 else 0,
                            ops.packed_weight_elems_bf3(c.Cout, C1, 3, True) if C1 else 0, ops.up2_packed_weight_elems(c.Cout, C0) * 3 // 2,
                            ops.up2_packed_weight_elems(C0, c.Cout) * 3 // 2]
+            elif c.bf3_ig:           # stride-2 3x3 / 1x1: the flattened kernel's bf16x3 packings live in the wp3 / wpd3 slots
+                ex += [ops.packed_weight_elems_bf3(c.Cout, c.Cin, c.K, False), ops.packed_weight_elems_bf3(c.Cout, c.Cin, c.K, True), 0, 0, 0, 0]
             else:
                 ex += [0, 0, 0, 0, 0, 0]
             if c.hp or c.hp_ig:      # fp16-pair copies of the tile packings (same roles as wp3 / wpd3 / wsk3 / wds3)
@@ -618,6 +624,8 @@ class Engine:
             if use_hp:
                 return self._cv_hp(d, src, hp[0], hp[1], out, publish=publish, **kw)
             return ops.conv3x3_bf3(d, src, w3, out, **kw)
+        if _BF3_IGEMM and w3 is not None and not ops._bf16x2 and ops.conv_igemm_hp_supported(d):
+            return ops.conv_igemm_bf3(d, src, w3, out, **kw)
         if _HP_IGEMM and hp is not None and hp[0] is not None and not ops._bf16x2 and ops.conv_igemm_hp_supported(d):
             return ops.conv_igemm_hp(d, src, hp[0], out, self.amax.get(src), hp[1], **kw)
         return ops.conv_igemm(d, src, None, self._need32(w32), out, **kw)
@@ -658,7 +666,7 @@ class Engine:
         if self._fold_buf is None:
             total = 0
             for c, _ in pairs:
-                n3 = ops.packed_weight_elems_bf3(c.Cout, c.Cin, 3, False) if c.bf3 else 0
+                n3 = ops.packed_weight_elems_bf3(c.Cout, c.Cin, c.K, False) if (c.bf3 or c.bf3_ig) else 0
                 n3 += ops.packed_weight_elems_hp(c.Cout, c.Cin, c.K, False) if (c.hp or c.hp_ig) else 0
                 total += c.w.numel() + ops.packed_weight_elems(c.Cout, c.Cin, c.K, False, c.stem) + n3 + c.Cout
             self._fold_buf = torch.empty(total, device=self.device)
@@ -670,7 +678,7 @@ class Engine:
                 n = ops.packed_weight_elems(c.Cout, c.Cin, c.K, False, c.stem)
                 c.fwp = self._fold_buf[o:o + n]
                 o += n
-                n = ops.packed_weight_elems_bf3(c.Cout, c.Cin, 3, False) if c.bf3 else 0
+                n = ops.packed_weight_elems_bf3(c.Cout, c.Cin, c.K, False) if (c.bf3 or c.bf3_ig) else 0
                 c.fwp3 = self._fold_buf[o:o + n] if n else None
                 o += n
                 n = ops.packed_weight_elems_hp(c.Cout, c.Cin, c.K, False) if (c.hp or c.hp_ig) else 0
@@ -721,11 +729,11 @@ class Engine:
                         self.amax.get(x, any_stream=True)
                     ops.event_wait(self.aux, self._record(ops.current_stream()))
                     with ops.on_stream(self.aux):
-                        idt = self._cv(dd, x, blk.ds.fwp, None, buf("b%d.idt" % i, (N, oh, ow, blk.Cout)), hp=(blk.ds.fhp, blk.ds.fslot),
+                        idt = self._cv(dd, x, blk.ds.fwp, blk.ds.fwp3, buf("b%d.idt" % i, (N, oh, ow, blk.Cout)), hp=(blk.ds.fhp, blk.ds.fslot),
                                        bias=blk.bnd.fshift)
                         ev_idt = self._record(self.aux)
                 else:
-                    idt = self._cv(dd, x, blk.ds.fwp, None, buf("b%d.idt" % i, (N, oh, ow, blk.Cout)), hp=(blk.ds.fhp, blk.ds.fslot),
+                    idt = self._cv(dd, x, blk.ds.fwp, blk.ds.fwp3, buf("b%d.idt" % i, (N, oh, ow, blk.Cout)), hp=(blk.ds.fhp, blk.ds.fslot),
                                    bias=blk.bnd.fshift)
             else:
                 idt = x
@@ -803,6 +811,7 @@ class Engine:
             tile = (c.wp3 is not None or (_HP_TILE and c.hp_f is not None and not ops._bf16x2)) and ops.conv3x3_bf3_supported(d)
             # ... or a strided / 1 x 1 convolution through the fp16-pair implicit GEMM: its split grids emit from their reduce launch
             tile = tile or (_HP_IGEMM and c.hp_f is not None and not ops._bf16x2 and ops.conv_igemm_hp_supported(d))
+            tile = tile or (_BF3_IGEMM and c.bf3_ig and not ops._bf16x2 and ops.conv_igemm_hp_supported(d))      # ... or the exact one
             if tile and ops._BN_EPI:
                 # one (count, mean, M2) triple per pixel tile and channel: tiles of 8 x 16 or 6 x 20 pixels, bounded by 6 x 16-pixel ones
                 cap = N * ((OH + 5) // 6) * ((OW + 15) // 16) * c.Cout * 3
@@ -1230,7 +1239,7 @@ class Engine:
                         self._sink_done(dzd)
                     self._wgrad(blk.ds, L.GATHER_FWD_ZERO, B["x"], None, dzd, N, h, w, hin, win, Cin, 0, accumulate, side)
                     d1 = ops.make_desc(N, hin, win, h, w, C, 0, Cin, 1, blk.stride, 0, L.GATHER_DGRAD_ZERO, epi=L.EPI_ACCUM)
-                    self._cv(d1, dzd, blk.ds.wpd, None, tgt, hp=(blk.ds.hp_d, blk.ds.wslot))
+                    self._cv(d1, dzd, blk.ds.wpd, blk.ds.wpd3, tgt, hp=(blk.ds.hp_d, blk.ds.wslot))
                     ev_ds = self._record(self.aux)
             if not _WGRAD_PAIR_FORK:
                 self._wgrad(blk.c2, L.GATHER_FWD_ZERO, B["a1"], None, dz2, N, h, w, h, w, C, 0, accumulate, side)
@@ -1280,7 +1289,7 @@ class Engine:
                 dgd.epi = L.EPI_ACCUM
                 self._cv(dgd, dz1, blk.c1.wpd, blk.c1.wpd3, tgt, hp=(blk.c1.hp_d, blk.c1.wslot))
                 d1 = ops.make_desc(N, hin, win, h, w, C, 0, Cin, 1, blk.stride, 0, L.GATHER_DGRAD_ZERO, epi=L.EPI_ACCUM)
-                self._cv(d1, dzd, blk.ds.wpd, None, tgt, hp=(blk.ds.hp_d, blk.ds.wslot))
+                self._cv(d1, dzd, blk.ds.wpd, blk.ds.wpd3, tgt, hp=(blk.ds.hp_d, blk.ds.wslot))
                 dnext = None
             elif first_of_layer:                        # layer1 block 0: input is the max-pool output
                 dpool = buf("g.dpool", (N, hin, win, Cin))

@@ -299,6 +299,29 @@ def conv3x3_hp(desc, src, wpacked_hp, y, amax_src, amax_w, amax_out=None, bias=N
     return y
 
 
+def conv_igemm_bf3(desc, src, wpacked_bf3, y, bias=None, addend=None, addend_mask=None, actsrc=None):
+    """flattened implicit GEMM with EXACTLY split bf16x3 operands (3x3 stride 2, 1x1, their data gradients; the default operand format):
+    weights from FP_PACK_{FWD,DGRAD}_BF3; shapes as conv_igemm_hp_supported"""
+    lib = _lib.load()
+    epi = desc.epi
+    if bias is not None:
+        epi |= _lib.EPI_BIAS
+    if addend is not None:
+        epi |= _lib.EPI_ADDEND
+    if addend_mask is not None:
+        epi |= _lib.EPI_ADDEND_MASK
+    d = ConvDesc.from_buffer_copy(desc)
+    d.epi = epi
+    need = 0 if _NO_SPLITK else _cached_query("fp_conv_igemm_workspace", d)
+    ws_ptr, ws_n = 0, 0
+    if need > 0:
+        ws = workspace(need, y.device, "igemm")
+        ws_ptr, ws_n = ws.data_ptr(), ws.numel()
+    _lib.check(lib.fp_conv_igemm_bf3(C.byref(d), _f32(src, "src"), _chk(wpacked_bf3, "wpacked_bf3"), _f32(bias), _f32(addend), _f32(addend_mask),
+                                     _f32(actsrc), _f32(y, "y"), ws_ptr, ws_n, stream()), "fp_conv_igemm_bf3")
+    return y
+
+
 def packed_weight_elems_bf3(Cout, Cin, K, for_dgrad=False):
     return int(_lib.load().fp_packed_weight_elems_bf3(Cout, Cin, K, K, int(for_dgrad)))
 

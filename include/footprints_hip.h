@@ -334,6 +334,12 @@ int fp_conv_igemm_hp_supported(const fp_conv_desc* d);
 int fp_conv_igemm_hp(const fp_conv_desc* d, const float* src, const void* wpacked_hp, const float* bias, const float* addend,
                      const float* addend_mask, const float* actsrc, float* y, void* workspace, int64_t workspace_bytes,
                      const uint32_t* amax_src, const uint32_t* amax_w, fp_stream_t stream);
+/* ... and with EXACTLY split bf16x3 operands (round 5): the default operand format's path for the same convolutions -- x = h + m + l in
+ * bf16, six MFMA products, no operand bit of fp32 dropped, no amax slots.  Weights from FP_PACK_FWD_BF3 / FP_PACK_DGRAD_BF3 jobs (any
+ * kernel size; fp_packed_weight_elems_bf3 floats).  Shapes: fp_conv_igemm_hp_supported.  Replaces aten::convolution /
+ * convolution_backward(data) of the stride-2 BasicBlock convs and the 1x1 downsample convs (footprints/network.py:38-44). */
+int fp_conv_igemm_bf3(const fp_conv_desc* d, const float* src, const void* wpacked_bf3, const float* bias, const float* addend,
+                      const float* addend_mask, const float* actsrc, float* y, void* workspace, int64_t workspace_bytes, fp_stream_t stream);
 
 int fp_bn_apply(const float* z, const float* scale, const float* shift, const float* residual, float* y, int64_t M,
                 int32_t C, int32_t relu, fp_stream_t stream);
@@ -481,6 +487,11 @@ int fp_ktime_begin(void);
 int32_t fp_ktime_end(void);
 int fp_ktime_row(int32_t i, char* name, int32_t name_cap, int64_t* launches, double* total_ms);
 
+/* measurement aid (bench.py --sustain): (shader cycles, constant-rate ticks) of each of the 8 XCDs into out16[xcc * 2 + {0, 1}] (device memory,
+ * 16 uint64); the difference of two probes on one stream gives the shader clock the chip sustained in between: d cycles / d ticks x
+ * fp_wall_clock_khz().  fp_wall_clock_khz: hipDeviceAttributeWallClockRate of the current device, -1 on error. */
+int fp_clock_probe(uint64_t* out16, fp_stream_t stream);
+int fp_wall_clock_khz(void);
 int fp_version(void);
 const char* fp_last_error_string(void);
 

@@ -505,7 +505,8 @@ def test_up2_phase_wgrad_hp(N, h, w, C0, Cout, acc):
     (12, 48, 160, 64, 128, 1, 2), (12, 12, 40, 256, 512, 1, 2), (4, 128, 160, 64, 128, 1, 2),      # 1x1 downsample convs (+ Matterport layer2)
     (2, 9, 13, 16, 24, 3, 2), (3, 7, 5, 4, 8, 1, 1), (1, 6, 20, 512, 128, 1, 1), (2, 10, 14, 36, 40, 3, 2)])     # ragged, odd sizes, C % 16 != 0
 @pytest.mark.parametrize("mode", ["fwd", "dgrad"])
-def test_igemm_hp_against_float64(N, H, W, Cin, Cout, K, stride, mode):
+@pytest.mark.parametrize("fmt", ["fp16_pair", "exact"])
+def test_igemm_hp_against_float64(N, H, W, Cin, Cout, K, stride, mode, fmt):
     """against a float64 convolution / its data gradient of the same fp32 operands: relative L2 <= 1e-6 (measured ~3e-7, like the tile
     kernel's), split-K and parity-major plans included; the accumulate epilogue (the form the backward pass uses) on top"""
     import torch.nn.functional as F
@@ -517,14 +518,20 @@ def test_igemm_hp_against_float64(N, H, W, Cin, Cout, K, stride, mode):
     pad = K // 2
     OH, OW = (H + 2 * pad - K) // stride + 1, (W + 2 * pad - K) // stride + 1
     slot_w = torch.zeros(ops.amax_elems(), dtype=torch.int32, device="cuda")
+    exact = fmt == "exact"              # fp_conv_igemm_bf3 (round 5): the same kernel template with exactly split bf16x3 operands, no amax slots
+
+    def packw(dgrad):
+        if exact:
+            return ops.pack_conv_weight_bf3(w, torch.empty(ops.packed_weight_elems_bf3(Cout, Cin, K, dgrad), device="cuda"), dgrad)
+        return ops.pack_conv_weight_hp(w, torch.empty(ops.packed_weight_elems_hp(Cout, Cin, K, dgrad), device="cuda"), slot_w, dgrad)
     if mode == "fwd":
-        wp = ops.pack_conv_weight_hp(w, torch.empty(ops.packed_weight_elems_hp(Cout, Cin, K, False), device="cuda"), slot_w, False)
+        wp = packw(False)
         src = x.permute(0, 2, 3, 1).contiguous()
         d = ops.make_desc(N, OH, OW, H, W, Cin, 0, Cout, K, stride, pad, L.GATHER_FWD_ZERO)
         y = torch.empty(N, OH, OW, Cout, device="cuda")
         ref = F.conv2d(x.double(), w.double(), stride=stride, padding=pad).permute(0, 2, 3, 1)
     else:
-        wp = ops.pack_conv_weight_hp(w, torch.empty(ops.packed_weight_elems_hp(Cout, Cin, K, True), device="cuda"), slot_w, True)
+        wp = packw(True)
         dz = ((torch.rand(N, Cout, OH, OW, generator=g) * 2 - 1) * 1e-6).cuda()              # gradients are small numbers: the scale has to find them
         src = dz.permute(0, 2, 3, 1).contiguous()
         d = ops.make_desc(N, H, W, OH, OW, Cout, 0, Cin, K, stride, pad, L.GATHER_DGRAD_ZERO)
@@ -534,17 +541,23 @@ def test_igemm_hp_against_float64(N, H, W, Cin, Cout, K, stride, mode):
         ref = xin.grad.permute(0, 2, 3, 1)
     assert ops.conv_igemm_hp_supported(d)
     slot_s = ops.amax_f32(src, torch.zeros(ops.amax_elems(), dtype=torch.int32, device="cuda"))
-    ops.conv_igemm_hp(d, src, wp, y, slot_s, slot_w)
+
+    def run(dst):
+        if exact:
+            ops.conv_igemm_bf3(d, src, wp, dst)
+        else:
+            ops.conv_igemm_hp(d, src, wp, dst, slot_s, slot_w)
+    run(y)
     err = ((y.double() - ref).norm() / ref.norm()).item()
     assert err <= 1e-6, err
     # the accumulating form, on top of an existing tensor
     base = torch.rand(y.shape, generator=g).cuda() * ref.abs().max().float()
     y2 = base.clone()
     d.epi = L.EPI_ACCUM
-    ops.conv_igemm_hp(d, src, wp, y2, slot_s, slot_w)
+    run(y2)
     err2 = ((y2.double() - (ref + base.double())).norm() / (ref + base.double()).norm()).item()
     assert err2 <= 1e-6, err2
     # bit-reproducible
     y3 = base.clone()
-    ops.conv_igemm_hp(d, src, wp, y3, slot_s, slot_w)
+    run(y3)
     assert torch.equal(y2, y3)

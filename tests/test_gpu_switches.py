@@ -30,7 +30,7 @@ print("LOSSES " + json.dumps(out))
 
 def run(env_extra):
     env = dict(os.environ)
-    for k in ("FP_OPERANDS", "FP_HP", "FP_BN_BWD_EPI", "FP_NO_BF3", "FP_SERIAL", "FP_NO_PHASE", "FP_DS_AUX", "FP_PLAN", "FP_NO_WBF3", "FP_WGRAD_PF", "FP_BN_EPI", "FP_ADAM_STAGED"):
+    for k in ("FP_OPERANDS", "FP_HP", "FP_BN_BWD_EPI", "FP_BF3_IGEMM", "FP_NO_BF3", "FP_SERIAL", "FP_NO_PHASE", "FP_DS_AUX", "FP_PLAN", "FP_NO_WBF3", "FP_WGRAD_PF", "FP_BN_EPI", "FP_ADAM_STAGED"):
         env.pop(k, None)
     env.update(env_extra)
     r = subprocess.run([sys.executable, "-c", PROG], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
@@ -61,6 +61,7 @@ def baseline(env):
     ({"FP_BN_EPI": "0"}, {}, False),           # BatchNorm statistics by a pass over the activation instead of the conv epilogue's partials
     ({"FP_ADAM_STAGED": "1"}, {}, True),       # a piece of the Adam update per stage under the backward pass instead of one launch after it (element-wise)
     ({"FP_WGRAD_PF": "0"}, {}, True),          # exact split: third-generation weight-gradient kernel instead of the ring (round 5): same sums, bit for bit
+    ({"FP_BF3_IGEMM": "0"}, {}, False),        # stride-2 3x3 / 1x1 convolutions on fp32 MFMA instead of exactly split bf16x3 operands (round 5)
     ({"FP_BN_BWD_EPI": "0"}, {}, False),       # BatchNorm backward sums by their own reduction pass instead of the data gradient's epilogue
     ({"FP_HP": "0"}, {}, True),                # the legacy spelling of the default format
     (PAIR, {}, False),                         # scaled fp16 pairs (opt-in) against the exact split (default): the 1e-4 contract
