@@ -27,6 +27,12 @@ natural-statistics case) a relative band of 1 % is 1 m while two conforming impl
 r3): that band is OPT-IN (`tie_sigma=TIE_SIGMA`, used by the natural-statistics / wide-range test only); the standard cases run with the
 1 % band alone, as in round 2, and every caller asserts an upper bound on the number of pixels it removed.
 
+Round 5 (profiles/round5_notes.md section 1) adds the decision-forced evaluation: every case is ALSO compared with the float64 oracle
+evaluated under the engine's own ReLU decisions (`decision_forced_report`).  Against that truth every tensor has to pass the per-tensor
+rule, the errors have ABSOLUTE bounds (FORCED_MAX_ERR / FORCED_MEDIAN_ERR), and the upper median gate applies to whichever of the two
+medians is smaller: a median above 1.5 against the plain float64 run that drops below it once the decisions are imposed is a draw of the
+ReLU lottery (89 of 104 693 760 decisions at 12x192x640), not a drift of the arithmetic.
+
 The gates are fixed (round 4; a change needs a written reason under profiles/): per tensor the rule above; per case the median of
 err(GPU) / err(CPU fp32) inside [0.4, 1.5] ([0.2, 1.5] for the natural-statistics case, whose bound comes from five fp32 runs).  The lower
 end is not a defect -- split operands with exact products are MORE accurate than an fp32 accumulation chain, a median of 0.5 says the
@@ -41,6 +47,13 @@ FLOOR = 2e-5          # relative L2; both implementations at fp32 round-off
 TIE = 1e-2            # |predicted depth - target| (metres, relative to max(depth, 1)) below which the L1 kink is undetermined in fp32
 MEDIAN_GATE = (0.4, 1.5)           # median err(GPU) / err(CPU fp32) per case (see the module docstring)
 MEDIAN_GATE_NATURAL = (0.2, 1.5)
+# Round 5: absolute bounds on err(GPU) against the float64 oracle evaluated under the engine's own ReLU decisions (decision_forced_report) -- with
+# the decisions taken out, what is left is arithmetic, and that has an absolute size: measured at 12x192x640 max 1.8e-4 / median 1.3e-6 (exact
+# bf16x3 operands) and 5.0e-4 / 9.1e-7 (fp16 pairs) over 196 tensors (profiles/round5_parity_ratios.md).  The maximum sits on the BatchNorm
+# affine gradients of the deepest layers (sums of ~1e3 terms that cancel to ~1e-2 of their magnitude: the amplification of section 8 of
+# profiles/round4_notes.md).  The bounds leave a factor ~4-5 over the worst measured case.
+FORCED_MAX_ERR = 2e-3
+FORCED_MEDIAN_ERR = 2e-5
 KINK_MAX_FRACTION = 0.005          # of the 2 B H W depth-target pixels, standard cases
 KINK_MAX_FRACTION_NATURAL = 0.02
 TIE_SIGMA = 1e-4      # (opt-in) ... and the output tolerance of the parity contract itself (north_star: depth / mask tensors within 1e-4): a sigmoid
