@@ -345,6 +345,21 @@ def load_traffic(workload, entry_point):
     return t, None
 
 
+def load_step_counters(workload):
+    """step-level MFMA busy % and HBM bytes from the committed counters-only passes of THIS build and operand format
+    (scripts/pmc_step.py -> profiles/round5_pmc_step_<workload>_<format>.json; digest-checked like load_traffic), or (None, why)"""
+    name = "round%d_pmc_step_%s_%s.json" % (PROFILE_ROUND, workload, FMT)
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as fh:
+            doc = json.load(fh)
+    except (OSError, ValueError):
+        return None, "no step-level counter file for this round and operand format (profiles/%s)" % name
+    have, want = doc.get("kernel_source_sha16"), kernel_source_digest()
+    if have != want:
+        return None, "step-level counter file was measured on another build of the kernel (source digest %s, this tree %s): not attached" % (have, want)
+    return doc, None
+
+
 def _pick_threads():
     """Fastest intra-op thread count among {8, 16, 32, 64, all effective cores} on a representative conv fwd+bwd
     (os.cpu_count() over-reports under cgroup quotas, and oneDNN stops scaling long before 256 threads)."""
@@ -943,6 +958,19 @@ def main():
                                           "under these kernels (profiles/round2_notes.md), i.e. 0.7 of the nominal peak is attainable",
                                "conv_exclusive_ms_per_step": round(sum(g["exclusive_ms_per_step"] for g in groups), 3),
                                "groups": groups}
+            sc, sc_why = load_step_counters(args.workload)
+            if sc:
+                hb = sc["hbm_bytes_per_step"]["total"]
+                out["roofline"]["step_counters"] = {
+                    "mfma_busy_fraction_of_serial_kernel_time": sc["mfma"]["busy_fraction_of_serial_kernel_time"],
+                    "hbm_bytes_per_step": hb, "hbm_gb_per_s": round(hb / ms_per_step / 1e6, 1),
+                    "hbm_fraction_of_peak": round(hb / ms_per_step / 1e6 / HBM_PEAK_GBS, 4),
+                    "kernel_launches_per_step": sc.get("kernel_launches_per_step"),
+                    "how": "rocprofv3 counters-only passes over scripts/step_loop.py on this build (scripts/pmc_step.py, profiles/round%d_pmc_step_%s_%s.json): "
+                           "MFMA busy = (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs) / (GRBM_GUI_ACTIVE / 8 XCDs) summed over every kernel of a step; HBM bytes = "
+                           "FETCH_SIZE x 2 + WRITE_SIZE per step, over THIS line's ms_per_step" % (PROFILE_ROUND, args.workload, FMT)}
+            else:
+                out["roofline"]["step_counters"] = {"attached": False, "why": sc_why}
             out["kernels"] = {"serial": (ktable or [])[:24], "concurrent": (ktable_conc or [])[:24],
                               "note": "per kernel symbol, from HIP events around every kernel launch of %d steps (fp_ktime_*): `serial` = one stream, "
                                       "eager launches (exclusive durations); `concurrent` = the default five-stream schedule replayed from the "

@@ -46,6 +46,11 @@ def collect(d, counter):
                     if hp:
                         key = {"conv3x3_bf3": "conv3x3_hp", "conv_wgrad_bf3": "conv_wgrad_hp", "conv_up2_phase_wgrad_bf3": "conv_up2_phase_wgrad_hp",
                                "conv_up2_phase_fwd_bf3": "conv_up2_phase_fwd_hp", "conv_up2_phase_dgrad_bf3": "conv_up2_phase_dgrad_hp"}[key]
+                # round 5: the ring weight gradient and the flattened split-operand GEMM also run with exact bf16x3 operands (last template argument 3)
+                if key == "conv_wgrad_hp" and name.rstrip().split("(")[0].endswith(", 3>"):
+                    key = "conv_wgrad_bf3"
+                if key == "conv_igemm_hp" and name.rstrip().split("(")[0].endswith(", 3>"):
+                    key = "conv_igemm_bf3"
                 if key is None:
                     continue
                 a = per.setdefault(key, [0, 0.0])

@@ -439,3 +439,25 @@ def test_ranks_on_one_physical_gpu_are_refused_unless_asked_for():
         p.join(timeout=60)
     assert res[0][1] == res[1][1] == "raised", res
     assert res[0][2] == res[1][2] and not res[0][2].startswith("logical:"), res        # the same PHYSICAL identity (uuid / PCI address) on both ranks
+
+
+# ---- bench.py's forced data-parallel line (world of one): the RCCL communicator counts its ranks itself, and the exchange costs nothing measurable --
+def test_bench_forced_data_parallel_line_counts_its_ranks_and_prices_the_exchange():
+    """`bench.py --force-dist` (what the N > 1 launches run, in a world of one): transport rccl, ncclCommCount == 1 (bench.py exits non-zero when the
+    communicator's own count differs from the ranks it was launched with), the bucket all-reduces inside the recorded plan, and
+    `exposed_communication` -- the same step with and without its all-reduces, alternating blocks in one process -- within 5 % of the step."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    for k in ("FP_DP_TRANSPORT", "FP_DP_FORCE", "WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--steps", "10", "--warmup", "5", "--sustain", "0",
+                        "--no-cpu-baseline", "--no-loader", "--no-other-format", "--no-kernel-events"], cwd=ROOT, env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, (r.stderr or r.stdout)[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    gx = d["config"]["gradient_exchange"]
+    assert d["rccl_ranks"] == 1 and gx["transport"] == "rccl" and gx["in_launch_plan"] and gx["buckets"] >= 7
+    ex = gx["exposed_communication"]
+    assert abs(ex["exposed_ms"]) <= 0.05 * ex["step_ms_without_exchange"], ex
