@@ -449,6 +449,7 @@ def test_bench_forced_data_parallel_line_counts_its_ranks_and_prices_the_exchang
     import json
     import subprocess
     import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ)
     for k in ("FP_DP_TRANSPORT", "FP_DP_FORCE", "WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
