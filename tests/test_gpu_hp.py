@@ -375,17 +375,20 @@ def test_conv3x3_hp_data_gradient_emits_batchnorm_backward_sums(N, H, W, C, emit
     used = tiles * C * 2
     assert not bool(torch.isnan(part[:used]).any()) and bool(torch.isnan(part[used:]).all())
     sums = part[:used].view(tiles, C, 2).double().sum(0).cpu()
-    assert relerr(sums[:, 0], s1) < 2e-6 and relerr(sums[:, 1], s2) < 2e-6
+    # (six MFMA products per multiply-add instead of three: twice the accumulation steps into the fp32 accumulator, and the per-channel sum over
+    # ~1e5 pixels shows their common sign -- measured 2.2e-6 of the largest channel sum with the exact operands where the fp16 pairs sit at ~1e-6)
+    tol_s = 2e-6 if hp else 3e-6
+    assert relerr(sums[:, 0], s1) < tol_s and relerr(sums[:, 1], s2) < tol_s
     dz, dg, db = torch.empty((N, H, W, C), device="cuda"), torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
     sz = ops.new_slot()
     ops.bn_bwd_partials(gout.view(-1, C), zs.view(-1, C), mean_d, invstd_d, gamma.cuda(), dz.view(-1, C), dg, db, part, tiles, amax_out=sz)
     check(nchw(dz), dz64, "bn backward from the epilogue's sums", 3e-6)
     check(nchw(dz_ref), dz64, "bn backward, own reduction", 3e-6)
-    assert relerr(dg, s2) < 2e-6 and relerr(db, s1) < 2e-6 and relerr(dg_ref, s2) < 2e-6 and relerr(db_ref, s1) < 2e-6
+    assert relerr(dg, s2) < tol_s and relerr(db, s1) < tol_s and relerr(dg_ref, s2) < tol_s and relerr(db_ref, s1) < tol_s
     assert ops.amax_value(sz) == float(dz.abs().max())
     dg2, db2 = dg.clone(), db.clone()                               # accumulate = True adds on top
     ops.bn_bwd_partials(gout.view(-1, C), zs.view(-1, C), mean_d, invstd_d, gamma.cuda(), dz.view(-1, C), dg2, db2, part, tiles, accumulate=True)
-    assert relerr(dg2, 2 * s2) < 2e-6 and relerr(db2, 2 * s1) < 2e-6
+    assert relerr(dg2, 2 * s2) < tol_s and relerr(db2, 2 * s1) < tol_s
 
 
 @pytest.mark.parametrize("N,h,w,C0,C1,Cout", [(12, 6, 20, 256, 256, 256), (8, 24, 32, 32, 16, 32), (16, 16, 32, 32, 0, 64), (12, 4, 24, 64, 64, 96)])
