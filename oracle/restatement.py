@@ -141,11 +141,26 @@ def _bn(x, P, B, prefix, training, momentum=0.1, eps=1e-5):
 
 
 class ReluDecisions:
-    """impose: list of boolean masks consumed in call order (None: the network decides itself); taken: the masks actually used"""
+    """The encoder's discrete decisions.  impose: list of boolean ReLU masks consumed in call order (None: the network decides itself);
+    taken: the masks actually used; pool_impose (optional, int64 [N, C, OH, OW]): the 3x3 / stride 2 max-pool's winning window position
+    ky * 3 + kx per output element (two window elements within round-off of each other are the same kind of decision as a ReLU at zero)."""
 
-    def __init__(self, impose=None):
+    def __init__(self, impose=None, pool_impose=None):
         self.impose = None if impose is None else iter(impose)
+        self.pool_impose = pool_impose
         self.taken = []
+
+
+def _maxpool(x, decisions):
+    """encoder.maxpool (network.py:41: MaxPool2d(3, 2, 1)), or -- decisions.pool_impose given -- the same gather with imposed winners"""
+    if decisions is None or decisions.pool_impose is None:
+        return F.max_pool2d(x, 3, 2, 1)
+    N, C, H, W = x.shape
+    OH, OW = (H + 1) // 2, (W + 1) // 2
+    idx = decisions.pool_impose
+    assert tuple(idx.shape) == (N, C, OH, OW), (tuple(idx.shape), (N, C, OH, OW))
+    patches = F.unfold(F.pad(x, (1, 1, 1, 1)), 3, stride=2).view(N, C, 9, OH, OW)      # padded positions are never imposed winners
+    return patches.gather(2, idx.unsqueeze(2).to(torch.int64)).squeeze(2)
 
 
 def _relu(x, decisions):
@@ -190,7 +205,7 @@ def resnet_encoder(image, P, B, training, record=None, relu_decisions=None):
     bi = 0
     for li, nblk in enumerate(RESNET34_BLOCKS, start=1):
         if li == 1:
-            x = F.max_pool2d(x, 3, 2, 1)                                  # encoder.maxpool (network.py:41)
+            x = _maxpool(x, decisions)                                    # encoder.maxpool (network.py:41)
         for _ in range(nblk):
             prefix, cin, cout, stride, ds = blocks[bi]
             x = _basic_block(x, P, B, prefix, stride, ds, training, decisions)

@@ -7,8 +7,9 @@ imported, so the format the test session itself runs in executes in-process and 
     out        {scale: [B,4,H,W]}            the network outputs (network.py:26-30)
     losses     {key: float}                  the 21 scalars of LossManager (training/losses.py:31-92)
     grads      {name: tensor | None}         d loss / d parameter
-    decisions  [33 bool NCHW masks]          the engine's ReLU decisions: stem, then (bn1's ReLU, block output) per BasicBlock -- what
-                                             tests/parity.py imposes on the float64 oracle to separate decisions from arithmetic
+    decisions  {"relu": [33 bool NCHW masks], the engine's discrete decisions: ReLU masks (stem, then (bn1's ReLU, block output) per BasicBlock) and the
+                "pool": int64 [N,64,OH,OW]}  max-pool's winning window positions -- what tests/parity.py imposes on the float64 oracle to separate
+                                             decisions from arithmetic
     state      {key: tensor}                 state_dict after the step (BatchNorm running statistics)
     taps       {name: tensor}                (tap_block = i) g / d out / z2 / out of encoder block i, see test_gpu_parity_fullsize.py
     format     str                           what the engine that ran really used
@@ -49,6 +50,10 @@ def _step_here(P, B, cpu_batch, tap_block=None):
     decisions = [_nchw_mask(S["feats"][0])]
     for Bk in S["blocks"]:
         decisions += [_nchw_mask(Bk["a1"]), _nchw_mask(Bk["out"])]
+    f0 = S["feats"][0]
+    hp, wp = (f0.shape[1] + 1) // 2, (f0.shape[2] + 1) // 2
+    am = eng._bufs["pool.argmax"][:f0.shape[0] * hp * wp * 64].view(f0.shape[0], hp, wp, 64)          # uint8 ky * 3 + kx (csrc/bn_pool.hip maxpool_fwd_kernel)
+    decisions = {"relu": decisions, "pool": am.permute(0, 3, 1, 2).contiguous().cpu().to(torch.int64)}
     losses = LossManager((0.1, 100), 0.25, compute_viz=False)(out, batch)
     losses["loss"].backward()
     torch.cuda.synchronize()

@@ -147,19 +147,22 @@ def decision_forced_report(P, B, cpu_batch, decisions, gpu, cpu32, ref64, spread
     side of its ReLU depending on the summation order of whoever computes it, and a flipped element moves a whole BatchNorm channel's
     gradient sums (profiles/round4_notes.md section 8: ONE element of 737 280 moved `encoder.layer4.2.bn2.weight` by 1e-4) -- the single-run
     rule of anchored_report then compares one draw of that lottery (the engine's) with another (the CPU fp32 run's).  Here the float64
-    oracle is evaluated once more with the ENGINE's own ReLU decisions imposed (oracle/restatement.py `_relu`; forward values are
+    oracle is evaluated once more with the ENGINE's own ReLU decisions -- and its max-pool winners: two window elements within round-off of
+    each other are the same kind of decision, and they reach the stem's weight gradient -- imposed (oracle/restatement.py `_relu`, `_maxpool`; forward values are
     unchanged to ~1e-7, a flipped element being ~0 on either side; the backward pass follows the engine's masks).  Against THAT truth the
     engine's gradients carry arithmetic error only, and every tensor has to pass the same bound as before: a tensor that fails the
     single-run rule but passes here differs from float64 by decisions at round-off distance from zero, which no fp32 implementation
     determines; one that fails here too is a defect.  Returns (failures, rows, grads of the forced oracle)."""
     from oracle.restatement import ReluDecisions
-    g64f = oracle_grads(P, B, cpu_batch, torch.float64, relu_decisions=ReluDecisions(impose=decisions))[2]
+    imposed = ReluDecisions(impose=decisions["relu"], pool_impose=decisions.get("pool")) if isinstance(decisions, dict) else ReluDecisions(impose=decisions)
+    g64f = oracle_grads(P, B, cpu_batch, torch.float64, relu_decisions=imposed)[2]
     bad, rows = anchored_report(gpu, cpu32, g64f, spread=spread, cpu_ref64=ref64)
     return bad, rows, g64f
 
 
 def count_decision_flips(decisions, decisions_ref):
     """number of ReLU decisions that differ between two runs, total number"""
+    decisions = decisions["relu"] if isinstance(decisions, dict) else decisions
     flips = sum(int((a != b).sum()) for a, b in zip(decisions, decisions_ref))
     return flips, sum(a.numel() for a in decisions)
 
