@@ -46,6 +46,9 @@ constexpr int CH = 4, CW = 16, HR = CH + 2;
 #ifndef FP_WGRAD_PF_DEFAULT
 #define FP_WGRAD_PF_DEFAULT 2
 #endif
+#ifndef FP_W3_INTERLEAVE
+#define FP_W3_INTERLEAVE 0          // 1: the exact ring kernel stages the next chunk between its MFMAs (round 5 experiment, see the kernel)
+#endif
 
 
 __device__ __forceinline__ void split_store(unsigned char* p, int plane_stride, const f32x4 v) {
@@ -491,6 +494,37 @@ __global__ void __launch_bounds__(256, D > 2 ? 1 : 2) wgrad3x3_hp_pf_kernel(cons
       // gfx950 (scripts/ubench/mfma_bf16_chain.hip), and keeping one tap's planes live instead of a row's 36 registers is what lets the
       // ring's two register slots fit beside 144 accumulator registers
       constexpr int PA3[6] = {2, 0, 1, 1, 0, 0}, PB3[6] = {0, 2, 1, 0, 1, 0};
+#if FP_W3_INTERLEAVE
+      // The staging of the NEXT chunk (slot `slot_`, into the other LDS buffer) in the shadow of this chunk's MFMAs: a wave issues in order,
+      // so VALU work placed BEHIND the 54 MFMAs runs after them (one wave per SIMD: nothing else fills the matrix pipe's shadow).  The split
+      // of the six staged float4 is cut into 18 parts (per item: h + store + residual; m + store + residual; l + store) and one part follows
+      // every three MFMAs, pinned by scheduling fences -- the compiler's own pipeline solver gives up on this region (round 3, and again
+      // with (MFMA 1, VALU 3) x 54 in round 5: every MFMA first, every VALU behind).  Same values, same stores, same sums.
+      constexpr int sl_ = decltype(slot_)::value;
+      unsigned char* const sbase = lds + ((k + 1) & 1) * BUF4;
+      const float live_ = k + 1 < cnt ? bias_on : 0.f;
+      f32x4 sres = {0.f, 0.f, 0.f, 0.f};
+      auto stage_part = [&](int i) {                  // i = 3 * item + phase; items 0..3 = X, 4..5 = dZ
+        const int j = i / 3, ph = i % 3;
+        unsigned char* dst = j < 4 ? sbase + (t + 256 * j) * 8 : sbase + XBN + (t + 256 * (j - 4)) * 8;
+        const int pstride = j < 4 ? XP4 : ZP3;
+        if (ph == 0) {
+          const float4 q4 = j < 4 ? xr[sl_][j < 4 ? j : 0] : zv[sl_][j >= 4 ? j - 4 : 0];
+          if (j >= 4) { bs[0] = fmaf(q4.x, live_, bs[0]); bs[1] = fmaf(q4.y, live_, bs[1]); bs[2] = fmaf(q4.z, live_, bs[2]); bs[3] = fmaf(q4.w, live_, bs[3]); }
+          const f32x4 v = {q4.x, q4.y, q4.z, q4.w};
+          const bf16x4 vh = __builtin_convertvector(v, bf16x4);
+          *reinterpret_cast<uint2*>(dst) = __builtin_bit_cast(uint2, vh);
+          sres = v - __builtin_convertvector(vh, f32x4);
+        } else if (ph == 1) {
+          const bf16x4 vm = __builtin_convertvector(sres, bf16x4);
+          *reinterpret_cast<uint2*>(dst + pstride) = __builtin_bit_cast(uint2, vm);
+          sres = sres - __builtin_convertvector(vm, f32x4);
+        } else {
+          const bf16x4 vl = __builtin_convertvector(sres, bf16x4);
+          *reinterpret_cast<uint2*>(dst + 2 * pstride) = __builtin_bit_cast(uint2, vl);
+        }
+      };
+#endif
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -503,10 +537,27 @@ __global__ void __launch_bounds__(256, D > 2 ? 1 : 2) wgrad3x3_hp_pf_kernel(cons
             a3[p] = make_uint4(lo.x, lo.y, hi.x, hi.y);
           }
 #pragma unroll
-          for (int qq = 0; qq < 6; ++qq)
+          for (int qq = 0; qq < 6; ++qq) {
             acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a3[PA3[qq]]), __builtin_bit_cast(bf16x8, bz[PB3[qq]]),
                                                                        acc[ky * 3 + kx], 0, 0, 0);
+#if FP_W3_INTERLEAVE
+            {                                        // a part behind every FP_W3_INTERLEAVE-th MFMA (3: evenly over the 54; 2: over the first 36)
+              constexpr int every = FP_W3_INTERLEAVE == 1 ? 3 : FP_W3_INTERLEAVE;
+              const int done = (ky * 3 + kx) * 6 + qq + 1;
+              if (done % every == 0 && done / every <= 18) {
+                stage_part(done / every - 1);
+                __builtin_amdgcn_sched_barrier(0);
+              }
+            }
+#endif
+          }
         }
+#if FP_W3_INTERLEAVE
+      __builtin_amdgcn_sched_barrier(0);
+      issue(slot_);
+      __syncthreads();
+      return;
+#endif
     } else {
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
