@@ -254,7 +254,8 @@ GROUPS = {
     "conv_up2_phase_fwd_bf3": dict(kernel="up2_phase_fwd_bf3_kernel", bf16x3=True),
     "conv_up2_phase_fwd": dict(kernel="up2_phase_fwd_kernel", bf16x3=False),
     "conv_up2_phase_dgrad_bf3": dict(kernel="up2_phase_dgrad_bf3_kernel", bf16x3=True),
-    "conv_wgrad_bf3": dict(kernel="wgrad3x3_bf3_v3_kernel (+ wgrad_reduce_bias[_t]_kernel of the same entry point)", bf16x3=True),
+    "conv_wgrad_bf3": dict(kernel="wgrad3x3_hp_pf_kernel<MODE, 2, 3> (exact bf16x3 operands on the prefetch ring; nearest-x2 gather form: wgrad3x3_bf3_v3_kernel; "
+                                  "+ wgrad_reduce_bias[_t]_kernel of the same entry point)", bf16x3=True),
     "conv_up2_phase_wgrad_bf3": dict(kernel="wgrad_up2_phase_bf3_kernel (+ its sum / un-collapse / bias reduce launches)", bf16x3=True),
     "conv_up2_phase_wgrad": dict(kernel="wgrad_up2_phase_kernel", bf16x3=False),
     "conv_wgrad": dict(kernel="wgrad_kernel / wgrad3x3_tile_kernel (fp32 MFMA: stem, stride 2, 1x1, shapes the bf16x3 kernel rejects)", bf16x3=False),
@@ -262,7 +263,7 @@ GROUPS = {
 # main kernel symbol(s) of each entry point (the name before the template arguments, as fp_ktime_row / rocprofv3 print it)
 GROUP_SYMBOL = {
     "conv3x3_hp": ("conv3x3_tile_bf3_kernel",), "conv3x3_bf3": ("conv3x3_tile_bf3_kernel",),
-    "conv_wgrad_hp": ("wgrad3x3_hp_pf_kernel", "wgrad3x3_bf3_v3_kernel"), "conv_wgrad_bf3": ("wgrad3x3_bf3_v3_kernel",),
+    "conv_wgrad_hp": ("wgrad3x3_hp_pf_kernel", "wgrad3x3_bf3_v3_kernel"), "conv_wgrad_bf3": ("wgrad3x3_hp_pf_kernel", "wgrad3x3_bf3_v3_kernel"),
     "conv_up2_phase_fwd_hp": ("up2_phase_fwd_bf3_kernel",), "conv_up2_phase_fwd_bf3": ("up2_phase_fwd_bf3_kernel",),
     "conv_up2_phase_dgrad_hp": ("up2_phase_dgrad_bf3_kernel",), "conv_up2_phase_dgrad_bf3": ("up2_phase_dgrad_bf3_kernel",),
     "conv_up2_phase_wgrad_hp": ("wgrad_up2_phase_bf3_kernel",), "conv_up2_phase_wgrad_bf3": ("wgrad_up2_phase_bf3_kernel",),

@@ -461,23 +461,26 @@ __global__ void __launch_bounds__(256) igemm_hp_kernel(const IgemmArgs a) {
     const float4 a0 = aok[set][0] ? ar[set][0] : make_float4(0.f, 0.f, 0.f, 0.f), a1 = aok[set][1] ? ar[set][1] : make_float4(0.f, 0.f, 0.f, 0.f);
     if constexpr (NP == 3) {
       // exact split of the lane's eight channels: h = bf16(x), m = bf16(x - h), l = bf16(x - h - m); each difference is exact in fp32
-      typedef float ig_f32x4 __attribute__((ext_vector_type(4)));
-      typedef __bf16 ig_bf16x4 __attribute__((ext_vector_type(4)));
+      typedef float ig_f32x2 __attribute__((ext_vector_type(2)));
+      typedef __bf16 ig_bf16x2 __attribute__((ext_vector_type(2)));
       typedef __bf16 ig_bf16x8 __attribute__((ext_vector_type(8)));
+      // two elements per conversion (v_cvt_pk_bf16_f32, round to nearest even); float(term) back by a shift / a mask of the packed pair
+      float e[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+      unsigned pk[3][4];
+#pragma unroll
+      for (int lv = 0; lv < 3; ++lv)
+#pragma unroll
+        for (int q2 = 0; q2 < 4; ++q2) {
+          const unsigned u = __builtin_bit_cast(unsigned, __builtin_convertvector(ig_f32x2{e[2 * q2], e[2 * q2 + 1]}, ig_bf16x2));
+          pk[lv][q2] = u;
+          if (lv < 2) {
+            e[2 * q2] -= __builtin_bit_cast(float, u << 16);
+            e[2 * q2 + 1] -= __builtin_bit_cast(float, u & 0xffff0000u);
+          }
+        }
       uint2 pl[3][2];
 #pragma unroll
-      for (int q2 = 0; q2 < 2; ++q2) {
-        const float4 af = q2 ? a1 : a0;
-        const ig_f32x4 v = {af.x, af.y, af.z, af.w};
-        const ig_bf16x4 vh = __builtin_convertvector(v, ig_bf16x4);
-        const ig_f32x4 r1 = v - __builtin_convertvector(vh, ig_f32x4);
-        const ig_bf16x4 vm = __builtin_convertvector(r1, ig_bf16x4);
-        const ig_f32x4 r2 = r1 - __builtin_convertvector(vm, ig_f32x4);
-        const ig_bf16x4 vl = __builtin_convertvector(r2, ig_bf16x4);
-        pl[0][q2] = __builtin_bit_cast(uint2, vh);
-        pl[1][q2] = __builtin_bit_cast(uint2, vm);
-        pl[2][q2] = __builtin_bit_cast(uint2, vl);
-      }
+      for (int lv = 0; lv < 3; ++lv) { pl[lv][0] = make_uint2(pk[lv][0], pk[lv][1]); pl[lv][1] = make_uint2(pk[lv][2], pk[lv][3]); }
       ig_bf16x8 va[3];
 #pragma unroll
       for (int p = 0; p < 3; ++p) va[p] = __builtin_bit_cast(ig_bf16x8, make_uint4(pl[p][0].x, pl[p][0].y, pl[p][1].x, pl[p][1].y));

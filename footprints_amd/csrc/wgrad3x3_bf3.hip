@@ -47,19 +47,33 @@ constexpr int CH = 4, CW = 16, HR = CH + 2;
 #define FP_WGRAD_PF_DEFAULT 2
 #endif
 #ifndef FP_W3_INTERLEAVE
-#define FP_W3_INTERLEAVE 0          // 1: the exact ring kernel stages the next chunk between its MFMAs (round 5 experiment, see the kernel)
+#define FP_W3_INTERLEAVE 1          // 1 (default since round 5): the ring kernels stage the next chunk BETWEEN their MFMAs (see the kernel); 0: behind them
 #endif
 
 
-__device__ __forceinline__ void split_store(unsigned char* p, int plane_stride, const f32x4 v) {
-  const bf16x4 vh = __builtin_convertvector(v, bf16x4);
-  const f32x4 r1 = v - __builtin_convertvector(vh, f32x4);
-  const bf16x4 vm = __builtin_convertvector(r1, bf16x4);
-  const f32x4 r2 = r1 - __builtin_convertvector(vm, f32x4);
-  const bf16x4 vl = __builtin_convertvector(r2, bf16x4);
-  *reinterpret_cast<uint2*>(p) = __builtin_bit_cast(uint2, vh);
-  *reinterpret_cast<uint2*>(p + plane_stride) = __builtin_bit_cast(uint2, vm);
-  *reinterpret_cast<uint2*>(p + 2 * plane_stride) = __builtin_bit_cast(uint2, vl);
+// One level of the exact split of a float4, two elements per conversion: q = bf16 pair (the stored form: v_cvt_pk_bf16_f32, round to nearest even),
+// r = v - float(q) (exact).  The generic vector conversion made the compiler convert every element twice (once alone with a zero partner to
+// rebuild float(h) by a shift, once in pairs for the store): 30 VALU instructions per float4 and plane pair instead of 22.
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint2 split_level(f32x4& v) {
+  const unsigned lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v.x, v.y}, bf16x2));
+  const unsigned hi = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v.z, v.w}, bf16x2));
+  v.x -= __builtin_bit_cast(float, lo << 16);
+  v.y -= __builtin_bit_cast(float, lo & 0xffff0000u);
+  v.z -= __builtin_bit_cast(float, hi << 16);
+  v.w -= __builtin_bit_cast(float, hi & 0xffff0000u);
+  return make_uint2(lo, hi);
+}
+__device__ __forceinline__ uint2 split_last(const f32x4 v) {
+  return make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v.x, v.y}, bf16x2)),
+                    __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v.z, v.w}, bf16x2)));
+}
+
+__device__ __forceinline__ void split_store(unsigned char* p, int plane_stride, f32x4 v) {
+  *reinterpret_cast<uint2*>(p) = split_level(v);
+  *reinterpret_cast<uint2*>(p + plane_stride) = split_level(v);
+  *reinterpret_cast<uint2*>(p + 2 * plane_stride) = split_last(v);
 }
 
 // (The first generation -- bf16 planes transposed at staging time, funnel shifts for the kx taps -- was kept behind FP_WGRAD_BF3_V=1 through round 3
@@ -511,17 +525,12 @@ __global__ void __launch_bounds__(256, D > 2 ? 1 : 2) wgrad3x3_hp_pf_kernel(cons
         if (ph == 0) {
           const float4 q4 = j < 4 ? xr[sl_][j < 4 ? j : 0] : zv[sl_][j >= 4 ? j - 4 : 0];
           if (j >= 4) { bs[0] = fmaf(q4.x, live_, bs[0]); bs[1] = fmaf(q4.y, live_, bs[1]); bs[2] = fmaf(q4.z, live_, bs[2]); bs[3] = fmaf(q4.w, live_, bs[3]); }
-          const f32x4 v = {q4.x, q4.y, q4.z, q4.w};
-          const bf16x4 vh = __builtin_convertvector(v, bf16x4);
-          *reinterpret_cast<uint2*>(dst) = __builtin_bit_cast(uint2, vh);
-          sres = v - __builtin_convertvector(vh, f32x4);
+          sres = f32x4{q4.x, q4.y, q4.z, q4.w};
+          *reinterpret_cast<uint2*>(dst) = split_level(sres);
         } else if (ph == 1) {
-          const bf16x4 vm = __builtin_convertvector(sres, bf16x4);
-          *reinterpret_cast<uint2*>(dst + pstride) = __builtin_bit_cast(uint2, vm);
-          sres = sres - __builtin_convertvector(vm, f32x4);
+          *reinterpret_cast<uint2*>(dst + pstride) = split_level(sres);
         } else {
-          const bf16x4 vl = __builtin_convertvector(sres, bf16x4);
-          *reinterpret_cast<uint2*>(dst + 2 * pstride) = __builtin_bit_cast(uint2, vl);
+          *reinterpret_cast<uint2*>(dst + 2 * pstride) = split_last(sres);
         }
       };
 #endif
@@ -542,19 +551,29 @@ __global__ void __launch_bounds__(256, D > 2 ? 1 : 2) wgrad3x3_hp_pf_kernel(cons
                                                                        acc[ky * 3 + kx], 0, 0, 0);
 #if FP_W3_INTERLEAVE
             {                                        // a part behind every FP_W3_INTERLEAVE-th MFMA (3: evenly over the 54; 2: over the first 36)
-              constexpr int every = FP_W3_INTERLEAVE == 1 ? 3 : FP_W3_INTERLEAVE;
+              constexpr int every = FP_W3_INTERLEAVE == 1 ? 3 : (FP_W3_INTERLEAVE == 4 ? 2 : FP_W3_INTERLEAVE);
               const int done = (ky * 3 + kx) * 6 + qq + 1;
               if (done % every == 0 && done / every <= 18) {
                 stage_part(done / every - 1);
                 __builtin_amdgcn_sched_barrier(0);
               }
+#if FP_W3_INTERLEAVE == 4
+              // variant: parts behind every second MFMA (all staged after 36), then the NEXT-next chunk's address math and loads (issue())
+              // behind MFMA 38 -- in the shadow of the last 16 MFMAs instead of behind them; border chunks' ~300 VALU of reflection / clamp math too
+              if (done == 38) {
+                issue(slot_);
+                __builtin_amdgcn_sched_barrier(0);
+              }
+#endif
             }
 #endif
           }
         }
 #if FP_W3_INTERLEAVE
       __builtin_amdgcn_sched_barrier(0);
+#if FP_W3_INTERLEAVE != 4
       issue(slot_);
+#endif
       __syncthreads();
       return;
 #endif
@@ -574,10 +593,39 @@ __global__ void __launch_bounds__(256, D > 2 ? 1 : 2) wgrad3x3_hp_pf_kernel(cons
 #pragma unroll
       for (int qq = 4 - FP_HP_PRODUCTS; qq < 4; ++qq)
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx)
+        for (int kx = 0; kx < 3; ++kx) {
           acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[kx][PA[qq]]), __builtin_bit_cast(f16x8, bz[PB[qq]]),
                                                                     acc[ky * 3 + kx], 0, 0, 0);
+#if FP_W3_INTERLEAVE
+          {                                          // fp16 pairs: one staged float4 (split + two stores) behind every fourth of the 9 x FP_HP_PRODUCTS MFMAs
+            constexpr int sl2 = decltype(slot_)::value;
+            const int done = (ky * FP_HP_PRODUCTS + (qq - (4 - FP_HP_PRODUCTS))) * 3 + kx + 1;
+            if (done % 4 == 0 && done / 4 <= 6) {
+              const int j = done / 4 - 1;
+              unsigned char* const sb2 = lds + ((k + 1) & 1) * BUF4;
+              const float live2 = k + 1 < cnt ? bias_on : 0.f;
+              if (j < 4) {
+                const float4 q4 = xr[sl2][j < 4 ? j : 0];
+                split_store_np<2>(sb2 + (t + 256 * j) * 8, XP4, f32x4{q4.x, q4.y, q4.z, q4.w}, kx_);
+              } else {
+                const float4 q4 = zv[sl2][j >= 4 ? j - 4 : 0];
+                bs[0] = fmaf(q4.x, live2, bs[0]); bs[1] = fmaf(q4.y, live2, bs[1]); bs[2] = fmaf(q4.z, live2, bs[2]); bs[3] = fmaf(q4.w, live2, bs[3]);
+                split_store_np<2>(sb2 + XBN + (t + 256 * (j - 4)) * 8, ZP3, f32x4{q4.x, q4.y, q4.z, q4.w}, kz_);
+              }
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+#endif
+        }
     }
+#if FP_W3_INTERLEAVE
+    if (FP_HP_PRODUCTS * 9 >= 24) {                  // all six items were staged between the MFMAs
+      __builtin_amdgcn_sched_barrier(0);
+      issue(slot_);
+      __syncthreads();
+      return;
+    }
+#endif
     }
     // nothing of the staging moves up among the MFMAs: its first instruction waits for the slot's loads, and every MFMA issued
     // before that wait is time the loads have to land (D chunk periods instead of D - 1)
