@@ -140,16 +140,10 @@ __device__ __forceinline__ void fp_tile_pixel(int pt, int& py, int& px) {
 // (3) Tried and removed (profiles/round4_notes.md): 16 x 16 pixel tiles with 64 x 64 per-wave register tiles (half the LDS reads and weight
 // loads per MFMA, two workgroups per CU): 64 -> 64 @ 96 x 320 124.6 us against 95.9 with 8 x 16 tiles and four workgroups per CU.
 struct TileGeo { int split, tile_n, tile_x, tile_y, n_img, y0, x0, n0; };
-// (FP_TILE_PERSIST_BUILD: 1 = the fp16-pair instantiations, 2 = the exact bf16x3 ones -- those run three workgroups per CU anyway (52 KB of LDS
-// each), so the registers the resident loop needs cost them no occupancy; their 64-channel data-gradient forms would spill 12-36 bytes under the
-// 168-register budget of three waves per SIMD and stay one tile per workgroup)
-constexpr bool fp_tile_persistent(int tw, bool wpf, bool hp, bool flip = false, int bn = 64) {
-  return !wpf && tw == 16 && ((FP_TILE_PERSIST_BUILD == 1 && hp) || (FP_TILE_PERSIST_BUILD == 2 && !hp && (!flip || bn == 32)));
-}
+constexpr bool fp_tile_persistent(int tw, bool wpf, bool hp) { return FP_TILE_PERSIST_BUILD != 0 && !wpf && hp && tw == 16; }
 
 template <int TH, int TW, int BN, int WM, int WN, bool FLIP, bool FOLD, int NP = 3, bool HP = false, bool WPF = false>
-__global__ void __launch_bounds__(256, WPF ? 1 : (TH * TW > 128 ? 2 : (HP ? (FOLD ? FP_TILE_HP_FOLD_WAVES : FP_TILE_HP_WAVES)
-                                                                           : (fp_tile_persistent(TW, WPF, HP, FLIP, BN) ? 3 : 1))))
+__global__ void __launch_bounds__(256, WPF ? 1 : (TH * TW > 128 ? 2 : (HP ? (FOLD ? FP_TILE_HP_FOLD_WAVES : FP_TILE_HP_WAVES) : 1)))
 conv3x3_tile_bf3_kernel(const Tile3Args a) {
   static_assert(!HP || NP == 2, "the fp16-pair format has two planes");
   constexpr int WPL = HP ? 2 : 3;                    // planes per weight slice in the packed buffer
@@ -160,7 +154,7 @@ conv3x3_tile_bf3_kernel(const Tile3Args a) {
   constexpr int PLANE = HPX * PIXB;                   // bytes per plane
   constexpr int BUF = NP * PLANE;                    // bytes per halo buffer
   constexpr int NPIX = TH * TW;                      // valid rows of the M tile
-  constexpr bool PERSIST = fp_tile_persistent(TW, WPF, HP, FLIP, BN);   // (the WPF grids are at most 400 workgroups, the 6 x 20 levels at most 768: one tile per workgroup)
+  constexpr bool PERSIST = fp_tile_persistent(TW, WPF, HP);   // (the WPF grids are at most 400 workgroups, the 6 x 20 levels at most 768: one tile per workgroup)
   constexpr unsigned OOB = 0x80000000u;              // buffer offset of a load that must return zeros
   static_assert(WM * WN == 4 && NPIX <= BM && TM >= 1 && TN >= 1, "tile shape");
   __shared__ __attribute__((aligned(16))) unsigned char lds[(2 * BUF + 1023) / 1024 * 1024];   // whole LDS allocation granules
@@ -752,7 +746,7 @@ int launch3(Tile3Args& a, hipStream_t stream) {
     if (persist > 1) resident = persist;             // experiments: an explicit workgroup budget
   }
   int grid = a.nwg;
-  if (persist && fp_tile_persistent(TW, WPF, HP, FLIP, BN) && a.nwg > resident) {
+  if (persist && fp_tile_persistent(TW, WPF, HP) && a.nwg > resident) {
     const int rounds = (a.nwg + resident - 1) / resident;
     grid = ((a.nwg + rounds - 1) / rounds + 7) & ~7;
     if (grid > a.nwg) grid = a.nwg;
