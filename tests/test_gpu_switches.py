@@ -83,3 +83,17 @@ def test_switch_reproduces_the_reference_run(env, ref, exact):
                 assert x == y, (env, step, x, y)
             else:
                 assert abs(x - y) <= 1e-4 * max(abs(y), 1e-3), (env, step, x, y)
+
+
+def test_network_and_trainer_suites_in_the_optin_format():
+    """the session itself runs in the default (exact) operand format; the network- and trainer-level tests once more in a child pytest with
+    FP_OPERANDS=fp16_pair, so that the driver's `pytest -m gpu` exercises the opt-in format end to end as well (golden vectors G2 / G3 / G5, drop-in
+    surface, TrainStep = drop-in path, launch plans, eval fast path; the full-size parity cases cover both formats themselves)"""
+    env = dict(os.environ)
+    for k in ("FP_OPERANDS", "FP_HP"):
+        env.pop(k, None)
+    env.update(PAIR)
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_network.py", "tests/test_gpu_trainer.py", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, (r.stdout or "")[-3000:] + (r.stderr or "")[-1000:]
+    assert " passed" in r.stdout, r.stdout[-500:]
