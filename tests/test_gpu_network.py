@@ -42,6 +42,34 @@ def nchw(t):
     return t.permute(0, 3, 1, 2).contiguous().cpu()
 
 
+def _g2_diagnose(eng, dec, S, D, P, decname, sig, feats_nchw):
+    """failure diagnostics of test_g2: every saved activation of the engine's decoder forward against the oracle's block functions on the CPU,
+    and the same forward once more in this process (a transient first-touch problem shows as a correct second pass)"""
+    import torch.nn.functional as F
+    from oracle import restatement as R
+    Pd = {k: v.detach() for k, v in P.items()}
+    x = feats_nchw[4]
+    print("\n[g2 diagnose] decoder %s" % decname)
+    for bi in range(4):
+        pre, post = "%s.block%d.pre_concat_conv" % (decname, bi + 1), "%s.block%d.post_concat_conv" % (decname, bi + 1)
+        r1 = F.elu(F.conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect"), Pd[pre + ".conv1.weight"], Pd[pre + ".conv1.bias"]))
+        r2 = F.elu(F.conv2d(F.pad(r1, (1, 1, 1, 1), mode="reflect"), Pd[pre + ".conv2.weight"], Pd[pre + ".conv2.bias"]))
+        cat = torch.cat([F.interpolate(r2, scale_factor=2, mode="nearest"), feats_nchw[3 - bi]], 1)
+        r3 = F.elu(F.conv2d(F.pad(cat, (1, 1, 1, 1), mode="reflect"), Pd[post + ".conv1.weight"], Pd[post + ".conv1.bias"]))
+        r4 = F.elu(F.conv2d(F.pad(r3, (1, 1, 1, 1), mode="reflect"), Pd[post + ".conv2.weight"], Pd[post + ".conv2.bias"]))
+        y1, y2, y3 = D["y"][bi]
+        errs = [relerr(nchw(a), b) for a, b in ((y1, r1), (y2, r2), (y3, r3), (D["x"][bi], r4))]
+        print("  block%d: pre1 %.2e pre2 %.2e post1 %.2e post2 %.2e  nan: %s" % (bi + 1, *errs, [bool(torch.isnan(t).any()) for t in (y1, y2, y3, D["x"][bi])]))
+        x = r4
+    outs2 = [torch.zeros((2, 4, 64, 96), device="cuda") for _ in range(4)]
+    D2 = {}
+    for _ in eng._decoder_forward(dec, S, outs2, D2):
+        pass
+    print("  second pass in the same process: y1 of block1 equal to the first pass: %s; max |diff| of the four outputs vs first pass: see below" %
+          bool(torch.equal(D2["y"][0][0], D["y"][0][0])))
+    print("  lazily packed fp32 layouts: used %d, fresh %d" % (len(eng._w32_used), len(eng._w32_fresh)))
+
+
 # ----------------------------------------------------------------------------------------------------------
 def test_g2_decoder_golden_through_engine():
     """SkipDecoder fwd + bwd (reference-authored golden vectors, real channel counts, 64x96 pyramid)."""
@@ -68,8 +96,12 @@ def test_g2_decoder_golden_through_engine():
         for _ in eng._decoder_forward(dec, S, outs, D):       # generators: sections are interleaved across streams in Engine.forward
             pass
         c0 = dec.c0
-        for k, o in zip(("1/8", "1/4", "1/2", "1/1"), outs):
-            compare(gold, tag + ".out" + k, o[:, c0:c0 + 2])
+        try:
+            for k, o in zip(("1/8", "1/4", "1/2", "1/1"), outs):
+                compare(gold, tag + ".out" + k, o[:, c0:c0 + 2])
+        except AssertionError:
+            _g2_diagnose(eng, dec, S, D, P, decname, sig, feats_nchw)      # prints where the forward left the oracle, then re-raises
+            raise
         gouts = []
         for k in ("1/8", "1/4", "1/2", "1/1"):
             g = torch.zeros((2, 4, 64, 96), device="cuda")
