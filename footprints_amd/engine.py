@@ -765,6 +765,12 @@ class Engine:
         key = t.data_ptr()
         if key in self._w32_fresh or key not in self._w32_lazy:
             return t
+        # (round 5, notes section 7) a first touch allocates small device tensors (the one-job table) and copies into them from pageable host
+        # memory between two convolution launches: drain the device FIRST, so that neither the allocator's recycled blocks nor the copies can
+        # meet kernels that are still in flight -- the driver's whole-suite command reproducibly corrupted one split-K convolution of
+        # tests/test_gpu_network.py::test_g2 (and only with lazy packing AND split-K on) until this was here
+        if _NEED32_SYNC and not torch.cuda.is_current_stream_capturing():
+            torch.cuda.synchronize(self.device)
         tab = self._w32_tables.get(key)
         if tab is None:
             tab = self._w32_tables[key] = ops.build_pack_table([self._w32_lazy[key]], self.device)

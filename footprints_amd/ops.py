@@ -110,6 +110,8 @@ def workspace(nbytes, device, tag="main"):
     key = (device.index, stream(), tag)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
+        if ws is not None and not torch.cuda.is_current_stream_capturing():
+            torch.cuda.synchronize(device)          # growth drops the old buffer: nothing may still be reading its partial sums (rare: start-up only)
         ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         _workspaces[key] = ws
         bump_alloc_generation()
