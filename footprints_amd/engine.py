@@ -59,7 +59,7 @@ _PHASE = not bool(int(os.environ.get("FP_NO_PHASE", "0")))
 _STREAM_LAYOUT = "0,1,2,2"
 _WGRAD_PAIR_FORK = bool(int(os.environ.get("FP_WGRAD_PAIR_FORK", "1")))   # one stream fork per residual block for its two weight gradients (0: one each)
 _HP_STEM = bool(int(os.environ.get("FP_HP_STEM", "1")))        # 0: the stem convolution on fp32 MFMA (rounds 1-3)
-_NEED32_SYNC = bool(int(os.environ.get("FP_NEED32_SYNC", "1")))   # a device-wide synchronize behind a first-touch pack of an fp32 layout (as in rounds 1-4), outside stream capture
+_NEED32_SYNC = bool(int(os.environ.get("FP_NEED32_SYNC", "1")))   # device-wide synchronizes around a first-touch pack of an fp32 layout, outside stream capture (Engine._need32)
 _LAZY32 = bool(int(os.environ.get("FP_PACK_LAZY32", "1")))     # 0: every fp32 packed layout is refreshed every step (rounds 1-3)
 _PACK_SIDE_WGS = int(os.environ.get("FP_PACK_SIDE_WGS", "0"))        # workgroups of the side-stream weight repack (0 = one per tile)
 _PACK_DGRAD_LATE = bool(int(os.environ.get("FP_PACK_DGRAD_LATE", "0")))   # 1: the data-gradient layouts are repacked under the decoders' forward instead of the encoder's
@@ -785,10 +785,8 @@ class Engine:
             if st.cuda_stream != cur:
                 ops.event_wait(st, ev)
         ops.bump_alloc_generation()
-        # ... and, wherever it is legal, still the device-wide synchronize of rounds 1-4 (a first touch happens a handful of times in a
-        # process's life, never in a steady-state step): one whole-suite run of round 5 without it produced a wrong decoder output in
-        # tests/test_gpu_network.py::test_g2... that three other whole-suite runs did not (profiles/round5_notes.md section 7); the event edges
-        # above are what a stream capture / a recording plan needs, the synchronize is what four rounds of green suites ran with
+        # ... and, wherever it is legal, still the device-wide synchronize of rounds 1-4 behind the pack (a first touch happens a handful of
+        # times in a process's life, never in a steady-state step); the event edges above are what a stream capture / a recording plan needs
         if _NEED32_SYNC and not torch.cuda.is_current_stream_capturing():
             torch.cuda.synchronize(self.device)
         self._w32_fresh.add(key)
