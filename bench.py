@@ -954,9 +954,9 @@ def main():
                                       "launch stream right around the kernel launch (fp_ktime_*: the per-kernel figure of rocprofv3 "
                                       "--kernel-trace --stats, see `kernels`)" % xsteps,
                                "reading": "frac prices EXECUTED MFMA FLOPs against the nominal dense peak, so it falls whenever products are removed "
-                                          "from the split (exact bf16x3: 6 per multiply-add, frac 0.33 at 136 fp32-equivalent TFLOP/s; scaled fp16 pairs: "
-                                          "3, frac 0.20 at 163): compare fp32_equiv_tflops across operand formats; the chip sustains ~1.7 of its 2.4 GHz "
-                                          "under these kernels (profiles/round2_notes.md), i.e. 0.7 of the nominal peak is attainable",
+                                          "from the split (exact bf16x3: 6 per multiply-add, frac 0.34 at 115 fp32-equivalent TFLOP/s; scaled fp16 pairs: "
+                                          "3, frac 0.24 at 150): compare fp32_equiv_tflops across operand formats; over a whole step the chip sustains ~1.9 of "
+                                          "its 2.4 GHz (`sustained.shader_clock_mhz`, from its own counters), i.e. ~0.8 of the nominal peak is attainable",
                                "conv_exclusive_ms_per_step": round(sum(g["exclusive_ms_per_step"] for g in groups), 3),
                                "groups": groups}
             sc, sc_why = load_step_counters(args.workload)
