@@ -532,9 +532,11 @@ class GpuSampler:
                 "source": "sysfs: %s (hwmon freq1_input / power1_average, gpu_busy_percent)" % (self.dev or "no amdgpu device node found")}
 
 
-def sustained_leg(step, batch, seconds, world, local_rank):
+def sustained_leg(step, batch, seconds, world, local_rank, n_steps=None):
     """loop the training step for `seconds` of wall clock (what a trainer sees: clocks and power settle over seconds, the timed region lasts
-    a fraction of one); per-step HIP events, per-second img/s, sysfs samples of the GPU this rank runs on"""
+    a fraction of one); per-step HIP events, per-second img/s, sysfs samples of the GPU this rank runs on.  n_steps: run exactly that many
+    steps instead (data-parallel runs: every step contains collectives, so all ranks must agree on the count -- a rank that stopped on its
+    own clock would leave the others waiting in an all-reduce)"""
     from footprints_amd import _lib
     lib = _lib.load()
     sampler = GpuSampler(index=local_rank).start()
@@ -562,7 +564,7 @@ def sustained_leg(step, batch, seconds, world, local_rank):
         host_t.append(time.perf_counter() - t0)
         if (len(marks) - 1) % 32 == 0:
             probe()
-        if host_t[-1] >= seconds or len(marks) > 200000:
+        if (n_steps is not None and len(marks) - 1 >= n_steps) or (n_steps is None and host_t[-1] >= seconds) or len(marks) > 200000:
             break
         if len(marks) % 64 == 0:
             marks[-32].synchronize()          # keep the host at most ~32 steps ahead: the loop ends on GPU time, not on queue depth
@@ -757,7 +759,10 @@ def main():
 
     sustained = None
     if args.sustain > 0:
-        sustained = sustained_leg(step, batch, args.sustain, world, local_rank % have)          # every rank loops (the steps contain the all-reduces)
+        # every rank loops (the steps contain the all-reduces): with collectives in the step the count comes from the timed region's
+        # rank-maximum step time, identical on all ranks
+        n_sus = max(8, int(args.sustain / (dt / args.steps))) if distributed else None
+        sustained = sustained_leg(step, batch, args.sustain, world, local_rank % have, n_steps=n_sus)
         if world > 1:
             dist.barrier()
 
