@@ -454,6 +454,11 @@ class Engine:
         if not (force or self.weights_dirty or vers != self._versions or key != self._pack_table_key):
             return
         if self._pack_table is None or self._pack_table_key != key:
+            # (re)building the device-resident job tables allocates and fills small tensors from pageable host memory: like a first touch in
+            # _need32 it drains the device first (start-up and the step after a first touch only; never under stream capture)
+            if _NEED32_SYNC and torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
+                torch.cuda.synchronize(self.device)
+
             def jobs_of(convs):
                 jobs = []
                 for c in convs:
