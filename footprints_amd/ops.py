@@ -105,7 +105,10 @@ def _cached_query(fn, desc):
 
 
 def workspace(nbytes, device, tag="main"):
-    """Grow-only scratch buffer per (device, tag); safe because all kernels of a step are stream-ordered."""
+    """Grow-only scratch buffer per (device, stream, tag).  Kernels that follow on the stream are ordered behind the launches that used it;
+    what the HOST does next is not -- a growth drops the old buffer, the caching allocator hands it out again at once, and a small
+    pageable host-to-device copy into it does not wait for kernels still writing partial sums there (round 5, profiles/round5_notes.md
+    section 7): a growth therefore waits for the device first."""
     # one scratch buffer per (device, stream, tag): kernels on concurrent streams must not share partials
     key = (device.index, stream(), tag)
     ws = _workspaces.get(key)
