@@ -1,0 +1,60 @@
+"""CPU: (1) the operand-format switch (footprints_amd/_format.py): the default is the exact bf16x3 split, fp16 pairs have to be asked for, the legacy
+spelling still works; (2) the decision-forced oracle (oracle/restatement.py ReluDecisions, tests/parity.py decision_forced_report): with its OWN ReLU /
+max-pool decisions imposed the float64 oracle reproduces itself, with one decision flipped the gradients behind it move -- the tool the GPU parity
+cases use to separate an implementation's decisions from its arithmetic (network.py:48-59: ResNet-34 encoder behind train-mode BatchNorm)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from footprints_amd._format import DTYPE_LABEL, FORMATS, format_env, operand_format
+
+
+def test_operand_format_defaults_to_exact_and_reads_both_spellings():
+    assert FORMATS == ("exact", "fp16_pair") and set(DTYPE_LABEL) == set(FORMATS)
+    assert operand_format({}) == "exact"
+    assert operand_format({"FP_OPERANDS": "fp16_pair"}) == "fp16_pair" and operand_format({"FP_OPERANDS": " Exact "}) == "exact"
+    assert operand_format({"FP_HP": "1"}) == "fp16_pair" and operand_format({"FP_HP": "0"}) == "exact"
+    assert operand_format({"FP_OPERANDS": "exact", "FP_HP": "1"}) == "exact"          # the new spelling wins over a stale legacy variable
+    with pytest.raises(ValueError):
+        operand_format({"FP_OPERANDS": "bf16"})
+    for f in FORMATS:
+        assert operand_format(format_env(f)) == f
+    assert "opt-in" in DTYPE_LABEL["fp16_pair"] and "exact" in DTYPE_LABEL["exact"]
+
+
+def _pool_winners(x):
+    """window position ky * 3 + kx of max_pool2d(3, 2, 1)'s winner per output element (the engine's encoding, csrc/bn_pool.hip)"""
+    N, C, H, W = x.shape
+    y, idx = F.max_pool2d(x, 3, 2, 1, return_indices=True)
+    OH, OW = y.shape[2:]
+    iy, ix = idx // W, idx % W
+    oy, ox = torch.arange(OH).view(1, 1, OH, 1), torch.arange(OW).view(1, 1, 1, OW)
+    return (iy - (oy * 2 - 1)) * 3 + (ix - (ox * 2 - 1))
+
+
+def test_the_oracle_under_its_own_decisions_is_itself_and_a_flipped_decision_moves_the_gradients():
+    from oracle import restatement as R
+    from tests.parity import count_decision_flips, oracle_grads, rel_l2
+    P, B = R.make_state(tag="dec")
+    batch = R.make_batch(1, 64, 96, tag="dec")
+    rec = R.ReluDecisions()
+    out, _, g, _, _ = oracle_grads(P, B, batch, torch.float64, relu_decisions=rec)
+    assert len(rec.taken) == 33                                      # stem + 2 per BasicBlock of ResNet-34 (3 + 4 + 6 + 3 blocks)
+    # the stem's output feeds the max-pool: its winners from the recorded stem activation
+    stem = R.resnet_encoder(batch["image"].double(), {k: v.double() for k, v in P.items()},
+                            {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in B.items()}, True)[0]
+    pool = _pool_winners(stem.detach())
+    out2, _, g2, _, _ = oracle_grads(P, B, batch, torch.float64, relu_decisions=R.ReluDecisions(impose=rec.taken, pool_impose=pool))
+    assert all(torch.equal(out[k], out2[k]) for k in out)
+    assert max(rel_l2(g2[k], g[k]) for k in g if g[k] is not None) < 1e-12
+    assert count_decision_flips({"relu": rec.taken, "pool": pool}, rec.taken) == (0, sum(m.numel() for m in rec.taken))
+    # flip ONE decision of the last block's output ReLU (an active element switched off): the forward hardly moves, gradients in front of it do
+    flipped = [m.clone() for m in rec.taken]
+    pos = flipped[-1].nonzero()[0]
+    flipped[-1][tuple(pos)] = False
+    assert count_decision_flips(flipped, rec.taken)[0] == 1
+    _, _, g3, _, _ = oracle_grads(P, B, batch, torch.float64, relu_decisions=R.ReluDecisions(impose=flipped))
+    moved = [k for k in g if g[k] is not None and k.startswith("encoder.layer4.2") and rel_l2(g3[k], g[k]) > 1e-9]
+    assert moved, "switching off an active element of the last encoder block must move that block's gradients"
+    # decoder parameters behind the flipped activation see a different feature, the stem in front of everything still gets a gradient
+    assert g3["encoder.layer0.0.weight"] is not None
