@@ -6,8 +6,10 @@ import sys
 s = open(sys.argv[1]).read()
 frag = sys.argv[2]
 which = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-labels = [ln for ln in s.splitlines() if ln.startswith("_Z") and frag in ln and ln.rstrip().endswith(":") is False and ":" in ln]
-name = [ln.split(":")[0] for ln in s.splitlines() if ln.startswith("_Z") and frag in ln and ln.split(":")[0].endswith(frag) is False][0]
+names = [ln.split(":")[0] for ln in s.splitlines() if ln.startswith("_Z") and ":" in ln and frag in ln.split(":")[0]]
+if not names:
+    raise SystemExit("no kernel label contains %r" % frag)
+name = names[0]
 a = s.index(name + ":")
 b = s.index(".end_amdhsa_kernel", a) if ".end_amdhsa_kernel" in s[a:] else len(s)
 body = s[a:b].splitlines()
