@@ -113,6 +113,29 @@ def _worker(rank, world, port, case, q):
                     self.steps, self.first, self.stride, self.batches, self.dataset = steps, 0, 1, [{"image": torch.zeros(1)}], range(steps)
             sh = ctx.shard(L(10 if rank == 0 else 6))
             q.put((rank, "ok", len(list(sh))))
+        elif case == "runs_dry":                                # rank 1's loader promises 5 batches and delivers 3: it must abort loudly
+            from footprints_amd.training.train import SyntheticLoader
+
+            class Lying(SyntheticLoader):
+                def __init__(self, steps, real):
+                    self.steps, self.first, self.stride, self.batches, self.dataset, self.real = steps, 0, 1, [{"image": torch.zeros(1)}], range(steps), real
+
+                def shard(self, rank_, world_):
+                    v = super().shard(rank_, world_)
+                    v.real = self.real
+                    return v
+
+                def __iter__(self):
+                    for i, b in enumerate(super().__iter__()):
+                        if i >= self.real:
+                            return
+                        yield b
+            sh = ctx.shard(Lying(10, 5 if rank == 0 else 3))
+            try:
+                n = len(list(sh))
+                q.put((rank, "ok", n))
+            except RuntimeError as e:
+                q.put((rank, "raised", str(e)[:40]))
     finally:
         dist.barrier()
         dist.destroy_process_group()
@@ -146,3 +169,11 @@ def test_ranks_agree_on_the_batch_count_of_an_epoch():
     """a rank whose loader is shorter must not leave the other one waiting in a gradient all-reduce: both iterate the minimum"""
     res = _run("unequal_counts")
     assert res[0] == ("ok", 3) and res[1] == ("ok", 3), res
+
+
+def test_a_rank_that_runs_dry_below_the_agreed_count_aborts_instead_of_stranding_the_others():
+    """every rank agreed on 5 batches for the epoch; rank 1's loader ends after 3: it raises (the launcher then stops the run) rather than
+    returning from the epoch while rank 0 walks into the next gradient all-reduce alone"""
+    res = _run("runs_dry")
+    assert res[0] == ("ok", 5), res
+    assert res[1][0] == "raised" and "ran out of batches" in res[1][1], res
