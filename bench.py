@@ -893,6 +893,10 @@ def main():
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": DTYPE_LABEL[FMT], "operand_format": FMT, "data": "synthetic",
+               "comparability": ("`value` is measured in the fp32-faithful default format (exact bf16x3 operands).  Rounds 2-4 reported the fp16-pair format as "
+                                 "`value` (round 4: 1065 img/s) and this format as the side leg `exact_split` (round 4: 768 img/s); the fp16-pair format is now "
+                                 "the side leg `fp16_pair`" if FMT == "exact" else
+                                 "started with FP_OPERANDS=fp16_pair: `value` is the OPT-IN 22-bit format, the fp32-faithful default is the side leg `exact`"),
                "arithmetic": ("fp32 tensors and accumulation; 3x3 stride-1 convs (fwd, dgrad, wgrad) multiply operands split into scaled fp16 "
                               "pairs (x * 2^k = h + m, per-tensor k from the tensor's largest magnitude, 22 significant bits, three fp16 MFMA "
                               "products hh + hm + mh, fp32 accumulate: measured error vs float64 equal to the exact bf16x3 split's and to fp32 "
