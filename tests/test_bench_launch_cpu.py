@@ -48,3 +48,46 @@ def test_single_rank_needs_a_gpu_and_says_so():
         return
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=300)
     assert p.returncode != 0 and "needs a GPU" in (p.stderr + p.stdout)
+
+
+def test_compact_line_is_small_and_round_trips():
+    """the driver parses the LAST stdout line and gave up on round 5's 34.6 KB one.  The line bench.py prints is
+    compact_record(full record): built here from round 5's committed full record (the largest one this repo ever printed) plus a
+    data-parallel config block, it must stay under 4 KB (hard cap 8 KB), round-trip through json and carry the contract keys."""
+    sys.path.insert(0, ROOT)
+    import bench
+    with open(os.path.join(ROOT, "profiles", "round5_bench_line_kitti_final_tree.json")) as fh:
+        full = json.load(fh)
+    assert len(json.dumps(full)) > 30000                           # the record that broke the driver
+    full["config"]["gradient_exchange"] = {"transport": "rccl", "buckets": 7, "overlap_with_backward": True, "rccl_ranks": 8,
+                                           "exposed_communication": {"exposed_ms": 0.41, "how": "x" * 500}, "allreduce_us": [{"bucket": "b" * 80}] * 7}
+    full["step_bytes"] = {"algorithmic_gb": 15.2, "hbm_gb": 30.8, "traffic_ratio": 2.03, "kernel_launches": 582, "note": "n" * 900}
+    line = bench.compact_record(full, "bench_detail.json")
+    assert "\n" not in line and len(line) <= bench.COMPACT_LIMIT <= 4096 < 8192
+    rec = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in rec, k
+    assert rec["value"] == full["value"] and rec["ms_per_step"] == full["ms_per_step"] and rec["vs_baseline"] is None
+    assert rec["config"]["workload"].startswith("KITTI 192x640 bs=12") and "model" not in rec["config"]
+    rf = rec["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_kernel_us", "launches_per_step"):
+        assert k in rf, k
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    cb = rec["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "single_thread" in cb and len(cb["sample"]) <= 160
+    assert rec["config"]["gradient_exchange"]["rccl_ranks"] == 8 and rec["step"]["traffic_ratio"] == 2.03
+    # a record with nothing optional in it (kernel events and CPU baseline switched off) still makes a valid line
+    bare = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                 "vs_baseline", "dtype", "data", "config")}
+    assert json.loads(bench.compact_record(bare))["value"] == full["value"]
+
+
+def test_default_run_skips_the_lab_notebook_legs():
+    """the default command line (what the driver runs) has the sustained leg and the second-format child switched off"""
+    sys.path.insert(0, ROOT)
+    import bench
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'ap.add_argument("--sustain", type=float, default=0.0' in src
+    assert 'ap.add_argument("--other-format", dest="other_format", action="store_true"' in src
+    assert "print(compact_record(out, write_detail(out)), flush=True)" in src and "print(json.dumps(out)" not in src
