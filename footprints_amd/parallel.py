@@ -137,7 +137,8 @@ def _host_group(group):
     if group not in _HOST_GROUPS:
         # dist.new_group must be entered by ALL ranks of the default group: created lazily from inside a sub-group's collective, the
         # non-members would never call it and the members would wait forever.  The default group is always complete here;
-        # a non-gloo SUB-group needs its twin made up front by everybody: prepare_host_group(group), called by DistContext.from_env
+        # a non-gloo SUB-group needs its twin made up front by everybody: prepare_host_group(group) on every rank right after the group
+        # is created (DistContext.from_env does it for the default group; sub-groups are the caller's)
         if group is not None:
             raise RuntimeError("footprints_amd.parallel: the gloo twin of a non-gloo sub-group has to be created by all ranks of the default "
                                "group together: call parallel.prepare_host_group(group) on every rank right after creating the group")
@@ -205,7 +206,13 @@ def destroy_communicators():
             c.destroy()
     _COMMS.clear()
     _SHARED_DEVICE.clear()
-    _HOST_GROUPS.clear()          # a re-initialised process group must not find the gloo twin of the destroyed one
+    for twin in _HOST_GROUPS.values():          # the gloo twins this module created are its own to destroy; a re-initialised
+        try:                                    # process group must not find the twin of the destroyed one either
+            if dist.is_initialized():
+                dist.destroy_process_group(twin)
+        except Exception:                       # already gone with the default group
+            pass
+    _HOST_GROUPS.clear()
 
 
 _SHARED_DEVICE = {}
@@ -219,10 +226,13 @@ def _physical_device_id(index=None):
     index = torch.cuda.current_device() if index is None else index
     p = torch.cuda.get_device_properties(index)
     uuid = getattr(p, "uuid", None)
-    if uuid is not None and str(uuid).strip("0-") != "":
-        return "uuid:%s" % uuid
     pci = tuple(getattr(p, k, None) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
-    if any(v is not None for v in pci):
+    have_pci = any(v is not None for v in pci)
+    if uuid is not None and str(uuid).strip("0-") != "":
+        # partitions of one GPU (CPX / NPS modes) may report the same uuid but sit on PCI functions of their own: both go into the identity
+        # so that they do not read as "two ranks on one device" 
+        return "uuid:%s%s" % (uuid, "/pci:%s" % (pci,) if have_pci else "")
+    if have_pci:
         return "pci:%s" % (pci,)
     vis = os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES", os.environ.get("CUDA_VISIBLE_DEVICES", "")))
     return "logical:%s/%d" % (vis, index)
@@ -404,6 +414,7 @@ class DistContext:
         if not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             dist.init_process_group("gloo", init_method="env://", rank=int(os.environ.get("RANK", "0")), world_size=world)
+        prepare_host_group(None)                # every rank is here: a non-gloo default group (launcher-made) gets its gloo twin now
         return cls(dist.get_rank(), dist.get_world_size(), local, None)
 
     @property
@@ -453,17 +464,32 @@ class ShardedLoader:
         self.epoch = 0
         self.mode, self.inner = "stride", None
         if hasattr(loader, "shard") and callable(loader.shard):
-            self.mode, self.inner = "index", loader.shard(rank, world)
-        else:
+            try:
+                self.mode, self.inner = "index", loader.shard(rank, world)
+            except (TypeError, NotImplementedError):
+                # a loader that HAS the method but cannot shard what it wraps (DeviceLoader over a custom sample source without
+                # shard(rank, world)): the fingerprinted stride mode below still works for it
+                self.mode, self.inner = "stride", None
+        if self.inner is None:
             try:
                 from torch.utils.data import DataLoader
             except Exception:                       # pragma: no cover
                 DataLoader = ()
             if DataLoader and isinstance(loader, DataLoader) and loader.batch_size is not None and hasattr(loader.dataset, "__len__"):
                 self.sampler = EpochShardSampler(len(loader.dataset), rank, world, loader.batch_size, shuffle=_is_shuffling(loader), seed=seed)
+                # everything else the caller configured travels along.  Replaced on purpose: the sampler (and with it a
+                # RandomSampler's own generator / seed -- the permutation must be the SAME on every rank, so it is seeded seed + epoch here)
+                # and drop_last (the ranks' counts must agree)
+                extra = {}
+                if loader.num_workers > 0 and getattr(loader, "prefetch_factor", None) is not None:
+                    extra["prefetch_factor"] = loader.prefetch_factor
+                for k in ("timeout", "generator", "multiprocessing_context", "pin_memory_device"):
+                    v = getattr(loader, k, None)
+                    if v not in (None, "", 0) and not (k == "multiprocessing_context" and loader.num_workers == 0):
+                        extra[k] = v
                 self.inner = DataLoader(loader.dataset, batch_size=loader.batch_size, sampler=self.sampler, num_workers=loader.num_workers,
                                         collate_fn=loader.collate_fn, pin_memory=loader.pin_memory, drop_last=True,
-                                        worker_init_fn=loader.worker_init_fn, persistent_workers=getattr(loader, "persistent_workers", False))
+                                        worker_init_fn=loader.worker_init_fn, persistent_workers=getattr(loader, "persistent_workers", False), **extra)
                 self.mode = "sampler"
 
     def __len__(self):
@@ -485,10 +511,12 @@ class ShardedLoader:
         return int(v[0])
 
     def _bounded(self, it, n):
-        out = 0
-        for b in it:
-            if n is not None and out >= n:
-                return
+        out, it = 0, iter(it)
+        while n is None or out < n:                 # checked BEFORE drawing: nothing is pulled (decoded, copied) past the agreed count
+            try:
+                b = next(it)
+            except StopIteration:
+                break
             yield b
             out += 1
         if n is not None and out < n:
@@ -505,10 +533,23 @@ class ShardedLoader:
             yield from self._bounded(self.inner, self._agreed(len(self.inner)))
             return
         n = self._agreed(len(self) if hasattr(self.loader, "__len__") else None)
+        if n == 0:
+            return                                  # agreed by all ranks: nobody enters the fingerprint collective
+        it = iter(self.loader)
+        try:
+            first = next(it)
+        except StopIteration:
+            first = _NO_BATCH
+        # EVERY rank enters this collective exactly once per epoch, with a sentinel when its loader is empty (a rank that
+        # drew nothing used to skip it and leave the others waiting, or pair up with their next collective)
+        _assert_same_first_batch(first, self.group)
+        if first is _NO_BATCH:
+            if n:
+                raise RuntimeError("ShardedLoader: rank %d has no batches but the ranks agreed on %d for this epoch" % (self.rank, n))
+            return
+        import itertools
         pending, out = [], 0
-        for b in self.loader:
-            if not pending and out == 0:
-                _assert_same_first_batch(b, self.group)
+        for b in itertools.chain([first], it):
             pending.append(b)
             if len(pending) == self.world:          # a full round: hand out this rank's batch
                 yield pending[self.rank]
@@ -578,11 +619,14 @@ def _fingerprint(obj):
     return int.from_bytes(h.digest()[:7], "little")
 
 
+_NO_BATCH = object()          # what a rank whose loader is empty brings to the fingerprint collective
+
+
 def _assert_same_first_batch(batch, group=None):
     """fallback sharding only: every rank must draw the same batch order -- compare a fingerprint of the epoch's first batch over the host group"""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
-    fp = _fingerprint(batch)
+    fp = 0 if batch is _NO_BATCH else max(1, _fingerprint(batch))
     v = torch.tensor([fp, -fp], dtype=torch.int64)
     dist.all_reduce(v, op=dist.ReduceOp.MAX, group=_host_group(group))
     if int(v[0]) != -int(v[1]):

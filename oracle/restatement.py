@@ -149,6 +149,14 @@ class ReluDecisions:
         self.impose = None if impose is None else iter(impose)
         self.pool_impose = pool_impose
         self.taken = []
+        # round 6: how far from the decision boundary every IMPOSED decision that differs from this run's own one sits (this run being
+        # the float64 oracle, that is the float64 value the other implementation resolved differently): an imposed mask is only
+        # legitimate where |z| is at round-off level, an imposed pool winner only where it ties the true maximum (tests/parity.py bounds both)
+        self.relu_flips = 0
+        self.relu_flip_worst = 0.0        # max |z| / RMS of z's channel over the flipped elements
+        self.relu_flip_where = None       # (index of the ReLU in call order, channel) of the worst one
+        self.pool_flips = 0
+        self.pool_flip_worst = 0.0        # max (true max - imposed winner) / RMS of the channel
 
 
 def _maxpool(x, decisions):
@@ -159,8 +167,17 @@ def _maxpool(x, decisions):
     OH, OW = (H + 1) // 2, (W + 1) // 2
     idx = decisions.pool_impose
     assert tuple(idx.shape) == (N, C, OH, OW), (tuple(idx.shape), (N, C, OH, OW))
-    patches = F.unfold(F.pad(x, (1, 1, 1, 1)), 3, stride=2).view(N, C, 9, OH, OW)      # padded positions are never imposed winners
-    return patches.gather(2, idx.unsqueeze(2).to(torch.int64)).squeeze(2)
+    patches = F.unfold(F.pad(x, (1, 1, 1, 1), value=float("-inf")), 3, stride=2).view(N, C, 9, OH, OW)   # padded positions never win
+    out = patches.gather(2, idx.unsqueeze(2).to(torch.int64)).squeeze(2)
+    with torch.no_grad():
+        gap = patches.max(2).values - out                                # >= 0; > 0 where the imposed winner is not this run's maximum
+        lose = gap > 0
+        n = int(lose.sum())
+        if n:
+            rms = x.pow(2).mean(dim=(0, 2, 3), keepdim=True).sqrt().clamp_min(1e-300)
+            decisions.pool_flips += n
+            decisions.pool_flip_worst = max(decisions.pool_flip_worst, float((gap / rms)[lose].max()))
+    return out
 
 
 def _relu(x, decisions):
@@ -174,6 +191,17 @@ def _relu(x, decisions):
         return F.relu(x)
     m = next(decisions.impose)
     assert m.shape == x.shape, (tuple(m.shape), tuple(x.shape))
+    with torch.no_grad():
+        flipped = m.to(torch.bool) != (x > 0)
+        n = int(flipped.sum())
+        if n:
+            rms = x.pow(2).mean(dim=(0, 2, 3), keepdim=True).sqrt().clamp_min(1e-300)
+            dist = torch.where(flipped, x.abs() / rms, torch.zeros((), dtype=x.dtype))
+            worst = float(dist.max())
+            decisions.relu_flips += n
+            if worst > decisions.relu_flip_worst:
+                decisions.relu_flip_worst = worst
+                decisions.relu_flip_where = (len(decisions.taken), int(dist.amax(dim=(0, 2, 3)).argmax()))
     decisions.taken.append(m)
     return x * m.to(x.dtype)
 

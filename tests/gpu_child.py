@@ -29,6 +29,18 @@ def _nchw_mask(t):
     return (t > 0).permute(0, 3, 1, 2).contiguous().cpu()
 
 
+def engine_decisions(eng):
+    """the discrete decisions of the engine's last train-mode forward (call before backward): {"relu": 33 bool NCHW masks, "pool": winners}"""
+    S = eng.saved
+    relu = [_nchw_mask(S["feats"][0])]
+    for Bk in S["blocks"]:
+        relu += [_nchw_mask(Bk["a1"]), _nchw_mask(Bk["out"])]
+    f0 = S["feats"][0]
+    hp, wp = (f0.shape[1] + 1) // 2, (f0.shape[2] + 1) // 2
+    am = eng._bufs["pool.argmax"][:f0.shape[0] * hp * wp * 64].view(f0.shape[0], hp, wp, 64)          # uint8 ky * 3 + kx (csrc/bn_pool.hip maxpool_fwd_kernel)
+    return {"relu": relu, "pool": am.permute(0, 3, 1, 2).contiguous().cpu().to(torch.int64)}
+
+
 def _step_here(P, B, cpu_batch, tap_block=None):
     from footprints_amd import FootprintNetwork
     from footprints_amd._format import operand_format
@@ -46,14 +58,7 @@ def _step_here(P, B, cpu_batch, tap_block=None):
     batch = {k: v.cuda() for k, v in cpu_batch.items()}
     out = model(batch["image"])
     torch.cuda.synchronize()
-    S = eng.saved
-    decisions = [_nchw_mask(S["feats"][0])]
-    for Bk in S["blocks"]:
-        decisions += [_nchw_mask(Bk["a1"]), _nchw_mask(Bk["out"])]
-    f0 = S["feats"][0]
-    hp, wp = (f0.shape[1] + 1) // 2, (f0.shape[2] + 1) // 2
-    am = eng._bufs["pool.argmax"][:f0.shape[0] * hp * wp * 64].view(f0.shape[0], hp, wp, 64)          # uint8 ky * 3 + kx (csrc/bn_pool.hip maxpool_fwd_kernel)
-    decisions = {"relu": decisions, "pool": am.permute(0, 3, 1, 2).contiguous().cpu().to(torch.int64)}
+    decisions = engine_decisions(eng)
     losses = LossManager((0.1, 100), 0.25, compute_viz=False)(out, batch)
     losses["loss"].backward()
     torch.cuda.synchronize()

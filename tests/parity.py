@@ -56,6 +56,13 @@ FORCED_MAX_ERR = 1e-3              # measured over 4 sizes x 2 formats: 1.3e-5 .
 FORCED_MEDIAN_ERR = 1e-5           # measured: 9.1e-7 .. 2.6e-6
 FORCED_MAX_ERR_NATURAL = 5e-3      # the natural-statistics / wide-range case (BatchNorm gammas spread over 2^16): measured 5.6e-4
 FORCED_MEDIAN_ERR_NATURAL = 2e-4   # measured 3.4e-5
+# Round 6 (VERDICT r5 "Next" 2 / ADVICE r5): the imposed decisions themselves are bounded -- without that the forced oracle could absorb a real
+# masking error of the engine.  Every ReLU decision of the engine that differs from the float64 run's must sit where float64 |z| is at
+# round-off distance from zero (relative to the RMS of z's channel), every differing max-pool winner must tie the true maximum to the same
+# degree, and the number of differing decisions is a vanishing fraction of all decisions.  Measured (profiles/round6_parity_ratios.md): 84-89 of
+# 104 693 760 at 12x192x640 (8e-7), worst |z64| / RMS ~1e-6.
+FLIP_MAX_FRACTION = 5e-6           # of all ReLU (resp. max-pool) decisions
+FLIP_MAX_DISTANCE = 1e-5           # |z64| / RMS(channel) at a flipped ReLU; (max - imposed winner) / RMS(channel) at a flipped pool window
 KINK_MAX_FRACTION = 0.005          # of the 2 B H W depth-target pixels, standard cases
 KINK_MAX_FRACTION_NATURAL = 0.02
 TIE_SIGMA = 1e-4      # (opt-in) ... and the output tolerance of the parity contract itself (north_star: depth / mask tensors within 1e-4): a sigmoid
@@ -152,12 +159,33 @@ def decision_forced_report(P, B, cpu_batch, decisions, gpu, cpu32, ref64, spread
     unchanged to ~1e-7, a flipped element being ~0 on either side; the backward pass follows the engine's masks).  Against THAT truth the
     engine's gradients carry arithmetic error only, and every tensor has to pass the same bound as before: a tensor that fails the
     single-run rule but passes here differs from float64 by decisions at round-off distance from zero, which no fp32 implementation
-    determines; one that fails here too is a defect.  Returns (failures, rows, grads of the forced oracle)."""
+    determines; one that fails here too is a defect.  Returns (failures, rows, grads of the forced oracle, flip statistics): the last is
+    what `assert_decisions_at_roundoff` bounds -- the imposed run measures, for every decision it was told to take against its own float64
+    judgement, how far from the boundary the float64 value sits."""
     from oracle.restatement import ReluDecisions
     imposed = ReluDecisions(impose=decisions["relu"], pool_impose=decisions.get("pool")) if isinstance(decisions, dict) else ReluDecisions(impose=decisions)
     g64f = oracle_grads(P, B, cpu_batch, torch.float64, relu_decisions=imposed)[2]
     bad, rows = anchored_report(gpu, cpu32, g64f, spread=spread, cpu_ref64=ref64)
-    return bad, rows, g64f
+    pool = decisions.get("pool") if isinstance(decisions, dict) else None
+    stats = {"relu_flips": imposed.relu_flips, "relu_decisions": sum(m.numel() for m in imposed.taken),
+             "relu_flip_worst_distance": imposed.relu_flip_worst, "relu_flip_worst_where": imposed.relu_flip_where,
+             "pool_flips": imposed.pool_flips, "pool_decisions": 0 if pool is None else pool.numel(), "pool_flip_worst_distance": imposed.pool_flip_worst}
+    return bad, rows, g64f, stats
+
+
+def assert_decisions_at_roundoff(stats, tag="", max_fraction=None, max_distance=None):
+    """the bound on what decision_forced_report imposed (round 6): few, and each at round-off distance from its boundary in float64"""
+    max_fraction = FLIP_MAX_FRACTION if max_fraction is None else max_fraction
+    max_distance = FLIP_MAX_DISTANCE if max_distance is None else max_distance
+    assert stats["relu_flips"] <= max(max_fraction * stats["relu_decisions"], 2), "%s: %d of %d ReLU decisions differ from float64 (bound %.1e)" % (
+        tag, stats["relu_flips"], stats["relu_decisions"], max_fraction)
+    assert stats["relu_flip_worst_distance"] <= max_distance, ("%s: a ReLU decision imposed on the float64 oracle sits at |z64| = %.2e x its channel's RMS "
+                                                                "(ReLU #%s, channel %s): not a round-off tie (bound %.1e)" % (
+        tag, stats["relu_flip_worst_distance"], *(stats["relu_flip_worst_where"] or (None, None)), max_distance))
+    assert stats["pool_flips"] <= max(max_fraction * max(stats["pool_decisions"], 1), 2), "%s: %d of %d max-pool winners differ from float64" % (
+        tag, stats["pool_flips"], stats["pool_decisions"])
+    assert stats["pool_flip_worst_distance"] <= max_distance, "%s: an imposed max-pool winner is %.2e x RMS below the float64 maximum (bound %.1e)" % (
+        tag, stats["pool_flip_worst_distance"], max_distance)
 
 
 def count_decision_flips(decisions, decisions_ref):

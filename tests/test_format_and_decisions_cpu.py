@@ -58,3 +58,51 @@ def test_the_oracle_under_its_own_decisions_is_itself_and_a_flipped_decision_mov
     assert moved, "switching off an active element of the last encoder block must move that block's gradients"
     # decoder parameters behind the flipped activation see a different feature, the stem in front of everything still gets a gradient
     assert g3["encoder.layer0.0.weight"] is not None
+
+
+def test_imposed_decisions_are_bounded_to_roundoff_ties():
+    """Round 6 (VERDICT r5 "Next" 2): the forced oracle must not be able to absorb a wrong mask.  decision_forced_report returns how many
+    imposed decisions differ from the float64 run's own and how far from the boundary the float64 value of the worst one sits;
+    assert_decisions_at_roundoff accepts the run's own decisions (0 flips), rejects an ordinary active element switched off (|z| ~ RMS, not a
+    tie), rejects a thin slab of wrong masks by COUNT, and rejects a max-pool winner that is not a tie."""
+    import pytest
+    from oracle import restatement as R
+    from tests.parity import FLIP_MAX_DISTANCE, assert_decisions_at_roundoff, decision_forced_report, oracle_grads
+    P, B = R.make_state(tag="dec")
+    batch = R.make_batch(1, 64, 96, tag="dec")
+    rec = R.ReluDecisions()
+    _, _, g, _, _ = oracle_grads(P, B, batch, torch.float64, relu_decisions=rec)
+    stem = R.resnet_encoder(batch["image"].double(), {k: v.double() for k, v in P.items()},
+                            {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in B.items()}, True)[0]
+    pool = _pool_winners(stem.detach())
+    own = {"relu": rec.taken, "pool": pool}
+    _, _, _, st = decision_forced_report(P, B, batch, own, g, g, g)
+    assert st["relu_flips"] == 0 and st["pool_flips"] == 0 and st["relu_flip_worst_distance"] == 0.0 and st["pool_flip_worst_distance"] == 0.0
+    assert st["relu_decisions"] == sum(m.numel() for m in rec.taken) and st["pool_decisions"] == pool.numel()
+    assert_decisions_at_roundoff(st, "own decisions")
+    # one ordinary active element switched off: the forward moves, so masks downstream of it stop matching the forced run's own judgement as
+    # well -- a wrong decision of ordinary magnitude announces itself in the count AND in the distance
+    flipped = [m.clone() for m in rec.taken]
+    pos = flipped[5].nonzero()[0]
+    flipped[5][tuple(pos)] = False
+    _, _, _, st = decision_forced_report(P, B, batch, {"relu": flipped, "pool": pool}, g, g, g)
+    assert st["relu_flips"] >= 1 and st["relu_flip_worst_distance"] > 100 * FLIP_MAX_DISTANCE and st["relu_flip_worst_where"][0] >= 5
+    with pytest.raises(AssertionError, match="not a round-off tie"):
+        assert_decisions_at_roundoff(st, "one wrong mask", max_fraction=1.0)     # count check disabled: the DISTANCE must catch it
+    with pytest.raises(AssertionError, match="ReLU decisions differ"):
+        assert_decisions_at_roundoff(st, "one wrong mask")
+    # a thin slab (one row of one channel) mis-masked: fails on the count as well
+    slab = [m.clone() for m in rec.taken]
+    slab[2][0, 3, 1, :] = ~slab[2][0, 3, 1, :]
+    _, _, _, st = decision_forced_report(P, B, batch, {"relu": slab, "pool": pool}, g, g, g)
+    assert st["relu_flips"] >= slab[2].shape[-1]
+    with pytest.raises(AssertionError):
+        assert_decisions_at_roundoff(st, "slab", max_distance=1e9)       # distance check disabled: the COUNT must catch it
+    # a pool window told to pick a non-maximal element
+    wrong = pool.clone()
+    wrong[0, 0, 4, 4] = (wrong[0, 0, 4, 4] + 1) % 9 if (wrong[0, 0, 4, 4] + 1) % 9 != pool[0, 0, 4, 4] else (wrong[0, 0, 4, 4] + 2) % 9
+    _, _, _, st = decision_forced_report(P, B, batch, {"relu": rec.taken, "pool": wrong}, g, g, g)
+    if st["pool_flips"]:                                                  # (the neighbour may hold exactly the same value: then it IS a tie)
+        assert st["pool_flip_worst_distance"] > FLIP_MAX_DISTANCE
+        with pytest.raises(AssertionError, match="max-pool winner"):
+            assert_decisions_at_roundoff(dict(st, relu_flips=0, relu_flip_worst_distance=0.0), "wrong pool winner")   # the pool's own check

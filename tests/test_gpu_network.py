@@ -220,15 +220,20 @@ def test_full_train_step_against_oracle_and_masks(Bn, Hn, Wn):
     outputs per channel, 21 losses, thresholded masks bit-exact, every parameter gradient fp64-anchored (tests/parity.py)."""
     from footprints_amd.training.losses import LossManager
     from oracle import restatement as R
-    from tests.parity import anchored_report, chan_relerr, oracle_grads, tie_free_batch
+    from tests.gpu_child import engine_decisions
+    from tests.parity import (anchored_report, assert_decisions_at_roundoff, chan_relerr, count_decision_flips, decision_forced_report, oracle_grads,
+                              tie_free_batch)
     P, B = R.make_state(tag="full")
     cpu_batch = R.make_batch(Bn, Hn, Wn, tag="full")
-    out64, l64, g64, _, cpu_batch = oracle_grads(P, B, cpu_batch, torch.float64, fix_batch=lambda b, o: tie_free_batch(b, o)[0])
+    dec64 = R.ReluDecisions()
+    out64, l64, g64, _, cpu_batch = oracle_grads(P, B, cpu_batch, torch.float64, fix_batch=lambda b, o: tie_free_batch(b, o)[0], relu_decisions=dec64)
     out_ref, l_ref, g32, _, _ = oracle_grads(P, B, cpu_batch, torch.float32)
     model = _new_model(P, B)
     model.train()
     batch = {k: v.cuda() for k, v in cpu_batch.items()}
     out = model(batch["image"])
+    torch.cuda.synchronize()
+    decisions = engine_decisions(model.engine())            # before backward: the saved activations are the engine's own buffers
     losses = LossManager((0.1, 100), 0.25)(out, batch)
     losses["loss"].backward()
     for k in R.SCALES:
@@ -245,20 +250,19 @@ def test_full_train_step_against_oracle_and_masks(Bn, Hn, Wn):
     # The encoder is piecewise linear (ReLU after train-mode BatchNorm over few samples at these sizes: 24 / 240 per channel at
     # layer4).  An activation within fp32 round-off of 0 that one fp32 implementation resolves differently from the float64 truth
     # moves a whole channel's statistics by ~1/samples and every gradient upstream with it -- for whichever implementation it
-    # happens to: the gradient is not a continuous function of the arithmetic there.  So the encoder part of the rule is applied
-    # only when the engine's ReLU masks equal the float64 oracle's; with a flip it is left to the benchmark-size tests
-    # (tests/test_gpu_parity_fullsize.py: >= 1440 samples per channel, where a flip moves gradients by less than the rule's slack).
-    rec = []
-    R.footprint_network(cpu_batch["image"].double(), OrderedDict((k, v.double()) for k, v in P.items()),
-                        OrderedDict((k, v.double() if v.is_floating_point() else v.clone()) for k, v in B.items()), True, record=rec)
-    saved = model.engine().saved["blocks"]
-    flips = [int(((blk["out"].permute(0, 3, 1, 2).cpu() > 0) != (r > 0)).sum()) for blk, r in zip(saved, rec)]
-    if sum(flips):
-        print("ReLU mask differences against the float64 oracle per encoder block: %s -> encoder gradients not compared at this size" % flips)
-        g_gpu = OrderedDict((n, g) for n, g in g_gpu.items() if "decoder" in n)
-        g32 = OrderedDict((n, g) for n, g in g32.items() if "decoder" in n)
-        g64 = OrderedDict((n, g) for n, g in g64.items() if "decoder" in n)
+    # happens to: the gradient is not a continuous function of the arithmetic there.  Round 6 (VERDICT r5 "Next" 2): the encoder part of
+    # the rule is never dropped.  With every decision equal to the float64 oracle's it is the plain rule; with a flip, the flips must be
+    # FEW and each a float64 round-off tie (tests/parity.py assert_decisions_at_roundoff -- a mis-masked element fails here), and the
+    # encoder gradients are then held to the same rule against the float64 oracle evaluated under the engine's decisions.
+    flips, total = count_decision_flips(decisions, dec64.taken)
     bad, rows = anchored_report(g_gpu, g32, g64)
+    if flips:
+        bad_f, rows_f, _, dstats = decision_forced_report(P, B, cpu_batch, decisions, g_gpu, g32, g64)
+        print("ReLU decisions differing from the float64 oracle: %d of %d -> imposed on the oracle: %s" % (flips, total, dstats))
+        assert_decisions_at_roundoff(dstats, "%dx%dx%d" % (Bn, Hn, Wn))
+        dec_bad = [b for b in bad if "decoder" in b.split(" ")[0]]
+        assert not dec_bad, dec_bad[:10]                    # decoders sit behind the features: a round-off flip moves them by round-off
+        bad, rows = bad_f, rows_f
     print("worst GPU/CPU32 error ratios vs fp64:", ["%s %.2f (gpu %.1e cpu %.1e)" % (n, r, eg, ec) for r, n, eg, ec in rows[:5]])
     assert not bad, bad[:10]
 

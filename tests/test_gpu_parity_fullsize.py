@@ -27,7 +27,7 @@ import torch
 
 from tests.gpu_child import gpu_step
 from tests.parity import (FORCED_MAX_ERR, FORCED_MAX_ERR_NATURAL, FORCED_MEDIAN_ERR, FORCED_MEDIAN_ERR_NATURAL, KINK_MAX_FRACTION, KINK_MAX_FRACTION_NATURAL, MEDIAN_GATE, MEDIAN_GATE_NATURAL, TIE_SIGMA,
-                          anchored_report, chan_relerr, count_decision_flips, decision_forced_report, oracle_grads, rel_l2, tie_free_batch)
+                          anchored_report, assert_decisions_at_roundoff, chan_relerr, count_decision_flips, decision_forced_report, oracle_grads, rel_l2, tie_free_batch)
 
 pytestmark = pytest.mark.gpu
 
@@ -139,7 +139,7 @@ def _decision_rule(tag, P, B, cpu_batch, res, g32, g64, bad, rows, dec64=None, s
     """the second half of the gradient rule (tests/parity.py decision_forced_report), run for EVERY case: the engine's gradients against the
     float64 oracle under the engine's own ReLU decisions -- the per-tensor rule once more (a tensor that failed the single-run rule has to pass
     here), absolute bounds on the errors, and the median of err(GPU forced) / err(CPU fp32).  Returns (what goes into the table, that median)."""
-    bad_f, rows_f, _ = decision_forced_report(P, B, cpu_batch, res["decisions"], res["grads"], g32, g64, spread=spread)
+    bad_f, rows_f, _, dstats = decision_forced_report(P, B, cpu_batch, res["decisions"], res["grads"], g32, g64, spread=spread)
     errs = sorted((eg for _, _, eg, _ in rows_f), reverse=True)
     med_f = float(np.median([r for r, *_ in rows_f]))
     extra = {"single_run_rule_failures": [b.split(" ")[0] for b in bad],
@@ -147,9 +147,12 @@ def _decision_rule(tag, P, B, cpu_batch, res, g32, g64, bad, rows, dec64=None, s
                                  "median_err": float("%.3e" % errs[len(errs) // 2]), "median_ratio": round(med_f, 4),
                                  "worst": [{"tensor": n, "err_gpu": float("%.3e" % eg), "err_cpu32": float("%.3e" % ec)} for _, n, eg, ec in
                                            sorted(rows_f, key=lambda r: -r[2])[:4]]}}
+    extra["imposed_decisions"] = {k: (float("%.3e" % v) if isinstance(v, float) else v) for k, v in dstats.items()}
     if dec64 is not None:
         flips, total = count_decision_flips(res["decisions"], dec64)
         extra["relu_decisions_differing_from_float64"] = {"engine": flips, "of": total}
+    # round 6: the imposed decisions are bounded BEFORE anything is concluded from the forced truth -- few, and each a float64 round-off tie
+    assert_decisions_at_roundoff(dstats, tag)
     print("\n[%s] single-run rule failures %d; against float64 under the engine's ReLU decisions: failures %d, max err %.2e, median %.2e, median ratio %.2f %s" % (
         tag, len(bad), len(bad_f), errs[0], errs[len(errs) // 2], med_f, extra.get("relu_decisions_differing_from_float64", "")))
     assert not bad_f, "gradients that differ from float64 by more than ReLU decisions at round-off distance from zero explain: %s" % bad_f[:10]

@@ -136,6 +136,30 @@ def _worker(rank, world, port, case, q):
                 q.put((rank, "ok", n))
             except RuntimeError as e:
                 q.put((rank, "raised", str(e)[:40]))
+        elif case == "one_rank_empty":                          # no __len__, rank 1 yields nothing -- every rank must still enter the
+            class NoLen:                                        # fingerprint collective (sentinel) and both must raise, nobody hangs
+                def __init__(self, tags):
+                    self.tags = list(tags)
+
+                def __iter__(self):
+                    for t in self.tags:
+                        yield {"image": torch.full((1, 3, 2, 2), float(t))}
+            sh = ctx.shard(NoLen(range(4) if rank == 0 else []))
+            try:
+                list(sh)
+                q.put((rank, "no error", None))
+            except RuntimeError as e:
+                q.put((rank, "raised", str(e)[:40]))
+        elif case == "zero_agreed":                             # a loader with fewer batches than ranks: 0 rounds agreed, nothing drawn, no collective left open
+            sh = ctx.shard(_Plain(range(1)))
+            q.put((rank, "ok", len(list(sh))))
+            assert ctx.mean_losses({"loss": float(rank)})["loss"] == 0.5     # the NEXT collective pairs up correctly on both ranks
+        elif case == "shard_method_cannot_shard":               # a loader WITH shard() that raises TypeError falls back to the stride mode
+            class Wrapped(_Plain):
+                def shard(self, r, w):
+                    raise TypeError("the sample source has no shard(rank, world)")
+            sh = ctx.shard(Wrapped(range(7)))
+            q.put((rank, sh.mode, [int(b["image"].flatten()[0]) for b in sh]))
     finally:
         dist.barrier()
         dist.destroy_process_group()
@@ -177,3 +201,36 @@ def test_a_rank_that_runs_dry_below_the_agreed_count_aborts_instead_of_stranding
     res = _run("runs_dry")
     assert res[0] == ("ok", 5), res
     assert res[1][0] == "raised" and "ran out of batches" in res[1][1], res
+
+
+def test_every_rank_enters_the_fingerprint_collective_even_with_an_empty_loader():
+    res = _run("one_rank_empty")
+    assert res[0][0] == "raised" and res[1][0] == "raised", res
+    res = _run("zero_agreed")
+    assert res[0] == ("ok", 0) and res[1] == ("ok", 0), res
+
+
+def test_a_loader_whose_shard_method_cannot_shard_falls_back_to_the_stride_mode():
+    res = _run("shard_method_cannot_shard")
+    assert res[0] == ("stride", [0, 2, 4]) and res[1] == ("stride", [1, 3, 5]), res
+
+
+def test_device_loader_over_a_custom_source_still_shards_by_stride():
+    """DeviceLoader always has a shard attribute; over a sample source without shard(rank, world) ShardedLoader used to fail at construction"""
+    from footprints_amd.datasets.device_path import DeviceLoader
+    from footprints_amd.parallel import ShardedLoader
+    dl = DeviceLoader([[("img", {})]] * 6, assembler=None)
+    sh = ShardedLoader(dl, 0, 2)
+    assert sh.mode == "stride" and len(sh) == 3
+
+
+def test_bounded_iteration_draws_nothing_past_the_agreed_count():
+    from footprints_amd.parallel import ShardedLoader
+    drawn = []
+
+    def gen():
+        for i in range(10):
+            drawn.append(i)
+            yield i
+    sh = ShardedLoader(_Plain(range(2)), 0, 1)
+    assert list(sh._bounded(gen(), 3)) == [0, 1, 2] and drawn == [0, 1, 2]
