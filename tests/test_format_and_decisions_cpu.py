@@ -106,3 +106,28 @@ def test_imposed_decisions_are_bounded_to_roundoff_ties():
         assert st["pool_flip_worst_distance"] > FLIP_MAX_DISTANCE
         with pytest.raises(AssertionError, match="max-pool winner"):
             assert_decisions_at_roundoff(dict(st, relu_flips=0, relu_flip_worst_distance=0.0), "wrong pool winner")   # the pool's own check
+
+
+def test_flip_distance_is_anchored_on_the_reference_arithmetic():
+    """the relative half of the bound: the engine's worst flipped decision may sit no further from zero (in float64) than FACTOR x the CPU fp32
+    run's own worst flip (floor 1e-5), and it may not flip many more decisions than the CPU fp32 run does"""
+    import pytest
+    from oracle import restatement as R
+    from tests.parity import assert_decisions_at_roundoff, oracle_grads, reference_flip_stats
+    base = {"relu_flips": 20, "relu_decisions": 10 ** 8, "relu_flip_worst_distance": 2e-5, "relu_flip_worst_where": (28, 83),
+            "pool_flips": 0, "pool_decisions": 10 ** 6, "pool_flip_worst_distance": 0.0}
+    assert_decisions_at_roundoff(base, "t", reference={"relu_flips": 15, "relu_flip_worst_distance": 1.2e-5})
+    assert_decisions_at_roundoff(dict(base, relu_flip_worst_distance=9e-6), "t", reference={"relu_flips": 15, "relu_flip_worst_distance": 1e-7})   # floor
+    with pytest.raises(AssertionError, match="CPU fp32"):
+        assert_decisions_at_roundoff(dict(base, relu_flip_worst_distance=6e-5), "t", reference={"relu_flips": 15, "relu_flip_worst_distance": 1.2e-5})
+    with pytest.raises(AssertionError, match="differ from float64"):
+        assert_decisions_at_roundoff(dict(base, relu_flips=100), "t", reference={"relu_flips": 15, "relu_flip_worst_distance": 1.2e-5})
+    with pytest.raises(AssertionError, match="not a round-off tie"):
+        assert_decisions_at_roundoff(dict(base, relu_flip_worst_distance=2e-4), "t")                                                               # absolute
+    # the measurement itself on the CPU: the fp32 oracle's decisions imposed on the float64 oracle
+    P, B = R.make_state(tag="dec")
+    batch = R.make_batch(1, 64, 96, tag="dec")
+    rec = R.ReluDecisions()
+    oracle_grads(P, B, batch, torch.float32, relu_decisions=rec)
+    st = reference_flip_stats(P, B, batch, rec.taken)
+    assert st["relu_decisions"] == sum(m.numel() for m in rec.taken) and st["relu_flips"] <= 8 and st["relu_flip_worst_distance"] <= 1e-4

@@ -27,7 +27,8 @@ import torch
 
 from tests.gpu_child import gpu_step
 from tests.parity import (FORCED_MAX_ERR, FORCED_MAX_ERR_NATURAL, FORCED_MEDIAN_ERR, FORCED_MEDIAN_ERR_NATURAL, KINK_MAX_FRACTION, KINK_MAX_FRACTION_NATURAL, MEDIAN_GATE, MEDIAN_GATE_NATURAL, TIE_SIGMA,
-                          anchored_report, assert_decisions_at_roundoff, chan_relerr, count_decision_flips, decision_forced_report, oracle_grads, rel_l2, tie_free_batch)
+                          anchored_report, assert_decisions_at_roundoff, chan_relerr, count_decision_flips, decision_forced_report, oracle_grads, reference_flip_stats, rel_l2,
+                          tie_free_batch)
 
 pytestmark = pytest.mark.gpu
 
@@ -135,7 +136,7 @@ def _table_tag(tag, fmt):
     return tag if fmt == "exact" else tag + "_fp16_pair"
 
 
-def _decision_rule(tag, P, B, cpu_batch, res, g32, g64, bad, rows, dec64=None, spread=(), max_err=FORCED_MAX_ERR, median_err=FORCED_MEDIAN_ERR):
+def _decision_rule(tag, P, B, cpu_batch, res, g32, g64, bad, rows, dec64=None, spread=(), max_err=FORCED_MAX_ERR, median_err=FORCED_MEDIAN_ERR, oracle=None):
     """the second half of the gradient rule (tests/parity.py decision_forced_report), run for EVERY case: the engine's gradients against the
     float64 oracle under the engine's own ReLU decisions -- the per-tensor rule once more (a tensor that failed the single-run rule has to pass
     here), absolute bounds on the errors, and the median of err(GPU forced) / err(CPU fp32).  Returns (what goes into the table, that median)."""
@@ -151,8 +152,17 @@ def _decision_rule(tag, P, B, cpu_batch, res, g32, g64, bad, rows, dec64=None, s
     if dec64 is not None:
         flips, total = count_decision_flips(res["decisions"], dec64)
         extra["relu_decisions_differing_from_float64"] = {"engine": flips, "of": total}
-    # round 6: the imposed decisions are bounded BEFORE anything is concluded from the forced truth -- few, and each a float64 round-off tie
-    assert_decisions_at_roundoff(dstats, tag)
+    # round 6: the imposed decisions are bounded BEFORE anything is concluded from the forced truth -- few, each a float64 round-off tie, and no
+    # further from the boundary than the reference's own fp32 arithmetic gets (its decisions imposed the same way; once per case, both formats)
+    ref = None
+    if oracle is not None and oracle.get("dec32") is not None:
+        if "flip32" not in oracle:
+            oracle["flip32"] = reference_flip_stats(P, B, cpu_batch, oracle["dec32"])
+        ref = oracle["flip32"]
+        extra["cpu_fp32_decisions_vs_float64"] = {k: (float("%.3e" % v) if isinstance(v, float) else v) for k, v in ref.items()}
+        print("[%s] decisions differing from float64: engine %d (worst %.2e x RMS), CPU fp32 %d (worst %.2e)" % (
+            tag, dstats["relu_flips"], dstats["relu_flip_worst_distance"], ref["relu_flips"], ref["relu_flip_worst_distance"]))
+    assert_decisions_at_roundoff(dstats, tag, reference=ref)
     print("\n[%s] single-run rule failures %d; against float64 under the engine's ReLU decisions: failures %d, max err %.2e, median %.2e, median ratio %.2f %s" % (
         tag, len(bad), len(bad_f), errs[0], errs[len(errs) // 2], med_f, extra.get("relu_decisions_differing_from_float64", "")))
     assert not bad_f, "gradients that differ from float64 by more than ReLU decisions at round-off distance from zero explain: %s" % bad_f[:10]
@@ -179,11 +189,12 @@ def test_train_step_fp64_anchored(Bn, Hn, Wn, fmt):
         rec64, rec32 = ([] if decompose else None), ([] if decompose else None)
         dec64 = R.ReluDecisions()
         out64, l64, g64, _, cpu_batch = oracle_grads(P, B, cpu_batch, torch.float64, fix_batch=fix, record=rec64, relu_decisions=dec64)   # float64 first: it defines the tie pixels
-        out32, l32, g32, tr32, _ = oracle_grads(P, B, cpu_batch, torch.float32, record=rec32)
+        dec32 = R.ReluDecisions()
+        out32, l32, g32, tr32, _ = oracle_grads(P, B, cpu_batch, torch.float32, record=rec32, relu_decisions=dec32)
         l64 = {k: float(v) for k, v in l64.items()}
         l32 = {k: float(v) for k, v in l32.items()}
         return dict(P=P, B=B, cpu_batch=cpu_batch, removed=removed[0], out64=out64, l64=l64, g64=g64, out32=out32, l32=l32, g32=g32,
-                    bn32={k: v.clone() for k, v in tr32.B.items()}, dec64=dec64.taken,
+                    bn32={k: v.clone() for k, v in tr32.B.items()}, dec64=dec64.taken, dec32=dec32.taken,
                     x64=rec64[-1] if decompose else None, x32=rec32[-1] if decompose else None)
     o = _oracle_runs(("train_step", Bn, Hn, Wn), build)
     P, B, cpu_batch, out64, out32, l64, l32, g64, g32 = (o[k] for k in ("P", "B", "cpu_batch", "out64", "out32", "l64", "l32", "g64", "g32"))
@@ -217,7 +228,7 @@ def test_train_step_fp64_anchored(Bn, Hn, Wn, fmt):
     # 4x512x640 (measured round 5: 0 failures, max 2.9e-5 / 1.9e-5) only when the plain rule or the median gate needs it -- the driver's suite time
     med_plain = float(np.median([r for r, *_ in rows]))
     if (Bn, Hn, Wn) != (4, 512, 640) or bad or not (MEDIAN_GATE[0] <= med_plain <= MEDIAN_GATE[1]):
-        forced, med_f = _decision_rule(case, P, B, cpu_batch, res, g32, g64, bad, rows, dec64=o["dec64"])
+        forced, med_f = _decision_rule(case, P, B, cpu_batch, res, g32, g64, bad, rows, dec64=o["dec64"], oracle=o)
         extra.update(forced)
     else:
         med_f = med_plain
