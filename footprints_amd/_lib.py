@@ -34,6 +34,16 @@ class PackJob(C.Structure):
 _P, _I32, _I64, _F, _D = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double
 _DESC = C.POINTER(ConvDesc)
 
+
+class Aux(C.Structure):
+    """fp_aux (include/footprints_hip.h): optional side outputs of ONE launch, passed explicitly (round 6; rounds 3-5 armed per-thread
+    `*_out_next` sinks instead) -- an amax slot receiving max |output|, BatchNorm partials out of a convolution's epilogue"""
+    _fields_ = [("amax_out", C.c_void_p), ("bn_part", C.c_void_p), ("bn_capacity_floats", C.c_int64), ("bn_nblk_out", C.POINTER(C.c_int32)),
+                ("bnb_z", C.c_void_p), ("bnb_mean", C.c_void_p), ("bnb_invstd", C.c_void_p)]
+
+
+_AUX = C.POINTER(Aux)
+
 # name -> (restype, argtypes); mirrors include/footprints_hip.h one to one
 SIGNATURES = {
     "fp_seg_loss_workspace": (_I64, [_I32, _I32, _I32]),
@@ -66,7 +76,7 @@ SIGNATURES = {
     "fp_bilinear_ac_bwd": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
     "fp_copy_channels": (C.c_int, [_P, _P, _I64, _I32, _I32, _I32, _I32, _I32, C.c_int, _P]),
     "fp_conv_igemm_workspace": (_I64, [_DESC]),
-    "fp_conv_igemm": (C.c_int, [_DESC, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
+    "fp_conv_igemm": (C.c_int, [_DESC, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _AUX, _P]),
     "fp_conv_wgrad_workspace": (_I64, [_DESC]),
     "fp_conv_wgrad": (C.c_int, [_DESC, _P, _P, _P, _P, C.c_int, _P, _I64, _P]),
     "fp_packed_weight_elems": (_I64, [_I32, _I32, _I32, _I32, _I32, _I32]),
@@ -78,7 +88,7 @@ SIGNATURES = {
     "fp_conv_up2_phase_fwd": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
     "fp_pack_up2_weight_dgrad": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P]),
     "fp_pack_conv_weight_dgrad_slice": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P]),
-    "fp_up2_fold_bwd": (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _P, _P, _P]),
+    "fp_up2_fold_bwd": (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _P, _P, _AUX, _P]),
     "fp_conv_wgrad_slice": (C.c_int, [_DESC, _P, _P, _P, _P, _I32, _I32, C.c_int, _P, _I64, _P]),
     "fp_conv_up2_phase_wgrad_workspace": (_I64, [_I32, _I32, _I32, _I32, _I32]),
     "fp_conv_up2_phase_wgrad": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, C.c_int, _P, _I64, _P]),
@@ -89,15 +99,14 @@ SIGNATURES = {
     "fp_pack_up2_weight_bf3": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P]),
     "fp_pack_up2_weight_dgrad_bf3": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P]),
     "fp_conv_up2_phase_dgrad_bf3": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P]),
-    "fp_conv_up2_phase_fwd_bf3": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
+    "fp_conv_up2_phase_fwd_bf3": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _AUX, _P]),
     "fp_conv_wgrad_bf3_workspace": (_I64, [_DESC]),
     "fp_conv_wgrad_bf3": (C.c_int, [_DESC, _P, _P, _P, _P, _I32, _I32, C.c_int, _P, _I64, _P]),
     "fp_conv3x3_bf3_supported": (C.c_int, [_DESC]),
     "fp_conv3x3_bf3_workspace": (_I64, [_DESC]),
-    "fp_conv3x3_bf3": (C.c_int, [_DESC, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
+    "fp_conv3x3_bf3": (C.c_int, [_DESC, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _AUX, _P]),
     "fp_packed_weight_elems_bf3": (_I64, [_I32, _I32, _I32, _I32, _I32]),
     "fp_amax_slot_elems": (_I32, []),
-    "fp_amax_out_next": (C.c_int, [_P]),
     "fp_conv_wgrad_hp": (C.c_int, [_DESC, _P, _P, _P, _P, _I32, _I32, C.c_int, _P, _I64, _P, _P, _P]),
     "fp_conv_up2_phase_wgrad_hp": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, C.c_int, _P, _I64, _P, _P, _P]),
     "fp_conv_up2_phase_fwd_hp": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P]),
@@ -108,7 +117,7 @@ SIGNATURES = {
     "fp_packed_weight_elems_hp": (_I64, [_I32, _I32, _I32, _I32, _I32]),
     "fp_pack_conv_weight_hp": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _P, _I32, _P]),
     "fp_pack_weights_amax": (C.c_int, [_P, _P, _I32, _P]),
-    "fp_conv3x3_hp": (C.c_int, [_DESC, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P]),
+    "fp_conv3x3_hp": (C.c_int, [_DESC, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _AUX, _P]),
     "fp_pack_conv_weight_bf3": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _P]),
     "fp_adam_hyper": (C.c_int, [_D, _D, _D, _D, _I32, _D, _P]),
     "fp_adam_step_dev": (C.c_int, [_P, _P, _P, _P, _I64, _P, _P]),
@@ -122,25 +131,23 @@ SIGNATURES = {
     "fp_head_fwd": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P]),
     "fp_head_upsample": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
     "fp_head_upsample_bwd": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
-    "fp_head_dgrad": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
+    "fp_head_dgrad": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _AUX, _P]),
     "fp_conv_stem_hp_supported": (C.c_int, [_P]),
-    "fp_conv_stem_hp": (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
+    "fp_conv_stem_hp": (C.c_int, [_P, _P, _P, _P, _P, _P, _AUX, _P]),
     "fp_conv_stem_wgrad_hp": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, _I64, _P, _P]),
     "fp_head_wgrad_workspace": (_I64, [_I32, _I32, _I32, _I32]),
     "fp_head_wgrad": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, C.c_int, _P, _I64, _P]),
     "fp_bn_workspace": (_I64, [_I64, _I32]),
     "fp_bn_train_stats": (C.c_int, [_P, _I64, _I32, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
-    "fp_bn_stats_out_next": (C.c_int, [_P, _I64, _P]),
     "fp_bn_train_stats_partials": (C.c_int, [_P, _I32, _I32, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "fp_bn_bwd_out_next": (C.c_int, [_P, _I64, _P, _P, _P, _P]),
-    "fp_bn_bwd_partials": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int, _I64, _I32, _P, _I32, _P, _P]),
+    "fp_bn_bwd_partials": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int, _I64, _I32, _P, _I32, _P, _AUX, _P]),
     "fp_bn_eval_coeffs": (C.c_int, [_P, _P, _P, _P, _F, _I32, _P, _P, _P]),
     "fp_conv_igemm_hp_supported": (C.c_int, [_DESC]),
-    "fp_conv_igemm_hp": (C.c_int, [_DESC, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P]),
-    "fp_conv_igemm_bf3": (C.c_int, [_DESC, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
-    "fp_bn_apply": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _I32, _P]),
-    "fp_bn_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, _I64, _I32, _P, _I64, _P]),
-    "fp_maxpool_fwd": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _P]),
+    "fp_conv_igemm_hp": (C.c_int, [_DESC, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _AUX, _P]),
+    "fp_conv_igemm_bf3": (C.c_int, [_DESC, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _AUX, _P]),
+    "fp_bn_apply": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _I32, _AUX, _P]),
+    "fp_bn_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, _I64, _I32, _P, _I64, _AUX, _P]),
+    "fp_maxpool_fwd": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _AUX, _P]),
     "fp_maxpool_bwd": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, C.c_int, _P]),
     "fp_loss_workspace": (_I64, [_I32, _I32, _I32]),
     "fp_loss_fwd_bwd": (C.c_int, [C.POINTER(_P), _P, _P, _P, _P, _P, _P, _F, _F, _F, C.POINTER(_P), _P, _I32, _I32, _I32,

@@ -364,7 +364,7 @@ extern "C" int fp_bn_train_stats(const float* z, int64_t M, int32_t C, const flo
 }
 
 // the second half of fp_bn_train_stats on Welford partials somebody else wrote: part[blk][c] = (n, mean, M2), e.g. the tile convolution's
-// epilogue (fp_bn_stats_out_next) -- one launch instead of two, and the activation is not read again
+// epilogue (fp_aux.bn_part) -- one launch instead of two, and the activation is not read again
 extern "C" int fp_bn_train_stats_partials(const float* part, int32_t nblk, int32_t C, const float* gamma, const float* beta, float eps,
                                           float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked,
                                           float* save_mean, float* save_invstd, float* scale, float* shift, fp_stream_t stream) {
@@ -388,8 +388,8 @@ extern "C" int fp_bn_eval_coeffs(const float* gamma, const float* beta, const fl
 }
 
 extern "C" int fp_bn_apply(const float* z, const float* scale, const float* shift, const float* residual, float* y, int64_t M,
-                           int32_t C, int32_t relu, fp_stream_t stream) {
-  unsigned* amax_out = fp_take_amax_out();     // consumed first: an argument error below must not leave the sink armed
+                           int32_t C, int32_t relu, const fp_aux* aux, fp_stream_t stream) {
+  unsigned* amax_out = fp_amax_out_of(aux);
   FP_REQUIRE(z && scale && shift && y && C % 4 == 0, "fp_bn_apply: bad arguments");
   const size_t total4 = (size_t)M * (C / 4);
   fp_launch(bn_apply_kernel, dim3(ew_grid(total4, 8192)), dim3(256), 0, (hipStream_t)stream, z, scale, shift,
@@ -399,8 +399,8 @@ extern "C" int fp_bn_apply(const float* z, const float* scale, const float* shif
 
 extern "C" int fp_bn_bwd(const float* dy, const float* relu_out, const float* z, const float* save_mean, const float* save_invstd,
                          const float* gamma, float* dz, float* g_out, float* dgamma, float* dbeta, int accumulate, int64_t M,
-                         int32_t C, void* workspace, int64_t workspace_bytes, fp_stream_t stream) {
-  unsigned* amax_out = fp_take_amax_out();     // consumed first: an argument error below must not leave the sink armed
+                         int32_t C, void* workspace, int64_t workspace_bytes, const fp_aux* aux, fp_stream_t stream) {
+  unsigned* amax_out = fp_amax_out_of(aux);
   FP_REQUIRE(dy && z && save_mean && save_invstd && gamma && dz && workspace, "fp_bn_bwd: null pointer");
   FP_REQUIRE(bn_c_ok(C) && M > 0 && M < ((int64_t)1 << 31), "fp_bn_bwd: unsupported C=%d", C);
   FP_REQUIRE(workspace_bytes >= fp_bn_workspace(M, C), "fp_bn_bwd: workspace too small");
@@ -417,12 +417,12 @@ extern "C" int fp_bn_bwd(const float* dy, const float* relu_out, const float* z,
   return fp_check_launch("fp_bn_bwd");
 }
 
-// fp_bn_bwd's second and third launch on partial sums (sum g, sum g * xhat) that a data-gradient epilogue already wrote (fp_bn_bwd_out_next):
+// fp_bn_bwd's second and third launch on partial sums (sum g, sum g * xhat) that a data-gradient epilogue already wrote (fp_aux.bnb_*):
 // `g` is the masked gradient as stored by that launch (no relu_out here), `part` = [nblk][C][2], `coef` = 2 C floats of scratch
 extern "C" int fp_bn_bwd_partials(const float* g, const float* z, const float* save_mean, const float* save_invstd, const float* gamma,
                                   float* dz, float* dgamma, float* dbeta, int accumulate, int64_t M, int32_t C, const float* part,
-                                  int32_t nblk, float* coef, fp_stream_t stream) {
-  unsigned* amax_out = fp_take_amax_out();     // consumed first: an argument error below must not leave the sink armed
+                                  int32_t nblk, float* coef, const fp_aux* aux, fp_stream_t stream) {
+  unsigned* amax_out = fp_amax_out_of(aux);
   FP_REQUIRE(g && z && save_mean && save_invstd && gamma && dz && part && coef, "fp_bn_bwd_partials: null pointer");
   FP_REQUIRE(bn_c_ok(C) && M > 0 && M < ((int64_t)1 << 31) && nblk > 0, "fp_bn_bwd_partials: unsupported C=%d / nblk=%d", C, nblk);
   fp_launch(bn_bwd_final_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, part, (int)nblk, C, 1.f / (float)M, coef, dgamma,
@@ -434,8 +434,8 @@ extern "C" int fp_bn_bwd_partials(const float* g, const float* z, const float* s
 }
 
 extern "C" int fp_maxpool_fwd(const float* x, float* y, uint8_t* argmax, int32_t N, int32_t H, int32_t W, int32_t C,
-                              fp_stream_t stream) {
-  unsigned* amax_out = fp_take_amax_out();     // consumed first: an argument error below must not leave the sink armed
+                              const fp_aux* aux, fp_stream_t stream) {
+  unsigned* amax_out = fp_amax_out_of(aux);
   FP_REQUIRE(x && y && argmax && C % 4 == 0, "fp_maxpool_fwd: bad arguments");
   const size_t total = (size_t)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
   fp_launch(maxpool_fwd_kernel, dim3(ew_grid(total, 8192)), dim3(256), 0, (hipStream_t)stream, x, y, argmax, N, H, W,

@@ -68,7 +68,7 @@ struct Tile3Args {
   unsigned* amax_out;
   float* bn_part;     // forward conv in front of a train-mode BatchNorm (unsplit, no epilogue options): Welford partials [pixel tile][Nout][3], or null
   // data gradient whose output is the masked gradient g entering a train-mode BatchNorm's backward (unsplit grids): partial sums
-  // [pixel tile][Nout][2] = (sum g, sum g * xhat), xhat = (z - mean) * invstd of THAT BatchNorm -- or null (fp_bn_bwd_out_next)
+  // [pixel tile][Nout][2] = (sum g, sum g * xhat), xhat = (z - mean) * invstd of THAT BatchNorm -- or null (fp_aux.bnb_*)
   float* bnb_part;
   const float* bnb_z;
   const float* bnb_mean;
@@ -826,8 +826,8 @@ struct HpSlots { const unsigned* a; const unsigned* a1; const unsigned* w; unsig
 
 int run_tile3(const char* who, const fp_conv_desc* d, const float* src, const float* src1, const void* wpacked, const float* bias,
               const float* addend, const float* addend_mask, const float* actsrc, float* y, void* workspace, int64_t workspace_bytes,
-              const HpSlots* hp, hipStream_t stream) {
-  const FpBnSink bn_sink = fp_take_bn_sink();        // consumed first: an argument error below must not leave the sink armed
+              const HpSlots* hp, const fp_aux* aux, hipStream_t stream) {
+  const FpBnSink bn_sink = fp_bn_sink_of(aux);       // (zeroes *bn_nblk_out: an argument error below reports "nothing emitted")
   FP_REQUIRE(d && src && wpacked && y, "fp_conv3x3_bf3 / fp_conv3x3_hp: null pointer");
   const Plan3 p = plan3(d);
   FP_REQUIRE(p.ok, "fp_conv3x3_bf3 / fp_conv3x3_hp: shape not supported (see fp_conv3x3_bf3_supported)");
@@ -858,11 +858,11 @@ int run_tile3(const char* who, const fp_conv_desc* d, const float* src, const fl
   a.amax_a = hp ? hp->a : nullptr; a.amax_a1 = hp && up2 && d->C1 ? hp->a1 : nullptr; a.amax_w = hp ? hp->w : nullptr;
   a.amax_out = hp ? hp->out : nullptr;
   {
-    // BatchNorm-statistics sink (fp_bn_stats_out_next): only the plain forward form on an unsplit grid emits -- its stored value is the
+    // BatchNorm-statistics sink (fp_aux.bn_part): only the plain forward form on an unsplit grid emits -- its stored value is the
     // accumulator itself -- everything else reports 0 blocks and the caller runs fp_bn_train_stats as before
     const int64_t blocks = (int64_t)d->N * p.tilesY * p.tilesX;
     bool emit;
-    if (bn_sink.z) {       // backward form (fp_bn_bwd_out_next): a data gradient on an unsplit grid that overwrites its output
+    if (bn_sink.z) {       // backward form (fp_aux.bnb_*): a data gradient on an unsplit grid that overwrites its output
       emit = bn_sink.part && p.SK <= 1 && flip && !fold && !(d->epi & FP_EPI_ACCUM) && d->act == 0 && blocks * d->Nout * 2 <= bn_sink.cap_floats;
       if (emit) { a.bnb_part = bn_sink.part; a.bnb_z = bn_sink.z; a.bnb_mean = bn_sink.mean; a.bnb_invstd = bn_sink.invstd; }
     } else {
@@ -932,9 +932,9 @@ int run_tile3(const char* who, const fp_conv_desc* d, const float* src, const fl
 
 extern "C" int fp_conv3x3_bf3(const fp_conv_desc* d, const float* src, const float* src1, const void* wpacked_bf3, const float* bias,
                               const float* addend, const float* addend_mask, const float* actsrc, float* y, void* workspace,
-                              int64_t workspace_bytes, fp_stream_t stream_) {
+                              int64_t workspace_bytes, const fp_aux* aux, fp_stream_t stream_) {
   return run_tile3("fp_conv3x3_bf3", d, src, src1, wpacked_bf3, bias, addend, addend_mask, actsrc, y, workspace, workspace_bytes, nullptr,
-                   (hipStream_t)stream_);
+                   aux, (hipStream_t)stream_);
 }
 
 // Same operation with fp16-pair operands (fp_common.h): weights from fp_pack_conv_weight_hp / FP_PACK_{FWD,DGRAD}_HP jobs with the
@@ -943,10 +943,10 @@ extern "C" int fp_conv3x3_bf3(const fp_conv_desc* d, const float* src, const flo
 extern "C" int fp_conv3x3_hp(const fp_conv_desc* d, const float* src, const float* src1, const void* wpacked_hp, const float* bias,
                              const float* addend, const float* addend_mask, const float* actsrc, float* y, void* workspace,
                              int64_t workspace_bytes, const uint32_t* amax_src, const uint32_t* amax_src1, const uint32_t* amax_w,
-                             uint32_t* amax_out, fp_stream_t stream_) {
+                             uint32_t* amax_out, const fp_aux* aux, fp_stream_t stream_) {
   FP_REQUIRE(amax_src && amax_w, "fp_conv3x3_hp: amax slots missing");
   FP_REQUIRE(!(d && d->gather == FP_GATHER_FWD_REFLECT_UP2 && d->C1) || amax_src1, "fp_conv3x3_hp: the skip tensor's amax slot is missing");
   const HpSlots hp = {amax_src, amax_src1, amax_w, amax_out};
   return run_tile3("fp_conv3x3_hp", d, src, src1, wpacked_hp, bias, addend, addend_mask, actsrc, y, workspace, workspace_bytes, &hp,
-                   (hipStream_t)stream_);
+                   aux, (hipStream_t)stream_);
 }

@@ -599,7 +599,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_stats_kernel(const float* _
   if (amax_out) fp_amax_publish_block(amax_out, ymax);
 }
 
-// ... and for a data gradient whose output is the masked gradient g entering a train-mode BatchNorm's backward (fp_bn_bwd_out_next): y =
+// ... and for a data gradient whose output is the masked gradient g entering a train-mode BatchNorm's backward (fp_aux.bnb_*): y =
 // epilogue(sum_s part[s]) as in splitk_reduce_kernel, plus (sum g, sum g * xhat) of the block's rows per channel -> bpart[block][Nout][2],
 // xhat = (z - mean) * invstd of that BatchNorm in the arithmetic form of bn_bwd_reduce_kernel
 __global__ void __launch_bounds__(256) splitk_reduce_bnb_kernel(const IgemmArgs a, const float* __restrict__ z, const float* __restrict__ mean,
@@ -715,7 +715,7 @@ int launch_hp(IgemmArgs& a, hipStream_t stream, int64_t ws_floats, const FpBnSin
   a.nwg = tilesM * a.tilesN * a.SK;
   fp_launch((igemm_hp_kernel<TN, NP>), dim3(a.nwg), dim3(256), 0, stream, a);
   if (a.SK > 1 && sink.part && !sink.z && a.epi == 0 && a.act == FP_ACT_NONE && !a.pm) {
-    // a strided / 1 x 1 forward convolution in front of a train-mode BatchNorm: the statistics out of the reduce launch (fp_bn_stats_out_next)
+    // a strided / 1 x 1 forward convolution in front of a train-mode BatchNorm: the statistics out of the reduce launch (fp_aux.bn_part)
     int rc2 = 0;
     const int nb = fp_splitk_reduce_stats_launch(a.part, a.SK, a.M, a.Nout, a.y, stream, a.amax_out, sink.part, sink.cap_floats, &rc2);
     if (nb > 0) {
@@ -794,8 +794,8 @@ extern "C" int64_t fp_conv_igemm_workspace(const fp_conv_desc* d) {
 
 extern "C" int fp_conv_igemm(const fp_conv_desc* d, const float* src0, const float* src1, const float* wpacked,
                              const float* bias, const float* addend, const float* addend_mask, const float* actsrc,
-                             float* y, void* workspace, int64_t workspace_bytes, fp_stream_t stream_) {
-  const FpBnSink bn_sink = fp_take_bn_sink();     // a statistics sink must not outlive a launch that cannot emit; the stem's tile kernel can
+                             float* y, void* workspace, int64_t workspace_bytes, const fp_aux* aux, fp_stream_t stream_) {
+  const FpBnSink bn_sink = fp_bn_sink_of(aux);    // only the stem's tile kernel can emit from this entry point
   hipStream_t stream = (hipStream_t)stream_;
   FP_REQUIRE(d && src0 && wpacked && y, "fp_conv_igemm: null pointer");
   FP_REQUIRE(d->N > 0 && d->OH > 0 && d->OW > 0 && d->Nout > 0, "fp_conv_igemm: empty problem");
@@ -877,8 +877,8 @@ extern "C" int fp_conv_igemm_hp_supported(const fp_conv_desc* d) {
 
 static int igemm_split_operands(const char* who, const fp_conv_desc* d, const float* src, const void* wpacked, const float* bias, const float* addend,
                                 const float* addend_mask, const float* actsrc, float* y, void* workspace, int64_t workspace_bytes,
-                                const uint32_t* amax_src, const uint32_t* amax_w, bool exact, fp_stream_t stream_) {
-  const FpBnSink bn_sink = fp_take_bn_sink();     // consumed by this launch: only a split grid's reduce launch can emit (launch_hp)
+                                const uint32_t* amax_src, const uint32_t* amax_w, bool exact, const fp_aux* aux, fp_stream_t stream_) {
+  const FpBnSink bn_sink = fp_bn_sink_of(aux);    // only a split grid's reduce launch can emit (launch_hp)
   hipStream_t stream = (hipStream_t)stream_;
   (void)who;
   FP_REQUIRE(d && src && wpacked && y && (exact || (amax_src && amax_w)), "fp_conv_igemm_hp / _bf3: null pointer");
@@ -919,9 +919,9 @@ static int igemm_split_operands(const char* who, const fp_conv_desc* d, const fl
 
 extern "C" int fp_conv_igemm_hp(const fp_conv_desc* d, const float* src, const void* wpacked_hp, const float* bias, const float* addend,
                                 const float* addend_mask, const float* actsrc, float* y, void* workspace, int64_t workspace_bytes,
-                                const uint32_t* amax_src, const uint32_t* amax_w, fp_stream_t stream_) {
+                                const uint32_t* amax_src, const uint32_t* amax_w, const fp_aux* aux, fp_stream_t stream_) {
   return igemm_split_operands("fp_conv_igemm_hp", d, src, wpacked_hp, bias, addend, addend_mask, actsrc, y, workspace, workspace_bytes, amax_src,
-                              amax_w, false, stream_);
+                              amax_w, false, aux, stream_);
 }
 
 // The same operation with EXACTLY split bf16x3 operands (round 5; the default operand format's path for the encoder's stride-2 3x3 and 1x1
@@ -929,7 +929,7 @@ extern "C" int fp_conv_igemm_hp(const fp_conv_desc* d, const float* src, const v
 // size; fp_packed_weight_elems_bf3 floats), no amax slots.  Shapes: fp_conv_igemm_hp_supported.
 extern "C" int fp_conv_igemm_bf3(const fp_conv_desc* d, const float* src, const void* wpacked_bf3, const float* bias, const float* addend,
                                  const float* addend_mask, const float* actsrc, float* y, void* workspace, int64_t workspace_bytes,
-                                 fp_stream_t stream_) {
+                                 const fp_aux* aux, fp_stream_t stream_) {
   return igemm_split_operands("fp_conv_igemm_bf3", d, src, wpacked_bf3, bias, addend, addend_mask, actsrc, y, workspace, workspace_bytes, nullptr,
-                              nullptr, true, stream_);
+                              nullptr, true, aux, stream_);
 }

@@ -637,8 +637,9 @@ static int phase_fwd_split(const float* low, const void* wphase_bf3, const float
   return fp_check_launch("fp_conv_up2_phase_fwd_bf3 / _hp");
 }
 extern "C" int fp_conv_up2_phase_fwd_bf3(const float* low, const void* wphase_bf3, const float* bias, const float* addend, float* y,
-                                         int32_t N, int32_t h, int32_t w, int32_t C0, int32_t Nout, int32_t act, fp_stream_t stream) {
-  return phase_fwd_split(low, wphase_bf3, bias, addend, y, N, h, w, C0, Nout, act, nullptr, nullptr, fp_take_amax_out(), stream);
+                                         int32_t N, int32_t h, int32_t w, int32_t C0, int32_t Nout, int32_t act, const fp_aux* aux,
+                                         fp_stream_t stream) {
+  return phase_fwd_split(low, wphase_bf3, bias, addend, y, N, h, w, C0, Nout, act, nullptr, nullptr, fp_amax_out_of(aux), stream);
 }
 // fp16-pair operands (fp_conv3x3_hp): weights from FP_PACK_UP2_FWD_HP jobs / fp_pack_up2_weight_hp with the slot they were scaled by
 extern "C" int fp_conv_up2_phase_fwd_hp(const float* low, const void* wphase_hp, const float* bias, const float* addend, float* y, int32_t N,
@@ -684,8 +685,8 @@ extern "C" int fp_conv_up2_phase_dgrad_hp(const float* dz, const void* wpacked_h
 }
 
 extern "C" int fp_up2_fold_bwd(const float* ext, int32_t N, int32_t h, int32_t w, int32_t C, const float* addend, const float* ylow_elu,
-                               float* dlow, fp_stream_t stream) {
-  unsigned* amax_out = fp_take_amax_out();     // consumed first: an argument error below must not leave the sink armed
+                               float* dlow, const fp_aux* aux, fp_stream_t stream) {
+  unsigned* amax_out = fp_amax_out_of(aux);
   FP_REQUIRE(ext && dlow && N > 0 && h > 0 && w > 0 && C > 0 && C % 4 == 0, "fp_up2_fold_bwd: bad arguments");
   int g = grid_for((size_t)N * h * w * (C / 4));
   fp_launch(up2_fold_bwd_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, ext, N, h, w, C, addend, ylow_elu, dlow, amax_out);

@@ -293,17 +293,25 @@ __device__ __forceinline__ void fp_wf_merge(FpWf& a, const FpWf& b) {
   a.m2 += b.m2 + d * d * a.n * f;
   a.n = n;
 }
-// BatchNorm-statistics sink (include/footprints_hip.h, fp_bn_stats_out_next): consumed -- and cleared -- by this thread's next convolution launch
+// BatchNorm side output of a convolution launch (include/footprints_hip.h, fp_aux.bn_*)
 struct FpBnSink {
   float* part;
   int64_t cap_floats;
   int32_t* nblk_out;
-  const float* z;        // backward form (fp_bn_bwd_out_next): the BatchNorm's input and its saved statistics; null = forward statistics
+  const float* z;        // backward form (fp_aux.bnb_*): the BatchNorm's input and its saved statistics; null = forward statistics
   const float* mean;
   const float* invstd;
 };
-FpBnSink fp_take_bn_sink();       // api.cpp
-unsigned* fp_take_amax_out();     // api.cpp: the slot registered by fp_amax_out_next for this thread's next publishing launch (then cleared)
+// round 6: side outputs arrive as an explicit `const fp_aux*` argument (include/footprints_hip.h); these two read it (null = none)
+static inline FpBnSink fp_bn_sink_of(const fp_aux* aux) {
+  if (!aux || !aux->bn_part) {
+    if (aux && aux->bn_nblk_out) *aux->bn_nblk_out = 0;
+    return FpBnSink{nullptr, 0, nullptr, nullptr, nullptr, nullptr};
+  }
+  if (aux->bn_nblk_out) *aux->bn_nblk_out = 0;
+  return FpBnSink{aux->bn_part, aux->bn_capacity_floats, aux->bn_nblk_out, aux->bnb_z, aux->bnb_mean, aux->bnb_invstd};
+}
+static inline unsigned* fp_amax_out_of(const fp_aux* aux) { return aux ? aux->amax_out : nullptr; }
 __device__ __forceinline__ float fp_wave_max(float v);
 // one candidate per workgroup: every thread of the block calls this once (wave maxima through 64 bytes of shared scratch)
 __device__ __forceinline__ void fp_amax_publish_block(unsigned* slot, float m) {

@@ -661,8 +661,8 @@ extern "C" int fp_head_upsample_bwd(const float* dout_nchw, const float* low, fl
 }
 
 extern "C" int fp_head_dgrad(const float* dzlow, const float* w_oihw, const float* elu_src, float* dx, int32_t N, int32_t h,
-                             int32_t w, int32_t Cin, fp_stream_t stream) {
-  unsigned* amax_out = fp_take_amax_out();     // consumed first: an argument error below must not leave the sink armed
+                             int32_t w, int32_t Cin, const fp_aux* aux, fp_stream_t stream) {
+  unsigned* amax_out = fp_amax_out_of(aux);
   FP_REQUIRE(dzlow && w_oihw && dx, "fp_head_dgrad: null pointer");
   FP_REQUIRE(head_cin_ok(Cin) && h >= 2 && w >= 2, "fp_head_dgrad: unsupported Cin=%d", Cin);
   const HeadGrid g = head_grid(N, h, w, Cin, 16);

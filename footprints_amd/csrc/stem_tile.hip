@@ -576,7 +576,7 @@ int fp_stem_tile_dispatch(const fp_conv_desc* d, const float* img, const float* 
   a.N = d->N; a.IH = d->IH; a.IW = d->IW; a.OH = d->OH; a.OW = d->OW; a.act = d->act;
   a.tilesX = (int)fp_ceil_div(d->OW, TW); a.tilesY = (int)fp_ceil_div(d->OH, TH);
   a.bn_part = nullptr;
-  // statistics sink (fp_bn_stats_out_next, forward form): the stored value is the accumulator itself only without bias / activation
+  // statistics sink (fp_aux.bn_part, forward form): the stored value is the accumulator itself only without bias / activation
   const int64_t ntiles = (int64_t)d->N * a.tilesX * a.tilesY;
   if (sink.part && !sink.z && !a.bias && d->act == FP_ACT_NONE && ntiles * 64 * 3 <= sink.cap_floats) {
     a.bn_part = sink.part;
@@ -591,9 +591,9 @@ extern "C" int fp_conv_stem_hp_supported(const fp_conv_desc* d) {
          !(d->epi & ~(unsigned)FP_EPI_BIAS) && d->IH == 2 * d->OH && d->IW == 2 * d->OW && d->N > 0 && d->OH > 0 && d->OW > 0;
 }
 extern "C" int fp_conv_stem_hp(const fp_conv_desc* d, const float* img, const void* wpacked_hp, const float* bias, float* y, const uint32_t* amax_w,
-                               fp_stream_t stream) {
-  const FpBnSink sink = fp_take_bn_sink();
-  unsigned* amax_out = fp_take_amax_out();
+                               const fp_aux* aux, fp_stream_t stream) {
+  const FpBnSink sink = fp_bn_sink_of(aux);
+  unsigned* amax_out = fp_amax_out_of(aux);
   FP_REQUIRE(d && img && wpacked_hp && y && amax_w, "fp_conv_stem_hp: null pointer");
   FP_REQUIRE(fp_conv_stem_hp_supported(d), "fp_conv_stem_hp: shape not supported (see fp_conv_stem_hp_supported)");
   FP_REQUIRE(!(d->epi & FP_EPI_BIAS) || bias, "fp_conv_stem_hp: bias flag without pointer");

@@ -820,10 +820,10 @@ class Engine:
 
     def _conv_enc(self, c, x, N, H, W, out, bn=None, part="bn.part"):
         """encoder convolution; `bn` = the BatchNorm record that follows in train mode: a tile-kernel launch then also writes the
-        Welford partials of its output (ops.bn_stats_out_next) and _bn_coeffs skips the statistics pass over the activation"""
+        Welford partials of its output (ops.bn_stats_out -> the launch's fp_aux) and _bn_coeffs skips the statistics pass over the activation"""
         OH, OW = (H + 2 * c.pad - c.K) // c.stride + 1, (W + 2 * c.pad - c.K) // c.stride + 1
         d = ops.make_desc(N, OH, OW, H, W, c.Cin, 0, c.Cout, c.K, c.stride, c.pad, L.GATHER_FWD_ZERO)
-        cell = None
+        bo = None
         if bn is not None:
             bn.stats_nblk = 0
             tile = (c.wp3 is not None or (_HP_TILE and c.hp_f is not None and not ops._bf16x2)) and ops.conv3x3_bf3_supported(d)
@@ -837,10 +837,10 @@ class Engine:
                     rows = 256 // (c.Cout // 4) * 4
                     cap = max(cap, min(512, (N * OH * OW + rows - 1) // rows) * c.Cout * 3)
                 bn.stats_part = self.buf(part, (max(cap, 1),))      # (`part`: the shortcut branch runs beside conv1 on another stream: its own buffer)
-                cell = ops.bn_stats_out_next(bn.stats_part)
-        y = self._cv(d, x, c.wp, c.wp3, out, hp=(c.hp_f, c.wslot))
-        if cell is not None:
-            bn.stats_nblk = int(cell.value)
+                bo = ops.bn_stats_out(bn.stats_part)
+        y = self._cv(d, x, c.wp, c.wp3, out, hp=(c.hp_f, c.wslot), bn_out=bo)
+        if bo is not None:
+            bn.stats_nblk = bo.nblk
         return y
 
     @staticmethod
@@ -910,18 +910,18 @@ class Engine:
         # ---- encoder --------------------------------------------------------------------------------
         h, w = H // 2, W // 2
         z0 = buf("z0", (N, h, w, 64))
-        cell = None
+        bo = None
         if training and ops._BN_EPI:            # the stem's tile kernel writes the Welford partials of its output (one per 8 x 16 pixel tile and channel)
             self.bn0.stats_nblk = 0
             self.bn0.stats_part = buf("bn.part0", (N * ((h + 7) // 8) * ((w + 15) // 16) * 64 * 3,))
-            cell = ops.bn_stats_out_next(self.bn0.stats_part)
+            bo = ops.bn_stats_out(self.bn0.stats_part)
         d0 = ops.make_desc(N, h, w, H, W, 3, 0, 64, 7, 2, 3, L.GATHER_STEM)
         if self.stem.hp_f is not None and not ops._bf16x2 and ops.conv_stem_hp_supported(d0):
-            ops.conv_stem_hp(d0, image, self.stem.hp_f, z0, self.stem.wslot)
+            ops.conv_stem_hp(d0, image, self.stem.hp_f, z0, self.stem.wslot, bn_out=bo)
         else:
-            ops.conv_igemm(d0, image, None, self.stem.wp, z0)
-        if cell is not None:
-            self.bn0.stats_nblk = int(cell.value)
+            ops.conv_igemm(d0, image, None, self.stem.wp, z0, bn_out=bo)
+        if bo is not None:
+            self.bn0.stats_nblk = bo.nblk
         f0 = self._bn(self.bn0, z0, buf("f0", (N, h, w, 64)), training)
         hp, wp_ = (h + 1) // 2, (w + 1) // 2
         pool = buf("pool", (N, hp, wp_, 64))
@@ -1215,14 +1215,14 @@ class Engine:
         bwd_epi = ops._BN_BWD_EPI and (_HP_TILE or _BF3) and not ops._bf16x2
 
         def bnb_arm(name, h_, w_, C_, z, rec):
-            """arm the BatchNorm-backward sink for the next tile data gradient at (h_, w_, C_): partial sums per pixel tile (8 x 16 or 6 x 20
+            """the BatchNorm-backward side output (ops.BnOut) for a tile data gradient at (h_, w_, C_): partial sums per pixel tile (8 x 16 or 6 x 20
             pixels, bounded by 6 x 16-pixel ones) and channel"""
             cap = N * ((h_ + 5) // 6) * ((w_ + 15) // 16) * C_ * 2
             if C_ % 4 == 0 and 256 % (C_ // 4) == 0:              # split-K grids: one pair per block of the reduce launch (fp_splitk_reduce_bnb_launch)
                 rows = 256 // (C_ // 4) * 4
                 cap = max(cap, min(512, (N * h_ * w_ + rows - 1) // rows) * C_ * 2)
             part = buf(name, (max(cap, 1),))
-            return part, ops.bn_bwd_out_next(part, z.view(-1, C_), rec.mean, rec.invstd)
+            return part, ops.bn_bwd_out(part, z.view(-1, C_), rec.mean, rec.invstd)
         for i in range(nblk - 1, -1, -1):
             blk, B = self.blocks[i], S["blocks"][i]
             h, w, hin, win = B["h"], B["w"], B["hin"], B["win"]
@@ -1267,11 +1267,11 @@ class Engine:
             if bwd_epi and (blk.c2.hp_d is not None or blk.c2.wpd3 is not None) and ops.conv3x3_bf3_supported(d2):
                 # conv2's data gradient applies bn1's ReLU mask itself (da1 = gradient * (a1 > 0)) and emits bn1's backward sums
                 d2.epi = L.EPI_ACTGRAD_RELU
-                part, cell = bnb_arm("bnb.part1", h, w, C, B["z1"], blk.bn1)
-                self._cv(d2, dz2, blk.c2.wpd, blk.c2.wpd3, da1, hp=(blk.c2.hp_d, blk.c2.wslot), actsrc=B["a1"])
-                if cell.value > 0:
+                part, bo = bnb_arm("bnb.part1", h, w, C, B["z1"], blk.bn1)
+                self._cv(d2, dz2, blk.c2.wpd, blk.c2.wpd3, da1, hp=(blk.c2.hp_d, blk.c2.wslot), actsrc=B["a1"], bn_out=bo)
+                if bo.nblk > 0:
                     ops.bn_bwd_partials(da1.view(M, C), B["z1"].view(M, C), blk.bn1.mean, blk.bn1.invstd, blk.bn1.bn.weight.data,
-                                        dz1.view(M, C), blk.bn1.gg, blk.bn1.gb, part, cell.value, accumulate=accumulate,
+                                        dz1.view(M, C), blk.bn1.gg, blk.bn1.gb, part, bo.nblk, accumulate=accumulate,
                                         amax_out=self._sink_slot(dz1))
                 else:                                   # split grid: the mask is applied, the sums are not there
                     ops.bn_bwd(da1.view(M, C), None, B["z1"].view(M, C), blk.bn1.mean, blk.bn1.invstd, blk.bn1.bn.weight.data,
@@ -1321,10 +1321,10 @@ class Engine:
                     # masked by (input > 0), IS the g of the previous block's bn2 -- stored as such, with that BatchNorm's backward sums
                     Bp, blkp = S["blocks"][i - 1], self.blocks[i - 1]
                     dgd.epi = L.EPI_ACTGRAD_RELU
-                    part, cell = bnb_arm("bnb.part2", hin, win, Cin, Bp["z2"], blkp.bn2)
-                    self._cv(dgd, dz1, blk.c1.wpd, blk.c1.wpd3, dx, hp=(blk.c1.hp_d, blk.c1.wslot), addend=g, actsrc=B["x"])
-                    if cell.value > 0:
-                        dnext_part = (part, cell.value)
+                    part, bo = bnb_arm("bnb.part2", hin, win, Cin, Bp["z2"], blkp.bn2)
+                    self._cv(dgd, dz1, blk.c1.wpd, blk.c1.wpd3, dx, hp=(blk.c1.hp_d, blk.c1.wslot), addend=g, actsrc=B["x"], bn_out=bo)
+                    if bo.nblk > 0:
+                        dnext_part = (part, bo.nblk)
                     else:                               # masked, no sums: the regular backward below must not mask again -- it would not
                         dnext_part = None               # change anything (g * (out > 0) is idempotent), so it simply runs as before
                 else:

@@ -125,7 +125,7 @@ def make_desc(N, OH, OW, IH, IW, C0, C1, Nout, K, stride, pad, gather, act=0, ep
     return ConvDesc(N, OH, OW, IH, IW, C0, C1, Nout, K, K, stride, pad, gather, act, epi)
 
 
-def conv_igemm(desc, src0, src1, wpacked, y, bias=None, addend=None, addend_mask=None, actsrc=None):
+def conv_igemm(desc, src0, src1, wpacked, y, bias=None, addend=None, addend_mask=None, actsrc=None, bn_out=None):
     lib = _lib.load()
     epi = desc.epi
     if bias is not None:
@@ -142,7 +142,7 @@ def conv_igemm(desc, src0, src1, wpacked, y, bias=None, addend=None, addend_mask
         ws = workspace(need, y.device, "igemm")
         ws_ptr, ws_n = ws.data_ptr(), ws.numel()
     _lib.check(lib.fp_conv_igemm(C.byref(d), _f32(src0, "src0"), _f32(src1, "src1"), _f32(wpacked, "wpacked"), _f32(bias),
-                                 _f32(addend), _f32(addend_mask), _f32(actsrc), _f32(y, "y"), ws_ptr, ws_n, stream()), "fp_conv_igemm")
+                                 _f32(addend), _f32(addend_mask), _f32(actsrc), _f32(y, "y"), ws_ptr, ws_n, _aux(bn_out=bn_out), stream()), "fp_conv_igemm")
     return y
 
 
@@ -150,13 +150,13 @@ def conv_stem_hp_supported(desc):
     return bool(_cached_query("fp_conv_stem_hp_supported", desc))
 
 
-def conv_stem_hp(desc, img, wpacked_hp, y, amax_w, bias=None, amax_out=None):
-    """the 7x7 / 2 stem on the NCHW image with fp16-pair operands (weights from a PACK_STEM_HP job); honors the statistics and amax sinks"""
+def conv_stem_hp(desc, img, wpacked_hp, y, amax_w, bias=None, amax_out=None, bn_out=None):
+    """the 7x7 / 2 stem on the NCHW image with fp16-pair operands (weights from a PACK_STEM_HP job); optional side outputs: amax_out, bn_out"""
     d = ConvDesc.from_buffer_copy(desc)
     if bias is not None:
         d.epi |= _lib.EPI_BIAS
-    _sink(amax_out)
-    _lib.check(_lib.load().fp_conv_stem_hp(C.byref(d), _f32(img), _f32(wpacked_hp), _f32(bias), _f32(y), _u32(amax_w, "amax_w"), stream()),
+    _lib.check(_lib.load().fp_conv_stem_hp(C.byref(d), _f32(img), _f32(wpacked_hp), _f32(bias), _f32(y), _u32(amax_w, "amax_w"),
+                                           _aux(amax_out, bn_out), stream()),
                "fp_conv_stem_hp")
     return y
 
@@ -173,7 +173,7 @@ def conv_igemm_hp_supported(desc):
     return bool(_cached_query("fp_conv_igemm_hp_supported", desc))
 
 
-def conv_igemm_hp(desc, src, wpacked_hp, y, amax_src, amax_w, bias=None, addend=None, addend_mask=None, actsrc=None):
+def conv_igemm_hp(desc, src, wpacked_hp, y, amax_src, amax_w, bias=None, addend=None, addend_mask=None, actsrc=None, bn_out=None):
     """flattened implicit GEMM with fp16-pair operands (3x3 stride 2, 1x1, their data gradients): weights from FP_PACK_{FWD,DGRAD}_HP"""
     lib = _lib.load()
     epi = desc.epi
@@ -191,7 +191,8 @@ def conv_igemm_hp(desc, src, wpacked_hp, y, amax_src, amax_w, bias=None, addend=
         ws = workspace(need, y.device, "igemm")
         ws_ptr, ws_n = ws.data_ptr(), ws.numel()
     _lib.check(lib.fp_conv_igemm_hp(C.byref(d), _f32(src, "src"), _chk(wpacked_hp, "wpacked_hp"), _f32(bias), _f32(addend), _f32(addend_mask),
-                                    _f32(actsrc), _f32(y, "y"), ws_ptr, ws_n, _u32(amax_src), _u32(amax_w), stream()), "fp_conv_igemm_hp")
+                                    _f32(actsrc), _f32(y, "y"), ws_ptr, ws_n, _u32(amax_src), _u32(amax_w), _aux(bn_out=bn_out), stream()),
+               "fp_conv_igemm_hp")
     return y
 
 
@@ -202,7 +203,7 @@ def conv3x3_bf3_supported(desc):
 _bf16x2 = False      # opt-in inference mode of the bf16 tile kernel (Engine.forward sets it around an eval forward): two bf16 terms per operand
 
 
-def conv3x3_bf3(desc, src, wpacked_bf3, y, bias=None, addend=None, addend_mask=None, actsrc=None, src1=None):
+def conv3x3_bf3(desc, src, wpacked_bf3, y, bias=None, addend=None, addend_mask=None, actsrc=None, src1=None, bn_out=None):
     """3x3 stride-1 conv / data-gradient with exactly split bf16x3 operands (same semantics as conv_igemm; src1 = the skip tensor
     of the GATHER_FWD_REFLECT_UP2 concat)"""
     epi = desc.epi | (_lib.EPI_BIAS if bias is not None else 0) | (_lib.EPI_ADDEND if addend is not None else 0) | \
@@ -218,7 +219,7 @@ def conv3x3_bf3(desc, src, wpacked_bf3, y, bias=None, addend=None, addend_mask=N
         ws = workspace(need, y.device, "igemm")
         ws_ptr, ws_n = ws.data_ptr(), ws.numel()
     _lib.check(lib.fp_conv3x3_bf3(C.byref(d), _f32(src, "src"), _f32(src1, "src1"), _f32(wpacked_bf3, "wpacked"), _f32(bias), _f32(addend),
-                                  _f32(addend_mask), _f32(actsrc), _f32(y, "y"), ws_ptr, ws_n, stream()), "fp_conv3x3_bf3")
+                                  _f32(addend_mask), _f32(actsrc), _f32(y, "y"), ws_ptr, ws_n, _aux(bn_out=bn_out), stream()), "fp_conv3x3_bf3")
     return y
 
 
@@ -242,10 +243,34 @@ def _u32(t, what="slot"):
     return t.data_ptr()
 
 
-def _sink(amax_out):
-    """register `amax_out` with the library: the NEXT launch of this thread publishes max |its output| there (then the sink is cleared)"""
+class BnOut:
+    """BatchNorm partials out of a convolution's epilogue (fp_aux.bn_* of include/footprints_hip.h): pass as `bn_out=` to the convolution
+    call; afterwards `.nblk` = number of partial blocks the launch wrote (0 = it could not emit: run the BatchNorm's own reduction pass).
+    Forward statistics (count, mean, M2) with z2d None; the backward sums (sum g, sum g * xhat) of the BatchNorm whose input z2d and saved
+    statistics are given otherwise.  Round 6: an explicit argument of the launch -- rounds 3-5 armed a per-thread sink in the library."""
+
+    def __init__(self, part, z2d=None, save_mean=None, save_invstd=None):
+        self.part, self.z, self.mean, self.invstd = part, z2d, save_mean, save_invstd
+        self._n = C.c_int32(0)
+
+    @property
+    def nblk(self):
+        return int(self._n.value)
+
+
+def _aux(amax_out=None, bn_out=None):
+    """the `const fp_aux*` argument of one launch: None when there is nothing to ask for (the struct is read during the call only)"""
+    if amax_out is None and bn_out is None:
+        return None
+    a = _lib.Aux()
     if amax_out is not None:
-        _lib.load().fp_amax_out_next(_u32(amax_out, "amax_out"))
+        a.amax_out = _u32(amax_out, "amax_out")
+    if bn_out is not None:
+        bn_out._n.value = 0
+        a.bn_part, a.bn_capacity_floats, a.bn_nblk_out = _f32(bn_out.part, "part"), bn_out.part.numel(), C.pointer(bn_out._n)
+        if bn_out.z is not None:
+            a.bnb_z, a.bnb_mean, a.bnb_invstd = _f32(bn_out.z, "z"), _f32(bn_out.mean, "save_mean"), _f32(bn_out.invstd, "save_invstd")
+    return C.byref(a)
 
 
 def zero_u32(t):
@@ -286,7 +311,7 @@ def pack_conv_weight_hp(w, wp, slot, for_dgrad=False, amax_ready=False):
 
 
 def conv3x3_hp(desc, src, wpacked_hp, y, amax_src, amax_w, amax_out=None, bias=None, addend=None, addend_mask=None, actsrc=None, src1=None,
-               amax_src1=None):
+               amax_src1=None, bn_out=None):
     """conv3x3_bf3 with fp16-pair operands; amax_* are slots (see amax_f32); amax_out (zeroed by the caller) receives max |y|"""
     epi = desc.epi | (_lib.EPI_BIAS if bias is not None else 0) | (_lib.EPI_ADDEND if addend is not None else 0) | \
         (_lib.EPI_ADDEND_MASK if addend_mask is not None else 0)
@@ -300,11 +325,12 @@ def conv3x3_hp(desc, src, wpacked_hp, y, amax_src, amax_w, amax_out=None, bias=N
         ws_ptr, ws_n = ws.data_ptr(), ws.numel()
     _lib.check(lib.fp_conv3x3_hp(C.byref(d), _f32(src, "src"), _f32(src1, "src1"), _f32(wpacked_hp, "wpacked"), _f32(bias), _f32(addend),
                                  _f32(addend_mask), _f32(actsrc), _f32(y, "y"), ws_ptr, ws_n, _u32(amax_src, "amax_src"),
-                                 _u32(amax_src1, "amax_src1"), _u32(amax_w, "amax_w"), _u32(amax_out, "amax_out"), stream()), "fp_conv3x3_hp")
+                                 _u32(amax_src1, "amax_src1"), _u32(amax_w, "amax_w"), _u32(amax_out, "amax_out"), _aux(bn_out=bn_out), stream()),
+               "fp_conv3x3_hp")
     return y
 
 
-def conv_igemm_bf3(desc, src, wpacked_bf3, y, bias=None, addend=None, addend_mask=None, actsrc=None):
+def conv_igemm_bf3(desc, src, wpacked_bf3, y, bias=None, addend=None, addend_mask=None, actsrc=None, bn_out=None):
     """flattened implicit GEMM with EXACTLY split bf16x3 operands (3x3 stride 2, 1x1, their data gradients; the default operand format):
     weights from FP_PACK_{FWD,DGRAD}_BF3; shapes as conv_igemm_hp_supported"""
     lib = _lib.load()
@@ -323,7 +349,7 @@ def conv_igemm_bf3(desc, src, wpacked_bf3, y, bias=None, addend=None, addend_mas
         ws = workspace(need, y.device, "igemm")
         ws_ptr, ws_n = ws.data_ptr(), ws.numel()
     _lib.check(lib.fp_conv_igemm_bf3(C.byref(d), _f32(src, "src"), _chk(wpacked_bf3, "wpacked_bf3"), _f32(bias), _f32(addend), _f32(addend_mask),
-                                     _f32(actsrc), _f32(y, "y"), ws_ptr, ws_n, stream()), "fp_conv_igemm_bf3")
+                                     _f32(actsrc), _f32(y, "y"), ws_ptr, ws_n, _aux(bn_out=bn_out), stream()), "fp_conv_igemm_bf3")
     return y
 
 
@@ -476,9 +502,8 @@ def conv_up2_phase_dgrad_hp(dz, wpacked_hp, ext, amax_dz, amax_w):
 
 def conv_up2_phase_fwd_bf3(low, wphase_bf3, bias, y, act=0, addend=None, amax_out=None):
     N, h, w, C0 = low.shape
-    _sink(amax_out)
     _lib.check(_lib.load().fp_conv_up2_phase_fwd_bf3(_f32(low), _f32(wphase_bf3), _f32(bias), _f32(addend), _f32(y), N, h, w, C0, y.shape[3],
-                                                     int(act), stream()), "fp_conv_up2_phase_fwd_bf3")
+                                                     int(act), _aux(amax_out), stream()), "fp_conv_up2_phase_fwd_bf3")
     return y
 
 
@@ -519,8 +544,7 @@ def pack_conv_weight_dgrad_slice(w, wp, c_begin, c_count):
 
 def up2_fold_bwd(ext, dlow, addend=None, ylow=None, amax_out=None):
     N, h, w, Cn = dlow.shape
-    _sink(amax_out)
-    _lib.check(_lib.load().fp_up2_fold_bwd(_f32(ext), N, h, w, Cn, _f32(addend), _f32(ylow), _f32(dlow), stream()), "fp_up2_fold_bwd")
+    _lib.check(_lib.load().fp_up2_fold_bwd(_f32(ext), N, h, w, Cn, _f32(addend), _f32(ylow), _f32(dlow), _aux(amax_out), stream()), "fp_up2_fold_bwd")
     return dlow
 
 
@@ -598,8 +622,7 @@ def head_upsample_bwd(dout_nchw, low, dzlow, scale, c0, sigmoid):
 
 def head_dgrad(dzlow, w, dx, elu_src=None, amax_out=None):
     N, h, wd, Cin = dx.shape
-    _sink(amax_out)
-    _lib.check(_lib.load().fp_head_dgrad(_f32(dzlow), _f32(w), _f32(elu_src), _f32(dx), N, h, wd, Cin, stream()), "fp_head_dgrad")
+    _lib.check(_lib.load().fp_head_dgrad(_f32(dzlow), _f32(w), _f32(elu_src), _f32(dx), N, h, wd, Cin, _aux(amax_out), stream()), "fp_head_dgrad")
     return dx
 
 
@@ -622,16 +645,13 @@ def bn_train_stats(z2d, gamma, beta, running_mean, running_var, nbt, save_mean, 
                                      ws.numel(), stream()), "fp_bn_train_stats")
 
 
-# statistics out of the producing tile convolution's epilogue (csrc/conv3x3_tile_bf3.hip, fp_bn_stats_out_next): FP_BN_EPI=0 switches it off
+# statistics out of the producing tile convolution's epilogue (csrc/conv3x3_tile_bf3.hip, fp_aux.bn_part): FP_BN_EPI=0 switches it off
 _BN_EPI = bool(int(os.environ.get("FP_BN_EPI", "1")))
 
 
-def bn_stats_out_next(part):
-    """arm the statistics sink for this thread's next tile-convolution launch; returns the int32 cell the launch writes its number of
-    partial blocks into (0 = nothing emitted) -- read `.value` after the convolution call"""
-    n = C.c_int32(0)
-    _lib.check(_lib.load().fp_bn_stats_out_next(_f32(part, "part"), part.numel(), C.addressof(n)), "fp_bn_stats_out_next")
-    return n
+def bn_stats_out(part):
+    """forward statistics out of the next convolution's epilogue: conv(..., bn_out=bn_stats_out(part)), then `.nblk`"""
+    return BnOut(part)
 
 
 def bn_train_stats_partials(part, nblk, Cn, gamma, beta, running_mean, running_var, nbt, save_mean, save_invstd, scale, shift, eps=1e-5,
@@ -643,18 +663,14 @@ def bn_train_stats_partials(part, nblk, Cn, gamma, beta, running_mean, running_v
                                                       _f32(scale), _f32(shift), stream()), "fp_bn_train_stats_partials")
 
 
-# the BatchNorm-backward reduction out of the producing data gradient's epilogue (csrc/conv3x3_tile_bf3.hip, fp_bn_bwd_out_next): FP_BN_BWD_EPI=0
+# the BatchNorm-backward reduction out of the producing data gradient's epilogue (csrc/conv3x3_tile_bf3.hip, fp_aux.bnb_*): FP_BN_BWD_EPI=0
 # keeps fp_bn_bwd's own reduction pass
 _BN_BWD_EPI = bool(int(os.environ.get("FP_BN_BWD_EPI", "1")))
 
 
-def bn_bwd_out_next(part, z2d, save_mean, save_invstd):
-    """arm the backward sink for this thread's next tile data-gradient launch; returns the int32 cell it writes its number of partial
-    blocks into (0 = nothing emitted) -- read `.value` after the convolution call"""
-    n = C.c_int32(0)
-    _lib.check(_lib.load().fp_bn_bwd_out_next(_f32(part, "part"), part.numel(), C.addressof(n), _f32(z2d, "z"), _f32(save_mean), _f32(save_invstd)),
-               "fp_bn_bwd_out_next")
-    return n
+def bn_bwd_out(part, z2d, save_mean, save_invstd):
+    """backward sums (sum g, sum g * xhat) out of a tile data gradient's epilogue: conv(..., bn_out=bn_bwd_out(...)), then `.nblk`"""
+    return BnOut(part, z2d, save_mean, save_invstd)
 
 
 def bn_bwd_partials(g2d, z2d, save_mean, save_invstd, gamma, dz2d, dgamma, dbeta, part, nblk, accumulate=False, amax_out=None):
@@ -662,9 +678,8 @@ def bn_bwd_partials(g2d, z2d, save_mean, save_invstd, gamma, dz2d, dgamma, dbeta
     lib = _lib.load()
     M, Cn = z2d.shape
     coef = workspace(lib.fp_bn_workspace(M, Cn), z2d.device)
-    _sink(amax_out)
     _lib.check(lib.fp_bn_bwd_partials(_f32(g2d), _f32(z2d), _f32(save_mean), _f32(save_invstd), _f32(gamma), _f32(dz2d), _f32(dgamma),
-                                      _f32(dbeta), int(bool(accumulate)), M, Cn, _f32(part), int(nblk), coef.data_ptr(), stream()),
+                                      _f32(dbeta), int(bool(accumulate)), M, Cn, _f32(part), int(nblk), coef.data_ptr(), _aux(amax_out), stream()),
                "fp_bn_bwd_partials")
     return dz2d
 
@@ -682,8 +697,7 @@ def scale_rows(w, scale, out):
 
 def bn_apply(z2d, scale, shift, y2d, residual=None, relu=True, amax_out=None):
     M, Cn = z2d.shape
-    _sink(amax_out)
-    _lib.check(_lib.load().fp_bn_apply(_f32(z2d), _f32(scale), _f32(shift), _f32(residual), _f32(y2d), M, Cn, int(bool(relu)), stream()),
+    _lib.check(_lib.load().fp_bn_apply(_f32(z2d), _f32(scale), _f32(shift), _f32(residual), _f32(y2d), M, Cn, int(bool(relu)), _aux(amax_out), stream()),
                "fp_bn_apply")
     return y2d
 
@@ -693,17 +707,15 @@ def bn_bwd(dy2d, relu_out, z2d, save_mean, save_invstd, gamma, dz2d, dgamma, dbe
     lib = _lib.load()
     M, Cn = z2d.shape
     ws = workspace(lib.fp_bn_workspace(M, Cn), z2d.device)
-    _sink(amax_out)
     _lib.check(lib.fp_bn_bwd(_f32(dy2d), _f32(relu_out), _f32(z2d), _f32(save_mean), _f32(save_invstd), _f32(gamma), _f32(dz2d),
-                             _f32(g_out), _f32(dgamma), _f32(dbeta), int(bool(accumulate)), M, Cn, ws.data_ptr(), ws.numel(), stream()),
+                             _f32(g_out), _f32(dgamma), _f32(dbeta), int(bool(accumulate)), M, Cn, ws.data_ptr(), ws.numel(), _aux(amax_out), stream()),
                "fp_bn_bwd")
     return dz2d
 
 
 def maxpool_fwd(x, y, argmax, amax_out=None):
     N, H, W, Cn = x.shape
-    _sink(amax_out)
-    _lib.check(_lib.load().fp_maxpool_fwd(_f32(x), _f32(y), _chk(argmax), N, H, W, Cn, stream()), "fp_maxpool_fwd")
+    _lib.check(_lib.load().fp_maxpool_fwd(_f32(x), _f32(y), _chk(argmax), N, H, W, Cn, _aux(amax_out), stream()), "fp_maxpool_fwd")
     return y
 
 

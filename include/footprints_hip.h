@@ -67,6 +67,32 @@ typedef struct fp_conv_desc {
   uint32_t epi;       /* FP_EPI_* */
 } fp_conv_desc;
 
+/* Optional side outputs of ONE launch (round 6; replaces the per-thread fp_amax_out_next / fp_bn_stats_out_next / fp_bn_bwd_out_next sinks of
+ * rounds 3-5: the library holds no state between calls besides the calling thread's last error string).  Passed as `const fp_aux* aux` right
+ * before the stream argument of the entry points that can produce them; NULL = none; fields that an entry point cannot serve are ignored.
+ * The struct is read during the call only.
+ *   amax_out   amax slot (see "fp16-pair operands" below; zeroed by the caller) that also receives max |output| of the launch:
+ *              fp_bn_apply, fp_bn_bwd / fp_bn_bwd_partials (their dz), fp_maxpool_fwd, fp_up2_fold_bwd, fp_head_dgrad,
+ *              fp_conv_up2_phase_fwd_bf3, fp_conv_stem_hp.
+ *   bn_part    BatchNorm partials out of a convolution's epilogue -- fp_conv3x3_bf3 / fp_conv3x3_hp, fp_conv_igemm_bf3 / _hp (split grids: from
+ *              their reduce launch), fp_conv_stem_hp, fp_conv_igemm (stem gather):
+ *                bnb_z == NULL: a plain forward launch (no bias / addend / activation) in front of a train-mode BatchNorm writes Welford partials
+ *                  bn_part[pixel tile][Nout] = (count, mean, M2) of what it stores -> fp_bn_train_stats_partials;
+ *                bnb_z != NULL: a data gradient whose stored output IS g = dy * (relu_out > 0) of a train-mode BatchNorm (mask applied by its own
+ *                  FP_EPI_ACTGRAD_RELU epilogue, no FP_EPI_ACCUM) writes bn_part[pixel tile][Nout] = (sum g, sum g * xhat), xhat = (bnb_z - bnb_mean)
+ *                  * bnb_invstd of THAT BatchNorm -> fp_bn_bwd_partials.
+ *              *bn_nblk_out (host memory) = number of pixel tiles written, set before the call returns; 0 = nothing emitted (launch form cannot
+ *              emit, bn_capacity_floats too small): the caller then runs the BatchNorm's own reduction pass. */
+typedef struct fp_aux {
+  uint32_t* amax_out;
+  float* bn_part;
+  int64_t bn_capacity_floats;
+  int32_t* bn_nblk_out;
+  const float* bnb_z;
+  const float* bnb_mean;
+  const float* bnb_invstd;
+} fp_aux;
+
 /* Y[m][n] = epilogue( sum_{tap,k} A[m][tap,k] * Wp[tap][k][n] ).
  * Wp is the packed weight produced by fp_pack_conv_weight (fwd) / fp_pack_conv_weight_dgrad.
  * Replaces aten::convolution (+reflection_pad2d, upsample_nearest2d, cat, elu_) and the
@@ -76,7 +102,7 @@ typedef struct fp_conv_desc {
 int64_t fp_conv_igemm_workspace(const fp_conv_desc* d);
 int fp_conv_igemm(const fp_conv_desc* d, const float* src0, const float* src1, const float* wpacked,
                   const float* bias, const float* addend, const float* addend_mask, const float* actsrc,
-                  float* y, void* workspace, int64_t workspace_bytes, fp_stream_t stream);
+                  float* y, void* workspace, int64_t workspace_bytes, const fp_aux* aux, fp_stream_t stream);
 
 /* Weight gradient: dW (OIHW [Nout][C0+C1][KH][KW]) = sum_m A[m][tap,k] * dZ[m][n]; A gathered as the
  * matching forward conv (desc.gather is a FWD_* / STEM mode, desc.OH/OW = conv output dims).
@@ -134,7 +160,7 @@ int fp_conv3x3_bf3_supported(const fp_conv_desc* d);
 int64_t fp_conv3x3_bf3_workspace(const fp_conv_desc* d);   /* split-K scratch for small grids (0 = none) */
 int fp_conv3x3_bf3(const fp_conv_desc* d, const float* src, const float* src1, const void* wpacked_bf3, const float* bias,
                    const float* addend, const float* addend_mask, const float* actsrc, float* y, void* workspace,
-                   int64_t workspace_bytes, fp_stream_t stream);
+                   int64_t workspace_bytes, const fp_aux* aux, fp_stream_t stream);
 int64_t fp_packed_weight_elems_bf3(int32_t Cout, int32_t Cin, int32_t KH, int32_t KW, int32_t for_dgrad);
 int fp_pack_conv_weight_bf3(const float* w_oihw, void* wp, int32_t Cout, int32_t Cin, int32_t KH, int32_t KW,
                             int32_t for_dgrad, fp_stream_t stream);
@@ -150,10 +176,6 @@ int fp_pack_conv_weight_bf3(const float* w_oihw, void* wp, int32_t Cout, int32_t
 #endif
 #define FP_AMAX_ELEMS (FP_AMAX_SLOTS * FP_AMAX_STRIDE)     /* uint32 elements of storage per slot */
 int32_t fp_amax_slot_elems(void);        /* = FP_AMAX_ELEMS of the loaded build */
-/* amax sink: the NEXT launch issued by this thread through fp_bn_apply, fp_bn_bwd (its dz), fp_maxpool_fwd, fp_up2_fold_bwd, fp_head_dgrad or
- * fp_conv_up2_phase_fwd_bf3 also publishes max |output| into `slot` (zeroed by the caller); the registration is consumed by that
- * call.  Keeps the signatures of the element-wise producers unchanged. */
-int fp_amax_out_next(uint32_t* slot);
 int fp_zero_u32(uint32_t* p, int64_t n, fp_stream_t stream);
 int fp_amax_f32(const float* x, int64_t n, uint32_t* slot, fp_stream_t stream);          /* x 16-byte aligned; slot zeroed by the caller */
 int fp_weight_amax(const float* w, int64_t n, uint32_t* amax_slot, fp_stream_t stream);  /* zero + reduce */
@@ -167,7 +189,7 @@ int fp_pack_weights_amax(const fp_pack_job* jobs_dev, const int32_t* blk2job_dev
 int fp_conv3x3_hp(const fp_conv_desc* d, const float* src, const float* src1, const void* wpacked_hp, const float* bias,
                   const float* addend, const float* addend_mask, const float* actsrc, float* y, void* workspace,
                   int64_t workspace_bytes, const uint32_t* amax_src, const uint32_t* amax_src1, const uint32_t* amax_w,
-                  uint32_t* amax_out, fp_stream_t stream);
+                  uint32_t* amax_out, const fp_aux* aux, fp_stream_t stream);
 
 /* nearest-x2 phase kernels (conv_up2_phase.hip) with fp16-pair operands: weights from FP_PACK_UP2_FWD_HP / FP_PACK_UP2_DGRAD_HP jobs */
 int fp_conv_up2_phase_fwd_hp(const float* low, const void* wphase_hp, const float* bias, const float* addend, float* y, int32_t N,
@@ -212,7 +234,8 @@ int fp_conv_up2_phase_fwd(const float* low, const float* wphase, const float* bi
 int fp_pack_up2_weight_bf3(const float* w_oihw, void* wp, int32_t Cout, int32_t Cin, int32_t c_begin, int32_t c_count,
                            fp_stream_t stream);
 int fp_conv_up2_phase_fwd_bf3(const float* low, const void* wphase_bf3, const float* bias, const float* addend, float* y,
-                              int32_t N, int32_t h, int32_t w, int32_t C0, int32_t Nout, int32_t act, fp_stream_t stream);
+                              int32_t N, int32_t h, int32_t w, int32_t C0, int32_t Nout, int32_t act, const fp_aux* aux,
+                              fp_stream_t stream);
 /* Backward (the upsample_nearest2d_backward + reflection_pad2d_backward + convolution_backward(data) chain): d(low) is a
  * 4x4 stride-2 convolution over dZ.  Pack with fp_pack_up2_weight_dgrad (fp_up2_packed_weight_elems(c_count, Cout)
  * floats), run fp_conv_igemm{FWD_ZERO, K=4, stride 2, pad 3, IH=2h, OH=h+2} into ext[N][h+2][w+2][c_count], then
@@ -229,7 +252,7 @@ int fp_pack_up2_weight_dgrad_bf3(const float* w_oihw, void* wp, int32_t Cout, in
 int fp_conv_up2_phase_dgrad_bf3(const float* dz, const void* wpacked_bf3, float* ext, int32_t N, int32_t h, int32_t w,
                                 int32_t Cout, int32_t C0, fp_stream_t stream);
 int fp_up2_fold_bwd(const float* ext, int32_t N, int32_t h, int32_t w, int32_t C, const float* addend,
-                    const float* ylow_elu, float* dlow, fp_stream_t stream);
+                    const float* ylow_elu, float* dlow, const fp_aux* aux, fp_stream_t stream);
 /* Weight gradient of the upsampled half: dw_oihw[:, k_begin:k_begin+C0] (+)= un-collapse of the 16 per-phase products
  * (dw_oihw is [Nout][kc_total][3][3]).  fp_conv_up2_phase_wgrad_workspace returns -1 for shapes it does not take
  * (C0, Nout multiples of 32; <= 30 % padded 2x16 chunks) -- use fp_conv_wgrad{FWD_REFLECT_UP2} there.  The skip half is
@@ -269,7 +292,7 @@ int fp_head_upsample_bwd(const float* dout_nchw, const float* low, float* dzlow,
 /* dx[N][h][w][Cin] = conv^T(dzlow) with the reflection halo folded back (plain store);
  * elu_src != NULL: dx *= elu'(elu_src) (the head is the only consumer of an ELU output: outconv4, network.py:78-80) */
 int fp_head_dgrad(const float* dzlow, const float* w_oihw, const float* elu_src, float* dx, int32_t N, int32_t h, int32_t w,
-                  int32_t Cin, fp_stream_t stream);
+                  int32_t Cin, const fp_aux* aux, fp_stream_t stream);
 /* dw_oihw[2][Cin][3][3], db[2] (+)= ... ; deterministic two-stage */
 int64_t fp_head_wgrad_workspace(int32_t N, int32_t h, int32_t w, int32_t Cin);
 int fp_head_wgrad(const float* x, const float* dzlow, float* dw_oihw, float* db, int32_t N, int32_t h, int32_t w,
@@ -281,7 +304,7 @@ int fp_head_wgrad(const float* x, const float* dzlow, float* dw_oihw, float* db,
  * (bias flag, act); honors the statistics and amax sinks.  fp_conv_stem_hp_supported: Nout == 64, IH == 2 OH, IW == 2 OW. */
 int fp_conv_stem_hp_supported(const fp_conv_desc* d);
 int fp_conv_stem_hp(const fp_conv_desc* d, const float* img_nchw, const void* wpacked_hp, const float* bias, float* y,
-                    const uint32_t* amax_w, fp_stream_t stream);
+                    const uint32_t* amax_w, const fp_aux* aux, fp_stream_t stream);
 
 /* ... and the stem's weight gradient likewise (dW [64][3][7][7] (+)= ...; desc / workspace of fp_conv_wgrad on the STEM gather): the image
  * patch and the dZ tile are split into fp16 pairs in LDS, fragments by gfx950's transposing LDS read; `amax_dz` = amax slot of dz */
@@ -297,27 +320,17 @@ int fp_bn_train_stats(const float* z, int64_t M, int32_t C, const float* gamma, 
                       float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked,
                       float* save_mean, float* save_invstd, float* scale, float* shift, void* workspace,
                       int64_t workspace_bytes, fp_stream_t stream);
-/* Statistics out of the producing convolution's epilogue (round 3): fp_bn_stats_out_next arms a per-thread sink that the NEXT
- * fp_conv3x3_hp / fp_conv3x3_bf3 launch of this thread consumes (any other convolution entry point clears it).  A plain forward launch on
- * an unsplit grid (no bias / addend / activation) then also writes Welford partials part[pixel tile][Nout] = (count, mean, M2) of what
- * it stores and sets *nblk_out = number of pixel tiles (written before the call returns; 0 = nothing emitted: split-K grid, epilogue
- * options, capacity_floats < tiles * Nout * 3).  fp_bn_train_stats_partials is fp_bn_train_stats's second launch on such partials:
- * same outputs, the activation is not read for its statistics (torchvision BatchNorm2d behind footprints/network.py:38-44). */
-int fp_bn_stats_out_next(float* part, int64_t capacity_floats, int32_t* nblk_out);
+/* fp_bn_train_stats's second launch on Welford partials that the producing convolution's epilogue wrote (fp_aux.bn_part, bnb_z == NULL): same
+ * outputs, the activation is not read for its statistics (torchvision BatchNorm2d behind footprints/network.py:38-44). */
 int fp_bn_train_stats_partials(const float* part, int32_t nblk, int32_t C, const float* gamma, const float* beta, float eps,
                                float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked,
                                float* save_mean, float* save_invstd, float* scale, float* shift, fp_stream_t stream);
-/* The backward counterpart (round 4): fp_bn_bwd_out_next arms the same per-thread sink for the NEXT fp_conv3x3_hp / fp_conv3x3_bf3 launch when
- * that launch is a data gradient whose stored output IS g = dy * (relu_out > 0) of a train-mode BatchNorm (its ReLU mask applied by the
- * launch's own FP_EPI_ACTGRAD_RELU epilogue): on an unsplit grid without FP_EPI_ACCUM it also writes part[pixel tile][Nout] = (sum g,
- * sum g * xhat), xhat = (z - save_mean) * save_invstd, and sets *nblk_out = number of pixel tiles (0 = nothing emitted).
- * fp_bn_bwd_partials then runs fp_bn_bwd's combination + apply launches on them: fp_bn_bwd's reduction pass over (dy, relu_out, z) and its
- * launch are gone (the backward of torchvision BatchNorm2d behind footprints/network.py:38-44; coef = 2 C floats of scratch). */
-int fp_bn_bwd_out_next(float* part, int64_t capacity_floats, int32_t* nblk_out, const float* z, const float* save_mean,
-                       const float* save_invstd);
+/* The backward counterpart (round 4): fp_bn_bwd's combination + apply launches on partial sums (sum g, sum g * xhat) that a data gradient's
+ * epilogue wrote (fp_aux.bn_part with bnb_z / bnb_mean / bnb_invstd): fp_bn_bwd's reduction pass over (dy, relu_out, z) and its launch are gone
+ * (the backward of torchvision BatchNorm2d behind footprints/network.py:38-44; coef = 2 C floats of scratch). */
 int fp_bn_bwd_partials(const float* g, const float* z, const float* save_mean, const float* save_invstd, const float* gamma, float* dz,
                        float* dgamma, float* dbeta, int accumulate, int64_t M, int32_t C, const float* part, int32_t nblk, float* coef,
-                       fp_stream_t stream);
+                       const fp_aux* aux, fp_stream_t stream);
 /* eval mode: scale/shift from running statistics */
 int fp_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                       float eps, int32_t C, float* scale, float* shift, fp_stream_t stream);
@@ -333,21 +346,22 @@ int fp_scale_rows(const float* w, const float* scale, float* out, int64_t rows, 
 int fp_conv_igemm_hp_supported(const fp_conv_desc* d);
 int fp_conv_igemm_hp(const fp_conv_desc* d, const float* src, const void* wpacked_hp, const float* bias, const float* addend,
                      const float* addend_mask, const float* actsrc, float* y, void* workspace, int64_t workspace_bytes,
-                     const uint32_t* amax_src, const uint32_t* amax_w, fp_stream_t stream);
+                     const uint32_t* amax_src, const uint32_t* amax_w, const fp_aux* aux, fp_stream_t stream);
 /* ... and with EXACTLY split bf16x3 operands (round 5): the default operand format's path for the same convolutions -- x = h + m + l in
  * bf16, six MFMA products, no operand bit of fp32 dropped, no amax slots.  Weights from FP_PACK_FWD_BF3 / FP_PACK_DGRAD_BF3 jobs (any
  * kernel size; fp_packed_weight_elems_bf3 floats).  Shapes: fp_conv_igemm_hp_supported.  Replaces aten::convolution /
  * convolution_backward(data) of the stride-2 BasicBlock convs and the 1x1 downsample convs (footprints/network.py:38-44). */
 int fp_conv_igemm_bf3(const fp_conv_desc* d, const float* src, const void* wpacked_bf3, const float* bias, const float* addend,
-                      const float* addend_mask, const float* actsrc, float* y, void* workspace, int64_t workspace_bytes, fp_stream_t stream);
+                      const float* addend_mask, const float* actsrc, float* y, void* workspace, int64_t workspace_bytes, const fp_aux* aux,
+                      fp_stream_t stream);
 
 int fp_bn_apply(const float* z, const float* scale, const float* shift, const float* residual, float* y, int64_t M,
-                int32_t C, int32_t relu, fp_stream_t stream);
+                int32_t C, int32_t relu, const fp_aux* aux, fp_stream_t stream);
 /* backward: g = dy * (relu_out > 0 if relu_out) ; dgamma (+)= sum g*xhat ; dbeta (+)= sum g ;
  * dz = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)) ; g_out (optional) = g. */
 int fp_bn_bwd(const float* dy, const float* relu_out, const float* z, const float* save_mean, const float* save_invstd,
               const float* gamma, float* dz, float* g_out, float* dgamma, float* dbeta, int accumulate, int64_t M,
-              int32_t C, void* workspace, int64_t workspace_bytes, fp_stream_t stream);
+              int32_t C, void* workspace, int64_t workspace_bytes, const fp_aux* aux, fp_stream_t stream);
 
 /* ---- test-set inference output: [B][4][H][W] fp32 predictions -> float16 with sigmoid on channels 0, 1
  * (reference evaluation/inference.py:105-108, datasets/inference_dataset.py:35-38) ---- */
@@ -364,7 +378,7 @@ int fp_eval_depth_sums(const void* pred_disp, int32_t pred_is_half, const float*
 
 /* ---- maxpool 3x3 stride 2 pad 1 (encoder.maxpool, network.py:41) ---------- */
 int fp_maxpool_fwd(const float* x, float* y, uint8_t* argmax, int32_t N, int32_t H, int32_t W, int32_t C,
-                   fp_stream_t stream);
+                   const fp_aux* aux, fp_stream_t stream);
 int fp_maxpool_bwd(const float* dy, const uint8_t* argmax, float* dx, int32_t N, int32_t H, int32_t W, int32_t C,
                    int accumulate, fp_stream_t stream);
 

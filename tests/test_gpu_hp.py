@@ -50,12 +50,12 @@ def test_conv_stem_hp(N, H, W):
     y = torch.full((N, OH, OW, 64), float("nan"), device="cuda")
     tiles = N * ((OH + 7) // 8) * ((OW + 15) // 16)
     part = torch.full((tiles * 64 * 3,), float("nan"), device="cuda")
-    cell = ops.bn_stats_out_next(part)
+    cell = ops.bn_stats_out(part)
     so = ops.new_slot()
-    ops.conv_stem_hp(d, img.cuda(), wp, y, sw, amax_out=so)
+    ops.conv_stem_hp(d, img.cuda(), wp, y, sw, amax_out=so, bn_out=cell)
     torch.cuda.synchronize()
     check(nchw(y), ref, "stem hp", 2e-6)
-    assert cell.value == tiles and ops.amax_value(so) == float(y.abs().max())
+    assert cell.nblk == tiles and ops.amax_value(so) == float(y.abs().max())
     assert float(part.view(tiles, 64, 3)[:, :, 0].sum(0).min()) == float(N * OH * OW)
     g, b = rnd((64,), 812, 0.5, 1.5).cuda(), rnd((64,), 813).cuda()
     outs = [[torch.zeros(64, device="cuda") for _ in range(4)] for _ in range(2)]
@@ -69,10 +69,10 @@ def test_conv_stem_hp(N, H, W):
         for o in outs:
             assert relerr(o[k], want) < 2e-6, k
     y2 = torch.empty_like(y)                                       # bias + ReLU (the eval path's folded BatchNorm), no statistics
-    cell = ops.bn_stats_out_next(part)
+    cell = ops.bn_stats_out(part)
     d2 = ops.make_desc(N, OH, OW, H, W, 3, 0, 64, 7, 2, 3, L.GATHER_STEM, act=L.ACT_RELU)
-    ops.conv_stem_hp(d2, img.cuda(), wp, y2, sw, bias=b)
-    assert cell.value == 0
+    ops.conv_stem_hp(d2, img.cuda(), wp, y2, sw, bias=b, bn_out=cell)
+    assert cell.nblk == 0
     check(nchw(y2), torch.relu(ref + b.double().cpu().view(1, 64, 1, 1)), "stem hp + bias + relu", 2e-6)
 
 
@@ -116,7 +116,7 @@ def test_amax_reduction_and_zeroing():
 
 
 def test_producers_publish_their_exact_amax():
-    """fp_amax_out_next: bn_apply, bn_bwd (dz), maxpool_fwd, up2_fold_bwd, head_dgrad and the split-K reduce publish max |output| from
+    """fp_aux.amax_out: bn_apply, bn_bwd (dz), maxpool_fwd, up2_fold_bwd, head_dgrad and the split-K reduce publish max |output| from
     XCD-local atomics; repeated launches must never lose an update"""
     ops, L = _ops()
     torch.manual_seed(5)
@@ -247,7 +247,7 @@ def test_conv3x3_hp_dynamic_range_and_specials():
     (12, 6, 20, 256, 512, "reduce"),
 ])
 def test_conv3x3_hp_emits_batchnorm_partials(N, H, W, C0, Cout, emits):
-    """fp_bn_stats_out_next: the forward tile convolution in front of a train-mode BatchNorm writes (count, mean, M2) per pixel tile and
+    """fp_aux.bn_part: the forward tile convolution in front of a train-mode BatchNorm writes (count, mean, M2) per pixel tile and
     channel of what it stores; fp_bn_train_stats_partials turns them into the same coefficients as fp_bn_train_stats on the tensor"""
     ops, L = _ops()
     w = rnd((Cout, C0, 3, 3), 601, -0.1, 0.1)
@@ -262,10 +262,10 @@ def test_conv3x3_hp_emits_batchnorm_partials(N, H, W, C0, Cout, emits):
     if emits == "reduce":
         cap = max(cap, nred * Cout * 3)
     part = torch.full((cap,), float("nan"), device="cuda")
-    cell = ops.bn_stats_out_next(part)
-    ops.conv3x3_hp(d, xs, wp, y, slot_of(xs), sw)
+    cell = ops.bn_stats_out(part)
+    ops.conv3x3_hp(d, xs, wp, y, slot_of(xs), sw, bn_out=cell)
     torch.cuda.synchronize()
-    expect_tiles = cell.value
+    expect_tiles = cell.nblk
     if emits == "reduce":
         assert expect_tiles == nred
     else:
@@ -305,7 +305,7 @@ def test_conv3x3_hp_emits_batchnorm_partials(N, H, W, C0, Cout, emits):
 ])
 @pytest.mark.parametrize("fmt", ["fp16_pair", "exact"])
 def test_conv3x3_hp_data_gradient_emits_batchnorm_backward_sums(N, H, W, C, emits, fmt):
-    """fp_bn_bwd_out_next: a tile data gradient whose epilogue applies the ReLU mask stores g = (dgrad + residual) * (out > 0) of the
+    """fp_aux.bn_part + bnb_*: a tile data gradient whose epilogue applies the ReLU mask stores g = (dgrad + residual) * (out > 0) of the
     BatchNorm below it AND that BatchNorm's backward sums (sum g, sum g * xhat) per pixel tile and channel; fp_bn_bwd_partials turns them into
     the same dz / dgamma / dbeta as fp_bn_bwd on (dy, relu_out, z) -- against float64 (torchvision BatchNorm2d backward)."""
     ops, L = _ops()
@@ -336,11 +336,11 @@ def test_conv3x3_hp_data_gradient_emits_batchnorm_backward_sums(N, H, W, C, emit
         wp, sw = pack_bf3(w, dgrad=True), None
     gzs, zs = nhwc(gz), nhwc(z)
 
-    def conv(dst, amax_out=None):
+    def conv(dst, amax_out=None, bn_out=None):
         if hp:
-            ops.conv3x3_hp(d, gzs, wp, dst, slot_of(gzs), sw, amax_out=amax_out, addend=nhwc(resid), actsrc=nhwc(out))
+            ops.conv3x3_hp(d, gzs, wp, dst, slot_of(gzs), sw, amax_out=amax_out, addend=nhwc(resid), actsrc=nhwc(out), bn_out=bn_out)
         else:
-            ops.conv3x3_bf3(d, gzs, wp, dst, addend=nhwc(resid), actsrc=nhwc(out))
+            ops.conv3x3_bf3(d, gzs, wp, dst, addend=nhwc(resid), actsrc=nhwc(out), bn_out=bn_out)
     mean_d, invstd_d = mean.float().cuda(), invstd.float().cuda()
     cap = N * ((H + 5) // 6) * ((W + 15) // 16) * C * 2
     rows = 256 // (C // 4) * 4
@@ -349,11 +349,11 @@ def test_conv3x3_hp_data_gradient_emits_batchnorm_backward_sums(N, H, W, C, emit
         cap = max(cap, nred * C * 2)
     part = torch.full((cap,), float("nan"), device="cuda")
     gout = torch.empty((N, H, W, C), device="cuda")
-    cell = ops.bn_bwd_out_next(part, zs.view(-1, C), mean_d, invstd_d)
+    cell = ops.bn_bwd_out(part, zs.view(-1, C), mean_d, invstd_d)
     so = ops.new_slot()
-    conv(gout, so)
+    conv(gout, so, cell)
     torch.cuda.synchronize()
-    tiles = cell.value
+    tiles = cell.nblk
     if emits == "reduce":
         assert tiles == nred
     else:

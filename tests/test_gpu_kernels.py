@@ -106,15 +106,15 @@ def test_conv_stem(N, H, W):
     d = ops.make_desc(N, OH, OW, H, W, 3, 0, 64, 7, 2, 3, L.GATHER_STEM)
     ops.conv_igemm(d, img.cuda(), None, pack(w, stem=True), y)
     check(nchw(y), ref, "conv_stem")
-    # the statistics sink (fp_bn_stats_out_next): (count, mean, M2) per 8 x 16 pixel tile and channel out of the stem's epilogue -> the same
+    # the statistics side output (fp_aux.bn_part): (count, mean, M2) per 8 x 16 pixel tile and channel out of the stem's epilogue -> the same
     # BatchNorm coefficients as the reduction over the stored tensor; one-shot; ragged tiles at the right / bottom edge count only real pixels
     tiles = N * ((OH + 7) // 8) * ((OW + 15) // 16)
     part = torch.full((tiles * 64 * 3 + 5,), float("nan"), device="cuda")
-    cell = ops.bn_stats_out_next(part)
+    cell = ops.bn_stats_out(part)
     y2 = torch.empty_like(y)
-    ops.conv_igemm(d, img.cuda(), None, pack(w, stem=True), y2)
+    ops.conv_igemm(d, img.cuda(), None, pack(w, stem=True), y2, bn_out=cell)
     torch.cuda.synchronize()
-    assert cell.value == tiles and torch.equal(y, y2)
+    assert cell.nblk == tiles and torch.equal(y, y2)
     used = tiles * 64 * 3
     assert not bool(torch.isnan(part[:used]).any()) and bool(torch.isnan(part[used:]).all())
     assert float(part[:used].view(tiles, 64, 3)[:, :, 0].sum(0).min()) == float(N * OH * OW) == float(part[:used].view(tiles, 64, 3)[:, :, 0].sum(0).max())
@@ -130,10 +130,10 @@ def test_conv_stem(N, H, W):
         for o in outs:
             assert float((o[k].double().cpu() - want).abs().max() / want.abs().max()) < 2e-6, k
     assert torch.allclose(rms[0], rms[1], rtol=1e-6, atol=1e-7) and torch.allclose(rvs[0], rvs[1], rtol=1e-6, atol=1e-7)
-    cell = ops.bn_stats_out_next(part)                             # a launch that cannot emit (bias) consumes the sink and reports 0
+    cell = ops.bn_stats_out(part)                                  # a launch that cannot emit (bias) reports 0
     d.epi = L.EPI_BIAS
-    ops.conv_igemm(d, img.cuda(), None, pack(w, stem=True), y2, bias=b)
-    assert cell.value == 0
+    ops.conv_igemm(d, img.cuda(), None, pack(w, stem=True), y2, bias=b, bn_out=cell)
+    assert cell.nblk == 0
 
 
 # ----------------------------------------------------------------------------------------------------------

@@ -54,8 +54,35 @@ def test_workspace_queries_and_argument_validation_without_gpu():
     assert lib.fp_packed_weight_elems(8, 20, 3, 3, 0, 0) == 9 * 2 * 8 * 16
     assert lib.fp_loss_workspace(12, 192, 640) > 0
     bad = ops.make_desc(2, 8, 8, 8, 8, 6, 0, 8, 3, 1, 1, _lib.GATHER_FWD_REFLECT)     # C0 not a multiple of 4
-    rc = lib.fp_conv_igemm(C.byref(bad), 1, 0, 1, 0, 0, 0, 0, 1, None, 0, None)
+    rc = lib.fp_conv_igemm(C.byref(bad), 1, 0, 1, 0, 0, 0, 0, 1, None, 0, None, None)
     assert rc == -1 and b"multiples of 4" in lib.fp_last_error_string()
+    # round 6: side outputs are an explicit `const fp_aux*` argument; a launch that fails its argument checks reports "nothing emitted"
+    n = C.c_int32(7)
+    aux = _lib.Aux()
+    aux.bn_part, aux.bn_capacity_floats, aux.bn_nblk_out = 1, 1 << 20, C.pointer(n)
+    rc = lib.fp_conv_igemm(C.byref(bad), 1, 0, 1, 0, 0, 0, 0, 1, None, 0, C.byref(aux), None)
+    assert rc == -1 and n.value == 0
+
+
+def test_no_hidden_state_in_the_c_abi():
+    """VERDICT r5 "Next" 8: the `*_out_next` sinks are gone -- no such symbol in the header, the binding or the library, fp_aux's layout in the
+    binding equals the header's field list, and the only thread-local object of api.cpp is the error string"""
+    import ctypes as C
+    from footprints_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "footprints_hip.h")).read()
+    decls = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)                       # declarations only: the comments may mention the old names
+    assert "_out_next" not in decls and not [n for n in _lib.SIGNATURES if n.endswith("_next")]
+    lib = _lib.load()
+    for old in ("fp_amax_out_next", "fp_bn_stats_out_next", "fp_bn_bwd_out_next"):
+        assert not hasattr(lib, old), old
+    body = re.search(r"typedef struct fp_aux \{(.*?)\} fp_aux;", decls, flags=re.S).group(1)
+    fields = [re.findall(r"(\w+)\s*;", line)[0] for line in body.splitlines() if ";" in line]
+    assert fields == [f[0] for f in _lib.Aux._fields_], (fields, _lib.Aux._fields_)
+    assert C.sizeof(_lib.Aux) == 7 * 8
+    api = open(os.path.join(ROOT, "footprints_amd", "csrc", "api.cpp")).read()
+    assert re.findall(r"thread_local\s+[^;=]*?(\w+)\s*(?:\[|=|;)", api) == ["g_err"]
+    n_aux = sum(1 for sig in _lib.SIGNATURES.values() if _lib._AUX in sig[1])
+    assert n_aux == 13 and decls.count("const fp_aux* aux") == n_aux
 
 
 def test_hp_host_side_contract_without_gpu():
@@ -81,7 +108,7 @@ def test_hp_host_side_contract_without_gpu():
     assert lib.fp_conv3x3_bf3_workspace(C.byref(small)) > 0
     mid = ops.make_desc(12, 12, 40, 12, 40, 256, 0, 256, 3, 1, 1, _lib.GATHER_FWD_ZERO)      # 180 tiles: unsplit since round 2
     assert lib.fp_conv3x3_bf3_workspace(C.byref(mid)) == 0
-    rc = lib.fp_conv3x3_hp(C.byref(d), 1, 0, 1, 0, 0, 0, 0, 1, None, 0, None, None, None, None, None)      # amax slots missing
+    rc = lib.fp_conv3x3_hp(C.byref(d), 1, 0, 1, 0, 0, 0, 0, 1, None, 0, None, None, None, None, None, None)      # amax slots missing
     assert rc == -1 and b"amax slots missing" in lib.fp_last_error_string()
     rc = lib.fp_conv_wgrad_hp(C.byref(d), 1, 1, 1, 0, 64, 0, 0, 1, 1 << 30, None, None, None)
     assert rc == -1 and b"amax slots missing" in lib.fp_last_error_string()
