@@ -649,10 +649,10 @@ def compact_record(out, detail_path=None):
         rec["config"]["operand_format"] = out["operand_format"]
     ge = cfg.get("gradient_exchange")
     if ge:
-        rec["config"]["gradient_exchange"] = _pick(ge, ("transport", "buckets", "overlap_with_backward", "rccl_ranks"))
+        rec["config"]["gradient_exchange"] = _pick(ge, ("transport", "buckets", "overlap_with_backward", "in_launch_plan", "rccl_ranks"))
         ex = ge.get("exposed_communication")
         if ex:
-            rec["config"]["gradient_exchange"]["exposed_ms"] = ex.get("exposed_ms")
+            rec["config"]["gradient_exchange"].update(_pick(ex, ("exposed_ms", "step_ms_with_exchange", "step_ms_without_exchange")))
     rf = out.get("roofline")
     if rf:
         r = _pick(rf, ("bound", "achieved", "peak", "unit", "frac"))

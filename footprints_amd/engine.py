@@ -560,8 +560,7 @@ class Engine:
             n *= s
         t = self._bufs.get(name)
         if t is None or t.numel() < n or t.dtype != dtype:
-            if t is not None and _NEED32_SYNC and not torch.cuda.is_current_stream_capturing():
-                torch.cuda.synchronize(self.device)   # replacing a buffer drops the old one: kernels of the previous shape may still be using it (ops.workspace says why)
+            ops.release(t, "arena:" + name)           # replacing a buffer drops the old one: kernels of the previous shape may still be using it
             t = torch.empty(max(n, 1), dtype=dtype, device=self.device)
             self._bufs[name] = t
             self.amax.name_of[t.data_ptr()] = name

@@ -104,17 +104,33 @@ def _cached_query(fn, desc):
     return v
 
 
+_RELEASE_SYNC = bool(int(os.environ.get("FP_RELEASE_SYNC", "1")))
+_release_hooks = []      # test instrumentation (tests/test_gpu_lifetime.py): callables (old tensor, what) run whenever a buffer is let go
+
+
+def release(old, what):
+    """Every place that REPLACES a device buffer which earlier launches were handed (a workspace that grows, an arena buffer of the engine
+    that is re-allocated) lets go of the old one through here.  Kernels that follow on the stream are ordered behind the launches that used
+    it; what the HOST does next is not -- the caching allocator hands the block out again at once, and a small pageable host-to-device copy
+    into it does not wait for kernels still writing there (round 5, profiles/round5_notes.md section 7: a split-K convolution's late partial
+    sums landed on a pack-job table).  So: wait for the device first (start-up and shape changes only; never under stream capture, where the
+    pool keeps captured blocks alive), then tell the hooks -- the lifetime stress test fills the old block with a sentinel on an idle stream
+    and checks afterwards that nothing wrote into it (round 6, VERDICT r5 "Next" 9)."""
+    if old is None:
+        return
+    if _RELEASE_SYNC and not torch.cuda.is_current_stream_capturing():
+        torch.cuda.synchronize(old.device)
+    for hook in _release_hooks:
+        hook(old, what)
+
+
 def workspace(nbytes, device, tag="main"):
-    """Grow-only scratch buffer per (device, stream, tag).  Kernels that follow on the stream are ordered behind the launches that used it;
-    what the HOST does next is not -- a growth drops the old buffer, the caching allocator hands it out again at once, and a small
-    pageable host-to-device copy into it does not wait for kernels still writing partial sums there (round 5, profiles/round5_notes.md
-    section 7): a growth therefore waits for the device first."""
+    """Grow-only scratch buffer per (device, stream, tag); a growth lets go of the old buffer through `release` (which says why it waits)."""
     # one scratch buffer per (device, stream, tag): kernels on concurrent streams must not share partials
     key = (device.index, stream(), tag)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
-        if ws is not None and not torch.cuda.is_current_stream_capturing():
-            torch.cuda.synchronize(device)          # growth drops the old buffer: nothing may still be reading its partial sums (rare: start-up only)
+        release(ws, "workspace:%s" % tag)
         ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         _workspaces[key] = ws
         bump_alloc_generation()

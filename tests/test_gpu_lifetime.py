@@ -1,0 +1,155 @@
+"""GPU: buffer lifetimes under launches still in flight (round 6, VERDICT r5 "Next" 9).
+
+Round 5's whole-suite failure (profiles/round5_notes.md section 7) was a host-side free racing kernels: a split-K workspace was dropped while
+the previous convolution was still reducing its partial sums in it, the caching allocator handed the block out again, and the late writes landed
+on somebody else's data.  It was only seen through the garbage collector's timing under one exact test selection.  This test makes the class
+deterministic:
+
+  * every place that lets go of a device buffer goes through `ops.release` (workspace growth, arena re-allocation); a hook keeps each released
+    block alive, fills it with a sentinel on an otherwise idle stream THE MOMENT the host lets go of it -- exactly what a new owner would do --
+    and, after the run, checks that the sentinel is intact: a kernel that was still using the block would have written into it;
+  * a spin kernel (`torch.cuda._sleep`) in front of every step keeps the launch queue deep, so "still in flight when the host gets there" does
+    not depend on timing;
+  * the steps run at four pyramid sizes (the tiny ones are the r5 repro: every convolution a first touch and a split-K grid) in three orders,
+    each on a fresh engine, and their outputs and gradients must be bit-identical to the same steps run one at a time with a device
+    synchronize in between (same kernels, same order => same bits, whatever the allocator did);
+  * the detector has teeth: with the wait in `ops.release` switched off the same run damages the sentinel (asserted).
+"""
+import random
+from collections import OrderedDict
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [(1, 64, 64), (2, 64, 96), (1, 96, 128), (2, 128, 160)]          # (batch, H, W): growing and shrinking pyramids (the tiny ones: every conv a split-K grid)
+SENTINEL = 0xA5
+SPIN = 2e8               # cycles of torch.cuda._sleep in front of every step (~0.1 s): the host finishes issuing a step long before the device starts it
+_BATCHES = {}
+
+
+def _state():
+    """parameters and buffers resident on the device: re-loading them before every step is then a set of asynchronous device copies (a
+    pageable host copy would drain the launch queue the test wants deep)"""
+    from oracle import restatement as R
+    P, B = R.make_state(tag="life")
+    return OrderedDict((k, v.cuda()) for k, v in P.items()), OrderedDict((k, v.cuda()) for k, v in B.items())
+
+
+def _batch(size):
+    from oracle import restatement as R
+    b, h, w = size
+    if size not in _BATCHES:
+        _BATCHES[size] = {k: v.cuda() for k, v in R.make_batch(b, h, w, tag="life%dx%dx%d" % size).items()}
+    return _BATCHES[size]
+
+
+def _step(model, lm, P, B, cpu_batch, spin):
+    """reload the state (weights dirty -> repack, lazily packed layouts -> first touches), one train-mode forward + loss + backward"""
+    model.load_state_dict({**P, **B})
+    model.train()
+    batch = cpu_batch                                    # (already on the device, see _batch)
+    if spin:
+        torch.cuda._sleep(int(spin))                     # the launches below queue up behind this: the host runs ahead of the device
+    out = model(batch["image"])
+    losses = lm(out, batch)
+    model.zero_grad()
+    losses["loss"].backward()
+    res = OrderedDict(("out." + k, v.detach().clone()) for k, v in out.items())
+    res.update(("grad." + n, p.grad.detach().clone()) for n, p in model.named_parameters() if p.grad is not None)
+    return res
+
+
+class _Sentinels:
+    """ops.release hook: own every released block, fill it at once from an idle stream, verify later"""
+
+    def __init__(self):
+        self.stream = torch.cuda.Stream()
+        self.held = []
+
+    def __call__(self, old, what):
+        flat = old.view(-1).view(torch.uint8)
+        with torch.cuda.stream(self.stream):
+            flat.fill_(SENTINEL)
+        self.held.append((what, old, flat))
+
+    def damaged(self):
+        torch.cuda.synchronize()
+        bad = []
+        for what, _, flat in self.held:
+            n = int((flat != SENTINEL).sum())
+            if n:
+                bad.append((what, n, flat.numel()))
+        return bad
+
+
+def _run(orders, spin):
+    from footprints_amd import FootprintNetwork, ops
+    from footprints_amd.training.losses import LossManager
+    P, B = _state()
+    lm = LossManager((0.1, 100), 0.25, compute_viz=False)
+    hook = _Sentinels()
+    ops._release_hooks.append(hook)
+    results = []
+    try:
+        for order in orders:
+            ops._workspaces.clear()                      # a fresh engine AND fresh scratch: every repetition grows its buffers again
+            model = FootprintNetwork(pretrained=False).cuda()
+            for size in order:
+                results.append((size, _step(model, lm, P, B, _batch(size), spin)))
+            torch.cuda.synchronize()
+            del model
+    finally:
+        ops._release_hooks.remove(hook)
+    return results, hook
+
+
+def _orders():
+    rng = random.Random(6)
+    asc = sorted(SIZES, key=lambda s: s[0] * s[1] * s[2])
+    o2, o3 = SIZES[:], SIZES[:]
+    rng.shuffle(o2)
+    rng.shuffle(o3)
+    return [asc + asc[::-1], o2 + o3, o3[::-1] + asc]
+
+
+def test_no_buffer_is_released_under_launches_still_in_flight():
+    from footprints_amd import FootprintNetwork
+    from footprints_amd.training.losses import LossManager
+    P, B = _state()
+    lm = LossManager((0.1, 100), 0.25, compute_viz=False)
+    # calm reference: one size at a time on its own engine, device drained around every step
+    ref = {}
+    for size in SIZES:
+        model = FootprintNetwork(pretrained=False).cuda()
+        torch.cuda.synchronize()
+        ref[size] = _step(model, lm, P, B, _batch(size), spin=0)
+        torch.cuda.synchronize()
+        del model
+    results, hook = _run(_orders(), spin=SPIN)
+    assert len(hook.held) >= 8, "the stress run must actually release buffers (got %d)" % len(hook.held)
+    bad = hook.damaged()
+    assert not bad, "blocks written to AFTER the host released them (what, bytes damaged, bytes): %s" % bad[:6]
+    for size, res in results:
+        for k, v in res.items():
+            assert torch.equal(v, ref[size][k]), "%s at %s differs from the calm run (max |d| %.3e)" % (k, size, float((v - ref[size][k]).abs().max()))
+    print("\n[lifetime] %d steps, %d released blocks (%s), all sentinels intact, all results bit-identical to the calm run" % (
+        len(results), len(hook.held), sorted({w.split(":")[0] for w, _, _ in hook.held})))
+
+
+def test_the_detector_fires_without_the_wait():
+    """negative control: the same run with ops.release's device wait switched off must leave damaged sentinels -- launches queued behind the spin
+    kernel write into blocks the host has already given away"""
+    from footprints_amd import ops
+    was = ops._RELEASE_SYNC
+    ops._RELEASE_SYNC = False
+    try:
+        _, hook = _run(_orders()[:1], spin=SPIN)
+    finally:
+        ops._RELEASE_SYNC = was
+        torch.cuda.synchronize()
+        ops._workspaces.clear()                          # nothing of this run is reused
+    bad = hook.damaged()
+    print("\n[lifetime, wait off] %d released blocks, %d damaged: %s" % (len(hook.held), len(bad), bad[:4]))
+    assert bad, "with the wait off, in-flight launches must have written into released blocks -- the detector saw nothing"
