@@ -325,6 +325,7 @@ class Engine:
         self.wg = pool[lay[1]]      # encoder weight gradients, side part of the weight repack
         self.dwg = [pool[lay[2]], pool[lay[3]]]   # decoder weight gradients
         tiny = torch.zeros(64, device=self.device)
+        torch.cuda.synchronize(self.device)          # `tiny` may sit in a recycled block: its previous owner's queued work first (see _flatten)
         for st in pool:
             with ops.on_stream(st):
                 ops.fill(tiny, 0.0)
@@ -353,6 +354,14 @@ class Engine:
                 v.copy_(p.data)
                 p.data = v
                 self.grad_views.append(self.flat_grad[o:o + p.numel()].view(p.shape))
+        # `p.data = v` dropped the last reference to every original parameter storage while the copies OUT of them are only queued: the caching
+        # allocator hands those blocks to the next allocations of this stream at once -- fine for launches on this stream, not for a block that
+        # is then first written from ANOTHER stream (the start-up fills of the side streams below, arena buffers of the decoder streams).  With
+        # work pending on the stream when the engine is built (a long kernel, a broadcast), 64 floats of a head's weights were zeroed before
+        # they were copied (round 6: found by tests/test_gpu_lifetime.py behind a spin kernel; first step of a fresh engine only).  Start-up
+        # and re-flattening only: wait for the copies.
+        if not torch.cuda.is_current_stream_capturing():
+            torch.cuda.synchronize(self.device)
         gv = dict(zip(self.live_names, self.grad_views))
 
         def bind_conv(c):
