@@ -109,6 +109,66 @@ def network_conv_gflop(n, h, w):
     return fwd / 1e9, tot / 1e9
 
 
+def step_algorithmic_bytes(n, h, w):
+    """fused-minimum HBM bytes of ONE training step, fp32, by SURVEY.md section 8(d)'s per-convolution rule applied to every convolution of
+    the network (VERDICT r5 "Next" 7): forward 4 (|X_unique| + |Y| + |W| + |b|), backward 4 (2 |Y| + 2 |X_unique| + 2 (|W| + |b|)) -- read dY, Y, X,
+    W; write dX, dW -- with padding / upsampling / concatenation never materialised and BatchNorm / ReLU / residual / max-pool fused into
+    their neighbours (the encoder's element-wise passes cost nothing extra at the fused minimum: that is what makes it a floor).  Heads count
+    their low-resolution output.  Plus the loss (reads 4 scales x 4 channels of predictions and the target maps, writes the prediction
+    gradients) and Adam (reads p, g, m, v; writes p, m, v).  Checks: decoders forward / backward and the loss reproduce SURVEY's 3.544 /
+    7.018 / 0.224 GB at 12x192x640 (tests/test_bench_launch_cpu.py).  Returns GB per family and the total."""
+    def conv(xu, y, cin, cout, k, bias):
+        wb = cout * cin * k * k + (cout if bias else 0)
+        return 4.0 * (xu + y + wb), 4.0 * (2 * y + 2 * xu + 2 * wb)
+    ef = eb = 0.0
+    f, b = conv(n * h * w * 3, n * (h // 2) * (w // 2) * 64, 3, 64, 7, False)            # stem (its input gradient is not needed: counted anyway, 3 channels)
+    ef, eb = ef + f, eb + b
+    res, cin = (h // 4, w // 4), 64
+    for cout, blocks, stride in ((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2)):
+        for bi in range(blocks):
+            s_ = stride if bi == 0 else 1
+            rin = res
+            res = (res[0] // s_, res[1] // s_)
+            px_in, px = n * rin[0] * rin[1], n * res[0] * res[1]
+            for (xu, ci, k) in ((px_in * cin, cin, 3), (px * cout, cout, 3)):
+                f, b = conv(xu, px * cout, ci, cout, k, False)
+                ef, eb = ef + f, eb + b
+            if s_ != 1 or cin != cout:
+                f, b = conv(px_in * cin, px * cout, cin, cout, 1, False)
+                ef, eb = ef + f, eb + b
+            cin = cout
+    df = db = 0.0
+    r = (h // 32, w // 32)
+    for ci, co in ((512, 256), (256, 128), (128, 64), (64, 64)):
+        px = n * r[0] * r[1]
+        for (xu, c_in) in ((px * ci, ci), (px * co, co)):                                   # pre_concat_conv
+            f, b = conv(xu, px * co, c_in, co, 3, True)
+            df, db = df + f, db + b
+        r = (r[0] * 2, r[1] * 2)
+        px2 = n * r[0] * r[1]
+        f, b = conv(px * co + px2 * co, px2 * co, 2 * co, co, 3, True)                      # post_concat_conv 1 on cat[up2(low), skip]: low read at ITS resolution
+        df, db = df + f, db + b
+        f, b = conv(px2 * co, px2 * co, co, co, 3, True)
+        df, db = df + f, db + b
+    px_lo, px_hi = n * r[0] * r[1], n * h * w
+    f, b = conv(px_lo * 64, px_hi * 32, 64, 32, 3, True)                                    # outconv4 ConvBlock: up2(64) -> 32 -> 32 at full resolution
+    df, db = df + f, db + b
+    f, b = conv(px_hi * 32, px_hi * 32, 32, 32, 3, True)
+    df, db = df + f, db + b
+    for s_, c in ((8, 128), (4, 64), (2, 64), (1, 32)):                                     # 2-channel heads at their own resolution
+        px = n * (h // s_) * (w // s_)
+        f, b = conv(px * c, px * 2, c, 2, 3, True)
+        df, db = df + f, db + b
+    df, db = 2 * df, 2 * db                                                                 # two decoders
+    loss = 4.0 * n * h * w * (4 * 4 + 4 * 4 + 7) / 1.0                                      # read 16 prediction planes, write 16 gradient planes, read 7 target maps
+    params = 31012944
+    adam = 4.0 * params * 7
+    gb = lambda v: round(v / 1e9, 3)
+    out = {"encoder_fwd": gb(ef), "encoder_bwd": gb(eb), "decoders_fwd": gb(df), "decoders_bwd": gb(db), "loss": gb(loss), "adam": gb(adam)}
+    out["total"] = gb(ef + eb + df + db + loss + adam)
+    return out
+
+
 class KernelTimer:
     """HIP-event bracket around every launch of a set of convolution entry points (events go on torch's current stream, which
     is the stream the C ABI launches on; used with concurrency switched off, so a bracket is that launch's exclusive time)."""
@@ -1084,6 +1144,14 @@ def main():
                            "FETCH_SIZE x 2 + WRITE_SIZE per step, over THIS line's ms_per_step" % (PROFILE_ROUND, args.workload, FMT)}
             else:
                 out["roofline"]["step_counters"] = {"attached": False, "why": sc_why}
+            # whole-step waste ratio (VERDICT r5 "Next" 7): counter traffic of one step over the fused-minimum bytes of the whole step
+            alg = step_algorithmic_bytes(B, H, W)
+            hb_gb = round(sc["hbm_bytes_per_step"]["total"] / 1e9, 3) if sc else None
+            out["step_bytes"] = {"algorithmic_gb": alg["total"], "hbm_gb": hb_gb, "traffic_ratio": round(hb_gb / alg["total"], 3) if hb_gb else None,
+                                 "kernel_launches": sc.get("kernel_launches_per_step") if sc else None, "algorithmic_by_family_gb": alg,
+                                 "note": "algorithmic = SURVEY.md section 8(d)'s per-convolution fused-minimum rule over every convolution of the "
+                                         "network + loss + Adam (bench.py step_algorithmic_bytes); hbm = FETCH_SIZE x 2 + WRITE_SIZE of one step from the "
+                                         "committed counters-only passes of this build (null when not collected for this build)"}
             out["kernels"] = {"serial": (ktable or [])[:24], "concurrent": (ktable_conc or [])[:24],
                               "note": "per kernel symbol, from HIP events around every kernel launch of %d steps (fp_ktime_*): `serial` = one stream, "
                                       "eager launches (exclusive durations); `concurrent` = the default five-stream schedule replayed from the "

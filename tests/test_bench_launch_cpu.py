@@ -91,3 +91,23 @@ def test_default_run_skips_the_lab_notebook_legs():
     assert 'ap.add_argument("--sustain", type=float, default=0.0' in src
     assert 'ap.add_argument("--other-format", dest="other_format", action="store_true"' in src
     assert "print(compact_record(out, write_detail(out)), flush=True)" in src and "print(json.dumps(out)" not in src
+
+
+def test_whole_step_algorithmic_bytes_reproduce_the_survey_figures():
+    """VERDICT r5 "Next" 7: the whole-step fused-minimum byte count behind `step.traffic_ratio`.  The decoder and loss families must land on
+    SURVEY.md section 8(d) / BASELINE.md section 3 (3.544 / 7.018 / 0.224 GB at 12x192x640, 3.155 / 6.247 / 0.199 at 4x512x640; the survey's
+    totals sit 2 % above the sum of its own per-convolution rows, which this function reproduces to the megabyte: 1 736.5 MB per decoder
+    forward), the encoder follows the same rule, backward = 2 x forward by construction, and Adam moves 7 floats per parameter."""
+    sys.path.insert(0, ROOT)
+    import bench
+    k = bench.step_algorithmic_bytes(12, 192, 640)
+    m = bench.step_algorithmic_bytes(4, 512, 640)
+    assert abs(k["decoders_fwd"] - 2 * 1.7365) < 0.002                     # the survey table's own rows, summed
+    for got, want in ((k["decoders_fwd"], 3.544), (k["decoders_bwd"], 7.018), (k["loss"], 0.224), (m["decoders_fwd"], 3.155),
+                      (m["decoders_bwd"], 6.247), (m["loss"], 0.199)):
+        assert abs(got - want) <= 0.03 * want, (got, want)
+    for d in (k, m):
+        assert abs(d["encoder_bwd"] - 2 * d["encoder_fwd"]) < 0.002 and abs(d["decoders_bwd"] - 2 * d["decoders_fwd"]) < 0.002
+        assert abs(d["adam"] - 31012944 * 28 / 1e9) < 0.001
+        assert abs(d["total"] - sum(v for kk, v in d.items() if kk != "total")) < 0.005
+    assert 0.8 < k["encoder_fwd"] < 1.1 and 13.5 < k["total"] < 15.0
