@@ -297,7 +297,7 @@ def phase_key(tag):
 HP_PRODUCTS = 3      # csrc/fp_common.h: FP_HP_PRODUCTS of the default build
 FMT = operand_format()              # "exact" (default) | "fp16_pair" (opt-in): footprints_amd/_format.py
 HP_ON = FMT == "fp16_pair" and os.environ.get("FP_NO_BF3", "0") == "0"      # mirrors footprints_amd.engine._HP
-PROFILE_ROUND = 5                   # profiles/round<N>_*: the counter files bench.py may attach
+PROFILE_ROUND = 6                   # profiles/round<N>_*: the counter files bench.py may attach
 GROUPS = {
     "conv3x3_bf3": dict(kernel="conv3x3_tile_bf3_kernel (+ splitk_reduce_kernel on small grids)", bf16x3=True),
     "conv3x3_hp": dict(kernel="conv3x3_tile_bf3_kernel<..., HP> (fp16-pair operands; + splitk_reduce_kernel / amax_kernel on small grids)", bf16x3=False,
@@ -392,7 +392,7 @@ def kernel_source_digest():
 
 
 def load_traffic(workload, entry_point):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (scripts/profile_session_r5.sh -> profiles/round5_pmc_hbm_*.json;
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (scripts/profile_session_r6.sh -> profiles/round6_pmc_hbm_*.json;
     the counters need rocprofv3 around the process, so they cannot be collected inside this one), or None.  The file records the digest of
     the kernel source it was measured on: a file from another build is NOT attached (its figure would describe a different kernel)."""
     name = "round%d_pmc_hbm_%s_%s.json" % (PROFILE_ROUND, workload, FMT)
@@ -412,7 +412,7 @@ def load_traffic(workload, entry_point):
 
 def load_step_counters(workload):
     """step-level MFMA busy % and HBM bytes from the committed counters-only passes of THIS build and operand format
-    (scripts/pmc_step.py -> profiles/round5_pmc_step_<workload>_<format>.json; digest-checked like load_traffic), or (None, why)"""
+    (scripts/pmc_step.py -> profiles/round6_pmc_step_<workload>_<format>.json; digest-checked like load_traffic), or (None, why)"""
     name = "round%d_pmc_step_%s_%s.json" % (PROFILE_ROUND, workload, FMT)
     try:
         with open(os.path.join(ROOT, "profiles", name)) as fh:

@@ -57,6 +57,7 @@ _PHASE = not bool(int(os.environ.get("FP_NO_PHASE", "0")))
 
 # role -> side-stream pool index: aux, encoder weight gradients, mask decoder's / depth decoder's weight gradients (see Engine.__init__)
 _STREAM_LAYOUT = "0,1,2,2"
+_HEAD_WGRAD_SIDE = bool(int(os.environ.get("FP_HEAD_WGRAD_SIDE", "0")))   # 1: the heads' weight gradients on the decoder's weight-gradient stream.  Measured round 6 (3 alternating pairs, one box): 14.43 / 14.61 / 14.77 ms on the chain vs 14.54 / 14.74 / 14.68 on the side stream -- no gain (the step is bound by the chip's throughput, not by the chain), so the default stays on the chain
 _WGRAD_PAIR_FORK = bool(int(os.environ.get("FP_WGRAD_PAIR_FORK", "1")))   # one stream fork per residual block for its two weight gradients (0: one each)
 _HP_STEM = bool(int(os.environ.get("FP_HP_STEM", "1")))        # 0: the stem convolution on fp32 MFMA (rounds 1-3)
 _NEED32_SYNC = bool(int(os.environ.get("FP_NEED32_SYNC", "1")))   # device-wide synchronizes around a first-touch pack of an fp32 layout, outside stream capture (Engine._need32)
@@ -620,17 +621,26 @@ class Engine:
     def _head_wb(hd):
         return (hd.w2, hd.b2) if hd.pad else (hd.w.data, hd.b.data)
 
-    @staticmethod
-    def _head_wgrad(hd, x, dzl, acc):
-        if not hd.pad:
-            return ops.head_wgrad(x, dzl, hd.gw, hd.gb, accumulate=acc)
-        ops.head_wgrad(x, dzl, hd.gw2, hd.gb2, accumulate=False)
-        if acc:
-            hd.gw.add_(hd.gw2[0:1])
-            hd.gb.add_(hd.gb2[0:1])
-        else:
-            hd.gw.copy_(hd.gw2[0:1])
-            hd.gb.copy_(hd.gb2[0:1])
+    def _head_wgrad(self, hd, x, dzl, acc, side=None):
+        """weight / bias gradient of a 2-channel head.  side = a stream (round 6): launched there behind a fork from the current stream, like
+        the convolutions' weight gradients (_wgrad) -- nothing on the data-gradient chain reads it, and at full resolution it is 160 us of
+        HBM-bound work that used to sit in front of the first big data gradient of the backward pass (ordered trace, profiles/round5_*).
+        The caller keeps x and dzl untouched until the join at the end of Engine.backward: dzl lives in a buffer of its own per scale."""
+        def launch():
+            if not hd.pad:
+                return ops.head_wgrad(x, dzl, hd.gw, hd.gb, accumulate=acc)
+            ops.head_wgrad(x, dzl, hd.gw2, hd.gb2, accumulate=False)
+            if acc:
+                hd.gw.add_(hd.gw2[0:1])
+                hd.gb.add_(hd.gb2[0:1])
+            else:
+                hd.gw.copy_(hd.gw2[0:1])
+                hd.gb.copy_(hd.gb2[0:1])
+        if side is None or not _HEAD_WGRAD_SIDE:
+            return launch()
+        ops.event_wait(side, self._record(ops.current_stream()))
+        with ops.on_stream(side):
+            launch()
 
     def _cv(self, d, src, w32, w3, out, hp=None, publish=True, **kw):
         """one 3x3 / 1x1 convolution or data-gradient launch: the split-operand tile kernel where it applies (hp = (fp16-pair packing,
@@ -1442,14 +1452,20 @@ class Engine:
         # ---- full-resolution tail: head4 <- o42 <- o41 <- up2(x4) ------------------------------------
         x4 = D["x"][3]
         h0, w0 = dims[0]
-        dzl = buf(pfx + "dzl", (N, H, W, 2))
+        side_h = side if _HEAD_WGRAD_SIDE else None
+        dzl = buf(pfx + "dzl3", (N, H, W, 2))         # (one buffer per scale: the side stream reads it until the end of the backward pass)
         ops.head_upsample_bwd(gouts[3], D["low"][3], dzl, dec.head_scales[3], dec.c0, dec.sig)
         hd = dec.heads[3]
-        self._head_wgrad(hd, D["x5"], dzl, acc)
+        if side_h is None:
+            self._head_wgrad(hd, D["x5"], dzl, acc)
         A = buf(pfx + "dz.o42", (N, H, W, 32))
         ops.head_dgrad(dzl, self._head_wb(hd)[0], A, elu_src=D["x5"], amax_out=self._sink_slot(A))
         self._sink_done(A)
-        self._wgrad(dec.o42, L.GATHER_FWD_REFLECT, D["y51"], None, A, N, H, W, H, W, 32, 0, acc, side)
+        if side_h is not None:                        # ONE fork for the head's and o42's weight gradients (dzl, x5 and A are all queued by now)
+            if _HP_WGRAD:
+                self.amax.get(D["y51"]); self.amax.get(A)
+            self._head_wgrad(hd, D["x5"], dzl, acc, side_h)
+        self._wgrad(dec.o42, L.GATHER_FWD_REFLECT, D["y51"], None, A, N, H, W, H, W, 32, 0, acc, side, fork=side_h is None)
         Bz = self._dgrad_dec(dec.o42, A, N, H, W, buf(pfx + "dz.o41", (N, H, W, 32)), actsrc=D["y51"])
         yield
         self._wgrad_up2(dec.o41, x4, None, Bz, N, h0, w0, 64, 0, acc, side)
@@ -1459,10 +1475,10 @@ class Engine:
         else:
             XV = self._dgrad_dec(dec.o41, Bz, N, H, W, buf(pfx + "XV", (N, H, W, 64)))
         # head3 on x4
-        dzl = buf(pfx + "dzl", (N, h0, w0, 2))
+        dzl = buf(pfx + "dzl2", (N, h0, w0, 2))
         ops.head_upsample_bwd(gouts[2], D["low"][2], dzl, dec.head_scales[2], dec.c0, dec.sig)
         hd = dec.heads[2]
-        self._head_wgrad(hd, x4, dzl, acc)
+        self._head_wgrad(hd, x4, dzl, acc, side_h)
         XH = buf(pfx + "XH", (N, h0, w0, 64))
         ops.head_dgrad(dzl, self._head_wb(hd)[0], XH)
         A = buf(pfx + "dz.post2.3", (N, h0, w0, 64))
@@ -1534,10 +1550,10 @@ class Engine:
                 XH = None
                 if bi >= 2:                          # heads on block2 / block3 outputs (x2: scale 8, x3: scale 4)
                     k = bi - 2
-                    dzl = buf(pfx + "dzl", (N, hl, wl, 2))
+                    dzl = buf(pfx + "dzl%d" % k, (N, hl, wl, 2))
                     ops.head_upsample_bwd(gouts[k], D["low"][k], dzl, dec.head_scales[k], dec.c0, dec.sig)
                     hd = dec.heads[k]
-                    self._head_wgrad(hd, xin, dzl, acc)
+                    self._head_wgrad(hd, xin, dzl, acc, side_h)
                     XH = buf(pfx + "XH", (N, hl, wl, cin))
                     ops.head_dgrad(dzl, self._head_wb(hd)[0], XH)
                 A = self._dgrad_dec(blk["pre1"], Bz, N, hl, wl, buf(pfx + "dz.post2.%d" % (bi - 1), (N, hl, wl, cin)), actsrc=xin, addend=XH)
