@@ -88,7 +88,24 @@ __device__ __forceinline__ constexpr FoldTap fold_tap3(int e) {
   }
 }
 
-constexpr int PIXB = 48;   // bytes per halo pixel per plane (16 bf16 + 8 pad)
+// Round 6 EXPERIMENT, off by default (-DFP_TILE_PIXB32=1 builds it): halo pixels of the 16-wide tiles of 32 bytes (no padding) with the two
+// 16-byte k-group halves of a pixel swapped on odd halo rows.  Measured (profiles/round6_notes.md section 5): the fourth workgroup per CU it
+// buys the 32-channel forms moves the training step by 0.03 ms (14.66 -> 14.63, inside the noise), and a 128-register budget for the
+// 64-channel forms (-DFP_TILE_EXACT64_WAVES=4) costs 0.4 ms -- occupancy is not what these kernels wait for.  Kernel and golden tests pass
+// with it (363); it stays a build option because it changes the order in which a tile's BatchNorm partials are merged (last-bit
+// differences in the statistics) for no gain.  The idea:  With 48-byte pixels two halo buffers of three planes are 51.8 KB: three workgroups per CU, and the
+// counters (profiles/round5_pmc_sq_exact.txt) show the matrix pipe idle 38 % of the time with the three waves of a SIMD all outside their
+// taps at once (prologue: three dependent memory latencies; epilogue: statistics + stores).  32-byte pixels are 34.6 KB: FOUR workgroups
+// per CU wherever the registers allow it (the 32-channel forms: 99-113 of 128; see fp_tile_min_waves).  Bank conflicts: a 16-lane service
+// group of ds_read_b128 ({0-3,12-15,20-27}, {4-11,16-19,28-31}, same k-group) covers 8 pixels of tile row r and 8 of row r + 1; a lane's
+// 16-byte slot mod 16 is 4 (py + ky) + 2 (px + kx) + half: each row's 8 pixels take the 8 even residues, so the two rows must differ in
+// the half bit -- half = k-group ^ (halo row & 1).  (18-pixel halo pitch = 36 slots = 4 mod 16: an even shift, the parity argument
+// holds for every tap.)  The 20-wide tiles keep 48-byte pixels (one workgroup per CU there; their pitch needs another scheme).
+#ifndef FP_TILE_PIXB32
+#define FP_TILE_PIXB32 0
+#endif
+template <int TW>
+constexpr int fp_tile_pixb() { return (FP_TILE_PIXB32 && TW == 16) ? 32 : 48; }
 
 // MFMA row -> tile pixel.  ds_read_b128 is serviced in four fixed 16-lane groups (lanes {0-3,12-15,20-27}, ...), conflict-free
 // when the 16 lanes hit 16 distinct 16-byte slots mod 256 B.  With 48-byte pixels a lane's slot is 3 * halo_pixel mod 16; a
@@ -99,7 +116,7 @@ template <int TW>
 __device__ __forceinline__ void fp_tile_pixel(int pt, int& py, int& px) {
   py = pt / TW;
   px = pt - py * TW;
-  if (TW == 16) px = (px - 2 * (py & 1)) & 15;
+  if (TW == 16 && fp_tile_pixb<TW>() == 48) px = (px - 2 * (py & 1)) & 15;     // (the 32-byte layout swaps halves instead of rotating columns)
 }
 
 // NP = number of bf16 terms per operand: 3 = the exact split (six products); 2 = h + m only (three products: ah*bh + ah*bm + am*bh,
@@ -142,8 +159,26 @@ __device__ __forceinline__ void fp_tile_pixel(int pt, int& py, int& px) {
 struct TileGeo { int split, tile_n, tile_x, tile_y, n_img, y0, x0, n0; };
 constexpr bool fp_tile_persistent(int tw, bool wpf, bool hp) { return FP_TILE_PERSIST_BUILD != 0 && !wpf && hp && tw == 16; }
 
+// waves per SIMD asked of the register allocator.  Exact operands (round 6): with 32-byte halo pixels four workgroups fit a CU's LDS; the
+// 32-channel forms use 99-113 registers (accumulators included) and take the fourth wave for free, the 64-channel forms need 140 and keep
+// three unless FP_TILE_EXACT64_WAVES says otherwise (A/B knob: 4 = a 128-register budget).
+#ifndef FP_TILE_EXACT32_WAVES
+#define FP_TILE_EXACT32_WAVES 4
+#endif
+#ifndef FP_TILE_EXACT64_WAVES
+#define FP_TILE_EXACT64_WAVES 1
+#endif
+template <int TH, int TW, int BN, bool FOLD, bool HP, bool WPF>
+constexpr int fp_tile_min_waves() {
+  if (WPF) return 1;
+  if (TH * TW > 128) return 2;
+  if (HP) return FOLD ? FP_TILE_HP_FOLD_WAVES : FP_TILE_HP_WAVES;
+  if (fp_tile_pixb<TW>() == 32) return BN == 32 ? FP_TILE_EXACT32_WAVES : FP_TILE_EXACT64_WAVES;
+  return 1;
+}
+
 template <int TH, int TW, int BN, int WM, int WN, bool FLIP, bool FOLD, int NP = 3, bool HP = false, bool WPF = false>
-__global__ void __launch_bounds__(256, WPF ? 1 : (TH * TW > 128 ? 2 : (HP ? (FOLD ? FP_TILE_HP_FOLD_WAVES : FP_TILE_HP_WAVES) : 1)))
+__global__ void __launch_bounds__(256, (fp_tile_min_waves<TH, TW, BN, FOLD, HP, WPF>()))
 conv3x3_tile_bf3_kernel(const Tile3Args a) {
   static_assert(!HP || NP == 2, "the fp16-pair format has two planes");
   constexpr int WPL = HP ? 2 : 3;                    // planes per weight slice in the packed buffer
@@ -151,6 +186,8 @@ conv3x3_tile_bf3_kernel(const Tile3Args a) {
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int HW2 = TW + 2, HPX = (TH + 2) * HW2;
   constexpr int NS = (HPX * 4 + 255) / 256;
+  constexpr int PIXB = fp_tile_pixb<TW>();           // bytes per halo pixel per plane: 16 bf16 (+ 8 pad in the 48-byte layout)
+  constexpr bool SWZ = PIXB == 32;                   // halves of a pixel swapped on odd halo rows (see fp_tile_pixb)
   constexpr int PLANE = HPX * PIXB;                   // bytes per plane
   constexpr int BUF = NP * PLANE;                    // bytes per halo buffer
   constexpr int NPIX = TH * TW;                      // valid rows of the M tile
@@ -189,7 +226,7 @@ conv3x3_tile_bf3_kernel(const Tile3Args a) {
 
   // ---- tile-independent lane geometry ----------------------------------------------------------------------------------------
   int lds_off[NS];
-  int abase[TM];
+  int abase[SWZ ? 2 : 1][TM];                        // [parity of the tap's row offset]: the swapped halves follow the HALO row's parity
   auto lane_setup = [&]() {
     int tq = threadIdx.x;
     if (PERSIST) asm volatile("" : "+v"(tq));
@@ -198,14 +235,24 @@ conv3x3_tile_bf3_kernel(const Tile3Args a) {
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
       const int lin = t + 256 * k;
-      lds_off[k] = (lin >> 2) < HPX ? (lin >> 2) * PIXB + (lin & 3) * 8 : -1;
+      if (SWZ) {
+        const int hp = lin >> 2, hy = hp / HW2;
+        lds_off[k] = hp < HPX ? hp * PIXB + ((((lin & 3) >> 1) ^ (hy & 1)) << 4) + (lin & 1) * 8 : -1;
+      } else {
+        lds_off[k] = (lin >> 2) < HPX ? (lin >> 2) * PIXB + (lin & 3) * 8 : -1;
+      }
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int pt = min((wm * TM + i) * 32 + idx, NPIX - 1);
       int py, px;
       fp_tile_pixel<TW>(pt, py, px);
-      abase[i] = (py * HW2 + px) * PIXB + h * 16;
+      if (SWZ) {
+        abase[0][i] = (py * HW2 + px) * PIXB + ((h ^ (py & 1)) << 4);
+        abase[1][i] = (py * HW2 + px) * PIXB + ((h ^ ((py + 1) & 1)) << 4);
+      } else {
+        abase[0][i] = (py * HW2 + px) * PIXB + h * 16;
+      }
     }
   };
   lane_setup();
@@ -388,10 +435,11 @@ conv3x3_tile_bf3_kernel(const Tile3Args a) {
     auto load_a = [&](int tap, uint4 (&dst)[TM][NP]) {
       const int ky = tap / 3, kx = tap % 3;
       const int toff = ((FLIP ? 2 - ky : ky) * HW2 + (FLIP ? 2 - kx : kx)) * PIXB;
+      const int ap = SWZ ? ((FLIP ? 2 - ky : ky) & 1) : 0;
 #pragma unroll
       for (int p = 0; p < NP; ++p)
 #pragma unroll
-        for (int i = 0; i < TM; ++i) dst[i][p] = *reinterpret_cast<const uint4*>(Hb + p * PLANE + abase[i] + toff);
+        for (int i = 0; i < TM; ++i) dst[i][p] = *reinterpret_cast<const uint4*>(Hb + p * PLANE + abase[ap][i] + toff);
     };
     // Border tiles of the reflection data-gradient run their fold taps (masked halo rows / columns, see kFoldTaps3) right behind
     // the regular tap that uses the SAME weight slice, from the registers it is already in: no extra weight loads (the former
@@ -423,6 +471,7 @@ conv3x3_tile_bf3_kernel(const Tile3Args a) {
             const bool need_c = ft.csel == 0 || (ft.csel == 1 ? has_c1 : has_cW);
             if (!(need_r && need_c)) continue;                             // uniform per workgroup
             const int toff = (ft.ao * HW2 + ft.bo) * PIXB;
+            const int ap = SWZ ? (ft.ao & 1) : 0;
             uint4 ax[TM][NP];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -431,7 +480,7 @@ conv3x3_tile_bf3_kernel(const Tile3Args a) {
               const unsigned mk = mr & mc;
 #pragma unroll
               for (int p = 0; p < NP; ++p) {
-                uint4 v = *reinterpret_cast<const uint4*>(Hb + p * PLANE + abase[i] + toff);
+                uint4 v = *reinterpret_cast<const uint4*>(Hb + p * PLANE + abase[ap][i] + toff);
                 v.x &= mk; v.y &= mk; v.z &= mk; v.w &= mk;
                 ax[i][p] = v;
               }
@@ -481,7 +530,7 @@ conv3x3_tile_bf3_kernel(const Tile3Args a) {
     auto acc_pixel = [&](int i, int r, int& py, int& px) {
       if (TW == 16) {              // pt = blk*32 + (r&3) + 8*(r>>2) + 4h  =>  row = 2*blk + (r>>3), column from constants and h
         py = 2 * (wm * TM + i) + (r >> 3);
-        px = ((r & 3) + 8 * ((r >> 2) & 1) + 4 * h - 2 * ((r >> 3) & 1)) & 15;
+        px = ((r & 3) + 8 * ((r >> 2) & 1) + 4 * h - (SWZ ? 0 : 2 * ((r >> 3) & 1))) & 15;
       } else {
         fp_tile_pixel<TW>((wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, py, px);
       }
