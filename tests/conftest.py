@@ -54,19 +54,25 @@ def pytest_sessionfinish(session, exitstatus):
              "(median inside [0.4, 1.5]; natural-statistics case [0.2, 1.5]).  `forced` = the same tensors against the float64 oracle evaluated under the "
              "ENGINE's own ReLU decisions (tests/parity.py decision_forced_report): failures / max err / median err; evaluated for the headline case and "
              "wherever the single-run rule failed.", "",
-             "| case | format | tensors | median | p90 | tensors > 2 | kink pixels removed | single-run failures | forced: failures / max / median | ReLU decisions != float64 | worst tensors (ratio; err GPU / err CPU fp32) |",
-             "|---|---|---|---|---|---|---|---|---|---|---|"]
+             "| case | format | tensors | median | p90 | tensors > 2 | kink pixels removed | single-run failures | forced: failures / max / median | ReLU decisions != float64 | imposed decisions: flips / worst distance from the boundary in float64 (x channel RMS), engine; CPU fp32 run | worst tensors (ratio; err GPU / err CPU fp32) |",
+             "|---|---|---|---|---|---|---|---|---|---|---|---|"]
     for d in docs:
         worst = ", ".join("%s %.1f (%.1e / %.1e)" % (t["tensor"].replace("encoder.", "enc.").replace("_decoder", "_dec"), t["ratio"], t["err_gpu"],
                                                      t["err_cpu32"]) for t in d.get("top6", [])[:3])
         f = d.get("decision_forced")
         forced = "%d / %.1e / %.1e" % (len(f["failures"]), f["max_err"], f["median_err"]) if f else ""
         fl = d.get("relu_decisions_differing_from_float64")
-        lines.append("| %s | %s | %s | %.2f | %.2f | %s | %s | %s | %s | %s | %s |" % (
+        im, rf = d.get("imposed_decisions"), d.get("cpu_fp32_decisions_vs_float64")
+        imposed = ""
+        if im:                                                   # round 6: the bound on what was imposed (tests/parity.py assert_decisions_at_roundoff)
+            imposed = "%d / %.1e (pool %d / %.1e)" % (im["relu_flips"], im["relu_flip_worst_distance"], im["pool_flips"], im["pool_flip_worst_distance"])
+            if rf:
+                imposed += "; %d / %.1e" % (rf["relu_flips"], rf["relu_flip_worst_distance"])
+        lines.append("| %s | %s | %s | %.2f | %.2f | %s | %s | %s | %s | %s | %s | %s |" % (
             d.get("case"), d.get("operand_format", ""), d.get("tensors"), d.get("median_ratio", float("nan")), d.get("p90_ratio", float("nan")),
             d.get("count_ratio_gt_2"), d.get("kink_pixels_removed", ""),
             len(d["single_run_rule_failures"]) if "single_run_rule_failures" in d else d.get("failures_under_single_run_rule", 0),
-            forced, ("%d of %d" % (fl["engine"], fl["of"])) if fl else "", worst))
+            forced, ("%d of %d" % (fl["engine"], fl["of"])) if fl else "", imposed, worst))
     try:
         with open(os.path.join(out_dir, "parity_ratios.md"), "w") as fh:
             fh.write("\n".join(lines) + "\n")
