@@ -139,6 +139,12 @@ __device__ __forceinline__ void fp_tile_pixel(int pt, int& py, int& px) {
 #ifndef FP_TILE_HP_FOLD_WAVES
 #define FP_TILE_HP_FOLD_WAVES FP_TILE_HP_WAVES
 #endif
+#ifndef FP_TILE_WPF_EXACT
+#define FP_TILE_WPF_EXACT 0          // 1: build the exact-format (NP = 3) weights-per-chunk-in-flight instantiations (round 6 experiment: 256 VGPRs + 60 AGPRs, no scratch; measured no gain, profiles/round6_notes.md 5e)
+#endif
+#ifndef FP_TILE_WPF_EXACT_DEFAULT_MAX_WG
+#define FP_TILE_WPF_EXACT_DEFAULT_MAX_WG 0     // grids up to this many workgroups take them (0: off; FP_TILE_WPF_EXACT_MAX_WG overrides at run time)
+#endif
 #ifndef FP_TILE_PERSIST_BUILD
 #define FP_TILE_PERSIST_BUILD 0     // 0: the tile loop compiled out (one tile per workgroup, as in rounds 1-3)
 #endif
@@ -937,6 +943,8 @@ int run_tile3(const char* who, const fp_conv_desc* d, const float* src, const fl
                               : launch3<TH_, TW_, 64, 2, 2, false, false, NP_, HP_>(a, stream))))
   // small grids (64-channel tiles of the 6 x 20 ... 24 x 80 levels: under ~1.5 workgroups per CU): the weights-per-chunk-in-flight variant
   static const int wpf_max = getenv("FP_TILE_WPF_MAX_WG") ? atoi(getenv("FP_TILE_WPF_MAX_WG")) : 400;
+  static const int wpf_exact_max = getenv("FP_TILE_WPF_EXACT_MAX_WG") ? atoi(getenv("FP_TILE_WPF_EXACT_MAX_WG")) : FP_TILE_WPF_EXACT_DEFAULT_MAX_WG;
+  (void)wpf_exact_max;
   if (hp && p.bn == 64 && a.nwg <= wpf_max) {
 #define FP_L3W(TH_, TW_)                                                                                                     \
   (fold ? launch3<TH_, TW_, 64, 2, 2, true, true, 2, true, true>(a, stream)                                                 \
@@ -946,6 +954,17 @@ int run_tile3(const char* who, const fp_conv_desc* d, const float* src, const fl
 #undef FP_L3W
   } else if (hp) {
     rc = p.th == 8 ? FP_L3X(8, 16, 2, true) : FP_L3X(6, 20, 2, true);
+#if FP_TILE_WPF_EXACT
+  } else if (!hp && !(d->epi & FP_EPI_BF16X2) && p.bn == 64 && a.nwg <= wpf_exact_max) {
+    // round 6: the exact format's small grids get the weights-per-chunk-in-flight form as well (one workgroup per CU there: the second
+    // register set -- 216 registers of weight slices -- costs occupancy the grid does not provide)
+#define FP_L3WE(TH_, TW_)                                                                                                    \
+  (fold ? launch3<TH_, TW_, 64, 2, 2, true, true, 3, false, true>(a, stream)                                                \
+        : (flip ? launch3<TH_, TW_, 64, 2, 2, true, false, 3, false, true>(a, stream)                                       \
+                : launch3<TH_, TW_, 64, 2, 2, false, false, 3, false, true>(a, stream)))
+    rc = p.th == 8 ? FP_L3WE(8, 16) : FP_L3WE(6, 20);
+#undef FP_L3WE
+#endif
   } else if ((d->epi & FP_EPI_BF16X2) && !flip) {   // opt-in inference mode: two bf16 terms per operand, three products (forward only)
     if (p.th == 8) rc = p.bn == 32 ? launch3<8, 16, 32, 4, 1, false, false, 2>(a, stream) : launch3<8, 16, 64, 2, 2, false, false, 2>(a, stream);
     else rc = p.bn == 32 ? launch3<6, 20, 32, 4, 1, false, false, 2>(a, stream) : launch3<6, 20, 64, 2, 2, false, false, 2>(a, stream);
