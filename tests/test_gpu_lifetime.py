@@ -167,3 +167,42 @@ def test_the_detector_fires_without_the_wait():
     bad = hook.damaged()
     print("\n[lifetime, wait off] %d released blocks, %d damaged: %s" % (len(hook.held), len(bad), bad[:4]))
     assert bad, "with the wait off, in-flight launches must have written into released blocks -- the detector saw nothing"
+
+
+def test_train_step_plan_record_and_replay_behind_a_deep_queue():
+    """the bench / trainer path: TrainStep issues two eager steps, records a launch plan on the third and replays it from C afterwards
+    (footprints_amd/training/train.py, csrc/plan.cpp) -- with a spin kernel in front of EVERY step, i.e. the engine is built, the plan is
+    recorded and the first replays run while earlier work is still queued.  Seven steps with Adam must leave the same 21 losses per step and
+    the same parameters, bit for bit, as the same seven steps with the device drained around each."""
+    from footprints_amd.model_manager import ModelManager
+    from footprints_amd.training.train import TrainStep
+    P, B = _state()
+    size = (2, 96, 128)
+    batch = _batch(size)
+
+    def run(spin, drain):
+        mm = ModelManager(use_cuda=True, learning_rate=1e-4)
+        mm.model.load_state_dict({**P, **B})
+        if spin:
+            torch.cuda._sleep(int(spin))
+        ts = TrainStep(mm.model, mm.optimiser)
+        losses = []
+        for _ in range(7):
+            if spin:
+                torch.cuda._sleep(int(spin))
+            losses.append(ts(batch).clone())
+            if drain:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        sd = OrderedDict((k, v.detach().clone()) for k, v in mm.model.state_dict().items())
+        used_plan = bool(getattr(ts, "use_plan", False))
+        del ts, mm
+        return losses, sd, used_plan
+
+    calm_l, calm_sd, _ = run(0, True)
+    deep_l, deep_sd, used_plan = run(SPIN / 4, False)
+    assert used_plan, "TrainStep is expected to record and replay a launch plan by default"
+    for i, (a, b) in enumerate(zip(calm_l, deep_l)):
+        assert torch.equal(a, b), "losses of step %d differ behind a deep queue: max |d| %.3e" % (i, float((a - b).abs().max()))
+    bad = [k for k in calm_sd if not torch.equal(calm_sd[k], deep_sd[k])]
+    assert not bad, "%d state tensors differ after seven steps behind a deep queue: %s" % (len(bad), bad[:6])
