@@ -47,7 +47,7 @@ Objects in the full record (bench_detail.json):
                 instrumentation (value, ms_per_step, step_ms, roofline with its own kernel events and counter file, kernels, decoder_backward,
                 sustained) -- a faster mode below fp32 that has to be asked for, never the headline.  Started with FP_OPERANDS=fp16_pair the
                 roles swap and `dtype` says so.
-  sustained     --sustain S (default 10 s): the step looped for S seconds of wall clock after the timed region: img/s over the whole span,
+  sustained     --sustain S (opt-in since round 6; default 0): the step looped for S seconds of wall clock after the timed region: img/s over the whole span,
                 per-second img/s, step_ms percentiles, and the GPU's sclk / power / busy % sampled from sysfs every 100 ms (what a trainer
                 that runs for hours sees; the timed region above is 0.2-0.6 s).
 """
