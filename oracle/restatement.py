@@ -145,10 +145,17 @@ class ReluDecisions:
     taken: the masks actually used; pool_impose (optional, int64 [N, C, OH, OW]): the 3x3 / stride 2 max-pool's winning window position
     ky * 3 + kx per output element (two window elements within round-off of each other are the same kind of decision as a ReLU at zero)."""
 
-    def __init__(self, impose=None, pool_impose=None):
+    def __init__(self, impose=None, pool_impose=None, probe=None):
         self.impose = None if impose is None else iter(impose)
         self.pool_impose = pool_impose
         self.taken = []
+        # probe (optional, recording runs only): somebody else's ReLU masks in call order -- the run keeps its OWN decisions and only measures
+        # how many of the probe's differ and how far from zero this run's value of the worst one sits (same statistics as for imposed masks:
+        # the reference's fp32 decisions measured against the float64 run without a float64 run of their own, tests/parity.py)
+        self.probe = None if probe is None else iter(probe)
+        self.probe_flips = 0
+        self.probe_flip_worst = 0.0
+        self.probe_flip_where = None
         # round 6: how far from the decision boundary every IMPOSED decision that differs from this run's own one sits (this run being
         # the float64 oracle, that is the float64 value the other implementation resolved differently): an imposed mask is only
         # legitimate where |z| is at round-off level, an imposed pool winner only where it ties the true maximum (tests/parity.py bounds both)
@@ -187,7 +194,21 @@ def _relu(x, decisions):
     if decisions is None:
         return F.relu(x)
     if decisions.impose is None:
-        decisions.taken.append((x > 0).detach())
+        own = (x > 0).detach()
+        if decisions.probe is not None:
+            with torch.no_grad():
+                m = next(decisions.probe)
+                flipped = m.to(torch.bool) != own
+                n = int(flipped.sum())
+                if n:
+                    rms = x.pow(2).mean(dim=(0, 2, 3), keepdim=True).sqrt().clamp_min(1e-300)
+                    dist = torch.where(flipped, x.abs() / rms, torch.zeros((), dtype=x.dtype))
+                    worst = float(dist.max())
+                    decisions.probe_flips += n
+                    if worst > decisions.probe_flip_worst:
+                        decisions.probe_flip_worst = worst
+                        decisions.probe_flip_where = (len(decisions.taken), int(dist.amax(dim=(0, 2, 3)).argmax()))
+        decisions.taken.append(own)
         return F.relu(x)
     m = next(decisions.impose)
     assert m.shape == x.shape, (tuple(m.shape), tuple(x.shape))

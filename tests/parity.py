@@ -191,6 +191,24 @@ def reference_flip_stats(P, B, cpu_batch, relu_decisions32):
             "relu_flip_worst_distance": imposed.relu_flip_worst, "relu_flip_worst_where": imposed.relu_flip_where}
 
 
+def fp32_forward_decisions(P, B, cpu_batch):
+    """the ReLU decisions of the CPU oracle's fp32 forward (train-mode BatchNorm on copies of the buffers, no gradients): what
+    `ReluDecisions(probe=...)` measures against a float64 run -- the reference-arithmetic anchor of the flip bound at the price of one fp32
+    forward instead of a float64 run of its own (`reference_flip_stats`, kept for the CPU tests, gives the same numbers to ~1e-7)"""
+    from oracle import restatement as R
+    rec = R.ReluDecisions()
+    with torch.no_grad():
+        R.footprint_network(cpu_batch["image"].float(), OrderedDict((k, v.float()) for k, v in P.items()),
+                            OrderedDict((k, v.clone()) for k, v in B.items()), True, relu_decisions=rec)
+    return rec.taken
+
+
+def probe_flip_stats(dec64):
+    """the statistics a float64 recording run collected about its probe (see fp32_forward_decisions), in reference_flip_stats's format"""
+    return {"relu_flips": dec64.probe_flips, "relu_decisions": sum(m.numel() for m in dec64.taken),
+            "relu_flip_worst_distance": dec64.probe_flip_worst, "relu_flip_worst_where": dec64.probe_flip_where}
+
+
 def assert_decisions_at_roundoff(stats, tag="", max_fraction=None, max_distance=None, reference=None):
     """the bound on what decision_forced_report imposed (round 6): few, and each at round-off distance from its boundary in float64;
     reference (optional, `reference_flip_stats`): additionally no further from the boundary than FACTOR x the CPU fp32 run's own worst flip"""

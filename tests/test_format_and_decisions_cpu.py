@@ -131,3 +131,21 @@ def test_flip_distance_is_anchored_on_the_reference_arithmetic():
     oracle_grads(P, B, batch, torch.float32, relu_decisions=rec)
     st = reference_flip_stats(P, B, batch, rec.taken)
     assert st["relu_decisions"] == sum(m.numel() for m in rec.taken) and st["relu_flips"] <= 8 and st["relu_flip_worst_distance"] <= 1e-4
+
+
+def test_probe_measurement_equals_the_forced_run():
+    """ReluDecisions(probe=...): the float64 recording run measures somebody else's masks without imposing them -- same flips and (to ~1e-7)
+    the same worst distance as a float64 run that has them imposed (reference_flip_stats)"""
+    from oracle import restatement as R
+    from tests.parity import fp32_forward_decisions, oracle_grads, probe_flip_stats, reference_flip_stats
+    P, B = R.make_state(tag="dec")
+    batch = R.make_batch(2, 64, 96, tag="probe")
+    dec32 = fp32_forward_decisions(P, B, batch)
+    rec32 = R.ReluDecisions()
+    oracle_grads(P, B, batch, torch.float32, relu_decisions=rec32)
+    assert all(torch.equal(a, b) for a, b in zip(dec32, rec32.taken))              # the forward-only pass takes the training run's decisions
+    dec64 = R.ReluDecisions(probe=dec32)
+    oracle_grads(P, B, batch, torch.float64, relu_decisions=dec64)
+    a, b = probe_flip_stats(dec64), reference_flip_stats(P, B, batch, dec32)
+    assert a["relu_decisions"] == b["relu_decisions"] and abs(a["relu_flips"] - b["relu_flips"]) <= 2
+    assert abs(a["relu_flip_worst_distance"] - b["relu_flip_worst_distance"]) <= 1e-6 + 0.05 * b["relu_flip_worst_distance"]

@@ -27,7 +27,8 @@ import torch
 
 from tests.gpu_child import gpu_step
 from tests.parity import (FORCED_MAX_ERR, FORCED_MAX_ERR_NATURAL, FORCED_MEDIAN_ERR, FORCED_MEDIAN_ERR_NATURAL, KINK_MAX_FRACTION, KINK_MAX_FRACTION_NATURAL, MEDIAN_GATE, MEDIAN_GATE_NATURAL, TIE_SIGMA,
-                          anchored_report, assert_decisions_at_roundoff, chan_relerr, count_decision_flips, decision_forced_report, oracle_grads, reference_flip_stats, rel_l2,
+                          anchored_report, assert_decisions_at_roundoff, chan_relerr, count_decision_flips, decision_forced_report, fp32_forward_decisions, oracle_grads, probe_flip_stats,
+                          reference_flip_stats, rel_l2,
                           tie_free_batch)
 
 pytestmark = pytest.mark.gpu
@@ -155,8 +156,8 @@ def _decision_rule(tag, P, B, cpu_batch, res, g32, g64, bad, rows, dec64=None, s
     # round 6: the imposed decisions are bounded BEFORE anything is concluded from the forced truth -- few, each a float64 round-off tie, and no
     # further from the boundary than the reference's own fp32 arithmetic gets (its decisions imposed the same way; once per case, both formats)
     ref = None
-    if oracle is not None and oracle.get("dec32") is not None:
-        if "flip32" not in oracle:
+    if oracle is not None and (oracle.get("flip32") is not None or oracle.get("dec32") is not None):
+        if oracle.get("flip32") is None:
             oracle["flip32"] = reference_flip_stats(P, B, cpu_batch, oracle["dec32"])
         ref = oracle["flip32"]
         extra["cpu_fp32_decisions_vs_float64"] = {k: (float("%.3e" % v) if isinstance(v, float) else v) for k, v in ref.items()}
@@ -187,14 +188,15 @@ def test_train_step_fp64_anchored(Bn, Hn, Wn, fmt):
             removed.append(n)
             return b
         rec64, rec32 = ([] if decompose else None), ([] if decompose else None)
-        dec64 = R.ReluDecisions()
+        # the fp32 forward's decisions first (they do not depend on the targets): the float64 run measures them as a probe -- the
+        # reference-arithmetic anchor of the flip bound without a float64 run of its own (tests/parity.py fp32_forward_decisions)
+        dec64 = R.ReluDecisions(probe=fp32_forward_decisions(P, B, cpu_batch))
         out64, l64, g64, _, cpu_batch = oracle_grads(P, B, cpu_batch, torch.float64, fix_batch=fix, record=rec64, relu_decisions=dec64)   # float64 first: it defines the tie pixels
-        dec32 = R.ReluDecisions()
-        out32, l32, g32, tr32, _ = oracle_grads(P, B, cpu_batch, torch.float32, record=rec32, relu_decisions=dec32)
+        out32, l32, g32, tr32, _ = oracle_grads(P, B, cpu_batch, torch.float32, record=rec32)
         l64 = {k: float(v) for k, v in l64.items()}
         l32 = {k: float(v) for k, v in l32.items()}
         return dict(P=P, B=B, cpu_batch=cpu_batch, removed=removed[0], out64=out64, l64=l64, g64=g64, out32=out32, l32=l32, g32=g32,
-                    bn32={k: v.clone() for k, v in tr32.B.items()}, dec64=dec64.taken, dec32=dec32.taken,
+                    bn32={k: v.clone() for k, v in tr32.B.items()}, dec64=dec64.taken, flip32=probe_flip_stats(dec64),
                     x64=rec64[-1] if decompose else None, x32=rec32[-1] if decompose else None)
     o = _oracle_runs(("train_step", Bn, Hn, Wn), build)
     P, B, cpu_batch, out64, out32, l64, l32, g64, g32 = (o[k] for k in ("P", "B", "cpu_batch", "out64", "out32", "l64", "l32", "g64", "g32"))
