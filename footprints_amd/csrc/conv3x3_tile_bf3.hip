@@ -139,6 +139,9 @@ __device__ __forceinline__ void fp_tile_pixel(int pt, int& py, int& px) {
 #ifndef FP_TILE_HP_FOLD_WAVES
 #define FP_TILE_HP_FOLD_WAVES FP_TILE_HP_WAVES
 #endif
+#ifndef FP_TILE_T16
+#define FP_TILE_T16 0                // 1: build the 16 x 16-pixel 32-channel exact instantiations (round 6 experiment, needs FP_TILE_PIXB32=1 for two workgroups per CU)
+#endif
 #ifndef FP_TILE_WPF_EXACT
 #define FP_TILE_WPF_EXACT 0          // 1: build the exact-format (NP = 3) weights-per-chunk-in-flight instantiations (round 6 experiment: 256 VGPRs + 60 AGPRs, no scratch; measured no gain, profiles/round6_notes.md 5e)
 #endif
@@ -840,6 +843,12 @@ Plan3 plan3(const fp_conv_desc* d) {
     const int64_t t64 = (int64_t)d->N * fp_ceil_div(d->OW, p.tw) * fp_ceil_div(d->OH, p.th) * fp_ceil_div(d->Nout, 64);
     if (exp_bn32 && t64 < exp_bn32) p.bn = 32;      // more, narrower workgroups instead of split-K partials
   }
+#if FP_TILE_T16
+  // round 6 experiment: 16 x 16 pixel tiles for the 32-channel forms on large grids (two accumulators and twice the MFMAs per wave; with
+  // 32-byte halo pixels 62 KB of LDS: two workgroups per CU).  FP_TILE_T16_BN32=1 selects it at run time (exact operands only, see run_tile3).
+  static const int t16 = getenv("FP_TILE_T16_BN32") ? atoi(getenv("FP_TILE_T16_BN32")) : 0;
+  if (t16 && p.bn == 32 && p.th == 8 && d->OH % 16 == 0 && d->OW % 16 == 0 && (int64_t)d->N * (d->OH / 16) * (d->OW / 16) >= 2048) p.th = 16;
+#endif
   p.tilesX = (int)fp_ceil_div(d->OW, p.tw); p.tilesY = (int)fp_ceil_div(d->OH, p.th); p.tilesN = (int)fp_ceil_div(d->Nout, p.bn);
   const int64_t tiles = (int64_t)d->N * p.tilesY * p.tilesX * p.tilesN;
   const int KC16 = (d->C0 + d->C1 + 15) / 16;
@@ -932,6 +941,9 @@ int run_tile3(const char* who, const fp_conv_desc* d, const float* src, const fl
   const bool stats_in_reduce = bn_sink.part && !bn_sink.z && p.SK > 1 && !flip && (d->epi & ~(unsigned)FP_EPI_BF16X2) == 0 && d->act == 0;
   const int planes = hp ? 4 : 6;                    // bytes of packed weight per element
   a.wmajor = (int64_t)9 * (d->C0 + d->C1) * d->Nout * planes > ((int64_t)4 << 20);
+#if FP_TILE_T16
+  FP_REQUIRE(!(p.th == 16 && (hp || (d->epi & FP_EPI_BF16X2))), "fp_conv3x3: FP_TILE_T16_BN32 is an exact-operand experiment");
+#endif
   a.nwg = d->N * p.tilesY * p.tilesX * p.tilesN * p.SK;
   int rc;
 #define FP_L3X(TH_, TW_, NP_, HP_)                                                                                            \
@@ -968,6 +980,11 @@ int run_tile3(const char* who, const fp_conv_desc* d, const float* src, const fl
   } else if ((d->epi & FP_EPI_BF16X2) && !flip) {   // opt-in inference mode: two bf16 terms per operand, three products (forward only)
     if (p.th == 8) rc = p.bn == 32 ? launch3<8, 16, 32, 4, 1, false, false, 2>(a, stream) : launch3<8, 16, 64, 2, 2, false, false, 2>(a, stream);
     else rc = p.bn == 32 ? launch3<6, 20, 32, 4, 1, false, false, 2>(a, stream) : launch3<6, 20, 64, 2, 2, false, false, 2>(a, stream);
+#if FP_TILE_T16
+  } else if (p.th == 16) {
+    rc = fold ? launch3<16, 16, 32, 4, 1, true, true, 3, false>(a, stream)
+              : (flip ? launch3<16, 16, 32, 4, 1, true, false, 3, false>(a, stream) : launch3<16, 16, 32, 4, 1, false, false, 3, false>(a, stream));
+#endif
   } else {
     rc = p.th == 8 ? FP_L3X(8, 16, 3, false) : FP_L3X(6, 20, 3, false);
   }
