@@ -687,6 +687,35 @@ def kernel_table(lib, steps):
     return sorted(rows, key=lambda r: -r["ms_per_step"])
 
 
+def mfma_random_operand_peak(lib, seconds=0.7, iters=4000):
+    """what v_mfma_f32_32x32x16_bf16 sustains on THIS chip, right now, with operands that toggle like real activations (fp_mfma_probe mode 1:
+    nothing but MFMAs, three waves per SIMD): launches of ~5 ms back to back for `seconds`, the rate and the shader clock of the last third.
+    Round 6 (profiles/round6_mfma_sustained_clock.txt): 2.46 PFLOP/s at 2.39 GHz on constant data, 1.85 PFLOP/s at 1.81 GHz on random data --
+    the clock the chip holds falls with the toggling of the operand buses, so the nominal dense peak `roofline.peak` is priced against is a
+    constant-data figure; this is the same instruction's ceiling on data, measured beside the run."""
+    import ctypes
+    out = torch.empty(768 * 256, device="cuda")
+    clk = torch.zeros(2, dtype=torch.int64, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    khz = int(lib.fp_wall_clock_khz())
+    flop = float(lib.fp_mfma_probe_flop(iters))
+    rows = []
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        lib.fp_mfma_probe(out.data_ptr(), clk.data_ptr(), iters, 1, st)
+        e1.record()
+        e1.synchronize()
+        c = clk.cpu()
+        rows.append((flop / e0.elapsed_time(e1) / 1e9, float(c[0]) / max(float(c[1]), 1.0) * khz / 1e3 if khz > 0 else None))
+    tail = rows[-max(1, len(rows) // 3):]
+    tf = sum(r[0] for r in tail) / len(tail)
+    mhz = [r[1] for r in tail if r[1]]
+    return {"tflops": round(tf, 1), "shader_mhz": round(sum(mhz) / len(mhz), 0) if mhz else None, "launches": len(rows),
+            "how": "fp_mfma_probe mode 1 (pseudo-random bf16 operands, MFMAs only) back to back for %.1f s; mean of the last third" % seconds}
+
+
 COMPACT_LIMIT = 4096              # bytes: the driver parses the LAST stdout line; round 5's 34.6 KB line came back unparsed (VERDICT r5 #1)
 
 
@@ -720,6 +749,9 @@ def compact_record(out, detail_path=None):
         r.update(_pick(rf, ("traffic_ratio", "algorithmic_mb_per_launch", "avg_kernel_us", "launches_per_step", "kernel_only_ms_per_step",
                             "fp32_equiv_tflops")))
         r["kernel"] = str(rf.get("kernel_symbol") or rf.get("kernel", ""))[:64]
+        mp = rf.get("mfma_random_operand_peak") or {}
+        if mp.get("tflops"):
+            r["mfma_random_operand_peak"] = _pick(mp, ("tflops", "shader_mhz", "frac_of_it"))
         sc = rf.get("step_counters") or {}
         if sc.get("hbm_bytes_per_step"):
             r["step"] = _pick(sc, ("mfma_busy_fraction_of_serial_kernel_time", "hbm_bytes_per_step", "hbm_fraction_of_peak", "kernel_launches_per_step"))
@@ -1131,6 +1163,12 @@ def main():
                                           "its 2.4 GHz (`sustained.shader_clock_mhz`, from its own counters), i.e. ~0.8 of the nominal peak is attainable",
                                "conv_exclusive_ms_per_step": round(sum(g["exclusive_ms_per_step"] for g in groups), 3),
                                "groups": groups}
+            # the same instruction's ceiling on toggling data, measured beside the run (the nominal peak is a constant-data figure)
+            try:
+                mp = mfma_random_operand_peak(lib)
+                out["roofline"]["mfma_random_operand_peak"] = dict(mp, frac_of_it=round(ach / mp["tflops"], 4))
+            except Exception as ex:                                # a measurement aid must not take the headline down
+                out["roofline"]["mfma_random_operand_peak"] = {"error": repr(ex)[:200]}
             sc, sc_why = load_step_counters(args.workload)
             if sc:
                 hb = sc["hbm_bytes_per_step"]["total"]

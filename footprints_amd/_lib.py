@@ -158,6 +158,8 @@ SIGNATURES = {
     "fp_fill": (C.c_int, [_P, _I64, _F, _P]),
     "fp_clock_probe": (C.c_int, [_P, _P]),
     "fp_wall_clock_khz": (C.c_int, []),
+    "fp_mfma_probe": (C.c_int, [_P, _P, _I32, _I32, _P]),
+    "fp_mfma_probe_flop": (C.c_double, [_I32]),
     "fp_version": (C.c_int, []),
     "fp_last_error_string": (C.c_char_p, []),
 }

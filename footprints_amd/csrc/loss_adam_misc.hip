@@ -470,6 +470,56 @@ extern "C" int fp_clock_probe(uint64_t* out16, fp_stream_t stream) {
   return fp_check_launch("fp_clock_probe");
 }
 
+// ---- matrix-pipe probe (bench.py's roofline leg, round 6): what v_mfma_f32_32x32x16_bf16 sustains on THIS chip with operands that toggle like
+// real activations.  768 workgroups (three waves per SIMD), two accumulator chains per wave, nothing but MFMAs in the loop; mode 0 = constant
+// operands, mode 1 = eight pseudo-random bf16 operand pairs per lane cycled without a vector instruction.  Measured (profiles/
+// round6_mfma_sustained_clock.txt): constant operands 2.46 PFLOP/s at 2.39 GHz for seconds on end; pseudo-random operands 1.85 PFLOP/s at
+// 1.81 GHz -- the clock the chip holds depends on how much the operand buses toggle, and the nominal dense peak (2.5 PFLOP/s = 2.4 GHz) is a
+// constant-data figure.  out: 768 * 256 floats (keeps the accumulators alive); clk2 (optional): shader cycles and constant-rate ticks of
+// workgroup 0 across the launch.
+namespace {
+typedef __bf16 fp_probe_bf16x8 __attribute__((ext_vector_type(8)));
+__global__ void __launch_bounds__(256) mfma_probe_kernel(float* __restrict__ out, int iters, unsigned long long* __restrict__ clk, int mode) {
+  f32x16 acc[2];
+  for (int j = 0; j < 2; ++j)
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  fp_probe_bf16x8 av[8], bv[8];
+  {
+    unsigned x = 0x9E3779B9u * (threadIdx.x + 1) + 0x85EBCA6Bu * (blockIdx.x + 1);
+    for (int q = 0; q < 8; ++q) {
+      unsigned w[8];
+      for (int e = 0; e < 8; ++e) {
+        x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+        w[e] = mode ? ((x & 0x807f807fu) | 0x3f003f00u) : (e < 4 ? 0x3f803f80u : 0x3c003c00u);      // sign + mantissa random, exponent of [0.5, 1)
+      }
+      av[q] = __builtin_bit_cast(fp_probe_bf16x8, make_uint4(w[0], w[1], w[2], w[3]));
+      bv[q] = __builtin_bit_cast(fp_probe_bf16x8, make_uint4(w[4], w[5], w[6], w[7]));
+    }
+  }
+  unsigned long long c0 = 0, r0 = 0;
+  if (clk && blockIdx.x == 0 && threadIdx.x == 0) { c0 = __builtin_readcyclecounter(); r0 = __builtin_amdgcn_s_memrealtime(); }
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int rep = 0; rep < 12; ++rep)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[(rep * 2 + j) & 7], bv[(rep * 5 + j * 3) & 7], acc[j], 0, 0, 0);
+  }
+  float sum = 0.f;
+  for (int j = 0; j < 2; ++j)
+    for (int r = 0; r < 16; ++r) sum += acc[j][r];
+  out[blockIdx.x * 256 + threadIdx.x] = sum;
+  if (clk && blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = __builtin_readcyclecounter() - c0; clk[1] = __builtin_amdgcn_s_memrealtime() - r0; }
+}
+}  // namespace
+
+// one launch of 768 x 4 waves x iters x 24 MFMAs = iters * 2.416e12 FLOP (fp_mfma_probe_flop); asynchronous on the stream
+extern "C" int fp_mfma_probe(float* out, uint64_t* clk2, int32_t iters, int32_t mode, fp_stream_t stream) {
+  FP_REQUIRE(out && iters > 0, "fp_mfma_probe: bad arguments");
+  fp_launch(mfma_probe_kernel, dim3(768), dim3(256), 0, (hipStream_t)stream, out, (int)iters, (unsigned long long*)clk2, (int)mode);
+  return fp_check_launch("fp_mfma_probe");
+}
+extern "C" double fp_mfma_probe_flop(int32_t iters) { return 768.0 * 4 * (double)iters * 24 * 2.0 * 32 * 32 * 16; }
+
 extern "C" int fp_wall_clock_khz(void) {
   int dev = 0, khz = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess) return -1;

@@ -506,6 +506,13 @@ int fp_ktime_row(int32_t i, char* name, int32_t name_cap, int64_t* launches, dou
  * fp_wall_clock_khz().  fp_wall_clock_khz: hipDeviceAttributeWallClockRate of the current device, -1 on error. */
 int fp_clock_probe(uint64_t* out16, fp_stream_t stream);
 int fp_wall_clock_khz(void);
+/* Matrix-pipe probe (round 6; bench.py's roofline leg): ONE launch of 768 workgroups x 4 waves x iters x 24 v_mfma_f32_32x32x16_bf16 and nothing
+ * else -- mode 0 constant operands, mode 1 pseudo-random bf16 operands (the operand buses toggle like on real activations).  out: 768 * 256
+ * floats of scratch; clk2 (optional): {shader cycles, constant-rate ticks} of workgroup 0 across the launch (clock = cycles / ticks x
+ * fp_wall_clock_khz).  fp_mfma_probe_flop(iters) = the FLOPs of one launch.  What it showed: 2.46 PFLOP/s at 2.39 GHz on constant data,
+ * 1.85 PFLOP/s at 1.81 GHz on random data (profiles/round6_mfma_sustained_clock.txt) -- the chip's dense bf16 peak is a constant-data figure. */
+int fp_mfma_probe(float* out, uint64_t* clk2, int32_t iters, int32_t mode, fp_stream_t stream);
+double fp_mfma_probe_flop(int32_t iters);
 int fp_version(void);
 const char* fp_last_error_string(void);
 
