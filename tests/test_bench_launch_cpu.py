@@ -62,6 +62,7 @@ def test_compact_line_is_small_and_round_trips():
     full["config"]["gradient_exchange"] = {"transport": "rccl", "buckets": 7, "overlap_with_backward": True, "rccl_ranks": 8,
                                            "exposed_communication": {"exposed_ms": 0.41, "how": "x" * 500}, "allreduce_us": [{"bucket": "b" * 80}] * 7}
     full["step_bytes"] = {"algorithmic_gb": 15.2, "hbm_gb": 30.8, "traffic_ratio": 2.03, "kernel_launches": 582, "note": "n" * 900}
+    full["roofline"]["mfma_random_operand_peak"] = {"tflops": 1850.0, "shader_mhz": 1814.0, "launches": 130, "frac_of_it": 0.46, "how": "h" * 300}
     line = bench.compact_record(full, "bench_detail.json")
     assert "\n" not in line and len(line) <= bench.COMPACT_LIMIT <= 4096 < 8192
     rec = json.loads(line)
@@ -77,6 +78,7 @@ def test_compact_line_is_small_and_round_trips():
     cb = rec["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "single_thread" in cb and len(cb["sample"]) <= 160
     assert rec["config"]["gradient_exchange"]["rccl_ranks"] == 8 and rec["step"]["traffic_ratio"] == 2.03
+    assert rf["mfma_random_operand_peak"] == {"tflops": 1850.0, "shader_mhz": 1814.0, "frac_of_it": 0.46}      # the measured ceiling on data, beside the nominal peak
     # a record with nothing optional in it (kernel events and CPU baseline switched off) still makes a valid line
     bare = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                                  "vs_baseline", "dtype", "data", "config")}
