@@ -25,7 +25,7 @@ pytestmark = pytest.mark.gpu
 
 SIZES = [(1, 64, 64), (2, 64, 96), (1, 96, 128), (2, 128, 160)]          # (batch, H, W): growing and shrinking pyramids (the tiny ones: every conv a split-K grid)
 SENTINEL = 0xA5
-SPIN = 2e8               # cycles of torch.cuda._sleep in front of every step (~0.1 s): the host finishes issuing a step long before the device starts it
+SPIN = 4e8               # cycles of torch.cuda._sleep in front of every step (~0.2 s): the host finishes issuing a step long before the device starts it, even on a loaded host
 _BATCHES = {}
 
 
