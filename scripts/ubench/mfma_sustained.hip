@@ -29,7 +29,12 @@ __global__ void __launch_bounds__(256) k(float* out, int iters, unsigned long lo
 #pragma unroll
     for (int rep = 0; rep < 12; ++rep)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[(rep * 2 + j) & 7], bv[(rep * 5 + j * 3) & 7], acc[j], 0, 0, 0);
+      for (int j = 0; j < 2; ++j) {
+        // mode 2: A fixed for the whole unrolled block (only B toggles); mode 3: both operands change only every fourth MFMA
+        const int ia = mode == 2 ? 0 : (mode == 3 ? ((rep * 2 + j) >> 2) & 7 : (rep * 2 + j) & 7);
+        const int ib = mode == 3 ? ((rep * 2 + j) >> 2) * 3 & 7 : (rep * 5 + j * 3) & 7;
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[ia], bv[ib], acc[j], 0, 0, 0);
+      }
   }
   float s = 0.f;
   for (int j = 0; j < 2; ++j)
@@ -60,6 +65,6 @@ int main(int argc, char** argv) {
     last = tf; total += ms; ++n;
     if (n <= 3 || n % 25 == 0) printf("launch %3d: %7.2f ms  %7.1f TF/s bf16  shader clock %5.0f MHz\n", n, ms, tf, mhz);
   }
-  printf("mode %d (%s operands): ", mode, mode ? "pseudo-random" : "constant"); printf("first %.1f TF/s, last %.1f TF/s after %.1f s of back-to-back MFMAs (%d launches)\n", first, last, total / 1e3, n);
+  printf("mode %d (%s): ", mode, mode == 0 ? "constant operands" : mode == 1 ? "pseudo-random operands, both change every MFMA" : mode == 2 ? "pseudo-random, A fixed, B changes every MFMA" : "pseudo-random, both change every fourth MFMA"); printf("first %.1f TF/s, last %.1f TF/s after %.1f s of back-to-back MFMAs (%d launches)\n", first, last, total / 1e3, n);
   return 0;
 }
