@@ -693,7 +693,6 @@ def mfma_random_operand_peak(lib, seconds=0.7, iters=4000):
     Round 6 (profiles/round6_mfma_sustained_clock.txt): 2.46 PFLOP/s at 2.39 GHz on constant data, 1.85 PFLOP/s at 1.81 GHz on random data --
     the clock the chip holds falls with the toggling of the operand buses, so the nominal dense peak `roofline.peak` is priced against is a
     constant-data figure; this is the same instruction's ceiling on data, measured beside the run."""
-    import ctypes
     out = torch.empty(768 * 256, device="cuda")
     clk = torch.zeros(2, dtype=torch.int64, device="cuda")
     st = torch.cuda.current_stream().cuda_stream
