@@ -32,6 +32,9 @@ Objects in the full record (bench_detail.json):
                 bytes per launch from the committed PMC passes (profiles/round2_pmc_hbm_*.json: FETCH_SIZE x2 per the gfx950
                 note of MI355X_MICROARCH.md, WRITE_SIZE as reported) next to the algorithmic bytes, or null when not collected.
                 `groups` lists every convolution kernel family of the step the same way.
+                `mfma_random_operand_peak` (round 6): what v_mfma_f32_32x32x16_bf16 sustains on this chip, measured for 0.7 s beside the run
+                with pseudo-random operands and nothing else in the loop (fp_mfma_probe): ~1.85 PFLOP/s at ~1.8 GHz -- the nominal peak `frac` is
+                quoted against is reached on constant data only (2.46 PFLOP/s at 2.39 GHz); `frac_of_it` = achieved / that.
   step_conv_tflops  the reference graph's conv FLOPs of one step (fwd + dgrad + wgrad) over the measured step time.
   decoder_backward  SURVEY.md section 8(d): both decoders' backward alone (d loss / d outputs -> d loss / d features + all decoder
                 weight gradients) timed with HIP events, as achieved_hbm = algorithmic GB / t against 8 TB/s and achieved_mfma =
